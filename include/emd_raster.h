@@ -1,0 +1,235 @@
+/*
+ * emd_raster.h -- C ABI of the MI355X (gfx950) street-Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for EMD's hot path.  The reference binds this path
+ * through a third-party CUDA extension that is NOT vendored in the reference tree
+ * (`from diff_gauss import GaussianRasterizationSettings, GaussianRasterizer`,
+ * S3Gaussian/gaussian_renderer/__init__.py:14; `gsplat.rendering.rasterization`,
+ * OmniRe/models/gaussians/basics.py:12).  The entry points below are what a Python
+ * `ctypes` binding of that path binds instead:
+ *
+ *   emd_raster_forward   <- GaussianRasterizer.forward(...)   S3Gaussian/gaussian_renderer/__init__.py:145-155
+ *                           rasterization(...)                OmniRe/models/trainers/base.py:393-408
+ *   emd_raster_backward  <- autograd of the same call         S3Gaussian/train.py:366
+ *   emd_motion_forward / emd_motion_backward
+ *                        <- RigidNodes.transform_means/quats  OmniRe/models/nodes/rigid.py:478-568
+ *                           DeformableNodes residual add      OmniRe/models/nodes/deformable.py:57-69
+ *                           (when EMD_FLAG_MOTION is set the same transform is fused
+ *                            into the projection kernel of emd_raster_forward)
+ *   emd_sh_forward / emd_sh_backward
+ *                        <- gsplat spherical_harmonics(...)   OmniRe/models/nodes/rigid.py:584
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions across the ABI; every pointer is a DEVICE
+ *     pointer to contiguous fp32/int32 memory unless marked "host".
+ *   - the library never allocates or frees device memory: all outputs, scratch and
+ *     saved-for-backward state live in caller-owned buffers whose sizes come from
+ *     emd_raster_workspace_size().
+ *   - every function returns 0 on success, a negative EMD_ERR_* code otherwise;
+ *     emd_last_error() returns a thread-local message for the last failure.
+ *   - kernels are enqueued on the hipStream_t passed by the caller (as void*).
+ *   - matrices use the row-vector convention of S3Gaussian/scene/cameras.py:61-65:
+ *     viewmatrix = W2C^T, projmatrix = viewmatrix @ P^T, both row-major 4x4, so that
+ *     p_view = [x y z 1] @ viewmatrix.
+ */
+#ifndef EMD_RASTER_H
+#define EMD_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMD_ABI_VERSION 3
+
+/* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
+#define EMD_TILE_X 16
+#define EMD_TILE_Y 16
+
+enum {
+    EMD_OK = 0,
+    EMD_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, both/neither of shs & colors...) */
+    EMD_ERR_CAPACITY = -2,  /* bin_capacity too small; EmdFwdArgs.num_rendered holds the needed count */
+    EMD_ERR_HIP = -3,       /* a HIP runtime call or kernel launch failed */
+    EMD_ERR_WORKSPACE = -4  /* a workspace buffer is smaller than emd_raster_workspace_size() reports */
+};
+
+enum {
+    EMD_FLAG_NORMAL   = 1 << 0, /* also composite the view-space normal image (out_normal) */
+    EMD_FLAG_MOTION   = 1 << 1, /* fuse the per-actor rigid transform + residual in front of the projection */
+    EMD_FLAG_ABSGRAD  = 1 << 2, /* backward also accumulates sum |d L/d mean2D| (gsplat absgrad) */
+    EMD_FLAG_NO_SYNC  = 1 << 3, /* never read the duplicate count back to the host; overflow is reported
+                                   through EmdStatus.overflow only (graph-capturable path) */
+    EMD_FLAG_CLAMP_RGB01 = 1 << 4 /* SH colour clamped to [0,1] (OmniRe, rigid.py:585) instead of >= 0 */
+};
+
+/* The 12 fields of GaussianRasterizationSettings (S3Gaussian/gaussian_renderer/__init__.py:49-62), by value. */
+typedef struct EmdSettings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float bg[3];
+    float scale_modifier;
+    float viewmatrix[16];
+    float projmatrix[16];
+    int32_t sh_degree;      /* active degree 0..3 */
+    float campos[3];
+    int32_t prefiltered;    /* accepted, ignored (reference always passes False) */
+    int32_t debug;          /* !=0: synchronise and check after every stage */
+    float near_plane;       /* cull view z <= near_plane; 0.2 for the diff_gauss surface, 0.1 for OmniRe */
+} EmdSettings;
+
+/* Per-actor pose row for the fused explicit-motion transform (12 floats, 48 B):
+ *   q_mean[4]  unit quaternion (w,x,y,z) rotating local means     rigid.py:499-503
+ *   trans[3]   translation incl. learned track offset             rigid.py:519-532
+ *   valid      1.0 / 0.0, multiplies opacity                      rigid.py:589-591
+ *   q_rot[4]   unit quaternion composed onto local quats (q_mean x track rot offset, rigid.py:562-566)
+ */
+#define EMD_ACTOR_STRIDE 12
+
+typedef struct EmdMotion {
+    const int32_t* actor_id;   /* [N]; -1 = static (identity) */
+    const float* actor_pose;   /* [A, EMD_ACTOR_STRIDE] */
+    int32_t num_actors;
+    const float* residual_dx;  /* [N,3] or NULL: added to the local mean before the rigid transform */
+    const float* residual_dq;  /* [N,4] or NULL: added to the local quaternion before normalisation */
+} EmdMotion;
+
+/* Small device-side status block written by the forward pass. */
+typedef struct EmdStatus {
+    uint32_t num_rendered;  /* D = sum of tiles touched */
+    uint32_t overflow;      /* 1 if D > bin_capacity (results invalid) */
+    uint32_t num_visible;   /* V = Gaussians with radii > 0 */
+    uint32_t reserved;
+} EmdStatus;
+
+typedef struct EmdDims {
+    int32_t num_gaussians;
+    int32_t image_height;
+    int32_t image_width;
+    int64_t bin_capacity;   /* max (tile, Gaussian) pairs the binning workspace can hold */
+    int32_t flags;
+} EmdDims;
+
+typedef struct EmdFwdArgs {
+    EmdSettings s;
+    int32_t num_gaussians;
+    int32_t sh_coeffs;            /* coefficients stored per Gaussian in shs ([N, sh_coeffs, 3]) */
+    int32_t flags;
+    int64_t bin_capacity;
+    /* inputs */
+    const float* means3D;         /* [N,3] (local means when EMD_FLAG_MOTION) */
+    const float* shs;             /* [N,sh_coeffs,3] or NULL */
+    const float* colors_precomp;  /* [N,3] or NULL; exactly one of shs / colors_precomp */
+    const float* opacities;       /* [N] activated */
+    const float* scales;          /* [N,3] activated, or NULL */
+    const float* rotations;       /* [N,4] (w,x,y,z), or NULL */
+    const float* cov3D_precomp;   /* [N,6] or NULL; exactly one of (scales,rotations) / cov3D_precomp */
+    EmdMotion motion;
+    /* outputs */
+    float* out_color;             /* [3,H,W] */
+    float* out_depth;             /* [1,H,W] */
+    float* out_normal;            /* [3,H,W] (EMD_FLAG_NORMAL) or NULL */
+    float* out_alpha;             /* [1,H,W] */
+    int32_t* radii;               /* [N] */
+    /* caller-owned scratch; kept alive by the caller until backward has run */
+    void* geom_ws;  size_t geom_bytes;
+    void* bin_ws;   size_t bin_bytes;
+    void* img_ws;   size_t img_bytes;
+    EmdStatus* status;            /* device, 16 B */
+    /* host-side results (filled unless EMD_FLAG_NO_SYNC) */
+    int64_t num_rendered;
+    int64_t num_visible;
+} EmdFwdArgs;
+
+typedef struct EmdBwdArgs {
+    EmdSettings s;
+    int32_t num_gaussians;
+    int32_t sh_coeffs;
+    int32_t flags;
+    int64_t bin_capacity;
+    int64_t num_rendered;         /* D from forward; <0 = read it from status on device */
+    /* forward inputs again */
+    const float* means3D;
+    const float* shs;
+    const float* colors_precomp;
+    const float* opacities;
+    const float* scales;
+    const float* rotations;
+    const float* cov3D_precomp;
+    EmdMotion motion;
+    const int32_t* radii;
+    /* forward state */
+    const void* geom_ws;  size_t geom_bytes;
+    const void* bin_ws;   size_t bin_bytes;
+    const void* img_ws;   size_t img_bytes;
+    const EmdStatus* status;
+    /* incoming gradients (any may be NULL = zero) */
+    const float* dL_dcolor;       /* [3,H,W] */
+    const float* dL_ddepth;       /* [1,H,W] */
+    const float* dL_dalpha;       /* [1,H,W] */
+    const float* dL_dnormal;      /* [3,H,W]  (propagated to the blended normal only) */
+    /* scratch for backward: [N, EMD_BWD_STRIDE] floats, zeroed by the library */
+    void* bwd_ws;  size_t bwd_bytes;
+    /* outgoing gradients (NULL = not wanted) */
+    float* dL_dmeans3D;           /* [N,3] */
+    float* dL_dmeans2D;           /* [N,3]  x,y in NDC-scaled pixel units (x 0.5 W, 0.5 H), z = 0 */
+    float* dL_dmeans2D_abs;       /* [N,2]  (EMD_FLAG_ABSGRAD) */
+    float* dL_dshs;               /* [N,sh_coeffs,3] */
+    float* dL_dcolors;            /* [N,3] */
+    float* dL_dopacities;         /* [N] */
+    float* dL_dscales;            /* [N,3] */
+    float* dL_drotations;         /* [N,4] */
+    float* dL_dcov3D;             /* [N,6] */
+    /* motion gradients (EMD_FLAG_MOTION) */
+    float* dL_dactor_pose;        /* [A, EMD_ACTOR_STRIDE], zeroed by the library */
+    float* dL_dresidual_dx;       /* [N,3] */
+    float* dL_dresidual_dq;       /* [N,4] */
+} EmdBwdArgs;
+
+int emd_abi_version(void);
+const char* emd_last_error(void);
+
+/* out[0..3] = bytes of geom_ws, bin_ws, img_ws, bwd_ws */
+int emd_raster_workspace_size(const EmdDims* dims, size_t out[4]);
+
+int emd_raster_forward(EmdFwdArgs* args, void* hip_stream);
+int emd_raster_backward(const EmdBwdArgs* args, void* hip_stream);
+
+/* Copy binning state out for parity tests: sorted keys (tile<<32 | depth bits), sorted Gaussian ids,
+ * per-tile [start,end) ranges.  Any output may be NULL.  keys/ids hold num_rendered entries. */
+int emd_raster_export_binning(const EmdDims* dims, const void* bin_ws, size_t bin_bytes,
+                              int64_t num_rendered, uint64_t* keys, uint32_t* ids, uint32_t* ranges /*[T,2]*/,
+                              void* hip_stream);
+
+/* Copy per-Gaussian projection state out for parity tests.  Any output may be NULL. */
+int emd_raster_export_geometry(const EmdDims* dims, const void* geom_ws, size_t geom_bytes,
+                               float* means2D /*[N,2]*/, float* depths /*[N]*/, float* conic_opacity /*[N,4]*/,
+                               float* rgb /*[N,3]*/, float* normal /*[N,3]*/, uint32_t* tiles_touched /*[N]*/,
+                               void* hip_stream);
+
+/* Stand-alone explicit-motion transform (same arithmetic as the fused path):
+ *   world_mean = R(q_mean[a]) (mean + dx) + trans[a];  world_quat = q_rot[a] (x) normalize(quat + dq);
+ *   opacity_out = opacity * valid[a].  Outputs may be NULL. */
+int emd_motion_forward(int32_t n, const float* means, const float* quats, const float* opacities,
+                       const EmdMotion* motion, float* world_means, float* world_quats, float* opacities_out,
+                       void* hip_stream);
+int emd_motion_backward(int32_t n, const float* means, const float* quats, const float* opacities,
+                        const EmdMotion* motion, const float* dL_dworld_means, const float* dL_dworld_quats,
+                        const float* dL_dopacities_out, float* dL_dmeans, float* dL_dquats, float* dL_dopacities,
+                        float* dL_dactor_pose /*[A,12] zeroed here*/, float* dL_dresidual_dx, float* dL_dresidual_dq,
+                        void* hip_stream);
+
+/* Spherical harmonics colour (no +0.5, no clamp): rgb = SH_deg(dirs / |dirs|) . coeffs */
+int emd_sh_forward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* dirs /*[N,3]*/,
+                   const float* coeffs /*[N,K,3]*/, float* rgb /*[N,3]*/, void* hip_stream);
+int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* dirs, const float* coeffs,
+                    const float* dL_drgb, float* dL_dcoeffs, float* dL_ddirs /*or NULL*/, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMD_RASTER_H */
