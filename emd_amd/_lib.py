@@ -1,0 +1,127 @@
+"""ctypes binding of libemd_raster.so (include/emd_raster.h).
+
+The library is built in-tree by `emd_amd.build.build_native()` (hipcc --offload-arch=gfx950).  There is NO
+fallback: if the shared object is missing or fails to load, every operator raises -- a silent CPU/eager path
+would void the parity claims of this package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
+
+ABI_VERSION = 3
+TILE = 16
+ACTOR_STRIDE = 12
+BWD_STRIDE = 12
+
+EMD_OK, EMD_ERR_INVALID, EMD_ERR_CAPACITY, EMD_ERR_HIP, EMD_ERR_WORKSPACE = 0, -1, -2, -3, -4
+FLAG_NORMAL, FLAG_MOTION, FLAG_ABSGRAD, FLAG_NO_SYNC, FLAG_CLAMP_RGB01 = 1, 2, 4, 8, 16
+
+_f = C.c_void_p  # device pointers are passed as integers
+
+
+class EmdSettings(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float),
+                ("tanfovy", C.c_float), ("bg", C.c_float * 3), ("scale_modifier", C.c_float),
+                ("viewmatrix", C.c_float * 16), ("projmatrix", C.c_float * 16), ("sh_degree", C.c_int32),
+                ("campos", C.c_float * 3), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+                ("near_plane", C.c_float)]
+
+
+class EmdMotion(C.Structure):
+    _fields_ = [("actor_id", _f), ("actor_pose", _f), ("num_actors", C.c_int32), ("residual_dx", _f),
+                ("residual_dq", _f)]
+
+
+class EmdDims(C.Structure):
+    _fields_ = [("num_gaussians", C.c_int32), ("image_height", C.c_int32), ("image_width", C.c_int32),
+                ("bin_capacity", C.c_int64), ("flags", C.c_int32)]
+
+
+class EmdFwdArgs(C.Structure):
+    _fields_ = [("s", EmdSettings), ("num_gaussians", C.c_int32), ("sh_coeffs", C.c_int32), ("flags", C.c_int32),
+                ("bin_capacity", C.c_int64),
+                ("means3D", _f), ("shs", _f), ("colors_precomp", _f), ("opacities", _f), ("scales", _f),
+                ("rotations", _f), ("cov3D_precomp", _f), ("motion", EmdMotion),
+                ("out_color", _f), ("out_depth", _f), ("out_normal", _f), ("out_alpha", _f), ("radii", _f),
+                ("geom_ws", _f), ("geom_bytes", C.c_size_t), ("bin_ws", _f), ("bin_bytes", C.c_size_t),
+                ("img_ws", _f), ("img_bytes", C.c_size_t), ("status", _f),
+                ("num_rendered", C.c_int64), ("num_visible", C.c_int64)]
+
+
+class EmdBwdArgs(C.Structure):
+    _fields_ = [("s", EmdSettings), ("num_gaussians", C.c_int32), ("sh_coeffs", C.c_int32), ("flags", C.c_int32),
+                ("bin_capacity", C.c_int64), ("num_rendered", C.c_int64),
+                ("means3D", _f), ("shs", _f), ("colors_precomp", _f), ("opacities", _f), ("scales", _f),
+                ("rotations", _f), ("cov3D_precomp", _f), ("motion", EmdMotion), ("radii", _f),
+                ("geom_ws", _f), ("geom_bytes", C.c_size_t), ("bin_ws", _f), ("bin_bytes", C.c_size_t),
+                ("img_ws", _f), ("img_bytes", C.c_size_t), ("status", _f),
+                ("dL_dcolor", _f), ("dL_ddepth", _f), ("dL_dalpha", _f), ("dL_dnormal", _f),
+                ("bwd_ws", _f), ("bwd_bytes", C.c_size_t),
+                ("dL_dmeans3D", _f), ("dL_dmeans2D", _f), ("dL_dmeans2D_abs", _f), ("dL_dshs", _f),
+                ("dL_dcolors", _f), ("dL_dopacities", _f), ("dL_dscales", _f), ("dL_drotations", _f),
+                ("dL_dcov3D", _f), ("dL_dactor_pose", _f), ("dL_dresidual_dx", _f), ("dL_dresidual_dq", _f)]
+
+
+# every symbol include/emd_raster.h declares
+EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_size", "emd_raster_forward",
+                    "emd_raster_backward", "emd_raster_export_binning", "emd_raster_export_geometry",
+                    "emd_motion_forward", "emd_motion_backward", "emd_sh_forward", "emd_sh_backward")
+
+_lib = None
+
+
+class EmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP extension; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EmdError(f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+                       f"g.build()'` (or `make -C emd_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTED_SYMBOLS:
+        if not hasattr(lib, name):
+            raise EmdError(f"{LIB_PATH} does not export {name}")
+    lib.emd_abi_version.restype = C.c_int
+    lib.emd_last_error.restype = C.c_char_p
+    v = lib.emd_abi_version()
+    if v != ABI_VERSION:
+        raise EmdError(f"ABI mismatch: library {v}, binding {ABI_VERSION}")
+    lib.emd_raster_workspace_size.argtypes = [C.POINTER(EmdDims), C.POINTER(C.c_size_t)]
+    lib.emd_raster_forward.argtypes = [C.POINTER(EmdFwdArgs), C.c_void_p]
+    lib.emd_raster_backward.argtypes = [C.POINTER(EmdBwdArgs), C.c_void_p]
+    lib.emd_raster_export_binning.argtypes = [C.POINTER(EmdDims), C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_raster_export_geometry.argtypes = [C.POINTER(EmdDims), C.c_void_p, C.c_size_t] + [C.c_void_p] * 7
+    lib.emd_motion_forward.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(EmdMotion),
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_motion_backward.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(EmdMotion)] + \
+        [C.c_void_p] * 10
+    lib.emd_sh_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_sh_backward.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().emd_last_error().decode("utf-8", "replace")
+        raise EmdError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def workspace_sizes(N, H, W, capacity, flags=0):
+    d = EmdDims(int(N), int(H), int(W), int(capacity), int(flags))
+    out = (C.c_size_t * 4)()
+    check(load().emd_raster_workspace_size(C.byref(d), out), "emd_raster_workspace_size")
+    return tuple(int(x) for x in out)

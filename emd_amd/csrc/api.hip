@@ -1,0 +1,238 @@
+// api.hip -- the C ABI of include/emd_raster.h: argument checking, workspace carving, stage sequencing.
+// No device memory is allocated or freed here; errors are returned as codes + a thread-local message.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void emd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int emd_launch_motion_forward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
+                              float* wm, float* wq, float* wo, hipStream_t st);
+int emd_launch_motion_backward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
+                               const float* g_wm, const float* g_wq, const float* g_wo, float* d_means, float* d_quats,
+                               float* d_opac, float* d_pose, float* d_rdx, float* d_rdq, hipStream_t st);
+int emd_launch_sh_forward(int n, int deg, int M, const float* dirs, const float* coeffs, float* rgb, hipStream_t st);
+int emd_launch_sh_backward(int n, int deg, int M, const float* dirs, const float* coeffs, const float* g_rgb,
+                           float* d_coeffs, float* d_dirs, hipStream_t st);
+int emd_launch_export_geometry(int N, const GeomWs& g, float* means2D, float* depths, float* conic_opacity, float* rgb,
+                               float* normal, uint32_t* tiles_touched, hipStream_t st);
+
+extern "C" {
+
+int emd_abi_version(void) { return EMD_ABI_VERSION; }
+
+const char* emd_last_error(void) { return g_err; }
+
+int emd_raster_workspace_size(const EmdDims* dims, size_t out[4]) {
+    if (!dims || !out) { emd_set_error("workspace_size: null argument"); return EMD_ERR_INVALID; }
+    if (dims->num_gaussians < 0 || dims->image_height <= 0 || dims->image_width <= 0 || dims->bin_capacity < 0) {
+        emd_set_error("workspace_size: bad dims N=%d H=%d W=%d cap=%lld", dims->num_gaussians, dims->image_height,
+                      dims->image_width, (long long)dims->bin_capacity);
+        return EMD_ERR_INVALID;
+    }
+    GeomWs g; BinWs b; ImgWs im;
+    const int gx = (dims->image_width + EMD_TILE_X - 1) / EMD_TILE_X, gy = (dims->image_height + EMD_TILE_Y - 1) / EMD_TILE_Y;
+    emd_carve_geom(nullptr, dims->num_gaussians, &g);
+    emd_carve_bin(nullptr, dims->bin_capacity, gx * gy, &b);
+    emd_carve_img(nullptr, dims->image_height, dims->image_width, &im);
+    out[0] = g.bytes; out[1] = b.bytes; out[2] = im.bytes;
+    out[3] = (size_t)(dims->num_gaussians > 0 ? dims->num_gaussians : 1) * EMD_BWD_STRIDE * sizeof(float);
+    return EMD_OK;
+}
+
+static int check_common(const EmdSettings& s, int N, int M, const float* means3D, const float* shs,
+                        const float* colors, const float* opac, const float* scales, const float* rots,
+                        const float* cov, int flags, const EmdMotion& mo) {
+    if (N < 0 || s.image_height <= 0 || s.image_width <= 0) { emd_set_error("bad sizes N=%d H=%d W=%d", N, s.image_height, s.image_width); return EMD_ERR_INVALID; }
+    if (N > 0 && (!means3D || !opac)) { emd_set_error("means3D / opacities must not be null"); return EMD_ERR_INVALID; }
+    if ((shs != nullptr) == (colors != nullptr) && N > 0) { emd_set_error("provide exactly one of shs / colors_precomp"); return EMD_ERR_INVALID; }
+    const bool sr = scales && rots;
+    if (((scales != nullptr) != (rots != nullptr)) || (sr == (cov != nullptr) && N > 0)) {
+        emd_set_error("provide exactly one of (scales, rotations) / cov3D_precomp"); return EMD_ERR_INVALID;
+    }
+    if (s.sh_degree < 0 || s.sh_degree > 3) { emd_set_error("sh_degree %d not in 0..3", s.sh_degree); return EMD_ERR_INVALID; }
+    if (shs && M < (s.sh_degree + 1) * (s.sh_degree + 1)) { emd_set_error("shs holds %d coefficients, degree %d needs %d", M, s.sh_degree, (s.sh_degree + 1) * (s.sh_degree + 1)); return EMD_ERR_INVALID; }
+    if (!(s.tanfovx > 0.f) || !(s.tanfovy > 0.f)) { emd_set_error("tanfov must be positive"); return EMD_ERR_INVALID; }
+    if (flags & EMD_FLAG_MOTION) {
+        if (mo.actor_id && (!mo.actor_pose || mo.num_actors <= 0)) { emd_set_error("motion: actor_id given without actor_pose"); return EMD_ERR_INVALID; }
+        if (cov) { emd_set_error("motion: cov3D_precomp cannot be combined with the fused motion transform"); return EMD_ERR_INVALID; }
+    }
+    return EMD_OK;
+}
+
+int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
+    if (!a) { emd_set_error("forward: null args"); return EMD_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int N = a->num_gaussians;
+    int rc = check_common(a->s, N, a->sh_coeffs, a->means3D, a->shs, a->colors_precomp, a->opacities, a->scales,
+                          a->rotations, a->cov3D_precomp, a->flags, a->motion);
+    if (rc) return rc;
+    if (!a->out_color || !a->out_depth || !a->out_alpha || !a->radii || !a->status || !a->geom_ws || !a->bin_ws || !a->img_ws) {
+        emd_set_error("forward: null output / workspace pointer"); return EMD_ERR_INVALID;
+    }
+    if ((a->flags & EMD_FLAG_NORMAL) && !a->out_normal) { emd_set_error("forward: EMD_FLAG_NORMAL without out_normal"); return EMD_ERR_INVALID; }
+    if (a->bin_capacity < 0) { emd_set_error("forward: negative bin_capacity"); return EMD_ERR_INVALID; }
+    const int gx = (a->s.image_width + EMD_TILE_X - 1) / EMD_TILE_X, gy = (a->s.image_height + EMD_TILE_Y - 1) / EMD_TILE_Y;
+    GeomWs g; BinWs b; ImgWs im;
+    emd_carve_geom(a->geom_ws, N, &g);
+    emd_carve_bin(a->bin_ws, a->bin_capacity, gx * gy, &b);
+    emd_carve_img(a->img_ws, a->s.image_height, a->s.image_width, &im);
+    if (g.bytes > a->geom_bytes || b.bytes > a->bin_bytes || im.bytes > a->img_bytes) {
+        emd_set_error("forward: workspace too small (geom %zu/%zu bin %zu/%zu img %zu/%zu)", a->geom_bytes, g.bytes,
+                      a->bin_bytes, b.bytes, a->img_bytes, im.bytes);
+        return EMD_ERR_WORKSPACE;
+    }
+    const bool dbg = a->s.debug != 0;
+#define STAGE_SYNC(name)                                                                                     \
+    if (dbg) {                                                                                               \
+        hipError_t e_ = hipStreamSynchronize(st);                                                            \
+        if (e_ != hipSuccess) { emd_set_error("stage %s failed: %s", name, hipGetErrorString(e_)); return EMD_ERR_HIP; } \
+    }
+    EMD_HIP_CHECK(hipMemsetAsync(a->status, 0, sizeof(EmdStatus), st));
+    PreArgs pa;
+    pa.s = a->s; pa.N = N; pa.M = a->sh_coeffs; pa.flags = a->flags;
+    pa.means3D = a->means3D; pa.shs = a->shs; pa.colors_precomp = a->colors_precomp; pa.opacities = a->opacities;
+    pa.scales = a->scales; pa.rotations = a->rotations; pa.cov3D_precomp = a->cov3D_precomp;
+    pa.motion = a->motion; pa.radii = a->radii; pa.g = g; pa.status = a->status;
+    if (!(a->flags & EMD_FLAG_MOTION)) memset(&pa.motion, 0, sizeof(pa.motion));
+    rc = emd_launch_preprocess(pa, st);
+    if (rc) return rc;
+    STAGE_SYNC("preprocess");
+    rc = emd_launch_binning(a->s, N, a->radii, g, b, a->bin_capacity, a->status, st);
+    if (rc) return rc;
+    STAGE_SYNC("binning");
+    a->num_rendered = -1;
+    a->num_visible = -1;
+    if (!(a->flags & EMD_FLAG_NO_SYNC)) {
+        EmdStatus hs;
+        EMD_HIP_CHECK(hipMemcpyAsync(&hs, a->status, sizeof(hs), hipMemcpyDeviceToHost, st));
+        EMD_HIP_CHECK(hipStreamSynchronize(st));
+        a->num_rendered = hs.num_rendered;
+        a->num_visible = hs.num_visible;
+        if (hs.overflow) {
+            emd_set_error("forward: %u (tile, Gaussian) pairs exceed bin_capacity %lld", hs.num_rendered, (long long)a->bin_capacity);
+            return EMD_ERR_CAPACITY;
+        }
+    }
+    rc = emd_launch_render_forward(a->s, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->out_alpha, st);
+    if (rc) return rc;
+    STAGE_SYNC("render_forward");
+    return EMD_OK;
+}
+
+int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
+    if (!a) { emd_set_error("backward: null args"); return EMD_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int N = a->num_gaussians;
+    int rc = check_common(a->s, N, a->sh_coeffs, a->means3D, a->shs, a->colors_precomp, a->opacities, a->scales,
+                          a->rotations, a->cov3D_precomp, a->flags, a->motion);
+    if (rc) return rc;
+    if (!a->radii || !a->geom_ws || !a->bin_ws || !a->img_ws || !a->bwd_ws || !a->status) { emd_set_error("backward: null state pointer"); return EMD_ERR_INVALID; }
+    const int gx = (a->s.image_width + EMD_TILE_X - 1) / EMD_TILE_X, gy = (a->s.image_height + EMD_TILE_Y - 1) / EMD_TILE_Y;
+    GeomWs g; BinWs b; ImgWs im;
+    emd_carve_geom((void*)a->geom_ws, N, &g);
+    emd_carve_bin((void*)a->bin_ws, a->bin_capacity, gx * gy, &b);
+    emd_carve_img((void*)a->img_ws, a->s.image_height, a->s.image_width, &im);
+    const size_t need = (size_t)(N > 0 ? N : 1) * EMD_BWD_STRIDE * sizeof(float);
+    if (g.bytes > a->geom_bytes || b.bytes > a->bin_bytes || im.bytes > a->img_bytes || need > a->bwd_bytes) {
+        emd_set_error("backward: workspace too small"); return EMD_ERR_WORKSPACE;
+    }
+    if ((a->flags & EMD_FLAG_ABSGRAD) && !a->dL_dmeans2D_abs) { emd_set_error("backward: EMD_FLAG_ABSGRAD without dL_dmeans2D_abs"); return EMD_ERR_INVALID; }
+    const bool dbg = a->s.debug != 0;
+    EMD_HIP_CHECK(hipMemsetAsync(a->bwd_ws, 0, need, st));
+    if ((a->flags & EMD_FLAG_MOTION) && a->dL_dactor_pose && a->motion.num_actors > 0)
+        EMD_HIP_CHECK(hipMemsetAsync(a->dL_dactor_pose, 0, (size_t)a->motion.num_actors * EMD_ACTOR_STRIDE * sizeof(float), st));
+    rc = emd_launch_render_backward(a->s, a->flags, g, b, im, a->dL_dcolor, a->dL_ddepth, a->dL_dalpha, a->dL_dnormal,
+                                    (float*)a->bwd_ws, st);
+    if (rc) return rc;
+    STAGE_SYNC("render_backward");
+    PreBwdArgs pb;
+    pb.s = a->s; pb.N = N; pb.M = a->sh_coeffs; pb.flags = a->flags;
+    pb.means3D = a->means3D; pb.shs = a->shs; pb.colors_precomp = a->colors_precomp; pb.opacities = a->opacities;
+    pb.scales = a->scales; pb.rotations = a->rotations; pb.cov3D_precomp = a->cov3D_precomp;
+    pb.motion = a->motion; pb.radii = a->radii; pb.g = g; pb.grad_rec = (const float*)a->bwd_ws;
+    if (!(a->flags & EMD_FLAG_MOTION)) memset(&pb.motion, 0, sizeof(pb.motion));
+    pb.dL_dmeans3D = a->dL_dmeans3D; pb.dL_dmeans2D = a->dL_dmeans2D; pb.dL_dmeans2D_abs = a->dL_dmeans2D_abs;
+    pb.dL_dshs = a->dL_dshs; pb.dL_dcolors = a->dL_dcolors; pb.dL_dopacities = a->dL_dopacities;
+    pb.dL_dscales = a->dL_dscales; pb.dL_drotations = a->dL_drotations; pb.dL_dcov3D = a->dL_dcov3D;
+    pb.dL_dactor_pose = a->dL_dactor_pose; pb.dL_dresidual_dx = a->dL_dresidual_dx; pb.dL_dresidual_dq = a->dL_dresidual_dq;
+    rc = emd_launch_preprocess_backward(pb, st);
+    if (rc) return rc;
+    STAGE_SYNC("preprocess_backward");
+    return EMD_OK;
+}
+
+int emd_raster_export_binning(const EmdDims* dims, const void* bin_ws, size_t bin_bytes, int64_t num_rendered,
+                              uint64_t* keys, uint32_t* ids, uint32_t* ranges, void* hip_stream) {
+    if (!dims || !bin_ws) { emd_set_error("export_binning: null argument"); return EMD_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int gx = (dims->image_width + EMD_TILE_X - 1) / EMD_TILE_X, gy = (dims->image_height + EMD_TILE_Y - 1) / EMD_TILE_Y;
+    BinWs b;
+    emd_carve_bin((void*)bin_ws, dims->bin_capacity, gx * gy, &b);
+    if (b.bytes > bin_bytes || num_rendered > dims->bin_capacity || num_rendered < 0) { emd_set_error("export_binning: bad sizes"); return EMD_ERR_WORKSPACE; }
+    if (keys && num_rendered) EMD_HIP_CHECK(hipMemcpyAsync(keys, b.keys[b.sorted_buf], (size_t)num_rendered * 8, hipMemcpyDeviceToDevice, st));
+    if (ids && num_rendered) EMD_HIP_CHECK(hipMemcpyAsync(ids, b.vals[b.sorted_buf], (size_t)num_rendered * 4, hipMemcpyDeviceToDevice, st));
+    if (ranges) EMD_HIP_CHECK(hipMemcpyAsync(ranges, b.ranges, (size_t)gx * gy * 8, hipMemcpyDeviceToDevice, st));
+    return EMD_OK;
+}
+
+int emd_raster_export_geometry(const EmdDims* dims, const void* geom_ws, size_t geom_bytes, float* means2D,
+                               float* depths, float* conic_opacity, float* rgb, float* normal, uint32_t* tiles_touched,
+                               void* hip_stream) {
+    if (!dims || !geom_ws) { emd_set_error("export_geometry: null argument"); return EMD_ERR_INVALID; }
+    GeomWs g;
+    emd_carve_geom((void*)geom_ws, dims->num_gaussians, &g);
+    if (g.bytes > geom_bytes) { emd_set_error("export_geometry: workspace too small"); return EMD_ERR_WORKSPACE; }
+    return emd_launch_export_geometry(dims->num_gaussians, g, means2D, depths, conic_opacity, rgb, normal, tiles_touched,
+                                      (hipStream_t)hip_stream);
+}
+
+int emd_motion_forward(int32_t n, const float* means, const float* quats, const float* opacities,
+                       const EmdMotion* motion, float* world_means, float* world_quats, float* opacities_out,
+                       void* hip_stream) {
+    if (n < 0 || !means || !motion) { emd_set_error("motion_forward: bad argument"); return EMD_ERR_INVALID; }
+    if (motion->actor_id && (!motion->actor_pose || motion->num_actors <= 0)) { emd_set_error("motion_forward: actor_id without actor_pose"); return EMD_ERR_INVALID; }
+    return emd_launch_motion_forward(n, means, quats, opacities, *motion, world_means, world_quats, opacities_out,
+                                     (hipStream_t)hip_stream);
+}
+
+int emd_motion_backward(int32_t n, const float* means, const float* quats, const float* opacities,
+                        const EmdMotion* motion, const float* dL_dworld_means, const float* dL_dworld_quats,
+                        const float* dL_dopacities_out, float* dL_dmeans, float* dL_dquats, float* dL_dopacities,
+                        float* dL_dactor_pose, float* dL_dresidual_dx, float* dL_dresidual_dq, void* hip_stream) {
+    if (n < 0 || !means || !motion) { emd_set_error("motion_backward: bad argument"); return EMD_ERR_INVALID; }
+    if (motion->actor_id && (!motion->actor_pose || motion->num_actors <= 0)) { emd_set_error("motion_backward: actor_id without actor_pose"); return EMD_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (dL_dactor_pose && motion->num_actors > 0)
+        EMD_HIP_CHECK(hipMemsetAsync(dL_dactor_pose, 0, (size_t)motion->num_actors * EMD_ACTOR_STRIDE * sizeof(float), st));
+    return emd_launch_motion_backward(n, means, quats, opacities, *motion, dL_dworld_means, dL_dworld_quats,
+                                      dL_dopacities_out, dL_dmeans, dL_dquats, dL_dopacities, dL_dactor_pose,
+                                      dL_dresidual_dx, dL_dresidual_dq, st);
+}
+
+int emd_sh_forward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* dirs, const float* coeffs, float* rgb,
+                   void* hip_stream) {
+    if (n < 0 || degree < 0 || degree > 3 || sh_coeffs < (degree + 1) * (degree + 1) || !dirs || !coeffs || !rgb) {
+        emd_set_error("sh_forward: bad argument (n=%d degree=%d K=%d)", n, degree, sh_coeffs); return EMD_ERR_INVALID;
+    }
+    return emd_launch_sh_forward(n, degree, sh_coeffs, dirs, coeffs, rgb, (hipStream_t)hip_stream);
+}
+
+int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* dirs, const float* coeffs,
+                    const float* dL_drgb, float* dL_dcoeffs, float* dL_ddirs, void* hip_stream) {
+    if (n < 0 || degree < 0 || degree > 3 || sh_coeffs < (degree + 1) * (degree + 1) || !dirs || !coeffs || !dL_drgb) {
+        emd_set_error("sh_backward: bad argument (n=%d degree=%d K=%d)", n, degree, sh_coeffs); return EMD_ERR_INVALID;
+    }
+    return emd_launch_sh_backward(n, degree, sh_coeffs, dirs, coeffs, dL_drgb, dL_dcoeffs, dL_ddirs, (hipStream_t)hip_stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,304 @@
+// binning.hip -- K2..K5: offsets scan, tile duplication with 64-bit keys, stable LSD radix sort, tile ranges.
+// [UPSTREAM K2-K5 in SURVEY.md section 2.4: CUB DeviceScan / duplicateWithKeys / DeviceRadixSort / identifyTileRanges]
+//
+// Design for gfx950:
+//   - the duplicate count D stays on the device (EmdStatus.num_rendered); every kernel here is launched on the
+//     caller-provided capacity and bounds itself by D, so the forward pass needs no host read-back to proceed.
+//   - duplication is balanced over output slots, not Gaussians: a 256-thread block scans the tile counts of its
+//     256 Gaussians (DPP wave scan + LDS), then lane e writes slot e, finding its Gaussian by binary search in
+//     LDS -- consecutive lanes write consecutive keys (coalesced 8 B + 4 B stores) regardless of footprint size.
+//   - the sort is a stable LSD radix sort (8-bit digits) on exactly the significant bits:
+//     32 depth bits + ceil(log2(tiles)) tile bits.  Ranking inside a block is wave-ballot based
+//     (8 ballots per key give the set of lanes with the same digit; no LDS atomics in the ranking loop), which keeps
+//     the sort stable so the final order is (tile, depth bits, Gaussian id) -- the bit-exact contract with the oracle.
+#include "common.h"
+#include "device_utils.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// generic inclusive scan over uint32 (in place), 3 phases, 1024 elements per block
+// ---------------------------------------------------------------------------------------------------
+#define SCAN_ITEMS 4
+#define SCAN_TILE (EMD_BLOCK * SCAN_ITEMS)
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_scan_reduce(const uint32_t* __restrict__ in, size_t n,
+                                                           uint32_t* __restrict__ partial) {
+    __shared__ uint32_t s[4];
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++)
+        if (base + k < n) v += in[base + k];
+    uint32_t total;
+    block_scan_add_u32(v, s, &total);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+// single block: inclusive scan of up to `n` partials in place (n may exceed the block: looped)
+__global__ void __launch_bounds__(EMD_BLOCK) k_scan_small(uint32_t* __restrict__ data, size_t n) {
+    __shared__ uint32_t s[4];
+    uint32_t carry = 0;
+    for (size_t base = 0; base < n; base += SCAN_TILE) {
+        size_t i0 = base + (size_t)threadIdx.x * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < n) ? data[i0 + k] : 0u; sum += v[k]; }
+        uint32_t total;
+        uint32_t inc = block_scan_add_u32(sum, s, &total);
+        uint32_t run = carry + inc - sum;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { run += v[k]; if (i0 + k < n) data[i0 + k] = run; }
+        carry += total;
+    }
+}
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_scan_down(uint32_t* __restrict__ data, size_t n,
+                                                         const uint32_t* __restrict__ partial_inc) {
+    __shared__ uint32_t s[4];
+    size_t i0 = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < n) ? data[i0 + k] : 0u; sum += v[k]; }
+    uint32_t total;
+    uint32_t inc = block_scan_add_u32(sum, s, &total);
+    uint32_t run = (blockIdx.x ? partial_inc[blockIdx.x - 1] : 0u) + inc - sum;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { run += v[k]; if (i0 + k < n) data[i0 + k] = run; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// D = last block sum; clamp against capacity; publish in status
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_publish_count(const uint32_t* __restrict__ block_sums_inc, int nb, uint64_t capacity,
+                                EmdStatus* status) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t D = nb > 0 ? block_sums_inc[nb - 1] : 0u;
+        status->num_rendered = D;
+        status->overflow = ((uint64_t)D > capacity) ? 1u : 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3 duplicate with keys
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tile_clamp(float f, int grid) {
+    float g = (float)grid;
+    if (!(f > 0.f)) return 0;
+    if (f > g) return grid;
+    return (int)f;
+}
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, int gy, const int32_t* __restrict__ radii,
+                                                         const float4* __restrict__ rec,
+                                                         const uint32_t* __restrict__ tiles_touched,
+                                                         const uint32_t* __restrict__ block_sums_inc,
+                                                         const EmdStatus* __restrict__ status,
+                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    __shared__ uint32_t s_scan[4];
+    __shared__ uint32_t s_excl[EMD_BLOCK];     // exclusive offsets inside the block
+    __shared__ uint32_t s_rect[EMD_BLOCK];     // x0 | y0 << 10 | width << 20   (grid dims < 1024 tiles = 16K px)
+    __shared__ uint32_t s_depth[EMD_BLOCK];
+    if (status->overflow) return;
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    uint32_t cnt = (i < N) ? tiles_touched[i] : 0u;
+    uint32_t total;
+    uint32_t inc = block_scan_add_u32(cnt, s_scan, &total);
+    s_excl[threadIdx.x] = inc - cnt;
+    uint32_t rectw = 0, dbits = 0;
+    if (cnt) {
+        const float4 r0 = rec[(size_t)i * EMD_REC_F4];
+        const float rad = (float)radii[i];
+        // identical arithmetic to K1 step 6 (same operands, same order) => same rectangle
+        int x0 = tile_clamp((r0.x - rad) / (float)EMD_TILE_X, gx);
+        int y0 = tile_clamp((r0.y - rad) / (float)EMD_TILE_Y, gy);
+        int x1 = tile_clamp((r0.x + rad + (float)(EMD_TILE_X - 1)) / (float)EMD_TILE_X, gx);
+        rectw = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
+        dbits = __float_as_uint(r0.z);
+    }
+    s_rect[threadIdx.x] = rectw;
+    s_depth[threadIdx.x] = dbits;
+    __syncthreads();
+    const uint32_t base = blockIdx.x ? block_sums_inc[blockIdx.x - 1] : 0u;
+    for (uint32_t e = threadIdx.x; e < total; e += EMD_BLOCK) {
+        // largest j with s_excl[j] <= e  (entries with cnt == 0 share offsets with their successor; the search
+        // lands on the last of an equal run, which is the one that owns slot e)
+        int lo = 0, hi = EMD_BLOCK - 1;
+#pragma unroll
+        for (int step = 0; step < 8; step++) {
+            int mid = (lo + hi + 1) >> 1;
+            if (s_excl[mid] <= e) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t local = e - s_excl[lo];
+        const uint32_t r = s_rect[lo];
+        const uint32_t w = r >> 20, x0 = r & 1023u, y0 = (r >> 10) & 1023u;
+        const uint32_t ty = y0 + local / w, tx = x0 + local % w;
+        const uint64_t key = ((uint64_t)(ty * (uint32_t)gx + tx) << 32) | s_depth[lo];
+        keys[(size_t)base + e] = key;
+        vals[(size_t)base + e] = (uint32_t)(blockIdx.x * EMD_BLOCK + lo);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4 radix sort: per pass (a) block histograms, (b) scan over [bin][block], (c) stable scatter
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EMD_BLOCK) k_radix_hist(const uint64_t* __restrict__ keys,
+                                                          const EmdStatus* __restrict__ status, int shift,
+                                                          uint32_t nblocks_cap, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_h[EMD_RADIX_BINS];
+    const uint32_t D = status->overflow ? 0u : status->num_rendered;
+    const uint32_t nblocks = (D + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
+    s_h[threadIdx.x] = 0;  // EMD_BLOCK == EMD_RADIX_BINS
+    __syncthreads();
+    if (blockIdx.x < nblocks) {
+        const size_t base = (size_t)blockIdx.x * EMD_SORT_TILE;
+#pragma unroll
+        for (int k = 0; k < EMD_SORT_ITEMS; k++) {
+            size_t idx = base + (size_t)k * EMD_BLOCK + threadIdx.x;
+            if (idx < D) atomicAdd(&s_h[(uint32_t)(keys[idx] >> shift) & (EMD_RADIX_BINS - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    // bin-major layout over the *capacity* block count so the scan length is launch-time constant
+    hist[(size_t)threadIdx.x * nblocks_cap + blockIdx.x] = s_h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint64_t* __restrict__ keys_in,
+                                                             const uint32_t* __restrict__ vals_in,
+                                                             uint64_t* __restrict__ keys_out,
+                                                             uint32_t* __restrict__ vals_out,
+                                                             const EmdStatus* __restrict__ status, int shift,
+                                                             uint32_t nblocks_cap,
+                                                             const uint32_t* __restrict__ hist_inc) {
+    // wave w of the block owns the contiguous slice [w*1024, (w+1)*1024) of the block's 4096 keys and walks it in
+    // 16 rounds of 64 consecutive keys: order inside the block = (wave, round, lane) = memory order => stable.
+    __shared__ uint32_t s_cnt[4][EMD_RADIX_BINS];   // running per-wave digit counts, then per-wave bases
+    const uint32_t D = status->overflow ? 0u : status->num_rendered;
+    const uint32_t nblocks = (D + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
+    if (blockIdx.x >= nblocks) return;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_cnt[k][threadIdx.x] = 0;
+    __syncthreads();
+    const size_t wbase = (size_t)blockIdx.x * EMD_SORT_TILE + (size_t)wave * (EMD_SORT_TILE / 4);
+    uint64_t key[EMD_SORT_ITEMS];
+    uint32_t rank[EMD_SORT_ITEMS];
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int k = 0; k < EMD_SORT_ITEMS; k++) {
+        const size_t idx = wbase + (size_t)k * 64 + lane;
+        const bool valid = idx < D;
+        key[k] = valid ? keys_in[idx] : ~0ull;
+        const uint32_t digit = (uint32_t)(key[k] >> shift) & (EMD_RADIX_BINS - 1);
+        // lanes with the same digit (invalid lanes form their own class and are ignored)
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < EMD_RADIX_BITS; b++) {
+            const unsigned long long bal = __ballot((digit >> b) & 1u);
+            same &= ((digit >> b) & 1u) ? bal : ~bal;
+        }
+        const uint32_t before = (uint32_t)__popcll(same & lt_mask);
+        const uint32_t prev = s_cnt[wave][digit];          // count from earlier rounds of this wave
+        rank[k] = prev + before;
+        // the highest lane of each class publishes the new count (wave-private row: no atomics, no race)
+        const bool leader = valid && ((same >> lane) >> 1) == 0ull;
+        __builtin_amdgcn_wave_barrier();
+        if (leader) s_cnt[wave][digit] = prev + (uint32_t)__popcll(same);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // per-wave exclusive bases inside the block + the block's global base for every digit
+    {
+        const uint32_t d = threadIdx.x;
+        const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
+        const size_t hidx = (size_t)d * nblocks_cap + blockIdx.x;
+        const uint32_t g = hidx ? hist_inc[hidx - 1] : 0u;  // exclusive prefix over [bin][block]
+        s_cnt[0][d] = g;
+        s_cnt[1][d] = g + c0;
+        s_cnt[2][d] = g + c0 + c1;
+        s_cnt[3][d] = g + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EMD_SORT_ITEMS; k++) {
+        const size_t idx = wbase + (size_t)k * 64 + lane;
+        if (idx < D) {
+            const uint32_t digit = (uint32_t)(key[k] >> shift) & (EMD_RADIX_BINS - 1);
+            const size_t dst = (size_t)s_cnt[wave][digit] + rank[k];
+            keys_out[dst] = key[k];
+            vals_out[dst] = vals_in[idx];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5 tile ranges
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EMD_BLOCK) k_tile_ranges(const uint64_t* __restrict__ keys,
+                                                           const EmdStatus* __restrict__ status,
+                                                           uint32_t* __restrict__ ranges) {
+    const uint32_t D = status->overflow ? 0u : status->num_rendered;
+    for (size_t idx = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; idx < D; idx += (size_t)gridDim.x * EMD_BLOCK) {
+        const uint32_t t = (uint32_t)(keys[idx] >> 32);
+        if (idx == 0) ranges[2 * t] = 0;
+        else {
+            const uint32_t tp = (uint32_t)(keys[idx - 1] >> 32);
+            if (tp != t) { ranges[2 * tp + 1] = (uint32_t)idx; ranges[2 * t] = (uint32_t)idx; }
+        }
+        if (idx == D - 1) ranges[2 * t + 1] = D;
+    }
+}
+
+}  // namespace
+
+int emd_launch_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st) {
+    if (n == 0) return EMD_OK;
+    if (n <= SCAN_TILE) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(EMD_BLOCK), 0, st, data, n);
+        EMD_LAUNCH_CHECK();
+        return EMD_OK;
+    }
+    const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(EMD_BLOCK), 0, st, data, n, tmp);
+    EMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(EMD_BLOCK), 0, st, tmp, nb);
+    EMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_down, dim3((unsigned)nb), dim3(EMD_BLOCK), 0, st, data, n, tmp);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_binning(const EmdSettings& s, int N, const int32_t* radii, const GeomWs& g, const BinWs& b,
+                       int64_t capacity, EmdStatus* status, hipStream_t st) {
+    const int gx = (s.image_width + EMD_TILE_X - 1) / EMD_TILE_X, gy = (s.image_height + EMD_TILE_Y - 1) / EMD_TILE_Y;
+    const int T = gx * gy;
+    if (gx >= 1024 || gy >= 1024) { emd_set_error("image too large: %d x %d tiles (max 1023)", gx, gy); return EMD_ERR_INVALID; }
+    const int nb = (N + EMD_BLOCK - 1) / EMD_BLOCK;
+    int rc = emd_launch_scan_u32(g.block_sums, (size_t)nb, g.scan_tmp, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(64), 0, st, g.block_sums, nb, (uint64_t)capacity, status);
+    EMD_LAUNCH_CHECK();
+    EMD_HIP_CHECK(hipMemsetAsync(b.ranges, 0, (size_t)T * 8, st));
+    if (N == 0 || capacity <= 0) return EMD_OK;
+    hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(EMD_BLOCK), 0, st, N, gx, gy, radii, g.rec, g.tiles_touched,
+                       g.block_sums, status, b.keys[0], b.vals[0]);
+    EMD_LAUNCH_CHECK();
+    const uint32_t nsb = (uint32_t)(((size_t)capacity + EMD_SORT_TILE - 1) / EMD_SORT_TILE);
+    const int passes = emd_sort_passes(T);
+    int cur = 0;
+    for (int p = 0; p < passes; p++) {
+        const int shift = p * EMD_RADIX_BITS;
+        hipLaunchKernelGGL(k_radix_hist, dim3(nsb), dim3(EMD_BLOCK), 0, st, b.keys[cur], status, shift, nsb, b.hist);
+        EMD_LAUNCH_CHECK();
+        rc = emd_launch_scan_u32(b.hist, (size_t)nsb * EMD_RADIX_BINS, b.scan_tmp, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nsb), dim3(EMD_BLOCK), 0, st, b.keys[cur], b.vals[cur], b.keys[cur ^ 1],
+                           b.vals[cur ^ 1], status, shift, nsb, b.hist);
+        EMD_LAUNCH_CHECK();
+        cur ^= 1;
+    }
+    const unsigned rb = (unsigned)(((size_t)capacity + EMD_BLOCK - 1) / EMD_BLOCK);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(rb < 4096u ? rb : 4096u), dim3(EMD_BLOCK), 0, st, b.keys[cur], status, b.ranges);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}

@@ -1,0 +1,148 @@
+// common.h -- shared host/device definitions of the gfx950 street-Gaussian rasterizer.
+// Wave = 64 lanes, 256-thread workgroups, 16x16 tiles.  No CUDA compatibility layer: HIP for CDNA4 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/emd_raster.h"
+
+#define EMD_WAVE 64
+#define EMD_BLOCK 256
+#define EMD_NUM_TILE_PIX (EMD_TILE_X * EMD_TILE_Y)
+
+// Per-Gaussian projected record: 4 x float4 = 64 B, one half cache line, gathered by the render kernels.
+//   r0 = (x_pix, y_pix, depth, opacity)   r1 = (conic A, B, C, bits)   r2 = (r, g, b, 0)   r3 = (nx, ny, nz, 0)
+// r1.w bits: 0..2 = SH colour channel clamped (zero gradient).
+#define EMD_REC_F4 4
+
+// Per-Gaussian gradient accumulator written by the render backward: 12 floats = 48 B (3 x float4)
+//   [0..1] d/d mean2D (pixel units)  [2] d/d depth  [3] d/d opacity
+//   [4..6] d/d conic (A,B,C)         [7..9] d/d rgb
+//   [10..11] sum |d/d mean2D| (EMD_FLAG_ABSGRAD)
+#define EMD_BWD_STRIDE 12
+
+struct GeomWs {
+    float4* rec;             // [N][4]
+    uint32_t* tiles_touched; // [N]
+    uint32_t* block_sums;    // [ceil(N/256)] inclusive-scanned in place
+    uint32_t* scan_tmp;      // scratch for the scans
+    size_t bytes;
+};
+
+struct BinWs {
+    uint64_t* keys[2];       // [capacity] ping-pong
+    uint32_t* vals[2];       // [capacity]
+    uint32_t* ranges;        // [T][2]
+    uint32_t* hist;          // radix histograms [bins][num_sort_blocks]
+    uint32_t* scan_tmp;      // scratch for the scans
+    int sorted_buf;          // which ping-pong buffer holds the sorted list after forward (fixed by #passes)
+    size_t bytes;
+};
+
+struct ImgWs {
+    float* final_T;          // [H*W]
+    uint32_t* n_contrib;     // [H*W]
+    size_t bytes;
+};
+
+static inline size_t emd_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// sort geometry
+#define EMD_SORT_ITEMS 16                       // keys per thread
+#define EMD_SORT_TILE (EMD_BLOCK * EMD_SORT_ITEMS)
+#define EMD_RADIX_BITS 8
+#define EMD_RADIX_BINS (1 << EMD_RADIX_BITS)
+
+static inline int emd_tile_bits(int num_tiles) {
+    int b = 0;
+    while ((1 << b) < num_tiles) b++;
+    return b;
+}
+// key = tile_id << 32 | depth bits: only the low 32 + ceil(log2(tiles)) bits take part in the sort
+static inline int emd_sort_passes(int num_tiles) { return (32 + emd_tile_bits(num_tiles) + EMD_RADIX_BITS - 1) / EMD_RADIX_BITS; }
+
+static inline size_t emd_scan_tmp_elems(size_t n) {
+    // partial sums of a 3-phase scan over n elements with 1024-element blocks, two levels
+    size_t l1 = (n + 1023) / 1024, l2 = (l1 + 1023) / 1024;
+    return l1 + l2 + 8;
+}
+
+static inline void emd_carve_geom(void* base, int N, GeomWs* w) {
+    char* p = (char*)base;
+    size_t off = 0;
+    w->rec = (float4*)(p + off); off = emd_align_up(off + (size_t)N * EMD_REC_F4 * sizeof(float4), 256);
+    w->tiles_touched = (uint32_t*)(p + off); off = emd_align_up(off + (size_t)N * 4, 256);
+    size_t nb = ((size_t)N + EMD_BLOCK - 1) / EMD_BLOCK;
+    w->block_sums = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 1) * 4, 256);
+    w->scan_tmp = (uint32_t*)(p + off); off = emd_align_up(off + emd_scan_tmp_elems(nb) * 4, 256);
+    w->bytes = off + 256;
+}
+
+static inline void emd_carve_bin(void* base, int64_t capacity, int num_tiles, BinWs* w) {
+    char* p = (char*)base;
+    size_t off = 0;
+    size_t cap = (size_t)(capacity > 0 ? capacity : 1);
+    for (int i = 0; i < 2; i++) { w->keys[i] = (uint64_t*)(p + off); off = emd_align_up(off + cap * 8, 256); }
+    for (int i = 0; i < 2; i++) { w->vals[i] = (uint32_t*)(p + off); off = emd_align_up(off + cap * 4, 256); }
+    w->ranges = (uint32_t*)(p + off); off = emd_align_up(off + (size_t)num_tiles * 8, 256);
+    size_t nsb = (cap + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
+    size_t hist_elems = nsb * EMD_RADIX_BINS;
+    w->hist = (uint32_t*)(p + off); off = emd_align_up(off + hist_elems * 4, 256);
+    w->scan_tmp = (uint32_t*)(p + off); off = emd_align_up(off + emd_scan_tmp_elems(hist_elems) * 4, 256);
+    w->sorted_buf = emd_sort_passes(num_tiles) & 1;
+    w->bytes = off + 256;
+}
+
+static inline void emd_carve_img(void* base, int H, int W, ImgWs* w) {
+    char* p = (char*)base;
+    size_t off = 0, hw = (size_t)H * W;
+    w->final_T = (float*)(p + off); off = emd_align_up(off + hw * 4, 256);
+    w->n_contrib = (uint32_t*)(p + off); off = emd_align_up(off + hw * 4, 256);
+    w->bytes = off + 256;
+}
+
+// ---- error plumbing (api.hip) -------------------------------------------------------------------
+void emd_set_error(const char* fmt, ...);
+#define EMD_HIP_CHECK(expr)                                                                          \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            emd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return EMD_ERR_HIP;                                                                      \
+        }                                                                                            \
+    } while (0)
+#define EMD_LAUNCH_CHECK() EMD_HIP_CHECK(hipGetLastError())
+
+// ---- stage launchers (one per translation unit) -------------------------------------------------
+struct PreArgs {
+    EmdSettings s;
+    int N, M, flags;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    EmdMotion motion;
+    int32_t* radii;
+    GeomWs g;
+    EmdStatus* status;
+};
+int emd_launch_preprocess(const PreArgs& a, hipStream_t st);                 // preprocess.hip
+int emd_launch_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st);  // binning.hip (inclusive, in place)
+int emd_launch_binning(const EmdSettings& s, int N, const int32_t* radii, const GeomWs& g, const BinWs& b,
+                       int64_t capacity, EmdStatus* status, hipStream_t st); // binning.hip
+int emd_launch_render_forward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
+                              float* out_color, float* out_depth, float* out_normal, float* out_alpha,
+                              hipStream_t st);                                 // render.hip
+int emd_launch_render_backward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
+                               const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                               const float* dL_dnormal, float* grad_rec, hipStream_t st);  // render.hip
+struct PreBwdArgs {
+    EmdSettings s;
+    int N, M, flags;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    EmdMotion motion;
+    const int32_t* radii;
+    GeomWs g;
+    const float* grad_rec;  // [N][EMD_BWD_STRIDE]
+    float *dL_dmeans3D, *dL_dmeans2D, *dL_dmeans2D_abs, *dL_dshs, *dL_dcolors, *dL_dopacities, *dL_dscales,
+        *dL_drotations, *dL_dcov3D, *dL_dactor_pose, *dL_dresidual_dx, *dL_dresidual_dq;
+};
+int emd_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t st);     // preprocess.hip

@@ -1,0 +1,69 @@
+// device_utils.h -- wave64 cross-lane primitives for gfx950 (DPP row shifts / broadcasts, ballot).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// DPP controls (gfx9): row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_f32(float v) {
+    // lanes whose DPP source is invalid (or masked rows) receive 0 and keep v
+    int src = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(src);
+}
+
+// Inclusive wave64 prefix sum; lane 63 ends up with the wave total.  6 v_add_f32_dpp.
+__device__ __forceinline__ float wave_scan_add_f32(float v) {
+    v = dpp_add_f32<DPP_ROW_SHR(1), 0xf>(v);
+    v = dpp_add_f32<DPP_ROW_SHR(2), 0xf>(v);
+    v = dpp_add_f32<DPP_ROW_SHR(4), 0xf>(v);
+    v = dpp_add_f32<DPP_ROW_SHR(8), 0xf>(v);
+    v = dpp_add_f32<DPP_ROW_BCAST15, 0xa>(v);
+    v = dpp_add_f32<DPP_ROW_BCAST31, 0xc>(v);
+    return v;
+}
+
+// Sum over the wave, valid in lane 63 only.
+__device__ __forceinline__ float wave_reduce_to_lane63(float v) { return wave_scan_add_f32(v); }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
+    int src = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return v + (uint32_t)src;
+}
+
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
+    v = dpp_add_u32<DPP_ROW_SHR(1), 0xf>(v);
+    v = dpp_add_u32<DPP_ROW_SHR(2), 0xf>(v);
+    v = dpp_add_u32<DPP_ROW_SHR(4), 0xf>(v);
+    v = dpp_add_u32<DPP_ROW_SHR(8), 0xf>(v);
+    v = dpp_add_u32<DPP_ROW_BCAST15, 0xa>(v);
+    v = dpp_add_u32<DPP_ROW_BCAST31, 0xc>(v);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ float readlane_f32(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+// Block-wide (256 threads = 4 waves) inclusive scan of one uint32 per thread.
+// `smem` needs 4 uint32.  Returns the inclusive prefix; *total gets the block sum.
+__device__ __forceinline__ uint32_t block_scan_add_u32(uint32_t v, uint32_t* smem, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = wave_scan_add_u32(v);
+    if (lane == 63) smem[wave] = inc;
+    __syncthreads();
+    uint32_t s0 = smem[0], s1 = smem[1], s2 = smem[2], s3 = smem[3];
+    uint32_t base = (wave > 0 ? s0 : 0) + (wave > 1 ? s1 : 0) + (wave > 2 ? s2 : 0);
+    *total = s0 + s1 + s2 + s3;
+    __syncthreads();
+    return inc + base;
+}

@@ -1,0 +1,756 @@
+// preprocess.hip -- K1 (fused explicit motion + projection + EWA covariance + SH colour) and K8 (its backward),
+// plus the stand-alone motion and SH entry points.  gfx950, one Gaussian per lane.
+//
+// Built with -ffp-contract=off: the view depth (sort key), radius and tile rectangle are a bit-exact
+// contract with oracle/raster_oracle.c, so every operation here is an individually rounded fp32 op in
+// the documented order ("pinned evaluation order").
+//
+// Reference behaviour this replaces (file:line):
+//   activations + rasterizer preprocess   S3Gaussian/gaussian_renderer/__init__.py:99-101,145-155 [UPSTREAM K1]
+//   cov3D                                 S3Gaussian/utils/general_utils.py:245-277, scene/gaussian_model.py:34-38
+//   SH colour                             S3Gaussian/utils/sh_utils.py:57-112, gaussian_renderer/__init__.py:19-25
+//   projection                            S3Gaussian/utils/graphics_utils.py:42-49
+//   rigid actor motion + residual         OmniRe/models/nodes/rigid.py:478-568, deformable.py:57-69
+#include "common.h"
+#include "device_utils.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ const float SH_C0 = 0.28209479177387814f;
+__device__ const float SH_C1 = 0.4886025119029199f;
+__device__ const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                   -1.0925484305920792f, 0.5462742152960396f};
+__device__ const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                   0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                   -0.5900435899266435f};
+
+__device__ __forceinline__ void quat_to_R(const float q[4], float R[9]) {
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1.f - 2.f * (y * y + z * z);
+    R[1] = 2.f * (x * y - r * z);
+    R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z);
+    R[4] = 1.f - 2.f * (x * x + z * z);
+    R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y);
+    R[7] = 2.f * (y * z + r * x);
+    R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+__device__ __forceinline__ void quat_mul(const float a[4], const float b[4], float o[4]) {
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+
+__device__ __forceinline__ float quat_norm(const float q[4]) {
+    return sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+}
+
+// World-space mean / quaternion / opacity of Gaussian i under the explicit-motion model.
+__device__ __forceinline__ void motion_point(int i, const float* __restrict__ means, const float* __restrict__ quats,
+                                             const float* __restrict__ opac, const EmdMotion& mo, float wm[3],
+                                             float wq[4], float* wo) {
+    float m[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    if (mo.residual_dx) {
+        m[0] += mo.residual_dx[3 * i]; m[1] += mo.residual_dx[3 * i + 1]; m[2] += mo.residual_dx[3 * i + 2];
+    }
+    int a = mo.actor_id ? mo.actor_id[i] : -1;
+    if (a < 0) {
+        wm[0] = m[0]; wm[1] = m[1]; wm[2] = m[2];
+        if (quats) { const float4 q = *(const float4*)(quats + 4 * i); wq[0] = q.x; wq[1] = q.y; wq[2] = q.z; wq[3] = q.w; }
+        if (opac) *wo = opac[i];
+        return;
+    }
+    const float4* Pp = (const float4*)(mo.actor_pose + (size_t)a * EMD_ACTOR_STRIDE);
+    const float4 p0 = Pp[0], p1 = Pp[1], p2 = Pp[2];
+    const float qm[4] = {p0.x, p0.y, p0.z, p0.w};
+    float R[9];
+    quat_to_R(qm, R);
+    wm[0] = ((R[0] * m[0] + R[1] * m[1]) + R[2] * m[2]) + p1.x;
+    wm[1] = ((R[3] * m[0] + R[4] * m[1]) + R[5] * m[2]) + p1.y;
+    wm[2] = ((R[6] * m[0] + R[7] * m[1]) + R[8] * m[2]) + p1.z;
+    if (quats) {
+        const float4 q = *(const float4*)(quats + 4 * i);
+        float ql[4] = {q.x, q.y, q.z, q.w};
+        if (mo.residual_dq) {
+            const float4 d = *(const float4*)(mo.residual_dq + 4 * i);
+            ql[0] += d.x; ql[1] += d.y; ql[2] += d.z; ql[3] += d.w;
+        }
+        float n = fmaxf(quat_norm(ql), 1e-12f);
+        float qn[4] = {ql[0] / n, ql[1] / n, ql[2] / n, ql[3] / n};
+        const float qr[4] = {p2.x, p2.y, p2.z, p2.w};
+        float p[4];
+        quat_mul(qr, qn, p);
+        float n2 = fmaxf(quat_norm(p), 1e-12f);
+        wq[0] = p[0] / n2; wq[1] = p[1] / n2; wq[2] = p[2] / n2; wq[3] = p[3] / n2;
+    }
+    if (opac) *wo = opac[i] * p1.w;
+}
+
+__device__ __forceinline__ void sh_basis(int deg, const float d[3], float b[16]) {
+    float x = d[0], y = d[1], z = d[2];
+    b[0] = SH_C0;
+    if (deg > 0) {
+        b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = SH_C2[0] * xy; b[5] = SH_C2[1] * yz; b[6] = SH_C2[2] * (2.f * zz - xx - yy);
+            b[7] = SH_C2[3] * xz; b[8] = SH_C2[4] * (xx - yy);
+            if (deg > 2) {
+                b[9] = SH_C3[0] * y * (3.f * xx - yy);
+                b[10] = SH_C3[1] * xy * z;
+                b[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+                b[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                b[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+                b[14] = SH_C3[5] * z * (xx - yy);
+                b[15] = SH_C3[6] * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void cov3d_from_sr(const float s[3], float mod, const float q[4], float c[6]) {
+    float R[9], L[9];
+    quat_to_R(q, R);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) L[3 * r + k] = R[3 * r + k] * (mod * s[k]);
+    c[0] = (L[0] * L[0] + L[1] * L[1]) + L[2] * L[2];
+    c[1] = (L[0] * L[3] + L[1] * L[4]) + L[2] * L[5];
+    c[2] = (L[0] * L[6] + L[1] * L[7]) + L[2] * L[8];
+    c[3] = (L[3] * L[3] + L[4] * L[4]) + L[5] * L[5];
+    c[4] = (L[3] * L[6] + L[4] * L[7]) + L[5] * L[8];
+    c[5] = (L[6] * L[6] + L[7] * L[7]) + L[8] * L[8];
+}
+
+__device__ __forceinline__ int tile_clamp(float f, int grid) {
+    float g = (float)grid;
+    if (!(f > 0.f)) return 0;
+    if (f > g) return grid;
+    return (int)f;
+}
+
+// Shared by K1 and K8: everything up to cov2D for one visible Gaussian.
+struct Proj {
+    float tx, ty, tz, cx, cy;
+    bool clx, cly;
+    float M0[3], M1[3], T0[3], T1[3];
+    float a, b, c, det;
+};
+
+__device__ __forceinline__ void project_cov2d(const EmdSettings& S, const float m[3], const float c3[6], float fx,
+                                              float fy, Proj& p) {
+    const float* V = S.viewmatrix;
+    float limx = 1.3f * S.tanfovx, limy = 1.3f * S.tanfovy;
+    float txtz = p.tx / p.tz, tytz = p.ty / p.tz;
+    p.clx = (txtz < -limx) || (txtz > limx);
+    p.cly = (tytz < -limy) || (tytz > limy);
+    p.cx = fminf(limx, fmaxf(-limx, txtz)) * p.tz;
+    p.cy = fminf(limy, fmaxf(-limy, tytz)) * p.tz;
+    float J00 = fx / p.tz, J02 = -(fx * p.cx) / (p.tz * p.tz), J11 = fy / p.tz, J12 = -(fy * p.cy) / (p.tz * p.tz);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        p.M0[k] = J00 * V[4 * k + 0] + J02 * V[4 * k + 2];
+        p.M1[k] = J11 * V[4 * k + 1] + J12 * V[4 * k + 2];
+    }
+    const float Sg[9] = {c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        p.T0[k] = (p.M0[0] * Sg[k] + p.M0[1] * Sg[3 + k]) + p.M0[2] * Sg[6 + k];
+        p.T1[k] = (p.M1[0] * Sg[k] + p.M1[1] * Sg[3 + k]) + p.M1[2] * Sg[6 + k];
+    }
+    p.a = ((p.T0[0] * p.M0[0] + p.T0[1] * p.M0[1]) + p.T0[2] * p.M0[2]) + 0.3f;
+    p.b = (p.T0[0] * p.M1[0] + p.T0[1] * p.M1[1]) + p.T0[2] * p.M1[2];
+    p.c = ((p.T1[0] * p.M1[0] + p.T1[1] * p.M1[1]) + p.T1[2] * p.M1[2]) + 0.3f;
+    p.det = p.a * p.c - p.b * p.b;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
+    __shared__ uint32_t s_red[8];
+    const EmdSettings& S = a.s;
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    uint32_t touched = 0;
+    int radius_out = 0;
+    if (i < a.N) {
+        const float* V = S.viewmatrix;
+        const float* P = S.projmatrix;
+        const int W = S.image_width, H = S.image_height;
+        const int gx = (W + EMD_TILE_X - 1) / EMD_TILE_X, gy = (H + EMD_TILE_Y - 1) / EMD_TILE_Y;
+        const float fx = (float)W / (2.f * S.tanfovx), fy = (float)H / (2.f * S.tanfovy);
+        float m[3], q[4] = {1.f, 0.f, 0.f, 0.f}, op = a.opacities[i];
+        if (a.flags & EMD_FLAG_MOTION) {
+            motion_point(i, a.means3D, a.rotations, a.opacities, a.motion, m, q, &op);
+        } else {
+            m[0] = a.means3D[3 * i]; m[1] = a.means3D[3 * i + 1]; m[2] = a.means3D[3 * i + 2];
+            if (a.rotations) { const float4 qq = *(const float4*)(a.rotations + 4 * i); q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w; }
+        }
+        Proj p;
+        p.tx = ((V[0] * m[0] + V[4] * m[1]) + V[8] * m[2]) + V[12];
+        p.ty = ((V[1] * m[0] + V[5] * m[1]) + V[9] * m[2]) + V[13];
+        p.tz = ((V[2] * m[0] + V[6] * m[1]) + V[10] * m[2]) + V[14];
+        if (p.tz > S.near_plane) {
+            float hx = ((P[0] * m[0] + P[4] * m[1]) + P[8] * m[2]) + P[12];
+            float hy = ((P[1] * m[0] + P[5] * m[1]) + P[9] * m[2]) + P[13];
+            float hw = ((P[3] * m[0] + P[7] * m[1]) + P[11] * m[2]) + P[15];
+            float pw = 1.f / (hw + 0.0000001f);
+            float px = hx * pw, py = hy * pw;
+            float c3[6];
+            float sc[3] = {1.f, 1.f, 1.f};
+            if (a.cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * i + k];
+            } else {
+                sc[0] = a.scales[3 * i]; sc[1] = a.scales[3 * i + 1]; sc[2] = a.scales[3 * i + 2];
+                cov3d_from_sr(sc, S.scale_modifier, q, c3);
+            }
+            project_cov2d(S, m, c3, fx, fy, p);
+            if (p.det != 0.f) {
+                float det_inv = 1.f / p.det;
+                float conA = p.c * det_inv, conB = -p.b * det_inv, conC = p.a * det_inv;
+                float mid = 0.5f * (p.a + p.c);
+                float sq = sqrtf(fmaxf(0.1f, mid * mid - p.det));
+                float lam1 = mid + sq, lam2 = mid - sq;
+                float rad = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
+                float ix = ((px + 1.f) * (float)W - 1.f) * 0.5f;
+                float iy = ((py + 1.f) * (float)H - 1.f) * 0.5f;
+                int x0 = tile_clamp((ix - rad) / (float)EMD_TILE_X, gx);
+                int y0 = tile_clamp((iy - rad) / (float)EMD_TILE_Y, gy);
+                int x1 = tile_clamp((ix + rad + (float)(EMD_TILE_X - 1)) / (float)EMD_TILE_X, gx);
+                int y1 = tile_clamp((iy + rad + (float)(EMD_TILE_Y - 1)) / (float)EMD_TILE_Y, gy);
+                int area = (x1 - x0) * (y1 - y0);
+                if (area > 0) {
+                    float col[3];
+                    uint32_t bits = 0;
+                    if (a.colors_precomp) {
+                        col[0] = a.colors_precomp[3 * i]; col[1] = a.colors_precomp[3 * i + 1];
+                        col[2] = a.colors_precomp[3 * i + 2];
+                    } else {
+                        float d[3] = {m[0] - S.campos[0], m[1] - S.campos[1], m[2] - S.campos[2]};
+                        float n = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+                        d[0] /= n; d[1] /= n; d[2] /= n;
+                        float bs[16];
+                        sh_basis(S.sh_degree, d, bs);
+                        const int K = (S.sh_degree + 1) * (S.sh_degree + 1);
+                        const float* sh = a.shs + (size_t)i * a.M * 3;
+                        col[0] = col[1] = col[2] = 0.f;
+                        for (int k = 0; k < K; k++) {
+                            col[0] += bs[k] * sh[3 * k]; col[1] += bs[k] * sh[3 * k + 1]; col[2] += bs[k] * sh[3 * k + 2];
+                        }
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            col[ch] += 0.5f;
+                            if (col[ch] < 0.f) { col[ch] = 0.f; bits |= 1u << ch; }
+                            if ((a.flags & EMD_FLAG_CLAMP_RGB01) && col[ch] > 1.f) { col[ch] = 1.f; bits |= 1u << ch; }
+                        }
+                    }
+                    float4* rec = a.g.rec + (size_t)i * EMD_REC_F4;
+                    rec[0] = make_float4(ix, iy, p.tz, op);
+                    rec[1] = make_float4(conA, conB, conC, __uint_as_float(bits));
+                    rec[2] = make_float4(col[0], col[1], col[2], 0.f);
+                    if (a.flags & EMD_FLAG_NORMAL) {
+                        float nv[3] = {0.f, 0.f, 0.f};
+                        if (a.scales) {
+                            int ax = 0;
+                            if (sc[1] < sc[ax]) ax = 1;
+                            if (sc[2] < sc[ax]) ax = 2;
+                            float R[9];
+                            quat_to_R(q, R);
+                            float nw[3] = {R[ax], R[3 + ax], R[6 + ax]};
+                            nv[0] = (V[0] * nw[0] + V[4] * nw[1]) + V[8] * nw[2];
+                            nv[1] = (V[1] * nw[0] + V[5] * nw[1]) + V[9] * nw[2];
+                            nv[2] = (V[2] * nw[0] + V[6] * nw[1]) + V[10] * nw[2];
+                            float dp = (nv[0] * p.tx + nv[1] * p.ty) + nv[2] * p.tz;
+                            if (dp > 0.f) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }
+                        }
+                        rec[3] = make_float4(nv[0], nv[1], nv[2], 0.f);
+                    }
+                    touched = (uint32_t)area;
+                    radius_out = (int)rad;
+                }
+            }
+        }
+        a.radii[i] = radius_out;
+        a.g.tiles_touched[i] = touched;
+    }
+    // block totals: tiles touched (feeds the duplicate offsets) and visible count
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t tsum = wave_scan_add_u32(touched);
+    uint32_t vsum = wave_scan_add_u32(touched ? 1u : 0u);
+    if (lane == 63) { s_red[wave] = tsum; s_red[4 + wave] = vsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.g.block_sums[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        uint32_t v = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+        if (v) atomicAdd(&a.status->num_visible, v);
+    }
+}
+
+// d colour / d (unit) direction contracted with the colour gradient gc: gd = sum_k d basis_k/d dir * (sh[k] . gc)
+__device__ __forceinline__ void sh_dir_backward(int deg, const float d[3], const float* __restrict__ sh,
+                                                const float gc[3], float gd[3]) {
+    const float x = d[0], y = d[1], z = d[2];
+    gd[0] = gd[1] = gd[2] = 0.f;
+#define SDOT(k) ((sh[3 * (k)] * gc[0] + sh[3 * (k) + 1] * gc[1]) + sh[3 * (k) + 2] * gc[2])
+    if (deg > 0) {
+        gd[1] += -SH_C1 * SDOT(1); gd[2] += SH_C1 * SDOT(2); gd[0] += -SH_C1 * SDOT(3);
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z;
+            float s4 = SDOT(4), s5 = SDOT(5), s6 = SDOT(6), s7 = SDOT(7), s8 = SDOT(8);
+            gd[0] += SH_C2[0] * y * s4 + SH_C2[2] * -2.f * x * s6 + SH_C2[3] * z * s7 + SH_C2[4] * 2.f * x * s8;
+            gd[1] += SH_C2[0] * x * s4 + SH_C2[1] * z * s5 + SH_C2[2] * -2.f * y * s6 + SH_C2[4] * -2.f * y * s8;
+            gd[2] += SH_C2[1] * y * s5 + SH_C2[2] * 4.f * z * s6 + SH_C2[3] * x * s7;
+            if (deg > 2) {
+                float s9 = SDOT(9), s10 = SDOT(10), s11 = SDOT(11), s12 = SDOT(12), s13 = SDOT(13),
+                      s14 = SDOT(14), s15 = SDOT(15);
+                gd[0] += SH_C3[0] * 6.f * x * y * s9 + SH_C3[1] * y * z * s10 + SH_C3[2] * -2.f * x * y * s11 +
+                         SH_C3[3] * -6.f * x * z * s12 + SH_C3[4] * (4.f * zz - 3.f * xx - yy) * s13 +
+                         SH_C3[5] * 2.f * x * z * s14 + SH_C3[6] * (3.f * xx - 3.f * yy) * s15;
+                gd[1] += SH_C3[0] * (3.f * xx - 3.f * yy) * s9 + SH_C3[1] * x * z * s10 +
+                         SH_C3[2] * (4.f * zz - xx - 3.f * yy) * s11 + SH_C3[3] * -6.f * y * z * s12 +
+                         SH_C3[4] * -2.f * x * y * s13 + SH_C3[5] * -2.f * y * z * s14 +
+                         SH_C3[6] * -6.f * x * y * s15;
+                gd[2] += SH_C3[1] * x * y * s10 + SH_C3[2] * 8.f * y * z * s11 +
+                         SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy) * s12 + SH_C3[4] * 8.f * x * z * s13 +
+                         SH_C3[5] * (xx - yy) * s14;
+            }
+        }
+    }
+#undef SDOT
+}
+
+__device__ __forceinline__ void dR_to_dq(const float q[4], const float dR[9], float dq[4]) {
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    dq[0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+    dq[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+    dq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+    dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+}
+
+__device__ __forceinline__ void dnormalize4(const float vu[4], float n, const float g[4], float out[4]) {
+    float dot = ((vu[0] * g[0] + vu[1] * g[1]) + vu[2] * g[2]) + vu[3] * g[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = (g[k] - vu[k] * dot) / n;
+}
+
+// Backward of motion_point for an actor point (a_id >= 0): world-space gradients (dm, dq, dop) -> local-space
+// gradients (dl, dql, dopl) and this point's contribution to its actor's pose row (pose_g[12]).
+__device__ __forceinline__ void motion_point_backward(int i, int a_id, const float* __restrict__ means,
+                                                      const float* __restrict__ quats, const float* __restrict__ opac,
+                                                      const EmdMotion& mo, const float dm[3], const float dq[4],
+                                                      float dop, float dl[3], float dql[4], float* dopl,
+                                                      float pose_g[12]) {
+    const float4* Pp = (const float4*)(mo.actor_pose + (size_t)a_id * EMD_ACTOR_STRIDE);
+    const float4 p0 = Pp[0], p1 = Pp[1], p2 = Pp[2];
+    const float qm[4] = {p0.x, p0.y, p0.z, p0.w};
+    float R[9];
+    quat_to_R(qm, R);
+    float ml[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    if (mo.residual_dx) { ml[0] += mo.residual_dx[3 * i]; ml[1] += mo.residual_dx[3 * i + 1]; ml[2] += mo.residual_dx[3 * i + 2]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) dl[k] = (R[k] * dm[0] + R[3 + k] * dm[1]) + R[6 + k] * dm[2];
+    float dRm[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) dRm[3 * r + k] = dm[r] * ml[k];
+    float dqm[4];
+    dR_to_dq(qm, dRm, dqm);
+    pose_g[0] = dqm[0]; pose_g[1] = dqm[1]; pose_g[2] = dqm[2]; pose_g[3] = dqm[3];
+    pose_g[4] = dm[0]; pose_g[5] = dm[1]; pose_g[6] = dm[2];
+    pose_g[7] = opac ? dop * opac[i] : 0.f;
+    pose_g[8] = pose_g[9] = pose_g[10] = pose_g[11] = 0.f;
+    dql[0] = dql[1] = dql[2] = dql[3] = 0.f;
+    if (quats) {
+        const float4 qq = *(const float4*)(quats + 4 * i);
+        float ql[4] = {qq.x, qq.y, qq.z, qq.w};
+        if (mo.residual_dq) {
+            const float4 d = *(const float4*)(mo.residual_dq + 4 * i);
+            ql[0] += d.x; ql[1] += d.y; ql[2] += d.z; ql[3] += d.w;
+        }
+        float n = fmaxf(quat_norm(ql), 1e-12f);
+        float qn[4] = {ql[0] / n, ql[1] / n, ql[2] / n, ql[3] / n};
+        const float qr[4] = {p2.x, p2.y, p2.z, p2.w};
+        float pp[4];
+        quat_mul(qr, qn, pp);
+        float n2 = fmaxf(quat_norm(pp), 1e-12f);
+        float pu[4] = {pp[0] / n2, pp[1] / n2, pp[2] / n2, pp[3] / n2};
+        float dp[4];
+        dnormalize4(pu, n2, dq, dp);
+        // p = a (x) b : dL/da = g (x) conj(b), dL/db = conj(a) (x) g
+        const float bc[4] = {qn[0], -qn[1], -qn[2], -qn[3]}, ac[4] = {qr[0], -qr[1], -qr[2], -qr[3]};
+        float dqa[4], dqb[4];
+        quat_mul(dp, bc, dqa);
+        quat_mul(ac, dp, dqb);
+        pose_g[8] = dqa[0]; pose_g[9] = dqa[1]; pose_g[10] = dqa[2]; pose_g[11] = dqa[3];
+        dnormalize4(qn, n, dqb, dql);
+    }
+    *dopl = dop * p1.w;
+}
+
+// Segmented reduction of per-point pose gradients into dL_dactor_pose.  Actor points are stored contiguously
+// per instance (rigid.py:53-145), so most waves hold one actor id: DPP wave sum, one atomic row per wave.
+__device__ __forceinline__ void reduce_pose_grad(int a_id, const float pose_g[12], float* __restrict__ dL_dpose) {
+    const unsigned long long has = __ballot(a_id >= 0);
+    if (!has) return;
+    const int first = __ffsll((long long)has) - 1;
+    const int a0 = __builtin_amdgcn_readlane(a_id, first);
+    const bool uniform = __ballot(a_id >= 0 && a_id != a0) == 0ull;
+    if (uniform) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            float v = wave_reduce_to_lane63(a_id >= 0 ? pose_g[k] : 0.f);
+            if ((threadIdx.x & 63) == 63) atomicAdd(dL_dpose + (size_t)a0 * EMD_ACTOR_STRIDE + k, v);
+        }
+    } else if (a_id >= 0) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) atomicAdd(dL_dpose + (size_t)a_id * EMD_ACTOR_STRIDE + k, pose_g[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K8
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a) {
+    const EmdSettings& S = a.s;
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    const bool in_range = i < a.N;
+    const float* V = S.viewmatrix;
+    const float* P = S.projmatrix;
+    const int W = S.image_width, H = S.image_height;
+    const float fx = (float)W / (2.f * S.tanfovx), fy = (float)H / (2.f * S.tanfovy);
+    float dm[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f}, dop = 0.f;
+    float dc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gm2[2] = {0.f, 0.f}, gabs[2] = {0.f, 0.f};
+    int a_id = -1;
+    float pose_g[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) pose_g[k] = 0.f;
+    if (in_range) {
+        const bool visible = a.radii[i] > 0;
+        float m[3], q[4] = {1.f, 0.f, 0.f, 0.f}, op = a.opacities[i];
+        if (a.flags & EMD_FLAG_MOTION) {
+            motion_point(i, a.means3D, a.rotations, a.opacities, a.motion, m, q, &op);
+            a_id = a.motion.actor_id ? a.motion.actor_id[i] : -1;
+        } else {
+            m[0] = a.means3D[3 * i]; m[1] = a.means3D[3 * i + 1]; m[2] = a.means3D[3 * i + 2];
+            if (a.rotations) { const float4 qq = *(const float4*)(a.rotations + 4 * i); q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w; }
+        }
+        float gcol[3] = {0.f, 0.f, 0.f};
+        if (visible) {
+            const float4* gr = (const float4*)(a.grad_rec + (size_t)i * EMD_BWD_STRIDE);
+            const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2];
+            const uint32_t bits = __float_as_uint(a.g.rec[(size_t)i * EMD_REC_F4 + 1].w);
+            gm2[0] = g0.x; gm2[1] = g0.y;
+            if (a.flags & EMD_FLAG_ABSGRAD) { gabs[0] = g2.z; gabs[1] = g2.w; }
+            const float g_depth = g0.z;
+            dop = g0.w;
+            const float gA = g1.x, gB = g1.y, gC = g1.z;
+            gcol[0] = g1.w; gcol[1] = g2.x; gcol[2] = g2.y;
+            Proj p;
+            p.tx = ((V[0] * m[0] + V[4] * m[1]) + V[8] * m[2]) + V[12];
+            p.ty = ((V[1] * m[0] + V[5] * m[1]) + V[9] * m[2]) + V[13];
+            p.tz = ((V[2] * m[0] + V[6] * m[1]) + V[10] * m[2]) + V[14];
+            // (e) colour
+            if (!a.colors_precomp) {
+                float d0[3] = {m[0] - S.campos[0], m[1] - S.campos[1], m[2] - S.campos[2]};
+                float n = sqrtf((d0[0] * d0[0] + d0[1] * d0[1]) + d0[2] * d0[2]);
+                float d[3] = {d0[0] / n, d0[1] / n, d0[2] / n};
+                float gc[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) gc[ch] = ((bits >> ch) & 1u) ? 0.f : gcol[ch];
+                const int deg = S.sh_degree;
+                const int K = (deg + 1) * (deg + 1);
+                const float* sh = a.shs + (size_t)i * a.M * 3;
+                float bs[16];
+                sh_basis(deg, d, bs);
+                if (a.dL_dshs) {
+                    float* o = a.dL_dshs + (size_t)i * a.M * 3;
+                    for (int k = 0; k < a.M; k++) {
+                        float bk = k < K ? bs[k] : 0.f;
+                        o[3 * k] = bk * gc[0]; o[3 * k + 1] = bk * gc[1]; o[3 * k + 2] = bk * gc[2];
+                    }
+                }
+                float gd[3];
+                sh_dir_backward(deg, d, sh, gc, gd);
+                float dot = (d[0] * gd[0] + d[1] * gd[1]) + d[2] * gd[2];
+#pragma unroll
+                for (int k = 0; k < 3; k++) dm[k] += (gd[k] - d[k] * dot) / n;
+            }
+            // (a) conic -> cov2D, (b) cov2D -> Sigma and J, t
+            float c3[6];
+            float sc[3] = {1.f, 1.f, 1.f};
+            if (a.cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * i + k];
+            } else {
+                sc[0] = a.scales[3 * i]; sc[1] = a.scales[3 * i + 1]; sc[2] = a.scales[3 * i + 2];
+                cov3d_from_sr(sc, S.scale_modifier, q, c3);
+            }
+            project_cov2d(S, m, c3, fx, fy, p);
+            float da = 0.f, db = 0.f, dc = 0.f;
+            if (p.det != 0.f) {
+                float i2 = 1.f / (p.det * p.det);
+                da = (-p.c * p.c * gA + p.b * p.c * gB - p.b * p.b * gC) * i2;
+                db = (2.f * p.b * p.c * gA - (p.a * p.c + p.b * p.b) * gB + 2.f * p.a * p.b * gC) * i2;
+                dc = (-p.b * p.b * gA + p.a * p.b * gB - p.a * p.a * gC) * i2;
+            }
+            const float* M0 = p.M0; const float* M1 = p.M1;
+            dc6[0] = da * M0[0] * M0[0] + db * M0[0] * M1[0] + dc * M1[0] * M1[0];
+            dc6[3] = da * M0[1] * M0[1] + db * M0[1] * M1[1] + dc * M1[1] * M1[1];
+            dc6[5] = da * M0[2] * M0[2] + db * M0[2] * M1[2] + dc * M1[2] * M1[2];
+            dc6[1] = 2.f * da * M0[0] * M0[1] + db * (M0[0] * M1[1] + M0[1] * M1[0]) + 2.f * dc * M1[0] * M1[1];
+            dc6[2] = 2.f * da * M0[0] * M0[2] + db * (M0[0] * M1[2] + M0[2] * M1[0]) + 2.f * dc * M1[0] * M1[2];
+            dc6[4] = 2.f * da * M0[1] * M0[2] + db * (M0[1] * M1[2] + M0[2] * M1[1]) + 2.f * dc * M1[1] * M1[2];
+            float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float dM0 = 2.f * da * p.T0[k] + db * p.T1[k];
+                float dM1 = 2.f * dc * p.T1[k] + db * p.T0[k];
+                dJ00 += dM0 * V[4 * k + 0]; dJ02 += dM0 * V[4 * k + 2];
+                dJ11 += dM1 * V[4 * k + 1]; dJ12 += dM1 * V[4 * k + 2];
+            }
+            float tz2 = 1.f / (p.tz * p.tz), tz3 = tz2 / p.tz;
+            float dtx = p.clx ? 0.f : -fx * tz2 * dJ02;
+            float dty = p.cly ? 0.f : -fy * tz2 * dJ12;
+            float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + 2.f * fx * p.cx * tz3 * dJ02 + 2.f * fy * p.cy * tz3 * dJ12;
+            dtz += g_depth;  // (d)
+#pragma unroll
+            for (int k = 0; k < 3; k++) dm[k] += V[4 * k + 0] * dtx + V[4 * k + 1] * dty + V[4 * k + 2] * dtz;
+            // (c) pixel mean -> clip -> world
+            float gxn = 0.5f * (float)W * gm2[0], gyn = 0.5f * (float)H * gm2[1];
+            gm2[0] = gxn; gm2[1] = gyn;
+            gabs[0] *= 0.5f * (float)W; gabs[1] *= 0.5f * (float)H;
+            float hx = ((P[0] * m[0] + P[4] * m[1]) + P[8] * m[2]) + P[12];
+            float hy = ((P[1] * m[0] + P[5] * m[1]) + P[9] * m[2]) + P[13];
+            float hw = ((P[3] * m[0] + P[7] * m[1]) + P[11] * m[2]) + P[15];
+            float pw = 1.f / (hw + 0.0000001f);
+            float mul1 = hx * pw * pw, mul2 = hy * pw * pw;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                dm[k] += (P[4 * k] * pw - P[4 * k + 3] * mul1) * gxn + (P[4 * k + 1] * pw - P[4 * k + 3] * mul2) * gyn;
+            // (f) Sigma -> scale, quaternion
+            if (!a.cov3D_precomp) {
+                float R[9], L[9];
+                quat_to_R(q, R);
+                const float mod = S.scale_modifier;
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) L[3 * r + k] = R[3 * r + k] * (mod * sc[k]);
+                const float Gf[9] = {dc6[0], 0.5f * dc6[1], 0.5f * dc6[2], 0.5f * dc6[1], dc6[3], 0.5f * dc6[4],
+                                     0.5f * dc6[2], 0.5f * dc6[4], dc6[5]};
+                float dL[9], dR[9];
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        dL[3 * r + k] = 2.f * ((Gf[3 * r] * L[k] + Gf[3 * r + 1] * L[3 + k]) + Gf[3 * r + 2] * L[6 + k]);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    ds[k] = mod * ((dL[k] * R[k] + dL[3 + k] * R[3 + k]) + dL[6 + k] * R[6 + k]);
+#pragma unroll
+                    for (int r = 0; r < 3; r++) dR[3 * r + k] = dL[3 * r + k] * (mod * sc[k]);
+                }
+                dR_to_dq(q, dR, dq);
+            }
+        } else if (a.dL_dshs) {
+            float* o = a.dL_dshs + (size_t)i * a.M * 3;
+            for (int k = 0; k < 3 * a.M; k++) o[k] = 0.f;
+        }
+        if (a.dL_dmeans2D) { a.dL_dmeans2D[3 * i] = gm2[0]; a.dL_dmeans2D[3 * i + 1] = gm2[1]; a.dL_dmeans2D[3 * i + 2] = 0.f; }
+        if (a.dL_dmeans2D_abs) { a.dL_dmeans2D_abs[2 * i] = gabs[0]; a.dL_dmeans2D_abs[2 * i + 1] = gabs[1]; }
+        if (a.dL_dcolors) { a.dL_dcolors[3 * i] = gcol[0]; a.dL_dcolors[3 * i + 1] = gcol[1]; a.dL_dcolors[3 * i + 2] = gcol[2]; }
+        if (a.dL_dcov3D) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * i + k] = dc6[k];
+        }
+        if (a.dL_dscales) { a.dL_dscales[3 * i] = ds[0]; a.dL_dscales[3 * i + 1] = ds[1]; a.dL_dscales[3 * i + 2] = ds[2]; }
+        // (h) explicit motion
+        float dl[3] = {dm[0], dm[1], dm[2]}, dql[4] = {dq[0], dq[1], dq[2], dq[3]}, dopl = dop;
+        if (a_id >= 0)
+            motion_point_backward(i, a_id, a.means3D, a.rotations, a.opacities, a.motion, dm, dq, dop, dl, dql, &dopl, pose_g);
+        if (a.dL_dmeans3D) { a.dL_dmeans3D[3 * i] = dl[0]; a.dL_dmeans3D[3 * i + 1] = dl[1]; a.dL_dmeans3D[3 * i + 2] = dl[2]; }
+        if (a.dL_dresidual_dx) { a.dL_dresidual_dx[3 * i] = dl[0]; a.dL_dresidual_dx[3 * i + 1] = dl[1]; a.dL_dresidual_dx[3 * i + 2] = dl[2]; }
+        if (a.dL_drotations) *(float4*)(a.dL_drotations + 4 * i) = make_float4(dql[0], dql[1], dql[2], dql[3]);
+        if (a.dL_dresidual_dq) {
+            *(float4*)(a.dL_dresidual_dq + 4 * i) = a_id >= 0 ? make_float4(dql[0], dql[1], dql[2], dql[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (a.dL_dopacities) a.dL_dopacities[i] = dopl;
+    }
+    if ((a.flags & EMD_FLAG_MOTION) && a.dL_dactor_pose) reduce_pose_grad(a_id, pose_g, a.dL_dactor_pose);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stand-alone motion / SH kernels
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EMD_BLOCK) k_motion_forward(int n, const float* means, const float* quats,
+                                                              const float* opac, EmdMotion mo, float* wm, float* wq,
+                                                              float* wo) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float m[3], q[4] = {1.f, 0.f, 0.f, 0.f}, o = 0.f;
+    motion_point(i, means, quats, opac, mo, m, q, &o);
+    if (wm) { wm[3 * i] = m[0]; wm[3 * i + 1] = m[1]; wm[3 * i + 2] = m[2]; }
+    if (wq && quats) *(float4*)(wq + 4 * i) = make_float4(q[0], q[1], q[2], q[3]);
+    if (wo && opac) wo[i] = o;
+}
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_sh_forward(int n, int deg, int M, const float* dirs,
+                                                          const float* coeffs, float* rgb) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float d[3] = {dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
+    float nn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    d[0] /= nn; d[1] /= nn; d[2] /= nn;
+    float bs[16];
+    sh_basis(deg, d, bs);
+    const int K = (deg + 1) * (deg + 1);
+    const float* sh = coeffs + (size_t)i * M * 3;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int k = 0; k < K; k++) { c0 += bs[k] * sh[3 * k]; c1 += bs[k] * sh[3 * k + 1]; c2 += bs[k] * sh[3 * k + 2]; }
+    rgb[3 * i] = c0; rgb[3 * i + 1] = c1; rgb[3 * i + 2] = c2;
+}
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_motion_backward(int n, const float* means, const float* quats,
+                                                               const float* opac, EmdMotion mo, const float* g_wm,
+                                                               const float* g_wq, const float* g_wo, float* d_means,
+                                                               float* d_quats, float* d_opac, float* d_pose,
+                                                               float* d_rdx, float* d_rdq) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    int a_id = -1;
+    float pose_g[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) pose_g[k] = 0.f;
+    if (i < n) {
+        float dm[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f}, dop = 0.f;
+        if (g_wm) { dm[0] = g_wm[3 * i]; dm[1] = g_wm[3 * i + 1]; dm[2] = g_wm[3 * i + 2]; }
+        if (g_wq) { const float4 t = *(const float4*)(g_wq + 4 * i); dq[0] = t.x; dq[1] = t.y; dq[2] = t.z; dq[3] = t.w; }
+        if (g_wo) dop = g_wo[i];
+        a_id = mo.actor_id ? mo.actor_id[i] : -1;
+        float dl[3] = {dm[0], dm[1], dm[2]}, dql[4] = {dq[0], dq[1], dq[2], dq[3]}, dopl = dop;
+        if (a_id >= 0) motion_point_backward(i, a_id, means, quats, opac, mo, dm, dq, dop, dl, dql, &dopl, pose_g);
+        if (d_means) { d_means[3 * i] = dl[0]; d_means[3 * i + 1] = dl[1]; d_means[3 * i + 2] = dl[2]; }
+        if (d_rdx) { d_rdx[3 * i] = dl[0]; d_rdx[3 * i + 1] = dl[1]; d_rdx[3 * i + 2] = dl[2]; }
+        if (d_quats) *(float4*)(d_quats + 4 * i) = make_float4(dql[0], dql[1], dql[2], dql[3]);
+        if (d_rdq) *(float4*)(d_rdq + 4 * i) = a_id >= 0 ? make_float4(dql[0], dql[1], dql[2], dql[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d_opac) d_opac[i] = dopl;
+    }
+    if (d_pose) reduce_pose_grad(a_id, pose_g, d_pose);
+}
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_sh_backward(int n, int deg, int M, const float* dirs,
+                                                           const float* coeffs, const float* g_rgb, float* d_coeffs,
+                                                           float* d_dirs) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float d0[3] = {dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
+    float nn = sqrtf((d0[0] * d0[0] + d0[1] * d0[1]) + d0[2] * d0[2]);
+    float d[3] = {d0[0] / nn, d0[1] / nn, d0[2] / nn};
+    const float gc[3] = {g_rgb[3 * i], g_rgb[3 * i + 1], g_rgb[3 * i + 2]};
+    const int K = (deg + 1) * (deg + 1);
+    if (d_coeffs) {
+        float bs[16];
+        sh_basis(deg, d, bs);
+        float* o = d_coeffs + (size_t)i * M * 3;
+        for (int k = 0; k < M; k++) {
+            float bk = k < K ? bs[k] : 0.f;
+            o[3 * k] = bk * gc[0]; o[3 * k + 1] = bk * gc[1]; o[3 * k + 2] = bk * gc[2];
+        }
+    }
+    if (d_dirs) {
+        float gd[3];
+        sh_dir_backward(deg, d, coeffs + (size_t)i * M * 3, gc, gd);
+        float dot = (d[0] * gd[0] + d[1] * gd[1]) + d[2] * gd[2];
+        d_dirs[3 * i] = (gd[0] - d[0] * dot) / nn;
+        d_dirs[3 * i + 1] = (gd[1] - d[1] * dot) / nn;
+        d_dirs[3 * i + 2] = (gd[2] - d[2] * dot) / nn;
+    }
+}
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_export_geometry(int N, const float4* rec, const uint32_t* tt,
+                                                               float* means2D, float* depths, float* conic_opacity,
+                                                               float* rgb, float* normal, uint32_t* tiles_touched) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const bool vis = tt[i] != 0;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 r0 = vis ? rec[(size_t)i * EMD_REC_F4] : z, r1 = vis ? rec[(size_t)i * EMD_REC_F4 + 1] : z,
+                 r2 = vis ? rec[(size_t)i * EMD_REC_F4 + 2] : z;
+    if (means2D) { means2D[2 * i] = r0.x; means2D[2 * i + 1] = r0.y; }
+    if (depths) depths[i] = r0.z;
+    if (conic_opacity) *(float4*)(conic_opacity + 4 * i) = make_float4(r1.x, r1.y, r1.z, r0.w);
+    if (rgb) { rgb[3 * i] = r2.x; rgb[3 * i + 1] = r2.y; rgb[3 * i + 2] = r2.z; }
+    if (normal) { const float4 r3 = vis ? rec[(size_t)i * EMD_REC_F4 + 3] : z; normal[3 * i] = r3.x; normal[3 * i + 1] = r3.y; normal[3 * i + 2] = r3.z; }
+    if (tiles_touched) tiles_touched[i] = tt[i];
+}
+
+}  // namespace
+
+int emd_launch_preprocess(const PreArgs& a, hipStream_t st) {
+    if (a.N <= 0) return EMD_OK;
+    const int nb = (a.N + EMD_BLOCK - 1) / EMD_BLOCK;
+    hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(EMD_BLOCK), 0, st, a);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t st) {
+    if (a.N <= 0) return EMD_OK;
+    const int nb = (a.N + EMD_BLOCK - 1) / EMD_BLOCK;
+    hipLaunchKernelGGL(k_preprocess_backward, dim3(nb), dim3(EMD_BLOCK), 0, st, a);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_motion_forward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
+                              float* wm, float* wq, float* wo, hipStream_t st) {
+    if (n <= 0) return EMD_OK;
+    hipLaunchKernelGGL(k_motion_forward, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, means, quats,
+                       opac, mo, wm, wq, wo);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_sh_forward(int n, int deg, int M, const float* dirs, const float* coeffs, float* rgb, hipStream_t st) {
+    if (n <= 0) return EMD_OK;
+    hipLaunchKernelGGL(k_sh_forward, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, deg, M, dirs,
+                       coeffs, rgb);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_motion_backward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
+                               const float* g_wm, const float* g_wq, const float* g_wo, float* d_means, float* d_quats,
+                               float* d_opac, float* d_pose, float* d_rdx, float* d_rdq, hipStream_t st) {
+    if (n <= 0) return EMD_OK;
+    hipLaunchKernelGGL(k_motion_backward, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, means, quats,
+                       opac, mo, g_wm, g_wq, g_wo, d_means, d_quats, d_opac, d_pose, d_rdx, d_rdq);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_sh_backward(int n, int deg, int M, const float* dirs, const float* coeffs, const float* g_rgb,
+                           float* d_coeffs, float* d_dirs, hipStream_t st) {
+    if (n <= 0) return EMD_OK;
+    hipLaunchKernelGGL(k_sh_backward, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, deg, M, dirs,
+                       coeffs, g_rgb, d_coeffs, d_dirs);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_export_geometry(int N, const GeomWs& g, float* means2D, float* depths, float* conic_opacity, float* rgb,
+                               float* normal, uint32_t* tiles_touched, hipStream_t st) {
+    if (N <= 0) return EMD_OK;
+    hipLaunchKernelGGL(k_export_geometry, dim3((N + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, N, g.rec,
+                       g.tiles_touched, means2D, depths, conic_opacity, rgb, normal, tiles_touched);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}

@@ -1,0 +1,309 @@
+// render.hip -- K6 per-tile front-to-back alpha compositing and K7 its backward.  gfx950.
+// [UPSTREAM K6/K7; call site S3Gaussian/gaussian_renderer/__init__.py:145-155,
+//  outputs consumed at :158-168,299-301 and S3Gaussian/train.py:226-368]
+//
+// Work decomposition (wave64):
+//   - one 256-thread workgroup per 16x16 tile; each of its 4 waves owns an 8x8 pixel quadrant (spatially compact,
+//     so "no lane of this wave is touched by Gaussian j" is common and whole waves skip work on a ballot);
+//   - the tile's depth-sorted list is staged through LDS 256 entries at a time: lane t gathers the 48/64-byte
+//     projected record of entry t (3-4 dwordx4 loads from one half cache line), then every lane walks the staged
+//     chunk with broadcast LDS reads;
+//   - K7 walks the same list back to front.  Per-(pixel, Gaussian) partial derivatives are reduced across the wave
+//     with DPP row shifts/broadcasts (6 v_add_f32_dpp per value, no LDS traffic), lane 63 of each wave adds the
+//     wave sums into an LDS accumulator row for the staged chunk, and after the chunk one lane per entry issues
+//     the global float atomics: at most one atomic row per (Gaussian, tile) instead of one per (Gaussian, pixel).
+#include "common.h"
+#include "device_utils.h"
+
+namespace {
+
+struct RenderDims {
+    int W, H, gx, gy;
+    float bg[3];
+};
+
+__device__ __forceinline__ void tile_pixel(const RenderDims& d, uint32_t tile, uint32_t tid, int& px, int& py) {
+    const uint32_t tx = tile % (uint32_t)d.gx, ty = tile / (uint32_t)d.gx;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    px = (int)(tx * EMD_TILE_X + (wave & 1) * 8 + (lane & 7));
+    py = (int)(ty * EMD_TILE_Y + (wave >> 1) * 8 + (lane >> 3));
+}
+
+// blockIdx -> tile.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one), so runs of
+// XCD_CHUNK horizontally adjacent tiles are handed to the same XCD: neighbouring tiles share most of their
+// Gaussians, which then stay in that XCD's L2.  Fine-grained interleave (not one band per XCD) keeps the load
+// of sky rows and ground rows spread over all XCDs.  Speed only, never correctness; the grid is padded to a
+// multiple of 8 * XCD_CHUNK and surplus workgroups exit.
+#define XCD_CHUNK 4
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b) {
+    const uint32_t xcd = b % 8, k = b / 8;
+    return ((k / XCD_CHUNK) * 8 + xcd) * XCD_CHUNK + (k % XCD_CHUNK);
+}
+static inline unsigned padded_tile_grid(int T) { return (unsigned)((T + 8 * XCD_CHUNK - 1) / (8 * XCD_CHUNK) * (8 * XCD_CHUNK)); }
+
+// Gaussian exponent, evaluated identically (explicit FMAs, no further contraction) in K6 and K7 so that both
+// kernels take the same skip decisions for the same (pixel, Gaussian) pair.
+__device__ __forceinline__ float gauss_power(float A, float B, float C, float dx, float dy) {
+#pragma clang fp contract(off)
+    const float q = __builtin_fmaf(A * dx, dx, (C * dy) * dy);
+    return __builtin_fmaf(-0.5f, q, -((B * dx) * dy));
+}
+
+template <bool NORMAL>
+__global__ void __launch_bounds__(EMD_BLOCK) k_render_forward(RenderDims d, const uint32_t* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ point_list,
+                                                              const float4* __restrict__ rec, float* __restrict__ out_color,
+                                                              float* __restrict__ out_depth, float* __restrict__ out_normal,
+                                                              float* __restrict__ out_alpha, float* __restrict__ final_T,
+                                                              uint32_t* __restrict__ n_contrib) {
+    __shared__ float4 s0[EMD_BLOCK], s1[EMD_BLOCK], s2[EMD_BLOCK];
+    __shared__ float4 s3[NORMAL ? EMD_BLOCK : 1];
+    const uint32_t tile = xcd_tile(blockIdx.x);
+    if (tile >= (uint32_t)(d.gx * d.gy)) return;
+    int px, py;
+    tile_pixel(d, tile, threadIdx.x, px, py);
+    const bool inside = px < d.W && py < d.H;
+    const float pfx = (float)px, pfy = (float)py;
+    const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
+    bool done = !inside;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+    uint32_t contributor = 0, last = 0;
+    for (uint32_t base = start; base < end; base += EMD_BLOCK) {
+        if (__syncthreads_count(done) == EMD_BLOCK) break;
+        const uint32_t idx = base + threadIdx.x;
+        if (idx < end) {
+            const float4* r = rec + (size_t)point_list[idx] * EMD_REC_F4;
+            s0[threadIdx.x] = r[0];
+            s1[threadIdx.x] = r[1];
+            s2[threadIdx.x] = r[2];
+            if (NORMAL) s3[threadIdx.x] = r[3];
+        }
+        __syncthreads();
+        const uint32_t cnt = min((uint32_t)EMD_BLOCK, end - base);
+        if (__ballot(!done) == 0ull) continue;  // whole wave finished: keep feeding the barriers only
+        for (uint32_t j = 0; j < cnt; j++) {
+            contributor++;
+            const float4 g0 = s0[j], g1 = s1[j];
+            const float dx = g0.x - pfx, dy = g0.y - pfy;
+            const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
+            const float alpha = fminf(0.99f, g0.w * __expf(power));
+            const bool hit = !done && power <= 0.f && alpha >= (1.f / 255.f);
+            if (__ballot(hit) == 0ull) continue;
+            if (hit) {
+                const float test_T = T * (1.f - alpha);
+                if (test_T < 0.0001f) {
+                    done = true;
+                } else {
+                    const float w = alpha * T;
+                    const float4 g2 = s2[j];
+                    C0 += g2.x * w; C1 += g2.y * w; C2 += g2.z * w;
+                    Dz += g0.z * w;
+                    if (NORMAL) { const float4 g3 = s3[j]; N0 += g3.x * w; N1 += g3.y * w; N2 += g3.z * w; }
+                    T = test_T;
+                    last = contributor;
+                }
+            }
+        }
+    }
+    if (inside) {
+        const size_t HW = (size_t)d.H * d.W, pix = (size_t)py * d.W + px;
+        out_color[pix] = C0 + T * d.bg[0];
+        out_color[HW + pix] = C1 + T * d.bg[1];
+        out_color[2 * HW + pix] = C2 + T * d.bg[2];
+        out_depth[pix] = Dz;
+        if (NORMAL) { out_normal[pix] = N0; out_normal[HW + pix] = N1; out_normal[2 * HW + pix] = N2; }
+        out_alpha[pix] = 1.f - T;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+    }
+}
+
+// number of reduced values per (Gaussian, tile): mean2D 2, depth 1, opacity 1, conic 3, rgb 3 (+ abs 2);
+// the global accumulator row is EMD_BWD_STRIDE = 12 floats in exactly this order
+#define NV_BASE 10
+
+template <bool NORMAL, bool ABS>
+__global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, const uint32_t* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ point_list,
+                                                               const float4* __restrict__ rec,
+                                                               const float* __restrict__ final_T,
+                                                               const uint32_t* __restrict__ n_contrib,
+                                                               const float* __restrict__ dL_dcolor,
+                                                               const float* __restrict__ dL_ddepth,
+                                                               const float* __restrict__ dL_dalpha,
+                                                               const float* __restrict__ dL_dnormal,
+                                                               float* __restrict__ grad_rec) {
+    constexpr int NV = NV_BASE + (ABS ? 2 : 0);
+    __shared__ float4 s0[EMD_BLOCK], s1[EMD_BLOCK], s2[EMD_BLOCK];
+    __shared__ float4 s3[NORMAL ? EMD_BLOCK : 1];
+    __shared__ uint32_t s_id[EMD_BLOCK];
+    __shared__ float s_acc[EMD_BLOCK][EMD_BWD_STRIDE + 1];  // odd row stride: conflict-free row and column walks
+    __shared__ uint32_t s_max[4];
+    const uint32_t tile = xcd_tile(blockIdx.x);
+    if (tile >= (uint32_t)(d.gx * d.gy)) return;
+    int px, py;
+    tile_pixel(d, tile, threadIdx.x, px, py);
+    const bool inside = px < d.W && py < d.H;
+    const float pfx = (float)px, pfy = (float)py;
+    const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t HW = (size_t)d.H * d.W, pix = (size_t)py * d.W + px;
+    const uint32_t my_n = inside ? n_contrib[pix] : 0u;
+    // longest contributing prefix over the tile: nothing behind it influences any pixel
+    {
+        uint32_t m = my_n;
+        for (int off = 32; off; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+        if (lane == 0) s_max[wave] = m;
+    }
+    __syncthreads();
+    const uint32_t tile_n = min(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), end - start);
+    if (tile_n == 0) return;
+    const float Tf = inside ? final_T[pix] : 0.f;
+    float T = Tf;
+    float dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dA = 0.f, dN0 = 0.f, dN1 = 0.f, dN2 = 0.f;
+    if (inside) {
+        if (dL_dcolor) { dC0 = dL_dcolor[pix]; dC1 = dL_dcolor[HW + pix]; dC2 = dL_dcolor[2 * HW + pix]; }
+        if (dL_ddepth) dD = dL_ddepth[pix];
+        if (dL_dalpha) dA = dL_dalpha[pix];
+        if (NORMAL && dL_dnormal) { dN0 = dL_dnormal[pix]; dN1 = dL_dnormal[HW + pix]; dN2 = dL_dnormal[2 * HW + pix]; }
+    }
+    const float bgdot = d.bg[0] * dC0 + d.bg[1] * dC1 + d.bg[2] * dC2;
+    // colour "behind" the current Gaussian per unit transmittance after it (recursive, back to front)
+    float aC0 = 0.f, aC1 = 0.f, aC2 = 0.f, aD = 0.f, aN0 = 0.f, aN1 = 0.f, aN2 = 0.f;
+    float last_alpha = 0.f, lC0 = 0.f, lC1 = 0.f, lC2 = 0.f, lD = 0.f, lN0 = 0.f, lN1 = 0.f, lN2 = 0.f;
+    for (uint32_t done_cnt = 0; done_cnt < tile_n; done_cnt += EMD_BLOCK) {
+        const uint32_t cnt = min((uint32_t)EMD_BLOCK, tile_n - done_cnt);
+        __syncthreads();  // previous chunk fully consumed (s_acc flushed) before restaging
+        // stage entries tile_n-1-done_cnt ... downwards: LDS slot j holds list position (tile_n - 1 - done_cnt - j)
+        if (threadIdx.x < cnt) {
+            const uint32_t id = point_list[start + (tile_n - 1 - done_cnt - threadIdx.x)];
+            const float4* r = rec + (size_t)id * EMD_REC_F4;
+            s_id[threadIdx.x] = id;
+            s0[threadIdx.x] = r[0];
+            s1[threadIdx.x] = r[1];
+            s2[threadIdx.x] = r[2];
+            if (NORMAL) s3[threadIdx.x] = r[3];
+        }
+#pragma unroll
+        for (int v = 0; v < EMD_BWD_STRIDE; v++) s_acc[threadIdx.x][v] = 0.f;
+        __syncthreads();
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t pos = tile_n - 1 - done_cnt - j;  // position in the tile list (0 = front)
+            const float4 g0 = s0[j], g1 = s1[j];
+            const float dx = g0.x - pfx, dy = g0.y - pfy;
+            const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
+            const float G = __expf(power);
+            const float alpha = fminf(0.99f, g0.w * G);
+            const bool hit = pos < my_n && power <= 0.f && alpha >= (1.f / 255.f);
+            if (__ballot(hit) == 0ull) continue;
+            float v_mx = 0.f, v_my = 0.f, v_dz = 0.f, v_op = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_r = 0.f,
+                  v_g = 0.f, v_b = 0.f;
+            if (hit) {
+                const float4 g2 = s2[j];
+                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                T = T * inv;
+                const float w = alpha * T;
+                float dL_da;
+                aC0 = last_alpha * lC0 + (1.f - last_alpha) * aC0; lC0 = g2.x;
+                aC1 = last_alpha * lC1 + (1.f - last_alpha) * aC1; lC1 = g2.y;
+                aC2 = last_alpha * lC2 + (1.f - last_alpha) * aC2; lC2 = g2.z;
+                aD = last_alpha * lD + (1.f - last_alpha) * aD; lD = g0.z;
+                dL_da = (g2.x - aC0) * dC0 + (g2.y - aC1) * dC1 + (g2.z - aC2) * dC2 + (g0.z - aD) * dD;
+                if (NORMAL) {
+                    const float4 g3 = s3[j];
+                    aN0 = last_alpha * lN0 + (1.f - last_alpha) * aN0; lN0 = g3.x;
+                    aN1 = last_alpha * lN1 + (1.f - last_alpha) * aN1; lN1 = g3.y;
+                    aN2 = last_alpha * lN2 + (1.f - last_alpha) * aN2; lN2 = g3.z;
+                    dL_da += (g3.x - aN0) * dN0 + (g3.y - aN1) * dN1 + (g3.z - aN2) * dN2;
+                }
+                dL_da *= T;
+                last_alpha = alpha;
+                dL_da += (Tf * inv) * (dA - bgdot);
+                const float dL_dG = g0.w * dL_da;
+                const float gdx = G * dx, gdy = G * dy;
+                v_mx = dL_dG * (-gdx * g1.x - gdy * g1.y);
+                v_my = dL_dG * (-gdy * g1.z - gdx * g1.y);
+                v_ca = -0.5f * gdx * dx * dL_dG;
+                v_cb = -gdx * dy * dL_dG;
+                v_cc = -0.5f * gdy * dy * dL_dG;
+                v_op = G * dL_da;
+                v_dz = w * dD;
+                v_r = w * dC0; v_g = w * dC1; v_b = w * dC2;
+            }
+            float r[NV];
+            r[0] = wave_reduce_to_lane63(v_mx);
+            r[1] = wave_reduce_to_lane63(v_my);
+            r[2] = wave_reduce_to_lane63(v_dz);
+            r[3] = wave_reduce_to_lane63(v_op);
+            r[4] = wave_reduce_to_lane63(v_ca);
+            r[5] = wave_reduce_to_lane63(v_cb);
+            r[6] = wave_reduce_to_lane63(v_cc);
+            r[7] = wave_reduce_to_lane63(v_r);
+            r[8] = wave_reduce_to_lane63(v_g);
+            r[9] = wave_reduce_to_lane63(v_b);
+            if (ABS) {
+                r[10] = wave_reduce_to_lane63(fabsf(v_mx));
+                r[11] = wave_reduce_to_lane63(fabsf(v_my));
+            }
+            if (lane == 63) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) atomicAdd(&s_acc[j][v], r[v]);
+            }
+        }
+        __syncthreads();
+        // flush: consecutive lanes add consecutive floats of one accumulator row (48-byte contiguous segments per
+        // Gaussian) -- the shape global float atomics like -- instead of one lane per scattered row.
+        for (uint32_t idx = threadIdx.x; idx < cnt * EMD_BWD_STRIDE; idx += EMD_BLOCK) {
+            const uint32_t e = idx / EMD_BWD_STRIDE, v = idx % EMD_BWD_STRIDE;
+            const float val = s_acc[e][v];
+            if (val != 0.f) atomicAdd(grad_rec + (size_t)s_id[e] * EMD_BWD_STRIDE + v, val);
+        }
+    }
+}
+
+RenderDims make_dims(const EmdSettings& s) {
+    RenderDims d;
+    d.W = s.image_width; d.H = s.image_height;
+    d.gx = (d.W + EMD_TILE_X - 1) / EMD_TILE_X; d.gy = (d.H + EMD_TILE_Y - 1) / EMD_TILE_Y;
+    d.bg[0] = s.bg[0]; d.bg[1] = s.bg[1]; d.bg[2] = s.bg[2];
+    return d;
+}
+
+}  // namespace
+
+int emd_launch_render_forward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
+                              float* out_color, float* out_depth, float* out_normal, float* out_alpha,
+                              hipStream_t st) {
+    const RenderDims d = make_dims(s);
+    const int T = d.gx * d.gy;
+    if (T <= 0) return EMD_OK;
+    const uint32_t* pl = b.vals[b.sorted_buf];
+    if (flags & EMD_FLAG_NORMAL)
+        hipLaunchKernelGGL(k_render_forward<true>, dim3(padded_tile_grid(T)), dim3(EMD_BLOCK), 0, st, d, b.ranges, pl, g.rec, out_color,
+                           out_depth, out_normal, out_alpha, im.final_T, im.n_contrib);
+    else
+        hipLaunchKernelGGL(k_render_forward<false>, dim3(padded_tile_grid(T)), dim3(EMD_BLOCK), 0, st, d, b.ranges, pl, g.rec, out_color,
+                           out_depth, out_normal, out_alpha, im.final_T, im.n_contrib);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_render_backward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
+                               const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                               const float* dL_dnormal, float* grad_rec, hipStream_t st) {
+    const RenderDims d = make_dims(s);
+    const int T = d.gx * d.gy;
+    if (T <= 0) return EMD_OK;
+    const uint32_t* pl = b.vals[b.sorted_buf];
+    const bool nrm = (flags & EMD_FLAG_NORMAL) && dL_dnormal, ab = flags & EMD_FLAG_ABSGRAD;
+#define LAUNCH_BWD(N_, A_)                                                                                          \
+    hipLaunchKernelGGL((k_render_backward<N_, A_>), dim3(padded_tile_grid(T)), dim3(EMD_BLOCK), 0, st, d, b.ranges, pl, g.rec,        \
+                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dL_dnormal, grad_rec)
+    if (nrm && ab) LAUNCH_BWD(true, true);
+    else if (nrm) LAUNCH_BWD(true, false);
+    else if (ab) LAUNCH_BWD(false, true);
+    else LAUNCH_BWD(false, false);
+#undef LAUNCH_BWD
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}

@@ -1,0 +1,328 @@
+"""`GaussianRasterizationSettings` / `GaussianRasterizer` -- the reference's operator surface for the hot path.
+
+Drop-in for `from diff_gauss import GaussianRasterizationSettings, GaussianRasterizer`
+(S3Gaussian/gaussian_renderer/__init__.py:14): same 12 settings fields (:49-62), same keyword call
+(:145-155), same 6-tuple result `(rendered_image[3,H,W], depth[1,H,W], normal[3,H,W], alpha[1,H,W],
+radii[N] int32, extra)`, gradients returned for means3D, means2D (grad sink, NDC-scaled pixel units as
+consumed at scene/gaussian_model.py:728-730), shs / colors_precomp, opacities, scales, rotations, cov3Ds_precomp.
+
+Extension (EMD explicit motion fused into the projection kernel): the optional keywords
+`actor_ids[N] int32, actor_pose[A,12], residual_dx[N,3], residual_dq[N,4]` make the kernel apply
+OmniRe/models/nodes/rigid.py:478-568 (+ deformable.py:57-69) per Gaussian before projecting, and return
+gradients for `actor_pose` and the residuals.
+
+All compute happens in libemd_raster.so (hand-written HIP for gfx950) through the C ABI of
+include/emd_raster.h.  There is no CPU or eager fallback; a missing extension raises.
+"""
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class RasterConfig:
+    """Process-wide knobs of the binding (not part of the reference surface)."""
+    compute_normal = True     # composite the normal image (reference returns it; only used for visualisation)
+    near_plane = 0.2          # view-space z cull of the diff_gauss surface
+    no_sync = False           # True: never read the duplicate count back (overflow only visible via last_status())
+    capacity_margin = 1.25    # head-room applied to the last observed duplicate count
+    min_capacity = 1 << 16
+    absgrad = False           # also accumulate sum |d/d mean2D| (read from GaussianRasterizer.last_absgrad)
+    clamp_rgb01 = False       # OmniRe colour clamp
+
+
+_capacity_hint = {}
+_host_cache = {}
+
+
+def _host_floats(t, n):
+    """Settings tensors -> python floats.  GPU tensors cost one sync the first time a camera is seen."""
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t, dtype=torch.float32)
+    if t.device.type == "cpu":
+        v = t.detach().reshape(-1).to(torch.float32).tolist()
+    else:
+        key = (t.data_ptr(), t._version, n)
+        v = _host_cache.get(key)
+        if v is None:
+            if len(_host_cache) > 4096:
+                _host_cache.clear()
+            v = t.detach().reshape(-1).to(torch.float32).cpu().tolist()
+            _host_cache[key] = v
+    if len(v) != n:
+        raise ValueError(f"expected {n} values, got {len(v)}")
+    return v
+
+
+def make_c_settings(rs: GaussianRasterizationSettings, near_plane=None) -> L.EmdSettings:
+    s = L.EmdSettings()
+    s.image_height, s.image_width = int(rs.image_height), int(rs.image_width)
+    s.tanfovx, s.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
+    s.bg[:] = _host_floats(rs.bg, 3)
+    s.scale_modifier = float(rs.scale_modifier)
+    s.viewmatrix[:] = _host_floats(rs.viewmatrix, 16)
+    s.projmatrix[:] = _host_floats(rs.projmatrix, 16)
+    s.sh_degree = int(rs.sh_degree)
+    s.campos[:] = _host_floats(rs.campos, 3)
+    s.prefiltered = int(bool(rs.prefiltered))
+    s.debug = int(bool(rs.debug))
+    s.near_plane = float(RasterConfig.near_plane if near_plane is None else near_plane)
+    return s
+
+
+def _f32c(t, name, shape_tail=None):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected [N, {', '.join(map(str, shape_tail))}]")
+    return t.contiguous()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _fill_motion(m: L.EmdMotion, actor_ids, actor_pose, residual_dx, residual_dq):
+    m.actor_id = L.ptr(actor_ids)
+    m.actor_pose = L.ptr(actor_pose)
+    m.num_actors = 0 if actor_pose is None else int(actor_pose.shape[0])
+    m.residual_dx = L.ptr(residual_dx)
+    m.residual_dq = L.ptr(residual_dq)
+
+
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose,
+                residual_dx, residual_dq, actor_ids, raster_settings, flags, near_plane):
+        lib = L.load()
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise L.EmdError("GaussianRasterizer needs tensors on a ROCm device (cuda:N); there is no CPU path")
+        N = means3D.shape[0]
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+        cs = make_c_settings(raster_settings, near_plane)
+        M = 0 if shs is None else int(shs.shape[1])
+
+        out_color = torch.empty(3, H, W, device=dev, dtype=torch.float32)
+        out_depth = torch.empty(1, H, W, device=dev, dtype=torch.float32)
+        out_alpha = torch.empty(1, H, W, device=dev, dtype=torch.float32)
+        out_normal = torch.empty(3, H, W, device=dev, dtype=torch.float32) if flags & L.FLAG_NORMAL else \
+            torch.zeros(3, H, W, device=dev, dtype=torch.float32)
+        radii = torch.empty(N, device=dev, dtype=torch.int32)
+        status = torch.empty(4, device=dev, dtype=torch.int32)
+
+        key = (dev.index, H, W)
+        capacity = max(int(_capacity_hint.get(key, 0)), RasterConfig.min_capacity, 4 * N if key not in _capacity_hint else 0)
+        a = L.EmdFwdArgs()
+        while True:
+            gb, bb, ib, _ = L.workspace_sizes(N, H, W, capacity, flags)
+            geom_ws = torch.empty(gb, device=dev, dtype=torch.uint8)
+            bin_ws = torch.empty(bb, device=dev, dtype=torch.uint8)
+            img_ws = torch.empty(ib, device=dev, dtype=torch.uint8)
+            a.s = cs
+            a.num_gaussians, a.sh_coeffs, a.flags, a.bin_capacity = N, M, flags, capacity
+            a.means3D, a.shs, a.colors_precomp = L.ptr(means3D), L.ptr(shs), L.ptr(colors_precomp)
+            a.opacities, a.scales, a.rotations = L.ptr(opacities), L.ptr(scales), L.ptr(rotations)
+            a.cov3D_precomp = L.ptr(cov3Ds_precomp)
+            _fill_motion(a.motion, actor_ids, actor_pose, residual_dx, residual_dq)
+            a.out_color, a.out_depth, a.out_alpha = out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr()
+            a.out_normal = out_normal.data_ptr()
+            a.radii = radii.data_ptr()
+            a.geom_ws, a.geom_bytes = geom_ws.data_ptr(), gb
+            a.bin_ws, a.bin_bytes = bin_ws.data_ptr(), bb
+            a.img_ws, a.img_bytes = img_ws.data_ptr(), ib
+            a.status = status.data_ptr()
+            rc = lib.emd_raster_forward(C.byref(a), _stream())
+            if rc == L.EMD_ERR_CAPACITY:
+                capacity = int(a.num_rendered * RasterConfig.capacity_margin) + 1024
+                continue
+            L.check(rc, "emd_raster_forward")
+            break
+        if a.num_rendered >= 0:
+            _capacity_hint[key] = max(int(a.num_rendered * RasterConfig.capacity_margin) + 1024, RasterConfig.min_capacity)
+        else:
+            _capacity_hint[key] = capacity
+
+        ctx.cs, ctx.flags, ctx.capacity, ctx.N, ctx.M = cs, flags, capacity, N, M
+        ctx.num_rendered = int(a.num_rendered)
+        ctx.sizes = (gb, bb, ib)
+        ctx.has = (shs is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None,
+                   actor_pose is not None, residual_dx is not None, residual_dq is not None)
+        ctx.save_for_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose,
+                              residual_dx, residual_dq, actor_ids, radii, geom_ws, bin_ws, img_ws, status)
+        ctx.mark_non_differentiable(radii)
+        GaussianRasterizer._last = dict(status=status, num_rendered=int(a.num_rendered), num_visible=int(a.num_visible),
+                                        geom_ws=geom_ws, bin_ws=bin_ws, img_ws=img_ws, sizes=(gb, bb, ib),
+                                        capacity=capacity, N=N, H=H, W=W, flags=flags)
+        return out_color, out_depth, out_normal, out_alpha, radii
+
+    @staticmethod
+    def backward(ctx, g_color, g_depth, g_normal, g_alpha, _g_radii):
+        lib = L.load()
+        (means3D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose, residual_dx,
+         residual_dq, actor_ids, radii, geom_ws, bin_ws, img_ws, status) = ctx.saved_tensors
+        dev = means3D.device
+        N, M, flags = ctx.N, ctx.M, ctx.flags
+        has_shs, has_col, has_sr, has_cov, has_pose, has_rdx, has_rdq = ctx.has
+        z = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        g_color = None if g_color is None else g_color.contiguous().float()
+        g_depth = None if g_depth is None else g_depth.contiguous().float()
+        g_alpha = None if g_alpha is None else g_alpha.contiguous().float()
+        g_normal = None if (g_normal is None or not (flags & L.FLAG_NORMAL)) else g_normal.contiguous().float()
+        d_means3D, d_means2D = z(N, 3), z(N, 3)
+        d_shs = z(N, M, 3) if has_shs else None
+        d_col = z(N, 3) if has_col else None
+        d_op = z(*opacities.shape)
+        d_sc = z(N, 3) if has_sr else None
+        d_rot = z(N, 4) if has_sr else None
+        d_cov = z(N, 6) if has_cov else None
+        d_pose = z(*actor_pose.shape) if has_pose else None
+        d_rdx = z(N, 3) if has_rdx else None
+        d_rdq = z(N, 4) if has_rdq else None
+        d_abs = z(N, 2) if flags & L.FLAG_ABSGRAD else None
+        bwd_ws = torch.empty(max(N, 1) * L.BWD_STRIDE, device=dev, dtype=torch.float32)
+
+        b = L.EmdBwdArgs()
+        b.s = ctx.cs
+        b.num_gaussians, b.sh_coeffs, b.flags, b.bin_capacity, b.num_rendered = N, M, flags, ctx.capacity, ctx.num_rendered
+        b.means3D, b.shs, b.colors_precomp = L.ptr(means3D), L.ptr(shs), L.ptr(colors_precomp)
+        b.opacities, b.scales, b.rotations, b.cov3D_precomp = L.ptr(opacities), L.ptr(scales), L.ptr(rotations), L.ptr(cov3Ds_precomp)
+        _fill_motion(b.motion, actor_ids, actor_pose, residual_dx, residual_dq)
+        b.radii = radii.data_ptr()
+        b.geom_ws, b.geom_bytes = geom_ws.data_ptr(), ctx.sizes[0]
+        b.bin_ws, b.bin_bytes = bin_ws.data_ptr(), ctx.sizes[1]
+        b.img_ws, b.img_bytes = img_ws.data_ptr(), ctx.sizes[2]
+        b.status = status.data_ptr()
+        b.dL_dcolor, b.dL_ddepth, b.dL_dalpha, b.dL_dnormal = L.ptr(g_color), L.ptr(g_depth), L.ptr(g_alpha), L.ptr(g_normal)
+        b.bwd_ws, b.bwd_bytes = bwd_ws.data_ptr(), bwd_ws.numel() * 4
+        b.dL_dmeans3D, b.dL_dmeans2D, b.dL_dmeans2D_abs = d_means3D.data_ptr(), d_means2D.data_ptr(), L.ptr(d_abs)
+        b.dL_dshs, b.dL_dcolors, b.dL_dopacities = L.ptr(d_shs), L.ptr(d_col), d_op.data_ptr()
+        b.dL_dscales, b.dL_drotations, b.dL_dcov3D = L.ptr(d_sc), L.ptr(d_rot), L.ptr(d_cov)
+        b.dL_dactor_pose, b.dL_dresidual_dx, b.dL_dresidual_dq = L.ptr(d_pose), L.ptr(d_rdx), L.ptr(d_rdq)
+        L.check(lib.emd_raster_backward(C.byref(b), _stream()), "emd_raster_backward")
+        if d_abs is not None:
+            GaussianRasterizer.last_absgrad = d_abs
+        return (d_means3D, d_means2D, d_shs, d_col, d_op, d_sc, d_rot, d_cov, d_pose, d_rdx, d_rdq, None, None, None, None)
+
+
+class GaussianRasterizer(nn.Module):
+    _last = None
+    last_absgrad = None
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Frustum test of the diff_gauss surface: view-space z > near plane."""
+        with torch.no_grad():
+            V = torch.as_tensor(self.raster_settings.viewmatrix, dtype=torch.float32, device=positions.device)
+            z = positions @ V[:3, 2] + V[3, 2]
+            return z > RasterConfig.near_plane
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3Ds_precomp=None, extra_attrs=None, actor_ids: Optional[torch.Tensor] = None,
+                actor_pose: Optional[torch.Tensor] = None, residual_dx: Optional[torch.Tensor] = None,
+                residual_dq: Optional[torch.Tensor] = None):
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3Ds_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3Ds_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if extra_attrs is not None:
+            raise NotImplementedError("extra_attrs: the reference always passes None "
+                                      "(S3Gaussian/gaussian_renderer/__init__.py:154); render them with colors_precomp")
+        N = means3D.shape[0]
+        means3D = _f32c(means3D, "means3D", (3,))
+        shs = _f32c(shs, "shs")
+        if shs is not None and (shs.dim() != 3 or shs.shape[2] != 3):
+            raise ValueError(f"shs must be [N, K, 3], got {tuple(shs.shape)}")
+        colors_precomp = _f32c(colors_precomp, "colors_precomp", (3,))
+        opacities = _f32c(opacities, "opacities")
+        if opacities.numel() != N:
+            raise ValueError(f"opacities must hold N={N} values, got {tuple(opacities.shape)}")
+        scales = _f32c(scales, "scales", (3,))
+        rotations = _f32c(rotations, "rotations", (4,))
+        cov3Ds_precomp = _f32c(cov3Ds_precomp, "cov3Ds_precomp", (6,))
+        flags = 0
+        if RasterConfig.compute_normal:
+            flags |= L.FLAG_NORMAL
+        if RasterConfig.no_sync:
+            flags |= L.FLAG_NO_SYNC
+        if RasterConfig.absgrad:
+            flags |= L.FLAG_ABSGRAD
+        if RasterConfig.clamp_rgb01:
+            flags |= L.FLAG_CLAMP_RGB01
+        if actor_ids is not None or residual_dx is not None or residual_dq is not None:
+            flags |= L.FLAG_MOTION
+            if actor_ids is not None:
+                if actor_pose is None or actor_pose.dim() != 2 or actor_pose.shape[1] != L.ACTOR_STRIDE:
+                    raise ValueError("actor_pose must be [A, 12] = (q_mean[4], trans[3], valid, q_rot[4])")
+                actor_ids = actor_ids.to(torch.int32).contiguous()
+                actor_pose = _f32c(actor_pose, "actor_pose")
+            residual_dx = _f32c(residual_dx, "residual_dx", (3,))
+            residual_dq = _f32c(residual_dq, "residual_dq", (4,))
+        color, depth, normal, alpha, radii = _Rasterize.apply(
+            means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose, residual_dx,
+            residual_dq, actor_ids, rs, flags, None)
+        return color, depth, normal, alpha, radii, None
+
+    # ---- introspection used by tests / bench (not part of the reference surface) --------------------------------
+    @classmethod
+    def last_status(cls):
+        """(num_rendered D, overflow, num_visible V) of the most recent forward; synchronises."""
+        st = cls._last["status"].cpu().tolist()
+        return dict(num_rendered=st[0] & 0xFFFFFFFF, overflow=st[1], num_visible=st[2] & 0xFFFFFFFF)
+
+    @classmethod
+    def export_binning(cls):
+        """Sorted keys (uint64 as int64 bit pattern), Gaussian ids and tile ranges of the most recent forward."""
+        lib = L.load()
+        last = cls._last
+        D = cls.last_status()["num_rendered"]
+        dev = last["status"].device
+        T = ((last["W"] + 15) // 16) * ((last["H"] + 15) // 16)
+        keys = torch.empty(max(D, 1), device=dev, dtype=torch.int64)
+        ids = torch.empty(max(D, 1), device=dev, dtype=torch.int32)
+        ranges = torch.empty(T, 2, device=dev, dtype=torch.int32)
+        d = L.EmdDims(last["N"], last["H"], last["W"], last["capacity"], last["flags"])
+        L.check(lib.emd_raster_export_binning(C.byref(d), last["bin_ws"].data_ptr(), last["sizes"][1], D, keys.data_ptr(),
+                                              ids.data_ptr(), ranges.data_ptr(), _stream()), "emd_raster_export_binning")
+        return keys[:D], ids[:D], ranges
+
+    @classmethod
+    def export_geometry(cls):
+        lib = L.load()
+        last = cls._last
+        dev, N = last["status"].device, last["N"]
+        e = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)
+        out = dict(means2D=e(N, 2), depths=e(N), conic_opacity=e(N, 4), rgb=e(N, 3),
+                   normal=e(N, 3) if last["flags"] & L.FLAG_NORMAL else None, tiles_touched=e(N, dt=torch.int32))
+        d = L.EmdDims(N, last["H"], last["W"], last["capacity"], last["flags"])
+        L.check(lib.emd_raster_export_geometry(C.byref(d), last["geom_ws"].data_ptr(), last["sizes"][0],
+                                               out["means2D"].data_ptr(), out["depths"].data_ptr(),
+                                               out["conic_opacity"].data_ptr(), out["rgb"].data_ptr(),
+                                               L.ptr(out["normal"]), out["tiles_touched"].data_ptr(), _stream()),
+                "emd_raster_export_geometry")
+        return out

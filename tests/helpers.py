@@ -1,0 +1,219 @@
+"""Shared test plumbing: seeded cases, the HIP path (through the C ABI), the CPU oracle, and the comparisons.
+
+The oracle is the checker only; the product path under test is emd_amd.GaussianRasterizer -> libemd_raster.so.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from emd_amd import scenes  # noqa: E402
+from oracle import cpu_oracle as co  # noqa: E402
+
+IMAGE_TOL = 1e-4   # north_star: rendered-image L_inf <= 1e-4 vs reference
+GRAD_RTOL = 2e-3   # gradients: |hip - oracle| <= GRAD_RTOL * max|oracle| (float atomics reorder sums)
+
+
+def make_case(n=2000, H=64, W=96, seed=0, sh_degree=3, colors_precomp=False, cov_precomp=False, motion=False,
+              residual=False, bg=(0.1, 0.2, 0.3), scale_mult=3.0, actors=3, yaw=0.0):
+    """A street-like scene squeezed into the frustum of a small camera so that most Gaussians are visible."""
+    sc = scenes.make_static_scene(n, seed=seed)
+    cam = scenes.small_camera(H, W, yaw=yaw)
+    means = sc.means.clone()
+    means[:, 0] = means[:, 0] * 0.25 + 1.0
+    means[:, 1] *= 0.3
+    means[:, 2] = means[:, 2] * 0.3 + 1.0
+    # a few Gaussians behind / very near the camera and far outside the frustum exercise the cull paths
+    k = max(n // 50, 1)
+    means[:k, 0] = -means[:k, 0]
+    means[k:2 * k, 0] = 0.15
+    means[2 * k:3 * k, 1] += 40.0
+    g = torch.Generator().manual_seed(seed + 1000)
+    case = dict(N=n, H=H, W=W, sh_degree=sh_degree, bg=torch.tensor(bg, dtype=torch.float32), cam=cam,
+                means3D=means, opacities=torch.sigmoid(sc.opacity_logits),
+                scales=torch.exp(sc.log_scales) * scale_mult, rotations=sc.quats.clone(), shs=sc.shs.clone(),
+                colors_precomp=None, cov3D_precomp=None, actor_ids=None, actor_pose=None, residual_dx=None,
+                residual_dq=None, flags=co.F_NORMAL)
+    if colors_precomp:
+        case["colors_precomp"] = torch.rand(n, 3, generator=g)
+        case["shs"] = None
+    if cov_precomp:
+        cov = co.cov3d(case["scales"].numpy(), 1.0, case["rotations"].numpy())
+        case["cov3D_precomp"] = torch.from_numpy(cov)
+        case["scales"] = None
+        case["rotations"] = None
+    if motion:
+        A = actors
+        ids = torch.full((n,), -1, dtype=torch.int32)
+        n_dyn = n // 2
+        ids[:n_dyn] = (torch.arange(n_dyn) * A // n_dyn).to(torch.int32)
+        # actor points live in a local box; the pose puts them in front of the camera
+        local = (torch.rand(n_dyn, 3, generator=g) - 0.5) * torch.tensor([4.5, 2.0, 1.6])
+        means[:n_dyn] = local
+        yaws = torch.rand(A, generator=g) * 2 * math.pi
+        qm = torch.stack([torch.cos(yaws / 2), torch.zeros(A), torch.zeros(A), torch.sin(yaws / 2)], 1)
+        dq = torch.randn(A, 4, generator=g) * 0.05 + torch.tensor([1.0, 0, 0, 0])
+        qr = torch.from_numpy(_quat_mul_np(qm.numpy(), (dq / dq.norm(dim=1, keepdim=True)).numpy()))
+        qr = qr / qr.norm(dim=1, keepdim=True)
+        trans = torch.stack([torch.rand(A, generator=g) * 20 + 6, torch.rand(A, generator=g) * 8 - 4,
+                             torch.full((A,), 1.2)], 1)
+        valid = torch.ones(A, 1)
+        valid[-1] = 0.0 if A > 2 else 1.0   # one invisible actor (instances_fv False, rigid.py:42-46)
+        case["actor_pose"] = torch.cat([qm, trans, valid, qr], 1).float().contiguous()
+        case["actor_ids"] = ids
+        case["means3D"] = means
+        # local quaternions are raw (un-normalised) for actor points, like RigidNodes._quats
+        rot = case["rotations"].clone()
+        rot[:n_dyn] = rot[:n_dyn] * (0.5 + torch.rand(n_dyn, 1, generator=g))
+        case["rotations"] = rot
+        case["flags"] |= co.F_MOTION
+    if residual:
+        case["residual_dx"] = 0.02 * torch.randn(n, 3, generator=g)
+        if motion:
+            case["residual_dq"] = 0.02 * torch.randn(n, 4, generator=g)
+        case["flags"] |= co.F_MOTION
+    gg = np.random.default_rng(seed + 5)
+    case["dL_dcolor"] = gg.standard_normal((3, H, W)).astype(np.float32)
+    case["dL_ddepth"] = (0.1 * gg.standard_normal((1, H, W))).astype(np.float32)
+    case["dL_dalpha"] = gg.standard_normal((1, H, W)).astype(np.float32)
+    return case
+
+
+def _quat_mul_np(a, b):
+    w1, x1, y1, z1 = a.T
+    w2, x2, y2, z2 = b.T
+    return np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], 1).astype(np.float32)
+
+
+def oracle_settings(case, near_plane=0.2):
+    cam = case["cam"]
+    return co.make_settings(case["H"], case["W"], cam.tanfovx, cam.tanfovy, case["bg"].numpy(),
+                            cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), case["sh_degree"],
+                            cam.camera_center.numpy(), 1.0, near_plane)
+
+
+def oracle_scene(case):
+    n = lambda t: None if t is None else t.numpy()
+    return co.Scene(n(case["means3D"]), n(case["opacities"]), shs=n(case["shs"]), colors_precomp=n(case["colors_precomp"]),
+                    scales=n(case["scales"]), rotations=n(case["rotations"]), cov3D_precomp=n(case["cov3D_precomp"]),
+                    actor_id=n(case["actor_ids"]), actor_pose=n(case["actor_pose"]), residual_dx=n(case["residual_dx"]),
+                    residual_dq=n(case["residual_dq"]))
+
+
+def run_oracle(case, backward=False):
+    S = oracle_settings(case)
+    sc = oracle_scene(case)
+    pre, b, img = co.forward(S, sc, case["flags"])
+    out = dict(pre=pre, bin=b, img=img, S=S, scene=sc)
+    if backward:
+        out["grads"] = co.backward(S, sc, pre, b, img, case["dL_dcolor"], case["dL_ddepth"], case["dL_dalpha"], None,
+                                   case["flags"])
+    return out
+
+
+def run_hip(case, backward=False, device="cuda:0", absgrad=False):
+    """The product path: emd_amd.GaussianRasterizer -> C ABI -> HIP kernels."""
+    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer, RasterConfig
+    cam = case["cam"]
+    dev = torch.device(device)
+    d = lambda t, rg=backward: None if t is None else t.to(dev).clone().requires_grad_(rg and t.is_floating_point())
+    rs = GaussianRasterizationSettings(image_height=case["H"], image_width=case["W"], tanfovx=cam.tanfovx,
+                                       tanfovy=cam.tanfovy, bg=case["bg"].to(dev), scale_modifier=1.0,
+                                       viewmatrix=cam.world_view_transform.to(dev),
+                                       projmatrix=cam.full_proj_transform.to(dev), sh_degree=case["sh_degree"],
+                                       campos=cam.camera_center.to(dev), prefiltered=False, debug=True)
+    T = dict(means3D=d(case["means3D"]), shs=d(case["shs"]), colors_precomp=d(case["colors_precomp"]),
+             opacities=d(case["opacities"]), scales=d(case["scales"]), rotations=d(case["rotations"]),
+             cov3Ds_precomp=d(case["cov3D_precomp"]), actor_pose=d(case["actor_pose"]),
+             residual_dx=d(case["residual_dx"]), residual_dq=d(case["residual_dq"]))
+    means2D = torch.zeros(case["N"], 3, device=dev, requires_grad=backward)
+    RasterConfig.absgrad = absgrad
+    RasterConfig.compute_normal = True
+    rast = GaussianRasterizer(rs)
+    kw = {}
+    if case["flags"] & co.F_MOTION:
+        kw = dict(actor_ids=None if case["actor_ids"] is None else case["actor_ids"].to(dev), actor_pose=T["actor_pose"],
+                  residual_dx=T["residual_dx"], residual_dq=T["residual_dq"])
+    color, depth, normal, alpha, radii, _ = rast(means3D=T["means3D"], means2D=means2D, shs=T["shs"],
+                                                 colors_precomp=T["colors_precomp"], opacities=T["opacities"],
+                                                 scales=T["scales"], rotations=T["rotations"],
+                                                 cov3Ds_precomp=T["cov3Ds_precomp"], extra_attrs=None, **kw)
+    out = dict(color=color.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(),
+               normal=normal.detach().cpu().numpy(), alpha=alpha.detach().cpu().numpy(), radii=radii.cpu().numpy())
+    keys, ids, ranges = GaussianRasterizer.export_binning()
+    out["keys"] = keys.cpu().numpy().view(np.uint64)
+    out["ids"] = ids.cpu().numpy().view(np.uint32)
+    out["ranges"] = ranges.cpu().numpy().view(np.uint32)
+    out["status"] = GaussianRasterizer.last_status()
+    geo = GaussianRasterizer.export_geometry()
+    out["geo"] = {k: (None if v is None else v.cpu().numpy()) for k, v in geo.items()}
+    if backward:
+        tc = lambda a: torch.from_numpy(a).to(dev)
+        loss = (color * tc(case["dL_dcolor"])).sum() + (depth * tc(case["dL_ddepth"])).sum() + \
+               (alpha * tc(case["dL_dalpha"])).sum()
+        loss.backward()
+        g = lambda t: None if t is None or t.grad is None else t.grad.detach().cpu().numpy()
+        out["grads"] = dict(means3D=g(T["means3D"]), means2D=g(means2D), shs=g(T["shs"]), colors=g(T["colors_precomp"]),
+                            opacities=g(T["opacities"]), scales=g(T["scales"]), rotations=g(T["rotations"]),
+                            cov3D=g(T["cov3Ds_precomp"]), actor_pose=g(T["actor_pose"]), residual_dx=g(T["residual_dx"]),
+                            residual_dq=g(T["residual_dq"]))
+        if absgrad:
+            out["grads"]["means2D_abs"] = GaussianRasterizer.last_absgrad.cpu().numpy()
+    RasterConfig.absgrad = False
+    return out
+
+
+def compare_forward(hip, orc, tol=IMAGE_TOL):
+    pre, b, img = orc["pre"], orc["bin"], orc["img"]
+    # integer / key contract: bit-exact
+    np.testing.assert_array_equal(hip["radii"], pre["radii"], err_msg="radii")
+    np.testing.assert_array_equal(hip["geo"]["tiles_touched"].view(np.uint32), pre["tiles_touched"], err_msg="tiles_touched")
+    assert hip["status"]["num_rendered"] == b["D"], (hip["status"], b["D"])
+    assert hip["status"]["num_visible"] == int((pre["radii"] > 0).sum())
+    np.testing.assert_array_equal(hip["keys"], b["keys"], err_msg="sorted keys (tile<<32 | depth bits)")
+    np.testing.assert_array_equal(hip["ids"], b["ids"], err_msg="sorted Gaussian ids")
+    np.testing.assert_array_equal(hip["ranges"], b["ranges"], err_msg="tile ranges")
+    vis = pre["radii"] > 0
+    # pixel means and depths feed the keys / rects: bit-exact; conic, colour: tolerance
+    np.testing.assert_array_equal(hip["geo"]["means2D"][vis].view(np.uint32), pre["means2D"][vis].view(np.uint32))
+    np.testing.assert_array_equal(hip["geo"]["depths"][vis].view(np.uint32), pre["depths"][vis].view(np.uint32))
+    np.testing.assert_allclose(hip["geo"]["conic_opacity"][vis], pre["conic_opacity"][vis], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(hip["geo"]["rgb"][vis], pre["rgb"][vis], rtol=0, atol=2e-6)
+    if hip["geo"]["normal"] is not None:
+        np.testing.assert_allclose(hip["geo"]["normal"][vis], pre["normal"][vis], rtol=0, atol=2e-6)
+    for k in ("color", "depth", "alpha", "normal"):
+        scale = max(1.0, float(np.abs(img[k]).max())) if k == "depth" else 1.0
+        err = float(np.abs(hip[k] - img[k]).max())
+        assert err <= tol * scale, f"{k}: L_inf {err:.3e} > {tol * scale:.1e}"
+
+
+def grad_err(a, b):
+    a = np.asarray(a, np.float64).reshape(-1)
+    b = np.asarray(b, np.float64).reshape(-1)
+    ref = max(float(np.abs(b).max()), 1e-12)
+    return float(np.abs(a - b).max()) / ref
+
+
+def compare_backward(hip, orc, rtol=GRAD_RTOL, names=None):
+    gh, go = hip["grads"], orc["grads"]
+    checked = []
+    for k in names or ("means3D", "means2D", "shs", "colors", "opacities", "scales", "rotations", "cov3D", "actor_pose",
+                       "residual_dx", "residual_dq", "means2D_abs"):
+        if gh.get(k) is None:
+            continue
+        ref = go[k]
+        got = gh[k].reshape(ref.shape) if gh[k].size == ref.size else gh[k]
+        if float(np.abs(ref).max()) == 0.0:
+            assert float(np.abs(got).max()) <= 1e-6, f"grad {k}: oracle is zero, hip is not"
+        else:
+            e = grad_err(got, ref)
+            assert e <= rtol, f"grad {k}: rel err {e:.3e} > {rtol:.1e}"
+        checked.append(k)
+    return checked
