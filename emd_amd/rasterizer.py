@@ -50,38 +50,42 @@ class RasterConfig:
 
 
 _capacity_hint = {}
-_host_cache = {}
 
 
-def _host_floats(t, n):
-    """Settings tensors -> python floats.  GPU tensors cost one sync the first time a camera is seen."""
-    if not isinstance(t, torch.Tensor):
-        t = torch.as_tensor(t, dtype=torch.float32)
-    if t.device.type == "cpu":
-        v = t.detach().reshape(-1).to(torch.float32).tolist()
+def _settings_host_values(rs):
+    """bg[3], viewmatrix[16], projmatrix[16], campos[3] as python floats.
+
+    The reference keeps these on the GPU (S3Gaussian/gaussian_renderer/__init__.py:54-59); they are packed and
+    brought to the host with ONE device-to-host copy per call (no caching by address: a recycled allocation
+    would alias a stale camera).  CPU tensors cost nothing.
+    """
+    parts = []
+    for t, n in ((rs.bg, 3), (rs.viewmatrix, 16), (rs.projmatrix, 16), (rs.campos, 3)):
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(t, dtype=torch.float32)
+        t = t.detach().reshape(-1).to(torch.float32)
+        if t.numel() != n:
+            raise ValueError(f"expected {n} values, got {t.numel()}")
+        parts.append(t)
+    if any(p.device.type != "cpu" for p in parts):
+        dev = next(p.device for p in parts if p.device.type != "cpu")
+        flat = torch.cat([p.to(dev) for p in parts]).cpu().tolist()
     else:
-        key = (t.data_ptr(), t._version, n)
-        v = _host_cache.get(key)
-        if v is None:
-            if len(_host_cache) > 4096:
-                _host_cache.clear()
-            v = t.detach().reshape(-1).to(torch.float32).cpu().tolist()
-            _host_cache[key] = v
-    if len(v) != n:
-        raise ValueError(f"expected {n} values, got {len(v)}")
-    return v
+        flat = torch.cat(parts).tolist()
+    return flat[0:3], flat[3:19], flat[19:35], flat[35:38]
 
 
 def make_c_settings(rs: GaussianRasterizationSettings, near_plane=None) -> L.EmdSettings:
     s = L.EmdSettings()
+    bg, view, proj, campos = _settings_host_values(rs)
     s.image_height, s.image_width = int(rs.image_height), int(rs.image_width)
     s.tanfovx, s.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
-    s.bg[:] = _host_floats(rs.bg, 3)
+    s.bg[:] = bg
     s.scale_modifier = float(rs.scale_modifier)
-    s.viewmatrix[:] = _host_floats(rs.viewmatrix, 16)
-    s.projmatrix[:] = _host_floats(rs.projmatrix, 16)
+    s.viewmatrix[:] = view
+    s.projmatrix[:] = proj
     s.sh_degree = int(rs.sh_degree)
-    s.campos[:] = _host_floats(rs.campos, 3)
+    s.campos[:] = campos
     s.prefiltered = int(bool(rs.prefiltered))
     s.debug = int(bool(rs.debug))
     s.near_plane = float(RasterConfig.near_plane if near_plane is None else near_plane)
