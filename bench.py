@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric: train iters/s (fwd+bwd) @1066x1600, 2M Gaussians; 1/2/4/8 GPU.
+
+One step = one pass of the hot path over one camera view per GPU:
+  activations + per-frame actor pose table -> fused explicit-motion transform + projection + SH colour ->
+  tile duplication + radix sort -> per-tile alpha compositing (forward) -> L1 loss vs a fixed target ->
+  backward to all 59 floats per Gaussian and the actor poses (-> RCCL all-reduce of the gradients for N > 1).
+Optimiser, densification and data loading are excluded (they are outside the path).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(N, V, D, HW, T, C, p, residual=False):
+    """Compulsory HBM bytes per stage (C blended channels, p radix passes)."""
+    return {
+        "preprocess": 56 * N + (12 * N if residual else 0) + V * (216 + 4 * C),
+        "scan_duplicate": 8 * N + 16 * V + 12 * D,
+        "radix_sort": p * 24 * D + 8 * D,
+        "tile_ranges": 8 * D + 8 * T,
+        "render_forward": D * (4 + 24 + 4 * C) + HW * (4 * (C + 1) + 8),
+        "render_backward": D * (28 + 4 * C) + HW * (4 * (C + 1) + 8) + V * (24 + 4 * C),
+        "preprocess_backward": V * ((24 + 4 * C) + 48 + 192) + N * (236 + 12),
+    }
+
+
+def cpu_baseline(scene, cam, budget_s=20.0):
+    """The reference's pure-PyTorch projection + cov3D + SH forward on the host cores."""
+    from oracle import torch_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    means, scales, rots, shs = scene.means, torch.exp(scene.log_scales), scene.quats, scene.shs
+    V, Pm, cp = cam.world_view_transform, cam.full_proj_transform, cam.camera_center
+    times = []
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        torch_ref.reference_projection_cpu(means, scales, rots, shs, V, Pm, cp, 3)   # warm-up
+        first = time.perf_counter() - t0
+        reps = int(max(3, min(20, budget_s / max(first, 1e-3))))
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            torch_ref.reference_projection_cpu(means, scales, rots, shs, V, Pm, cp, 3)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "iters/s (projection+cov3D+SH forward stage only)", "cores": cores,
+            "kind": "port", "ms_per_call": med * 1e3, "gaussians_per_s": scene.N / med,
+            "sample": f"reference pure-PyTorch geom_transform_points + get_covariance + eval_sh(deg 3) forward, "
+                      f"N={scene.N}, fp32, median of {len(times)} calls after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=2_000_000)
+    ap.add_argument("--height", type=int, default=1066)
+    ap.add_argument("--width", type=int, default=1600)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-count", action="store_true", help="read the duplicate count back every forward (reference behaviour)")
+    ap.add_argument("--no-normal", action="store_true", help="skip the normal image (unused by the training loss)")
+    args = ap.parse_args()
+
+    from emd_amd import dp, scenes, _lib
+    from emd_amd import RasterConfig, GaussianRasterizer
+    from emd_amd.model import StreetGaussians, render, l1_loss
+
+    rank, world, local = dp.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    N, H, W = args.gaussians, args.height, args.width
+    num_frames, num_actors = 50, 32
+    scene = scenes.add_actors(scenes.make_static_scene(N, seed=0), num_actors=num_actors, pts_per_actor=5000,
+                              num_frames=num_frames, seed=1)
+    model = StreetGaussians(scene, dev)
+    params = [p for p in model.parameters()]
+    bg = torch.zeros(3)
+    g3 = torch.Generator().manual_seed(3)
+    target = torch.rand(3, H, W, generator=g3).to(dev)
+
+    RasterConfig.compute_normal = not args.no_normal
+    RasterConfig.no_sync = not args.sync_count
+    cams = {}
+
+    def cam_for(step):
+        # frame of the 50-frame clip; rank r looks through rig camera r at that timestamp
+        f, c = step % num_frames, rank % len(scenes.RIG_YAWS)
+        if (f, c) not in cams:
+            cams[(f, c)] = scenes.rig_camera(f, c, H, W)
+        return f, cams[(f, c)]
+
+    def one_step(step):
+        f, cam = cam_for(step)
+        for p in params:
+            p.grad = None
+        out = render(model, cam, bg, frame=f)
+        loss = l1_loss(out["render"], target)
+        loss.backward()
+        dp.allreduce_gradients(params)
+        return out
+
+    # first call sizes the binning workspace with a synchronising forward, then the async path takes over
+    RasterConfig.no_sync = False
+    out = one_step(0)
+    st = GaussianRasterizer.last_status()
+    RasterConfig.no_sync = not args.sync_count
+    for s in range(args.warmup):
+        one_step(s)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    _lib.profile_enable(True)
+    _lib.profile_read()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        out = one_step(args.warmup + s)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    status = GaussianRasterizer.last_status()
+    assert status["overflow"] == 0, "binning workspace overflowed during the timed region"
+
+    if rank == 0:
+        V, D = st["num_visible"], st["num_rendered"]
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        C = 7 if RasterConfig.compute_normal else 4
+        passes = (32 + max(T - 1, 1).bit_length() + 7) // 8
+        ab = algorithmic_bytes(N, V, D, H * W, T, C, passes)
+        stages = {}
+        for name, (ms, cnt) in prof.items():
+            if cnt and name in ab:
+                avg = ms / cnt
+                stages[name] = {"ms": round(avg, 4), "alg_GB": round(ab[name] / 1e9, 4),
+                                "GBps": round(ab[name] / 1e9 / (avg * 1e-3), 1)}
+        dom = max(stages, key=lambda k: stages[k]["ms"])
+        kernel_ms = sum(v["ms"] for v in stages.values())
+        total_alg = sum(ab.values())
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": stages[dom]["ms"],
+                    "whole_iter": {"algorithmic_GB": round(total_alg / 1e9, 3), "kernel_ms": round(kernel_ms, 3),
+                                   "GBps": round(total_alg / 1e9 / (kernel_ms * 1e-3), 1),
+                                   "frac": round(total_alg / 1e9 / (kernel_ms * 1e-3) / HBM_PEAK_GBS, 4)},
+                    "stages": stages}
+        res = {
+            "metric": "train iters/s (fwd+bwd) @1066x1600, 2M Gaussians; 1/2/4/8 GPU",
+            "value": world * args.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 50-frame dynamic clip, per-actor rigid motion on 2M Gaussians "
+                                   "(32 actors x 5000), SH degree 3, one 1066x1600 view per GPU per step, L1 loss, "
+                                   "fwd+bwd to all 59 floats/Gaussian + actor poses",
+                       "gaussians": N, "height": H, "width": W, "visible_V": V, "duplicates_D": D, "tiles_T": T,
+                       "radix_passes_p": passes, "blended_channels_C": C, "views_per_step": world,
+                       "parallelism": f"view-parallel dp{world}", "count_readback": bool(args.sync_count)},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(scene, cam_for(0)[1])
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

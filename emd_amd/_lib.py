@@ -67,7 +67,9 @@ class EmdBwdArgs(C.Structure):
 # every symbol include/emd_raster.h declares
 EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_size", "emd_raster_forward",
                     "emd_raster_backward", "emd_raster_export_binning", "emd_raster_export_geometry",
-                    "emd_motion_forward", "emd_motion_backward", "emd_sh_forward", "emd_sh_backward")
+                    "emd_motion_forward", "emd_motion_backward", "emd_sh_forward", "emd_sh_backward",
+                    "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name")
+PROF_STAGES = 8
 
 _lib = None
 
@@ -105,8 +107,25 @@ def load():
         [C.c_void_p] * 10
     lib.emd_sh_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_sh_backward.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6
+    lib.emd_profile_enable.argtypes = [C.c_int]
+    lib.emd_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
+    lib.emd_profile_stage_name.argtypes = [C.c_int]
+    lib.emd_profile_stage_name.restype = C.c_char_p
     _lib = lib
     return lib
+
+
+def profile_enable(on=True):
+    load().emd_profile_enable(1 if on else 0)
+
+
+def profile_read():
+    """{stage name: (total ms, launches)} since the last read (HIP events on the launch stream)."""
+    lib = load()
+    ms = (C.c_double * PROF_STAGES)()
+    cnt = (C.c_int64 * PROF_STAGES)()
+    lib.emd_profile_read(ms, cnt, PROF_STAGES)
+    return {lib.emd_profile_stage_name(i).decode(): (ms[i], cnt[i]) for i in range(PROF_STAGES)}
 
 
 def check(rc, what):

@@ -15,6 +15,46 @@ void emd_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- profiling ------------------------------------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec { int stage; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t g_prof_open[EMD_PROF_STAGES];
+const char* kStageNames[EMD_PROF_STAGES] = {"preprocess", "scan_duplicate", "radix_sort", "tile_ranges", "render_forward",
+                                            "render_backward", "preprocess_backward", "other"};
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+void emd_prof_begin(int stage, hipStream_t st) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEvent_t e = prof_event();
+    if (!e) return;
+    (void)hipEventRecord(e, st);
+    g_prof_open[stage] = e;
+}
+
+void emd_prof_end(int stage, hipStream_t st) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_open[stage]) return;
+    hipEvent_t e = prof_event();
+    if (!e) return;
+    (void)hipEventRecord(e, st);
+    g_prof_recs.push_back({stage, g_prof_open[stage], e});
+    g_prof_open[stage] = nullptr;
+}
+
 int emd_launch_motion_forward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
                               float* wm, float* wq, float* wo, hipStream_t st);
 int emd_launch_motion_backward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
@@ -29,6 +69,29 @@ int emd_launch_export_geometry(int N, const GeomWs& g, float* means2D, float* de
 extern "C" {
 
 int emd_abi_version(void) { return EMD_ABI_VERSION; }
+
+int emd_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return EMD_OK;
+}
+
+const char* emd_profile_stage_name(int stage) { return (stage >= 0 && stage < EMD_PROF_STAGES) ? kStageNames[stage] : ""; }
+
+int emd_profile_read(double* ms, int64_t* count, int max_stages) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof_recs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.stage < max_stages) {
+            if (ms) ms[r.stage] += (double)t;
+            if (count) count[r.stage] += 1;
+        }
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof_recs.clear();
+    return EMD_PROF_STAGES;
+}
 
 const char* emd_last_error(void) { return g_err; }
 
@@ -104,7 +167,9 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
     pa.scales = a->scales; pa.rotations = a->rotations; pa.cov3D_precomp = a->cov3D_precomp;
     pa.motion = a->motion; pa.radii = a->radii; pa.g = g; pa.status = a->status;
     if (!(a->flags & EMD_FLAG_MOTION)) memset(&pa.motion, 0, sizeof(pa.motion));
+    emd_prof_begin(PROF_PREPROCESS, st);
     rc = emd_launch_preprocess(pa, st);
+    emd_prof_end(PROF_PREPROCESS, st);
     if (rc) return rc;
     STAGE_SYNC("preprocess");
     rc = emd_launch_binning(a->s, N, a->radii, g, b, a->bin_capacity, a->status, st);
@@ -123,7 +188,9 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
             return EMD_ERR_CAPACITY;
         }
     }
+    emd_prof_begin(PROF_RENDER_FWD, st);
     rc = emd_launch_render_forward(a->s, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->out_alpha, st);
+    emd_prof_end(PROF_RENDER_FWD, st);
     if (rc) return rc;
     STAGE_SYNC("render_forward");
     return EMD_OK;
@@ -148,11 +215,15 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     }
     if ((a->flags & EMD_FLAG_ABSGRAD) && !a->dL_dmeans2D_abs) { emd_set_error("backward: EMD_FLAG_ABSGRAD without dL_dmeans2D_abs"); return EMD_ERR_INVALID; }
     const bool dbg = a->s.debug != 0;
+    emd_prof_begin(PROF_OTHER, st);
     EMD_HIP_CHECK(hipMemsetAsync(a->bwd_ws, 0, need, st));
+    emd_prof_end(PROF_OTHER, st);
     if ((a->flags & EMD_FLAG_MOTION) && a->dL_dactor_pose && a->motion.num_actors > 0)
         EMD_HIP_CHECK(hipMemsetAsync(a->dL_dactor_pose, 0, (size_t)a->motion.num_actors * EMD_ACTOR_STRIDE * sizeof(float), st));
+    emd_prof_begin(PROF_RENDER_BWD, st);
     rc = emd_launch_render_backward(a->s, a->flags, g, b, im, a->dL_dcolor, a->dL_ddepth, a->dL_dalpha, a->dL_dnormal,
                                     (float*)a->bwd_ws, st);
+    emd_prof_end(PROF_RENDER_BWD, st);
     if (rc) return rc;
     STAGE_SYNC("render_backward");
     PreBwdArgs pb;
@@ -165,7 +236,9 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     pb.dL_dshs = a->dL_dshs; pb.dL_dcolors = a->dL_dcolors; pb.dL_dopacities = a->dL_dopacities;
     pb.dL_dscales = a->dL_dscales; pb.dL_drotations = a->dL_drotations; pb.dL_dcov3D = a->dL_dcov3D;
     pb.dL_dactor_pose = a->dL_dactor_pose; pb.dL_dresidual_dx = a->dL_dresidual_dx; pb.dL_dresidual_dq = a->dL_dresidual_dq;
+    emd_prof_begin(PROF_PREPROCESS_BWD, st);
     rc = emd_launch_preprocess_backward(pb, st);
+    emd_prof_end(PROF_PREPROCESS_BWD, st);
     if (rc) return rc;
     STAGE_SYNC("preprocess_backward");
     return EMD_OK;

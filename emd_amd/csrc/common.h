@@ -114,6 +114,11 @@ void emd_set_error(const char* fmt, ...);
     } while (0)
 #define EMD_LAUNCH_CHECK() EMD_HIP_CHECK(hipGetLastError())
 
+// ---- per-stage HIP-event timing (api.hip); no-ops unless emd_profile_enable(1) ------------------------------
+enum { PROF_PREPROCESS = 0, PROF_DUPLICATE, PROF_SORT, PROF_RANGES, PROF_RENDER_FWD, PROF_RENDER_BWD, PROF_PREPROCESS_BWD, PROF_OTHER };
+void emd_prof_begin(int stage, hipStream_t st);
+void emd_prof_end(int stage, hipStream_t st);
+
 // ---- stage launchers (one per translation unit) -------------------------------------------------
 struct PreArgs {
     EmdSettings s;

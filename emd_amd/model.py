@@ -1,0 +1,71 @@
+"""Host-side mirror of the reference's per-step render glue around the rasterizer (benchmark / training harness).
+
+What one step does, with the reference line each piece restates:
+  activations exp / normalize / sigmoid          S3Gaussian/gaussian_renderer/__init__.py:99-101
+  per-frame actor pose table (q, t, valid)        OmniRe/models/nodes/rigid.py:478-568 (gather + rigid transform are
+                                                  fused into the projection kernel; the table is built here)
+  GaussianRasterizationSettings + rasterizer call S3Gaussian/gaussian_renderer/__init__.py:49-62,145-155
+  L1 photometric loss                             S3Gaussian/train.py:226
+  loss.backward()                                 S3Gaussian/train.py:366
+Parameters, optimiser and densification stay PyTorch (out of scope).
+"""
+import torch
+import torch.nn.functional as F
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .scenes import GaussianScene
+
+
+class StreetGaussians(torch.nn.Module):
+    """Parameter store in the reference's layout (S3Gaussian/scene/gaussian_model.py:54-71)."""
+
+    def __init__(self, scene: GaussianScene, device):
+        super().__init__()
+        P = lambda t: torch.nn.Parameter(t.to(device).contiguous())
+        self._xyz = P(scene.means)
+        self._scaling = P(scene.log_scales)
+        self._rotation = P(scene.quats)
+        self._opacity = P(scene.opacity_logits)
+        self._features = P(scene.shs)           # [N,16,3] = cat(features_dc, features_rest)
+        self.has_actors = scene.actor_id is not None
+        if self.has_actors:
+            self.register_buffer("actor_id", scene.actor_id.to(device))
+            self.instances_quats = P(scene.actor_quats)    # [F,A,4]
+            self.instances_trans = P(scene.actor_trans)    # [F,A,3]
+            self.register_buffer("instances_fv", scene.actor_valid.to(device))
+        self.active_sh_degree = 3
+
+    @property
+    def num_points(self):
+        return self._xyz.shape[0]
+
+    def actor_pose(self, frame):
+        """[A,12] pose rows for one frame (track offsets would be added to q_rot / trans here)."""
+        q = F.normalize(self.instances_quats[frame], dim=-1)
+        return torch.cat([q, self.instances_trans[frame], self.instances_fv[frame].float()[:, None], q], dim=1)
+
+
+def render(model: StreetGaussians, cam, bg, frame=0, debug=False):
+    """The reference render() restricted to the hot path; returns the dict the training loop consumes."""
+    dev = model._xyz.device
+    screenspace_points = torch.zeros_like(model._xyz, requires_grad=True)
+    rs = GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+        bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+        sh_degree=model.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=debug)
+    rasterizer = GaussianRasterizer(raster_settings=rs)
+    scales = torch.exp(model._scaling)
+    rotations = F.normalize(model._rotation)
+    opacity = torch.sigmoid(model._opacity)
+    kw = {}
+    if model.has_actors:
+        kw = dict(actor_ids=model.actor_id, actor_pose=model.actor_pose(frame))
+    image, depth, normal, weight, radii, _ = rasterizer(
+        means3D=model._xyz, means2D=screenspace_points, shs=model._features, colors_precomp=None, opacities=opacity,
+        scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, **kw)
+    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+            "depth": depth, "weight": weight, "normal": normal}
+
+
+def l1_loss(a, b):
+    return torch.abs(a - b).mean()

@@ -229,6 +229,15 @@ int emd_sh_forward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* di
 int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* dirs, const float* coeffs,
                     const float* dL_drgb, float* dL_dcoeffs, float* dL_ddirs /*or NULL*/, void* hip_stream);
 
+/* Per-stage device timing with HIP events recorded on the caller's stream around each stage (bench.py's roofline
+ * leg).  Stages: see emd_profile_stage_name().  emd_profile_read synchronises on the recorded events, adds the
+ * elapsed milliseconds and launch counts per stage into ms[]/count[] (up to max_stages entries) and clears the
+ * recorded events; returns the number of stages. */
+#define EMD_PROF_STAGES 8
+int emd_profile_enable(int on);
+int emd_profile_read(double* ms, int64_t* count, int max_stages);
+const char* emd_profile_stage_name(int stage);
+
 #ifdef __cplusplus
 }
 #endif
