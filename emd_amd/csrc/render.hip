@@ -49,6 +49,59 @@ __device__ __forceinline__ float gauss_power(float A, float B, float C, float dx
     return __builtin_fmaf(-0.5f, q, -((B * dx) * dy));
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Exact-conservative footprint culling.  A pixel receives alpha >= 1/255 from a Gaussian only if
+// power >= -tau with tau = ln(255 * opacity), i.e. inside the ellipse d^T Conic d <= 2 tau, whose axis-aligned
+// bounding box has half-extents sqrt(2 tau * cov_xx), sqrt(2 tau * cov_yy) (cov = Conic^-1).  That box is much
+// tighter than the 3-sigma square of the largest eigenvalue that defines the tile list (anisotropic or faint
+// Gaussians), so: the lane that stages entry t computes the box once and a 4-bit mask of the 8x8 quadrants it
+// overlaps; ballots compact the 256 staged entries into one index list per quadrant (order preserved), and each
+// wave walks only its own list.  Pixels outside the box would have been rejected by the alpha test anyway, so the
+// result is unchanged; the box carries a small margin so float rounding can never cull a contributing pixel.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t quadrant_mask(const float4& r0, const float4& r1, float tile_x0, float tile_y0) {
+    const float o = r0.w;
+    if (!(o >= (1.f / 255.f))) return 0u;            // can never reach alpha >= 1/255 (also catches NaN)
+    const float det = r1.x * r1.z - r1.y * r1.y;
+    if (!(det > 0.f)) return 0xFu;                   // degenerate conic: no culling
+    const float tau2 = 2.f * __logf(255.f * o);
+    const float inv = 1.f / det;
+    const float bx = sqrtf(tau2 * r1.z * inv) * 1.0001f + 0.01f;
+    const float by = sqrtf(tau2 * r1.x * inv) * 1.0001f + 0.01f;
+    if (!(bx == bx) || !(by == by)) return 0xFu;
+    const float lx = r0.x - bx, hx = r0.x + bx, ly = r0.y - by, hy = r0.y + by;
+    // quadrant q covers pixel centres [x0 + 8(q&1), +7] x [y0 + 8(q>>1), +7]
+    const bool xl = lx <= tile_x0 + 7.f && hx >= tile_x0, xr = lx <= tile_x0 + 15.f && hx >= tile_x0 + 8.f;
+    const bool yt = ly <= tile_y0 + 7.f && hy >= tile_y0, yb = ly <= tile_y0 + 15.f && hy >= tile_y0 + 8.f;
+    return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+}
+
+// Compacts the staged slots whose qmask has bit q set into s_list[q][...] (ascending slot order).
+// Needs one barrier before (counts) and one after (lists); returns this wave's list length.
+__device__ __forceinline__ uint32_t build_quadrant_lists(uint32_t qmask, uint16_t (*s_list)[EMD_BLOCK],
+                                                         uint32_t (*s_qcnt)[4]) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    unsigned long long bal[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) bal[q] = __ballot((qmask >> q) & 1u);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) s_qcnt[wave][q] = (uint32_t)__popcll(bal[q]);
+    }
+    __syncthreads();  // counts visible; also orders the staged records before any reader
+    uint32_t my_n = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t c0 = s_qcnt[0][q], c1 = s_qcnt[1][q], c2 = s_qcnt[2][q], c3 = s_qcnt[3][q];
+        const uint32_t base = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u);
+        if ((qmask >> q) & 1u) s_list[q][base + (uint32_t)__popcll(bal[q] & lt)] = (uint16_t)threadIdx.x;
+        if ((uint32_t)q == wave) my_n = c0 + c1 + c2 + c3;
+    }
+    __syncthreads();
+    return my_n;
+}
+
 template <bool NORMAL>
 __global__ void __launch_bounds__(EMD_BLOCK) k_render_forward(RenderDims d, const uint32_t* __restrict__ ranges,
                                                               const uint32_t* __restrict__ point_list,
@@ -58,31 +111,38 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_forward(RenderDims d, cons
                                                               uint32_t* __restrict__ n_contrib) {
     __shared__ float4 s0[EMD_BLOCK], s1[EMD_BLOCK], s2[EMD_BLOCK];
     __shared__ float4 s3[NORMAL ? EMD_BLOCK : 1];
+    __shared__ uint16_t s_list[4][EMD_BLOCK];
+    __shared__ uint32_t s_qcnt[4][4];
     const uint32_t tile = xcd_tile(blockIdx.x);
     if (tile >= (uint32_t)(d.gx * d.gy)) return;
     int px, py;
     tile_pixel(d, tile, threadIdx.x, px, py);
     const bool inside = px < d.W && py < d.H;
     const float pfx = (float)px, pfy = (float)py;
+    const float tile_x0 = (float)((tile % (uint32_t)d.gx) * EMD_TILE_X), tile_y0 = (float)((tile / (uint32_t)d.gx) * EMD_TILE_Y);
     const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
+    const uint32_t wave = threadIdx.x >> 6;
     bool done = !inside;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
-    uint32_t contributor = 0, last = 0;
+    uint32_t last = 0;
     for (uint32_t base = start; base < end; base += EMD_BLOCK) {
-        if (__syncthreads_count(done) == EMD_BLOCK) break;
+        if (__syncthreads_count(done) == EMD_BLOCK) break;   // also: previous chunk fully consumed
         const uint32_t idx = base + threadIdx.x;
+        uint32_t qmask = 0;
         if (idx < end) {
             const float4* r = rec + (size_t)point_list[idx] * EMD_REC_F4;
-            s0[threadIdx.x] = r[0];
-            s1[threadIdx.x] = r[1];
+            const float4 r0 = r[0], r1 = r[1];
+            s0[threadIdx.x] = r0;
+            s1[threadIdx.x] = r1;
             s2[threadIdx.x] = r[2];
             if (NORMAL) s3[threadIdx.x] = r[3];
+            qmask = quadrant_mask(r0, r1, tile_x0, tile_y0);
         }
-        __syncthreads();
-        const uint32_t cnt = min((uint32_t)EMD_BLOCK, end - base);
+        const uint32_t n = build_quadrant_lists(qmask, s_list, s_qcnt);
         if (__ballot(!done) == 0ull) continue;  // whole wave finished: keep feeding the barriers only
-        for (uint32_t j = 0; j < cnt; j++) {
-            contributor++;
+        const uint16_t* list = s_list[wave];
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t j = list[i];
             const float4 g0 = s0[j], g1 = s1[j];
             const float dx = g0.x - pfx, dy = g0.y - pfy;
             const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
@@ -100,7 +160,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_forward(RenderDims d, cons
                     Dz += g0.z * w;
                     if (NORMAL) { const float4 g3 = s3[j]; N0 += g3.x * w; N1 += g3.y * w; N2 += g3.z * w; }
                     T = test_T;
-                    last = contributor;
+                    last = base - start + j + 1;   // 1-based position in the tile list
                 }
             }
         }
@@ -138,6 +198,8 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
     __shared__ float4 s3[NORMAL ? EMD_BLOCK : 1];
     __shared__ uint32_t s_id[EMD_BLOCK];
     __shared__ float s_acc[EMD_BLOCK][EMD_BWD_STRIDE + 1];  // odd row stride: conflict-free row and column walks
+    __shared__ uint16_t s_list[4][EMD_BLOCK];
+    __shared__ uint32_t s_qcnt[4][4];
     __shared__ uint32_t s_max[4];
     const uint32_t tile = xcd_tile(blockIdx.x);
     if (tile >= (uint32_t)(d.gx * d.gy)) return;
@@ -145,6 +207,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
     tile_pixel(d, tile, threadIdx.x, px, py);
     const bool inside = px < d.W && py < d.H;
     const float pfx = (float)px, pfy = (float)py;
+    const float tile_x0 = (float)((tile % (uint32_t)d.gx) * EMD_TILE_X), tile_y0 = (float)((tile / (uint32_t)d.gx) * EMD_TILE_Y);
     const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t HW = (size_t)d.H * d.W, pix = (size_t)py * d.W + px;
@@ -175,19 +238,24 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
         const uint32_t cnt = min((uint32_t)EMD_BLOCK, tile_n - done_cnt);
         __syncthreads();  // previous chunk fully consumed (s_acc flushed) before restaging
         // stage entries tile_n-1-done_cnt ... downwards: LDS slot j holds list position (tile_n - 1 - done_cnt - j)
+        uint32_t qmask = 0;
         if (threadIdx.x < cnt) {
             const uint32_t id = point_list[start + (tile_n - 1 - done_cnt - threadIdx.x)];
             const float4* r = rec + (size_t)id * EMD_REC_F4;
+            const float4 r0 = r[0], r1 = r[1];
             s_id[threadIdx.x] = id;
-            s0[threadIdx.x] = r[0];
-            s1[threadIdx.x] = r[1];
+            s0[threadIdx.x] = r0;
+            s1[threadIdx.x] = r1;
             s2[threadIdx.x] = r[2];
             if (NORMAL) s3[threadIdx.x] = r[3];
+            qmask = quadrant_mask(r0, r1, tile_x0, tile_y0);
         }
 #pragma unroll
         for (int v = 0; v < EMD_BWD_STRIDE; v++) s_acc[threadIdx.x][v] = 0.f;
-        __syncthreads();
-        for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t n = build_quadrant_lists(qmask, s_list, s_qcnt);
+        const uint16_t* list = s_list[wave];
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t j = list[i];
             const uint32_t pos = tile_n - 1 - done_cnt - j;  // position in the tile list (0 = front)
             const float4 g0 = s0[j], g1 = s1[j];
             const float dx = g0.x - pfx, dy = g0.y - pfy;
