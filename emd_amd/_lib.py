@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 TILE = 16
 ACTOR_STRIDE = 12
 BWD_STRIDE = 12
@@ -57,6 +57,7 @@ class EmdBwdArgs(C.Structure):
                 ("rotations", _f), ("cov3D_precomp", _f), ("motion", EmdMotion), ("radii", _f),
                 ("geom_ws", _f), ("geom_bytes", C.c_size_t), ("bin_ws", _f), ("bin_bytes", C.c_size_t),
                 ("img_ws", _f), ("img_bytes", C.c_size_t), ("status", _f),
+                ("out_color", _f), ("out_depth", _f), ("out_normal", _f),
                 ("dL_dcolor", _f), ("dL_ddepth", _f), ("dL_dalpha", _f), ("dL_dnormal", _f),
                 ("bwd_ws", _f), ("bwd_bytes", C.c_size_t),
                 ("dL_dmeans3D", _f), ("dL_dmeans2D", _f), ("dL_dmeans2D_abs", _f), ("dL_dshs", _f),

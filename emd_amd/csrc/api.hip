@@ -203,7 +203,9 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     int rc = check_common(a->s, N, a->sh_coeffs, a->means3D, a->shs, a->colors_precomp, a->opacities, a->scales,
                           a->rotations, a->cov3D_precomp, a->flags, a->motion);
     if (rc) return rc;
-    if (!a->radii || !a->geom_ws || !a->bin_ws || !a->img_ws || !a->bwd_ws || !a->status) { emd_set_error("backward: null state pointer"); return EMD_ERR_INVALID; }
+    if (!a->radii || !a->geom_ws || !a->bin_ws || !a->img_ws || !a->bwd_ws || !a->status || !a->out_color || !a->out_depth) {
+        emd_set_error("backward: null state pointer"); return EMD_ERR_INVALID;
+    }
     const int gx = (a->s.image_width + EMD_TILE_X - 1) / EMD_TILE_X, gy = (a->s.image_height + EMD_TILE_Y - 1) / EMD_TILE_Y;
     GeomWs g; BinWs b; ImgWs im;
     emd_carve_geom((void*)a->geom_ws, N, &g);
@@ -221,8 +223,8 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     if ((a->flags & EMD_FLAG_MOTION) && a->dL_dactor_pose && a->motion.num_actors > 0)
         EMD_HIP_CHECK(hipMemsetAsync(a->dL_dactor_pose, 0, (size_t)a->motion.num_actors * EMD_ACTOR_STRIDE * sizeof(float), st));
     emd_prof_begin(PROF_RENDER_BWD, st);
-    rc = emd_launch_render_backward(a->s, a->flags, g, b, im, a->dL_dcolor, a->dL_ddepth, a->dL_dalpha, a->dL_dnormal,
-                                    (float*)a->bwd_ws, st);
+    rc = emd_launch_render_backward(a->s, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->dL_dcolor,
+                                    a->dL_ddepth, a->dL_dalpha, a->dL_dnormal, (float*)a->bwd_ws, st);
     emd_prof_end(PROF_RENDER_BWD, st);
     if (rc) return rc;
     STAGE_SYNC("render_backward");

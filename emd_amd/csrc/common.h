@@ -137,6 +137,7 @@ int emd_launch_render_forward(const EmdSettings& s, int flags, const GeomWs& g, 
                               float* out_color, float* out_depth, float* out_normal, float* out_alpha,
                               hipStream_t st);                                 // render.hip
 int emd_launch_render_backward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
+                               const float* out_color, const float* out_depth, const float* out_normal,
                                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                                const float* dL_dnormal, float* grad_rec, hipStream_t st);  // render.hip
 struct PreBwdArgs {

@@ -26,6 +26,27 @@ __device__ __forceinline__ float wave_scan_add_f32(float v) {
     return v;
 }
 
+// Inclusive wave64 prefix product; invalid / masked DPP sources read as 1.0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mul_f32(float v) {
+    int src = __builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v * __int_as_float(src);
+}
+__device__ __forceinline__ float wave_scan_mul_f32(float v) {
+    v = dpp_mul_f32<DPP_ROW_SHR(1), 0xf>(v);
+    v = dpp_mul_f32<DPP_ROW_SHR(2), 0xf>(v);
+    v = dpp_mul_f32<DPP_ROW_SHR(4), 0xf>(v);
+    v = dpp_mul_f32<DPP_ROW_SHR(8), 0xf>(v);
+    v = dpp_mul_f32<DPP_ROW_BCAST15, 0xa>(v);
+    v = dpp_mul_f32<DPP_ROW_BCAST31, 0xc>(v);
+    return v;
+}
+// Shift the whole wave up by one lane (lane l receives lane l-1; lane 0 receives `fill`): DPP wave_shr:1.
+#define DPP_WAVE_SHR1 0x138
+__device__ __forceinline__ float wave_shift_up1_f32(float v, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), DPP_WAVE_SHR1, 0xf, 0xf, false));
+}
+
 // Sum over the wave, valid in lane 63 only.
 __device__ __forceinline__ float wave_reduce_to_lane63(float v) { return wave_scan_add_f32(v); }
 

@@ -12,6 +12,8 @@
 //     with DPP row shifts/broadcasts (6 v_add_f32_dpp per value, no LDS traffic), lane 63 of each wave adds the
 //     wave sums into an LDS accumulator row for the staged chunk, and after the chunk one lane per entry issues
 //     the global float atomics: at most one atomic row per (Gaussian, tile) instead of one per (Gaussian, pixel).
+#include <stdlib.h>
+
 #include "common.h"
 #include "device_utils.h"
 
@@ -178,8 +180,23 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_forward(RenderDims d, cons
     }
 }
 
-// number of reduced values per (Gaussian, tile): mean2D 2, depth 1, opacity 1, conic 3, rgb 3 (+ abs 2);
-// the global accumulator row is EMD_BWD_STRIDE = 12 floats in exactly this order
+// ---------------------------------------------------------------------------------------------------
+// K7, entry-parallel formulation for wave64.
+//
+// Upstream walks each pixel's list back to front and needs, per (pixel, Gaussian), ten partial derivatives summed
+// over the pixels of the tile: a 64-lane reduction of ten values per list entry.  On CDNA4 that reduction (60
+// v_add_f32_dpp per entry and wave) costs as much as all the arithmetic (measured: profiles/r01_ablation.txt).
+// Here the roles are swapped: a lane owns one list ENTRY of the wave's quadrant list, the wave loops over the 64
+// PIXELS of its quadrant, and the per-pixel recurrences become wave prefix scans in list order:
+//     T_k  = prod_{i<k} (1 - alpha_i)                 exclusive scan-product   (6 v_mul_f32_dpp + 1 wave_shr)
+//     S_k  = sum_{i<=k} g_i alpha_i T_i               inclusive scan-sum       (6 v_add_f32_dpp)
+//     dL/dalpha_k = g_k T_k + (Q + S_k) / (1 - alpha_k),   g = colour . dL/dC + depth dL/dD (+ normal . dL/dN),
+//     Q = T_final (dL/dalpha_img - bg . dL/dC) - S_total,  S_total from the forward outputs.
+// (algebraically the upstream gradient: sum_{i>k} g_i alpha_i T_i = S_total - S_k; no T / (1 - alpha)
+// reconstruction by division).  The ten derivative sums then accumulate in the lane's registers over the 64 pixels
+// with no cross-lane traffic at all; per 64 (pixel, entry) pairs the wave spends 13 DPP ops instead of 60.
+// Running T and S per pixel are carried across batches of 64 entries in lane p (v_readlane / lane select).
+// ---------------------------------------------------------------------------------------------------
 #define NV_BASE 10
 
 template <bool NORMAL, bool ABS>
@@ -188,6 +205,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
                                                                const float4* __restrict__ rec,
                                                                const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
+                                                               const float* __restrict__ out_color,
+                                                               const float* __restrict__ out_depth,
+                                                               const float* __restrict__ out_normal,
                                                                const float* __restrict__ dL_dcolor,
                                                                const float* __restrict__ dL_ddepth,
                                                                const float* __restrict__ dL_dalpha,
@@ -206,13 +226,13 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
     int px, py;
     tile_pixel(d, tile, threadIdx.x, px, py);
     const bool inside = px < d.W && py < d.H;
-    const float pfx = (float)px, pfy = (float)py;
     const float tile_x0 = (float)((tile % (uint32_t)d.gx) * EMD_TILE_X), tile_y0 = (float)((tile / (uint32_t)d.gx) * EMD_TILE_Y);
     const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float qx0 = tile_x0 + (float)((wave & 1) * 8), qy0 = tile_y0 + (float)((wave >> 1) * 8);
     const size_t HW = (size_t)d.H * d.W, pix = (size_t)py * d.W + px;
+    // ---- per-pixel constants live in lane p of the wave that owns the pixel ----
     const uint32_t my_n = inside ? n_contrib[pix] : 0u;
-    // longest contributing prefix over the tile: nothing behind it influences any pixel
     {
         uint32_t m = my_n;
         for (int off = 32; off; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
@@ -221,26 +241,27 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
     __syncthreads();
     const uint32_t tile_n = min(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), end - start);
     if (tile_n == 0) return;
-    const float Tf = inside ? final_T[pix] : 0.f;
-    float T = Tf;
-    float dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dA = 0.f, dN0 = 0.f, dN1 = 0.f, dN2 = 0.f;
+    float dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dN0 = 0.f, dN1 = 0.f, dN2 = 0.f, Q = 0.f;
     if (inside) {
+        const float Tf = final_T[pix];
+        float dA = 0.f;
         if (dL_dcolor) { dC0 = dL_dcolor[pix]; dC1 = dL_dcolor[HW + pix]; dC2 = dL_dcolor[2 * HW + pix]; }
         if (dL_ddepth) dD = dL_ddepth[pix];
         if (dL_dalpha) dA = dL_dalpha[pix];
         if (NORMAL && dL_dnormal) { dN0 = dL_dnormal[pix]; dN1 = dL_dnormal[HW + pix]; dN2 = dL_dnormal[2 * HW + pix]; }
+        const float bgdot = d.bg[0] * dC0 + d.bg[1] * dC1 + d.bg[2] * dC2;
+        float Stot = (out_color[pix] - Tf * d.bg[0]) * dC0 + (out_color[HW + pix] - Tf * d.bg[1]) * dC1 +
+                     (out_color[2 * HW + pix] - Tf * d.bg[2]) * dC2 + out_depth[pix] * dD;
+        if (NORMAL && dL_dnormal) Stot += out_normal[pix] * dN0 + out_normal[HW + pix] * dN1 + out_normal[2 * HW + pix] * dN2;
+        Q = Tf * (dA - bgdot) - Stot;
     }
-    const float bgdot = d.bg[0] * dC0 + d.bg[1] * dC1 + d.bg[2] * dC2;
-    // colour "behind" the current Gaussian per unit transmittance after it (recursive, back to front)
-    float aC0 = 0.f, aC1 = 0.f, aC2 = 0.f, aD = 0.f, aN0 = 0.f, aN1 = 0.f, aN2 = 0.f;
-    float last_alpha = 0.f, lC0 = 0.f, lC1 = 0.f, lC2 = 0.f, lD = 0.f, lN0 = 0.f, lN1 = 0.f, lN2 = 0.f;
+    float cT = 1.f, cS = 0.f;  // running transmittance / running S of pixel `lane`, carried across batches
     for (uint32_t done_cnt = 0; done_cnt < tile_n; done_cnt += EMD_BLOCK) {
         const uint32_t cnt = min((uint32_t)EMD_BLOCK, tile_n - done_cnt);
         __syncthreads();  // previous chunk fully consumed (s_acc flushed) before restaging
-        // stage entries tile_n-1-done_cnt ... downwards: LDS slot j holds list position (tile_n - 1 - done_cnt - j)
         uint32_t qmask = 0;
         if (threadIdx.x < cnt) {
-            const uint32_t id = point_list[start + (tile_n - 1 - done_cnt - threadIdx.x)];
+            const uint32_t id = point_list[start + done_cnt + threadIdx.x];
             const float4* r = rec + (size_t)id * EMD_REC_F4;
             const float4 r0 = r[0], r1 = r[1];
             s_id[threadIdx.x] = id;
@@ -254,68 +275,65 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
         for (int v = 0; v < EMD_BWD_STRIDE; v++) s_acc[threadIdx.x][v] = 0.f;
         const uint32_t n = build_quadrant_lists(qmask, s_list, s_qcnt);
         const uint16_t* list = s_list[wave];
-        for (uint32_t i = 0; i < n; i++) {
-            const uint32_t j = list[i];
-            const uint32_t pos = tile_n - 1 - done_cnt - j;  // position in the tile list (0 = front)
-            const float4 g0 = s0[j], g1 = s1[j];
-            const float dx = g0.x - pfx, dy = g0.y - pfy;
-            const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, g0.w * G);
-            const bool hit = pos < my_n && power <= 0.f && alpha >= (1.f / 255.f);
-            if (__ballot(hit) == 0ull) continue;
-            float v_mx = 0.f, v_my = 0.f, v_dz = 0.f, v_op = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_r = 0.f,
-                  v_g = 0.f, v_b = 0.f;
-            if (hit) {
-                const float4 g2 = s2[j];
-                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-                T = T * inv;
-                const float w = alpha * T;
-                float dL_da;
-                aC0 = last_alpha * lC0 + (1.f - last_alpha) * aC0; lC0 = g2.x;
-                aC1 = last_alpha * lC1 + (1.f - last_alpha) * aC1; lC1 = g2.y;
-                aC2 = last_alpha * lC2 + (1.f - last_alpha) * aC2; lC2 = g2.z;
-                aD = last_alpha * lD + (1.f - last_alpha) * aD; lD = g0.z;
-                dL_da = (g2.x - aC0) * dC0 + (g2.y - aC1) * dC1 + (g2.z - aC2) * dC2 + (g0.z - aD) * dD;
-                if (NORMAL) {
-                    const float4 g3 = s3[j];
-                    aN0 = last_alpha * lN0 + (1.f - last_alpha) * aN0; lN0 = g3.x;
-                    aN1 = last_alpha * lN1 + (1.f - last_alpha) * aN1; lN1 = g3.y;
-                    aN2 = last_alpha * lN2 + (1.f - last_alpha) * aN2; lN2 = g3.z;
-                    dL_da += (g3.x - aN0) * dN0 + (g3.y - aN1) * dN1 + (g3.z - aN2) * dN2;
-                }
-                dL_da *= T;
-                last_alpha = alpha;
-                dL_da += (Tf * inv) * (dA - bgdot);
+        for (uint32_t b = 0; b < n; b += EMD_WAVE) {
+            const uint32_t i = b + lane;
+            const bool valid = i < n;
+            const uint32_t j = list[valid ? i : n - 1];
+            const float4 g0 = s0[j], g1 = s1[j], g2 = s2[j];
+            float4 g3 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NORMAL) g3 = s3[j];
+            const uint32_t pos = done_cnt + j;                       // 0-based position in the tile list
+            const uint32_t first_pos = readlane_u32(pos, 0);         // list is ascending: lane 0 is the front-most
+            float a_mx = 0.f, a_my = 0.f, a_dz = 0.f, a_op = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_r = 0.f,
+                  a_g = 0.f, a_b = 0.f, a_ax = 0.f, a_ay = 0.f;
+            for (int p = 0; p < EMD_WAVE; p++) {
+                const uint32_t n_p = readlane_u32(my_n, p);
+                if (n_p <= first_pos) continue;                      // pixel p terminated before this batch
+                const float pxs = qx0 + (float)(p & 7), pys = qy0 + (float)(p >> 3);
+                const float dx = g0.x - pxs, dy = g0.y - pys;
+                const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
+                const float G = __expf(power);
+                const float alpha = fminf(0.99f, g0.w * G);
+                const bool hit = valid && pos < n_p && power <= 0.f && alpha >= (1.f / 255.f);
+                if (__ballot(hit) == 0ull) continue;
+                const float a = hit ? alpha : 0.f;
+                const float om = 1.f - a;
+                const float t_incl = wave_scan_mul_f32(om);
+                const float cTp = readlane_f32(cT, p), cSp = readlane_f32(cS, p);
+                const float Tk = cTp * wave_shift_up1_f32(t_incl, 1.f);
+                const float w = a * Tk;
+                const float c0 = readlane_f32(dC0, p), c1 = readlane_f32(dC1, p), c2 = readlane_f32(dC2, p),
+                            cd = readlane_f32(dD, p);
+                float g = g2.x * c0 + g2.y * c1 + g2.z * c2 + g0.z * cd;
+                if (NORMAL) g += g3.x * readlane_f32(dN0, p) + g3.y * readlane_f32(dN1, p) + g3.z * readlane_f32(dN2, p);
+                const float s_incl = wave_scan_add_f32(g * w);
+                const float Sk = cSp + s_incl;
+                const float inv = __builtin_amdgcn_rcpf(om);
+                float dL_da = g * Tk + inv * (readlane_f32(Q, p) + Sk);
+                dL_da = hit ? dL_da : 0.f;
                 const float dL_dG = g0.w * dL_da;
                 const float gdx = G * dx, gdy = G * dy;
-                v_mx = dL_dG * (-gdx * g1.x - gdy * g1.y);
-                v_my = dL_dG * (-gdy * g1.z - gdx * g1.y);
-                v_ca = -0.5f * gdx * dx * dL_dG;
-                v_cb = -gdx * dy * dL_dG;
-                v_cc = -0.5f * gdy * dy * dL_dG;
-                v_op = G * dL_da;
-                v_dz = w * dD;
-                v_r = w * dC0; v_g = w * dC1; v_b = w * dC2;
+                const float v_mx = dL_dG * (-gdx * g1.x - gdy * g1.y);
+                const float v_my = dL_dG * (-gdy * g1.z - gdx * g1.y);
+                a_mx += v_mx; a_my += v_my;
+                if (ABS) { a_ax += fabsf(v_mx); a_ay += fabsf(v_my); }
+                a_ca += -0.5f * gdx * dx * dL_dG;
+                a_cb += -gdx * dy * dL_dG;
+                a_cc += -0.5f * gdy * dy * dL_dG;
+                a_op += G * dL_da;
+                a_dz += w * cd;
+                a_r += w * c0; a_g += w * c1; a_b += w * c2;
+                // carry the running T and S of pixel p to the next batch
+                const float nT = cTp * readlane_f32(t_incl, 63), nS = cSp + readlane_f32(s_incl, 63);
+                cT = (lane == (uint32_t)p) ? nT : cT;
+                cS = (lane == (uint32_t)p) ? nS : cS;
             }
-            float r[NV];
-            r[0] = wave_reduce_to_lane63(v_mx);
-            r[1] = wave_reduce_to_lane63(v_my);
-            r[2] = wave_reduce_to_lane63(v_dz);
-            r[3] = wave_reduce_to_lane63(v_op);
-            r[4] = wave_reduce_to_lane63(v_ca);
-            r[5] = wave_reduce_to_lane63(v_cb);
-            r[6] = wave_reduce_to_lane63(v_cc);
-            r[7] = wave_reduce_to_lane63(v_r);
-            r[8] = wave_reduce_to_lane63(v_g);
-            r[9] = wave_reduce_to_lane63(v_b);
-            if (ABS) {
-                r[10] = wave_reduce_to_lane63(fabsf(v_mx));
-                r[11] = wave_reduce_to_lane63(fabsf(v_my));
-            }
-            if (lane == 63) {
-#pragma unroll
-                for (int v = 0; v < NV; v++) atomicAdd(&s_acc[j][v], r[v]);
+            if (valid) {
+                float* row = s_acc[j];   // the 4 waves may meet on one entry: LDS float atomics
+                atomicAdd(row + 0, a_mx); atomicAdd(row + 1, a_my); atomicAdd(row + 2, a_dz); atomicAdd(row + 3, a_op);
+                atomicAdd(row + 4, a_ca); atomicAdd(row + 5, a_cb); atomicAdd(row + 6, a_cc);
+                atomicAdd(row + 7, a_r); atomicAdd(row + 8, a_g); atomicAdd(row + 9, a_b);
+                if (ABS) { atomicAdd(row + 10, a_ax); atomicAdd(row + 11, a_ay); }
             }
         }
         __syncthreads();
@@ -327,6 +345,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
             if (val != 0.f) atomicAdd(grad_rec + (size_t)s_id[e] * EMD_BWD_STRIDE + v, val);
         }
     }
+    (void)NV;
 }
 
 RenderDims make_dims(const EmdSettings& s) {
@@ -357,16 +376,18 @@ int emd_launch_render_forward(const EmdSettings& s, int flags, const GeomWs& g, 
 }
 
 int emd_launch_render_backward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
+                               const float* out_color, const float* out_depth, const float* out_normal,
                                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                                const float* dL_dnormal, float* grad_rec, hipStream_t st) {
     const RenderDims d = make_dims(s);
     const int T = d.gx * d.gy;
     if (T <= 0) return EMD_OK;
     const uint32_t* pl = b.vals[b.sorted_buf];
-    const bool nrm = (flags & EMD_FLAG_NORMAL) && dL_dnormal, ab = flags & EMD_FLAG_ABSGRAD;
+    const bool nrm = (flags & EMD_FLAG_NORMAL) && dL_dnormal && out_normal, ab = flags & EMD_FLAG_ABSGRAD;
 #define LAUNCH_BWD(N_, A_)                                                                                          \
     hipLaunchKernelGGL((k_render_backward<N_, A_>), dim3(padded_tile_grid(T)), dim3(EMD_BLOCK), 0, st, d, b.ranges, pl, g.rec,        \
-                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dL_dnormal, grad_rec)
+                       im.final_T, im.n_contrib, out_color, out_depth, out_normal, dL_dcolor, dL_ddepth, dL_dalpha,    \
+                       dL_dnormal, grad_rec)
     if (nrm && ab) LAUNCH_BWD(true, true);
     else if (nrm) LAUNCH_BWD(true, false);
     else if (ab) LAUNCH_BWD(false, true);

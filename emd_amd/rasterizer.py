@@ -173,7 +173,8 @@ class _Rasterize(torch.autograd.Function):
         ctx.has = (shs is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None,
                    actor_pose is not None, residual_dx is not None, residual_dq is not None)
         ctx.save_for_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose,
-                              residual_dx, residual_dq, actor_ids, radii, geom_ws, bin_ws, img_ws, status)
+                              residual_dx, residual_dq, actor_ids, radii, geom_ws, bin_ws, img_ws, status, out_color,
+                              out_depth, out_normal)
         ctx.mark_non_differentiable(radii)
         GaussianRasterizer._last = dict(status=status, num_rendered=int(a.num_rendered), num_visible=int(a.num_visible),
                                         geom_ws=geom_ws, bin_ws=bin_ws, img_ws=img_ws, sizes=(gb, bb, ib),
@@ -184,7 +185,8 @@ class _Rasterize(torch.autograd.Function):
     def backward(ctx, g_color, g_depth, g_normal, g_alpha, _g_radii):
         lib = L.load()
         (means3D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose, residual_dx,
-         residual_dq, actor_ids, radii, geom_ws, bin_ws, img_ws, status) = ctx.saved_tensors
+         residual_dq, actor_ids, radii, geom_ws, bin_ws, img_ws, status, out_color, out_depth,
+         out_normal) = ctx.saved_tensors
         dev = means3D.device
         N, M, flags = ctx.N, ctx.M, ctx.flags
         has_shs, has_col, has_sr, has_cov, has_pose, has_rdx, has_rdq = ctx.has
@@ -217,6 +219,8 @@ class _Rasterize(torch.autograd.Function):
         b.bin_ws, b.bin_bytes = bin_ws.data_ptr(), ctx.sizes[1]
         b.img_ws, b.img_bytes = img_ws.data_ptr(), ctx.sizes[2]
         b.status = status.data_ptr()
+        b.out_color, b.out_depth = out_color.data_ptr(), out_depth.data_ptr()
+        b.out_normal = out_normal.data_ptr() if flags & L.FLAG_NORMAL else None
         b.dL_dcolor, b.dL_ddepth, b.dL_dalpha, b.dL_dnormal = L.ptr(g_color), L.ptr(g_depth), L.ptr(g_alpha), L.ptr(g_normal)
         b.bwd_ws, b.bwd_bytes = bwd_ws.data_ptr(), bwd_ws.numel() * 4
         b.dL_dmeans3D, b.dL_dmeans2D, b.dL_dmeans2D_abs = d_means3D.data_ptr(), d_means2D.data_ptr(), L.ptr(d_abs)

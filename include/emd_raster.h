@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 3
+#define EMD_ABI_VERSION 4
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -167,6 +167,10 @@ typedef struct EmdBwdArgs {
     const void* bin_ws;   size_t bin_bytes;
     const void* img_ws;   size_t img_bytes;
     const EmdStatus* status;
+    /* forward outputs again (the backward pass needs the composited totals per pixel) */
+    const float* out_color;       /* [3,H,W] */
+    const float* out_depth;       /* [1,H,W] */
+    const float* out_normal;      /* [3,H,W] or NULL */
     /* incoming gradients (any may be NULL = zero) */
     const float* dL_dcolor;       /* [3,H,W] */
     const float* dL_ddepth;       /* [1,H,W] */
