@@ -1,0 +1,181 @@
+"""EMD explicit motion, host side: per-actor pose table + learned track offsets, and the per-Gaussian transform
+through the HIP kernels (`emd_motion_forward/backward`, or fused into the projection kernel via
+`GaussianRasterizer(..., actor_ids=, actor_pose=)`).
+
+Mirrors, with the same names and argument meaning (behaviour restated, not copied):
+  RigidNodes.transform_means / transform_quats / get_pts_valid_mask   OmniRe/models/nodes/rigid.py:42-46,478-568
+  embedding_track_trans_offset / embedding_track_rot_offset           OmniRe/models/nodes/rigid.py:203-246
+  get_temporal_embed / query_time / int_lininterp                     OmniRe/models/nodes/rigid.py:147-192
+  quat_mult / interpolate_quats / quat_act                            OmniRe/models/gaussians/basics.py:53-110, vanilla.py:145-146
+  DeformableNodes residual add                                        OmniRe/models/nodes/deformable.py:57-69
+
+What changes versus the reference is WHERE the work runs, not what is computed: the reference loops over
+instances in Python (rigid.py:520-530,550-562; ~15 tiny launches per instance, twice); here the per-actor
+quantities are batched over actors in a handful of torch ops and packed into one [A,12] table, and the per-point
+gather + rigid transform + quaternion composition + validity mask is one HIP kernel (or no kernel at all when fused).
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+
+
+def quat_act(q):
+    return F.normalize(q, dim=-1)
+
+
+def quat_mult(q1, q2):
+    w1, x1, y1, z1 = q1.unbind(-1)
+    w2, x2, y2, z2 = q2.unbind(-1)
+    return torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                        w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], -1)
+
+
+def interpolate_quats(q1, q2, fraction=0.5):
+    """Slerp with the reference's branches (basics.py:53-81): sign flip for dot < 0, lerp when dot > 0.9995."""
+    q1 = q1 / torch.norm(q1, dim=-1, keepdim=True)
+    q2 = q2 / torch.norm(q2, dim=-1, keepdim=True)
+    dot = (q1 * q2).sum(dim=-1).clamp(-1, 1)
+    neg = dot < 0
+    q2 = torch.where(neg[..., None], -q2, q2)
+    dot = torch.where(neg, -dot, dot)
+    similar = dot > 0.9995
+    lerp = q1 + fraction * (q2 - q1)
+    theta_0 = torch.acos(dot)
+    theta = theta_0 * fraction
+    s2 = torch.sin(theta) / torch.sin(theta_0)
+    s1 = torch.cos(theta) - dot * s2
+    slerp = s1[..., None] * q1 + s2[..., None] * q2
+    return torch.where(similar[..., None], lerp, slerp)
+
+
+class TrackOffsetHeads(torch.nn.Module):
+    """Per-actor learned track offsets, batched over actors (rigid.py:108-122,150-246).
+
+    Delta t = W_c h_c + W_f h_f,   theta_{c,f} = w_{c,f} . h_{c,f},   Delta q = (cos th_c,0,0,sin th_c) (x) (cos th_f,0,0,sin th_f)
+    with h = cat[TE_k(t) from the actor's temporal table, mean of the actor's Gaussian embeddings];
+    k = 30 for the coarse head, int_lininterp(step, 30, 150, 25000) for the fine head.
+    """
+
+    def __init__(self, num_actors, temporal_embedding_dim=32, gaussian_embedding_dim=4, max_embeddings=150,
+                 min_embeddings=30, c2f_temporal_iter=25000):
+        super().__init__()
+        self.fdim, self.edim = temporal_embedding_dim, gaussian_embedding_dim
+        self.max_embeddings, self.min_embeddings, self.c2f_temporal_iter = max_embeddings, min_embeddings, c2f_temporal_iter
+        self.weight = torch.nn.Parameter(torch.randn(num_actors, max_embeddings, temporal_embedding_dim) * 0.01 / temporal_embedding_dim ** 0.5)
+        d = temporal_embedding_dim + gaussian_embedding_dim
+        mk = lambda o: torch.nn.Linear(d, o)
+        self.track_rot_c, self.track_rot_f, self.track_trans_c, self.track_trans_f = mk(1), mk(1), mk(3), mk(3)
+        for lin in (self.track_rot_c, self.track_rot_f, self.track_trans_c, self.track_trans_f):  # zero init, rigid.py:113-122
+            torch.nn.init.zeros_(lin.weight)
+            torch.nn.init.zeros_(lin.bias)
+
+    def int_lininterp(self, t, init_val, final_val, until):
+        return int(init_val + (final_val - init_val) * min(max(t, 0), until) / until)
+
+    def temporal_embed(self, t, k):
+        """Row t (normalised, [0,1]) of every actor's table resized bilinearly to k rows (align_corners)."""
+        emb = F.interpolate(self.weight[:, None], size=(k, self.fdim), mode="bilinear", align_corners=True)[:, 0]  # [A,k,32]
+        y = float(t) * (k - 1)
+        y0 = min(max(int(y // 1), 0), k - 1)
+        y1 = min(y0 + 1, k - 1)
+        w = y - y0
+        return emb[:, y0] * (1 - w) + emb[:, y1] * w
+
+    def forward(self, frame, num_frames, embeddings, point_ids, step):
+        """-> (track_trans [A,3], track_rot [A,4]).  embeddings [N,4]; point_ids [N] actor of every point."""
+        A = self.weight.shape[0]
+        t = (frame - 0) / (num_frames - 1 - 0)
+        ids = point_ids.long()
+        cnt = torch.zeros(A, device=embeddings.device).index_add_(0, ids, torch.ones_like(ids, dtype=embeddings.dtype))
+        mean_emb = torch.zeros(A, self.edim, device=embeddings.device, dtype=embeddings.dtype).index_add_(0, ids, embeddings) / cnt[:, None]
+        k_f = self.int_lininterp(step, self.min_embeddings, self.max_embeddings, self.c2f_temporal_iter)
+        h_c = torch.cat([self.temporal_embed(t, self.min_embeddings), mean_emb], -1)
+        h_f = torch.cat([self.temporal_embed(t, k_f), mean_emb], -1)
+        trans = self.track_trans_c(h_c) + self.track_trans_f(h_f)
+        th_c, th_f = self.track_rot_c(h_c)[:, 0], self.track_rot_f(h_f)[:, 0]
+        z = torch.zeros_like(th_c)
+        rot = quat_mult(torch.stack([torch.cos(th_c), z, z, torch.sin(th_c)], -1),
+                        torch.stack([torch.cos(th_f), z, z, torch.sin(th_f)], -1))
+        return trans, rot
+
+
+def build_actor_pose(instances_quats, instances_trans, instances_fv, cur_frame, track_trans=None, track_rot=None,
+                     in_test_set=False):
+    """[A,12] rows (q_mean[4], trans[3], valid, q_rot[4]) for one frame -- the table the HIP kernels gather from.
+
+    Reproduces the reference's asymmetry: the mean's rotation uses the (test-time interpolated) pose quaternion
+    WITHOUT the learned rotation offset (rigid.py:485-503), the quaternion composition uses the un-interpolated
+    pose quaternion WITH it (rigid.py:547-566); NaN offsets are skipped (rigid.py:528,559).
+    """
+    num_frames = instances_quats.shape[0]
+    q_cur, t_cur = instances_quats[cur_frame], instances_trans[cur_frame]
+    q_mean, trans = q_cur, t_cur
+    if in_test_set and (cur_frame - 1 > 0 and cur_frame + 1 < num_frames):
+        ok = (instances_fv[cur_frame - 1] & instances_fv[cur_frame + 1])[:, None]
+        q_mean = torch.where(ok, interpolate_quats(instances_quats[cur_frame - 1], instances_quats[cur_frame + 1]), q_cur)
+        trans = torch.where(ok, (instances_trans[cur_frame - 1] + instances_trans[cur_frame + 1]) * 0.5, t_cur)
+    q_mean = quat_act(q_mean)
+    if track_trans is not None:
+        bad = track_trans.isnan().any(dim=-1, keepdim=True)
+        trans = trans + torch.where(bad, torch.zeros_like(track_trans), track_trans)
+    q_rot = q_cur
+    if track_rot is not None:
+        bad = track_rot.isnan().any(dim=-1, keepdim=True)
+        q_rot = torch.where(bad, q_cur, quat_mult(q_cur, track_rot))
+    q_rot = quat_act(q_rot)
+    valid = instances_fv[cur_frame].to(q_mean.dtype)[:, None]
+    return torch.cat([q_mean, trans, valid, q_rot], dim=1).contiguous()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _MotionTransform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, opacities, actor_pose, residual_dx, residual_dq, actor_ids):
+        lib = L.load()
+        if means.device.type != "cuda":
+            raise L.EmdError("transform_gaussians needs tensors on a ROCm device; there is no CPU path")
+        N = means.shape[0]
+        wm = torch.empty_like(means)
+        wq = torch.empty_like(quats) if quats is not None else None
+        wo = torch.empty_like(opacities) if opacities is not None else None
+        m = L.EmdMotion(L.ptr(actor_ids), L.ptr(actor_pose), int(actor_pose.shape[0]), L.ptr(residual_dx), L.ptr(residual_dq))
+        L.check(lib.emd_motion_forward(N, means.data_ptr(), L.ptr(quats), L.ptr(opacities), C.byref(m), wm.data_ptr(),
+                                       L.ptr(wq), L.ptr(wo), _stream()), "emd_motion_forward")
+        ctx.save_for_backward(means, quats, opacities, actor_pose, residual_dx, residual_dq, actor_ids)
+        return wm, wq, wo
+
+    @staticmethod
+    def backward(ctx, g_wm, g_wq, g_wo):
+        lib = L.load()
+        means, quats, opacities, actor_pose, residual_dx, residual_dq, actor_ids = ctx.saved_tensors
+        N = means.shape[0]
+        c = lambda t: None if t is None else t.contiguous()
+        g_wm, g_wq, g_wo = c(g_wm), c(g_wq), c(g_wo)
+        d_means = torch.empty_like(means)
+        d_quats = torch.empty_like(quats) if quats is not None else None
+        d_opac = torch.empty_like(opacities) if opacities is not None else None
+        d_pose = torch.empty_like(actor_pose)
+        d_rdx = torch.empty_like(residual_dx) if residual_dx is not None else None
+        d_rdq = torch.empty_like(residual_dq) if residual_dq is not None else None
+        m = L.EmdMotion(L.ptr(actor_ids), L.ptr(actor_pose), int(actor_pose.shape[0]), L.ptr(residual_dx), L.ptr(residual_dq))
+        L.check(lib.emd_motion_backward(N, means.data_ptr(), L.ptr(quats), L.ptr(opacities), C.byref(m), L.ptr(g_wm),
+                                        L.ptr(g_wq), L.ptr(g_wo), d_means.data_ptr(), L.ptr(d_quats), L.ptr(d_opac),
+                                        d_pose.data_ptr(), L.ptr(d_rdx), L.ptr(d_rdq), _stream()), "emd_motion_backward")
+        return d_means, d_quats, d_opac, d_pose, d_rdx, d_rdq, None
+
+
+def transform_gaussians(means, quats, opacities, actor_ids, actor_pose, residual_dx=None, residual_dq=None):
+    """world_means, world_quats (already `quat_act`-ed), opacities * valid -- one HIP kernel, differentiable.
+
+    Equivalent of RigidNodes.transform_means + transform_quats + the validity mask of get_gaussians
+    (rigid.py:575-576,589-591); points with actor_id < 0 pass through unchanged (static background).
+    """
+    f = lambda t: None if t is None else t.contiguous().float()
+    return _MotionTransform.apply(f(means), f(quats), None if opacities is None else f(opacities).reshape(-1),
+                                  f(actor_pose), f(residual_dx), f(residual_dq), actor_ids.to(torch.int32).contiguous())

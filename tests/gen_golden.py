@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by IMPORTING the reference's Python from /root/reference (build container only).
+
+The reference never travels to the GPU box: only the small input/expected-output vectors written here do.
+Recipe: stub the absent third-party modules with a meta_path finder, rewrite
+device='cuda' to CPU with a TorchFunctionMode, make .cuda() the identity, then call the reference functions.
+
+    python tests/gen_golden.py          # rewrites tests/golden/*.npz  (seeds fixed below)
+
+Fixtures (all fp32):
+  s3g_sh.npz        eval_sh deg 0..3 + clamp_min(sh + 0.5, 0)     S3Gaussian/utils/sh_utils.py:57-112, gaussian_renderer/__init__.py:19-25
+  s3g_cov.npz       build_covariance_from_scaling_rotation          S3Gaussian/scene/gaussian_model.py:34-38, utils/general_utils.py:231-277
+  s3g_proj.npz      geom_transform_points                           S3Gaussian/utils/graphics_utils.py:42-49
+  s3g_camera.npz    getWorld2View2 / getProjectionMatrix / Camera   S3Gaussian/utils/graphics_utils.py:58-92, scene/cameras.py:55-66
+  s3g_quat.npz      batch_quaternion_multiply                       S3Gaussian/utils/graphics_utils.py:172-195
+  or_quat.npz       quat_to_rotmat, quat_mult, interpolate_quats    OmniRe/models/gaussians/basics.py:30-110
+  or_rigid.npz      RigidNodes.transform_means / transform_quats / opacity mask (+ gradients), train and
+                    test-interpolation branches, non-zero track heads  OmniRe/models/nodes/rigid.py:42-46,150-246,478-615
+"""
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "golden")
+REF = "/root/reference"
+
+ABSENT = {"diff_gauss", "plyfile", "simple_knn", "open3d", "nvdiffrast", "cv2", "imageio", "tkinter", "tinycudann",
+          "skimage", "torchvision", "mmcv", "pytorch3d", "gsplat", "omegaconf", "trimesh", "smplx", "kornia", "viser",
+          "nerfview", "pytorch_msssim", "torchmetrics", "wandb", "chumpy", "third_party", "lpips", "tensorboard"}
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return type(name, (), {"__init__": lambda self, *a, **k: None})
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split(".")[0] in ABSENT:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _Stub(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+class _CpuMode(torch.overrides.TorchFunctionMode):
+    def __torch_function__(self, func, types_, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if "device" in kwargs and str(kwargs["device"]).startswith("cuda"):
+            kwargs["device"] = "cpu"
+        return func(*args, **kwargs)
+
+
+def install_shims():
+    sys.meta_path.insert(0, _Finder())
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+
+def unload(prefixes):
+    for k in list(sys.modules):
+        if any(k == p or k.startswith(p + ".") for p in prefixes):
+            del sys.modules[k]
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    clean = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        v = np.asarray(v)
+        if v.dtype == np.float64:
+            v = v.astype(np.float32)
+        clean[k] = v
+    np.savez_compressed(os.path.join(OUT, name), **clean)
+    print(f"  wrote {name}: " + ", ".join(f"{k}{list(v.shape)}" for k, v in clean.items()))
+
+
+def gen_s3g():
+    sys.path.insert(0, os.path.join(REF, "S3Gaussian"))
+    from utils.sh_utils import eval_sh
+    from utils.graphics_utils import (geom_transform_points, getWorld2View2, getProjectionMatrix,
+                                      batch_quaternion_multiply, focal2fov)
+    g = torch.Generator().manual_seed(100)
+    # SH
+    n = 96
+    shs = torch.randn(n, 16, 3, generator=g) * 0.3
+    shs[:, 0] += 0.5
+    xyz = torch.randn(n, 3, generator=g) * 5
+    campos = torch.tensor([0.3, -0.2, 1.5])
+    d = xyz - campos
+    d = d / d.norm(dim=1, keepdim=True)
+    out = {}
+    for deg in range(4):
+        r = eval_sh(deg, shs.transpose(1, 2).view(-1, 3, 16), d)
+        out[f"sh_deg{deg}"] = r
+        out[f"rgb_deg{deg}"] = torch.clamp_min(r + 0.5, 0.0)
+    save("s3g_sh.npz", shs=shs, xyz=xyz, campos=campos, dirs=d, **out)
+    # covariance (general_utils hard-codes device='cuda' -> rewritten by _CpuMode)
+    with _CpuMode():
+        from utils.general_utils import build_scaling_rotation, strip_symmetric
+        scales = torch.exp(torch.randn(n, 3, generator=g) * 0.7 - 2.0)
+        rots = torch.randn(n, 4, generator=g)
+        cov = {}
+        for mod in (1.0, 0.5):
+            L = build_scaling_rotation(mod * scales, rots)
+            cov[f"cov_mod{mod}"] = strip_symmetric(L @ L.transpose(1, 2))
+    save("s3g_cov.npz", scales=scales, rots_raw=rots, **cov)
+    # camera + projection
+    yaw = 0.3
+    c2w_R = np.array([[np.sin(yaw), 0, np.cos(yaw)], [-np.cos(yaw), 0, np.sin(yaw)], [0, -1, 0]], np.float64)
+    eye = np.array([2.0, -1.0, 1.5])
+    T = -c2w_R.T @ eye
+    H, W, fx, fy = 64, 96, 110.0, 105.0
+    fovx, fovy = focal2fov(fx, W), focal2fov(fy, H)
+    w2c = getWorld2View2(c2w_R, T, np.array([0.0, 0.0, 0.0]), 1.0)
+    wvt = torch.tensor(w2c).transpose(0, 1)
+    proj = getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)
+    full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
+    center = wvt.inverse()[3, :3]
+    save("s3g_camera.npz", R=c2w_R, T=T, H=H, W=W, fx=fx, fy=fy, fovx=fovx, fovy=fovy, w2c=w2c, world_view_transform=wvt,
+         projection_matrix=proj, full_proj_transform=full, camera_center=center)
+    pts = torch.randn(n, 3, generator=g) * 4 + torch.tensor([8.0, 0.0, 1.0])
+    save("s3g_proj.npz", points=pts, full_proj_transform=full, world_view_transform=wvt,
+         ndc=geom_transform_points(pts, full), view=geom_transform_points(pts, wvt))
+    q1, q2 = torch.randn(n, 4, generator=g), torch.randn(n, 4, generator=g)
+    save("s3g_quat.npz", q1=q1, q2=q2, out=batch_quaternion_multiply(q1, q2))
+    sys.path.pop(0)
+    unload(["utils", "scene", "arguments", "gaussian_renderer"])
+
+
+def _matrix_to_quaternion(M):
+    """Stand-in for pytorch3d.transforms.matrix_to_quaternion (only used at RigidNodes init, rigid.py:271)."""
+    M = M.reshape(-1, 3, 3)
+    out = []
+    for m in M:
+        m = m.double().numpy()
+        t = np.trace(m)
+        if t > 0:
+            s = np.sqrt(t + 1.0) * 2
+            q = [0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s]
+        else:
+            i = int(np.argmax(np.diag(m)))
+            j, k = (i + 1) % 3, (i + 2) % 3
+            s = np.sqrt(1.0 + m[i, i] - m[j, j] - m[k, k]) * 2
+            q = [0.0] * 4
+            q[0] = (m[k, j] - m[j, k]) / s
+            q[1 + i] = 0.25 * s
+            q[1 + j] = (m[j, i] + m[i, j]) / s
+            q[1 + k] = (m[k, i] + m[i, k]) / s
+        out.append(q)
+    return torch.tensor(out, dtype=torch.float32)
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def gen_omnire():
+    sys.path.insert(0, os.path.join(REF, "OmniRe"))
+    import pytorch3d.transforms as p3t  # stub module
+    p3t.matrix_to_quaternion = lambda M: _matrix_to_quaternion(M).reshape(*M.shape[:-2], 4)
+    with _CpuMode():
+        from models.gaussians import basics
+        basics.matrix_to_quaternion = p3t.matrix_to_quaternion
+        g = torch.Generator().manual_seed(200)
+        n = 80
+        q = torch.randn(n, 4, generator=g)
+        q1, q2 = torch.randn(n, 4, generator=g), torch.randn(n, 4, generator=g)
+        qa, qb = torch.randn(n, 4, generator=g), torch.randn(n, 4, generator=g)
+        qb[: n // 4] = qa[: n // 4] + 0.001 * qb[: n // 4]     # exercises the "similar" (lerp) branch
+        save("or_quat.npz", q=q, rotmat=basics.quat_to_rotmat(q), q1=q1, q2=q2, mult=basics.quat_mult(q1, q2),
+             qa=qa, qb=qb, interp=basics.interpolate_quats(qa.clone(), qb.clone()))
+
+        from models.nodes.rigid import RigidNodes
+        import models.nodes.rigid as rigid_mod
+        rigid_mod.matrix_to_quaternion = p3t.matrix_to_quaternion
+        ctrl = _Cfg(sh_degree=3, gaussian_embedding_dim=4, temporal_embedding_dim=32, no_gaussian_embedding_dim=False,
+                    no_temporal_embedding_dim=False, no_coarse_deform=False, no_fine_deform=False,
+                    no_c2f_temporal_embedding=False, min_embeddings=30, max_embeddings=150, c2f_temporal_iter=25000,
+                    no_apply_embed_shs=True, no_apply_embed_track=False, sh_degree_interval=1000)
+        ctrl.get = lambda k, d=None: dict.get(ctrl, k, d)
+        F_, A, P = 6, 3, 40
+        torch.manual_seed(201)
+        node = RigidNodes(class_name="RigidNodes", ctrl=ctrl, reg=_Cfg(), networks=_Cfg(), scene_scale=30.0,
+                          scene_origin=torch.zeros(3), num_train_images=10, device=torch.device("cpu"))
+        inst = {}
+        for a in range(A):
+            yaw = torch.linspace(0.1 * (a + 1), 0.1 * (a + 1) + 0.5, F_)
+            poses = torch.eye(4).repeat(F_, 1, 1)
+            poses[:, 0, 0], poses[:, 0, 1], poses[:, 1, 0], poses[:, 1, 1] = torch.cos(yaw), -torch.sin(yaw), torch.sin(yaw), torch.cos(yaw)
+            poses[:, :3, 3] = torch.stack([10.0 + 3 * a + torch.arange(F_) * 0.8, torch.full((F_,), -3.0 + 3 * a), torch.full((F_,), 0.8)], 1)
+            fv = torch.ones(F_, dtype=torch.bool)
+            if a == 1:
+                fv[2] = False
+            inst[a] = dict(class_name="car", pts=(torch.rand(P, 3) - 0.5) * torch.tensor([4.5, 2.0, 1.6]),
+                           colors=torch.rand(P, 3), poses=poses, size=torch.tensor([4.5, 2.0, 1.6]), frame_info=fv, num_pts=P)
+        node.create_from_pcd(inst)
+        # non-zero track heads, non-trivial embeddings and pose noise so every term is exercised
+        for lin in (node.track_rot_c, node.track_rot_f, node.track_trans_c, node.track_trans_f):
+            lin.weight.data.normal_(0, 0.05)
+            lin.bias.data.normal_(0, 0.02)
+        node._embeddings.data.normal_(0, 0.5)
+        node.weight.data.normal_(0, 0.3)
+        node.instances_quats.data += 0.05 * torch.randn_like(node.instances_quats)   # un-normalised on purpose
+        node._quats.data *= 1.7
+        node.step = 12000
+        rec = dict(means=node._means.data.clone(), quats=node._quats.data.clone(), opacity_logits=node._opacities.data.clone(),
+                   point_ids=node.point_ids[:, 0].to(torch.int32), instances_quats=node.instances_quats.data.clone(),
+                   instances_trans=node.instances_trans.data.clone(), instances_fv=node.instances_fv.clone(),
+                   num_frames=F_, step=node.step, embeddings=node._embeddings.data.clone(), temporal_weight=node.weight.data.clone(),
+                   track_rot_c_w=node.track_rot_c.weight.data.clone(), track_rot_c_b=node.track_rot_c.bias.data.clone(),
+                   track_rot_f_w=node.track_rot_f.weight.data.clone(), track_rot_f_b=node.track_rot_f.bias.data.clone(),
+                   track_trans_c_w=node.track_trans_c.weight.data.clone(), track_trans_c_b=node.track_trans_c.bias.data.clone(),
+                   track_trans_f_w=node.track_trans_f.weight.data.clone(), track_trans_f_b=node.track_trans_f.bias.data.clone())
+        for tag, frame, test in (("train", 2, False), ("train5", 5, False), ("test", 3, True), ("test_edge", 1, True)):
+            node.cur_frame = frame
+            node.in_test_set = test
+            for p in node.parameters():
+                p.grad = None
+            with torch.set_grad_enabled(not test):   # the test-time interpolation is in-place / eval-only in the reference
+                wm = node.transform_means(node._means)
+                wq = node.transform_quats(node._quats)
+                valid = node.get_pts_valid_mask()
+                opac = torch.sigmoid(node._opacities) * valid.float().unsqueeze(-1)
+                wq_act = node.quat_act(wq)
+            gm = torch.randn(wm.shape, generator=g)
+            gq = torch.randn(wq.shape, generator=g)
+            if not test:
+                ((wm * gm).sum() + (wq_act * gq).sum()).backward()
+            # per-actor offsets the reference produced (inputs of this build's pose-table builder)
+            dts, dqs = [], []
+            with torch.no_grad():
+                for a in range(A):
+                    emb = node._embeddings[(node.point_ids == a).squeeze(1), :]
+                    dts.append(node.embedding_track_trans_offset(frame=frame, start_frame=0, end_frame=F_ - 1, embeddings=emb, weight=node.weight[a]))
+                    dqs.append(node.embedding_track_rot_offset(frame=frame, start_frame=0, end_frame=F_ - 1, embeddings=emb, weight=node.weight[a]))
+            rec.update({f"{tag}_frame": frame, f"{tag}_in_test": int(test), f"{tag}_world_means": wm, f"{tag}_world_quats_act": wq_act,
+                        f"{tag}_opacity": opac, f"{tag}_track_trans": torch.stack(dts), f"{tag}_track_rot": torch.stack(dqs),
+                        f"{tag}_gm": gm, f"{tag}_gq": gq})
+            if not test:
+                rec.update({f"{tag}_grad_means": node._means.grad.clone(), f"{tag}_grad_quats": node._quats.grad.clone(),
+                            f"{tag}_grad_instances_trans": node.instances_trans.grad.clone(),
+                            f"{tag}_grad_instances_quats": node.instances_quats.grad.clone()})
+        save("or_rigid.npz", **rec)
+    sys.path.pop(0)
+    unload(["models", "utils", "datasets"])
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "the reference is only mounted in the build container"
+    install_shims()
+    print("S3Gaussian:")
+    gen_s3g()
+    print("OmniRe:")
+    gen_omnire()

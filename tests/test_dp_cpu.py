@@ -1,0 +1,78 @@
+"""-m "not gpu": the N > 1 path of the view-parallel DP layer with world_size-2 gloo processes on CPU
+(view sharding, in-place gradient averaging, densification statistics reduced as sum / sum / max)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from emd_amd import dp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and dp.world_size() == world
+    g = torch.Generator().manual_seed(0)           # identical replicas on every rank
+    params = [torch.nn.Parameter(torch.randn(50, 3, generator=g)), torch.nn.Parameter(torch.randn(50, 16, 3, generator=g)),
+              torch.nn.Parameter(torch.randn(50, 1, generator=g))]
+    views = list(range(6))
+    picked = []
+    for step in range(3):
+        v = views[dp.view_for(step, rank, world, len(views))]
+        picked.append(v)
+        for p in params:
+            p.grad = None
+        # a per-view "loss": gradients differ per view, third parameter untouched by odd views (grad None on some ranks is
+        # not allowed in DP; give it zeros like a rasterizer backward does for invisible Gaussians)
+        loss = sum(((p * (v + 1)) ** 2).sum() for p in params[:2]) + params[2].sum() * (0.0 if v % 2 else 1.0)
+        loss.backward()
+        dp.allreduce_gradients(params)
+    gn = torch.full((50, 1), float(rank + 1))
+    dn = torch.ones(50, 1)
+    mr = torch.arange(50, dtype=torch.float32) * (rank + 1)
+    dp.reduce_densification_stats(gn, dn, mr)
+    torch.save(dict(picked=picked, grads=[p.grad.clone() for p in params], gn=gn, dn=dn, mr=mr), os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_parallel_gradient_averaging_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    # step s: rank r renders view (2 s + r) % 6 -> disjoint views per step, all views covered over 3 steps
+    assert r0["picked"] == [0, 2, 4] and r1["picked"] == [1, 3, 5]
+    for a, b in zip(r0["grads"], r1["grads"]):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)           # replicas hold identical averaged gradients
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(50, 3, generator=g)
+    expect = 0.5 * (2 * p0 * 5 ** 2 + 2 * p0 * 6 ** 2)             # last step: views 4 and 5 -> factors 5 and 6
+    torch.testing.assert_close(r0["grads"][0], expect, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(r0["grads"][2], torch.full((50, 1), 0.5))
+    torch.testing.assert_close(r0["gn"], torch.full((50, 1), 3.0))    # sum over views
+    torch.testing.assert_close(r0["dn"], torch.full((50, 1), 2.0))
+    torch.testing.assert_close(r0["mr"], torch.arange(50, dtype=torch.float32) * 2)   # max over views
+
+
+def test_world_size_one_is_the_reference_step():
+    p = torch.nn.Parameter(torch.ones(4, 3))
+    (p * 3).sum().backward()
+    before = p.grad.clone()
+    dp.allreduce_gradients([p])                # no process group: must be a no-op
+    assert torch.equal(p.grad, before) and dp.world_size() == 1
+    assert dp.view_for(7, 0, 1, 5) == 2
+    vg = torch.tensor([[3.0, 4.0, 9.0], [1.0, 0.0, 0.0]])
+    g, d, r = dp.densification_stats(vg, torch.tensor([5, 0], dtype=torch.int32))
+    assert g[0, 0] == 5.0 and g[1, 0] == 0.0 and d[:, 0].tolist() == [1.0, 0.0] and r.tolist() == [5.0, 0.0]

@@ -1,0 +1,91 @@
+"""-m gpu: the stand-alone HIP motion / SH entry points (through the C ABI) against the golden vectors of the
+imported reference (RigidNodes, eval_sh) and against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from emd_amd import gsplat_api, motion
+from oracle import cpu_oracle as co
+from tests.test_golden_cpu import _heads_from_golden, ld
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("tag", ["train", "train5", "test"])
+def test_hip_motion_forward_matches_reference(tag):
+    z = ld("or_rigid.npz")
+    frame, in_test = int(z[f"{tag}_frame"]), bool(z[f"{tag}_in_test"])
+    heads = _heads_from_golden(z).to(DEV)
+    g = lambda k: torch.tensor(z[k]).to(DEV)
+    ids = g("point_ids")
+    with torch.no_grad():
+        tt, trq = heads(frame, int(z["num_frames"]), g("embeddings"), ids, int(z["step"]))
+        pose = motion.build_actor_pose(g("instances_quats"), g("instances_trans"), g("instances_fv"), frame, tt, trq, in_test)
+        wm, wq, wo = motion.transform_gaussians(g("means"), g("quats"), torch.sigmoid(g("opacity_logits")), ids, pose)
+    np.testing.assert_allclose(wm.cpu().numpy(), z[f"{tag}_world_means"], rtol=1e-6, atol=5e-6)
+    np.testing.assert_allclose(wq.cpu().numpy(), z[f"{tag}_world_quats_act"], atol=2e-6)
+    np.testing.assert_allclose(wo.cpu().numpy(), z[f"{tag}_opacity"][:, 0], atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["train", "train5"])
+def test_hip_motion_backward_matches_reference(tag):
+    z = ld("or_rigid.npz")
+    frame = int(z[f"{tag}_frame"])
+    heads = _heads_from_golden(z).to(DEV)
+    t = lambda k: torch.tensor(z[k]).to(DEV).requires_grad_(True)
+    means, quats, iq, it = t("means"), t("quats"), t("instances_quats"), t("instances_trans")
+    ids = torch.tensor(z["point_ids"]).to(DEV)
+    tt, trq = heads(frame, int(z["num_frames"]), torch.tensor(z["embeddings"]).to(DEV), ids, int(z["step"]))
+    pose = motion.build_actor_pose(iq, it, torch.tensor(z["instances_fv"]).to(DEV), frame, tt, trq)
+    wm, wq, _ = motion.transform_gaussians(means, quats, None, ids, pose)
+    ((wm * torch.tensor(z[f"{tag}_gm"]).to(DEV)).sum() + (wq * torch.tensor(z[f"{tag}_gq"]).to(DEV)).sum()).backward()
+    for got, name in ((means.grad, "grad_means"), (quats.grad, "grad_quats"), (it.grad, "grad_instances_trans"),
+                      (iq.grad, "grad_instances_quats")):
+        ref = z[f"{tag}_{name}"]
+        assert np.abs(got.cpu().numpy() - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), name
+    # the learned track heads receive gradients through the pose table as well
+    assert heads.track_trans_c.weight.grad is not None and heads.track_trans_c.weight.grad.abs().sum() > 0
+    assert heads.weight.grad.abs().sum() > 0
+
+
+def test_hip_motion_mixed_static_and_residual_matches_oracle():
+    rng = np.random.default_rng(0)
+    n, A = 5000, 7
+    means = rng.standard_normal((n, 3)).astype(np.float32)
+    quats = rng.standard_normal((n, 4)).astype(np.float32)
+    opac = rng.random(n).astype(np.float32)
+    ids = rng.integers(-1, A, n).astype(np.int32)
+    pose = rng.standard_normal((A, 12)).astype(np.float32)
+    pose[:, 0:4] /= np.linalg.norm(pose[:, 0:4], axis=1, keepdims=True)
+    pose[:, 8:12] /= np.linalg.norm(pose[:, 8:12], axis=1, keepdims=True)
+    pose[:, 7] = (rng.random(A) > 0.3)
+    rdx = (0.05 * rng.standard_normal((n, 3))).astype(np.float32)
+    rdq = (0.05 * rng.standard_normal((n, 4))).astype(np.float32)
+    wm, wq, wo = co.motion_forward(means, quats, opac, ids, pose, rdx, rdq)
+    g = lambda a: torch.tensor(a).to(DEV)
+    hm, hq, ho = motion.transform_gaussians(g(means), g(quats), g(opac), g(ids), g(pose), g(rdx), g(rdq))
+    np.testing.assert_array_equal(hm.cpu().numpy().view(np.uint32), wm.view(np.uint32))   # same pinned fp32 order: bit-exact
+    np.testing.assert_array_equal(hq.cpu().numpy().view(np.uint32), wq.view(np.uint32))
+    np.testing.assert_array_equal(ho.cpu().numpy().view(np.uint32), wo.view(np.uint32))
+
+
+def test_hip_spherical_harmonics_matches_reference_and_autograd():
+    z = ld("s3g_sh.npz")
+    dirs = torch.tensor(z["xyz"] - z["campos"]).to(DEV)
+    for deg in range(4):
+        out = gsplat_api.spherical_harmonics(deg, dirs, torch.tensor(z["shs"]).to(DEV))
+        np.testing.assert_allclose(out.cpu().numpy(), z[f"sh_deg{deg}"], atol=3e-6)
+    # backward vs fp64 autograd of the reference polynomial
+    from oracle import torch_ref as tr
+    d64 = torch.tensor(z["xyz"] - z["campos"], dtype=torch.float64, requires_grad=True)
+    c64 = torch.tensor(z["shs"], dtype=torch.float64, requires_grad=True)
+    w = torch.randn(z["shs"].shape[0], 3, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    (tr.eval_sh(3, c64.transpose(1, 2), d64 / d64.norm(dim=1, keepdim=True)) * w).sum().backward()
+    dg = dirs.clone().requires_grad_(True)
+    cg = torch.tensor(z["shs"]).to(DEV).requires_grad_(True)
+    (gsplat_api.spherical_harmonics(3, dg, cg) * w.float().to(DEV)).sum().backward()
+    np.testing.assert_allclose(cg.grad.cpu().numpy(), c64.grad.numpy(), atol=1e-5)
+    np.testing.assert_allclose(dg.grad.cpu().numpy(), d64.grad.numpy(), atol=1e-5)
