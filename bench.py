@@ -41,18 +41,24 @@ def algorithmic_bytes(N, V, D, HW, T, C, p, residual=False):
     }
 
 
-def cpu_baseline(scene, cam, budget_s=20.0):
-    """The reference's pure-PyTorch projection + cov3D + SH forward on the host cores."""
+def cpu_baseline(scene, cam, budget_s=15.0):
+    """The reference's pure-PyTorch projection + cov3D + SH forward on the host cores.
+
+    Thread count: measured on the MI355X host (256 hardware threads), torch's intra-op pool is fastest at 64 threads
+    for these element-wise ops (70 M Gaussians/s at N = 1 M) and collapses beyond 128 (profiles/r01_cpu_thread_scan.txt),
+    so min(cores, 64) threads are used and reported.
+    """
     from oracle import torch_ref
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     means, scales, rots, shs = scene.means, torch.exp(scene.log_scales), scene.quats, scene.shs
     V, Pm, cp = cam.world_view_transform, cam.full_proj_transform, cam.camera_center
     times = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        torch_ref.reference_projection_cpu(means, scales, rots, shs, V, Pm, cp, 3)   # warm-up
-        first = time.perf_counter() - t0
+        for _ in range(2):   # warm-up (thread pool, allocator)
+            t0 = time.perf_counter()
+            torch_ref.reference_projection_cpu(means, scales, rots, shs, V, Pm, cp, 3)
+            first = time.perf_counter() - t0
         reps = int(max(3, min(20, budget_s / max(first, 1e-3))))
         for _ in range(reps):
             t0 = time.perf_counter()
@@ -63,7 +69,7 @@ def cpu_baseline(scene, cam, budget_s=20.0):
     return {"value": 1.0 / med, "unit": "iters/s (projection+cov3D+SH forward stage only)", "cores": cores,
             "kind": "port", "ms_per_call": med * 1e3, "gaussians_per_s": scene.N / med,
             "sample": f"reference pure-PyTorch geom_transform_points + get_covariance + eval_sh(deg 3) forward, "
-                      f"N={scene.N}, fp32, median of {len(times)} calls after 1 warm-up"}
+                      f"N={scene.N}, fp32, median of {len(times)} calls after 2 warm-ups, {cores} torch threads"}
 
 
 def main():
