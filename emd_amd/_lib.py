@@ -16,7 +16,7 @@ ACTOR_STRIDE = 12
 BWD_STRIDE = 12
 
 EMD_OK, EMD_ERR_INVALID, EMD_ERR_CAPACITY, EMD_ERR_HIP, EMD_ERR_WORKSPACE = 0, -1, -2, -3, -4
-FLAG_NORMAL, FLAG_MOTION, FLAG_ABSGRAD, FLAG_NO_SYNC, FLAG_CLAMP_RGB01 = 1, 2, 4, 8, 16
+FLAG_NORMAL, FLAG_MOTION, FLAG_ABSGRAD, FLAG_NO_SYNC, FLAG_CLAMP_RGB01, FLAG_RAW_PARAMS = 1, 2, 4, 8, 16, 32
 
 _f = C.c_void_p  # device pointers are passed as integers
 
@@ -69,7 +69,7 @@ class EmdBwdArgs(C.Structure):
 EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_size", "emd_raster_forward",
                     "emd_raster_backward", "emd_raster_export_binning", "emd_raster_export_geometry",
                     "emd_motion_forward", "emd_motion_backward", "emd_sh_forward", "emd_sh_backward",
-                    "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name")
+                    "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward")
 PROF_STAGES = 8
 
 _lib = None
@@ -108,6 +108,7 @@ def load():
         [C.c_void_p] * 10
     lib.emd_sh_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_sh_backward.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6
+    lib.emd_activations_forward.argtypes = [C.c_int32] + [C.c_void_p] * 7
     lib.emd_profile_enable.argtypes = [C.c_int]
     lib.emd_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     lib.emd_profile_stage_name.argtypes = [C.c_int]

@@ -63,6 +63,7 @@ int emd_launch_motion_backward(int n, const float* means, const float* quats, co
 int emd_launch_sh_forward(int n, int deg, int M, const float* dirs, const float* coeffs, float* rgb, hipStream_t st);
 int emd_launch_sh_backward(int n, int deg, int M, const float* dirs, const float* coeffs, const float* g_rgb,
                            float* d_coeffs, float* d_dirs, hipStream_t st);
+int emd_launch_activations(int n, const float* ls, float* sc, const float* rq, float* q, const float* lo, float* o, hipStream_t st);
 int emd_launch_export_geometry(int N, const GeomWs& g, float* means2D, float* depths, float* conic_opacity, float* rgb,
                                float* normal, uint32_t* tiles_touched, hipStream_t st);
 
@@ -129,6 +130,7 @@ static int check_common(const EmdSettings& s, int N, int M, const float* means3D
         if (mo.actor_id && (!mo.actor_pose || mo.num_actors <= 0)) { emd_set_error("motion: actor_id given without actor_pose"); return EMD_ERR_INVALID; }
         if (cov) { emd_set_error("motion: cov3D_precomp cannot be combined with the fused motion transform"); return EMD_ERR_INVALID; }
     }
+    if ((flags & EMD_FLAG_RAW_PARAMS) && cov) { emd_set_error("raw params: cov3D_precomp has no raw form"); return EMD_ERR_INVALID; }
     return EMD_OK;
 }
 
@@ -308,6 +310,12 @@ int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* d
         emd_set_error("sh_backward: bad argument (n=%d degree=%d K=%d)", n, degree, sh_coeffs); return EMD_ERR_INVALID;
     }
     return emd_launch_sh_backward(n, degree, sh_coeffs, dirs, coeffs, dL_drgb, dL_dcoeffs, dL_ddirs, (hipStream_t)hip_stream);
+}
+
+int emd_activations_forward(int32_t n, const float* log_scales, float* scales, const float* raw_quats, float* quats,
+                            const float* opacity_logits, float* opacities, void* hip_stream) {
+    if (n < 0) { emd_set_error("activations_forward: negative n"); return EMD_ERR_INVALID; }
+    return emd_launch_activations(n, log_scales, scales, raw_quats, quats, opacity_logits, opacities, (hipStream_t)hip_stream);
 }
 
 }  // extern "C"

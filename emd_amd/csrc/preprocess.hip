@@ -51,9 +51,13 @@ __device__ __forceinline__ float quat_norm(const float q[4]) {
 }
 
 // World-space mean / quaternion / opacity of Gaussian i under the explicit-motion model.
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// raw = EMD_FLAG_RAW_PARAMS: opacities are logits (sigmoid here), static quaternions are un-normalised (normalised
+// here, F.normalize eps 1e-12) -- the activations of S3Gaussian/gaussian_renderer/__init__.py:99-101 fused in.
 __device__ __forceinline__ void motion_point(int i, const float* __restrict__ means, const float* __restrict__ quats,
                                              const float* __restrict__ opac, const EmdMotion& mo, float wm[3],
-                                             float wq[4], float* wo) {
+                                             float wq[4], float* wo, bool raw = false) {
     float m[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
     if (mo.residual_dx) {
         m[0] += mo.residual_dx[3 * i]; m[1] += mo.residual_dx[3 * i + 1]; m[2] += mo.residual_dx[3 * i + 2];
@@ -61,8 +65,12 @@ __device__ __forceinline__ void motion_point(int i, const float* __restrict__ me
     int a = mo.actor_id ? mo.actor_id[i] : -1;
     if (a < 0) {
         wm[0] = m[0]; wm[1] = m[1]; wm[2] = m[2];
-        if (quats) { const float4 q = *(const float4*)(quats + 4 * i); wq[0] = q.x; wq[1] = q.y; wq[2] = q.z; wq[3] = q.w; }
-        if (opac) *wo = opac[i];
+        if (quats) {
+            const float4 q = *(const float4*)(quats + 4 * i);
+            wq[0] = q.x; wq[1] = q.y; wq[2] = q.z; wq[3] = q.w;
+            if (raw) { const float n = fmaxf(quat_norm(wq), 1e-12f); wq[0] /= n; wq[1] /= n; wq[2] /= n; wq[3] /= n; }
+        }
+        if (opac) *wo = raw ? sigmoidf_(opac[i]) : opac[i];
         return;
     }
     const float4* Pp = (const float4*)(mo.actor_pose + (size_t)a * EMD_ACTOR_STRIDE);
@@ -88,7 +96,7 @@ __device__ __forceinline__ void motion_point(int i, const float* __restrict__ me
         float n2 = fmaxf(quat_norm(p), 1e-12f);
         wq[0] = p[0] / n2; wq[1] = p[1] / n2; wq[2] = p[2] / n2; wq[3] = p[3] / n2;
     }
-    if (opac) *wo = opac[i] * p1.w;
+    if (opac) *wo = (raw ? sigmoidf_(opac[i]) : opac[i]) * p1.w;
 }
 
 __device__ __forceinline__ void sh_basis(int deg, const float d[3], float b[16]) {
@@ -185,12 +193,17 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
         const int W = S.image_width, H = S.image_height;
         const int gx = (W + EMD_TILE_X - 1) / EMD_TILE_X, gy = (H + EMD_TILE_Y - 1) / EMD_TILE_Y;
         const float fx = (float)W / (2.f * S.tanfovx), fy = (float)H / (2.f * S.tanfovy);
-        float m[3], q[4] = {1.f, 0.f, 0.f, 0.f}, op = a.opacities[i];
+        const bool raw = (a.flags & EMD_FLAG_RAW_PARAMS) != 0;
+        float m[3], q[4] = {1.f, 0.f, 0.f, 0.f}, op;
         if (a.flags & EMD_FLAG_MOTION) {
-            motion_point(i, a.means3D, a.rotations, a.opacities, a.motion, m, q, &op);
+            motion_point(i, a.means3D, a.rotations, a.opacities, a.motion, m, q, &op, raw);
         } else {
+            op = raw ? sigmoidf_(a.opacities[i]) : a.opacities[i];
             m[0] = a.means3D[3 * i]; m[1] = a.means3D[3 * i + 1]; m[2] = a.means3D[3 * i + 2];
-            if (a.rotations) { const float4 qq = *(const float4*)(a.rotations + 4 * i); q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w; }
+            if (a.rotations) {
+                const float4 qq = *(const float4*)(a.rotations + 4 * i); q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
+                if (raw) { const float n = fmaxf(quat_norm(q), 1e-12f); q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
+            }
         }
         Proj p;
         p.tx = ((V[0] * m[0] + V[4] * m[1]) + V[8] * m[2]) + V[12];
@@ -209,6 +222,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
                 for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * i + k];
             } else {
                 sc[0] = a.scales[3 * i]; sc[1] = a.scales[3 * i + 1]; sc[2] = a.scales[3 * i + 2];
+                if (raw) { sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]); }
                 cov3d_from_sr(sc, S.scale_modifier, q, c3);
             }
             project_cov2d(S, m, c3, fx, fy, p);
@@ -346,7 +360,7 @@ __device__ __forceinline__ void motion_point_backward(int i, int a_id, const flo
                                                       const float* __restrict__ quats, const float* __restrict__ opac,
                                                       const EmdMotion& mo, const float dm[3], const float dq[4],
                                                       float dop, float dl[3], float dql[4], float* dopl,
-                                                      float pose_g[12]) {
+                                                      float pose_g[12], bool raw = false) {
     const float4* Pp = (const float4*)(mo.actor_pose + (size_t)a_id * EMD_ACTOR_STRIDE);
     const float4 p0 = Pp[0], p1 = Pp[1], p2 = Pp[2];
     const float qm[4] = {p0.x, p0.y, p0.z, p0.w};
@@ -365,7 +379,7 @@ __device__ __forceinline__ void motion_point_backward(int i, int a_id, const flo
     dR_to_dq(qm, dRm, dqm);
     pose_g[0] = dqm[0]; pose_g[1] = dqm[1]; pose_g[2] = dqm[2]; pose_g[3] = dqm[3];
     pose_g[4] = dm[0]; pose_g[5] = dm[1]; pose_g[6] = dm[2];
-    pose_g[7] = opac ? dop * opac[i] : 0.f;
+    pose_g[7] = opac ? dop * (raw ? sigmoidf_(opac[i]) : opac[i]) : 0.f;
     pose_g[8] = pose_g[9] = pose_g[10] = pose_g[11] = 0.f;
     dql[0] = dql[1] = dql[2] = dql[3] = 0.f;
     if (quats) {
@@ -435,13 +449,21 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
     for (int k = 0; k < 12; k++) pose_g[k] = 0.f;
     if (in_range) {
         const bool visible = a.radii[i] > 0;
-        float m[3], q[4] = {1.f, 0.f, 0.f, 0.f}, op = a.opacities[i];
+        const bool raw = (a.flags & EMD_FLAG_RAW_PARAMS) != 0;
+        float m[3], q[4] = {1.f, 0.f, 0.f, 0.f}, op, q_norm = 1.f;
         if (a.flags & EMD_FLAG_MOTION) {
-            motion_point(i, a.means3D, a.rotations, a.opacities, a.motion, m, q, &op);
+            motion_point(i, a.means3D, a.rotations, a.opacities, a.motion, m, q, &op, raw);
             a_id = a.motion.actor_id ? a.motion.actor_id[i] : -1;
         } else {
+            op = raw ? sigmoidf_(a.opacities[i]) : a.opacities[i];
             m[0] = a.means3D[3 * i]; m[1] = a.means3D[3 * i + 1]; m[2] = a.means3D[3 * i + 2];
             if (a.rotations) { const float4 qq = *(const float4*)(a.rotations + 4 * i); q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w; }
+        }
+        if (raw && a_id < 0 && a.rotations) {   // static point: q is the raw quaternion (no-motion path) or already unit (motion path)
+            const float4 qq = *(const float4*)(a.rotations + 4 * i);
+            const float qr[4] = {qq.x, qq.y, qq.z, qq.w};
+            q_norm = fmaxf(quat_norm(qr), 1e-12f);
+            q[0] = qr[0] / q_norm; q[1] = qr[1] / q_norm; q[2] = qr[2] / q_norm; q[3] = qr[3] / q_norm;
         }
         float gcol[3] = {0.f, 0.f, 0.f};
         if (visible) {
@@ -492,6 +514,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
                 for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * i + k];
             } else {
                 sc[0] = a.scales[3 * i]; sc[1] = a.scales[3 * i + 1]; sc[2] = a.scales[3 * i + 2];
+                if (raw) { sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]); }
                 cov3d_from_sr(sc, S.scale_modifier, q, c3);
             }
             project_cov2d(S, m, c3, fx, fy, p);
@@ -560,6 +583,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
                     for (int r = 0; r < 3; r++) dR[3 * r + k] = dL[3 * r + k] * (mod * sc[k]);
                 }
                 dR_to_dq(q, dR, dq);
+                if (raw) { ds[0] *= sc[0]; ds[1] *= sc[1]; ds[2] *= sc[2]; }   // d exp(x) = exp(x)
             }
         } else if (a.dL_dshs) {
             float* o = a.dL_dshs + (size_t)i * a.M * 3;
@@ -576,7 +600,12 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
         // (h) explicit motion
         float dl[3] = {dm[0], dm[1], dm[2]}, dql[4] = {dq[0], dq[1], dq[2], dq[3]}, dopl = dop;
         if (a_id >= 0)
-            motion_point_backward(i, a_id, a.means3D, a.rotations, a.opacities, a.motion, dm, dq, dop, dl, dql, &dopl, pose_g);
+            motion_point_backward(i, a_id, a.means3D, a.rotations, a.opacities, a.motion, dm, dq, dop, dl, dql, &dopl, pose_g, raw);
+        if (raw) {
+            if (a_id < 0 && a.rotations) dnormalize4(q, q_norm, dq, dql);          // through F.normalize of the raw quaternion
+            const float o = sigmoidf_(a.opacities[i]);
+            dopl *= o * (1.f - o);                                                 // through the sigmoid
+        }
         if (a.dL_dmeans3D) { a.dL_dmeans3D[3 * i] = dl[0]; a.dL_dmeans3D[3 * i + 1] = dl[1]; a.dL_dmeans3D[3 * i + 2] = dl[2]; }
         if (a.dL_dresidual_dx) { a.dL_dresidual_dx[3 * i] = dl[0]; a.dL_dresidual_dx[3 * i + 1] = dl[1]; a.dL_dresidual_dx[3 * i + 2] = dl[2]; }
         if (a.dL_drotations) *(float4*)(a.dL_drotations + 4 * i) = make_float4(dql[0], dql[1], dql[2], dql[3]);
@@ -692,6 +721,20 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_export_geometry(int N, const floa
     if (tiles_touched) tiles_touched[i] = tt[i];
 }
 
+__global__ void __launch_bounds__(EMD_BLOCK) k_activations(int n, const float* ls, float* sc, const float* rq, float* q,
+                                                           const float* lo, float* o) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (ls && sc) { sc[3 * i] = expf(ls[3 * i]); sc[3 * i + 1] = expf(ls[3 * i + 1]); sc[3 * i + 2] = expf(ls[3 * i + 2]); }
+    if (rq && q) {
+        const float4 t = *(const float4*)(rq + 4 * i);
+        float v[4] = {t.x, t.y, t.z, t.w};
+        const float nn = fmaxf(quat_norm(v), 1e-12f);
+        *(float4*)(q + 4 * i) = make_float4(v[0] / nn, v[1] / nn, v[2] / nn, v[3] / nn);
+    }
+    if (lo && o) o[i] = sigmoidf_(lo[i]);
+}
+
 }  // namespace
 
 int emd_launch_preprocess(const PreArgs& a, hipStream_t st) {
@@ -751,6 +794,13 @@ int emd_launch_export_geometry(int N, const GeomWs& g, float* means2D, float* de
     if (N <= 0) return EMD_OK;
     hipLaunchKernelGGL(k_export_geometry, dim3((N + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, N, g.rec,
                        g.tiles_touched, means2D, depths, conic_opacity, rgb, normal, tiles_touched);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_activations(int n, const float* ls, float* sc, const float* rq, float* q, const float* lo, float* o, hipStream_t st) {
+    if (n <= 0) return EMD_OK;
+    hipLaunchKernelGGL(k_activations, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, ls, sc, rq, q, lo, o);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

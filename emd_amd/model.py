@@ -45,7 +45,7 @@ class StreetGaussians(torch.nn.Module):
         return torch.cat([q, self.instances_trans[frame], self.instances_fv[frame].float()[:, None], q], dim=1)
 
 
-def render(model: StreetGaussians, cam, bg, frame=0, debug=False):
+def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activations=True):
     """The reference render() restricted to the hot path; returns the dict the training loop consumes."""
     dev = model._xyz.device
     screenspace_points = torch.zeros_like(model._xyz, requires_grad=True)
@@ -54,15 +54,19 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False):
         bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
         sh_degree=model.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=debug)
     rasterizer = GaussianRasterizer(raster_settings=rs)
-    scales = torch.exp(model._scaling)
-    rotations = F.normalize(model._rotation)
-    opacity = torch.sigmoid(model._opacity)
+    if fuse_activations:
+        # the three activations of the reference run inside K1 / K8 (raw_params), not as ~25 separate torch launches
+        scales, rotations, opacity = model._scaling, model._rotation, model._opacity
+    else:
+        scales = torch.exp(model._scaling)
+        rotations = F.normalize(model._rotation)
+        opacity = torch.sigmoid(model._opacity)
     kw = {}
     if model.has_actors:
         kw = dict(actor_ids=model.actor_id, actor_pose=model.actor_pose(frame))
     image, depth, normal, weight, radii, _ = rasterizer(
         means3D=model._xyz, means2D=screenspace_points, shs=model._features, colors_precomp=None, opacities=opacity,
-        scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, **kw)
+        scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, raw_params=fuse_activations, **kw)
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
             "depth": depth, "weight": weight, "normal": normal}
 

@@ -251,7 +251,7 @@ class GaussianRasterizer(nn.Module):
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3Ds_precomp=None, extra_attrs=None, actor_ids: Optional[torch.Tensor] = None,
                 actor_pose: Optional[torch.Tensor] = None, residual_dx: Optional[torch.Tensor] = None,
-                residual_dq: Optional[torch.Tensor] = None):
+                residual_dq: Optional[torch.Tensor] = None, raw_params: bool = False):
         rs = self.raster_settings
         if (shs is None) == (colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
@@ -282,6 +282,12 @@ class GaussianRasterizer(nn.Module):
             flags |= L.FLAG_ABSGRAD
         if RasterConfig.clamp_rgb01:
             flags |= L.FLAG_CLAMP_RGB01
+        if raw_params:
+            # scales / rotations / opacities are the raw parameters; exp / normalize / sigmoid
+            # (S3Gaussian/gaussian_renderer/__init__.py:99-101) run inside the projection kernel, forward and backward
+            if cov3Ds_precomp is not None:
+                raise ValueError("raw_params needs scales / rotations, not cov3Ds_precomp")
+            flags |= L.FLAG_RAW_PARAMS
         if actor_ids is not None or residual_dx is not None or residual_dq is not None:
             flags |= L.FLAG_MOTION
             if actor_ids is not None:

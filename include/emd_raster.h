@@ -62,7 +62,10 @@ enum {
     EMD_FLAG_ABSGRAD  = 1 << 2, /* backward also accumulates sum |d L/d mean2D| (gsplat absgrad) */
     EMD_FLAG_NO_SYNC  = 1 << 3, /* never read the duplicate count back to the host; overflow is reported
                                    through EmdStatus.overflow only (graph-capturable path) */
-    EMD_FLAG_CLAMP_RGB01 = 1 << 4 /* SH colour clamped to [0,1] (OmniRe, rigid.py:585) instead of >= 0 */
+    EMD_FLAG_CLAMP_RGB01 = 1 << 4, /* SH colour clamped to [0,1] (OmniRe, rigid.py:585) instead of >= 0 */
+    EMD_FLAG_RAW_PARAMS = 1 << 5   /* inputs are the raw parameters: scales = log-scales (exp applied here), rotations
+                                      un-normalised (normalised here), opacities = logits (sigmoid here); gradients are
+                                      returned w.r.t. the raw parameters.  Fuses S3Gaussian/gaussian_renderer/__init__.py:99-101 */
 };
 
 /* The 12 fields of GaussianRasterizationSettings (S3Gaussian/gaussian_renderer/__init__.py:49-62), by value. */
@@ -232,6 +235,10 @@ int emd_sh_forward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* di
                    const float* coeffs /*[N,K,3]*/, float* rgb /*[N,3]*/, void* hip_stream);
 int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* dirs, const float* coeffs,
                     const float* dL_drgb, float* dL_dcoeffs, float* dL_ddirs /*or NULL*/, void* hip_stream);
+
+/* The activations exactly as EMD_FLAG_RAW_PARAMS applies them (exp, F.normalize, sigmoid); any pair may be NULL. */
+int emd_activations_forward(int32_t n, const float* log_scales, float* scales, const float* raw_quats, float* quats,
+                            const float* opacity_logits, float* opacities, void* hip_stream);
 
 /* Per-stage device timing with HIP events recorded on the caller's stream around each stage (bench.py's roofline
  * leg).  Stages: see emd_profile_stage_name().  emd_profile_read synchronises on the recorded events, adds the

@@ -129,3 +129,77 @@ def test_round_trip_properties_full_size():
     c2, _, _, a2, _, _ = r(colors_precomp=2 * col, **args)
     torch.testing.assert_close(c2, 2 * c1, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(a2, a1, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("motion", [False, True], ids=["static", "motion"])
+def test_fused_activations_raw_params(motion):
+    """EMD_FLAG_RAW_PARAMS: exp / normalize / sigmoid (gaussian_renderer/__init__.py:99-101) fused into K1 / K8.
+    The oracle is fed the activations exactly as the library computes them (emd_activations_forward), so the integer
+    contract stays bit-exact; gradients are chained through the activations in numpy."""
+    import ctypes as C
+    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer, RasterConfig, _lib as L
+    from tests.helpers import oracle_scene, oracle_settings
+    from oracle import cpu_oracle as co
+    case = make_case(n=4000, H=64, W=96, seed=61, motion=motion)
+    dev = torch.device("cuda:0")
+    N = case["N"]
+    g = torch.Generator().manual_seed(5)
+    log_s = torch.log(case["scales"]).to(dev).requires_grad_(True)
+    raw_q = (case["rotations"] * (0.5 + torch.rand(N, 1, generator=g))).to(dev).requires_grad_(True)
+    logit = torch.logit(case["opacities"].clamp(1e-4, 1 - 1e-4)).to(dev).requires_grad_(True)
+    # activations as the library computes them
+    s_act, q_act, o_act = torch.empty(N, 3, device=dev), torch.empty(N, 4, device=dev), torch.empty(N, device=dev)
+    L.check(L.load().emd_activations_forward(N, log_s.data_ptr(), s_act.data_ptr(), raw_q.data_ptr(), q_act.data_ptr(),
+                                             logit.data_ptr(), o_act.data_ptr(), None), "emd_activations_forward")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(s_act, torch.exp(log_s.detach()), rtol=2e-6, atol=0)
+    torch.testing.assert_close(o_act, torch.sigmoid(logit.detach()).reshape(-1), rtol=2e-6, atol=1e-7)
+    ocase = dict(case)
+    ocase["scales"], ocase["opacities"] = s_act.cpu(), o_act.cpu()[:, None]
+    rots = q_act.cpu().clone()
+    if motion:   # actor points are normalised inside the motion transform from the raw quaternion
+        dyn = case["actor_ids"] >= 0
+        rots[dyn] = raw_q.detach().cpu()[dyn]
+    ocase["rotations"] = rots
+    orc = run_oracle(ocase, backward=True)
+    cam = case["cam"]
+    rs = GaussianRasterizationSettings(case["H"], case["W"], cam.tanfovx, cam.tanfovy, case["bg"], 1.0, cam.world_view_transform,
+                                       cam.full_proj_transform, case["sh_degree"], cam.camera_center, False, True)
+    means = case["means3D"].to(dev).requires_grad_(True)
+    shs = case["shs"].to(dev).requires_grad_(True)
+    m2 = torch.zeros(N, 3, device=dev, requires_grad=True)
+    kw = {}
+    if motion:
+        pose = case["actor_pose"].to(dev).requires_grad_(True)
+        kw = dict(actor_ids=case["actor_ids"].to(dev), actor_pose=pose)
+    RasterConfig.compute_normal = True
+    color, depth, normal, alpha, radii, _ = GaussianRasterizer(rs)(means3D=means, means2D=m2, shs=shs, opacities=logit, scales=log_s,
+                                                                  rotations=raw_q, raw_params=True, **kw)
+    keys, ids, ranges = GaussianRasterizer.export_binning()
+    np.testing.assert_array_equal(radii.cpu().numpy(), orc["pre"]["radii"])
+    np.testing.assert_array_equal(keys.cpu().numpy().view(np.uint64), orc["bin"]["keys"])
+    np.testing.assert_array_equal(ids.cpu().numpy().view(np.uint32), orc["bin"]["ids"])
+    for name, t in (("color", color), ("depth", depth), ("alpha", alpha), ("normal", normal)):
+        scale = max(1.0, float(np.abs(orc["img"][name]).max())) if name == "depth" else 1.0
+        assert np.abs(t.detach().cpu().numpy() - orc["img"][name]).max() <= IMAGE_TOL * scale, name
+    tc = lambda a: torch.from_numpy(a).to(dev)
+    ((color * tc(case["dL_dcolor"])).sum() + (depth * tc(case["dL_ddepth"])).sum() + (alpha * tc(case["dL_dalpha"])).sum()).backward()
+    go = orc["grads"]
+    s_np, o_np = s_act.cpu().numpy(), o_act.cpu().numpy()
+    exp_ls = go["scales"] * s_np
+    exp_logit = go["opacities"] * o_np * (1 - o_np)
+    rq = raw_q.detach().cpu().numpy().astype(np.float64)
+    nrm = np.linalg.norm(rq, axis=1, keepdims=True)
+    qu = rq / nrm
+    gq = go["rotations"].astype(np.float64)
+    exp_q = (gq - qu * (qu * gq).sum(1, keepdims=True)) / nrm
+    if motion:
+        exp_q[dyn.numpy()] = go["rotations"][dyn.numpy()]      # oracle already differentiates the in-transform normalisation
+    rel = lambda a, r: np.abs(a - r).max() / max(np.abs(r).max(), 1e-12)
+    assert rel(log_s.grad.cpu().numpy(), exp_ls) < GRAD_RTOL
+    assert rel(logit.grad.cpu().numpy().reshape(-1), exp_logit) < GRAD_RTOL
+    assert rel(raw_q.grad.cpu().numpy(), exp_q) < GRAD_RTOL
+    assert rel(means.grad.cpu().numpy(), go["means3D"]) < GRAD_RTOL
+    assert rel(shs.grad.cpu().numpy(), go["shs"]) < GRAD_RTOL
+    if motion:
+        assert rel(pose.grad.cpu().numpy(), go["actor_pose"]) < GRAD_RTOL
