@@ -179,11 +179,55 @@ __device__ __forceinline__ void project_cov2d(const EmdSettings& S, const float 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// SH rows through LDS.  shs is [N,16,3]: 192 contiguous bytes per Gaussian, so one-Gaussian-per-lane loads/stores
+// touch 64 different cache lines per instruction.  Instead the block moves its 256 rows (48 KiB, contiguous in HBM)
+// with fully coalesced dwordx4 accesses and each lane reads / writes its own row in LDS.  Rows are padded to
+// 13 float4 (52 dwords): 52 t mod 64 takes 16 distinct multiples of 4, so a ds_read_b128 lane group is conflict-free.
+// ---------------------------------------------------------------------------------------------------
+#define SH_ROW4 13
+__device__ __forceinline__ void sh_block_load(const float* __restrict__ shs, int N, float4* s_sh) {
+    const size_t base4 = (size_t)blockIdx.x * EMD_BLOCK * 12, lim4 = (size_t)N * 12;
+    const float4* src = (const float4*)shs;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const uint32_t idx = threadIdx.x + EMD_BLOCK * j;
+        if (base4 + idx < lim4) s_sh[(idx / 12) * SH_ROW4 + (idx % 12)] = src[base4 + idx];
+    }
+}
+__device__ __forceinline__ void sh_block_store(float* __restrict__ dst, int N, const float4* s_sh) {
+    const size_t base4 = (size_t)blockIdx.x * EMD_BLOCK * 12, lim4 = (size_t)N * 12;
+    float4* out = (float4*)dst;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const uint32_t idx = threadIdx.x + EMD_BLOCK * j;
+        if (base4 + idx < lim4) out[base4 + idx] = s_sh[(idx / 12) * SH_ROW4 + (idx % 12)];
+    }
+}
+// this lane's 48 coefficients [k][c] into registers (staged row, or straight from HBM for M != 16)
+__device__ __forceinline__ void sh_row_load(bool staged, const float4* s_sh, const float* __restrict__ shs, int i, int M,
+                                            int K, float v[48]) {
+    if (staged) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const float4 t = s_sh[threadIdx.x * SH_ROW4 + j];
+            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+        }
+    } else {
+        const float* sh = shs + (size_t)i * M * 3;
+#pragma unroll
+        for (int k = 0; k < 48; k++) v[k] = (k < 3 * K) ? sh[k] : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
     __shared__ uint32_t s_red[8];
+    __shared__ float4 s_sh[EMD_BLOCK * SH_ROW4];
     const EmdSettings& S = a.s;
+    const bool sh_staged = a.shs && a.M == 16;
+    if (sh_staged) { sh_block_load(a.shs, a.N, s_sh); __syncthreads(); }
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
     uint32_t touched = 0;
     int radius_out = 0;
@@ -253,10 +297,12 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
                         float bs[16];
                         sh_basis(S.sh_degree, d, bs);
                         const int K = (S.sh_degree + 1) * (S.sh_degree + 1);
-                        const float* sh = a.shs + (size_t)i * a.M * 3;
+                        float sh[48];
+                        sh_row_load(sh_staged, s_sh, a.shs, i, a.M, K, sh);
                         col[0] = col[1] = col[2] = 0.f;
-                        for (int k = 0; k < K; k++) {
-                            col[0] += bs[k] * sh[3 * k]; col[1] += bs[k] * sh[3 * k + 1]; col[2] += bs[k] * sh[3 * k + 2];
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            if (k < K) { col[0] += bs[k] * sh[3 * k]; col[1] += bs[k] * sh[3 * k + 1]; col[2] += bs[k] * sh[3 * k + 2]; }
                         }
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++) {
@@ -434,6 +480,9 @@ __device__ __forceinline__ void reduce_pose_grad(int a_id, const float pose_g[12
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a) {
     const EmdSettings& S = a.s;
+    __shared__ float4 s_sh[EMD_BLOCK * SH_ROW4];
+    const bool sh_staged = a.shs && a.M == 16;
+    if (sh_staged) { sh_block_load(a.shs, a.N, s_sh); __syncthreads(); }
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
     const bool in_range = i < a.N;
     const float* V = S.viewmatrix;
@@ -490,18 +539,31 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
                 for (int ch = 0; ch < 3; ch++) gc[ch] = ((bits >> ch) & 1u) ? 0.f : gcol[ch];
                 const int deg = S.sh_degree;
                 const int K = (deg + 1) * (deg + 1);
-                const float* sh = a.shs + (size_t)i * a.M * 3;
+                float sh[48];
+                sh_row_load(sh_staged, s_sh, a.shs, i, a.M, K, sh);
                 float bs[16];
                 sh_basis(deg, d, bs);
-                if (a.dL_dshs) {
-                    float* o = a.dL_dshs + (size_t)i * a.M * 3;
-                    for (int k = 0; k < a.M; k++) {
-                        float bk = k < K ? bs[k] : 0.f;
-                        o[3 * k] = bk * gc[0]; o[3 * k + 1] = bk * gc[1]; o[3 * k + 2] = bk * gc[2];
-                    }
-                }
                 float gd[3];
                 sh_dir_backward(deg, d, sh, gc, gd);
+                if (a.dL_dshs) {
+                    if (sh_staged) {          // own row only: overwrite the coefficients with their gradients
+                        float g48[48];
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const float bk = k < K ? bs[k] : 0.f;
+                            g48[3 * k] = bk * gc[0]; g48[3 * k + 1] = bk * gc[1]; g48[3 * k + 2] = bk * gc[2];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 12; j++)
+                            s_sh[threadIdx.x * SH_ROW4 + j] = make_float4(g48[4 * j], g48[4 * j + 1], g48[4 * j + 2], g48[4 * j + 3]);
+                    } else {
+                        float* o = a.dL_dshs + (size_t)i * a.M * 3;
+                        for (int k = 0; k < a.M; k++) {
+                            float bk = k < K ? bs[k] : 0.f;
+                            o[3 * k] = bk * gc[0]; o[3 * k + 1] = bk * gc[1]; o[3 * k + 2] = bk * gc[2];
+                        }
+                    }
+                }
                 float dot = (d[0] * gd[0] + d[1] * gd[1]) + d[2] * gd[2];
 #pragma unroll
                 for (int k = 0; k < 3; k++) dm[k] += (gd[k] - d[k] * dot) / n;
@@ -586,8 +648,13 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
                 if (raw) { ds[0] *= sc[0]; ds[1] *= sc[1]; ds[2] *= sc[2]; }   // d exp(x) = exp(x)
             }
         } else if (a.dL_dshs) {
-            float* o = a.dL_dshs + (size_t)i * a.M * 3;
-            for (int k = 0; k < 3 * a.M; k++) o[k] = 0.f;
+            if (sh_staged) {
+#pragma unroll
+                for (int j = 0; j < 12; j++) s_sh[threadIdx.x * SH_ROW4 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                float* o = a.dL_dshs + (size_t)i * a.M * 3;
+                for (int k = 0; k < 3 * a.M; k++) o[k] = 0.f;
+            }
         }
         if (a.dL_dmeans2D) { a.dL_dmeans2D[3 * i] = gm2[0]; a.dL_dmeans2D[3 * i + 1] = gm2[1]; a.dL_dmeans2D[3 * i + 2] = 0.f; }
         if (a.dL_dmeans2D_abs) { a.dL_dmeans2D_abs[2 * i] = gabs[0]; a.dL_dmeans2D_abs[2 * i + 1] = gabs[1]; }
@@ -614,6 +681,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
         }
         if (a.dL_dopacities) a.dL_dopacities[i] = dopl;
     }
+    if (sh_staged && a.dL_dshs) { __syncthreads(); sh_block_store(a.dL_dshs, a.N, s_sh); }
     if ((a.flags & EMD_FLAG_MOTION) && a.dL_dactor_pose) reduce_pose_grad(a_id, pose_g, a.dL_dactor_pose);
 }
 
