@@ -143,28 +143,34 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_forward(RenderDims d, cons
         const uint32_t n = build_quadrant_lists(qmask, s_list, s_qcnt);
         if (__ballot(!done) == 0ull) continue;  // whole wave finished: keep feeding the barriers only
         const uint16_t* list = s_list[wave];
+        if (n == 0) continue;
+        // software pipeline: the index and record of entry i+1 are in flight while entry i is evaluated
+        uint32_t j = list[0];
+        float4 g0 = s0[j], g1 = s1[j];
         for (uint32_t i = 0; i < n; i++) {
-            const uint32_t j = list[i];
-            const float4 g0 = s0[j], g1 = s1[j];
+            const uint32_t jn = list[min(i + 1, n - 1)];
+            const float4 g0n = s0[jn], g1n = s1[jn];
             const float dx = g0.x - pfx, dy = g0.y - pfy;
             const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
             const float alpha = fminf(0.99f, g0.w * __expf(power));
             const bool hit = !done && power <= 0.f && alpha >= (1.f / 255.f);
-            if (__ballot(hit) == 0ull) continue;
-            if (hit) {
-                const float test_T = T * (1.f - alpha);
-                if (test_T < 0.0001f) {
-                    done = true;
-                } else {
-                    const float w = alpha * T;
-                    const float4 g2 = s2[j];
-                    C0 += g2.x * w; C1 += g2.y * w; C2 += g2.z * w;
-                    Dz += g0.z * w;
-                    if (NORMAL) { const float4 g3 = s3[j]; N0 += g3.x * w; N1 += g3.y * w; N2 += g3.z * w; }
-                    T = test_T;
-                    last = base - start + j + 1;   // 1-based position in the tile list
+            if (__ballot(hit) != 0ull) {
+                if (hit) {
+                    const float test_T = T * (1.f - alpha);
+                    if (test_T < 0.0001f) {
+                        done = true;
+                    } else {
+                        const float w = alpha * T;
+                        const float4 g2 = s2[j];
+                        C0 += g2.x * w; C1 += g2.y * w; C2 += g2.z * w;
+                        Dz += g0.z * w;
+                        if (NORMAL) { const float4 g3 = s3[j]; N0 += g3.x * w; N1 += g3.y * w; N2 += g3.z * w; }
+                        T = test_T;
+                        last = base - start + j + 1;   // 1-based position in the tile list
+                    }
                 }
             }
+            j = jn; g0 = g0n; g1 = g1n;
         }
     }
     if (inside) {
