@@ -47,6 +47,30 @@ __device__ __forceinline__ float wave_shift_up1_f32(float v, float fill) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), DPP_WAVE_SHR1, 0xf, 0xf, false));
 }
 
+// Hand-fused scans: one VALU op per step (v_mul_f32_dpp / v_add_f32_dpp with the destination doubling as `old`, so
+// lanes without a valid source keep their value).  hipcc emits v_mov_b32_dpp + v_mul_f32 (+ an identity v_mov) per
+// step for the product scan.  The s_nop 1 in front of each step covers the VALU-write -> DPP-read hazard, which the
+// compiler does not pad inside asm statements.
+#define EMD_DPP_STEP(op, v, ctrl) asm volatile("s_nop 1\n\t" op " %0, %0, %0 " ctrl : "+v"(v))
+__device__ __forceinline__ float wave_scan_mul_f32_asm(float v) {
+    EMD_DPP_STEP("v_mul_f32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP("v_mul_f32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP("v_mul_f32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP("v_mul_f32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP("v_mul_f32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    EMD_DPP_STEP("v_mul_f32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add_f32_asm(float v) {
+    EMD_DPP_STEP("v_add_f32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP("v_add_f32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP("v_add_f32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP("v_add_f32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP("v_add_f32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    EMD_DPP_STEP("v_add_f32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    return v;
+}
+
 // Sum over the wave, valid in lane 63 only.
 __device__ __forceinline__ float wave_reduce_to_lane63(float v) { return wave_scan_add_f32(v); }
 

@@ -290,8 +290,10 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
             if (NORMAL) g3 = s3[j];
             const uint32_t pos = done_cnt + j;                       // 0-based position in the tile list
             const uint32_t first_pos = readlane_u32(pos, 0);         // list is ascending: lane 0 is the front-most
-            float a_mx = 0.f, a_my = 0.f, a_dz = 0.f, a_op = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_r = 0.f,
-                  a_g = 0.f, a_b = 0.f, a_ax = 0.f, a_ay = 0.f;
+            // per-entry sums over the quadrant's pixels.  With u = G dL/dG the conic / mean derivatives are moments of u:
+            //   m0 = sum u, m1 = sum u d, m2 = sum u d d^T  =>  d mean = -Conic m1, d conic = -(1/2, 1, 1/2) m2, d opacity = m0 / o
+            float m0 = 0.f, m1x = 0.f, m1y = 0.f, m2xx = 0.f, m2xy = 0.f, m2yy = 0.f, a_dz = 0.f, a_r = 0.f, a_g = 0.f,
+                  a_b = 0.f, a_ax = 0.f, a_ay = 0.f;
             for (int p = 0; p < EMD_WAVE; p++) {
                 const uint32_t n_p = readlane_u32(my_n, p);
                 if (n_p <= first_pos) continue;                      // pixel p terminated before this batch
@@ -304,7 +306,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
                 if (__ballot(hit) == 0ull) continue;
                 const float a = hit ? alpha : 0.f;
                 const float om = 1.f - a;
-                const float t_incl = wave_scan_mul_f32(om);
+                const float t_incl = wave_scan_mul_f32_asm(om);
                 const float cTp = readlane_f32(cT, p), cSp = readlane_f32(cS, p);
                 const float Tk = cTp * wave_shift_up1_f32(t_incl, 1.f);
                 const float w = a * Tk;
@@ -312,21 +314,19 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
                             cd = readlane_f32(dD, p);
                 float g = g2.x * c0 + g2.y * c1 + g2.z * c2 + g0.z * cd;
                 if (NORMAL) g += g3.x * readlane_f32(dN0, p) + g3.y * readlane_f32(dN1, p) + g3.z * readlane_f32(dN2, p);
-                const float s_incl = wave_scan_add_f32(g * w);
+                const float s_incl = wave_scan_add_f32_asm(g * w);
                 const float Sk = cSp + s_incl;
                 const float inv = __builtin_amdgcn_rcpf(om);
                 float dL_da = g * Tk + inv * (readlane_f32(Q, p) + Sk);
                 dL_da = hit ? dL_da : 0.f;
-                const float dL_dG = g0.w * dL_da;
-                const float gdx = G * dx, gdy = G * dy;
-                const float v_mx = dL_dG * (-gdx * g1.x - gdy * g1.y);
-                const float v_my = dL_dG * (-gdy * g1.z - gdx * g1.y);
-                a_mx += v_mx; a_my += v_my;
-                if (ABS) { a_ax += fabsf(v_mx); a_ay += fabsf(v_my); }
-                a_ca += -0.5f * gdx * dx * dL_dG;
-                a_cb += -gdx * dy * dL_dG;
-                a_cc += -0.5f * gdy * dy * dL_dG;
-                a_op += G * dL_da;
+                const float u = G * (g0.w * dL_da);                  // G dL/dG
+                const float ux = u * dx, uy = u * dy;
+                m0 += u; m1x += ux; m1y += uy;
+                m2xx += ux * dx; m2xy += ux * dy; m2yy += uy * dy;
+                if (ABS) {
+                    a_ax += fabsf(ux * g1.x + uy * g1.y);
+                    a_ay += fabsf(uy * g1.z + ux * g1.y);
+                }
                 a_dz += w * cd;
                 a_r += w * c0; a_g += w * c1; a_b += w * c2;
                 // carry the running T and S of pixel p to the next batch
@@ -336,8 +336,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
             }
             if (valid) {
                 float* row = s_acc[j];   // the 4 waves may meet on one entry: LDS float atomics
-                atomicAdd(row + 0, a_mx); atomicAdd(row + 1, a_my); atomicAdd(row + 2, a_dz); atomicAdd(row + 3, a_op);
-                atomicAdd(row + 4, a_ca); atomicAdd(row + 5, a_cb); atomicAdd(row + 6, a_cc);
+                atomicAdd(row + 0, -(g1.x * m1x + g1.y * m1y)); atomicAdd(row + 1, -(g1.z * m1y + g1.y * m1x));
+                atomicAdd(row + 2, a_dz); atomicAdd(row + 3, m0 * __builtin_amdgcn_rcpf(g0.w));
+                atomicAdd(row + 4, -0.5f * m2xx); atomicAdd(row + 5, -m2xy); atomicAdd(row + 6, -0.5f * m2yy);
                 atomicAdd(row + 7, a_r); atomicAdd(row + 8, a_g); atomicAdd(row + 9, a_b);
                 if (ABS) { atomicAdd(row + 10, a_ax); atomicAdd(row + 11, a_ay); }
             }

@@ -176,6 +176,7 @@ class _Rasterize(torch.autograd.Function):
                               residual_dx, residual_dq, actor_ids, radii, geom_ws, bin_ws, img_ws, status, out_color,
                               out_depth, out_normal)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # unused outputs (normal, depth, alpha) arrive as None, not as zero images
         GaussianRasterizer._last = dict(status=status, num_rendered=int(a.num_rendered), num_visible=int(a.num_visible),
                                         geom_ws=geom_ws, bin_ws=bin_ws, img_ws=img_ws, sizes=(gb, bb, ib),
                                         capacity=capacity, N=N, H=H, W=W, flags=flags)
