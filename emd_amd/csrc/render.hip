@@ -153,23 +153,20 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_forward(RenderDims d, cons
             const float dx = g0.x - pfx, dy = g0.y - pfy;
             const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
             const float alpha = fminf(0.99f, g0.w * __expf(power));
+            // Branch-free: after culling almost every (entry, wave) pair has hitting lanes, so predication (v_cndmask)
+            // is cheaper than exec-mask branches.  Arithmetic is identical to the branchy form lane by lane.
             const bool hit = !done && power <= 0.f && alpha >= (1.f / 255.f);
-            if (__ballot(hit) != 0ull) {
-                if (hit) {
-                    const float test_T = T * (1.f - alpha);
-                    if (test_T < 0.0001f) {
-                        done = true;
-                    } else {
-                        const float w = alpha * T;
-                        const float4 g2 = s2[j];
-                        C0 += g2.x * w; C1 += g2.y * w; C2 += g2.z * w;
-                        Dz += g0.z * w;
-                        if (NORMAL) { const float4 g3 = s3[j]; N0 += g3.x * w; N1 += g3.y * w; N2 += g3.z * w; }
-                        T = test_T;
-                        last = base - start + j + 1;   // 1-based position in the tile list
-                    }
-                }
-            }
+            const float test_T = T * (1.f - alpha);
+            const bool stop = hit && test_T < 0.0001f;
+            const bool take = hit && !stop;
+            const float w = take ? alpha * T : 0.f;
+            const float4 g2 = s2[j];
+            C0 += g2.x * w; C1 += g2.y * w; C2 += g2.z * w;
+            Dz += g0.z * w;
+            if (NORMAL) { const float4 g3 = s3[j]; N0 += g3.x * w; N1 += g3.y * w; N2 += g3.z * w; }
+            T = take ? test_T : T;
+            last = take ? base - start + j + 1 : last;   // 1-based position in the tile list
+            done = done || stop;
             j = jn; g0 = g0n; g1 = g1n;
         }
     }
