@@ -173,6 +173,10 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint64_t* __r
     // wave w of the block owns the contiguous slice [w*1024, (w+1)*1024) of the block's 4096 keys and walks it in
     // 16 rounds of 64 consecutive keys: order inside the block = (wave, round, lane) = memory order => stable.
     __shared__ uint32_t s_cnt[4][EMD_RADIX_BINS];   // running per-wave digit counts, then per-wave bases
+    __shared__ uint32_t s_gbase[EMD_RADIX_BINS];
+    __shared__ uint64_t s_keys[EMD_SORT_TILE];
+    __shared__ uint32_t s_vals[EMD_SORT_TILE];
+    __shared__ uint32_t s_scan[4];
     const uint32_t D = status->overflow ? 0u : status->num_rendered;
     const uint32_t nblocks = (D + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
     if (blockIdx.x >= nblocks) return;
@@ -207,26 +211,45 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint64_t* __r
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // per-wave exclusive bases inside the block + the block's global base for every digit
+    // per-wave bases in the block's digit-sorted order + the block's global base for every digit
     {
         const uint32_t d = threadIdx.x;
-        const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
+        const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
         const size_t hidx = (size_t)d * nblocks_cap + blockIdx.x;
         const uint32_t g = hidx ? hist_inc[hidx - 1] : 0u;  // exclusive prefix over [bin][block]
-        s_cnt[0][d] = g;
-        s_cnt[1][d] = g + c0;
-        s_cnt[2][d] = g + c0 + c1;
-        s_cnt[3][d] = g + c0 + c1 + c2;
+        const uint32_t c = c0 + c1 + c2 + c3;
+        uint32_t total;
+        const uint32_t bpre = block_scan_add_u32(c, s_scan, &total) - c;
+        s_gbase[d] = g - bpre;                   // global slot = s_gbase[digit] + position in block order
+        s_cnt[0][d] = bpre;
+        s_cnt[1][d] = bpre + c0;
+        s_cnt[2][d] = bpre + c0 + c1;
+        s_cnt[3][d] = bpre + c0 + c1 + c2;
     }
     __syncthreads();
+    // Reorder inside LDS first, then write: consecutive lanes hold consecutive output slots, so every digit run
+    // leaves the block as one contiguous segment.  Scattering straight from registers wrote 8- and 4-byte fragments
+    // of 256 different runs: 2.2x write amplification at the memory side (profiles/r01_pmc_hbm_traffic.csv).
 #pragma unroll
     for (int k = 0; k < EMD_SORT_ITEMS; k++) {
         const size_t idx = wbase + (size_t)k * 64 + lane;
         if (idx < D) {
             const uint32_t digit = (uint32_t)(key[k] >> shift) & (EMD_RADIX_BINS - 1);
-            const size_t dst = (size_t)s_cnt[wave][digit] + rank[k];
-            keys_out[dst] = key[k];
-            vals_out[dst] = vals_in[idx];
+            const uint32_t pos = s_cnt[wave][digit] + rank[k];
+            s_keys[pos] = key[k];
+            s_vals[pos] = vals_in[idx];
+        }
+    }
+    __syncthreads();
+    const uint32_t nvalid = min((uint32_t)EMD_SORT_TILE, D - blockIdx.x * (uint32_t)EMD_SORT_TILE);
+#pragma unroll
+    for (int k = 0; k < EMD_SORT_ITEMS; k++) {
+        const uint32_t pos = threadIdx.x + (uint32_t)k * EMD_BLOCK;
+        if (pos < nvalid) {
+            const uint64_t kk = s_keys[pos];
+            const size_t dst = (size_t)s_gbase[(uint32_t)(kk >> shift) & (EMD_RADIX_BINS - 1)] + pos;
+            keys_out[dst] = kk;
+            vals_out[dst] = s_vals[pos];
         }
     }
 }
