@@ -28,14 +28,40 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def algorithmic_bytes(N, V, D, HW, T, C, p, residual=False):
+PMC_STAGE_KERNELS = {"preprocess": ("k_preprocess",), "scan_duplicate": ("k_duplicate",),
+                     "radix_sort": ("k_radix_hist", "k_radix_scatter"), "tile_ranges": ("k_tile_ranges",),
+                     "render_forward": ("k_render_forward",), "render_backward": ("k_render_backward",),
+                     "preprocess_backward": ("k_preprocess_backward",)}
+
+
+def pmc_traffic(stage, passes):
+    """HBM-side bytes per launch of `stage` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE, separate passes, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md) -- collected on
+    this exact workload; None when the summary is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.csv")
+    if not os.path.exists(path):
+        return None
+    tot = 0.0
+    for line in open(path):
+        if line.startswith("#") or line.startswith("kernel,"):
+            continue
+        f = line.rstrip("\n").split(",")
+        name = f[0].split("<")[0]
+        if name in PMC_STAGE_KERNELS.get(stage, ()):
+            per_launch = (float(f[-3]) + float(f[-2])) * 1e6        # fetch_MB_x2 + write_MB
+            tot += per_launch * (passes if stage == "radix_sort" else 1)
+    return tot or None
+
+
+def algorithmic_bytes(N, V, D, HW, T, C, p, residual=False, C_bwd=None):
     """Compulsory HBM bytes per stage (C blended channels, p radix passes)."""
+    Cf, C = C, (C if C_bwd is None else C_bwd)
     return {
-        "preprocess": 56 * N + (12 * N if residual else 0) + V * (216 + 4 * C),
+        "preprocess": 56 * N + (12 * N if residual else 0) + V * (216 + 4 * Cf),
         "scan_duplicate": 8 * N + 16 * V + 12 * D,
         "radix_sort": p * 24 * D + 8 * D,
         "tile_ranges": 8 * D + 8 * T,
-        "render_forward": D * (4 + 24 + 4 * C) + HW * (4 * (C + 1) + 8),
+        "render_forward": D * (4 + 24 + 4 * Cf) + HW * (4 * (Cf + 1) + 8),
         "render_backward": D * (28 + 4 * C) + HW * (4 * (C + 1) + 8) + V * (24 + 4 * C),
         "preprocess_backward": V * ((24 + 4 * C) + 48 + 192) + N * (236 + 12),
     }
@@ -159,7 +185,7 @@ def main():
         T = ((W + 15) // 16) * ((H + 15) // 16)
         C = 7 if RasterConfig.compute_normal else 4
         passes = (32 + max(T - 1, 1).bit_length() + 7) // 8
-        ab = algorithmic_bytes(N, V, D, H * W, T, C, passes)
+        ab = algorithmic_bytes(N, V, D, H * W, T, C, passes, C_bwd=4)   # the L1 loss sends no gradient into the normal image
         stages = {}
         for name, (ms, cnt) in prof.items():
             if cnt and name in ab:
@@ -170,7 +196,10 @@ def main():
         kernel_ms = sum(v["ms"] for v in stages.values())
         total_alg = sum(ab.values())
         roofline = {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 4),
+                    "traffic": pmc_traffic(dom, passes) if (N, H, W) == (2_000_000, 1066, 1600) else None,
+                    "traffic_source": "profiles/r01_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
+                    "secondary_bound": "fp32 vector issue rate: the render kernels are VALU-bound (DESIGN.md section 3)",
                     "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": stages[dom]["ms"],
                     "whole_iter": {"algorithmic_GB": round(total_alg / 1e9, 3), "kernel_ms": round(kernel_ms, 3),
                                    "GBps": round(total_alg / 1e9 / (kernel_ms * 1e-3), 1),

@@ -19,7 +19,7 @@ void emd_set_error(const char* fmt, ...) {
 #include <mutex>
 #include <vector>
 namespace {
-struct ProfRec { int stage; hipEvent_t a, b; };
+struct ProfRec { int stage; hipEvent_t a, b; bool b_shared; };
 bool g_prof_on = false;
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof_recs;
@@ -51,8 +51,18 @@ void emd_prof_end(int stage, hipStream_t st) {
     hipEvent_t e = prof_event();
     if (!e) return;
     (void)hipEventRecord(e, st);
-    g_prof_recs.push_back({stage, g_prof_open[stage], e});
+    g_prof_recs.push_back({stage, g_prof_open[stage], e, false});
     g_prof_open[stage] = nullptr;
+}
+
+void emd_prof_switch(int ended, int started, hipStream_t st) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEvent_t e = prof_event();
+    if (!e) return;
+    (void)hipEventRecord(e, st);
+    if (g_prof_open[ended]) { g_prof_recs.push_back({ended, g_prof_open[ended], e, true}); g_prof_open[ended] = nullptr; }
+    g_prof_open[started] = e;
 }
 
 int emd_launch_motion_forward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
@@ -63,6 +73,10 @@ int emd_launch_motion_backward(int n, const float* means, const float* quats, co
 int emd_launch_sh_forward(int n, int deg, int M, const float* dirs, const float* coeffs, float* rgb, hipStream_t st);
 int emd_launch_sh_backward(int n, int deg, int M, const float* dirs, const float* coeffs, const float* g_rgb,
                            float* d_coeffs, float* d_dirs, hipStream_t st);
+int emd_launch_actor_pose_forward(int A, const float* q, const float* t, const uint8_t* valid, const float* dt, const float* dq,
+                                  float* pose, hipStream_t st);
+int emd_launch_actor_pose_backward(int A, const float* q, const float* dt, const float* dq, const float* g_pose, float* d_q,
+                                   float* d_t, float* d_dt, float* d_dq, hipStream_t st);
 int emd_launch_activations(int n, const float* ls, float* sc, const float* rq, float* q, const float* lo, float* o, hipStream_t st);
 int emd_launch_export_geometry(int N, const GeomWs& g, float* means2D, float* depths, float* conic_opacity, float* rgb,
                                float* normal, uint32_t* tiles_touched, hipStream_t st);
@@ -87,8 +101,8 @@ int emd_profile_read(double* ms, int64_t* count, int max_stages) {
             if (ms) ms[r.stage] += (double)t;
             if (count) count[r.stage] += 1;
         }
-        g_prof_pool.push_back(r.a);
-        g_prof_pool.push_back(r.b);
+        g_prof_pool.push_back(r.a);                 // a shared end event is the next record's `a`: pooled there
+        if (!r.b_shared) g_prof_pool.push_back(r.b);
     }
     g_prof_recs.clear();
     return EMD_PROF_STAGES;
@@ -171,7 +185,6 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
     if (!(a->flags & EMD_FLAG_MOTION)) memset(&pa.motion, 0, sizeof(pa.motion));
     emd_prof_begin(PROF_PREPROCESS, st);
     rc = emd_launch_preprocess(pa, st);
-    emd_prof_end(PROF_PREPROCESS, st);
     if (rc) return rc;
     STAGE_SYNC("preprocess");
     rc = emd_launch_binning(a->s, N, a->radii, g, b, a->bin_capacity, a->status, st);
@@ -190,7 +203,7 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
             return EMD_ERR_CAPACITY;
         }
     }
-    emd_prof_begin(PROF_RENDER_FWD, st);
+    emd_prof_switch(PROF_RANGES, PROF_RENDER_FWD, st);
     rc = emd_launch_render_forward(a->s, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->out_alpha, st);
     emd_prof_end(PROF_RENDER_FWD, st);
     if (rc) return rc;
@@ -221,13 +234,11 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     const bool dbg = a->s.debug != 0;
     emd_prof_begin(PROF_OTHER, st);
     EMD_HIP_CHECK(hipMemsetAsync(a->bwd_ws, 0, need, st));
-    emd_prof_end(PROF_OTHER, st);
     if ((a->flags & EMD_FLAG_MOTION) && a->dL_dactor_pose && a->motion.num_actors > 0)
         EMD_HIP_CHECK(hipMemsetAsync(a->dL_dactor_pose, 0, (size_t)a->motion.num_actors * EMD_ACTOR_STRIDE * sizeof(float), st));
-    emd_prof_begin(PROF_RENDER_BWD, st);
+    emd_prof_switch(PROF_OTHER, PROF_RENDER_BWD, st);
     rc = emd_launch_render_backward(a->s, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->dL_dcolor,
                                     a->dL_ddepth, a->dL_dalpha, a->dL_dnormal, (float*)a->bwd_ws, st);
-    emd_prof_end(PROF_RENDER_BWD, st);
     if (rc) return rc;
     STAGE_SYNC("render_backward");
     PreBwdArgs pb;
@@ -240,7 +251,7 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     pb.dL_dshs = a->dL_dshs; pb.dL_dcolors = a->dL_dcolors; pb.dL_dopacities = a->dL_dopacities;
     pb.dL_dscales = a->dL_dscales; pb.dL_drotations = a->dL_drotations; pb.dL_dcov3D = a->dL_dcov3D;
     pb.dL_dactor_pose = a->dL_dactor_pose; pb.dL_dresidual_dx = a->dL_dresidual_dx; pb.dL_dresidual_dq = a->dL_dresidual_dq;
-    emd_prof_begin(PROF_PREPROCESS_BWD, st);
+    emd_prof_switch(PROF_RENDER_BWD, PROF_PREPROCESS_BWD, st);
     rc = emd_launch_preprocess_backward(pb, st);
     emd_prof_end(PROF_PREPROCESS_BWD, st);
     if (rc) return rc;
@@ -310,6 +321,18 @@ int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* d
         emd_set_error("sh_backward: bad argument (n=%d degree=%d K=%d)", n, degree, sh_coeffs); return EMD_ERR_INVALID;
     }
     return emd_launch_sh_backward(n, degree, sh_coeffs, dirs, coeffs, dL_drgb, dL_dcoeffs, dL_ddirs, (hipStream_t)hip_stream);
+}
+
+int emd_actor_pose_forward(int32_t num_actors, const float* q_f, const float* t_f, const uint8_t* valid, const float* dt,
+                           const float* dq, float* pose, void* hip_stream) {
+    if (num_actors < 0 || (num_actors > 0 && (!q_f || !t_f || !pose))) { emd_set_error("actor_pose_forward: bad argument"); return EMD_ERR_INVALID; }
+    return emd_launch_actor_pose_forward(num_actors, q_f, t_f, valid, dt, dq, pose, (hipStream_t)hip_stream);
+}
+
+int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* dt, const float* dq, const float* dL_dpose,
+                            float* dL_dq_f, float* dL_dt_f, float* dL_ddt, float* dL_ddq, void* hip_stream) {
+    if (num_actors < 0 || (num_actors > 0 && (!q_f || !dL_dpose || !dL_dq_f || !dL_dt_f))) { emd_set_error("actor_pose_backward: bad argument"); return EMD_ERR_INVALID; }
+    return emd_launch_actor_pose_backward(num_actors, q_f, dt, dq, dL_dpose, dL_dq_f, dL_dt_f, dL_ddt, dL_ddq, (hipStream_t)hip_stream);
 }
 
 int emd_activations_forward(int32_t n, const float* log_scales, float* scales, const float* raw_quats, float* quats,

@@ -297,18 +297,17 @@ int emd_launch_binning(const EmdSettings& s, int N, const int32_t* radii, const 
     const int T = gx * gy;
     if (gx >= 1024 || gy >= 1024) { emd_set_error("image too large: %d x %d tiles (max 1023)", gx, gy); return EMD_ERR_INVALID; }
     const int nb = (N + EMD_BLOCK - 1) / EMD_BLOCK;
-    emd_prof_begin(PROF_DUPLICATE, st);
+    emd_prof_switch(PROF_PREPROCESS, PROF_DUPLICATE, st);
     int rc = emd_launch_scan_u32(g.block_sums, (size_t)nb, g.scan_tmp, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(64), 0, st, g.block_sums, nb, (uint64_t)capacity, status);
     EMD_LAUNCH_CHECK();
     EMD_HIP_CHECK(hipMemsetAsync(b.ranges, 0, (size_t)T * 8, st));
-    if (N == 0 || capacity <= 0) { emd_prof_end(PROF_DUPLICATE, st); return EMD_OK; }
+    if (N == 0 || capacity <= 0) { emd_prof_switch(PROF_DUPLICATE, PROF_RANGES, st); return EMD_OK; }
     hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(EMD_BLOCK), 0, st, N, gx, gy, radii, g.rec, g.tiles_touched,
                        g.block_sums, status, b.keys[0], b.vals[0]);
     EMD_LAUNCH_CHECK();
-    emd_prof_end(PROF_DUPLICATE, st);
-    emd_prof_begin(PROF_SORT, st);
+    emd_prof_switch(PROF_DUPLICATE, PROF_SORT, st);
     const uint32_t nsb = (uint32_t)(((size_t)capacity + EMD_SORT_TILE - 1) / EMD_SORT_TILE);
     const int passes = emd_sort_passes(T);
     int cur = 0;
@@ -323,11 +322,9 @@ int emd_launch_binning(const EmdSettings& s, int N, const int32_t* radii, const 
         EMD_LAUNCH_CHECK();
         cur ^= 1;
     }
-    emd_prof_end(PROF_SORT, st);
-    emd_prof_begin(PROF_RANGES, st);
+    emd_prof_switch(PROF_SORT, PROF_RANGES, st);
     const unsigned rb = (unsigned)(((size_t)capacity + EMD_BLOCK - 1) / EMD_BLOCK);
     hipLaunchKernelGGL(k_tile_ranges, dim3(rb < 4096u ? rb : 4096u), dim3(EMD_BLOCK), 0, st, b.keys[cur], status, b.ranges);
     EMD_LAUNCH_CHECK();
-    emd_prof_end(PROF_RANGES, st);
-    return EMD_OK;
+    return EMD_OK;   // PROF_RANGES is closed by the render-forward switch
 }

@@ -118,6 +118,7 @@ void emd_set_error(const char* fmt, ...);
 enum { PROF_PREPROCESS = 0, PROF_DUPLICATE, PROF_SORT, PROF_RANGES, PROF_RENDER_FWD, PROF_RENDER_BWD, PROF_PREPROCESS_BWD, PROF_OTHER };
 void emd_prof_begin(int stage, hipStream_t st);
 void emd_prof_end(int stage, hipStream_t st);
+void emd_prof_switch(int ended, int started, hipStream_t st);   // one event closes `ended` and opens `started`
 
 // ---- stage launchers (one per translation unit) -------------------------------------------------
 struct PreArgs {

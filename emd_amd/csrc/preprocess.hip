@@ -803,6 +803,75 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_activations(int n, const float* l
     if (lo && o) o[i] = sigmoidf_(lo[i]);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Per-frame actor pose table (training branch of rigid.py:478-568): one lane per actor.
+//   q_mean = normalize(q_f)                       rotation applied to local means          (rigid.py:499-503)
+//   trans  = t_f + dt      (dt skipped when NaN)                                            (rigid.py:519-532)
+//   q_rot  = normalize(q_f (x) dq)  (dq skipped when NaN) composed onto local quaternions   (rigid.py:547-566)
+// Replaces ~25 launch-bound torch kernels (normalize / cat / index and their backward) per step.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool any_nan(const float* v, int n) {
+    bool b = false;
+    for (int k = 0; k < n; k++) b |= !(v[k] == v[k]);
+    return b;
+}
+
+__global__ void k_actor_pose_forward(int A, const float* __restrict__ q_f, const float* __restrict__ t_f,
+                                     const uint8_t* __restrict__ valid, const float* __restrict__ dt,
+                                     const float* __restrict__ dq, float* __restrict__ pose) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A) return;
+    const float q[4] = {q_f[4 * a], q_f[4 * a + 1], q_f[4 * a + 2], q_f[4 * a + 3]};
+    const float n = fmaxf(quat_norm(q), 1e-12f);
+    float* P = pose + (size_t)a * EMD_ACTOR_STRIDE;
+    for (int k = 0; k < 4; k++) P[k] = q[k] / n;
+    float t[3] = {t_f[3 * a], t_f[3 * a + 1], t_f[3 * a + 2]};
+    if (dt && !any_nan(dt + 3 * a, 3)) { t[0] += dt[3 * a]; t[1] += dt[3 * a + 1]; t[2] += dt[3 * a + 2]; }
+    P[4] = t[0]; P[5] = t[1]; P[6] = t[2];
+    P[7] = valid ? (valid[a] ? 1.f : 0.f) : 1.f;
+    float p[4] = {q[0], q[1], q[2], q[3]};
+    if (dq && !any_nan(dq + 4 * a, 4)) { const float r[4] = {dq[4 * a], dq[4 * a + 1], dq[4 * a + 2], dq[4 * a + 3]}; quat_mul(q, r, p); }
+    const float n2 = fmaxf(quat_norm(p), 1e-12f);
+    for (int k = 0; k < 4; k++) P[8 + k] = p[k] / n2;
+}
+
+__global__ void k_actor_pose_backward(int A, const float* __restrict__ q_f, const float* __restrict__ dt,
+                                      const float* __restrict__ dq, const float* __restrict__ g_pose,
+                                      float* __restrict__ d_q_f, float* __restrict__ d_t_f, float* __restrict__ d_dt,
+                                      float* __restrict__ d_dq) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A) return;
+    const float* G = g_pose + (size_t)a * EMD_ACTOR_STRIDE;
+    const float q[4] = {q_f[4 * a], q_f[4 * a + 1], q_f[4 * a + 2], q_f[4 * a + 3]};
+    const float n = fmaxf(quat_norm(q), 1e-12f);
+    const float qu[4] = {q[0] / n, q[1] / n, q[2] / n, q[3] / n};
+    const float gm[4] = {G[0], G[1], G[2], G[3]};
+    float dqf[4];
+    dnormalize4(qu, n, gm, dqf);
+    const bool use_r = dq && !any_nan(dq + 4 * a, 4);
+    float p[4] = {q[0], q[1], q[2], q[3]}, r[4] = {1.f, 0.f, 0.f, 0.f};
+    if (use_r) { r[0] = dq[4 * a]; r[1] = dq[4 * a + 1]; r[2] = dq[4 * a + 2]; r[3] = dq[4 * a + 3]; quat_mul(q, r, p); }
+    const float n2 = fmaxf(quat_norm(p), 1e-12f);
+    const float pu[4] = {p[0] / n2, p[1] / n2, p[2] / n2, p[3] / n2};
+    const float gr[4] = {G[8], G[9], G[10], G[11]};
+    float dp[4];
+    dnormalize4(pu, n2, gr, dp);
+    float dr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (use_r) {   // p = q (x) r : dL/dq = dp (x) conj(r), dL/dr = conj(q) (x) dp
+        const float rc[4] = {r[0], -r[1], -r[2], -r[3]}, qc[4] = {q[0], -q[1], -q[2], -q[3]};
+        float t1[4];
+        quat_mul(dp, rc, t1);
+        quat_mul(qc, dp, dr);
+        for (int k = 0; k < 4; k++) dqf[k] += t1[k];
+    } else {
+        for (int k = 0; k < 4; k++) dqf[k] += dp[k];
+    }
+    for (int k = 0; k < 4; k++) d_q_f[4 * a + k] = dqf[k];
+    for (int k = 0; k < 3; k++) d_t_f[3 * a + k] = G[4 + k];
+    if (d_dt) { const bool ok = dt && !any_nan(dt + 3 * a, 3); for (int k = 0; k < 3; k++) d_dt[3 * a + k] = ok ? G[4 + k] : 0.f; }
+    if (d_dq) for (int k = 0; k < 4; k++) d_dq[4 * a + k] = dr[k];
+}
+
 }  // namespace
 
 int emd_launch_preprocess(const PreArgs& a, hipStream_t st) {
@@ -869,6 +938,22 @@ int emd_launch_export_geometry(int N, const GeomWs& g, float* means2D, float* de
 int emd_launch_activations(int n, const float* ls, float* sc, const float* rq, float* q, const float* lo, float* o, hipStream_t st) {
     if (n <= 0) return EMD_OK;
     hipLaunchKernelGGL(k_activations, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, ls, sc, rq, q, lo, o);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_actor_pose_forward(int A, const float* q, const float* t, const uint8_t* valid, const float* dt, const float* dq,
+                                  float* pose, hipStream_t st) {
+    if (A <= 0) return EMD_OK;
+    hipLaunchKernelGGL(k_actor_pose_forward, dim3((A + 63) / 64), dim3(64), 0, st, A, q, t, valid, dt, dq, pose);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_actor_pose_backward(int A, const float* q, const float* dt, const float* dq, const float* g_pose, float* d_q,
+                                   float* d_t, float* d_dt, float* d_dq, hipStream_t st) {
+    if (A <= 0) return EMD_OK;
+    hipLaunchKernelGGL(k_actor_pose_backward, dim3((A + 63) / 64), dim3(64), 0, st, A, q, dt, dq, g_pose, d_q, d_t, d_dt, d_dq);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

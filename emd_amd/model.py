@@ -41,8 +41,8 @@ class StreetGaussians(torch.nn.Module):
 
     def actor_pose(self, frame):
         """[A,12] pose rows for one frame (track offsets would be added to q_rot / trans here)."""
-        q = F.normalize(self.instances_quats[frame], dim=-1)
-        return torch.cat([q, self.instances_trans[frame], self.instances_fv[frame].float()[:, None], q], dim=1)
+        from .motion import actor_pose_table
+        return actor_pose_table(self.instances_quats, self.instances_trans, self.instances_fv, frame)
 
 
 def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activations=True):

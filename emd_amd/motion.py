@@ -124,7 +124,10 @@ def build_actor_pose(instances_quats, instances_trans, instances_fv, cur_frame, 
     q_rot = q_cur
     if track_rot is not None:
         bad = track_rot.isnan().any(dim=-1, keepdim=True)
-        q_rot = torch.where(bad, q_cur, quat_mult(q_cur, track_rot))
+        ident = torch.zeros_like(track_rot)
+        ident[:, 0] = 1.0
+        # skipped rows multiply by the identity, so no NaN reaches the value or the gradient (rigid.py:559 `continue`)
+        q_rot = quat_mult(q_cur, torch.where(bad, ident, track_rot))
     q_rot = quat_act(q_rot)
     valid = instances_fv[cur_frame].to(q_mean.dtype)[:, None]
     return torch.cat([q_mean, trans, valid, q_rot], dim=1).contiguous()
@@ -132,6 +135,44 @@ def build_actor_pose(instances_quats, instances_trans, instances_fv, cur_frame, 
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _ActorPose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, instances_quats, instances_trans, instances_fv, frame, track_trans, track_rot):
+        lib = L.load()
+        if instances_quats.device.type != "cuda":
+            raise L.EmdError("actor_pose_table needs tensors on a ROCm device; there is no CPU path")
+        q_f, t_f = instances_quats[frame].contiguous(), instances_trans[frame].contiguous()
+        valid = None if instances_fv is None else instances_fv[frame].contiguous().view(torch.uint8)   # bool bytes, no copy kernel
+        A = q_f.shape[0]
+        pose = torch.empty(A, L.ACTOR_STRIDE, device=q_f.device, dtype=torch.float32)
+        L.check(lib.emd_actor_pose_forward(A, q_f.data_ptr(), t_f.data_ptr(), L.ptr(valid), L.ptr(track_trans), L.ptr(track_rot),
+                                           pose.data_ptr(), _stream()), "emd_actor_pose_forward")
+        ctx.frame, ctx.shapes = int(frame), (instances_quats.shape, instances_trans.shape)
+        ctx.save_for_backward(q_f, track_trans, track_rot)
+        return pose
+
+    @staticmethod
+    def backward(ctx, g_pose):
+        lib = L.load()
+        q_f, track_trans, track_rot = ctx.saved_tensors
+        A = q_f.shape[0]
+        d_q = torch.zeros(ctx.shapes[0], device=q_f.device, dtype=torch.float32)
+        d_t = torch.zeros(ctx.shapes[1], device=q_f.device, dtype=torch.float32)
+        d_dt = torch.empty_like(track_trans) if track_trans is not None else None
+        d_dq = torch.empty_like(track_rot) if track_rot is not None else None
+        L.check(lib.emd_actor_pose_backward(A, q_f.data_ptr(), L.ptr(track_trans), L.ptr(track_rot), g_pose.contiguous().data_ptr(),
+                                            d_q[ctx.frame].data_ptr(), d_t[ctx.frame].data_ptr(), L.ptr(d_dt), L.ptr(d_dq),
+                                            _stream()), "emd_actor_pose_backward")
+        return d_q, d_t, None, None, d_dt, d_dq
+
+
+def actor_pose_table(instances_quats, instances_trans, instances_fv, frame, track_trans=None, track_rot=None):
+    """[A,12] pose table of one training frame in ONE HIP launch (and one for its backward): same result as
+    `build_actor_pose(..., in_test_set=False)`; the test-time interpolation branch stays in `build_actor_pose`."""
+    c = lambda t: None if t is None else t.contiguous().float()
+    return _ActorPose.apply(instances_quats, instances_trans, instances_fv, int(frame), c(track_trans), c(track_rot))
 
 
 class _MotionTransform(torch.autograd.Function):

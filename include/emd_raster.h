@@ -236,6 +236,16 @@ int emd_sh_forward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* di
 int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* dirs, const float* coeffs,
                     const float* dL_drgb, float* dL_dcoeffs, float* dL_ddirs /*or NULL*/, void* hip_stream);
 
+/* Per-frame actor pose table, training branch of RigidNodes.transform_means / transform_quats
+ * (OmniRe/models/nodes/rigid.py:499-503,519-532,547-566): pose[a] = (normalize(q_f[a]), t_f[a] + dt[a], valid[a],
+ * normalize(q_f[a] (x) dq[a])).  q_f [A,4] raw pose quaternions of the frame, t_f [A,3], valid [A] bytes or NULL,
+ * dt [A,3] / dq [A,4] learned track offsets or NULL (NaN rows are skipped as the reference does). */
+int emd_actor_pose_forward(int32_t num_actors, const float* q_f, const float* t_f, const uint8_t* valid, const float* dt,
+                           const float* dq, float* pose /*[A,12]*/, void* hip_stream);
+int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* dt, const float* dq, const float* dL_dpose,
+                            float* dL_dq_f, float* dL_dt_f, float* dL_ddt /*or NULL*/, float* dL_ddq /*or NULL*/,
+                            void* hip_stream);
+
 /* The activations exactly as EMD_FLAG_RAW_PARAMS applies them (exp, F.normalize, sigmoid); any pair may be NULL. */
 int emd_activations_forward(int32_t n, const float* log_scales, float* scales, const float* raw_quats, float* quats,
                             const float* opacity_logits, float* opacities, void* hip_stream);

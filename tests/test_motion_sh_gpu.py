@@ -89,3 +89,36 @@ def test_hip_spherical_harmonics_matches_reference_and_autograd():
     (gsplat_api.spherical_harmonics(3, dg, cg) * w.float().to(DEV)).sum().backward()
     np.testing.assert_allclose(cg.grad.cpu().numpy(), c64.grad.numpy(), atol=1e-5)
     np.testing.assert_allclose(dg.grad.cpu().numpy(), d64.grad.numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize("with_offsets", [False, True])
+def test_fused_actor_pose_table_matches_host_mirror(with_offsets):
+    """emd_actor_pose_forward/backward (one launch each) == build_actor_pose (torch ops, itself pinned by the
+    reference golden or_rigid.npz), values and gradients; NaN track offsets are skipped as rigid.py:528,559 do."""
+    g = torch.Generator().manual_seed(9)
+    F_, A = 7, 37
+    iq = (torch.randn(F_, A, 4, generator=g) * 1.3).to(DEV).requires_grad_(True)
+    it = torch.randn(F_, A, 3, generator=g).to(DEV).requires_grad_(True)
+    fv = (torch.rand(F_, A, generator=g) > 0.2).to(DEV)
+    tt = tr_ = None
+    if with_offsets:
+        tt = (0.1 * torch.randn(A, 3, generator=g)).to(DEV)
+        tr_ = torch.randn(A, 4, generator=g).to(DEV)
+        tt[3] = float("nan")
+        tr_[5, 1] = float("nan")
+        tt.requires_grad_(True)
+        tr_.requires_grad_(True)
+    frame = 4
+    ref = motion.build_actor_pose(iq, it, fv, frame, tt, tr_)
+    w = torch.randn(A, 12, generator=g).to(DEV)
+    (ref * w).sum().backward()
+    ref_grads = [iq.grad.clone(), it.grad.clone()] + ([torch.nan_to_num(tt.grad.clone()), torch.nan_to_num(tr_.grad.clone())] if with_offsets else [])
+    for t in (iq, it, tt, tr_):
+        if t is not None:
+            t.grad = None
+    got = motion.actor_pose_table(iq, it, fv, frame, tt, tr_)
+    torch.testing.assert_close(got, ref.detach(), rtol=1e-6, atol=1e-6)
+    (got * w).sum().backward()
+    got_grads = [iq.grad, it.grad] + ([tt.grad, tr_.grad] if with_offsets else [])
+    for a, b in zip(got_grads, ref_grads):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
