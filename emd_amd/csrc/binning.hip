@@ -163,6 +163,26 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_hist(const uint64_t* __rest
     hist[(size_t)threadIdx.x * nblocks_cap + blockIdx.x] = s_h[threadIdx.x];
 }
 
+// One workgroup per digit: inclusive scan of that digit's per-block counts (row `bin` of the bin-major table) in place.
+// Replaces three launch-bound generic scan launches per pass; the cross-digit offsets are formed in the scatter kernel.
+__global__ void __launch_bounds__(EMD_BLOCK) k_radix_scan_bins(uint32_t* __restrict__ hist, uint32_t nblocks_cap) {
+    __shared__ uint32_t s[4];
+    uint32_t* row = hist + (size_t)blockIdx.x * nblocks_cap;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblocks_cap; base += SCAN_TILE) {
+        const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < nblocks_cap) ? row[i0 + k] : 0u; sum += v[k]; }
+        uint32_t total;
+        const uint32_t inc = block_scan_add_u32(sum, s, &total);
+        uint32_t run = carry + inc - sum;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { run += v[k]; if (i0 + k < nblocks_cap) row[i0 + k] = run; }
+        carry += total;
+    }
+}
+
 __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint64_t* __restrict__ keys_in,
                                                              const uint32_t* __restrict__ vals_in,
                                                              uint64_t* __restrict__ keys_out,
@@ -215,10 +235,13 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint64_t* __r
     {
         const uint32_t d = threadIdx.x;
         const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
-        const size_t hidx = (size_t)d * nblocks_cap + blockIdx.x;
-        const uint32_t g = hidx ? hist_inc[hidx - 1] : 0u;  // exclusive prefix over [bin][block]
-        const uint32_t c = c0 + c1 + c2 + c3;
+        // keys of digit d in earlier blocks (row-wise inclusive scan) + all keys of smaller digits (row totals)
+        const uint32_t* row = hist_inc + (size_t)d * nblocks_cap;
+        const uint32_t before = blockIdx.x ? row[blockIdx.x - 1] : 0u;
+        const uint32_t dtot = row[nblocks_cap - 1];
         uint32_t total;
+        const uint32_t g = (block_scan_add_u32(dtot, s_scan, &total) - dtot) + before;
+        const uint32_t c = c0 + c1 + c2 + c3;
         const uint32_t bpre = block_scan_add_u32(c, s_scan, &total) - c;
         s_gbase[d] = g - bpre;                   // global slot = s_gbase[digit] + position in block order
         s_cnt[0][d] = bpre;
@@ -315,8 +338,8 @@ int emd_launch_binning(const EmdSettings& s, int N, const int32_t* radii, const 
         const int shift = p * EMD_RADIX_BITS;
         hipLaunchKernelGGL(k_radix_hist, dim3(nsb), dim3(EMD_BLOCK), 0, st, b.keys[cur], status, shift, nsb, b.hist);
         EMD_LAUNCH_CHECK();
-        rc = emd_launch_scan_u32(b.hist, (size_t)nsb * EMD_RADIX_BINS, b.scan_tmp, st);
-        if (rc) return rc;
+        hipLaunchKernelGGL(k_radix_scan_bins, dim3(EMD_RADIX_BINS), dim3(EMD_BLOCK), 0, st, b.hist, nsb);
+        EMD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_radix_scatter, dim3(nsb), dim3(EMD_BLOCK), 0, st, b.keys[cur], b.vals[cur], b.keys[cur ^ 1],
                            b.vals[cur ^ 1], status, shift, nsb, b.hist);
         EMD_LAUNCH_CHECK();
