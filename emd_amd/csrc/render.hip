@@ -104,6 +104,24 @@ __device__ __forceinline__ uint32_t build_quadrant_lists(uint32_t qmask, uint16_
     return my_n;
 }
 
+// exp(x) for x <= 0, fully specified (bit-exact twin of pinned_exp in oracle/raster_oracle.c): a pixel's colour depends
+// discontinuously on alpha >= 1/255 and T (1 - alpha) >= 1e-4, so the hardware v_exp_f32 (1 ulp, unspecified) cannot
+// be part of a contract that must hold on all 1.7 M pixels of a 1066 x 1600 image.
+__device__ __forceinline__ float pinned_exp(float x) {
+#pragma clang fp contract(off)
+    const float t = x * 1.44269504088896341f;
+    const float n = __builtin_rintf(t);
+    const float f = t - n;
+    float p = 1.54035304e-4f;
+    p = __builtin_fmaf(p, f, 1.33335581e-3f);
+    p = __builtin_fmaf(p, f, 9.61812911e-3f);
+    p = __builtin_fmaf(p, f, 5.55041087e-2f);
+    p = __builtin_fmaf(p, f, 2.40226507e-1f);
+    p = __builtin_fmaf(p, f, 6.93147181e-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return __builtin_ldexpf(p, (int)n);
+}
+
 template <bool NORMAL>
 __global__ void __launch_bounds__(EMD_BLOCK) k_render_forward(RenderDims d, const uint32_t* __restrict__ ranges,
                                                               const uint32_t* __restrict__ point_list,
@@ -111,6 +129,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_forward(RenderDims d, cons
                                                               float* __restrict__ out_depth, float* __restrict__ out_normal,
                                                               float* __restrict__ out_alpha, float* __restrict__ final_T,
                                                               uint32_t* __restrict__ n_contrib) {
+#pragma clang fp contract(off)   // the forward image is a bit-exact contract: only the explicit fma calls below fuse
     __shared__ float4 s0[EMD_BLOCK], s1[EMD_BLOCK], s2[EMD_BLOCK];
     __shared__ float4 s3[NORMAL ? EMD_BLOCK : 1];
     __shared__ uint16_t s_list[4][EMD_BLOCK];
@@ -152,18 +171,21 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_forward(RenderDims d, cons
             const float4 g0n = s0[jn], g1n = s1[jn];
             const float dx = g0.x - pfx, dy = g0.y - pfy;
             const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
-            const float alpha = fminf(0.99f, g0.w * __expf(power));
+            const float alpha = fminf(0.99f, g0.w * pinned_exp(power));
             // Branch-free: after culling almost every (entry, wave) pair has hitting lanes, so predication (v_cndmask)
             // is cheaper than exec-mask branches.  Arithmetic is identical to the branchy form lane by lane.
             const bool hit = !done && power <= 0.f && alpha >= (1.f / 255.f);
             const float test_T = T * (1.f - alpha);
             const bool stop = hit && test_T < 0.0001f;
             const bool take = hit && !stop;
-            const float w = take ? alpha * T : 0.f;
+            const float w = take ? alpha * T : 0.f;   // w = 0 leaves every accumulator bit-identical (fma(c, 0, acc) = acc)
             const float4 g2 = s2[j];
-            C0 += g2.x * w; C1 += g2.y * w; C2 += g2.z * w;
-            Dz += g0.z * w;
-            if (NORMAL) { const float4 g3 = s3[j]; N0 += g3.x * w; N1 += g3.y * w; N2 += g3.z * w; }
+            C0 = __builtin_fmaf(g2.x, w, C0); C1 = __builtin_fmaf(g2.y, w, C1); C2 = __builtin_fmaf(g2.z, w, C2);
+            Dz = __builtin_fmaf(g0.z, w, Dz);
+            if (NORMAL) {
+                const float4 g3 = s3[j];
+                N0 = __builtin_fmaf(g3.x, w, N0); N1 = __builtin_fmaf(g3.y, w, N1); N2 = __builtin_fmaf(g3.z, w, N2);
+            }
             T = take ? test_T : T;
             last = take ? base - start + j + 1 : last;   // 1-based position in the tile list
             done = done || stop;
@@ -172,9 +194,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_forward(RenderDims d, cons
     }
     if (inside) {
         const size_t HW = (size_t)d.H * d.W, pix = (size_t)py * d.W + px;
-        out_color[pix] = C0 + T * d.bg[0];
-        out_color[HW + pix] = C1 + T * d.bg[1];
-        out_color[2 * HW + pix] = C2 + T * d.bg[2];
+        out_color[pix] = __builtin_fmaf(T, d.bg[0], C0);
+        out_color[HW + pix] = __builtin_fmaf(T, d.bg[1], C1);
+        out_color[2 * HW + pix] = __builtin_fmaf(T, d.bg[2], C2);
         out_depth[pix] = Dz;
         if (NORMAL) { out_normal[pix] = N0; out_normal[HW + pix] = N1; out_normal[2 * HW + pix] = N2; }
         out_alpha[pix] = 1.f - T;
@@ -297,7 +319,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
                 const float pxs = qx0 + (float)(p & 7), pys = qy0 + (float)(p >> 3);
                 const float dx = g0.x - pxs, dy = g0.y - pys;
                 const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
-                const float G = __expf(power);
+                const float G = pinned_exp(power);
                 const float alpha = fminf(0.99f, g0.w * G);
                 const bool hit = valid && pos < n_p && power <= 0.f && alpha >= (1.f / 255.f);
                 if (__ballot(hit) == 0ull) continue;

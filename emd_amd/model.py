@@ -49,10 +49,7 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
     """The reference render() restricted to the hot path; returns the dict the training loop consumes."""
     dev = model._xyz.device
     screenspace_points = torch.zeros_like(model._xyz, requires_grad=True)
-    rs = GaussianRasterizationSettings(
-        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
-        bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
-        sh_degree=model.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=debug)
+    rs = raster_settings_for(cam, bg, model.active_sh_degree, 1.0, debug)
     rasterizer = GaussianRasterizer(raster_settings=rs)
     if fuse_activations:
         # the three activations of the reference run inside K1 / K8 (raw_params), not as ~25 separate torch launches
@@ -69,6 +66,37 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, raw_params=fuse_activations, **kw)
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
             "depth": depth, "weight": weight, "normal": normal}
+
+
+def raster_settings_for(cam, bg, sh_degree, scaling_modifier=1.0, debug=False):
+    """The 12-field record exactly as S3Gaussian/gaussian_renderer/__init__.py:46-62 builds it from a camera."""
+    return GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+        bg=bg, scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+        sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=debug)
+
+
+def apply_deform(point, scales, rotations, opacity, shs, ddict_c=None, ddict_f=None):
+    """Final adds of the EMD deformation (S3Gaussian/scene/deformation.py:439-481) under the run-script flags
+    (`no_ds`, `no_dr`: scales and rotations pass through; dx, do, dshs of the coarse and fine level are added).
+    The MLP / HexPlane that produce the residuals stay PyTorch."""
+    for dd in (ddict_c, ddict_f):
+        if dd is None:
+            continue
+        point = point + dd["dx"]
+        opacity = opacity + dd["do"]
+        shs = shs + dd["dshs"]
+    return point, scales, rotations, opacity, shs
+
+
+def boundary_tensors(xyz, scaling, rotation, opacity, features, stage="coarse", ddict=None):
+    """What render() hands to the rasterizer (gaussian_renderer/__init__.py:86-101,145-155): deformation in the
+    fine stage, then exp / normalize / sigmoid."""
+    if "fine" in stage:
+        xyz, scaling, rotation, opacity, features = apply_deform(xyz, scaling, rotation, opacity, features,
+                                                                 ddict["coarse"], ddict["fine"])
+    return dict(means3D=xyz, scales=torch.exp(scaling), rotations=F.normalize(rotation), opacities=torch.sigmoid(opacity),
+                shs=features)
 
 
 def l1_loss(a, b):

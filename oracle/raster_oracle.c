@@ -23,7 +23,8 @@
  *
  * All arithmetic is fp32 in a pinned evaluation order (compile with -ffp-contract=off): the
  * sort keys (tile_id << 32 | float bits of view depth), radii and tile rectangles are a bit-exact
- * contract between this file and the HIP kernels; images and gradients are a tolerance contract.
+ * contract between this file and the HIP kernels, and so is the FORWARD IMAGE (pinned exp and FMA placement, see
+ * "Pinned compositing arithmetic" below); gradients are a tolerance contract.
  */
 #include <math.h>
 #include <stdint.h>
@@ -188,6 +189,34 @@ static void cov3d_from_sr(const float s[3], float mod, const float q[4], float c
 int orc_cov3d(int N, const float* scales, float mod, const float* rots, float* cov) {
     for (int i = 0; i < N; i++) cov3d_from_sr(scales + 3 * i, mod, rots + 4 * i, cov + 6 * i);
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Pinned compositing arithmetic (bit-exact contract with render.hip for the FORWARD image).
+ * A pixel's colour depends discontinuously on alpha >= 1/255 and T (1 - alpha) >= 1e-4: with two different exp
+ * implementations a handful of the 1.7 M pixels of a 1066x1600 image flip and move by ~1/255.  Hence exp and every
+ * rounding of the compositing loop are specified, not left to libm / the compiler:
+ *   power = fma(-0.5, fma(A dx, dx, (C dy) dy), -((B dx) dy))
+ *   exp(x) = ldexp(P6(t - n), n), t = x * log2(e), n = rint(t), P6 = degree-6 Taylor of 2^f in Horner/FMA form
+ *   w = alpha T; acc = fma(feature, w, acc); out = fma(T_final, bg, acc)
+ * ---------------------------------------------------------------------------------------------- */
+static float gauss_power(float A, float B, float C, float dx, float dy) {
+    const float q = fmaf(A * dx, dx, (C * dy) * dy);
+    return fmaf(-0.5f, q, -((B * dx) * dy));
+}
+
+static float pinned_exp(float x) {
+    const float t = x * 1.44269504088896341f;
+    const float n = rintf(t);
+    const float f = t - n;
+    float p = 1.54035304e-4f;
+    p = fmaf(p, f, 1.33335581e-3f);
+    p = fmaf(p, f, 9.61812911e-3f);
+    p = fmaf(p, f, 5.55041087e-2f);
+    p = fmaf(p, f, 2.40226507e-1f);
+    p = fmaf(p, f, 6.93147181e-1f);
+    p = fmaf(p, f, 1.0f);
+    return ldexpf(p, (int)n);
 }
 
 /* clamp-then-truncate of a tile coordinate (identical to min(grid, max(0, (int)f)) for finite f) */
@@ -386,21 +415,21 @@ int orc_render_forward(const OrcSettings* S, int flags, const uint32_t* ranges, 
                 uint32_t g = ids[k];
                 float dx = means2D[2 * g] - (float)px, dy = means2D[2 * g + 1] - (float)py;
                 const float* co = conic_opacity + 4 * g;
-                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                float power = gauss_power(co[0], co[1], co[2], dx, dy);
                 if (power > 0.f) continue;
-                float alpha = fminf(0.99f, co[3] * expf(power));
+                float alpha = fminf(0.99f, co[3] * pinned_exp(power));
                 if (alpha < 1.f / 255.f) continue;
                 float test_T = T * (1.f - alpha);
                 if (test_T < 0.0001f) break;
                 float w = alpha * T;
-                for (int ch = 0; ch < 3; ch++) C[ch] += rgb[3 * g + ch] * w;
-                Dp += depths[g] * w;
-                if (flags & F_NORMAL) for (int ch = 0; ch < 3; ch++) Nn[ch] += normal[3 * g + ch] * w;
+                for (int ch = 0; ch < 3; ch++) C[ch] = fmaf(rgb[3 * g + ch], w, C[ch]);
+                Dp = fmaf(depths[g], w, Dp);
+                if (flags & F_NORMAL) for (int ch = 0; ch < 3; ch++) Nn[ch] = fmaf(normal[3 * g + ch], w, Nn[ch]);
                 T = test_T;
                 last = contributor;
             }
             size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-            for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pix] = C[ch] + T * S->bg[ch];
+            for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pix] = fmaf(T, S->bg[ch], C[ch]);
             out_depth[pix] = Dp;
             if ((flags & F_NORMAL) && out_normal) for (int ch = 0; ch < 3; ch++) out_normal[ch * HW + pix] = Nn[ch];
             out_alpha[pix] = 1.f - T;
@@ -454,9 +483,9 @@ int orc_render_backward(const OrcSettings* S, int N, int flags, const uint32_t* 
                 uint32_t g = ids[k];
                 float dx = means2D[2 * g] - (float)px, dy = means2D[2 * g + 1] - (float)py;
                 const float* co = conic_opacity + 4 * g;
-                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                float power = gauss_power(co[0], co[1], co[2], dx, dy);
                 if (power > 0.f) continue;
-                float G = expf(power);
+                float G = pinned_exp(power);
                 float alpha = fminf(0.99f, co[3] * G);
                 if (alpha < 1.f / 255.f) continue;
                 T = T / (1.f - alpha);

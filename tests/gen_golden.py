@@ -14,6 +14,9 @@ Fixtures (all fp32):
   s3g_camera.npz    getWorld2View2 / getProjectionMatrix / Camera   S3Gaussian/utils/graphics_utils.py:58-92, scene/cameras.py:55-66
   s3g_quat.npz      batch_quaternion_multiply                       S3Gaussian/utils/graphics_utils.py:172-195
   or_quat.npz       quat_to_rotmat, quat_mult, interpolate_quats    OmniRe/models/gaussians/basics.py:30-110
+  s3g_render.npz    render() executed with a recording stand-in for diff_gauss: the 12 settings fields and the tensors at
+                    the rasterizer boundary (coarse and fine stage, run-script flags no_ds / no_dr), plus the deformation
+                    network's residuals that produced them                S3Gaussian/gaussian_renderer/__init__.py:27-168
   or_rigid.npz      RigidNodes.transform_means / transform_quats / opacity mask (+ gradients), train and
                     test-interpolation branches, non-zero track heads  OmniRe/models/nodes/rigid.py:42-46,150-246,478-615
 """
@@ -144,6 +147,103 @@ def gen_s3g():
     unload(["utils", "scene", "arguments", "gaussian_renderer"])
 
 
+def gen_s3g_render():
+    """Run the reference render() on CPU with a recording fake rasterizer."""
+    from typing import NamedTuple
+    sys.path.insert(0, os.path.join(REF, "S3Gaussian"))
+    sys.modules["utils.tcnn_modules"] = _Stub("utils.tcnn_modules")   # raises at import without CUDA (tcnn_modules.py:36-39)
+    import diff_gauss
+
+    class RS(NamedTuple):
+        image_height: int
+        image_width: int
+        tanfovx: float
+        tanfovy: float
+        bg: torch.Tensor
+        scale_modifier: float
+        viewmatrix: torch.Tensor
+        projmatrix: torch.Tensor
+        sh_degree: int
+        campos: torch.Tensor
+        prefiltered: bool
+        debug: bool
+
+    rec = []
+
+    class FakeRast(torch.nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.rs = raster_settings
+
+        def forward(self, **kw):
+            rec.append((self.rs, kw))
+            n, H, W = kw["means3D"].shape[0], self.rs.image_height, self.rs.image_width
+            z = kw["means3D"].sum() * 0
+            return (torch.zeros(3, H, W) + z, torch.zeros(1, H, W) + z, torch.zeros(3, H, W) + z, torch.zeros(1, H, W) + z,
+                    torch.ones(n, dtype=torch.int32), None)
+
+    diff_gauss.GaussianRasterizationSettings, diff_gauss.GaussianRasterizer = RS, FakeRast
+    with _CpuMode():
+        from arguments.gaussian_options import BaseOptions
+        args = BaseOptions()
+        for k in ("no_ds", "no_dr", "no_fine_hexplane_features"):   # scripts/dynamic/run_dynamic_nvs.sh
+            setattr(args, k, True)
+        args.feat_head = False
+        torch.manual_seed(301)
+        from scene.gaussian_model import GaussianModel
+        from gaussian_renderer import render
+        from scene.cameras import Camera
+        from utils.graphics_utils import focal2fov
+        pc = GaussianModel(args)
+        N = 64
+        g = torch.Generator().manual_seed(300)
+        P = torch.nn.Parameter
+        pc._xyz = P(torch.randn(N, 3, generator=g) * 3 + torch.tensor([8.0, 0, 1]))
+        pc._features_dc = P(torch.randn(N, 1, 3, generator=g))
+        pc._features_rest = P(torch.randn(N, 15, 3, generator=g) * 0.1)
+        pc._scaling = P(torch.randn(N, 3, generator=g) * 0.5 - 2)
+        pc._rotation = P(torch.randn(N, 4, generator=g))
+        pc._opacity = P(torch.randn(N, 1, generator=g))
+        pc._embedding = P(torch.randn(N, 4, generator=g) * 0.1)
+        pc._deformation_table = torch.ones(N, dtype=torch.bool)
+        pc.active_sh_degree = 2
+        pc._deformation.deformation_net.set_aabb([20.0, 10.0, 10.0], [-5.0, -10.0, -5.0])
+        for prm in pc._deformation.parameters():     # heads are near-zero at init: make the residuals visible
+            if prm.dim() > 1:
+                prm.data.normal_(0, 0.05)
+        pc._sky_model = lambda cam, acc=None, is_train=False: torch.zeros(3, int(cam.image_height), int(cam.image_width))
+        yaw = 0.3
+        c2w_R = np.array([[np.sin(yaw), 0, np.cos(yaw)], [-np.cos(yaw), 0, np.sin(yaw)], [0, -1, 0]], np.float64)
+        T = -c2w_R.T @ np.array([2.0, -1.0, 1.5])
+        cam = Camera(colmap_id=0, R=c2w_R, T=T, FoVx=focal2fov(110.0, 96), FoVy=focal2fov(105.0, 64), image=torch.zeros(3, 64, 96),
+                     gt_alpha_mask=None, image_name="x", uid=0, data_device="cpu", intrinsic=torch.eye(3), c2w=torch.eye(4),
+                     time=0.3, cam_no=0, time_diff=0.0)
+        bg = torch.tensor([0.1, 0.2, 0.3])
+        out = dict(R=c2w_R, T=T, fovx=cam.FoVx, fovy=cam.FoVy, H=64, W=96, bg=bg, xyz=pc._xyz.data, scaling=pc._scaling.data,
+                   rotation=pc._rotation.data, opacity=pc._opacity.data, features=pc.get_features.data, active_sh_degree=2)
+        for stage in ("coarse", "fine"):
+            rec.clear()
+            res = render(args, cam, pc, bg, stage=stage, return_dx=True, iter=3000, is_train=True)
+            rs, kw = rec[0]
+            assert len(rec) == 1
+            out.update({f"{stage}_tanfovx": rs.tanfovx, f"{stage}_tanfovy": rs.tanfovy, f"{stage}_scale_modifier": rs.scale_modifier,
+                        f"{stage}_viewmatrix": rs.viewmatrix, f"{stage}_projmatrix": rs.projmatrix, f"{stage}_campos": rs.campos,
+                        f"{stage}_sh_degree": rs.sh_degree, f"{stage}_prefiltered": int(rs.prefiltered), f"{stage}_debug": int(rs.debug),
+                        f"{stage}_image_height": rs.image_height, f"{stage}_image_width": rs.image_width, f"{stage}_bg": rs.bg})
+            for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+                out[f"{stage}_{k}"] = kw[k]
+            assert kw["colors_precomp"] is None and kw["cov3Ds_precomp"] is None and kw["extra_attrs"] is None
+            if stage == "fine":
+                dd = res["ddict"]
+                for lvl in ("coarse", "fine"):
+                    for k in ("dx", "do", "dshs"):
+                        out[f"ddict_{lvl}_{k}"] = dd[lvl][k]
+                    assert dd[lvl]["ds"] is None and dd[lvl]["dr"] is None
+        save("s3g_render.npz", **out)
+    sys.path.pop(0)
+    unload(["utils", "scene", "arguments", "gaussian_renderer"])
+
+
 def _matrix_to_quaternion(M):
     """Stand-in for pytorch3d.transforms.matrix_to_quaternion (only used at RigidNodes init, rigid.py:271)."""
     M = M.reshape(-1, 3, 3)
@@ -267,5 +367,6 @@ if __name__ == "__main__":
     install_shims()
     print("S3Gaussian:")
     gen_s3g()
+    gen_s3g_render()
     print("OmniRe:")
     gen_omnire()

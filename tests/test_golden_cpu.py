@@ -131,3 +131,30 @@ def test_rigid_motion_gradients_match_reference(tag):
                       (iq.grad, "grad_instances_quats")):
         ref = z[f"{tag}_{name}"]
         assert np.abs(got.numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), name
+
+
+@pytest.mark.parametrize("stage", ["coarse", "fine"])
+def test_render_glue_matches_reference_render(stage):
+    """Settings record and boundary tensors of the reference render() (captured with a recording stand-in for
+    diff_gauss) are reproduced by the host-side glue: camera -> settings, deformation adds, activations."""
+    from emd_amd import model
+    z = ld("s3g_render.npz")
+    cam = camera.make_camera(z["R"].astype(np.float64), z["T"].astype(np.float64), float(z["fovx"]), float(z["fovy"]), int(z["H"]), int(z["W"]))
+    rs = model.raster_settings_for(cam, torch.tensor(z["bg"]), int(z["active_sh_degree"]))
+    assert (rs.image_height, rs.image_width) == (int(z[f"{stage}_image_height"]), int(z[f"{stage}_image_width"]))
+    assert abs(rs.tanfovx - float(z[f"{stage}_tanfovx"])) < 1e-7 and abs(rs.tanfovy - float(z[f"{stage}_tanfovy"])) < 1e-7
+    assert rs.scale_modifier == float(z[f"{stage}_scale_modifier"]) and rs.sh_degree == int(z[f"{stage}_sh_degree"])
+    assert int(rs.prefiltered) == int(z[f"{stage}_prefiltered"]) and int(rs.debug) == int(z[f"{stage}_debug"])
+    np.testing.assert_allclose(rs.viewmatrix.numpy(), z[f"{stage}_viewmatrix"], atol=1e-6)
+    np.testing.assert_allclose(rs.projmatrix.numpy(), z[f"{stage}_projmatrix"], atol=2e-6)
+    np.testing.assert_allclose(rs.campos.numpy(), z[f"{stage}_campos"], atol=2e-6)
+    np.testing.assert_allclose(rs.bg.numpy(), z[f"{stage}_bg"], atol=0)
+    t = lambda k: torch.tensor(z[k])
+    dd = None
+    if stage == "fine":
+        dd = {lvl: {k: t(f"ddict_{lvl}_{k}") for k in ("dx", "do", "dshs")} for lvl in ("coarse", "fine")}
+    b = model.boundary_tensors(t("xyz"), t("scaling"), t("rotation"), t("opacity"), t("features"), stage, dd)
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        np.testing.assert_allclose(b[k].numpy(), z[f"{stage}_{k}"], rtol=1e-6, atol=1e-6, err_msg=k)
+    if stage == "fine":
+        assert np.abs(z["fine_means3D"] - z["coarse_means3D"]).max() > 1e-4, "the deformation must have been exercised"
