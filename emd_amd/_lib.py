@@ -69,7 +69,7 @@ class EmdBwdArgs(C.Structure):
 EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_size", "emd_raster_forward",
                     "emd_raster_backward", "emd_raster_export_binning", "emd_raster_export_geometry",
                     "emd_motion_forward", "emd_motion_backward", "emd_sh_forward", "emd_sh_backward",
-                    "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward", "emd_actor_pose_forward", "emd_actor_pose_backward")
+                    "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward", "emd_actor_pose_forward", "emd_actor_pose_backward", "emd_l1_loss")
 PROF_STAGES = 8
 
 _lib = None
@@ -111,6 +111,7 @@ def load():
     lib.emd_activations_forward.argtypes = [C.c_int32] + [C.c_void_p] * 7
     lib.emd_actor_pose_forward.argtypes = [C.c_int32] + [C.c_void_p] * 7
     lib.emd_actor_pose_backward.argtypes = [C.c_int32] + [C.c_void_p] * 9
+    lib.emd_l1_loss.argtypes = [C.c_int64] + [C.c_void_p] * 5
     lib.emd_profile_enable.argtypes = [C.c_int]
     lib.emd_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     lib.emd_profile_stage_name.argtypes = [C.c_int]

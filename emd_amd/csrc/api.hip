@@ -77,6 +77,7 @@ int emd_launch_actor_pose_forward(int A, const float* q, const float* t, const u
                                   float* pose, hipStream_t st);
 int emd_launch_actor_pose_backward(int A, const float* q, const float* dt, const float* dq, const float* g_pose, float* d_q,
                                    float* d_t, float* d_dt, float* d_dq, hipStream_t st);
+int emd_launch_l1_loss(size_t n, const float* a, const float* b, float* loss, float* grad, hipStream_t st);
 int emd_launch_activations(int n, const float* ls, float* sc, const float* rq, float* q, const float* lo, float* o, hipStream_t st);
 int emd_launch_export_geometry(int N, const GeomWs& g, float* means2D, float* depths, float* conic_opacity, float* rgb,
                                float* normal, uint32_t* tiles_touched, hipStream_t st);
@@ -333,6 +334,11 @@ int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* d
                             float* dL_dq_f, float* dL_dt_f, float* dL_ddt, float* dL_ddq, void* hip_stream) {
     if (num_actors < 0 || (num_actors > 0 && (!q_f || !dL_dpose || !dL_dq_f || !dL_dt_f))) { emd_set_error("actor_pose_backward: bad argument"); return EMD_ERR_INVALID; }
     return emd_launch_actor_pose_backward(num_actors, q_f, dt, dq, dL_dpose, dL_dq_f, dL_dt_f, dL_ddt, dL_ddq, (hipStream_t)hip_stream);
+}
+
+int emd_l1_loss(int64_t n, const float* a, const float* b, float* loss, float* grad, void* hip_stream) {
+    if (n < 0 || !loss || (n > 0 && (!a || !b))) { emd_set_error("l1_loss: bad argument"); return EMD_ERR_INVALID; }
+    return emd_launch_l1_loss((size_t)n, a, b, loss, grad, (hipStream_t)hip_stream);
 }
 
 int emd_activations_forward(int32_t n, const float* log_scales, float* scales, const float* raw_quats, float* quats,

@@ -872,6 +872,35 @@ __global__ void k_actor_pose_backward(int A, const float* __restrict__ q_f, cons
     if (d_dq) for (int k = 0; k < 4; k++) d_dq[4 * a + k] = dr[k];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// L1 photometric loss (S3Gaussian/utils/loss_utils.py:21-22, train.py:226): mean |a - b| and its gradient
+// sign(a - b) / n in one pass (the reference spends ~9 element-wise launches on it per step).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EMD_BLOCK) k_l1_loss(size_t n, const float* __restrict__ a, const float* __restrict__ b,
+                                                       float inv_n, float* __restrict__ loss, float* __restrict__ grad) {
+    __shared__ float s_part[4];
+    float acc = 0.f;
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * EMD_BLOCK;
+    for (size_t i = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; i < n4; i += stride) {
+        const float4 x = ((const float4*)a)[i], y = ((const float4*)b)[i];
+        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+        acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+        if (grad) {
+            auto sg = [inv_n](float d) { return d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f); };
+            ((float4*)grad)[i] = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
+        }
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float d = a[i] - b[i];
+        acc += fabsf(d);
+        if (grad) grad[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+    }
+    acc = wave_reduce_to_lane63(acc);
+    if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) * inv_n);
+}
+
 }  // namespace
 
 int emd_launch_preprocess(const PreArgs& a, hipStream_t st) {
@@ -954,6 +983,17 @@ int emd_launch_actor_pose_backward(int A, const float* q, const float* dt, const
                                    float* d_t, float* d_dt, float* d_dq, hipStream_t st) {
     if (A <= 0) return EMD_OK;
     hipLaunchKernelGGL(k_actor_pose_backward, dim3((A + 63) / 64), dim3(64), 0, st, A, q, dt, dq, g_pose, d_q, d_t, d_dt, d_dq);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_l1_loss(size_t n, const float* a, const float* b, float* loss, float* grad, hipStream_t st) {
+    EMD_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), st));
+    if (n == 0) return EMD_OK;
+    size_t blocks = (n / 4 + EMD_BLOCK - 1) / EMD_BLOCK;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_l1_loss, dim3((unsigned)blocks), dim3(EMD_BLOCK), 0, st, n, a, b, 1.0f / (float)n, loss, grad);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

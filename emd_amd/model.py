@@ -99,5 +99,27 @@ def boundary_tensors(xyz, scaling, rotation, opacity, features, stage="coarse", 
                 shs=features)
 
 
-def l1_loss(a, b):
-    return torch.abs(a - b).mean()
+class _L1Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        import ctypes as C
+        from . import _lib as L
+        if a.device.type != "cuda":
+            raise L.EmdError("l1_loss needs tensors on a ROCm device; there is no CPU path")
+        a, b = a.contiguous(), b.contiguous()
+        loss = torch.empty(1, device=a.device, dtype=torch.float32)
+        grad = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        L.check(L.load().emd_l1_loss(a.numel(), a.data_ptr(), b.data_ptr(), loss.data_ptr(), L.ptr(grad),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_l1_loss")
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+def l1_loss(network_output, gt):
+    """mean |network_output - gt| (S3Gaussian/utils/loss_utils.py:21-22) and its gradient in one HIP launch."""
+    return _L1Loss.apply(network_output.float(), gt.float())

@@ -246,6 +246,10 @@ int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* d
                             float* dL_dq_f, float* dL_dt_f, float* dL_ddt /*or NULL*/, float* dL_ddq /*or NULL*/,
                             void* hip_stream);
 
+/* L1 photometric loss of the training step (S3Gaussian/utils/loss_utils.py:21-22, train.py:226):
+ * loss[0] = mean |a - b| over n elements, grad[i] = sign(a[i] - b[i]) / n (grad may be NULL).  One launch. */
+int emd_l1_loss(int64_t n, const float* a, const float* b, float* loss /*[1]*/, float* grad /*[n] or NULL*/, void* hip_stream);
+
 /* The activations exactly as EMD_FLAG_RAW_PARAMS applies them (exp, F.normalize, sigmoid); any pair may be NULL. */
 int emd_activations_forward(int32_t n, const float* log_scales, float* scales, const float* raw_quats, float* quats,
                             const float* opacity_logits, float* opacities, void* hip_stream);

@@ -122,3 +122,20 @@ def test_fused_actor_pose_table_matches_host_mirror(with_offsets):
     got_grads = [iq.grad, it.grad] + ([tt.grad, tr_.grad] if with_offsets else [])
     for a, b in zip(got_grads, ref_grads):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+
+
+def test_fused_l1_loss_matches_torch():
+    from emd_amd.model import l1_loss
+    g = torch.Generator().manual_seed(4)
+    for shape in ((3, 67, 101), (3, 1066, 1600), (5,)):
+        a = torch.randn(*shape, generator=g).to(DEV).requires_grad_(True)
+        b = torch.randn(*shape, generator=g).to(DEV)
+        b.view(-1)[0] = a.detach().view(-1)[0]          # exact tie -> zero gradient like torch.sign
+        ref = torch.abs(a - b).mean()
+        (ref * 2.5).backward()
+        gref = a.grad.clone()
+        a.grad = None
+        out = l1_loss(a, b)
+        (out * 2.5).backward()
+        torch.testing.assert_close(out, ref.detach(), rtol=2e-5, atol=1e-7)
+        torch.testing.assert_close(a.grad, gref, rtol=1e-6, atol=0)
