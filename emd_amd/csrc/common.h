@@ -49,7 +49,7 @@ struct ImgWs {
 static inline size_t emd_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // sort geometry
-#define EMD_SORT_ITEMS 16                       // keys per thread
+#define EMD_SORT_ITEMS 8                        // keys per thread
 #define EMD_SORT_TILE (EMD_BLOCK * EMD_SORT_ITEMS)
 #define EMD_RADIX_BITS 8
 #define EMD_RADIX_BINS (1 << EMD_RADIX_BITS)
