@@ -24,6 +24,8 @@
 
 struct GeomWs {
     float4* rec;             // [N][4]
+    float4* shjac;           // [N][3] d rgb_c / d (unit view direction): row c = (d/dx, d/dy, d/dz, -); written by K1 for
+                             // visible Gaussians so that K8 need not re-read the 192 B of SH coefficients
     uint32_t* tiles_touched; // [N]
     uint32_t* block_sums;    // [ceil(N/256)] inclusive-scanned in place
     uint32_t* scan_tmp;      // scratch for the scans
@@ -72,6 +74,7 @@ static inline void emd_carve_geom(void* base, int N, GeomWs* w) {
     char* p = (char*)base;
     size_t off = 0;
     w->rec = (float4*)(p + off); off = emd_align_up(off + (size_t)N * EMD_REC_F4 * sizeof(float4), 256);
+    w->shjac = (float4*)(p + off); off = emd_align_up(off + (size_t)N * 3 * sizeof(float4), 256);
     w->tiles_touched = (uint32_t*)(p + off); off = emd_align_up(off + (size_t)N * 4, 256);
     size_t nb = ((size_t)N + EMD_BLOCK - 1) / EMD_BLOCK;
     w->block_sums = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 1) * 4, 256);

@@ -178,6 +178,50 @@ __device__ __forceinline__ void project_cov2d(const EmdSettings& S, const float 
     p.det = p.a * p.c - p.b * p.b;
 }
 
+// d colour / d (unit) direction contracted with the colour gradient gc: gd = sum_k d basis_k/d dir * (sh[k] . gc)
+__device__ __forceinline__ void sh_dir_backward(int deg, const float d[3], const float* __restrict__ sh,
+                                                const float gc[3], float gd[3]) {
+    const float x = d[0], y = d[1], z = d[2];
+    gd[0] = gd[1] = gd[2] = 0.f;
+#define SDOT(k) ((sh[3 * (k)] * gc[0] + sh[3 * (k) + 1] * gc[1]) + sh[3 * (k) + 2] * gc[2])
+    if (deg > 0) {
+        gd[1] += -SH_C1 * SDOT(1); gd[2] += SH_C1 * SDOT(2); gd[0] += -SH_C1 * SDOT(3);
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z;
+            float s4 = SDOT(4), s5 = SDOT(5), s6 = SDOT(6), s7 = SDOT(7), s8 = SDOT(8);
+            gd[0] += SH_C2[0] * y * s4 + SH_C2[2] * -2.f * x * s6 + SH_C2[3] * z * s7 + SH_C2[4] * 2.f * x * s8;
+            gd[1] += SH_C2[0] * x * s4 + SH_C2[1] * z * s5 + SH_C2[2] * -2.f * y * s6 + SH_C2[4] * -2.f * y * s8;
+            gd[2] += SH_C2[1] * y * s5 + SH_C2[2] * 4.f * z * s6 + SH_C2[3] * x * s7;
+            if (deg > 2) {
+                float s9 = SDOT(9), s10 = SDOT(10), s11 = SDOT(11), s12 = SDOT(12), s13 = SDOT(13),
+                      s14 = SDOT(14), s15 = SDOT(15);
+                gd[0] += SH_C3[0] * 6.f * x * y * s9 + SH_C3[1] * y * z * s10 + SH_C3[2] * -2.f * x * y * s11 +
+                         SH_C3[3] * -6.f * x * z * s12 + SH_C3[4] * (4.f * zz - 3.f * xx - yy) * s13 +
+                         SH_C3[5] * 2.f * x * z * s14 + SH_C3[6] * (3.f * xx - 3.f * yy) * s15;
+                gd[1] += SH_C3[0] * (3.f * xx - 3.f * yy) * s9 + SH_C3[1] * x * z * s10 +
+                         SH_C3[2] * (4.f * zz - xx - 3.f * yy) * s11 + SH_C3[3] * -6.f * y * z * s12 +
+                         SH_C3[4] * -2.f * x * y * s13 + SH_C3[5] * -2.f * y * z * s14 +
+                         SH_C3[6] * -6.f * x * y * s15;
+                gd[2] += SH_C3[1] * x * y * s10 + SH_C3[2] * 8.f * y * z * s11 +
+                         SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy) * s12 + SH_C3[4] * 8.f * x * z * s13 +
+                         SH_C3[5] * (xx - yy) * s14;
+            }
+        }
+    }
+#undef SDOT
+}
+
+// d colour_c / d (unit direction) for the three channels: J[3 c + axis] = sum_k d basis_k / d axis * sh[k][c].
+// K1 stores it (36 B) so that K8 gets d L / d dir = J^T gc without touching the SH coefficients again.
+__device__ __forceinline__ void sh_dir_jacobian(int deg, const float d[3], const float* __restrict__ sh, float J[9]) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float gc[3] = {0.f, 0.f, 0.f};
+        gc[c] = 1.f;
+        sh_dir_backward(deg, d, sh, gc, J + 3 * c);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // SH rows through LDS.  shs is [N,16,3]: 192 contiguous bytes per Gaussian, so one-Gaussian-per-lane loads/stores
 // touch 64 different cache lines per instruction.  Instead the block moves its 256 rows (48 KiB, contiguous in HBM)
@@ -310,6 +354,12 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
                             if (col[ch] < 0.f) { col[ch] = 0.f; bits |= 1u << ch; }
                             if ((a.flags & EMD_FLAG_CLAMP_RGB01) && col[ch] > 1.f) { col[ch] = 1.f; bits |= 1u << ch; }
                         }
+                        float J[9];
+                        sh_dir_jacobian(S.sh_degree, d, sh, J);
+                        float4* jr = a.g.shjac + (size_t)i * 3;
+                        jr[0] = make_float4(J[0], J[1], J[2], 0.f);
+                        jr[1] = make_float4(J[3], J[4], J[5], 0.f);
+                        jr[2] = make_float4(J[6], J[7], J[8], 0.f);
                     }
                     float4* rec = a.g.rec + (size_t)i * EMD_REC_F4;
                     rec[0] = make_float4(ix, iy, p.tz, op);
@@ -351,39 +401,6 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
         uint32_t v = s_red[4] + s_red[5] + s_red[6] + s_red[7];
         if (v) atomicAdd(&a.status->num_visible, v);
     }
-}
-
-// d colour / d (unit) direction contracted with the colour gradient gc: gd = sum_k d basis_k/d dir * (sh[k] . gc)
-__device__ __forceinline__ void sh_dir_backward(int deg, const float d[3], const float* __restrict__ sh,
-                                                const float gc[3], float gd[3]) {
-    const float x = d[0], y = d[1], z = d[2];
-    gd[0] = gd[1] = gd[2] = 0.f;
-#define SDOT(k) ((sh[3 * (k)] * gc[0] + sh[3 * (k) + 1] * gc[1]) + sh[3 * (k) + 2] * gc[2])
-    if (deg > 0) {
-        gd[1] += -SH_C1 * SDOT(1); gd[2] += SH_C1 * SDOT(2); gd[0] += -SH_C1 * SDOT(3);
-        if (deg > 1) {
-            float xx = x * x, yy = y * y, zz = z * z;
-            float s4 = SDOT(4), s5 = SDOT(5), s6 = SDOT(6), s7 = SDOT(7), s8 = SDOT(8);
-            gd[0] += SH_C2[0] * y * s4 + SH_C2[2] * -2.f * x * s6 + SH_C2[3] * z * s7 + SH_C2[4] * 2.f * x * s8;
-            gd[1] += SH_C2[0] * x * s4 + SH_C2[1] * z * s5 + SH_C2[2] * -2.f * y * s6 + SH_C2[4] * -2.f * y * s8;
-            gd[2] += SH_C2[1] * y * s5 + SH_C2[2] * 4.f * z * s6 + SH_C2[3] * x * s7;
-            if (deg > 2) {
-                float s9 = SDOT(9), s10 = SDOT(10), s11 = SDOT(11), s12 = SDOT(12), s13 = SDOT(13),
-                      s14 = SDOT(14), s15 = SDOT(15);
-                gd[0] += SH_C3[0] * 6.f * x * y * s9 + SH_C3[1] * y * z * s10 + SH_C3[2] * -2.f * x * y * s11 +
-                         SH_C3[3] * -6.f * x * z * s12 + SH_C3[4] * (4.f * zz - 3.f * xx - yy) * s13 +
-                         SH_C3[5] * 2.f * x * z * s14 + SH_C3[6] * (3.f * xx - 3.f * yy) * s15;
-                gd[1] += SH_C3[0] * (3.f * xx - 3.f * yy) * s9 + SH_C3[1] * x * z * s10 +
-                         SH_C3[2] * (4.f * zz - xx - 3.f * yy) * s11 + SH_C3[3] * -6.f * y * z * s12 +
-                         SH_C3[4] * -2.f * x * y * s13 + SH_C3[5] * -2.f * y * z * s14 +
-                         SH_C3[6] * -6.f * x * y * s15;
-                gd[2] += SH_C3[1] * x * y * s10 + SH_C3[2] * 8.f * y * z * s11 +
-                         SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy) * s12 + SH_C3[4] * 8.f * x * z * s13 +
-                         SH_C3[5] * (xx - yy) * s14;
-            }
-        }
-    }
-#undef SDOT
 }
 
 __device__ __forceinline__ void dR_to_dq(const float q[4], const float dR[9], float dq[4]) {
@@ -480,9 +497,8 @@ __device__ __forceinline__ void reduce_pose_grad(int a_id, const float pose_g[12
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a) {
     const EmdSettings& S = a.s;
-    __shared__ float4 s_sh[EMD_BLOCK * SH_ROW4];
+    __shared__ float4 s_sh[EMD_BLOCK * SH_ROW4];      // staging of the dL/dshs rows only (coalesced copy-out)
     const bool sh_staged = a.shs && a.M == 16;
-    if (sh_staged) { sh_block_load(a.shs, a.N, s_sh); __syncthreads(); }
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
     const bool in_range = i < a.N;
     const float* V = S.viewmatrix;
@@ -539,12 +555,15 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
                 for (int ch = 0; ch < 3; ch++) gc[ch] = ((bits >> ch) & 1u) ? 0.f : gcol[ch];
                 const int deg = S.sh_degree;
                 const int K = (deg + 1) * (deg + 1);
-                float sh[48];
-                sh_row_load(sh_staged, s_sh, a.shs, i, a.M, K, sh);
                 float bs[16];
                 sh_basis(deg, d, bs);
+                // d L / d dir = J^T gc with the 3x3 Jacobian K1 stored: no second pass over the 192 B of coefficients
+                const float4* jr = a.g.shjac + (size_t)i * 3;
+                const float4 j0 = jr[0], j1 = jr[1], j2 = jr[2];
                 float gd[3];
-                sh_dir_backward(deg, d, sh, gc, gd);
+                gd[0] = (j0.x * gc[0] + j1.x * gc[1]) + j2.x * gc[2];
+                gd[1] = (j0.y * gc[0] + j1.y * gc[1]) + j2.y * gc[2];
+                gd[2] = (j0.z * gc[0] + j1.z * gc[1]) + j2.z * gc[2];
                 if (a.dL_dshs) {
                     if (sh_staged) {          // own row only: overwrite the coefficients with their gradients
                         float g48[48];
