@@ -443,6 +443,193 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_backward(RenderDims d, con
     (void)NV;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K7, wave-autonomous variant: one wave (64-thread workgroup) per 8x8 quadrant.
+//
+// The workgroup-per-tile kernel above stages 256 list entries at a time and cuts each quadrant's list at the chunk
+// boundary, so the 64-entry batches of the entry-parallel loop are only ~78 % full, and four waves wait on three
+// barriers per chunk.  Here a wave scans the tile list by itself, 64 entries per step (records prefetched one step
+// ahead), keeps the entries whose tight footprint overlaps ITS quadrant in a small LDS queue, and runs the pixel loop
+// whenever 64 entries are queued: every batch but the last is full, there is no workgroup barrier, and the scan stops
+// at the deepest contributor of this quadrant rather than of the whole tile.  Gradients leave per batch as
+// row-shaped global float atomics (48 contiguous bytes per Gaussian) through a per-wave LDS staging tile.
+// ---------------------------------------------------------------------------------------------------
+#define BQ_QUEUE 128
+
+__device__ __forceinline__ uint32_t xcd_quadrant_block(uint32_t b, uint32_t* quad) {
+    // the four quadrants of a tile and runs of XCD_CHUNK neighbouring tiles stay on one XCD (blocks b, b+8, ... share it)
+    const uint32_t xcd = b % 8, k = b / 8, tl = k >> 2;
+    *quad = k & 3u;
+    return ((tl / XCD_CHUNK) * 8 + xcd) * XCD_CHUNK + (tl % XCD_CHUNK);
+}
+
+template <bool NORMAL, bool ABS>
+__global__ void __launch_bounds__(EMD_WAVE) k_render_backward_q(RenderDims d, const uint32_t* __restrict__ ranges,
+                                                                const uint32_t* __restrict__ point_list,
+                                                                const float4* __restrict__ rec,
+                                                                const float* __restrict__ final_T,
+                                                                const uint32_t* __restrict__ n_contrib,
+                                                                const float* __restrict__ out_color,
+                                                                const float* __restrict__ out_depth,
+                                                                const float* __restrict__ out_normal,
+                                                                const float* __restrict__ dL_dcolor,
+                                                                const float* __restrict__ dL_ddepth,
+                                                                const float* __restrict__ dL_dalpha,
+                                                                const float* __restrict__ dL_dnormal,
+                                                                float* __restrict__ grad_rec) {
+    __shared__ float4 q0[BQ_QUEUE], q1[BQ_QUEUE], q2[BQ_QUEUE];
+    __shared__ float4 q3[NORMAL ? BQ_QUEUE : 1];
+    __shared__ uint32_t q_id[BQ_QUEUE], q_pos[BQ_QUEUE];
+    __shared__ float s_stage[EMD_WAVE][EMD_BWD_STRIDE + 1];
+    uint32_t quad;
+    const uint32_t tile = xcd_quadrant_block(blockIdx.x, &quad);
+    if (tile >= (uint32_t)(d.gx * d.gy)) return;
+    const uint32_t lane = threadIdx.x;
+    const float tile_x0 = (float)((tile % (uint32_t)d.gx) * EMD_TILE_X), tile_y0 = (float)((tile / (uint32_t)d.gx) * EMD_TILE_Y);
+    const float qx0 = tile_x0 + (float)((quad & 1) * 8), qy0 = tile_y0 + (float)((quad >> 1) * 8);
+    const int px = (int)qx0 + (int)(lane & 7), py = (int)qy0 + (int)(lane >> 3);
+    const bool inside = px < d.W && py < d.H;
+    const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
+    const size_t HW = (size_t)d.H * d.W, pix = (size_t)py * d.W + px;
+    const uint32_t my_n = inside ? n_contrib[pix] : 0u;
+    uint32_t wave_n = my_n;
+    for (int off = 32; off; off >>= 1) wave_n = max(wave_n, (uint32_t)__shfl_xor((int)wave_n, off));
+    wave_n = min(wave_n, end - start);       // deepest contributor of THIS quadrant
+    if (wave_n == 0) return;
+    float dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dN0 = 0.f, dN1 = 0.f, dN2 = 0.f, Q = 0.f;
+    if (inside) {
+        const float Tf = final_T[pix];
+        float dA = 0.f;
+        if (dL_dcolor) { dC0 = dL_dcolor[pix]; dC1 = dL_dcolor[HW + pix]; dC2 = dL_dcolor[2 * HW + pix]; }
+        if (dL_ddepth) dD = dL_ddepth[pix];
+        if (dL_dalpha) dA = dL_dalpha[pix];
+        if (NORMAL && dL_dnormal) { dN0 = dL_dnormal[pix]; dN1 = dL_dnormal[HW + pix]; dN2 = dL_dnormal[2 * HW + pix]; }
+        const float bgdot = d.bg[0] * dC0 + d.bg[1] * dC1 + d.bg[2] * dC2;
+        float Stot = (out_color[pix] - Tf * d.bg[0]) * dC0 + (out_color[HW + pix] - Tf * d.bg[1]) * dC1 +
+                     (out_color[2 * HW + pix] - Tf * d.bg[2]) * dC2 + out_depth[pix] * dD;
+        if (NORMAL && dL_dnormal) Stot += out_normal[pix] * dN0 + out_normal[HW + pix] * dN1 + out_normal[2 * HW + pix] * dN2;
+        Q = Tf * (dA - bgdot) - Stot;
+    }
+    float cT = 1.f, cS = 0.f;  // running transmittance / running S of pixel `lane`, carried across batches
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // One batch: lane = queue slot; identical arithmetic to the workgroup-per-tile kernel's pixel loop.
+    auto process_batch = [&](uint32_t nb) {
+        const bool valid = lane < nb;
+        const uint32_t sl = valid ? lane : 0u;
+        const float4 g0 = q0[sl], g1 = q1[sl], g2 = q2[sl];
+        float4 g3 = zero4;
+        if (NORMAL) g3 = q3[sl];
+        const uint32_t id = q_id[sl], pos = q_pos[sl];
+        const uint32_t first_pos = readlane_u32(pos, 0);
+        float m0 = 0.f, m1x = 0.f, m1y = 0.f, m2xx = 0.f, m2xy = 0.f, m2yy = 0.f, a_dz = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f,
+              a_ax = 0.f, a_ay = 0.f;
+        for (int p = 0; p < EMD_WAVE; p++) {
+            const uint32_t n_p = readlane_u32(my_n, p);
+            if (n_p <= first_pos) continue;                      // pixel p terminated before this batch
+            const float pxs = qx0 + (float)(p & 7), pys = qy0 + (float)(p >> 3);
+            const float dx = g0.x - pxs, dy = g0.y - pys;
+            const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
+            const float G = pinned_exp(power);
+            const float alpha = fminf(0.99f, g0.w * G);
+            const bool hit = valid && pos < n_p && power <= 0.f && alpha >= (1.f / 255.f);
+            if (__ballot(hit) == 0ull) continue;
+            const float a = hit ? alpha : 0.f;
+            const float om = 1.f - a;
+            const float t_incl = wave_scan_mul_f32_asm(om);
+            const float cTp = readlane_f32(cT, p), cSp = readlane_f32(cS, p);
+            const float Tk = cTp * wave_shift_up1_f32(t_incl, 1.f);
+            const float w = a * Tk;
+            const float c0 = readlane_f32(dC0, p), c1 = readlane_f32(dC1, p), c2 = readlane_f32(dC2, p), cd = readlane_f32(dD, p);
+            float g = g2.x * c0 + g2.y * c1 + g2.z * c2 + g0.z * cd;
+            if (NORMAL) g += g3.x * readlane_f32(dN0, p) + g3.y * readlane_f32(dN1, p) + g3.z * readlane_f32(dN2, p);
+            const float s_incl = wave_scan_add_f32_asm(g * w);
+            const float Sk = cSp + s_incl;
+            const float inv = __builtin_amdgcn_rcpf(om);
+            float dL_da = g * Tk + inv * (readlane_f32(Q, p) + Sk);
+            dL_da = hit ? dL_da : 0.f;
+            const float u = G * (g0.w * dL_da);                  // G dL/dG
+            const float ux = u * dx, uy = u * dy;
+            m0 += u; m1x += ux; m1y += uy;
+            m2xx += ux * dx; m2xy += ux * dy; m2yy += uy * dy;
+            if (ABS) { a_ax += fabsf(ux * g1.x + uy * g1.y); a_ay += fabsf(uy * g1.z + ux * g1.y); }
+            a_dz += w * cd;
+            a_r += w * c0; a_g += w * c1; a_b += w * c2;
+            const float nT = cTp * readlane_f32(t_incl, 63), nS = cSp + readlane_f32(s_incl, 63);
+            cT = (lane == (uint32_t)p) ? nT : cT;
+            cS = (lane == (uint32_t)p) ? nS : cS;
+        }
+        // rows through LDS so that consecutive lanes add consecutive floats of one 48-byte accumulator row
+        float* row = s_stage[lane];
+        row[0] = -(g1.x * m1x + g1.y * m1y); row[1] = -(g1.z * m1y + g1.y * m1x); row[2] = a_dz;
+        row[3] = m0 * __builtin_amdgcn_rcpf(g0.w);
+        row[4] = -0.5f * m2xx; row[5] = -m2xy; row[6] = -0.5f * m2yy;
+        row[7] = a_r; row[8] = a_g; row[9] = a_b;
+        row[10] = ABS ? a_ax : 0.f; row[11] = ABS ? a_ay : 0.f;
+        __syncthreads();
+        for (uint32_t idx = lane; idx < nb * EMD_BWD_STRIDE; idx += EMD_WAVE) {
+            const uint32_t e = idx / EMD_BWD_STRIDE, v = idx % EMD_BWD_STRIDE;
+            const float val = s_stage[e][v];
+            if (val != 0.f) atomicAdd(grad_rec + (size_t)q_id[e] * EMD_BWD_STRIDE + v, val);
+        }
+        __syncthreads();
+        (void)id;
+    };
+
+    // prefetch of the first step
+    uint32_t head = 0;
+    float4 p0 = zero4, p1 = zero4, p2 = zero4, p3 = zero4;
+    uint32_t pid = 0;
+    if (lane < wave_n) {
+        pid = point_list[start + lane];
+        const float4* r = rec + (size_t)pid * EMD_REC_F4;
+        p0 = r[0]; p1 = r[1]; p2 = r[2];
+        if (NORMAL) p3 = r[3];
+    }
+    for (uint32_t base = 0; base < wave_n; base += EMD_WAVE) {
+        const uint32_t idx = base + lane;
+        const float4 c0r = p0, c1r = p1, c2r = p2, c3r = p3;
+        const uint32_t cid = pid;
+        if (idx + EMD_WAVE < wave_n) {           // next step's records in flight while this one is queued / processed
+            pid = point_list[start + idx + EMD_WAVE];
+            const float4* r = rec + (size_t)pid * EMD_REC_F4;
+            p0 = r[0]; p1 = r[1]; p2 = r[2];
+            if (NORMAL) p3 = r[3];
+        }
+        const bool keep = idx < wave_n && ((quadrant_mask(c0r, c1r, tile_x0, tile_y0) >> quad) & 1u);
+        const unsigned long long bal = __ballot(keep);
+        if (keep) {
+            const uint32_t slot = head + (uint32_t)__popcll(bal & lt);
+            q0[slot] = c0r; q1[slot] = c1r; q2[slot] = c2r;
+            if (NORMAL) q3[slot] = c3r;
+            q_id[slot] = cid; q_pos[slot] = idx;
+        }
+        head += (uint32_t)__popcll(bal);
+        __syncthreads();
+        if (head >= EMD_WAVE) {
+            process_batch(EMD_WAVE);
+            const uint32_t rest = head - EMD_WAVE;
+            float4 t0 = zero4, t1 = zero4, t2 = zero4, t3 = zero4;
+            uint32_t ti = 0, tp = 0;
+            if (lane < rest) {
+                t0 = q0[EMD_WAVE + lane]; t1 = q1[EMD_WAVE + lane]; t2 = q2[EMD_WAVE + lane];
+                if (NORMAL) t3 = q3[EMD_WAVE + lane];
+                ti = q_id[EMD_WAVE + lane]; tp = q_pos[EMD_WAVE + lane];
+            }
+            __syncthreads();
+            if (lane < rest) {
+                q0[lane] = t0; q1[lane] = t1; q2[lane] = t2;
+                if (NORMAL) q3[lane] = t3;
+                q_id[lane] = ti; q_pos[lane] = tp;
+            }
+            head = rest;
+            __syncthreads();
+        }
+    }
+    if (head > 0) process_batch(head);
+}
+
 RenderDims make_dims(const EmdSettings& s) {
     RenderDims d;
     d.W = s.image_width; d.H = s.image_height;
@@ -480,7 +667,7 @@ int emd_launch_render_backward(const EmdSettings& s, int flags, const GeomWs& g,
     const uint32_t* pl = b.vals[b.sorted_buf];
     const bool nrm = (flags & EMD_FLAG_NORMAL) && dL_dnormal && out_normal, ab = flags & EMD_FLAG_ABSGRAD;
 #define LAUNCH_BWD(N_, A_)                                                                                          \
-    hipLaunchKernelGGL((k_render_backward<N_, A_>), dim3(padded_tile_grid(T)), dim3(EMD_BLOCK), 0, st, d, b.ranges, pl, g.rec,        \
+    hipLaunchKernelGGL((k_render_backward_q<N_, A_>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.ranges, pl, g.rec,   \
                        im.final_T, im.n_contrib, out_color, out_depth, out_normal, dL_dcolor, dL_ddepth, dL_dalpha,    \
                        dL_dnormal, grad_rec)
     if (nrm && ab) LAUNCH_BWD(true, true);
