@@ -477,10 +477,17 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_backward_q(RenderDims d, co
                                                                 const float* __restrict__ dL_dalpha,
                                                                 const float* __restrict__ dL_dnormal,
                                                                 float* __restrict__ grad_rec) {
-    __shared__ float4 q0[BQ_QUEUE], q1[BQ_QUEUE], q2[BQ_QUEUE];
-    __shared__ float4 q3[NORMAL ? BQ_QUEUE : 1];
+    // queue slot s lives in half s>>6: the gradient staging tile (64 rows x 12 floats = 3 KB) overlays the records of
+    // the lower half, which are dead (held in registers) by the time a batch's gradients are staged.
+    constexpr int NR = NORMAL ? 4 : 3;
+    __shared__ float4 q_rec[2][NR][EMD_WAVE];
     __shared__ uint32_t q_id[BQ_QUEUE], q_pos[BQ_QUEUE];
-    __shared__ float s_stage[EMD_WAVE][EMD_BWD_STRIDE + 1];
+    float* const s_stage = reinterpret_cast<float*>(&q_rec[0][0][0]);
+    // per-pixel constants and running state, read back as wave-uniform (broadcast) LDS loads in the pixel loop: keeps
+    // ~15 v_readlane / v_mov / v_cndmask per pixel-iteration off the VALU, which is what bounds this kernel.
+    //   [p][0] = (dL/dC rgb, dL/dD)   [p][1] = (Q, running T, running S, -)   [p][2] = dL/dN
+    __shared__ float4 s_pix[EMD_WAVE][NORMAL ? 3 : 2];
+#define QREC(r, s) q_rec[(s) >> 6][r][(s) & 63]
     uint32_t quad;
     const uint32_t tile = xcd_quadrant_block(blockIdx.x, &quad);
     if (tile >= (uint32_t)(d.gx * d.gy)) return;
@@ -510,7 +517,10 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_backward_q(RenderDims d, co
         if (NORMAL && dL_dnormal) Stot += out_normal[pix] * dN0 + out_normal[HW + pix] * dN1 + out_normal[2 * HW + pix] * dN2;
         Q = Tf * (dA - bgdot) - Stot;
     }
-    float cT = 1.f, cS = 0.f;  // running transmittance / running S of pixel `lane`, carried across batches
+    s_pix[lane][0] = make_float4(dC0, dC1, dC2, dD);
+    s_pix[lane][1] = make_float4(Q, 1.f, 0.f, 0.f);   // running transmittance / running S, carried across batches
+    if (NORMAL) s_pix[lane][2] = make_float4(dN0, dN1, dN2, 0.f);
+    __syncthreads();
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -518,16 +528,17 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_backward_q(RenderDims d, co
     auto process_batch = [&](uint32_t nb) {
         const bool valid = lane < nb;
         const uint32_t sl = valid ? lane : 0u;
-        const float4 g0 = q0[sl], g1 = q1[sl], g2 = q2[sl];
+        const float4 g0 = QREC(0, sl), g1 = QREC(1, sl), g2 = QREC(2, sl);
         float4 g3 = zero4;
-        if (NORMAL) g3 = q3[sl];
-        const uint32_t id = q_id[sl], pos = q_pos[sl];
+        if (NORMAL) g3 = QREC(3, sl);
+        const uint32_t pos = q_pos[sl];
         const uint32_t first_pos = readlane_u32(pos, 0);
         float m0 = 0.f, m1x = 0.f, m1y = 0.f, m2xx = 0.f, m2xy = 0.f, m2yy = 0.f, a_dz = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f,
               a_ax = 0.f, a_ay = 0.f;
         for (int p = 0; p < EMD_WAVE; p++) {
             const uint32_t n_p = readlane_u32(my_n, p);
             if (n_p <= first_pos) continue;                      // pixel p terminated before this batch
+            const float4 pa = s_pix[p][0], pb = s_pix[p][1];
             const float pxs = qx0 + (float)(p & 7), pys = qy0 + (float)(p >> 3);
             const float dx = g0.x - pxs, dy = g0.y - pys;
             const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
@@ -538,43 +549,38 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_backward_q(RenderDims d, co
             const float a = hit ? alpha : 0.f;
             const float om = 1.f - a;
             const float t_incl = wave_scan_mul_f32_asm(om);
-            const float cTp = readlane_f32(cT, p), cSp = readlane_f32(cS, p);
-            const float Tk = cTp * wave_shift_up1_f32(t_incl, 1.f);
+            const float Tk = pb.y * wave_shift_up1_f32(t_incl, 1.f);
             const float w = a * Tk;
-            const float c0 = readlane_f32(dC0, p), c1 = readlane_f32(dC1, p), c2 = readlane_f32(dC2, p), cd = readlane_f32(dD, p);
-            float g = g2.x * c0 + g2.y * c1 + g2.z * c2 + g0.z * cd;
-            if (NORMAL) g += g3.x * readlane_f32(dN0, p) + g3.y * readlane_f32(dN1, p) + g3.z * readlane_f32(dN2, p);
+            float g = g2.x * pa.x + g2.y * pa.y + g2.z * pa.z + g0.z * pa.w;
+            if (NORMAL) { const float4 pn = s_pix[p][2]; g += g3.x * pn.x + g3.y * pn.y + g3.z * pn.z; }
             const float s_incl = wave_scan_add_f32_asm(g * w);
-            const float Sk = cSp + s_incl;
+            const float Sk = pb.z + s_incl;
             const float inv = __builtin_amdgcn_rcpf(om);
-            float dL_da = g * Tk + inv * (readlane_f32(Q, p) + Sk);
+            float dL_da = g * Tk + inv * (pb.x + Sk);
             dL_da = hit ? dL_da : 0.f;
             const float u = G * (g0.w * dL_da);                  // G dL/dG
             const float ux = u * dx, uy = u * dy;
             m0 += u; m1x += ux; m1y += uy;
             m2xx += ux * dx; m2xy += ux * dy; m2yy += uy * dy;
             if (ABS) { a_ax += fabsf(ux * g1.x + uy * g1.y); a_ay += fabsf(uy * g1.z + ux * g1.y); }
-            a_dz += w * cd;
-            a_r += w * c0; a_g += w * c1; a_b += w * c2;
-            const float nT = cTp * readlane_f32(t_incl, 63), nS = cSp + readlane_f32(s_incl, 63);
-            cT = (lane == (uint32_t)p) ? nT : cT;
-            cS = (lane == (uint32_t)p) ? nS : cS;
+            a_dz += w * pa.w;
+            a_r += w * pa.x; a_g += w * pa.y; a_b += w * pa.z;
+            // lane 63 holds the batch totals: carry the running T and S of pixel p to the next batch
+            if (lane == 63) *reinterpret_cast<float2*>(&s_pix[p][1].y) = make_float2(pb.y * t_incl, Sk);
         }
         // rows through LDS so that consecutive lanes add consecutive floats of one 48-byte accumulator row
-        float* row = s_stage[lane];
-        row[0] = -(g1.x * m1x + g1.y * m1y); row[1] = -(g1.z * m1y + g1.y * m1x); row[2] = a_dz;
-        row[3] = m0 * __builtin_amdgcn_rcpf(g0.w);
-        row[4] = -0.5f * m2xx; row[5] = -m2xy; row[6] = -0.5f * m2yy;
-        row[7] = a_r; row[8] = a_g; row[9] = a_b;
-        row[10] = ABS ? a_ax : 0.f; row[11] = ABS ? a_ay : 0.f;
+        __syncthreads();   // every lane holds its record in registers: the lower half may be overwritten
+        float4* row = reinterpret_cast<float4*>(s_stage + lane * EMD_BWD_STRIDE);
+        row[0] = make_float4(-(g1.x * m1x + g1.y * m1y), -(g1.z * m1y + g1.y * m1x), a_dz, m0 * __builtin_amdgcn_rcpf(g0.w));
+        row[1] = make_float4(-0.5f * m2xx, -m2xy, -0.5f * m2yy, a_r);
+        row[2] = make_float4(a_g, a_b, ABS ? a_ax : 0.f, ABS ? a_ay : 0.f);
         __syncthreads();
         for (uint32_t idx = lane; idx < nb * EMD_BWD_STRIDE; idx += EMD_WAVE) {
             const uint32_t e = idx / EMD_BWD_STRIDE, v = idx % EMD_BWD_STRIDE;
-            const float val = s_stage[e][v];
+            const float val = s_stage[idx];
             if (val != 0.f) atomicAdd(grad_rec + (size_t)q_id[e] * EMD_BWD_STRIDE + v, val);
         }
         __syncthreads();
-        (void)id;
     };
 
     // prefetch of the first step
@@ -601,8 +607,8 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_backward_q(RenderDims d, co
         const unsigned long long bal = __ballot(keep);
         if (keep) {
             const uint32_t slot = head + (uint32_t)__popcll(bal & lt);
-            q0[slot] = c0r; q1[slot] = c1r; q2[slot] = c2r;
-            if (NORMAL) q3[slot] = c3r;
+            QREC(0, slot) = c0r; QREC(1, slot) = c1r; QREC(2, slot) = c2r;
+            if (NORMAL) QREC(3, slot) = c3r;
             q_id[slot] = cid; q_pos[slot] = idx;
         }
         head += (uint32_t)__popcll(bal);
@@ -613,14 +619,14 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_backward_q(RenderDims d, co
             float4 t0 = zero4, t1 = zero4, t2 = zero4, t3 = zero4;
             uint32_t ti = 0, tp = 0;
             if (lane < rest) {
-                t0 = q0[EMD_WAVE + lane]; t1 = q1[EMD_WAVE + lane]; t2 = q2[EMD_WAVE + lane];
-                if (NORMAL) t3 = q3[EMD_WAVE + lane];
+                t0 = q_rec[1][0][lane]; t1 = q_rec[1][1][lane]; t2 = q_rec[1][2][lane];
+                if (NORMAL) t3 = q_rec[1][3][lane];
                 ti = q_id[EMD_WAVE + lane]; tp = q_pos[EMD_WAVE + lane];
             }
             __syncthreads();
             if (lane < rest) {
-                q0[lane] = t0; q1[lane] = t1; q2[lane] = t2;
-                if (NORMAL) q3[lane] = t3;
+                q_rec[0][0][lane] = t0; q_rec[0][1][lane] = t1; q_rec[0][2][lane] = t2;
+                if (NORMAL) q_rec[0][3][lane] = t3;
                 q_id[lane] = ti; q_pos[lane] = tp;
             }
             head = rest;
