@@ -275,6 +275,147 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_render_forward(RenderDims d, cons
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K6, wave-autonomous variant: one wave (64-thread workgroup) per 8x8 quadrant, four DPP rows = its four 4x4 sub-blocks.
+//
+// Same compositing loop as above, but the wave feeds itself: it scans the tile list 64 entries per step (records
+// prefetched one step ahead), keeps the entries whose tight footprint touches the quadrant in a 128-slot LDS ring and
+// appends the slot to the byte list of every sub-block it touches.  Once more than 64 entries are queued (or the list
+// ends) the four rows drain their lists.  No workgroup barriers, no 256-entry chunk granularity, and the scan stops as
+// soon as the 64 pixels of THIS quadrant are saturated rather than all 256 of the tile.
+// The position of an entry in the tile list (needed for n_contrib) rides in the unused .w of the colour record.
+// ---------------------------------------------------------------------------------------------------
+#define FQ_RING 128
+
+// bit r (r = sby * 2 + sbx) set when the tight alpha >= 1/255 box overlaps 4x4 sub-block r of the quadrant at (qx0, qy0)
+__device__ __forceinline__ uint32_t quad_subblock_mask(const float4& r0, const float4& r1, float qx0, float qy0) {
+    const float o = r0.w;
+    if (!(o >= (1.f / 255.f))) return 0u;
+    const float det = r1.x * r1.z - r1.y * r1.y;
+    if (!(det > 0.f)) return 0xFu;
+    const float tau2 = 2.f * __logf(255.f * o);
+    const float inv = 1.f / det;
+    const float bx = sqrtf(tau2 * r1.z * inv) * 1.0001f + 0.01f;
+    const float by = sqrtf(tau2 * r1.x * inv) * 1.0001f + 0.01f;
+    if (!(bx == bx) || !(by == by)) return 0xFu;
+    const float lx = r0.x - bx, hx = r0.x + bx, ly = r0.y - by, hy = r0.y + by;
+    const bool c0 = lx <= qx0 + 3.f && hx >= qx0, c1 = lx <= qx0 + 7.f && hx >= qx0 + 4.f;
+    const bool w0 = ly <= qy0 + 3.f && hy >= qy0, w1 = ly <= qy0 + 7.f && hy >= qy0 + 4.f;
+    return (c0 && w0 ? 1u : 0u) | (c1 && w0 ? 2u : 0u) | (c0 && w1 ? 4u : 0u) | (c1 && w1 ? 8u : 0u);
+}
+
+template <bool NORMAL>
+__global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, const uint32_t* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ point_list,
+                                                               const float4* __restrict__ rec, float* __restrict__ out_color,
+                                                               float* __restrict__ out_depth, float* __restrict__ out_normal,
+                                                               float* __restrict__ out_alpha, float* __restrict__ final_T,
+                                                               uint32_t* __restrict__ n_contrib) {
+#pragma clang fp contract(off)   // the forward image is a bit-exact contract: only the explicit fma calls below fuse
+    __shared__ float4 s0[FQ_RING], s1[FQ_RING], s2[FQ_RING];
+    __shared__ float4 s3[NORMAL ? FQ_RING : 1];
+    __shared__ uint8_t s_list[4][FQ_RING];
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b % 8, k = b / 8, tl = k >> 2, quad = k & 3u;
+    const uint32_t tile = ((tl / XCD_CHUNK) * 8 + xcd) * XCD_CHUNK + (tl % XCD_CHUNK);
+    if (tile >= (uint32_t)(d.gx * d.gy)) return;
+    const uint32_t lane = threadIdx.x, row = lane >> 4, l = lane & 15;
+    const int qxi = (int)((tile % (uint32_t)d.gx) * EMD_TILE_X + (quad & 1) * 8), qyi = (int)((tile / (uint32_t)d.gx) * EMD_TILE_Y + (quad >> 1) * 8);
+    const float qx0 = (float)qxi, qy0 = (float)qyi;
+    const int px = qxi + (int)((row & 1) * 4 + (l & 3)), py = qyi + (int)((row >> 1) * 4 + (l >> 2));
+    const bool inside = px < d.W && py < d.H;
+    const float pfx = (float)px, pfy = (float)py;
+    const uint32_t start = ranges[2 * tile], n_tile = ranges[2 * tile + 1] - start;
+    bool done = !inside;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+    uint32_t last = 0;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 p0 = zero4, p1 = zero4, p2 = zero4, p3 = zero4;
+    if (lane < n_tile) {
+        const float4* r = rec + (size_t)point_list[start + lane] * EMD_REC_F4;
+        p0 = r[0]; p1 = r[1]; p2 = r[2];
+        if (NORMAL) p3 = r[3];
+    }
+    uint32_t scanned = 0;
+    while (scanned < n_tile) {
+        if (__ballot(!done) == 0ull) break;
+        // ---- scan: queue entries until more than 64 wait or the list ends ----
+        uint32_t head = 0, len0 = 0, len1 = 0, len2 = 0, len3 = 0;
+        while (head <= EMD_WAVE && scanned < n_tile) {
+            const uint32_t idx = scanned + lane;
+            const float4 c0r = p0, c1r = p1, c3r = p3;
+            float4 c2r = p2;
+            if (idx + EMD_WAVE < n_tile) {
+                const float4* r = rec + (size_t)point_list[start + idx + EMD_WAVE] * EMD_REC_F4;
+                p0 = r[0]; p1 = r[1]; p2 = r[2];
+                if (NORMAL) p3 = r[3];
+            }
+            const uint32_t m4 = idx < n_tile ? quad_subblock_mask(c0r, c1r, qx0, qy0) : 0u;
+            const unsigned long long bal = __ballot(m4 != 0u);
+            const uint32_t slot = head + (uint32_t)__popcll(bal & lt);
+            if (m4) {
+                c2r.w = __uint_as_float(idx + 1);           // 1-based position in the tile list
+                s0[slot] = c0r; s1[slot] = c1r; s2[slot] = c2r;
+                if (NORMAL) s3[slot] = c3r;
+            }
+            const unsigned long long b0 = __ballot(m4 & 1u), b1 = __ballot(m4 & 2u), b2 = __ballot(m4 & 4u), b3 = __ballot(m4 & 8u);
+            if (m4 & 1u) s_list[0][len0 + (uint32_t)__popcll(b0 & lt)] = (uint8_t)slot;
+            if (m4 & 2u) s_list[1][len1 + (uint32_t)__popcll(b1 & lt)] = (uint8_t)slot;
+            if (m4 & 4u) s_list[2][len2 + (uint32_t)__popcll(b2 & lt)] = (uint8_t)slot;
+            if (m4 & 8u) s_list[3][len3 + (uint32_t)__popcll(b3 & lt)] = (uint8_t)slot;
+            len0 += (uint32_t)__popcll(b0); len1 += (uint32_t)__popcll(b1); len2 += (uint32_t)__popcll(b2); len3 += (uint32_t)__popcll(b3);
+            head += (uint32_t)__popcll(bal);
+            scanned += EMD_WAVE;
+        }
+        __syncthreads();
+        const uint32_t nmax = max(max(len0, len1), max(len2, len3));
+        if (nmax) {
+            const uint32_t n = row == 0 ? len0 : row == 1 ? len1 : row == 2 ? len2 : len3;
+            const uint8_t* list = s_list[row];
+            // software pipeline: the index and record of entry i+1 are in flight while entry i is evaluated
+            uint32_t j = n ? list[0] : 0u;
+            float4 g0 = s0[j], g1 = s1[j];
+            for (uint32_t i = 0; i < nmax; i++) {
+                const bool active = i < n;
+                const uint32_t jn = (i + 1 < n) ? list[i + 1] : j;
+                const float4 g0n = s0[jn], g1n = s1[jn];
+                const float dx = g0.x - pfx, dy = g0.y - pfy;
+                const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
+                const float alpha = fminf(0.99f, g0.w * pinned_exp(power));
+                const bool hit = active && !done && power <= 0.f && alpha >= (1.f / 255.f);
+                const float test_T = T * (1.f - alpha);
+                const bool stop = hit && test_T < 0.0001f;
+                const bool take = hit && !stop;
+                const float w = take ? alpha * T : 0.f;
+                const float4 g2 = s2[j];
+                C0 = __builtin_fmaf(g2.x, w, C0); C1 = __builtin_fmaf(g2.y, w, C1); C2 = __builtin_fmaf(g2.z, w, C2);
+                Dz = __builtin_fmaf(g0.z, w, Dz);
+                if (NORMAL) {
+                    const float4 g3 = s3[j];
+                    N0 = __builtin_fmaf(g3.x, w, N0); N1 = __builtin_fmaf(g3.y, w, N1); N2 = __builtin_fmaf(g3.z, w, N2);
+                }
+                T = take ? test_T : T;
+                last = take ? __float_as_uint(g2.w) : last;
+                done = done || stop;
+                j = jn; g0 = g0n; g1 = g1n;
+            }
+        }
+        __syncthreads();   // ring and lists fully consumed before the next scan overwrites them
+    }
+    if (inside) {
+        const size_t HW = (size_t)d.H * d.W, pix = (size_t)py * d.W + px;
+        out_color[pix] = __builtin_fmaf(T, d.bg[0], C0);
+        out_color[HW + pix] = __builtin_fmaf(T, d.bg[1], C1);
+        out_color[2 * HW + pix] = __builtin_fmaf(T, d.bg[2], C2);
+        out_depth[pix] = Dz;
+        if (NORMAL) { out_normal[pix] = N0; out_normal[HW + pix] = N1; out_normal[2 * HW + pix] = N2; }
+        out_alpha[pix] = 1.f - T;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K7, entry-parallel formulation for wave64.
 //
 // Upstream walks each pixel's list back to front and needs, per (pixel, Gaussian), ten partial derivatives summed
@@ -654,10 +795,10 @@ int emd_launch_render_forward(const EmdSettings& s, int flags, const GeomWs& g, 
     if (T <= 0) return EMD_OK;
     const uint32_t* pl = b.vals[b.sorted_buf];
     if (flags & EMD_FLAG_NORMAL)
-        hipLaunchKernelGGL(k_render_forward<true>, dim3(padded_tile_grid(T)), dim3(EMD_BLOCK), 0, st, d, b.ranges, pl, g.rec, out_color,
+        hipLaunchKernelGGL(k_render_forward_q<true>, dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.ranges, pl, g.rec, out_color,
                            out_depth, out_normal, out_alpha, im.final_T, im.n_contrib);
     else
-        hipLaunchKernelGGL(k_render_forward<false>, dim3(padded_tile_grid(T)), dim3(EMD_BLOCK), 0, st, d, b.ranges, pl, g.rec, out_color,
+        hipLaunchKernelGGL(k_render_forward_q<false>, dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.ranges, pl, g.rec, out_color,
                            out_depth, out_normal, out_alpha, im.final_T, im.n_contrib);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
