@@ -375,6 +375,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
             // software pipeline: the index and record of entry i+1 are in flight while entry i is evaluated
             uint32_t j = n ? list[0] : 0u;
             float4 g0 = s0[j], g1 = s1[j];
+#pragma unroll 2
             for (uint32_t i = 0; i < nmax; i++) {
                 const bool active = i < n;
                 const uint32_t jn = (i + 1 < n) ? list[i + 1] : j;
