@@ -57,10 +57,12 @@ def algorithmic_bytes(N, V, D, HW, T, C, p, residual=False, C_bwd=None):
     """Compulsory HBM bytes per stage (C blended channels, p radix passes)."""
     Cf, C = C, (C if C_bwd is None else C_bwd)
     return {
-        "preprocess": 56 * N + (12 * N if residual else 0) + V * (216 + 4 * Cf),
-        "scan_duplicate": 8 * N + 16 * V + 12 * D,
-        "radix_sort": p * 24 * D + 8 * D,
-        "tile_ranges": 8 * D + 8 * T,
+        "preprocess": 68 * N + (12 * N if residual else 0) + V * (216 + 4 * Cf),
+        # depth-ordered Gaussians -> (rect, count) gather, scan, (tile id, Gaussian id) pairs
+        "scan_duplicate": 28 * N + 8 * V + 8 * D,
+        # 4 passes over the N (depth, id) pairs + p passes over the D (tile, id) pairs, 8 B read + 8 B written each
+        "radix_sort": 4 * 16 * N + p * 16 * D,
+        "tile_ranges": 4 * D + 8 * T,
         "render_forward": D * (4 + 24 + 4 * Cf) + HW * (4 * (Cf + 1) + 8),
         "render_backward": D * (28 + 4 * C) + HW * (4 * (C + 1) + 8) + V * (24 + 4 * C),
         "preprocess_backward": V * ((24 + 4 * C) + 48 + 192) + N * (236 + 12),
@@ -196,12 +198,12 @@ def main():
         V, D = st["num_visible"], st["num_rendered"]
         T = ((W + 15) // 16) * ((H + 15) // 16)
         C = 7 if RasterConfig.compute_normal else 4
-        passes = (32 + max(T - 1, 1).bit_length() + 7) // 8
+        passes = (max(T - 1, 1).bit_length() + 7) // 8            # radix passes over the D duplicates (tile bits)
         ab = algorithmic_bytes(N, V, D, H * W, T, C, passes, C_bwd=4)   # the L1 loss sends no gradient into the normal image
         stages = {}
         for name, (ms, cnt) in prof.items():
             if cnt and name in ab:
-                avg = ms / cnt
+                avg = ms / args.steps                                # per iteration (a stage may open twice per step)
                 stages[name] = {"ms": round(avg, 4), "alg_GB": round(ab[name] / 1e9, 4),
                                 "GBps": round(ab[name] / 1e9 / (avg * 1e-3), 1)}
         dom = max(stages, key=lambda k: stages[k]["ms"])
@@ -226,7 +228,7 @@ def main():
                                    "(32 actors x 5000), SH degree 3, one 1066x1600 view per GPU per step, L1 loss, "
                                    "fwd+bwd to all 59 floats/Gaussian + actor poses",
                        "gaussians": N, "height": H, "width": W, "visible_V": V, "duplicates_D": D, "tiles_T": T,
-                       "radix_passes_p": passes, "blended_channels_C": C, "views_per_step": world,
+                       "radix_passes_depth_on_N": 4, "radix_passes_tile_on_D": passes, "blended_channels_C": C, "views_per_step": world,
                        "parallelism": f"view-parallel dp{world}", "count_readback": bool(args.sync_count)},
             "roofline": roofline,
         }

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 TILE = 16
 ACTOR_STRIDE = 12
 BWD_STRIDE = 12
@@ -99,7 +99,7 @@ def load():
     lib.emd_raster_workspace_size.argtypes = [C.POINTER(EmdDims), C.POINTER(C.c_size_t)]
     lib.emd_raster_forward.argtypes = [C.POINTER(EmdFwdArgs), C.c_void_p]
     lib.emd_raster_backward.argtypes = [C.POINTER(EmdBwdArgs), C.c_void_p]
-    lib.emd_raster_export_binning.argtypes = [C.POINTER(EmdDims), C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
+    lib.emd_raster_export_binning.argtypes = [C.POINTER(EmdDims), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_raster_export_geometry.argtypes = [C.POINTER(EmdDims), C.c_void_p, C.c_size_t] + [C.c_void_p] * 7
     lib.emd_motion_forward.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(EmdMotion),

@@ -188,7 +188,7 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
     rc = emd_launch_preprocess(pa, st);
     if (rc) return rc;
     STAGE_SYNC("preprocess");
-    rc = emd_launch_binning(a->s, N, a->radii, g, b, a->bin_capacity, a->status, st);
+    rc = emd_launch_binning(a->s, N, g, b, a->bin_capacity, a->status, st);
     if (rc) return rc;
     STAGE_SYNC("binning");
     a->num_rendered = -1;
@@ -260,15 +260,17 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     return EMD_OK;
 }
 
-int emd_raster_export_binning(const EmdDims* dims, const void* bin_ws, size_t bin_bytes, int64_t num_rendered,
-                              uint64_t* keys, uint32_t* ids, uint32_t* ranges, void* hip_stream) {
-    if (!dims || !bin_ws) { emd_set_error("export_binning: null argument"); return EMD_ERR_INVALID; }
+int emd_raster_export_binning(const EmdDims* dims, const void* geom_ws, size_t geom_bytes, const void* bin_ws, size_t bin_bytes,
+                              int64_t num_rendered, uint64_t* keys, uint32_t* ids, uint32_t* ranges, void* hip_stream) {
+    if (!dims || !bin_ws || !geom_ws) { emd_set_error("export_binning: null argument"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     const int gx = (dims->image_width + EMD_TILE_X - 1) / EMD_TILE_X, gy = (dims->image_height + EMD_TILE_Y - 1) / EMD_TILE_Y;
-    BinWs b;
+    GeomWs g; BinWs b;
+    emd_carve_geom((void*)geom_ws, dims->num_gaussians, &g);
     emd_carve_bin((void*)bin_ws, dims->bin_capacity, gx * gy, &b);
-    if (b.bytes > bin_bytes || num_rendered > dims->bin_capacity || num_rendered < 0) { emd_set_error("export_binning: bad sizes"); return EMD_ERR_WORKSPACE; }
-    if (keys && num_rendered) EMD_HIP_CHECK(hipMemcpyAsync(keys, b.keys[b.sorted_buf], (size_t)num_rendered * 8, hipMemcpyDeviceToDevice, st));
+    if (g.bytes > geom_bytes || b.bytes > bin_bytes || num_rendered > dims->bin_capacity || num_rendered < 0) { emd_set_error("export_binning: bad sizes"); return EMD_ERR_WORKSPACE; }
+    // the sort moves (tile id, Gaussian id) pairs; upstream's 64-bit key is tile id << 32 | depth bits of the Gaussian
+    if (keys && num_rendered) { int rc = emd_launch_export_keys(num_rendered, g, b, keys, st); if (rc) return rc; }
     if (ids && num_rendered) EMD_HIP_CHECK(hipMemcpyAsync(ids, b.vals[b.sorted_buf], (size_t)num_rendered * 4, hipMemcpyDeviceToDevice, st));
     if (ranges) EMD_HIP_CHECK(hipMemcpyAsync(ranges, b.ranges, (size_t)gx * gy * 8, hipMemcpyDeviceToDevice, st));
     return EMD_OK;

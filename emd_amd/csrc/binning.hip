@@ -1,20 +1,38 @@
-// binning.hip -- K2..K5: offsets scan, tile duplication with 64-bit keys, stable LSD radix sort, tile ranges.
+// binning.hip -- K2..K5: depth order, tile duplication, stable partition by tile, tile ranges.
 // [UPSTREAM K2-K5 in SURVEY.md section 2.4: CUB DeviceScan / duplicateWithKeys / DeviceRadixSort / identifyTileRanges]
+//
+// Upstream sorts D = sum(tiles touched) 64-bit keys (tile << 32 | depth bits) with their 32-bit values: 12 bytes per
+// duplicate through every radix pass.  The depth bits of a key are a property of the GAUSSIAN, not of the duplicate, so
+// the least-significant 32 bits of the LSD sort can be done BEFORE duplicating, on N (depth, id) pairs instead of
+// D (key, id) triples (D ~ 3.8 V on the bench scene):
+//     1. stable LSD radix sort of the N Gaussians by depth bits (4 passes over 8 B pairs; invisible ones sort last),
+//     2. gather the tile rectangle / tile count of each Gaussian in that order, scan, duplicate: the duplicates appear
+//        ordered by (depth, Gaussian id) and carry only (tile id, Gaussian id),
+//     3. stable LSD radix sort of the D pairs by the ceil(log2(tiles)) tile bits (2 passes for up to 64 K tiles).
+// A stable sort by a low key followed by a stable sort by a high key IS the LSD sort of the concatenated key, and the
+// initial order is the Gaussian index in both formulations, so the final order is bit-for-bit the order of the upstream
+// sort of the 64-bit keys: (tile, depth bits, Gaussian id).  emd_raster_export_binning rebuilds the 64-bit keys from
+// (tile id, depth bits of the Gaussian) for the parity tests.  Bytes through the radix passes on the bench scene:
+// 6 x 24 B x 5.7 M = 820 MB before, 4 x 16 B x 2 M + 2 x 16 B x 5.7 M = 310 MB now.
 //
 // Design for gfx950:
 //   - the duplicate count D stays on the device (EmdStatus.num_rendered); every kernel here is launched on the
 //     caller-provided capacity and bounds itself by D, so the forward pass needs no host read-back to proceed.
 //   - duplication is balanced over output slots, not Gaussians: a 256-thread block scans the tile counts of its
 //     256 Gaussians (DPP wave scan + LDS), then lane e writes slot e, finding its Gaussian by binary search in
-//     LDS -- consecutive lanes write consecutive keys (coalesced 8 B + 4 B stores) regardless of footprint size.
-//   - the sort is a stable LSD radix sort (8-bit digits) on exactly the significant bits:
-//     32 depth bits + ceil(log2(tiles)) tile bits.  Ranking inside a block is wave-ballot based
-//     (8 ballots per key give the set of lanes with the same digit; no LDS atomics in the ranking loop), which keeps
-//     the sort stable so the final order is (tile, depth bits, Gaussian id) -- the bit-exact contract with the oracle.
+//     LDS -- consecutive lanes write consecutive pairs (coalesced 4 B + 4 B stores) regardless of footprint size.
+//   - ranking inside a radix block is wave-ballot based (8 ballots per key give the set of lanes with the same digit;
+//     no LDS atomics in the ranking loop), which keeps every pass stable.
 #include "common.h"
 #include "device_utils.h"
 
 namespace {
+
+// number of elements of a radix pass: a launch-time constant (Gaussian depth sort) or the device-side duplicate count
+struct SortN { const EmdStatus* status; uint32_t fixed; };
+__device__ __forceinline__ uint32_t sort_n(const SortN& c) {
+    return c.status ? (c.status->overflow ? 0u : c.status->num_rendered) : c.fixed;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // generic inclusive scan over uint32 (in place), 3 phases, 1024 elements per block
@@ -80,44 +98,44 @@ __global__ void k_publish_count(const uint32_t* __restrict__ block_sums_inc, int
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K3 duplicate with keys
+// K2': tile rectangle and tile count of the Gaussians in depth order (one 8-byte gather each) + block totals
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tile_clamp(float f, int grid) {
-    float g = (float)grid;
-    if (!(f > 0.f)) return 0;
-    if (f > g) return grid;
-    return (int)f;
+__global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32_t* __restrict__ depth_sorted,
+                                                             const uint32_t* __restrict__ perm,
+                                                             const uint2* __restrict__ binrec,
+                                                             uint32_t* __restrict__ rect_s, uint32_t* __restrict__ cnt_s,
+                                                             uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_scan[4];
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    uint2 br = make_uint2(0u, 0u);
+    if (i < N && depth_sorted[i] != 0xFFFFFFFFu) br = binrec[perm[i]];   // invisible Gaussians sort last, count 0
+    if (i < N) { rect_s[i] = br.x; cnt_s[i] = br.y; }
+    uint32_t total;
+    block_scan_add_u32(br.y, s_scan, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, int gy, const int32_t* __restrict__ radii,
-                                                         const float4* __restrict__ rec,
-                                                         const uint32_t* __restrict__ tiles_touched,
+// ---------------------------------------------------------------------------------------------------
+// K3 duplicate: (tile id, Gaussian id) pairs in (depth, Gaussian id) order
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const uint32_t* __restrict__ rect_s,
+                                                         const uint32_t* __restrict__ cnt_s,
+                                                         const uint32_t* __restrict__ perm,
                                                          const uint32_t* __restrict__ block_sums_inc,
                                                          const EmdStatus* __restrict__ status,
-                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                         uint32_t* __restrict__ tkeys, uint32_t* __restrict__ vals) {
     __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_excl[EMD_BLOCK];     // exclusive offsets inside the block
     __shared__ uint32_t s_rect[EMD_BLOCK];     // x0 | y0 << 10 | width << 20   (grid dims < 1024 tiles = 16K px)
-    __shared__ uint32_t s_depth[EMD_BLOCK];
+    __shared__ uint32_t s_id[EMD_BLOCK];
     if (status->overflow) return;
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
-    uint32_t cnt = (i < N) ? tiles_touched[i] : 0u;
+    const uint32_t cnt = (i < N) ? cnt_s[i] : 0u;
     uint32_t total;
-    uint32_t inc = block_scan_add_u32(cnt, s_scan, &total);
+    const uint32_t inc = block_scan_add_u32(cnt, s_scan, &total);
     s_excl[threadIdx.x] = inc - cnt;
-    uint32_t rectw = 0, dbits = 0;
-    if (cnt) {
-        const float4 r0 = rec[(size_t)i * EMD_REC_F4];
-        const float rad = (float)radii[i];
-        // identical arithmetic to K1 step 6 (same operands, same order) => same rectangle
-        int x0 = tile_clamp((r0.x - rad) / (float)EMD_TILE_X, gx);
-        int y0 = tile_clamp((r0.y - rad) / (float)EMD_TILE_Y, gy);
-        int x1 = tile_clamp((r0.x + rad + (float)(EMD_TILE_X - 1)) / (float)EMD_TILE_X, gx);
-        rectw = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
-        dbits = __float_as_uint(r0.z);
-    }
-    s_rect[threadIdx.x] = rectw;
-    s_depth[threadIdx.x] = dbits;
+    s_rect[threadIdx.x] = cnt ? rect_s[i] : 0u;
+    s_id[threadIdx.x] = cnt ? perm[i] : 0u;
     __syncthreads();
     const uint32_t base = blockIdx.x ? block_sums_inc[blockIdx.x - 1] : 0u;
     for (uint32_t e = threadIdx.x; e < total; e += EMD_BLOCK) {
@@ -133,20 +151,18 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, int gy, 
         const uint32_t r = s_rect[lo];
         const uint32_t w = r >> 20, x0 = r & 1023u, y0 = (r >> 10) & 1023u;
         const uint32_t ty = y0 + local / w, tx = x0 + local % w;
-        const uint64_t key = ((uint64_t)(ty * (uint32_t)gx + tx) << 32) | s_depth[lo];
-        keys[(size_t)base + e] = key;
-        vals[(size_t)base + e] = (uint32_t)(blockIdx.x * EMD_BLOCK + lo);
+        tkeys[(size_t)base + e] = ty * (uint32_t)gx + tx;
+        vals[(size_t)base + e] = s_id[lo];
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K4 radix sort: per pass (a) block histograms, (b) scan over [bin][block], (c) stable scatter
+// K4 radix pass on 32-bit keys with 32-bit values: (a) block histograms, (b) scan over [bin][block], (c) stable scatter
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(EMD_BLOCK) k_radix_hist(const uint64_t* __restrict__ keys,
-                                                          const EmdStatus* __restrict__ status, int shift,
-                                                          uint32_t nblocks_cap, uint32_t* __restrict__ hist) {
+__global__ void __launch_bounds__(EMD_BLOCK) k_radix_hist(const uint32_t* __restrict__ keys, SortN cnt, int shift,
+                                                          uint32_t mask, uint32_t nblocks_cap, uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_h[EMD_RADIX_BINS];
-    const uint32_t D = status->overflow ? 0u : status->num_rendered;
+    const uint32_t D = sort_n(cnt);
     const uint32_t nblocks = (D + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
     s_h[threadIdx.x] = 0;  // EMD_BLOCK == EMD_RADIX_BINS
     __syncthreads();
@@ -155,7 +171,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_hist(const uint64_t* __rest
 #pragma unroll
         for (int k = 0; k < EMD_SORT_ITEMS; k++) {
             size_t idx = base + (size_t)k * EMD_BLOCK + threadIdx.x;
-            if (idx < D) atomicAdd(&s_h[(uint32_t)(keys[idx] >> shift) & (EMD_RADIX_BINS - 1)], 1u);
+            if (idx < D) atomicAdd(&s_h[(keys[idx] >> shift) & mask], 1u);
         }
     }
     __syncthreads();
@@ -183,21 +199,21 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scan_bins(uint32_t* __restr
     }
 }
 
-__global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint64_t* __restrict__ keys_in,
+// vals_in == nullptr: the value of element idx is idx itself (first pass of the Gaussian depth sort)
+__global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                              const uint32_t* __restrict__ vals_in,
-                                                             uint64_t* __restrict__ keys_out,
-                                                             uint32_t* __restrict__ vals_out,
-                                                             const EmdStatus* __restrict__ status, int shift,
-                                                             uint32_t nblocks_cap,
+                                                             uint32_t* __restrict__ keys_out,
+                                                             uint32_t* __restrict__ vals_out, SortN cnt, int shift,
+                                                             uint32_t mask, uint32_t nblocks_cap,
                                                              const uint32_t* __restrict__ hist_inc) {
-    // wave w of the block owns the contiguous slice [w*1024, (w+1)*1024) of the block's 4096 keys and walks it in
-    // 16 rounds of 64 consecutive keys: order inside the block = (wave, round, lane) = memory order => stable.
+    // wave w of the block owns the contiguous slice [w*512, (w+1)*512) of the block's 2048 keys and walks it in
+    // 8 rounds of 64 consecutive keys: order inside the block = (wave, round, lane) = memory order => stable.
     __shared__ uint32_t s_cnt[4][EMD_RADIX_BINS];   // running per-wave digit counts, then per-wave bases
     __shared__ uint32_t s_gbase[EMD_RADIX_BINS];
-    __shared__ uint64_t s_keys[EMD_SORT_TILE];
+    __shared__ uint32_t s_keys[EMD_SORT_TILE];
     __shared__ uint32_t s_vals[EMD_SORT_TILE];
     __shared__ uint32_t s_scan[4];
-    const uint32_t D = status->overflow ? 0u : status->num_rendered;
+    const uint32_t D = sort_n(cnt);
     const uint32_t nblocks = (D + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
     if (blockIdx.x >= nblocks) return;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -205,15 +221,15 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint64_t* __r
     for (int k = 0; k < 4; k++) s_cnt[k][threadIdx.x] = 0;
     __syncthreads();
     const size_t wbase = (size_t)blockIdx.x * EMD_SORT_TILE + (size_t)wave * (EMD_SORT_TILE / 4);
-    uint64_t key[EMD_SORT_ITEMS];
+    uint32_t key[EMD_SORT_ITEMS];
     uint32_t rank[EMD_SORT_ITEMS];
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int k = 0; k < EMD_SORT_ITEMS; k++) {
         const size_t idx = wbase + (size_t)k * 64 + lane;
         const bool valid = idx < D;
-        key[k] = valid ? keys_in[idx] : ~0ull;
-        const uint32_t digit = (uint32_t)(key[k] >> shift) & (EMD_RADIX_BINS - 1);
+        key[k] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        const uint32_t digit = (key[k] >> shift) & mask;
         // lanes with the same digit (invalid lanes form their own class and are ignored)
         unsigned long long same = __ballot(valid);
 #pragma unroll
@@ -251,16 +267,16 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint64_t* __r
     }
     __syncthreads();
     // Reorder inside LDS first, then write: consecutive lanes hold consecutive output slots, so every digit run
-    // leaves the block as one contiguous segment.  Scattering straight from registers wrote 8- and 4-byte fragments
+    // leaves the block as one contiguous segment.  Scattering straight from registers wrote 4-byte fragments
     // of 256 different runs: 2.2x write amplification at the memory side (profiles/r01_pmc_hbm_traffic.csv).
 #pragma unroll
     for (int k = 0; k < EMD_SORT_ITEMS; k++) {
         const size_t idx = wbase + (size_t)k * 64 + lane;
         if (idx < D) {
-            const uint32_t digit = (uint32_t)(key[k] >> shift) & (EMD_RADIX_BINS - 1);
+            const uint32_t digit = (key[k] >> shift) & mask;
             const uint32_t pos = s_cnt[wave][digit] + rank[k];
             s_keys[pos] = key[k];
-            s_vals[pos] = vals_in[idx];
+            s_vals[pos] = vals_in ? vals_in[idx] : (uint32_t)idx;
         }
     }
     __syncthreads();
@@ -269,8 +285,8 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint64_t* __r
     for (int k = 0; k < EMD_SORT_ITEMS; k++) {
         const uint32_t pos = threadIdx.x + (uint32_t)k * EMD_BLOCK;
         if (pos < nvalid) {
-            const uint64_t kk = s_keys[pos];
-            const size_t dst = (size_t)s_gbase[(uint32_t)(kk >> shift) & (EMD_RADIX_BINS - 1)] + pos;
+            const uint32_t kk = s_keys[pos];
+            const size_t dst = (size_t)s_gbase[(kk >> shift) & mask] + pos;
             keys_out[dst] = kk;
             vals_out[dst] = s_vals[pos];
         }
@@ -280,19 +296,42 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint64_t* __r
 // ---------------------------------------------------------------------------------------------------
 // K5 tile ranges
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(EMD_BLOCK) k_tile_ranges(const uint64_t* __restrict__ keys,
+__global__ void __launch_bounds__(EMD_BLOCK) k_tile_ranges(const uint32_t* __restrict__ tkeys,
                                                            const EmdStatus* __restrict__ status,
                                                            uint32_t* __restrict__ ranges) {
     const uint32_t D = status->overflow ? 0u : status->num_rendered;
     for (size_t idx = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; idx < D; idx += (size_t)gridDim.x * EMD_BLOCK) {
-        const uint32_t t = (uint32_t)(keys[idx] >> 32);
+        const uint32_t t = tkeys[idx];
         if (idx == 0) ranges[2 * t] = 0;
         else {
-            const uint32_t tp = (uint32_t)(keys[idx - 1] >> 32);
+            const uint32_t tp = tkeys[idx - 1];
             if (tp != t) { ranges[2 * tp + 1] = (uint32_t)idx; ranges[2 * t] = (uint32_t)idx; }
         }
         if (idx == D - 1) ranges[2 * t + 1] = D;
     }
+}
+
+// upstream's 64-bit keys, rebuilt for the parity tests: tile id << 32 | depth bits of the Gaussian
+__global__ void __launch_bounds__(EMD_BLOCK) k_export_keys(size_t D, const uint32_t* __restrict__ tkeys,
+                                                           const uint32_t* __restrict__ vals,
+                                                           const uint32_t* __restrict__ depth_key,
+                                                           uint64_t* __restrict__ keys) {
+    const size_t i = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i < D) keys[i] = ((uint64_t)tkeys[i] << 32) | depth_key[vals[i]];
+}
+
+// one stable LSD pass over `n_cap` (launch bound) / sort_n(cnt) (actual) pairs
+int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, SortN cnt, size_t n_cap, int shift,
+               int bits, uint32_t* hist, hipStream_t st) {
+    const uint32_t nsb = (uint32_t)((n_cap + EMD_SORT_TILE - 1) / EMD_SORT_TILE);
+    const uint32_t mask = (1u << bits) - 1u;
+    hipLaunchKernelGGL(k_radix_hist, dim3(nsb), dim3(EMD_BLOCK), 0, st, kin, cnt, shift, mask, nsb, hist);
+    EMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_radix_scan_bins, dim3(1u << bits), dim3(EMD_BLOCK), 0, st, hist, nsb);
+    EMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_radix_scatter, dim3(nsb), dim3(EMD_BLOCK), 0, st, kin, vin, kout, vout, cnt, shift, mask, nsb, hist);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
 }
 
 }  // namespace
@@ -314,40 +353,64 @@ int emd_launch_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st)
     return EMD_OK;
 }
 
-int emd_launch_binning(const EmdSettings& s, int N, const int32_t* radii, const GeomWs& g, const BinWs& b,
-                       int64_t capacity, EmdStatus* status, hipStream_t st) {
+int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,
+                       hipStream_t st) {
     const int gx = (s.image_width + EMD_TILE_X - 1) / EMD_TILE_X, gy = (s.image_height + EMD_TILE_Y - 1) / EMD_TILE_Y;
     const int T = gx * gy;
     if (gx >= 1024 || gy >= 1024) { emd_set_error("image too large: %d x %d tiles (max 1023)", gx, gy); return EMD_ERR_INVALID; }
     const int nb = (N + EMD_BLOCK - 1) / EMD_BLOCK;
-    emd_prof_switch(PROF_PREPROCESS, PROF_DUPLICATE, st);
-    int rc = emd_launch_scan_u32(g.block_sums, (size_t)nb, g.scan_tmp, st);
+    int rc;
+    // 1. Gaussians in depth order: depth_key -> gkeys[0] -> gkeys[1] -> gkeys[0] -> gkeys[1]
+    emd_prof_switch(PROF_PREPROCESS, PROF_SORT, st);
+    if (N > 0) {
+        const SortN cn = {nullptr, (uint32_t)N};
+        const uint32_t* kin = g.depth_key;
+        const uint32_t* vin = nullptr;
+        for (int p = 0; p < EMD_DEPTH_PASSES; p++) {
+            rc = radix_pass(kin, vin, g.gkeys[p & 1], g.gvals[p & 1], cn, (size_t)N, p * EMD_RADIX_BITS, EMD_RADIX_BITS, g.ghist, st);
+            if (rc) return rc;
+            kin = g.gkeys[p & 1]; vin = g.gvals[p & 1];
+        }
+    }
+    const uint32_t* depth_sorted = g.gkeys[(EMD_DEPTH_PASSES - 1) & 1];
+    const uint32_t* perm = g.gvals[(EMD_DEPTH_PASSES - 1) & 1];
+    // 2. tile counts in that order, offsets, duplicate
+    emd_prof_switch(PROF_SORT, PROF_DUPLICATE, st);
+    if (N > 0) {
+        hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, depth_sorted, perm, g.binrec, g.rect_s, g.cnt_s,
+                           g.block_sums);
+        EMD_LAUNCH_CHECK();
+    }
+    rc = emd_launch_scan_u32(g.block_sums, (size_t)nb, g.scan_tmp, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(64), 0, st, g.block_sums, nb, (uint64_t)capacity, status);
     EMD_LAUNCH_CHECK();
     EMD_HIP_CHECK(hipMemsetAsync(b.ranges, 0, (size_t)T * 8, st));
     if (N == 0 || capacity <= 0) { emd_prof_switch(PROF_DUPLICATE, PROF_RANGES, st); return EMD_OK; }
-    hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(EMD_BLOCK), 0, st, N, gx, gy, radii, g.rec, g.tiles_touched,
-                       g.block_sums, status, b.keys[0], b.vals[0]);
+    hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(EMD_BLOCK), 0, st, N, gx, g.rect_s, g.cnt_s, perm, g.block_sums, status,
+                       b.tkeys[0], b.vals[0]);
     EMD_LAUNCH_CHECK();
+    // 3. stable partition by tile id
     emd_prof_switch(PROF_DUPLICATE, PROF_SORT, st);
-    const uint32_t nsb = (uint32_t)(((size_t)capacity + EMD_SORT_TILE - 1) / EMD_SORT_TILE);
-    const int passes = emd_sort_passes(T);
+    const SortN cd = {status, 0u};
+    const int passes = emd_tile_passes(T), bits = emd_tile_pass_bits(T);
     int cur = 0;
     for (int p = 0; p < passes; p++) {
-        const int shift = p * EMD_RADIX_BITS;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nsb), dim3(EMD_BLOCK), 0, st, b.keys[cur], status, shift, nsb, b.hist);
-        EMD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_radix_scan_bins, dim3(EMD_RADIX_BINS), dim3(EMD_BLOCK), 0, st, b.hist, nsb);
-        EMD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nsb), dim3(EMD_BLOCK), 0, st, b.keys[cur], b.vals[cur], b.keys[cur ^ 1],
-                           b.vals[cur ^ 1], status, shift, nsb, b.hist);
-        EMD_LAUNCH_CHECK();
+        rc = radix_pass(b.tkeys[cur], b.vals[cur], b.tkeys[cur ^ 1], b.vals[cur ^ 1], cd, (size_t)capacity, p * bits, bits, b.hist, st);
+        if (rc) return rc;
         cur ^= 1;
     }
     emd_prof_switch(PROF_SORT, PROF_RANGES, st);
     const unsigned rb = (unsigned)(((size_t)capacity + EMD_BLOCK - 1) / EMD_BLOCK);
-    hipLaunchKernelGGL(k_tile_ranges, dim3(rb < 4096u ? rb : 4096u), dim3(EMD_BLOCK), 0, st, b.keys[cur], status, b.ranges);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(rb < 4096u ? rb : 4096u), dim3(EMD_BLOCK), 0, st, b.tkeys[cur], status, b.ranges);
     EMD_LAUNCH_CHECK();
     return EMD_OK;   // PROF_RANGES is closed by the render-forward switch
+}
+
+int emd_launch_export_keys(int64_t D, const GeomWs& g, const BinWs& b, uint64_t* keys, hipStream_t st) {
+    if (D <= 0) return EMD_OK;
+    hipLaunchKernelGGL(k_export_keys, dim3((unsigned)((D + EMD_BLOCK - 1) / EMD_BLOCK)), dim3(EMD_BLOCK), 0, st, (size_t)D,
+                       b.tkeys[b.sorted_buf], b.vals[b.sorted_buf], g.depth_key, keys);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
 }

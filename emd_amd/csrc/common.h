@@ -26,18 +26,23 @@ struct GeomWs {
     float4* rec;             // [N][4]
     float4* shjac;           // [N][3] d rgb_c / d (unit view direction): row c = (d/dx, d/dy, d/dz, -); written by K1 for
                              // visible Gaussians so that K8 need not re-read the 192 B of SH coefficients
-    uint32_t* tiles_touched; // [N]
-    uint32_t* block_sums;    // [ceil(N/256)] inclusive-scanned in place
+    uint2* binrec;           // [N] by Gaussian id: x = tile rectangle x0 | y0 << 10 | width << 20, y = tiles touched (K1)
+    uint32_t* depth_key;     // [N] by Gaussian id: float bits of the view depth, 0xFFFFFFFF when not visible (K1)
+    uint32_t* gkeys[2];      // [N] ping-pong of the Gaussian depth sort
+    uint32_t* gvals[2];      // [N] Gaussian ids in depth order after the sort (gvals[1])
+    uint32_t* rect_s;        // [N] tile rectangle of the Gaussians in depth order
+    uint32_t* cnt_s;         // [N] tiles touched of the Gaussians in depth order
+    uint32_t* ghist;         // radix histograms of the depth sort [bins][ceil(N / sort tile)]
+    uint32_t* block_sums;    // [ceil(N/256)] tile counts per block of depth-ordered Gaussians, inclusive-scanned in place
     uint32_t* scan_tmp;      // scratch for the scans
     size_t bytes;
 };
 
 struct BinWs {
-    uint64_t* keys[2];       // [capacity] ping-pong
-    uint32_t* vals[2];       // [capacity]
+    uint32_t* tkeys[2];      // [capacity] ping-pong: tile id of every (tile, Gaussian) pair
+    uint32_t* vals[2];       // [capacity] Gaussian id
     uint32_t* ranges;        // [T][2]
     uint32_t* hist;          // radix histograms [bins][num_sort_blocks]
-    uint32_t* scan_tmp;      // scratch for the scans
     int sorted_buf;          // which ping-pong buffer holds the sorted list after forward (fixed by #passes)
     size_t bytes;
 };
@@ -61,8 +66,14 @@ static inline int emd_tile_bits(int num_tiles) {
     while ((1 << b) < num_tiles) b++;
     return b;
 }
-// key = tile_id << 32 | depth bits: only the low 32 + ceil(log2(tiles)) bits take part in the sort
-static inline int emd_sort_passes(int num_tiles) { return (32 + emd_tile_bits(num_tiles) + EMD_RADIX_BITS - 1) / EMD_RADIX_BITS; }
+// Upstream key = tile_id << 32 | depth bits.  Sorted here as 4 radix passes over the depth bits of the N Gaussians,
+// then ceil(tile bits / 8) passes of equal width over the tile ids of the duplicates (binning.hip).
+#define EMD_DEPTH_PASSES (32 / EMD_RADIX_BITS)
+static inline int emd_tile_passes(int num_tiles) { return (emd_tile_bits(num_tiles) + EMD_RADIX_BITS - 1) / EMD_RADIX_BITS; }
+static inline int emd_tile_pass_bits(int num_tiles) {
+    const int p = emd_tile_passes(num_tiles);
+    return p ? (emd_tile_bits(num_tiles) + p - 1) / p : 0;
+}
 
 static inline size_t emd_scan_tmp_elems(size_t n) {
     // partial sums of a 3-phase scan over n elements with 1024-element blocks, two levels
@@ -73,10 +84,18 @@ static inline size_t emd_scan_tmp_elems(size_t n) {
 static inline void emd_carve_geom(void* base, int N, GeomWs* w) {
     char* p = (char*)base;
     size_t off = 0;
-    w->rec = (float4*)(p + off); off = emd_align_up(off + (size_t)N * EMD_REC_F4 * sizeof(float4), 256);
-    w->shjac = (float4*)(p + off); off = emd_align_up(off + (size_t)N * 3 * sizeof(float4), 256);
-    w->tiles_touched = (uint32_t*)(p + off); off = emd_align_up(off + (size_t)N * 4, 256);
-    size_t nb = ((size_t)N + EMD_BLOCK - 1) / EMD_BLOCK;
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    w->rec = (float4*)(p + off); off = emd_align_up(off + n * EMD_REC_F4 * sizeof(float4), 256);
+    w->shjac = (float4*)(p + off); off = emd_align_up(off + n * 3 * sizeof(float4), 256);
+    w->binrec = (uint2*)(p + off); off = emd_align_up(off + n * 8, 256);
+    w->depth_key = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256);
+    for (int i = 0; i < 2; i++) { w->gkeys[i] = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256); }
+    for (int i = 0; i < 2; i++) { w->gvals[i] = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256); }
+    w->rect_s = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256);
+    w->cnt_s = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256);
+    size_t nsb = (n + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
+    w->ghist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_RADIX_BINS * 4, 256);
+    size_t nb = (n + EMD_BLOCK - 1) / EMD_BLOCK;
     w->block_sums = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 1) * 4, 256);
     w->scan_tmp = (uint32_t*)(p + off); off = emd_align_up(off + emd_scan_tmp_elems(nb) * 4, 256);
     w->bytes = off + 256;
@@ -86,14 +105,12 @@ static inline void emd_carve_bin(void* base, int64_t capacity, int num_tiles, Bi
     char* p = (char*)base;
     size_t off = 0;
     size_t cap = (size_t)(capacity > 0 ? capacity : 1);
-    for (int i = 0; i < 2; i++) { w->keys[i] = (uint64_t*)(p + off); off = emd_align_up(off + cap * 8, 256); }
+    for (int i = 0; i < 2; i++) { w->tkeys[i] = (uint32_t*)(p + off); off = emd_align_up(off + cap * 4, 256); }
     for (int i = 0; i < 2; i++) { w->vals[i] = (uint32_t*)(p + off); off = emd_align_up(off + cap * 4, 256); }
     w->ranges = (uint32_t*)(p + off); off = emd_align_up(off + (size_t)num_tiles * 8, 256);
     size_t nsb = (cap + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
-    size_t hist_elems = nsb * EMD_RADIX_BINS;
-    w->hist = (uint32_t*)(p + off); off = emd_align_up(off + hist_elems * 4, 256);
-    w->scan_tmp = (uint32_t*)(p + off); off = emd_align_up(off + emd_scan_tmp_elems(hist_elems) * 4, 256);
-    w->sorted_buf = emd_sort_passes(num_tiles) & 1;
+    w->hist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_RADIX_BINS * 4, 256);
+    w->sorted_buf = emd_tile_passes(num_tiles) & 1;
     w->bytes = off + 256;
 }
 
@@ -135,8 +152,9 @@ struct PreArgs {
 };
 int emd_launch_preprocess(const PreArgs& a, hipStream_t st);                 // preprocess.hip
 int emd_launch_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st);  // binning.hip (inclusive, in place)
-int emd_launch_binning(const EmdSettings& s, int N, const int32_t* radii, const GeomWs& g, const BinWs& b,
-                       int64_t capacity, EmdStatus* status, hipStream_t st); // binning.hip
+int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,
+                       hipStream_t st);                                       // binning.hip
+int emd_launch_export_keys(int64_t D, const GeomWs& g, const BinWs& b, uint64_t* keys, hipStream_t st);  // binning.hip
 int emd_launch_render_forward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                               float* out_color, float* out_depth, float* out_normal, float* out_alpha,
                               hipStream_t st);                                 // render.hip

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
     const bool sh_staged = a.shs && a.M == 16;
     if (sh_staged) { sh_block_load(a.shs, a.N, s_sh); __syncthreads(); }
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
-    uint32_t touched = 0;
+    uint32_t touched = 0, rect = 0, dkey = 0xFFFFFFFFu;
     int radius_out = 0;
     if (i < a.N) {
         const float* V = S.viewmatrix;
@@ -383,22 +383,23 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
                         rec[3] = make_float4(nv[0], nv[1], nv[2], 0.f);
                     }
                     touched = (uint32_t)area;
+                    rect = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
+                    dkey = __float_as_uint(p.tz);
                     radius_out = (int)rad;
                 }
             }
         }
         a.radii[i] = radius_out;
-        a.g.tiles_touched[i] = touched;
+        a.g.binrec[i] = make_uint2(rect, touched);     // binning input: tile rectangle, tiles touched
+        a.g.depth_key[i] = dkey;                         // key of the depth sort (invisible: sorts last)
     }
-    // block totals: tiles touched (feeds the duplicate offsets) and visible count
+    // visible count
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t tsum = wave_scan_add_u32(touched);
-    uint32_t vsum = wave_scan_add_u32(touched ? 1u : 0u);
-    if (lane == 63) { s_red[wave] = tsum; s_red[4 + wave] = vsum; }
+    const uint32_t vsum = (uint32_t)__popcll(__ballot(touched != 0u));
+    if (lane == 0) s_red[wave] = vsum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.g.block_sums[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-        uint32_t v = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+        uint32_t v = s_red[0] + s_red[1] + s_red[2] + s_red[3];
         if (v) atomicAdd(&a.status->num_visible, v);
     }
 }
@@ -791,12 +792,13 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sh_backward(int n, int deg, int M
     }
 }
 
-__global__ void __launch_bounds__(EMD_BLOCK) k_export_geometry(int N, const float4* rec, const uint32_t* tt,
+__global__ void __launch_bounds__(EMD_BLOCK) k_export_geometry(int N, const float4* rec, const uint2* binrec,
                                                                float* means2D, float* depths, float* conic_opacity,
                                                                float* rgb, float* normal, uint32_t* tiles_touched) {
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
     if (i >= N) return;
-    const bool vis = tt[i] != 0;
+    const uint32_t tt = binrec[i].y;
+    const bool vis = tt != 0;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 r0 = vis ? rec[(size_t)i * EMD_REC_F4] : z, r1 = vis ? rec[(size_t)i * EMD_REC_F4 + 1] : z,
                  r2 = vis ? rec[(size_t)i * EMD_REC_F4 + 2] : z;
@@ -805,7 +807,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_export_geometry(int N, const floa
     if (conic_opacity) *(float4*)(conic_opacity + 4 * i) = make_float4(r1.x, r1.y, r1.z, r0.w);
     if (rgb) { rgb[3 * i] = r2.x; rgb[3 * i + 1] = r2.y; rgb[3 * i + 2] = r2.z; }
     if (normal) { const float4 r3 = vis ? rec[(size_t)i * EMD_REC_F4 + 3] : z; normal[3 * i] = r3.x; normal[3 * i + 1] = r3.y; normal[3 * i + 2] = r3.z; }
-    if (tiles_touched) tiles_touched[i] = tt[i];
+    if (tiles_touched) tiles_touched[i] = tt;
 }
 
 __global__ void __launch_bounds__(EMD_BLOCK) k_activations(int n, const float* ls, float* sc, const float* rq, float* q,
@@ -978,7 +980,7 @@ int emd_launch_export_geometry(int N, const GeomWs& g, float* means2D, float* de
                                float* normal, uint32_t* tiles_touched, hipStream_t st) {
     if (N <= 0) return EMD_OK;
     hipLaunchKernelGGL(k_export_geometry, dim3((N + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, N, g.rec,
-                       g.tiles_touched, means2D, depths, conic_opacity, rgb, normal, tiles_touched);
+                       g.binrec, means2D, depths, conic_opacity, rgb, normal, tiles_touched);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

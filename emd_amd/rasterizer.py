@@ -322,7 +322,8 @@ class GaussianRasterizer(nn.Module):
         ids = torch.empty(max(D, 1), device=dev, dtype=torch.int32)
         ranges = torch.empty(T, 2, device=dev, dtype=torch.int32)
         d = L.EmdDims(last["N"], last["H"], last["W"], last["capacity"], last["flags"])
-        L.check(lib.emd_raster_export_binning(C.byref(d), last["bin_ws"].data_ptr(), last["sizes"][1], D, keys.data_ptr(),
+        L.check(lib.emd_raster_export_binning(C.byref(d), last["geom_ws"].data_ptr(), last["sizes"][0],
+                                              last["bin_ws"].data_ptr(), last["sizes"][1], D, keys.data_ptr(),
                                               ids.data_ptr(), ranges.data_ptr(), _stream()), "emd_raster_export_binning")
         return keys[:D], ids[:D], ranges
 

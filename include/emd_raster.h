@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 4
+#define EMD_ABI_VERSION 5
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -207,8 +207,10 @@ int emd_raster_forward(EmdFwdArgs* args, void* hip_stream);
 int emd_raster_backward(const EmdBwdArgs* args, void* hip_stream);
 
 /* Copy binning state out for parity tests: sorted keys (tile<<32 | depth bits), sorted Gaussian ids,
- * per-tile [start,end) ranges.  Any output may be NULL.  keys/ids hold num_rendered entries. */
-int emd_raster_export_binning(const EmdDims* dims, const void* bin_ws, size_t bin_bytes,
+ * per-tile [start,end) ranges.  Any output may be NULL.  keys/ids hold num_rendered entries.
+ * The sort itself moves (tile id, Gaussian id) pairs of Gaussians pre-ordered by depth; the 64-bit keys of the
+ * reference are rebuilt here from the tile id and the depth bits kept per Gaussian in geom_ws. */
+int emd_raster_export_binning(const EmdDims* dims, const void* geom_ws, size_t geom_bytes, const void* bin_ws, size_t bin_bytes,
                               int64_t num_rendered, uint64_t* keys, uint32_t* ids, uint32_t* ranges /*[T,2]*/,
                               void* hip_stream);
 
