@@ -177,8 +177,7 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
         hipError_t e_ = hipStreamSynchronize(st);                                                            \
         if (e_ != hipSuccess) { emd_set_error("stage %s failed: %s", name, hipGetErrorString(e_)); return EMD_ERR_HIP; } \
     }
-    EMD_HIP_CHECK(hipMemsetAsync(a->status, 0, sizeof(EmdStatus), st));
-    PreArgs pa;
+    PreArgs pa;   // (the status word is written by the binning stage)
     pa.s = a->s; pa.N = N; pa.M = a->sh_coeffs; pa.flags = a->flags;
     pa.means3D = a->means3D; pa.shs = a->shs; pa.colors_precomp = a->colors_precomp; pa.opacities = a->opacities;
     pa.scales = a->scales; pa.rotations = a->rotations; pa.cov3D_precomp = a->cov3D_precomp;

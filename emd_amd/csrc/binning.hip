@@ -86,42 +86,82 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_scan_down(uint32_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// D = last block sum; clamp against capacity; publish in status
-// ---------------------------------------------------------------------------------------------------
-__global__ void k_publish_count(const uint32_t* __restrict__ block_sums_inc, int nb, uint64_t capacity,
-                                EmdStatus* status) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint32_t D = nb > 0 ? block_sums_inc[nb - 1] : 0u;
-        status->num_rendered = D;
-        status->overflow = ((uint64_t)D > capacity) ? 1u : 0u;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // K2': tile rectangle and tile count of the Gaussians in depth order (one 8-byte gather each) + block totals
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32_t* __restrict__ depth_sorted,
                                                              const uint32_t* __restrict__ perm,
                                                              const uint2* __restrict__ binrec,
                                                              uint32_t* __restrict__ rect_s, uint32_t* __restrict__ cnt_s,
-                                                             uint32_t* __restrict__ block_sums) {
+                                                             uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_vis,
+                                                             uint32_t* __restrict__ ranges, uint32_t n_ranges) {
     __shared__ uint32_t s_scan[4];
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
     uint2 br = make_uint2(0u, 0u);
     if (i < N && depth_sorted[i] != 0xFFFFFFFFu) br = binrec[perm[i]];   // invisible Gaussians sort last, count 0
     if (i < N) { rect_s[i] = br.x; cnt_s[i] = br.y; }
-    uint32_t total;
+    // empty tiles keep the range (0, 0): cleared here instead of by a separate memset launch
+    for (uint32_t r = (uint32_t)i; r < n_ranges; r += gridDim.x * EMD_BLOCK) ranges[r] = 0u;
+    uint32_t total, vis;
     block_scan_add_u32(br.y, s_scan, &total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    block_scan_add_u32(br.y ? 1u : 0u, s_scan, &vis);
+    if (threadIdx.x == 0) { block_sums[blockIdx.x] = total; block_vis[blockIdx.x] = vis; }
+}
+
+// Single workgroup: inclusive scan of the per-block tile counts in place, D / overflow / V into the status word, and for
+// every 2048-slot output block of the duplicate kernel the block of Gaussians that holds its first slot.
+#define DUP_SLOTS EMD_SORT_TILE
+__global__ void __launch_bounds__(EMD_BLOCK) k_scan_publish(uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ block_vis,
+                                                            uint32_t nb, uint64_t capacity, EmdStatus* __restrict__ status,
+                                                            uint32_t* __restrict__ slot_start, uint32_t n_slot_blocks) {
+    __shared__ uint32_t s[4];
+    uint32_t carry = 0, vis = 0;
+    for (uint32_t base = 0; base < nb; base += SCAN_TILE) {
+        const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            v[k] = (i0 + k < nb) ? block_sums[i0 + k] : 0u;
+            vis += (i0 + k < nb) ? block_vis[i0 + k] : 0u;
+            sum += v[k];
+        }
+        uint32_t total;
+        const uint32_t inc = block_scan_add_u32(sum, s, &total);
+        uint32_t run = carry + inc - sum;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            const uint32_t excl = run;
+            run += v[k];
+            if (i0 + k < nb) {
+                block_sums[i0 + k] = run;
+                // output blocks whose first slot falls into [excl, run)
+                for (uint32_t sb = (excl + DUP_SLOTS - 1) / DUP_SLOTS; sb < n_slot_blocks && (uint64_t)sb * DUP_SLOTS < run; sb++)
+                    slot_start[sb] = i0 + k;
+            }
+        }
+        carry += total;
+    }
+    uint32_t vtot;
+    block_scan_add_u32(vis, s, &vtot);
+    if (threadIdx.x == 0) {
+        status->num_rendered = carry;
+        status->overflow = ((uint64_t)carry > capacity) ? 1u : 0u;
+        status->num_visible = vtot;
+        status->reserved = 0u;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // K3 duplicate: (tile id, Gaussian id) pairs in (depth, Gaussian id) order
 // ---------------------------------------------------------------------------------------------------
+// Balanced over OUTPUT slots: workgroup b writes slots [2048 b, 2048 (b + 1)) and walks the blocks of 256 depth-ordered
+// Gaussians that own them (the nearest Gaussians cover thousands of tiles each and all sit at the front of the order, so
+// a Gaussian-block-per-workgroup split would leave a long tail).  Inside a Gaussian block the owner of a slot is found
+// by binary search over the block's exclusive offsets in LDS; consecutive lanes write consecutive pairs.
 __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const uint32_t* __restrict__ rect_s,
                                                          const uint32_t* __restrict__ cnt_s,
                                                          const uint32_t* __restrict__ perm,
                                                          const uint32_t* __restrict__ block_sums_inc,
+                                                         const uint32_t* __restrict__ slot_start,
                                                          const EmdStatus* __restrict__ status,
                                                          uint32_t* __restrict__ tkeys, uint32_t* __restrict__ vals) {
     __shared__ uint32_t s_scan[4];
@@ -129,30 +169,43 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
     __shared__ uint32_t s_rect[EMD_BLOCK];     // x0 | y0 << 10 | width << 20   (grid dims < 1024 tiles = 16K px)
     __shared__ uint32_t s_id[EMD_BLOCK];
     if (status->overflow) return;
-    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
-    const uint32_t cnt = (i < N) ? cnt_s[i] : 0u;
-    uint32_t total;
-    const uint32_t inc = block_scan_add_u32(cnt, s_scan, &total);
-    s_excl[threadIdx.x] = inc - cnt;
-    s_rect[threadIdx.x] = cnt ? rect_s[i] : 0u;
-    s_id[threadIdx.x] = cnt ? perm[i] : 0u;
-    __syncthreads();
-    const uint32_t base = blockIdx.x ? block_sums_inc[blockIdx.x - 1] : 0u;
-    for (uint32_t e = threadIdx.x; e < total; e += EMD_BLOCK) {
-        // largest j with s_excl[j] <= e  (entries with cnt == 0 share offsets with their successor; the search
-        // lands on the last of an equal run, which is the one that owns slot e)
-        int lo = 0, hi = EMD_BLOCK - 1;
+    const uint32_t D = status->num_rendered;
+    const uint64_t S0l = (uint64_t)blockIdx.x * DUP_SLOTS;
+    if (S0l >= D) return;
+    const uint32_t S0 = (uint32_t)S0l, S1 = (uint32_t)min((uint64_t)D, S0l + DUP_SLOTS);
+    const uint32_t nb = ((uint32_t)N + EMD_BLOCK - 1) / EMD_BLOCK;
+    for (uint32_t gb = slot_start[blockIdx.x]; gb < nb; gb++) {
+        const uint32_t base = gb ? block_sums_inc[gb - 1] : 0u;
+        if (base >= S1) break;
+        const uint32_t end = block_sums_inc[gb];
+        if (end <= S0) continue;
+        const uint32_t i = gb * EMD_BLOCK + threadIdx.x;
+        const uint32_t cnt = (i < (uint32_t)N) ? cnt_s[i] : 0u;
+        uint32_t total;
+        const uint32_t inc = block_scan_add_u32(cnt, s_scan, &total);
+        s_excl[threadIdx.x] = inc - cnt;
+        s_rect[threadIdx.x] = cnt ? rect_s[i] : 0u;
+        s_id[threadIdx.x] = cnt ? perm[i] : 0u;
+        __syncthreads();
+        const uint32_t lo_slot = max(S0, base), hi_slot = min(S1, end);
+        for (uint32_t eg = lo_slot + threadIdx.x; eg < hi_slot; eg += EMD_BLOCK) {
+            const uint32_t e = eg - base;
+            // largest j with s_excl[j] <= e  (entries with cnt == 0 share offsets with their successor; the search
+            // lands on the last of an equal run, which is the one that owns slot e)
+            int lo = 0, hi = EMD_BLOCK - 1;
 #pragma unroll
-        for (int step = 0; step < 8; step++) {
-            int mid = (lo + hi + 1) >> 1;
-            if (s_excl[mid] <= e) lo = mid; else hi = mid - 1;
+            for (int step = 0; step < 8; step++) {
+                int mid = (lo + hi + 1) >> 1;
+                if (s_excl[mid] <= e) lo = mid; else hi = mid - 1;
+            }
+            const uint32_t local = e - s_excl[lo];
+            const uint32_t r = s_rect[lo];
+            const uint32_t w = r >> 20, x0 = r & 1023u, y0 = (r >> 10) & 1023u;
+            const uint32_t ty = y0 + local / w, tx = x0 + local % w;
+            tkeys[eg] = ty * (uint32_t)gx + tx;
+            vals[eg] = s_id[lo];
         }
-        const uint32_t local = e - s_excl[lo];
-        const uint32_t r = s_rect[lo];
-        const uint32_t w = r >> 20, x0 = r & 1023u, y0 = (r >> 10) & 1023u;
-        const uint32_t ty = y0 + local / w, tx = x0 + local % w;
-        tkeys[(size_t)base + e] = ty * (uint32_t)gx + tx;
-        vals[(size_t)base + e] = s_id[lo];
+        __syncthreads();   // LDS reused by the next block of Gaussians
     }
 }
 
@@ -376,19 +429,29 @@ int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs
     const uint32_t* perm = g.gvals[(EMD_DEPTH_PASSES - 1) & 1];
     // 2. tile counts in that order, offsets, duplicate
     emd_prof_switch(PROF_SORT, PROF_DUPLICATE, st);
-    if (N > 0) {
-        hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, depth_sorted, perm, g.binrec, g.rect_s, g.cnt_s,
-                           g.block_sums);
-        EMD_LAUNCH_CHECK();
+    if (N == 0 || capacity <= 0) {
+        EMD_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(EmdStatus), st));
+        EMD_HIP_CHECK(hipMemsetAsync(b.ranges, 0, (size_t)T * 8, st));
+        if (N > 0) {   // D and V are still reported (capacity 0 is how callers size the workspace)
+            hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, depth_sorted, perm, g.binrec, g.rect_s, g.cnt_s,
+                               g.block_sums, g.block_vis, b.ranges, 0u);
+            EMD_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(EMD_BLOCK), 0, st, g.block_sums, g.block_vis, (uint32_t)nb,
+                               (uint64_t)(capacity > 0 ? capacity : 0), status, b.slot_start, 0u);
+            EMD_LAUNCH_CHECK();
+        }
+        emd_prof_switch(PROF_DUPLICATE, PROF_RANGES, st);
+        return EMD_OK;
     }
-    rc = emd_launch_scan_u32(g.block_sums, (size_t)nb, g.scan_tmp, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(64), 0, st, g.block_sums, nb, (uint64_t)capacity, status);
+    const uint32_t nslot = (uint32_t)(((size_t)capacity + DUP_SLOTS - 1) / DUP_SLOTS);
+    hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, depth_sorted, perm, g.binrec, g.rect_s, g.cnt_s,
+                       g.block_sums, g.block_vis, b.ranges, (uint32_t)(2 * T));
     EMD_LAUNCH_CHECK();
-    EMD_HIP_CHECK(hipMemsetAsync(b.ranges, 0, (size_t)T * 8, st));
-    if (N == 0 || capacity <= 0) { emd_prof_switch(PROF_DUPLICATE, PROF_RANGES, st); return EMD_OK; }
-    hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(EMD_BLOCK), 0, st, N, gx, g.rect_s, g.cnt_s, perm, g.block_sums, status,
-                       b.tkeys[0], b.vals[0]);
+    hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(EMD_BLOCK), 0, st, g.block_sums, g.block_vis, (uint32_t)nb, (uint64_t)capacity,
+                       status, b.slot_start, nslot);
+    EMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_duplicate, dim3(nslot), dim3(EMD_BLOCK), 0, st, N, gx, g.rect_s, g.cnt_s, perm, g.block_sums, b.slot_start,
+                       status, b.tkeys[0], b.vals[0]);
     EMD_LAUNCH_CHECK();
     // 3. stable partition by tile id
     emd_prof_switch(PROF_DUPLICATE, PROF_SORT, st);

@@ -34,6 +34,7 @@ struct GeomWs {
     uint32_t* cnt_s;         // [N] tiles touched of the Gaussians in depth order
     uint32_t* ghist;         // radix histograms of the depth sort [bins][ceil(N / sort tile)]
     uint32_t* block_sums;    // [ceil(N/256)] tile counts per block of depth-ordered Gaussians, inclusive-scanned in place
+    uint32_t* block_vis;     // [ceil(N/256)] visible Gaussians per block
     uint32_t* scan_tmp;      // scratch for the scans
     size_t bytes;
 };
@@ -43,6 +44,7 @@ struct BinWs {
     uint32_t* vals[2];       // [capacity] Gaussian id
     uint32_t* ranges;        // [T][2]
     uint32_t* hist;          // radix histograms [bins][num_sort_blocks]
+    uint32_t* slot_start;    // [ceil(capacity / 2048)] first block of Gaussians of every output block of the duplicate kernel
     int sorted_buf;          // which ping-pong buffer holds the sorted list after forward (fixed by #passes)
     size_t bytes;
 };
@@ -97,6 +99,7 @@ static inline void emd_carve_geom(void* base, int N, GeomWs* w) {
     w->ghist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_RADIX_BINS * 4, 256);
     size_t nb = (n + EMD_BLOCK - 1) / EMD_BLOCK;
     w->block_sums = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 1) * 4, 256);
+    w->block_vis = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 1) * 4, 256);
     w->scan_tmp = (uint32_t*)(p + off); off = emd_align_up(off + emd_scan_tmp_elems(nb) * 4, 256);
     w->bytes = off + 256;
 }
@@ -110,6 +113,7 @@ static inline void emd_carve_bin(void* base, int64_t capacity, int num_tiles, Bi
     w->ranges = (uint32_t*)(p + off); off = emd_align_up(off + (size_t)num_tiles * 8, 256);
     size_t nsb = (cap + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
     w->hist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_RADIX_BINS * 4, 256);
+    w->slot_start = (uint32_t*)(p + off); off = emd_align_up(off + (nsb + 1) * 4, 256);
     w->sorted_buf = emd_tile_passes(num_tiles) & 1;
     w->bytes = off + 256;
 }

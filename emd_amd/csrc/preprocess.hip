@@ -267,7 +267,6 @@ __device__ __forceinline__ void sh_row_load(bool staged, const float4* s_sh, con
 // K1
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
-    __shared__ uint32_t s_red[8];
     __shared__ float4 s_sh[EMD_BLOCK * SH_ROW4];
     const EmdSettings& S = a.s;
     const bool sh_staged = a.shs && a.M == 16;
@@ -392,15 +391,6 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
         a.radii[i] = radius_out;
         a.g.binrec[i] = make_uint2(rect, touched);     // binning input: tile rectangle, tiles touched
         a.g.depth_key[i] = dkey;                         // key of the depth sort (invisible: sorts last)
-    }
-    // visible count
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t vsum = (uint32_t)__popcll(__ballot(touched != 0u));
-    if (lane == 0) s_red[wave] = vsum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t v = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-        if (v) atomicAdd(&a.status->num_visible, v);
     }
 }
 
