@@ -229,21 +229,13 @@ __device__ __forceinline__ void sh_dir_jacobian(int deg, const float d[3], const
 // 13 float4 (52 dwords): 52 t mod 64 takes 16 distinct multiples of 4, so a ds_read_b128 lane group is conflict-free.
 // ---------------------------------------------------------------------------------------------------
 #define SH_ROW4 13
-__device__ __forceinline__ void sh_block_load(const float* __restrict__ shs, int N, float4* s_sh) {
-    const size_t base4 = (size_t)blockIdx.x * EMD_BLOCK * 12, lim4 = (size_t)N * 12;
-    const float4* src = (const float4*)shs;
-#pragma unroll
-    for (int j = 0; j < 12; j++) {
-        const uint32_t idx = threadIdx.x + EMD_BLOCK * j;
-        if (base4 + idx < lim4) s_sh[(idx / 12) * SH_ROW4 + (idx % 12)] = src[base4 + idx];
-    }
-}
+template <int BLK>
 __device__ __forceinline__ void sh_block_store(float* __restrict__ dst, int N, const float4* s_sh) {
-    const size_t base4 = (size_t)blockIdx.x * EMD_BLOCK * 12, lim4 = (size_t)N * 12;
+    const size_t base4 = (size_t)blockIdx.x * BLK * 12, lim4 = (size_t)N * 12;
     float4* out = (float4*)dst;
 #pragma unroll
     for (int j = 0; j < 12; j++) {
-        const uint32_t idx = threadIdx.x + EMD_BLOCK * j;
+        const uint32_t idx = threadIdx.x + BLK * j;
         if (base4 + idx < lim4) out[base4 + idx] = s_sh[(idx / 12) * SH_ROW4 + (idx % 12)];
     }
 }
@@ -264,24 +256,30 @@ __device__ __forceinline__ void sh_row_load(bool staged, const float4* s_sh, con
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K1
+// K1.  One wave per workgroup.  Order of work: (1) geometry of the lane's Gaussian up to the visibility decision, (2) the
+// wave stages the 192-byte SH rows of its VISIBLE Gaussians only (coalesced dwordx4 pieces, predicated per row by the
+// visibility ballot: a quarter of the bench scene is culled and its coefficients are never read), (3) colour, the
+// colour Jacobian and the record stores.  Twelve independent 13 KB workgroups per CU overlap these phases.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
-    __shared__ float4 s_sh[EMD_BLOCK * SH_ROW4];
+#define PRE_BLOCK 64
+__global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(PreArgs a) {
+    __shared__ float4 s_sh[PRE_BLOCK * SH_ROW4];
     const EmdSettings& S = a.s;
     const bool sh_staged = a.shs && a.M == 16;
-    if (sh_staged) { sh_block_load(a.shs, a.N, s_sh); __syncthreads(); }
-    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
     uint32_t touched = 0, rect = 0, dkey = 0xFFFFFFFFu;
     int radius_out = 0;
+    const float* V = S.viewmatrix;
+    float m[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, op = 0.f, sc[3] = {1.f, 1.f, 1.f};
+    float ix = 0.f, iy = 0.f, conA = 0.f, conB = 0.f, conC = 0.f;
+    Proj p;
+    p.tx = p.ty = p.tz = 0.f;
     if (i < a.N) {
-        const float* V = S.viewmatrix;
         const float* P = S.projmatrix;
         const int W = S.image_width, H = S.image_height;
         const int gx = (W + EMD_TILE_X - 1) / EMD_TILE_X, gy = (H + EMD_TILE_Y - 1) / EMD_TILE_Y;
         const float fx = (float)W / (2.f * S.tanfovx), fy = (float)H / (2.f * S.tanfovy);
         const bool raw = (a.flags & EMD_FLAG_RAW_PARAMS) != 0;
-        float m[3], q[4] = {1.f, 0.f, 0.f, 0.f}, op;
         if (a.flags & EMD_FLAG_MOTION) {
             motion_point(i, a.means3D, a.rotations, a.opacities, a.motion, m, q, &op, raw);
         } else {
@@ -292,7 +290,6 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
                 if (raw) { const float n = fmaxf(quat_norm(q), 1e-12f); q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
             }
         }
-        Proj p;
         p.tx = ((V[0] * m[0] + V[4] * m[1]) + V[8] * m[2]) + V[12];
         p.ty = ((V[1] * m[0] + V[5] * m[1]) + V[9] * m[2]) + V[13];
         p.tz = ((V[2] * m[0] + V[6] * m[1]) + V[10] * m[2]) + V[14];
@@ -303,7 +300,6 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
             float pw = 1.f / (hw + 0.0000001f);
             float px = hx * pw, py = hy * pw;
             float c3[6];
-            float sc[3] = {1.f, 1.f, 1.f};
             if (a.cov3D_precomp) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * i + k];
@@ -315,72 +311,19 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
             project_cov2d(S, m, c3, fx, fy, p);
             if (p.det != 0.f) {
                 float det_inv = 1.f / p.det;
-                float conA = p.c * det_inv, conB = -p.b * det_inv, conC = p.a * det_inv;
+                conA = p.c * det_inv; conB = -p.b * det_inv; conC = p.a * det_inv;
                 float mid = 0.5f * (p.a + p.c);
                 float sq = sqrtf(fmaxf(0.1f, mid * mid - p.det));
                 float lam1 = mid + sq, lam2 = mid - sq;
                 float rad = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
-                float ix = ((px + 1.f) * (float)W - 1.f) * 0.5f;
-                float iy = ((py + 1.f) * (float)H - 1.f) * 0.5f;
+                ix = ((px + 1.f) * (float)W - 1.f) * 0.5f;
+                iy = ((py + 1.f) * (float)H - 1.f) * 0.5f;
                 int x0 = tile_clamp((ix - rad) / (float)EMD_TILE_X, gx);
                 int y0 = tile_clamp((iy - rad) / (float)EMD_TILE_Y, gy);
                 int x1 = tile_clamp((ix + rad + (float)(EMD_TILE_X - 1)) / (float)EMD_TILE_X, gx);
                 int y1 = tile_clamp((iy + rad + (float)(EMD_TILE_Y - 1)) / (float)EMD_TILE_Y, gy);
                 int area = (x1 - x0) * (y1 - y0);
                 if (area > 0) {
-                    float col[3];
-                    uint32_t bits = 0;
-                    if (a.colors_precomp) {
-                        col[0] = a.colors_precomp[3 * i]; col[1] = a.colors_precomp[3 * i + 1];
-                        col[2] = a.colors_precomp[3 * i + 2];
-                    } else {
-                        float d[3] = {m[0] - S.campos[0], m[1] - S.campos[1], m[2] - S.campos[2]};
-                        float n = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
-                        d[0] /= n; d[1] /= n; d[2] /= n;
-                        float bs[16];
-                        sh_basis(S.sh_degree, d, bs);
-                        const int K = (S.sh_degree + 1) * (S.sh_degree + 1);
-                        float sh[48];
-                        sh_row_load(sh_staged, s_sh, a.shs, i, a.M, K, sh);
-                        col[0] = col[1] = col[2] = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 16; k++) {
-                            if (k < K) { col[0] += bs[k] * sh[3 * k]; col[1] += bs[k] * sh[3 * k + 1]; col[2] += bs[k] * sh[3 * k + 2]; }
-                        }
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) {
-                            col[ch] += 0.5f;
-                            if (col[ch] < 0.f) { col[ch] = 0.f; bits |= 1u << ch; }
-                            if ((a.flags & EMD_FLAG_CLAMP_RGB01) && col[ch] > 1.f) { col[ch] = 1.f; bits |= 1u << ch; }
-                        }
-                        float J[9];
-                        sh_dir_jacobian(S.sh_degree, d, sh, J);
-                        float4* jr = a.g.shjac + (size_t)i * 3;
-                        jr[0] = make_float4(J[0], J[1], J[2], 0.f);
-                        jr[1] = make_float4(J[3], J[4], J[5], 0.f);
-                        jr[2] = make_float4(J[6], J[7], J[8], 0.f);
-                    }
-                    float4* rec = a.g.rec + (size_t)i * EMD_REC_F4;
-                    rec[0] = make_float4(ix, iy, p.tz, op);
-                    rec[1] = make_float4(conA, conB, conC, __uint_as_float(bits));
-                    rec[2] = make_float4(col[0], col[1], col[2], 0.f);
-                    if (a.flags & EMD_FLAG_NORMAL) {
-                        float nv[3] = {0.f, 0.f, 0.f};
-                        if (a.scales) {
-                            int ax = 0;
-                            if (sc[1] < sc[ax]) ax = 1;
-                            if (sc[2] < sc[ax]) ax = 2;
-                            float R[9];
-                            quat_to_R(q, R);
-                            float nw[3] = {R[ax], R[3 + ax], R[6 + ax]};
-                            nv[0] = (V[0] * nw[0] + V[4] * nw[1]) + V[8] * nw[2];
-                            nv[1] = (V[1] * nw[0] + V[5] * nw[1]) + V[9] * nw[2];
-                            nv[2] = (V[2] * nw[0] + V[6] * nw[1]) + V[10] * nw[2];
-                            float dp = (nv[0] * p.tx + nv[1] * p.ty) + nv[2] * p.tz;
-                            if (dp > 0.f) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }
-                        }
-                        rec[3] = make_float4(nv[0], nv[1], nv[2], 0.f);
-                    }
                     touched = (uint32_t)area;
                     rect = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
                     dkey = __float_as_uint(p.tz);
@@ -391,6 +334,73 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess(PreArgs a) {
         a.radii[i] = radius_out;
         a.g.binrec[i] = make_uint2(rect, touched);     // binning input: tile rectangle, tiles touched
         a.g.depth_key[i] = dkey;                         // key of the depth sort (invisible: sorts last)
+    }
+    const bool vis = touched != 0u;
+    if (sh_staged) {
+        const unsigned long long vmask = __ballot(vis);
+        const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12;
+        const float4* src = (const float4*)a.shs;
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const uint32_t idx = threadIdx.x + PRE_BLOCK * j, row = idx / 12;
+            if ((vmask >> row) & 1ull) s_sh[row * SH_ROW4 + (idx % 12)] = src[base4 + idx];
+        }
+        __syncthreads();
+    }
+    if (vis) {
+        float col[3];
+        uint32_t bits = 0;
+        if (a.colors_precomp) {
+            col[0] = a.colors_precomp[3 * i]; col[1] = a.colors_precomp[3 * i + 1];
+            col[2] = a.colors_precomp[3 * i + 2];
+        } else {
+            float d[3] = {m[0] - S.campos[0], m[1] - S.campos[1], m[2] - S.campos[2]};
+            float n = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+            d[0] /= n; d[1] /= n; d[2] /= n;
+            float bs[16];
+            sh_basis(S.sh_degree, d, bs);
+            const int K = (S.sh_degree + 1) * (S.sh_degree + 1);
+            float sh[48];
+            sh_row_load(sh_staged, s_sh, a.shs, i, a.M, K, sh);
+            col[0] = col[1] = col[2] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < K) { col[0] += bs[k] * sh[3 * k]; col[1] += bs[k] * sh[3 * k + 1]; col[2] += bs[k] * sh[3 * k + 2]; }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                col[ch] += 0.5f;
+                if (col[ch] < 0.f) { col[ch] = 0.f; bits |= 1u << ch; }
+                if ((a.flags & EMD_FLAG_CLAMP_RGB01) && col[ch] > 1.f) { col[ch] = 1.f; bits |= 1u << ch; }
+            }
+            float J[9];
+            sh_dir_jacobian(S.sh_degree, d, sh, J);
+            float4* jr = a.g.shjac + (size_t)i * 3;
+            jr[0] = make_float4(J[0], J[1], J[2], 0.f);
+            jr[1] = make_float4(J[3], J[4], J[5], 0.f);
+            jr[2] = make_float4(J[6], J[7], J[8], 0.f);
+        }
+        float4* rec = a.g.rec + (size_t)i * EMD_REC_F4;
+        rec[0] = make_float4(ix, iy, p.tz, op);
+        rec[1] = make_float4(conA, conB, conC, __uint_as_float(bits));
+        rec[2] = make_float4(col[0], col[1], col[2], 0.f);
+        if (a.flags & EMD_FLAG_NORMAL) {
+            float nv[3] = {0.f, 0.f, 0.f};
+            if (a.scales) {
+                int ax = 0;
+                if (sc[1] < sc[ax]) ax = 1;
+                if (sc[2] < sc[ax]) ax = 2;
+                float R[9];
+                quat_to_R(q, R);
+                float nw[3] = {R[ax], R[3 + ax], R[6 + ax]};
+                nv[0] = (V[0] * nw[0] + V[4] * nw[1]) + V[8] * nw[2];
+                nv[1] = (V[1] * nw[0] + V[5] * nw[1]) + V[9] * nw[2];
+                nv[2] = (V[2] * nw[0] + V[6] * nw[1]) + V[10] * nw[2];
+                float dp = (nv[0] * p.tx + nv[1] * p.ty) + nv[2] * p.tz;
+                if (dp > 0.f) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }
+            }
+            rec[3] = make_float4(nv[0], nv[1], nv[2], 0.f);
+        }
     }
 }
 
@@ -691,7 +701,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
         }
         if (a.dL_dopacities) a.dL_dopacities[i] = dopl;
     }
-    if (sh_staged && a.dL_dshs) { __syncthreads(); sh_block_store(a.dL_dshs, a.N, s_sh); }
+    if (sh_staged && a.dL_dshs) { __syncthreads(); sh_block_store<EMD_BLOCK>(a.dL_dshs, a.N, s_sh); }
     if ((a.flags & EMD_FLAG_MOTION) && a.dL_dactor_pose) reduce_pose_grad(a_id, pose_g, a.dL_dactor_pose);
 }
 
@@ -916,8 +926,8 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_l1_loss(size_t n, const float* __
 
 int emd_launch_preprocess(const PreArgs& a, hipStream_t st) {
     if (a.N <= 0) return EMD_OK;
-    const int nb = (a.N + EMD_BLOCK - 1) / EMD_BLOCK;
-    hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(EMD_BLOCK), 0, st, a);
+    const int nb = (a.N + PRE_BLOCK - 1) / PRE_BLOCK;
+    hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(PRE_BLOCK), 0, st, a);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }
