@@ -28,16 +28,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-PMC_STAGE_KERNELS = {"preprocess": ("k_preprocess",), "scan_duplicate": ("k_duplicate",),
-                     "radix_sort": ("k_radix_hist", "k_radix_scatter"), "tile_ranges": ("k_tile_ranges",),
-                     "render_forward": ("k_render_forward",), "render_backward": ("k_render_backward",),
-                     "preprocess_backward": ("k_preprocess_backward",)}
+PMC_STAGE_KERNELS = {"preprocess": ("k_preprocess",), "scan_duplicate": ("k_sorted_counts", "k_scan_publish", "k_duplicate"),
+                     "radix_sort": ("k_radix_hist[N]", "k_radix_scatter[N]", "k_radix_scan_bins[N]", "k_radix_hist[D]",
+                                    "k_radix_scatter[D]"),
+                     "tile_ranges": ("k_tile_ranges",), "render_forward": ("k_render_forward_q",),
+                     "render_backward": ("k_render_backward_q",), "preprocess_backward": ("k_preprocess_backward",)}
 
 
 def pmc_traffic(stage, passes):
-    """HBM-side bytes per launch of `stage` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE, separate passes, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md) -- collected on
-    this exact workload; None when the summary is missing."""
+    """HBM-side bytes per iteration of `stage` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE, separate passes, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md; produced by
+    profiles/make_pmc_summary.py) -- collected on this exact workload; None when the summary is missing."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.csv")
     if not os.path.exists(path):
         return None
@@ -46,10 +47,15 @@ def pmc_traffic(stage, passes):
         if line.startswith("#") or line.startswith("kernel,"):
             continue
         f = line.rstrip("\n").split(",")
-        name = f[0].split("<")[0]
+        name = f[0]
         if name in PMC_STAGE_KERNELS.get(stage, ()):
-            per_launch = (float(f[-3]) + float(f[-2])) * 1e6        # fetch_MB_x2 + write_MB
-            tot += per_launch * (passes if stage == "radix_sort" else 1)
+            per_launch = (float(f[3]) + float(f[4])) * 1e6        # fetch_MB_x2 + write_MB
+            launches = 1
+            if name.endswith("[N]"):
+                launches = 4 + (passes if "scan_bins" in name else 0)      # depth passes (+ the tile passes' scans)
+            elif name.endswith("[D]"):
+                launches = passes
+            tot += per_launch * launches
     return tot or None
 
 
