@@ -49,6 +49,35 @@ def test_fused_motion_parity(kw):
         assert "residual_dx" in checked
 
 
+@pytest.mark.parametrize("kw", [
+    dict(n=300, H=16, W=16, seed=41),                  # one tile: zero tile passes, list = depth order
+    dict(n=600, H=16, W=40, seed=42),                  # three tiles, ragged width
+    dict(n=400, H=4112, W=4100, seed=43),              # 257 x 257 = 66 049 tiles: 17 tile bits -> three tile passes
+], ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+def test_tile_pass_counts(kw):
+    """The tile sort runs ceil(log2(T) / 8) passes: 0, 1 and 3 here (2 everywhere else in this file)."""
+    case = make_case(**kw)
+    orc = run_oracle(case, backward=False)
+    hip = run_hip(case, backward=False)
+    compare_forward(hip, orc, tol=IMAGE_TOL)
+
+
+def test_equal_depth_ties_keep_gaussian_order():
+    """Gaussians at exactly the same view depth: the reference's stable sort leaves them in index order inside a tile.
+    The depth-first sort must do the same (stable depth sort of the Gaussians, stable partition by tile)."""
+    case = make_case(n=4000, H=64, W=96, seed=44)
+    m = case["means3D"]
+    m[:, 0] = torch.round(m[:, 0] * 2.0) / 2.0        # camera looks along +x: depth quantised to 0.5 m -> thousands of ties
+    orc = run_oracle(case, backward=True)
+    hip = run_hip(case, backward=True)
+    compare_forward(hip, orc, tol=IMAGE_TOL)
+    compare_backward(hip, orc, rtol=GRAD_RTOL)
+    keys = hip["keys"] if "keys" in hip else None
+    if keys is not None:
+        d = (keys & 0xFFFFFFFF)
+        assert (np.diff(d) == 0).sum() > 100, "test did not produce depth ties"
+
+
 def test_absgrad():
     case = make_case(n=3000, H=64, W=96, seed=21)
     orc = run_oracle(case, backward=True)
