@@ -382,26 +382,35 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_backward_q(RenderDims d, co
         __syncthreads();
     };
 
-    // prefetch of the first step
+    // Software pipeline of the list scan: Gaussian ids three steps ahead, records two steps ahead of the step being
+    // queued, so the dependent id -> record gather (two L2 round trips) is off the critical path of a wave that shares
+    // its SIMD with only ~3 others.
     uint32_t head = 0;
-    float4 p0 = zero4, p1 = zero4, p2 = zero4, p3 = zero4;
-    uint32_t pid = 0;
+    auto load_id = [&](uint32_t i) -> uint32_t { return i < wave_n ? point_list[start + i] : 0u; };
+    float4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4, b0 = zero4, b1 = zero4, b2 = zero4, b3 = zero4;
+    uint32_t idA = load_id(lane), idB = load_id(EMD_WAVE + lane), idC = load_id(2 * EMD_WAVE + lane);
     if (lane < wave_n) {
-        pid = point_list[start + lane];
-        const float4* r = rec + (size_t)pid * EMD_REC_F4;
-        p0 = r[0]; p1 = r[1]; p2 = r[2];
-        if (NORMAL) p3 = r[3];
+        const float4* r = rec + (size_t)idA * EMD_REC_F4;
+        a0 = r[0]; a1 = r[1]; a2 = r[2];
+        if (NORMAL) a3 = r[3];
+    }
+    if (EMD_WAVE + lane < wave_n) {
+        const float4* r = rec + (size_t)idB * EMD_REC_F4;
+        b0 = r[0]; b1 = r[1]; b2 = r[2];
+        if (NORMAL) b3 = r[3];
     }
     for (uint32_t base = 0; base < wave_n; base += EMD_WAVE) {
         const uint32_t idx = base + lane;
-        const float4 c0r = p0, c1r = p1, c2r = p2, c3r = p3;
-        const uint32_t cid = pid;
-        if (idx + EMD_WAVE < wave_n) {           // next step's records in flight while this one is queued / processed
-            pid = point_list[start + idx + EMD_WAVE];
-            const float4* r = rec + (size_t)pid * EMD_REC_F4;
-            p0 = r[0]; p1 = r[1]; p2 = r[2];
-            if (NORMAL) p3 = r[3];
+        const float4 c0r = a0, c1r = a1, c2r = a2, c3r = a3;
+        const uint32_t cid = idA;
+        a0 = b0; a1 = b1; a2 = b2; a3 = b3; idA = idB;
+        idB = idC;
+        if (idx + 2 * EMD_WAVE < wave_n) {
+            const float4* r = rec + (size_t)idB * EMD_REC_F4;
+            b0 = r[0]; b1 = r[1]; b2 = r[2];
+            if (NORMAL) b3 = r[3];
         }
+        idC = load_id(idx + 3 * EMD_WAVE);
         const bool keep = idx < wave_n && ((quadrant_mask(c0r, c1r, tile_x0, tile_y0) >> quad) & 1u);
         const unsigned long long bal = __ballot(keep);
         if (keep) {
