@@ -72,6 +72,17 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float4& r0, const float4
     return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
 }
 
+// Two-wide forms of gauss_power / pinned_exp (same operations per component, so bit-identical results): CDNA3/4 issue
+// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 on register pairs at the rate of the scalar forms, which halves the VALU
+// slots of everything that is not a DPP scan, a compare or a transcendental.  K7 evaluates two pixels per iteration.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
+__device__ __forceinline__ v2f gauss_power2(float A, float B, float C, v2f dx, float dy) {
+#pragma clang fp contract(off)
+    const v2f q = __builtin_elementwise_fma(splat2(A) * dx, dx, splat2((C * dy) * dy));
+    return __builtin_elementwise_fma(splat2(-0.5f), q, -((splat2(B) * dx) * splat2(dy)));
+}
+
 // exp(x) for x <= 0, fully specified (bit-exact twin of pinned_exp in oracle/raster_oracle.c): a pixel's colour depends
 // discontinuously on alpha >= 1/255 and T (1 - alpha) >= 1e-4, so the hardware v_exp_f32 (1 ulp, unspecified) cannot
 // be part of a contract that must hold on all 1.7 M pixels of a 1066 x 1600 image.
@@ -88,6 +99,21 @@ __device__ __forceinline__ float pinned_exp(float x) {
     p = __builtin_fmaf(p, f, 6.93147181e-1f);
     p = __builtin_fmaf(p, f, 1.0f);
     return __builtin_ldexpf(p, (int)n);
+}
+
+__device__ __forceinline__ v2f pinned_exp2(v2f x) {
+#pragma clang fp contract(off)
+    const v2f t = x * splat2(1.44269504088896341f);
+    const v2f n = __builtin_elementwise_rint(t);
+    const v2f f = t - n;
+    v2f p = splat2(1.54035304e-4f);
+    p = __builtin_elementwise_fma(p, f, splat2(1.33335581e-3f));
+    p = __builtin_elementwise_fma(p, f, splat2(9.61812911e-3f));
+    p = __builtin_elementwise_fma(p, f, splat2(5.55041087e-2f));
+    p = __builtin_elementwise_fma(p, f, splat2(2.40226507e-1f));
+    p = __builtin_elementwise_fma(p, f, splat2(6.93147181e-1f));
+    p = __builtin_elementwise_fma(p, f, splat2(1.0f));
+    return (v2f){__builtin_ldexpf(p.x, (int)n.x), __builtin_ldexpf(p.y, (int)n.y)};
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -284,8 +310,10 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_backward_q(RenderDims d, co
     float* const s_stage = reinterpret_cast<float*>(&q_rec[0][0][0]);
     // per-pixel constants and running state, read back as wave-uniform (broadcast) LDS loads in the pixel loop: keeps
     // ~15 v_readlane / v_mov / v_cndmask per pixel-iteration off the VALU, which is what bounds this kernel.
-    //   [p][0] = (dL/dC rgb, dL/dD)   [p][1] = (Q, running T, running S, -)   [p][2] = dL/dN
-    __shared__ float4 s_pix[EMD_WAVE][NORMAL ? 3 : 2];
+    // Pixels are handled in horizontal pairs (a, b) = (2 pp, 2 pp + 1); every quantity is stored as the pair:
+    //   [pp][0] = (dC0 a,b | dC1 a,b)  [pp][1] = (dC2 a,b | dD a,b)  [pp][2] = (running T a,b | running S a,b)
+    //   [pp][3] = (Q a,b | -)          [pp][4] = (dN0 a,b | dN1 a,b) [pp][5] = (dN2 a,b | -)
+    __shared__ float4 s_pix[EMD_WAVE / 2][NORMAL ? 6 : 4];
 #define QREC(r, s) q_rec[(s) >> 6][r][(s) & 63]
     uint32_t quad;
     const uint32_t tile = xcd_quadrant_block(blockIdx.x, &quad);
@@ -316,9 +344,13 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_backward_q(RenderDims d, co
         if (NORMAL && dL_dnormal) Stot += out_normal[pix] * dN0 + out_normal[HW + pix] * dN1 + out_normal[2 * HW + pix] * dN2;
         Q = Tf * (dA - bgdot) - Stot;
     }
-    s_pix[lane][0] = make_float4(dC0, dC1, dC2, dD);
-    s_pix[lane][1] = make_float4(Q, 1.f, 0.f, 0.f);   // running transmittance / running S, carried across batches
-    if (NORMAL) s_pix[lane][2] = make_float4(dN0, dN1, dN2, 0.f);
+    {
+        float* sp = reinterpret_cast<float*>(&s_pix[lane >> 1][0]) + (lane & 1);
+        sp[0] = dC0; sp[2] = dC1; sp[4] = dC2; sp[6] = dD;
+        sp[8] = 1.f; sp[10] = 0.f;      // running transmittance / running S, carried across batches
+        sp[12] = Q; sp[14] = 0.f;
+        if (NORMAL) { sp[16] = dN0; sp[18] = dN1; sp[20] = dN2; sp[22] = 0.f; }
+    }
     __syncthreads();
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -332,41 +364,59 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_backward_q(RenderDims d, co
         if (NORMAL) g3 = QREC(3, sl);
         const uint32_t pos = q_pos[sl];
         const uint32_t first_pos = readlane_u32(pos, 0);
-        float m0 = 0.f, m1x = 0.f, m1y = 0.f, m2xx = 0.f, m2xy = 0.f, m2yy = 0.f, a_dz = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f,
-              a_ax = 0.f, a_ay = 0.f;
-        for (int p = 0; p < EMD_WAVE; p++) {
-            const uint32_t n_p = readlane_u32(my_n, p);
-            if (n_p <= first_pos) continue;                      // pixel p terminated before this batch
-            const float4 pa = s_pix[p][0], pb = s_pix[p][1];
-            const float pxs = qx0 + (float)(p & 7), pys = qy0 + (float)(p >> 3);
-            const float dx = g0.x - pxs, dy = g0.y - pys;
-            const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
-            const float G = pinned_exp(power);
-            const float alpha = fminf(0.99f, g0.w * G);
-            const bool hit = valid && pos < n_p && power <= 0.f && alpha >= (1.f / 255.f);
-            if (__ballot(hit) == 0ull) continue;
-            const float a = hit ? alpha : 0.f;
-            const float om = 1.f - a;
-            const float t_incl = wave_scan_mul_f32_asm(om);
-            const float Tk = pb.y * wave_shift_up1_f32(t_incl, 1.f);
-            const float w = a * Tk;
-            float g = g2.x * pa.x + g2.y * pa.y + g2.z * pa.z + g0.z * pa.w;
-            if (NORMAL) { const float4 pn = s_pix[p][2]; g += g3.x * pn.x + g3.y * pn.y + g3.z * pn.z; }
-            const float s_incl = wave_scan_add_f32_asm(g * w);
-            const float Sk = pb.z + s_incl;
-            const float inv = __builtin_amdgcn_rcpf(om);
-            float dL_da = g * Tk + inv * (pb.x + Sk);
-            dL_da = hit ? dL_da : 0.f;
-            const float u = G * (g0.w * dL_da);                  // G dL/dG
-            const float ux = u * dx, uy = u * dy;
-            m0 += u; m1x += ux; m1y += uy;
-            m2xx += ux * dx; m2xy += ux * dy; m2yy += uy * dy;
-            if (ABS) { a_ax += fabsf(ux * g1.x + uy * g1.y); a_ay += fabsf(uy * g1.z + ux * g1.y); }
-            a_dz += w * pa.w;
-            a_r += w * pa.x; a_g += w * pa.y; a_b += w * pa.z;
-            // lane 63 holds the batch totals: carry the running T and S of pixel p to the next batch
-            if (lane == 63) *reinterpret_cast<float2*>(&s_pix[p][1].y) = make_float2(pb.y * t_incl, Sk);
+        const v2f z2 = splat2(0.f);
+        v2f m0_2 = z2, m1x_2 = z2, m1y_2 = z2, m2xx_2 = z2, m2xy_2 = z2, m2yy_2 = z2, dz_2 = z2, r_2 = z2, g_2 = z2, b_2 = z2;
+        float a_ax = 0.f, a_ay = 0.f;
+        for (int pp = 0; pp < EMD_WAVE / 2; pp++) {
+            const uint32_t n_a = readlane_u32(my_n, 2 * pp), n_b = readlane_u32(my_n, 2 * pp + 1);
+            if (max(n_a, n_b) <= first_pos) continue;            // both pixels terminated before this batch
+            const float4 c01 = s_pix[pp][0], c2d = s_pix[pp][1], ts = s_pix[pp][2], qq = s_pix[pp][3];
+            const float pxs = qx0 + (float)((2 * pp) & 7), pys = qy0 + (float)(pp >> 2);
+            const float dy = g0.y - pys;
+            const v2f dx = (v2f){g0.x - pxs, g0.x - (pxs + 1.f)};
+            const v2f power = gauss_power2(g1.x, g1.y, g1.z, dx, dy);
+            const v2f G = pinned_exp2(power);
+            const v2f aw = splat2(g0.w) * G;
+            const v2f alpha = (v2f){fminf(0.99f, aw.x), fminf(0.99f, aw.y)};
+            const bool hit_a = valid && pos < n_a && power.x <= 0.f && alpha.x >= (1.f / 255.f);
+            const bool hit_b = valid && pos < n_b && power.y <= 0.f && alpha.y >= (1.f / 255.f);
+            if (__ballot(hit_a || hit_b) == 0ull) continue;
+            const v2f a = (v2f){hit_a ? alpha.x : 0.f, hit_b ? alpha.y : 0.f};
+            const v2f om = splat2(1.f) - a;
+            float t_a = om.x, t_b = om.y;
+            wave_scan_mul2_f32_asm(t_a, t_b);
+            const v2f cT = (v2f){ts.x, ts.y}, cS = (v2f){ts.z, ts.w};
+            const v2f Tk = cT * (v2f){wave_shift_up1_f32(t_a, 1.f), wave_shift_up1_f32(t_b, 1.f)};
+            const v2f w = a * Tk;
+            v2f g = splat2(g2.x) * (v2f){c01.x, c01.y} + splat2(g2.y) * (v2f){c01.z, c01.w} + splat2(g2.z) * (v2f){c2d.x, c2d.y} +
+                    splat2(g0.z) * (v2f){c2d.z, c2d.w};
+            if (NORMAL) {
+                const float4 n01 = s_pix[pp][4], n2 = s_pix[pp][5];
+                g += splat2(g3.x) * (v2f){n01.x, n01.y} + splat2(g3.y) * (v2f){n01.z, n01.w} + splat2(g3.z) * (v2f){n2.x, n2.y};
+            }
+            const v2f gw = g * w;
+            float s_a = gw.x, s_b = gw.y;
+            wave_scan_add2_f32_asm(s_a, s_b);
+            const v2f Sk = cS + (v2f){s_a, s_b};
+            const v2f inv = (v2f){__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+            v2f dL_da = g * Tk + inv * ((v2f){qq.x, qq.y} + Sk);
+            dL_da = (v2f){hit_a ? dL_da.x : 0.f, hit_b ? dL_da.y : 0.f};
+            const v2f u = G * (splat2(g0.w) * dL_da);           // G dL/dG
+            const v2f ux = u * dx, uy = u * splat2(dy);
+            m0_2 += u; m1x_2 += ux; m1y_2 += uy;
+            m2xx_2 += ux * dx; m2xy_2 += ux * splat2(dy); m2yy_2 += uy * splat2(dy);
+            if (ABS) {
+                const v2f ax = ux * splat2(g1.x) + uy * splat2(g1.y), ay = uy * splat2(g1.z) + ux * splat2(g1.y);
+                a_ax += fabsf(ax.x) + fabsf(ax.y); a_ay += fabsf(ay.x) + fabsf(ay.y);
+            }
+            dz_2 += w * (v2f){c2d.z, c2d.w};
+            r_2 += w * (v2f){c01.x, c01.y}; g_2 += w * (v2f){c01.z, c01.w}; b_2 += w * (v2f){c2d.x, c2d.y};
+            // lane 63 holds the batch totals: carry the running T and S of both pixels to the next batch
+            if (lane == 63) s_pix[pp][2] = make_float4(cT.x * t_a, cT.y * t_b, Sk.x, Sk.y);
         }
+        const float m0 = m0_2.x + m0_2.y, m1x = m1x_2.x + m1x_2.y, m1y = m1y_2.x + m1y_2.y, m2xx = m2xx_2.x + m2xx_2.y,
+                    m2xy = m2xy_2.x + m2xy_2.y, m2yy = m2yy_2.x + m2yy_2.y, a_dz = dz_2.x + dz_2.y, a_r = r_2.x + r_2.y,
+                    a_g = g_2.x + g_2.y, a_b = b_2.x + b_2.y;
         // rows through LDS so that consecutive lanes add consecutive floats of one 48-byte accumulator row
         __syncthreads();   // every lane holds its record in registers: the lower half may be overwritten
         float4* row = reinterpret_cast<float4*>(s_stage + lane * EMD_BWD_STRIDE);
