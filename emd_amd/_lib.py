@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 TILE = 16
 ACTOR_STRIDE = 12
 BWD_STRIDE = 12
@@ -65,11 +65,26 @@ class EmdBwdArgs(C.Structure):
                 ("dL_dcov3D", _f), ("dL_dactor_pose", _f), ("dL_dresidual_dx", _f), ("dL_dresidual_dq", _f)]
 
 
+SKY_CLAMP01, SKY_BLEND_S3G, SKY_BLEND_ADD, SKY_INTERLEAVED = 1, 2, 4, 8
+
+
+class EmdSkyArgs(C.Structure):
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("resolution", C.c_int32), ("flags", C.c_int32),
+                ("cube", _f), ("dirs", _f), ("Kinv", C.c_float * 9), ("R", C.c_float * 9), ("T", C.c_float * 3),
+                ("jitter", _f), ("acc", _f), ("mask_threshold", C.c_float), ("fill", C.c_float), ("fg", _f),
+                ("sky", _f), ("out", _f)]
+
+
+class EmdSkyBwdArgs(C.Structure):
+    _fields_ = [("f", EmdSkyArgs), ("dL_dout", _f), ("dL_dsky", _f), ("dL_dcube", _f), ("dL_dacc", _f), ("dL_dfg", _f)]
+
+
 # every symbol include/emd_raster.h declares
 EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_size", "emd_raster_forward",
                     "emd_raster_backward", "emd_raster_export_binning", "emd_raster_export_geometry",
                     "emd_motion_forward", "emd_motion_backward", "emd_sh_forward", "emd_sh_backward",
-                    "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward", "emd_actor_pose_forward", "emd_actor_pose_backward", "emd_l1_loss")
+                    "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward", "emd_actor_pose_forward", "emd_actor_pose_backward", "emd_l1_loss",
+                    "emd_sky_forward", "emd_sky_backward")
 PROF_STAGES = 8
 
 _lib = None
@@ -113,6 +128,8 @@ def load():
     lib.emd_actor_pose_backward.argtypes = [C.c_int32] + [C.c_void_p] * 9
     lib.emd_l1_loss.argtypes = [C.c_int64] + [C.c_void_p] * 5
     lib.emd_profile_enable.argtypes = [C.c_int]
+    lib.emd_sky_forward.argtypes = [C.POINTER(EmdSkyArgs), C.c_void_p]
+    lib.emd_sky_backward.argtypes = [C.POINTER(EmdSkyBwdArgs), C.c_void_p]
     lib.emd_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     lib.emd_profile_stage_name.argtypes = [C.c_int]
     lib.emd_profile_stage_name.restype = C.c_char_p

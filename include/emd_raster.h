@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 5
+#define EMD_ABI_VERSION 6
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -196,6 +196,43 @@ typedef struct EmdBwdArgs {
     float* dL_dresidual_dx;       /* [N,3] */
     float* dL_dresidual_dq;       /* [N,4] */
 } EmdBwdArgs;
+
+/* ---- sky cube map + final blend -------------------------------------------------
+ * Replaces S3Gaussian/scene/sky_cubemap.py:41-87 (SkyCubeMap.forward: get_rays_torch, mask, nvdiffrast dr.texture
+ * 'linear'/'cube', clamp) with the blend of gaussian_renderer/__init__.py:299-301, and OmniRe/models/modules.py:174-208
+ * (EnvLight.forward) with the blend of models/trainers/base.py:491-497. */
+#define EMD_SKY_CLAMP01     1   /* clamp the looked-up colour to [0,1] (S3G) */
+#define EMD_SKY_BLEND_S3G   2   /* out = fg * acc + sky * (1 - acc) */
+#define EMD_SKY_BLEND_ADD   4   /* out = fg + sky * (1 - acc) (OmniRe) */
+#define EMD_SKY_INTERLEAVED 8   /* images are [P,3]; default planar [3,P] */
+
+typedef struct EmdSkyArgs {
+    int32_t height, width;      /* P = height * width pixels (a flat list of directions: height 1) */
+    int32_t resolution;         /* cube faces are resolution x resolution texels */
+    int32_t flags;              /* EMD_SKY_* */
+    const float* cube;          /* [6,res,res,3] faces +x,-x,+y,-y,+z,-z (OpenGL orientation) */
+    const float* dirs;          /* [P,3] lookup directions in the cube's frame, or NULL: pinhole rays below */
+    float Kinv[9], R[9], T[3];  /* row-major inverse intrinsics, w2c rotation, w2c translation: get_rays_torch(H,W,K,R,T) */
+    const float* jitter;        /* [P,2] sub-pixel offsets (training: U[0,1)), or NULL: pixel centres (+0.5) */
+    const float* acc;           /* [P] foreground opacity ("weight"), or NULL */
+    float mask_threshold;       /* with acc: texture sampled where (1 - acc) > threshold (S3G: 1e-3), else sky = fill; <0: always */
+    float fill;                 /* sky colour of masked-out pixels */
+    const float* fg;            /* foreground image for the blend, or NULL */
+    float* sky;                 /* out: sky colour, or NULL */
+    float* out;                 /* out: blended image, or NULL */
+} EmdSkyArgs;
+
+typedef struct EmdSkyBwdArgs {
+    EmdSkyArgs f;               /* the forward arguments (sky / out unused) */
+    const float* dL_dout;       /* gradient of the blended image, or NULL */
+    const float* dL_dsky;       /* gradient of the sky colour output, or NULL */
+    float* dL_dcube;            /* [6,res,res,3], zeroed here and accumulated with float atomics; or NULL */
+    float* dL_dacc;             /* [P] through the blend only (the mask is not differentiated), or NULL */
+    float* dL_dfg;              /* like fg, or NULL */
+} EmdSkyBwdArgs;
+
+int emd_sky_forward(const EmdSkyArgs* args, void* hip_stream);
+int emd_sky_backward(const EmdSkyBwdArgs* args, void* hip_stream);
 
 int emd_abi_version(void);
 const char* emd_last_error(void);

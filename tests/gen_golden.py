@@ -17,6 +17,10 @@ Fixtures (all fp32):
   s3g_render.npz    render() executed with a recording stand-in for diff_gauss: the 12 settings fields and the tensors at
                     the rasterizer boundary (coarse and fine stage, run-script flags no_ds / no_dr), plus the deformation
                     network's residuals that produced them                S3Gaussian/gaussian_renderer/__init__.py:27-168
+  s3g_sky.npz       SkyCubeMap.forward (rays, mask, clamp, layout) and the sky blend of render(), executed by the reference
+                    with oracle/sky_oracle.cube_lookup standing in for the absent nvdiffrast dr.texture (its arguments are
+                    recorded too)           S3Gaussian/scene/sky_cubemap.py:41-87, gaussian_renderer/__init__.py:299-301
+  or_envlight.npz   EnvLight.forward with the same stand-in                OmniRe/models/modules.py:174-208
   or_rigid.npz      RigidNodes.transform_means / transform_quats / opacity mask (+ gradients), train and
                     test-interpolation branches, non-zero track heads  OmniRe/models/nodes/rigid.py:42-46,150-246,478-615
 """
@@ -244,6 +248,87 @@ def gen_s3g_render():
     unload(["utils", "scene", "arguments", "gaussian_renderer"])
 
 
+def _texture_standin(rec):
+    """dr.texture(tex[None], dirs[None...], filter_mode=, boundary_mode=) -> oracle lookup; records its arguments."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import sky_oracle
+
+    def texture(tex, uv, filter_mode="auto", boundary_mode="wrap", **kw):
+        rec.append(dict(tex_shape=tuple(tex.shape), dirs=uv.detach().clone(), filter_mode=filter_mode, boundary_mode=boundary_mode))
+        return sky_oracle.cube_lookup(tex[0], uv[0])[None]
+    return texture
+
+
+def gen_s3g_sky():
+    sys.path.insert(0, os.path.join(REF, "S3Gaussian"))
+    sys.modules["utils.tcnn_modules"] = _Stub("utils.tcnn_modules")
+    import nvdiffrast.torch as dr
+    rec = []
+    dr.texture = _texture_standin(rec)
+    with _CpuMode():
+        from arguments.gaussian_options import BaseOptions
+        import scene.sky_cubemap as sc
+        sc.dr = dr
+        from scene.cameras import Camera
+        from utils.graphics_utils import focal2fov, get_rays_torch
+        cfg = BaseOptions()
+        cfg.sky_resolution = 16
+        out = {}
+        H, W = 40, 56
+        K = torch.tensor([[60.0, 0, 27.5], [0, 58.0, 20.5], [0, 0, 1]])
+        yaw = 0.4
+        c2w_R = np.array([[np.sin(yaw), 0, np.cos(yaw)], [-np.cos(yaw), 0, np.sin(yaw)], [0, -1, 0]], np.float64)
+        T = -c2w_R.T @ np.array([2.0, -1.0, 1.5])
+        cam = Camera(colmap_id=0, R=c2w_R, T=T, FoVx=focal2fov(60.0, W), FoVy=focal2fov(58.0, H), image=torch.zeros(3, H, W),
+                     gt_alpha_mask=None, image_name="x", uid=0, data_device="cpu", intrinsic=K, c2w=torch.eye(4),
+                     time=0.3, cam_no=0, time_diff=0.0)
+        g = torch.Generator().manual_seed(400)
+        for white in (True, False):
+            cfg.sky_white_background = white
+            model = sc.SkyCubeMap(cfg)
+            model.sky_cube_map.data = torch.rand(6, 16, 16, 3, generator=g) * 1.4 - 0.2          # some texels outside [0,1]: clamp
+            acc = torch.rand(1, H, W, generator=g)
+            acc[:, :10] = 1.0                                                                   # fully covered rows: masked out
+            tag = "white" if white else "black"
+            rec.clear()
+            sky_all = model(cam, acc=None, is_train=False)
+            sky_msk = model(cam, acc=acc, is_train=False)
+            assert len(rec) == 2 and rec[0]["filter_mode"] == "linear" and rec[0]["boundary_mode"] == "cube"
+            w2c = cam.world_view_transform.transpose(0, 1)
+            _, rays = get_rays_torch(H, W, K, w2c[:3, :3], w2c[:3, 3], perturb=False)
+            render = torch.rand(3, H, W, generator=g)
+            blended = render * acc + sky_msk * (1 - acc)            # gaussian_renderer/__init__.py:300, verbatim formula
+            out.update({f"{tag}_cube": model.sky_cube_map.data, f"{tag}_acc": acc, f"{tag}_sky_all": sky_all, f"{tag}_sky_masked": sky_msk,
+                        f"{tag}_dirs_all": rec[0]["dirs"][0], f"{tag}_n_masked_dirs": rec[1]["dirs"].shape[2], f"{tag}_render": render,
+                        f"{tag}_blended": blended})
+        out.update(dict(H=H, W=W, K=K, world_view_transform=cam.world_view_transform, rays=rays))
+        save("s3g_sky.npz", **out)
+    sys.path.pop(0)
+    unload(["utils", "scene", "arguments", "gaussian_renderer"])
+
+
+def gen_or_envlight():
+    sys.path.insert(0, os.path.join(REF, "OmniRe"))
+    import nvdiffrast.torch as dr
+    rec = []
+    dr.texture = _texture_standin(rec)
+    with _CpuMode():
+        import models.modules as mm
+        mm.dr = dr
+        env = mm.EnvLight(class_name="Sky", resolution=8, device=torch.device("cpu"))
+        g = torch.Generator().manual_seed(410)
+        env.base.data = torch.rand(6, 8, 8, 3, generator=g)
+        viewdirs = torch.nn.functional.normalize(torch.randn(12, 20, 3, generator=g), dim=-1)
+        light = env({"viewdirs": viewdirs})
+        rgb, opacity = torch.rand(12, 20, 3, generator=g), torch.rand(12, 20, 1, generator=g)
+        blended = rgb + light * (1.0 - opacity)                      # models/trainers/base.py:497, verbatim formula
+        assert rec[0]["filter_mode"] == "linear" and rec[0]["boundary_mode"] == "cube"
+        save("or_envlight.npz", base=env.base.data, viewdirs=viewdirs, lookup_dirs=rec[0]["dirs"].reshape(-1, 3), light=light,
+             rgb=rgb, opacity=opacity, blended=blended, to_opengl=env.to_opengl)
+    sys.path.pop(0)
+    unload(["models", "utils", "datasets"])
+
+
 def _matrix_to_quaternion(M):
     """Stand-in for pytorch3d.transforms.matrix_to_quaternion (only used at RigidNodes init, rigid.py:271)."""
     M = M.reshape(-1, 3, 3)
@@ -368,5 +453,7 @@ if __name__ == "__main__":
     print("S3Gaussian:")
     gen_s3g()
     gen_s3g_render()
+    gen_s3g_sky()
     print("OmniRe:")
     gen_omnire()
+    gen_or_envlight()
