@@ -234,11 +234,15 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     const bool dbg = a->s.debug != 0;
     emd_prof_begin(PROF_OTHER, st);
     EMD_HIP_CHECK(hipMemsetAsync(a->bwd_ws, 0, need, st));
-    if ((a->flags & EMD_FLAG_MOTION) && a->dL_dactor_pose && a->motion.num_actors > 0)
-        EMD_HIP_CHECK(hipMemsetAsync(a->dL_dactor_pose, 0, (size_t)a->motion.num_actors * EMD_ACTOR_STRIDE * sizeof(float), st));
+    float* pose_grad = nullptr;       // accumulated by K8 with atomics; cleared by K7's first workgroup
+    int pose_grad_n = 0;
+    if ((a->flags & EMD_FLAG_MOTION) && a->dL_dactor_pose && a->motion.num_actors > 0) {
+        pose_grad = a->dL_dactor_pose;
+        pose_grad_n = a->motion.num_actors * EMD_ACTOR_STRIDE;
+    }
     emd_prof_switch(PROF_OTHER, PROF_RENDER_BWD, st);
     rc = emd_launch_render_backward(a->s, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->dL_dcolor,
-                                    a->dL_ddepth, a->dL_dalpha, a->dL_dnormal, (float*)a->bwd_ws, st);
+                                    a->dL_ddepth, a->dL_dalpha, a->dL_dnormal, (float*)a->bwd_ws, pose_grad, pose_grad_n, st);
     if (rc) return rc;
     STAGE_SYNC("render_backward");
     PreBwdArgs pb;

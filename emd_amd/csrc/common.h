@@ -165,7 +165,8 @@ int emd_launch_render_forward(const EmdSettings& s, int flags, const GeomWs& g, 
 int emd_launch_render_backward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                                const float* out_color, const float* out_depth, const float* out_normal,
                                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                               const float* dL_dnormal, float* grad_rec, hipStream_t st);  // render.hip
+                               const float* dL_dnormal, float* grad_rec, float* zero_buf, int zero_n,
+                               hipStream_t st);  // render.hip (zero_buf: small table cleared by block 0 for K8)
 struct PreBwdArgs {
     EmdSettings s;
     int N, M, flags;

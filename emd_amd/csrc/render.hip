@@ -301,7 +301,11 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
                                                                 const float* __restrict__ dL_ddepth,
                                                                 const float* __restrict__ dL_dalpha,
                                                                 const float* __restrict__ dL_dnormal,
-                                                                float* __restrict__ grad_rec) {
+                                                                float* __restrict__ grad_rec,
+                                                                float* __restrict__ zero_buf, int zero_n) {
+    // the tiny actor-pose gradient table K8 accumulates into is cleared here (K8 starts after this kernel): no memset launch
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < zero_n; i += EMD_WAVE) zero_buf[i] = 0.f;
     // queue slot s lives in half s>>6: the gradient staging tile (64 rows x 12 floats = 3 KB) overlays the records of
     // the lower half, which are dead (held in registers) by the time a batch's gradients are staged.
     constexpr int NR = NORMAL ? 4 : 3;
@@ -524,7 +528,7 @@ int emd_launch_render_forward(const EmdSettings& s, int flags, const GeomWs& g, 
 int emd_launch_render_backward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                                const float* out_color, const float* out_depth, const float* out_normal,
                                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                               const float* dL_dnormal, float* grad_rec, hipStream_t st) {
+                               const float* dL_dnormal, float* grad_rec, float* zero_buf, int zero_n, hipStream_t st) {
     const RenderDims d = make_dims(s);
     const int T = d.gx * d.gy;
     if (T <= 0) return EMD_OK;
@@ -533,7 +537,7 @@ int emd_launch_render_backward(const EmdSettings& s, int flags, const GeomWs& g,
 #define LAUNCH_BWD(N_, A_)                                                                                          \
     hipLaunchKernelGGL((k_render_backward_q<N_, A_>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.ranges, pl, g.rec,   \
                        im.final_T, im.n_contrib, out_color, out_depth, out_normal, dL_dcolor, dL_ddepth, dL_dalpha,    \
-                       dL_dnormal, grad_rec)
+                       dL_dnormal, grad_rec, zero_buf, zero_n)
     if (nrm && ab) LAUNCH_BWD(true, true);
     else if (nrm) LAUNCH_BWD(true, false);
     else if (ab) LAUNCH_BWD(false, true);

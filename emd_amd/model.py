@@ -48,7 +48,12 @@ class StreetGaussians(torch.nn.Module):
 def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activations=True):
     """The reference render() restricted to the hot path; returns the dict the training loop consumes."""
     dev = model._xyz.device
-    screenspace_points = torch.zeros_like(model._xyz, requires_grad=True)
+    # the reference's zero "screen-space points" leaf that only collects dL/dmean2D: the zeros are never written, so one
+    # cached buffer per model serves every step (a fresh leaf view each time, no 24 MB fill launch)
+    z = getattr(model, "_zero_xyz", None)
+    if z is None or z.shape != model._xyz.shape or z.device != model._xyz.device:
+        z = model._zero_xyz = torch.zeros_like(model._xyz)
+    screenspace_points = z.detach().requires_grad_(True)
     rs = raster_settings_for(cam, bg, model.active_sh_degree, 1.0, debug)
     rasterizer = GaussianRasterizer(raster_settings=rs)
     if fuse_activations:

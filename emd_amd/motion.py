@@ -158,8 +158,9 @@ class _ActorPose(torch.autograd.Function):
         lib = L.load()
         q_f, track_trans, track_rot = ctx.saved_tensors
         A = q_f.shape[0]
-        d_q = torch.zeros(ctx.shapes[0], device=q_f.device, dtype=torch.float32)
-        d_t = torch.zeros(ctx.shapes[1], device=q_f.device, dtype=torch.float32)
+        nq, nt = ctx.shapes[0].numel(), ctx.shapes[1].numel()
+        flat = torch.zeros(nq + nt, device=q_f.device, dtype=torch.float32)          # one fill for both dense clip gradients
+        d_q, d_t = flat[:nq].view(ctx.shapes[0]), flat[nq:].view(ctx.shapes[1])
         d_dt = torch.empty_like(track_trans) if track_trans is not None else None
         d_dq = torch.empty_like(track_rot) if track_rot is not None else None
         L.check(lib.emd_actor_pose_backward(A, q_f.data_ptr(), L.ptr(track_trans), L.ptr(track_rot), g_pose.contiguous().data_ptr(),
