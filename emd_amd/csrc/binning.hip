@@ -35,55 +35,10 @@ __device__ __forceinline__ uint32_t sort_n(const SortN& c) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// generic inclusive scan over uint32 (in place), 3 phases, 1024 elements per block
+// scan geometry of the single-workgroup scans below: 1024 elements per trip
 // ---------------------------------------------------------------------------------------------------
 #define SCAN_ITEMS 4
 #define SCAN_TILE (EMD_BLOCK * SCAN_ITEMS)
-
-__global__ void __launch_bounds__(EMD_BLOCK) k_scan_reduce(const uint32_t* __restrict__ in, size_t n,
-                                                           uint32_t* __restrict__ partial) {
-    __shared__ uint32_t s[4];
-    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++)
-        if (base + k < n) v += in[base + k];
-    uint32_t total;
-    block_scan_add_u32(v, s, &total);
-    if (threadIdx.x == 0) partial[blockIdx.x] = total;
-}
-
-// single block: inclusive scan of up to `n` partials in place (n may exceed the block: looped)
-__global__ void __launch_bounds__(EMD_BLOCK) k_scan_small(uint32_t* __restrict__ data, size_t n) {
-    __shared__ uint32_t s[4];
-    uint32_t carry = 0;
-    for (size_t base = 0; base < n; base += SCAN_TILE) {
-        size_t i0 = base + (size_t)threadIdx.x * SCAN_ITEMS;
-        uint32_t v[SCAN_ITEMS], sum = 0;
-#pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < n) ? data[i0 + k] : 0u; sum += v[k]; }
-        uint32_t total;
-        uint32_t inc = block_scan_add_u32(sum, s, &total);
-        uint32_t run = carry + inc - sum;
-#pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; k++) { run += v[k]; if (i0 + k < n) data[i0 + k] = run; }
-        carry += total;
-    }
-}
-
-__global__ void __launch_bounds__(EMD_BLOCK) k_scan_down(uint32_t* __restrict__ data, size_t n,
-                                                         const uint32_t* __restrict__ partial_inc) {
-    __shared__ uint32_t s[4];
-    size_t i0 = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS], sum = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < n) ? data[i0 + k] : 0u; sum += v[k]; }
-    uint32_t total;
-    uint32_t inc = block_scan_add_u32(sum, s, &total);
-    uint32_t run = (blockIdx.x ? partial_inc[blockIdx.x - 1] : 0u) + inc - sum;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) { run += v[k]; if (i0 + k < n) data[i0 + k] = run; }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // K2': tile rectangle and tile count of the Gaussians in depth order (one 8-byte gather each) + block totals
@@ -388,23 +343,6 @@ int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_
 }
 
 }  // namespace
-
-int emd_launch_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st) {
-    if (n == 0) return EMD_OK;
-    if (n <= SCAN_TILE) {
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(EMD_BLOCK), 0, st, data, n);
-        EMD_LAUNCH_CHECK();
-        return EMD_OK;
-    }
-    const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(EMD_BLOCK), 0, st, data, n, tmp);
-    EMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(EMD_BLOCK), 0, st, tmp, nb);
-    EMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_down, dim3((unsigned)nb), dim3(EMD_BLOCK), 0, st, data, n, tmp);
-    EMD_LAUNCH_CHECK();
-    return EMD_OK;
-}
 
 int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,
                        hipStream_t st) {

@@ -35,7 +35,6 @@ struct GeomWs {
     uint32_t* ghist;         // radix histograms of the depth sort [bins][ceil(N / sort tile)]
     uint32_t* block_sums;    // [ceil(N/256)] tile counts per block of depth-ordered Gaussians, inclusive-scanned in place
     uint32_t* block_vis;     // [ceil(N/256)] visible Gaussians per block
-    uint32_t* scan_tmp;      // scratch for the scans
     size_t bytes;
 };
 
@@ -77,12 +76,6 @@ static inline int emd_tile_pass_bits(int num_tiles) {
     return p ? (emd_tile_bits(num_tiles) + p - 1) / p : 0;
 }
 
-static inline size_t emd_scan_tmp_elems(size_t n) {
-    // partial sums of a 3-phase scan over n elements with 1024-element blocks, two levels
-    size_t l1 = (n + 1023) / 1024, l2 = (l1 + 1023) / 1024;
-    return l1 + l2 + 8;
-}
-
 static inline void emd_carve_geom(void* base, int N, GeomWs* w) {
     char* p = (char*)base;
     size_t off = 0;
@@ -100,7 +93,6 @@ static inline void emd_carve_geom(void* base, int N, GeomWs* w) {
     size_t nb = (n + EMD_BLOCK - 1) / EMD_BLOCK;
     w->block_sums = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 1) * 4, 256);
     w->block_vis = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 1) * 4, 256);
-    w->scan_tmp = (uint32_t*)(p + off); off = emd_align_up(off + emd_scan_tmp_elems(nb) * 4, 256);
     w->bytes = off + 256;
 }
 
@@ -155,7 +147,6 @@ struct PreArgs {
     EmdStatus* status;
 };
 int emd_launch_preprocess(const PreArgs& a, hipStream_t st);                 // preprocess.hip
-int emd_launch_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st);  // binning.hip (inclusive, in place)
 int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,
                        hipStream_t st);                                       // binning.hip
 int emd_launch_export_keys(int64_t D, const GeomWs& g, const BinWs& b, uint64_t* keys, hipStream_t st);  // binning.hip
