@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 TILE = 16
 ACTOR_STRIDE = 12
 BWD_STRIDE = 12
@@ -79,12 +79,19 @@ class EmdSkyBwdArgs(C.Structure):
     _fields_ = [("f", EmdSkyArgs), ("dL_dout", _f), ("dL_dsky", _f), ("dL_dcube", _f), ("dL_dacc", _f), ("dL_dfg", _f)]
 
 
+class EmdLossArgs(C.Structure):
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("image", _f), ("gt", _f), ("depth", _f), ("gt_depth", _f),
+                ("mask", _f), ("weight", _f), ("sky_mask", _f), ("lambda_dssim", C.c_float), ("lambda_depth", C.c_float),
+                ("lambda_sky", C.c_float), ("max_depth", C.c_float), ("losses", _f), ("dL_dimage", _f), ("dL_ddepth", _f),
+                ("dL_dweight", _f)]
+
+
 # every symbol include/emd_raster.h declares
 EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_size", "emd_raster_forward",
                     "emd_raster_backward", "emd_raster_export_binning", "emd_raster_export_geometry",
                     "emd_motion_forward", "emd_motion_backward", "emd_sh_forward", "emd_sh_backward",
                     "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward", "emd_actor_pose_forward", "emd_actor_pose_backward", "emd_l1_loss",
-                    "emd_sky_forward", "emd_sky_backward")
+                    "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss")
 PROF_STAGES = 8
 
 _lib = None
@@ -128,6 +135,9 @@ def load():
     lib.emd_actor_pose_backward.argtypes = [C.c_int32] + [C.c_void_p] * 9
     lib.emd_l1_loss.argtypes = [C.c_int64] + [C.c_void_p] * 5
     lib.emd_profile_enable.argtypes = [C.c_int]
+    lib.emd_image_loss_workspace.argtypes = [C.c_int, C.c_int]
+    lib.emd_image_loss_workspace.restype = C.c_size_t
+    lib.emd_image_loss.argtypes = [C.POINTER(EmdLossArgs), C.c_void_p, C.c_size_t, C.c_void_p]
     lib.emd_sky_forward.argtypes = [C.POINTER(EmdSkyArgs), C.c_void_p]
     lib.emd_sky_backward.argtypes = [C.POINTER(EmdSkyBwdArgs), C.c_void_p]
     lib.emd_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]

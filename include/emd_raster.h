@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 6
+#define EMD_ABI_VERSION 7
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -233,6 +233,29 @@ typedef struct EmdSkyBwdArgs {
 
 int emd_sky_forward(const EmdSkyArgs* args, void* hip_stream);
 int emd_sky_backward(const EmdSkyBwdArgs* args, void* hip_stream);
+
+/* ---- image-loss tail -----------------------------------------------------------------
+ * loss = L1 + lambda_depth * depth L2 + lambda_dssim * (1 - SSIM 11x11) + lambda_sky * sky BCE, with the gradients with
+ * respect to the rendered image, depth and weight in the planar layouts emd_raster_backward consumes.  Replaces
+ * S3Gaussian/utils/loss_utils.py:21-98 (compute_depth "l2", l1_loss, ssim) as used in S3Gaussian/train.py:226-363. */
+typedef struct EmdLossArgs {
+    int32_t height, width;
+    const float* image;        /* [3,H,W] rendered */
+    const float* gt;           /* [3,H,W] target */
+    const float* depth;        /* [H,W] rendered depth, or NULL (no depth term) */
+    const float* gt_depth;     /* [H,W] lidar depth (0 where absent) */
+    const float* mask;         /* [H,W] multiplies both depths (train.py: ~sky_mask), or NULL = ones */
+    const float* weight;       /* [H,W] rendered opacity, or NULL (no sky term) */
+    const uint8_t* sky_mask;   /* [H,W] 1 = sky */
+    float lambda_dssim, lambda_depth, lambda_sky, max_depth;   /* reference: 0.2, 0.5, 0.05, 80 */
+    float* losses;             /* out [5]: total, l1, ssim, depth, sky */
+    float* dL_dimage;          /* out [3,H,W] or NULL */
+    float* dL_ddepth;          /* out [H,W] or NULL */
+    float* dL_dweight;         /* out [H,W] or NULL */
+} EmdLossArgs;
+
+size_t emd_image_loss_workspace(int height, int width);
+int emd_image_loss(const EmdLossArgs* args, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 int emd_abi_version(void);
 const char* emd_last_error(void);

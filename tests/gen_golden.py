@@ -20,6 +20,8 @@ Fixtures (all fp32):
   s3g_sky.npz       SkyCubeMap.forward (rays, mask, clamp, layout) and the sky blend of render(), executed by the reference
                     with oracle/sky_oracle.cube_lookup standing in for the absent nvdiffrast dr.texture (its arguments are
                     recorded too)           S3Gaussian/scene/sky_cubemap.py:41-87, gaussian_renderer/__init__.py:299-301
+  s3g_loss.npz      l1_loss, ssim, compute_depth("l2"), the sky BCE and the total of train.py:226-363 with their
+                    gradients w.r.t. image / depth / weight      S3Gaussian/utils/loss_utils.py:21-98, train.py:226-363
   or_envlight.npz   EnvLight.forward with the same stand-in                OmniRe/models/modules.py:174-208
   or_rigid.npz      RigidNodes.transform_means / transform_quats / opacity mask (+ gradients), train and
                     test-interpolation branches, non-zero track heads  OmniRe/models/nodes/rigid.py:42-46,150-246,478-615
@@ -307,6 +309,43 @@ def gen_s3g_sky():
     unload(["utils", "scene", "arguments", "gaussian_renderer"])
 
 
+def gen_s3g_loss():
+    sys.path.insert(0, os.path.join(REF, "S3Gaussian"))
+    with _CpuMode():
+        from utils.loss_utils import l1_loss, ssim, compute_depth
+        g = torch.Generator().manual_seed(500)
+        H, W = 45, 70
+        gt = torch.rand(3, H, W, generator=g)
+        image = (gt + 0.15 * torch.randn(3, H, W, generator=g)).clamp(0, 1).requires_grad_(True)
+        gt_depth = torch.rand(1, H, W, generator=g) * 100.0
+        gt_depth[:, ::3] = 0.0                                  # no lidar return
+        depth = (gt_depth + 3.0 * torch.randn(1, H, W, generator=g)).abs()
+        depth[:, :, :4] = 95.0                                  # beyond max_depth: clamp, zero gradient
+        depth.requires_grad_(True)
+        sky_mask = torch.rand(1, H, W, generator=g) < 0.25
+        weight = torch.rand(1, H, W, generator=g)
+        weight[0, 0, :5] = 0.0                                  # outside the clamp range
+        weight[0, 1, :5] = 1.0
+        weight.requires_grad_(True)
+        lam_dssim, lam_depth, lam_sky = 0.2, 0.5, 0.05         # arguments/gaussian_options.py:95-105
+        mask = ~sky_mask                                        # train.py:221-222
+        Ll1 = l1_loss(image, gt)
+        loss = Ll1
+        depth_loss = compute_depth("l2", depth * mask, gt_depth * mask) * lam_depth          # train.py:346-349
+        loss = loss + depth_loss
+        ssim_val = ssim(image, gt)
+        loss = loss + lam_dssim * (1.0 - ssim_val)                                           # train.py:351-355
+        w = torch.clamp(weight, min=1e-6, max=1. - 1e-6)                                     # train.py:357-361
+        sky_loss = torch.where(sky_mask, -torch.log(1 - w), -torch.log(w)).mean()
+        loss = loss + lam_sky * sky_loss
+        loss.backward()
+        save("s3g_loss.npz", image=image.data, gt=gt, depth=depth.data, gt_depth=gt_depth, sky_mask=sky_mask.to(torch.uint8),
+             weight=weight.data, l1=Ll1, ssim=ssim_val, depth_l2=depth_loss / lam_depth, sky=sky_loss, total=loss,
+             g_image=image.grad, g_depth=depth.grad, g_weight=weight.grad, lambdas=torch.tensor([lam_dssim, lam_depth, lam_sky]))
+    sys.path.pop(0)
+    unload(["utils", "scene", "arguments", "gaussian_renderer"])
+
+
 def gen_or_envlight():
     sys.path.insert(0, os.path.join(REF, "OmniRe"))
     import nvdiffrast.torch as dr
@@ -454,6 +493,7 @@ if __name__ == "__main__":
     gen_s3g()
     gen_s3g_render()
     gen_s3g_sky()
+    gen_s3g_loss()
     print("OmniRe:")
     gen_omnire()
     gen_or_envlight()
