@@ -59,6 +59,23 @@ def pmc_traffic(stage, passes):
     return tot or None
 
 
+def pmc_valu(stage):
+    """Fraction of the fp32 vector issue slots the stage's dominant kernel fills (profiles/r01_pmc_valu.csv: rocprofv3 --pmc
+    SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x duration of the same dispatch)); None when the summary is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_valu.csv")
+    if not os.path.exists(path):
+        return None
+    names = PMC_STAGE_KERNELS.get(stage, ())
+    for line in open(path):
+        if line.startswith("#") or line.startswith("kernel,"):
+            continue
+        f = line.rstrip("\n").split(",")
+        if f[0] in names:
+            return {"kernel": f[0], "SQ_INSTS_VALU": float(f[2]), "utilisation": float(f[-1]), "peak_Ginst_per_s": 614.4,
+                    "source": "profiles/r01_pmc_valu.csv"}
+    return None
+
+
 def algorithmic_bytes(N, V, D, HW, T, C, p, residual=False, C_bwd=None):
     """Compulsory HBM bytes per stage (C blended channels, p radix passes)."""
     Cf, C = C, (C if C_bwd is None else C_bwd)
@@ -221,6 +238,7 @@ def main():
                     "traffic": pmc_traffic(dom, passes) if (N, H, W) == (2_000_000, 1066, 1600) else None,
                     "traffic_source": "profiles/r01_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
                     "secondary_bound": "fp32 vector issue rate: the render kernels are VALU-bound (DESIGN.md section 3)",
+                    "valu": pmc_valu(dom) if (N, H, W) == (2_000_000, 1066, 1600) else None,
                     "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": stages[dom]["ms"],
                     "whole_iter": {"algorithmic_GB": round(total_alg / 1e9, 3), "kernel_ms": round(kernel_ms, 3),
                                    "GBps": round(total_alg / 1e9 / (kernel_ms * 1e-3), 1),
