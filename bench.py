@@ -126,8 +126,8 @@ def cpu_baseline(scene, cam, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gaussians", type=int, default=2_000_000)
     ap.add_argument("--height", type=int, default=1066)
     ap.add_argument("--width", type=int, default=1600)
