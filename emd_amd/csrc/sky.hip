@@ -140,18 +140,18 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sky_forward(EmdSkyArgs a) {
 // Texel gradients are combined per workgroup before they touch memory.  A workgroup owns a 16 x 16 pixel tile, whose
 // bilinear taps fall on a few dozen texels when the map is magnified (1024^2 faces under a 1700-px focal length: ~7
 // pixels per texel); issued one by one, that many float atomics to the same address serialise in L2 (measured
-// 1.17 ms for a 1066 x 1600 view).  An LDS hash table keyed by texel index (512 slots, linear probing, ds atomics) absorbs
-// them; one global atomic per distinct texel and channel leaves the workgroup.  A probe that runs too long (heavily
-// minified map: more distinct texels than slots) falls back to the direct global atomic.
-#define SKY_SLOTS 512
-#define SKY_EMPTY 0xFFFFFFFFu
+// 1.17 ms for a 1066 x 1600 view).  The tile's taps lie in a small window of one face, so the workgroup accumulates into
+// an LDS window of SKY_WIN x SKY_WIN texels anchored at the tap of its first pixel (plain ds_add_f32, no hashing); taps
+// outside the window or on another face (tiles that straddle a cube edge, heavily minified maps) go straight to the
+// global atomic.  One global atomic per touched texel and channel leaves the workgroup.
+#define SKY_WIN 24
 __global__ void __launch_bounds__(EMD_BLOCK) k_sky_backward(EmdSkyBwdArgs b) {
-    __shared__ uint32_t s_key[SKY_SLOTS];
-    __shared__ float s_val[SKY_SLOTS * 3];
+    __shared__ float s_val[SKY_WIN * SKY_WIN * 3];
+    __shared__ int s_org[3];     // face, u0, v0 of the window
     const EmdSkyArgs& a = b.f;
-    for (int i = threadIdx.x; i < SKY_SLOTS; i += EMD_BLOCK) { s_key[i] = SKY_EMPTY; s_val[3 * i] = 0.f; s_val[3 * i + 1] = 0.f; s_val[3 * i + 2] = 0.f; }
-    __syncthreads();
+    for (int i = threadIdx.x; i < SKY_WIN * SKY_WIN * 3; i += EMD_BLOCK) s_val[i] = 0.f;
     const size_t P = (size_t)a.height * a.width;
+    const int res = a.resolution;
     size_t p;
     int px, py;
     bool valid;
@@ -166,17 +166,19 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sky_backward(EmdSkyBwdArgs b) {
         valid = p < P;
         px = (int)p; py = 0;
     }
+    const bool il = (a.flags & EMD_SKY_INTERLEAVED) != 0;
+    float acc = 0.f, gs[3] = {0.f, 0.f, 0.f};
+    bool sampled = false;
+    Tap tp;
     if (valid) {
-        const bool il = (a.flags & EMD_SKY_INTERLEAVED) != 0;
-        const float acc = a.acc ? a.acc[p] : 0.f;
-        const bool sampled = !(a.acc && a.mask_threshold >= 0.f) || (1.f - acc) > a.mask_threshold;
+        acc = a.acc ? a.acc[p] : 0.f;
+        sampled = !(a.acc && a.mask_threshold >= 0.f) || (1.f - acc) > a.mask_threshold;
         float s[3] = {a.fill, a.fill, a.fill};
         bool pass[3] = {false, false, false};
-        Tap tp;
         if (sampled) {
             float dx, dy, dz;
             pixel_ray(a, px, py, p, dx, dy, dz);
-            cube_taps(dx, dy, dz, a.resolution, tp);
+            cube_taps(dx, dy, dz, res, tp);
             s[0] = s[1] = s[2] = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sky_backward(EmdSkyBwdArgs b) {
 #pragma unroll
             for (int c = 0; c < 3; c++) s[c] = fminf(fmaxf(s[c], 0.f), 1.f);
         }
-        float gs[3], dacc = 0.f;
+        float dacc = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const size_t q = il ? 3 * p + c : (size_t)c * P + p;
@@ -204,34 +206,46 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sky_backward(EmdSkyBwdArgs b) {
             if (!pass[c]) gs[c] = 0.f;
         }
         if (b.dL_dacc) b.dL_dacc[p] = dacc;
-        if (sampled && b.dL_dcube && (gs[0] != 0.f || gs[1] != 0.f || gs[2] != 0.f)) {
+    }
+    if (!b.dL_dcube) return;
+    // window origin: centred on the first tap of the lowest contributing lane of the workgroup
+    __shared__ int s_leader;
+    if (threadIdx.x == 0) s_leader = EMD_BLOCK;
+    __syncthreads();                                  // also: s_val is cleared
+    const bool contributes = valid && sampled && (gs[0] != 0.f || gs[1] != 0.f || gs[2] != 0.f);
+    if (contributes) atomicMin(&s_leader, (int)threadIdx.x);
+    __syncthreads();
+    if (s_leader == EMD_BLOCK) return;                // nothing to scatter (uniform)
+    if ((int)threadIdx.x == s_leader) {
+        const uint32_t t0 = tp.idx[0];
+        const int f = (int)(t0 / (uint32_t)(res * res)), r = (int)(t0 % (uint32_t)(res * res));
+        s_org[0] = f; s_org[1] = r % res - SKY_WIN / 2; s_org[2] = r / res - SKY_WIN / 2;
+    }
+    __syncthreads();
+    const int of = s_org[0], ou = s_org[1], ov = s_org[2];
+    if (contributes) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (tp.w[k] == 0.f) continue;
-                const uint32_t key = tp.idx[k];
-                uint32_t h = (key * 2654435761u) >> 23;          // 9 bits
-                int slot = -1;
-                for (int probe = 0; probe < 24; probe++) {
-                    const uint32_t prev = atomicCAS(&s_key[h], SKY_EMPTY, key);
-                    if (prev == SKY_EMPTY || prev == key) { slot = (int)h; break; }
-                    h = (h + 1) & (SKY_SLOTS - 1);
-                }
+        for (int k = 0; k < 4; k++) {
+            if (tp.w[k] == 0.f) continue;
+            const uint32_t key = tp.idx[k];
+            const int f = (int)(key / (uint32_t)(res * res)), r = (int)(key % (uint32_t)(res * res));
+            const int wu = r % res - ou, wv = r / res - ov;
+            const bool in_win = f == of && wu >= 0 && wu < SKY_WIN && wv >= 0 && wv < SKY_WIN;
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    if (gs[c] == 0.f) continue;
-                    if (slot >= 0) atomicAdd(&s_val[3 * slot + c], tp.w[k] * gs[c]);
-                    else atomicAdd(b.dL_dcube + (size_t)key * 3 + c, tp.w[k] * gs[c]);
-                }
+            for (int c = 0; c < 3; c++) {
+                if (gs[c] == 0.f) continue;
+                if (in_win) atomicAdd(&s_val[(wv * SKY_WIN + wu) * 3 + c], tp.w[k] * gs[c]);
+                else atomicAdd(b.dL_dcube + (size_t)key * 3 + c, tp.w[k] * gs[c]);
             }
         }
     }
     __syncthreads();
-    if (b.dL_dcube) {
-        for (int i = threadIdx.x; i < SKY_SLOTS * 3; i += EMD_BLOCK) {
-            const uint32_t key = s_key[i / 3];
-            const float v = s_val[i];
-            if (key != SKY_EMPTY && v != 0.f) atomicAdd(b.dL_dcube + (size_t)key * 3 + (i % 3), v);
-        }
+    for (int i = threadIdx.x; i < SKY_WIN * SKY_WIN * 3; i += EMD_BLOCK) {
+        const float v = s_val[i];
+        if (v == 0.f) continue;
+        const int t = i / 3, wu = t % SKY_WIN + ou, wv = t / SKY_WIN + ov;
+        if (wu < 0 || wu >= res || wv < 0 || wv >= res) continue;     // never written: in_win implies a real texel
+        atomicAdd(b.dL_dcube + ((size_t)(of * res + wv) * res + wu) * 3 + (i % 3), v);
     }
 }
 
