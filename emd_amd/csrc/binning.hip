@@ -319,6 +319,41 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_tile_ranges(const uint32_t* __res
     }
 }
 
+// Dispatch order of the render kernels: tiles by descending list length (1024 buckets of 16 entries), so the deep tiles
+// start first and the kernel's tail is made of short ones (longest-processing-time-first).  Order inside a bucket is
+// arbitrary: it only decides when a tile is rendered, never what is rendered.  One workgroup; above 64 K tiles the
+// identity order is kept (plenty of tiles to fill the tail anyway).
+#define ORDER_BUCKETS 1024
+__global__ void __launch_bounds__(ORDER_BUCKETS) k_tile_order(const uint32_t* __restrict__ ranges, uint32_t T, uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_h[ORDER_BUCKETS];
+    __shared__ uint32_t s_w[ORDER_BUCKETS / 64];
+    s_h[threadIdx.x] = 0;                                    // one thread per bucket
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < T; t += ORDER_BUCKETS) {
+        const uint32_t len = ranges[2 * t + 1] - ranges[2 * t];
+        atomicAdd(&s_h[ORDER_BUCKETS - 1 - min(len >> 4, (uint32_t)ORDER_BUCKETS - 1)], 1u);     // bucket 0 = longest
+    }
+    __syncthreads();
+    {   // exclusive scan over the buckets: wave scans + the 16 wave totals
+        const uint32_t v = s_h[threadIdx.x];
+        const uint32_t inc = wave_scan_add_u32(v);
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += s_w[w];
+        s_h[threadIdx.x] = base + inc - v;
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < T; t += ORDER_BUCKETS) {
+        const uint32_t len = ranges[2 * t + 1] - ranges[2 * t];
+        order[atomicAdd(&s_h[ORDER_BUCKETS - 1 - min(len >> 4, (uint32_t)ORDER_BUCKETS - 1)], 1u)] = t;
+    }
+}
+__global__ void __launch_bounds__(EMD_BLOCK) k_tile_order_identity(uint32_t T, uint32_t* __restrict__ order) {
+    const uint32_t t = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (t < T) order[t] = t;
+}
+
 // upstream's 64-bit keys, rebuilt for the parity tests: tile id << 32 | depth bits of the Gaussian
 __global__ void __launch_bounds__(EMD_BLOCK) k_export_keys(size_t D, const uint32_t* __restrict__ tkeys,
                                                            const uint32_t* __restrict__ vals,
@@ -378,6 +413,8 @@ int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs
                                (uint64_t)(capacity > 0 ? capacity : 0), status, b.slot_start, 0u);
             EMD_LAUNCH_CHECK();
         }
+        hipLaunchKernelGGL(k_tile_order_identity, dim3((T + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, (uint32_t)T, b.tile_order);
+        EMD_LAUNCH_CHECK();
         emd_prof_switch(PROF_DUPLICATE, PROF_RANGES, st);
         return EMD_OK;
     }
@@ -404,6 +441,9 @@ int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs
     emd_prof_switch(PROF_SORT, PROF_RANGES, st);
     const unsigned rb = (unsigned)(((size_t)capacity + EMD_BLOCK - 1) / EMD_BLOCK);
     hipLaunchKernelGGL(k_tile_ranges, dim3(rb < 4096u ? rb : 4096u), dim3(EMD_BLOCK), 0, st, b.tkeys[cur], status, b.ranges);
+    EMD_LAUNCH_CHECK();
+    if (T <= 65536) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(ORDER_BUCKETS), 0, st, b.ranges, (uint32_t)T, b.tile_order);
+    else hipLaunchKernelGGL(k_tile_order_identity, dim3((T + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, (uint32_t)T, b.tile_order);
     EMD_LAUNCH_CHECK();
     return EMD_OK;   // PROF_RANGES is closed by the render-forward switch
 }

@@ -42,6 +42,7 @@ struct BinWs {
     uint32_t* tkeys[2];      // [capacity] ping-pong: tile id of every (tile, Gaussian) pair
     uint32_t* vals[2];       // [capacity] Gaussian id
     uint32_t* ranges;        // [T][2]
+    uint32_t* tile_order;    // [T] tile ids by descending list length: dispatch order of the render kernels
     uint32_t* hist;          // radix histograms [bins][num_sort_blocks]
     uint32_t* slot_start;    // [ceil(capacity / 2048)] first block of Gaussians of every output block of the duplicate kernel
     int sorted_buf;          // which ping-pong buffer holds the sorted list after forward (fixed by #passes)
@@ -103,6 +104,7 @@ static inline void emd_carve_bin(void* base, int64_t capacity, int num_tiles, Bi
     for (int i = 0; i < 2; i++) { w->tkeys[i] = (uint32_t*)(p + off); off = emd_align_up(off + cap * 4, 256); }
     for (int i = 0; i < 2; i++) { w->vals[i] = (uint32_t*)(p + off); off = emd_align_up(off + cap * 4, 256); }
     w->ranges = (uint32_t*)(p + off); off = emd_align_up(off + (size_t)num_tiles * 8, 256);
+    w->tile_order = (uint32_t*)(p + off); off = emd_align_up(off + (size_t)num_tiles * 4, 256);
     size_t nsb = (cap + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
     w->hist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_RADIX_BINS * 4, 256);
     w->slot_start = (uint32_t*)(p + off); off = emd_align_up(off + (nsb + 1) * 4, 256);

@@ -35,6 +35,14 @@ __device__ __forceinline__ uint32_t xcd_quadrant_block(uint32_t b, uint32_t* qua
     *quad = k & 3u;
     return ((tl / XCD_CHUNK) * 8 + xcd) * XCD_CHUNK + (tl % XCD_CHUNK);
 }
+// The same with the tiles taken from `order` (descending list length, binning.hip): position tl * 8 + xcd of the order,
+// so every XCD works through the order front to back and the four quadrant waves of a tile still share an XCD.
+__device__ __forceinline__ uint32_t ordered_quadrant_block(uint32_t b, uint32_t T, const uint32_t* __restrict__ order, uint32_t* quad) {
+    const uint32_t xcd = b % 8, k = b / 8, tl = k >> 2;
+    *quad = k & 3u;
+    const uint32_t pos = tl * 8 + xcd;
+    return pos < T ? order[pos] : 0xFFFFFFFFu;
+}
 static inline unsigned padded_tile_grid(int T) { return (unsigned)((T + 8 * XCD_CHUNK - 1) / (8 * XCD_CHUNK) * (8 * XCD_CHUNK)); }
 
 // Gaussian exponent, evaluated identically (explicit FMAs, no further contraction) in K6 and K7 so that both
@@ -146,7 +154,7 @@ __device__ __forceinline__ uint32_t quad_subblock_mask(const float4& r0, const f
 }
 
 template <bool NORMAL>
-__global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, const uint32_t* __restrict__ ranges,
+__global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ ranges,
                                                                const uint32_t* __restrict__ point_list,
                                                                const float4* __restrict__ rec, float* __restrict__ out_color,
                                                                float* __restrict__ out_depth, float* __restrict__ out_normal,
@@ -157,7 +165,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
     __shared__ float4 s3[NORMAL ? FQ_RING : 1];
     __shared__ uint8_t s_list[4][FQ_RING];
     uint32_t quad;
-    const uint32_t tile = xcd_quadrant_block(blockIdx.x, &quad);
+    const uint32_t tile = ordered_quadrant_block(blockIdx.x, (uint32_t)(d.gx * d.gy), tile_order, &quad);
     if (tile >= (uint32_t)(d.gx * d.gy)) return;
     const uint32_t lane = threadIdx.x, row = lane >> 4, l = lane & 15;
     const int qxi = (int)((tile % (uint32_t)d.gx) * EMD_TILE_X + (quad & 1) * 8), qyi = (int)((tile / (uint32_t)d.gx) * EMD_TILE_Y + (quad >> 1) * 8);
@@ -289,7 +297,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
 #define BQ_QUEUE 128
 
 template <bool NORMAL, bool ABS>
-__global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4))) k_render_backward_q(RenderDims d, const uint32_t* __restrict__ ranges,
+__global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4))) k_render_backward_q(RenderDims d, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ point_list,
                                                                 const float4* __restrict__ rec,
                                                                 const float* __restrict__ final_T,
@@ -320,7 +328,7 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
     __shared__ float4 s_pix[EMD_WAVE / 2][NORMAL ? 6 : 4];
 #define QREC(r, s) q_rec[(s) >> 6][r][(s) & 63]
     uint32_t quad;
-    const uint32_t tile = xcd_quadrant_block(blockIdx.x, &quad);
+    const uint32_t tile = ordered_quadrant_block(blockIdx.x, (uint32_t)(d.gx * d.gy), tile_order, &quad);
     if (tile >= (uint32_t)(d.gx * d.gy)) return;
     const uint32_t lane = threadIdx.x;
     const float tile_x0 = (float)((tile % (uint32_t)d.gx) * EMD_TILE_X), tile_y0 = (float)((tile / (uint32_t)d.gx) * EMD_TILE_Y);
@@ -516,10 +524,10 @@ int emd_launch_render_forward(const EmdSettings& s, int flags, const GeomWs& g, 
     if (T <= 0) return EMD_OK;
     const uint32_t* pl = b.vals[b.sorted_buf];
     if (flags & EMD_FLAG_NORMAL)
-        hipLaunchKernelGGL(k_render_forward_q<true>, dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.ranges, pl, g.rec, out_color,
+        hipLaunchKernelGGL(k_render_forward_q<true>, dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec, out_color,
                            out_depth, out_normal, out_alpha, im.final_T, im.n_contrib);
     else
-        hipLaunchKernelGGL(k_render_forward_q<false>, dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.ranges, pl, g.rec, out_color,
+        hipLaunchKernelGGL(k_render_forward_q<false>, dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec, out_color,
                            out_depth, out_normal, out_alpha, im.final_T, im.n_contrib);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
@@ -535,7 +543,7 @@ int emd_launch_render_backward(const EmdSettings& s, int flags, const GeomWs& g,
     const uint32_t* pl = b.vals[b.sorted_buf];
     const bool nrm = (flags & EMD_FLAG_NORMAL) && dL_dnormal && out_normal, ab = flags & EMD_FLAG_ABSGRAD;
 #define LAUNCH_BWD(N_, A_)                                                                                          \
-    hipLaunchKernelGGL((k_render_backward_q<N_, A_>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.ranges, pl, g.rec,   \
+    hipLaunchKernelGGL((k_render_backward_q<N_, A_>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec,   \
                        im.final_T, im.n_contrib, out_color, out_depth, out_normal, dL_dcolor, dL_ddepth, dL_dalpha,    \
                        dL_dnormal, grad_rec, zero_buf, zero_n)
     if (nrm && ab) LAUNCH_BWD(true, true);
