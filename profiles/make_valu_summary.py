@@ -37,6 +37,8 @@ def main(d):
     print("# (two passes) -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline; wave-level instruction counts per dispatch, averaged over dispatches.")
     print("# dur_us = duration of the same dispatches (kernel trace of the counter run); valu_util = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x dur),")
     print("# averaged per dispatch: the fraction of the fp32 vector issue slots the kernel fills (a wave64 VALU instruction occupies its SIMD for 4 cycles).")
+    print("# A value slightly above 1 (K6) means the kernel issues a VALU instruction practically every cycle of every SIMD and the nominal")
+    print("# 2.4 GHz x 4-cycle model is a little conservative; it is reported raw.")
     print("kernel," + ",".join(cols))
     for k in sorted(rows):
         print(k + "," + ",".join(f"{rows[k].get(c, 0):.4g}" for c in cols))
