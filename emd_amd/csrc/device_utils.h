@@ -26,21 +26,6 @@ __device__ __forceinline__ float wave_scan_add_f32(float v) {
     return v;
 }
 
-// Inclusive wave64 prefix product; invalid / masked DPP sources read as 1.0.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_mul_f32(float v) {
-    int src = __builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-    return v * __int_as_float(src);
-}
-__device__ __forceinline__ float wave_scan_mul_f32(float v) {
-    v = dpp_mul_f32<DPP_ROW_SHR(1), 0xf>(v);
-    v = dpp_mul_f32<DPP_ROW_SHR(2), 0xf>(v);
-    v = dpp_mul_f32<DPP_ROW_SHR(4), 0xf>(v);
-    v = dpp_mul_f32<DPP_ROW_SHR(8), 0xf>(v);
-    v = dpp_mul_f32<DPP_ROW_BCAST15, 0xa>(v);
-    v = dpp_mul_f32<DPP_ROW_BCAST31, 0xc>(v);
-    return v;
-}
 // Shift the whole wave up by one lane (lane l receives lane l-1; lane 0 receives `fill`): DPP wave_shr:1.
 #define DPP_WAVE_SHR1 0x138
 __device__ __forceinline__ float wave_shift_up1_f32(float v, float fill) {
@@ -48,29 +33,8 @@ __device__ __forceinline__ float wave_shift_up1_f32(float v, float fill) {
 }
 
 // Hand-fused scans: one VALU op per step (v_mul_f32_dpp / v_add_f32_dpp with the destination doubling as `old`, so
-// lanes without a valid source keep their value).  hipcc emits v_mov_b32_dpp + v_mul_f32 (+ an identity v_mov) per
-// step for the product scan.  The s_nop 1 in front of each step covers the VALU-write -> DPP-read hazard, which the
-// compiler does not pad inside asm statements.
-#define EMD_DPP_STEP(op, v, ctrl) asm volatile("s_nop 1\n\t" op " %0, %0, %0 " ctrl : "+v"(v))
-__device__ __forceinline__ float wave_scan_mul_f32_asm(float v) {
-    EMD_DPP_STEP("v_mul_f32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
-    EMD_DPP_STEP("v_mul_f32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
-    EMD_DPP_STEP("v_mul_f32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
-    EMD_DPP_STEP("v_mul_f32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
-    EMD_DPP_STEP("v_mul_f32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
-    EMD_DPP_STEP("v_mul_f32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
-    return v;
-}
-__device__ __forceinline__ float wave_scan_add_f32_asm(float v) {
-    EMD_DPP_STEP("v_add_f32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
-    EMD_DPP_STEP("v_add_f32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
-    EMD_DPP_STEP("v_add_f32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
-    EMD_DPP_STEP("v_add_f32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
-    EMD_DPP_STEP("v_add_f32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
-    EMD_DPP_STEP("v_add_f32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
-    return v;
-}
-
+// lanes without a valid source keep their value); hipcc emits v_mov_b32_dpp + v_mul_f32 (+ an identity v_mov) per
+// step for the product scan.  The compiler does not pad the VALU-write -> DPP-read hazard inside asm statements.
 // Two independent scans interleaved: each DPP step of one chain sits between two steps of the other, so one s_nop 0
 // per pair covers the VALU-write -> DPP-read hazard (2 wait states) of both chains.
 #define EMD_DPP_STEP2(op, a, b, ctrl)                                                                          \
