@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 TILE = 16
 ACTOR_STRIDE = 12
 BWD_STRIDE = 12
@@ -86,12 +86,25 @@ class EmdLossArgs(C.Structure):
                 ("dL_dweight", _f)]
 
 
+HEX_MAX_SCALES = 8
+
+
+class EmdHexArgs(C.Structure):
+    _fields_ = [("num_points", C.c_int32), ("channels", C.c_int32), ("num_scales", C.c_int32), ("reserved", C.c_int32),
+                ("res", (C.c_int32 * 4) * HEX_MAX_SCALES), ("planes", (_f * 6) * HEX_MAX_SCALES), ("pts", _f), ("times", _f),
+                ("aabb", C.c_float * 6), ("out", _f)]
+
+
+class EmdHexGrads(C.Structure):
+    _fields_ = [("dL_dout", _f), ("dL_dplanes", (_f * 6) * HEX_MAX_SCALES), ("dL_dpts", _f)]
+
+
 # every symbol include/emd_raster.h declares
 EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_size", "emd_raster_forward",
                     "emd_raster_backward", "emd_raster_export_binning", "emd_raster_export_geometry",
                     "emd_motion_forward", "emd_motion_backward", "emd_sh_forward", "emd_sh_backward",
                     "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward", "emd_actor_pose_forward", "emd_actor_pose_backward", "emd_l1_loss",
-                    "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss")
+                    "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss", "emd_hexplane_forward", "emd_hexplane_backward")
 PROF_STAGES = 8
 
 _lib = None
@@ -138,6 +151,8 @@ def load():
     lib.emd_image_loss_workspace.argtypes = [C.c_int, C.c_int]
     lib.emd_image_loss_workspace.restype = C.c_size_t
     lib.emd_image_loss.argtypes = [C.POINTER(EmdLossArgs), C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.emd_hexplane_forward.argtypes = [C.POINTER(EmdHexArgs), C.c_void_p]
+    lib.emd_hexplane_backward.argtypes = [C.POINTER(EmdHexArgs), C.POINTER(EmdHexGrads), C.c_void_p]
     lib.emd_sky_forward.argtypes = [C.POINTER(EmdSkyArgs), C.c_void_p]
     lib.emd_sky_backward.argtypes = [C.POINTER(EmdSkyBwdArgs), C.c_void_p]
     lib.emd_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]

@@ -1,0 +1,125 @@
+"""HexPlane feature field on the HIP path.
+
+`HexPlaneField` mirrors S3Gaussian/scene/hexplane.py:112-183 (constructor arguments, `grids` ParameterList layout
+[scale][plane] = [1, C, res_h, res_w], initialisation, `aabb`, `set_aabb`, `get_density`, `forward`), so checkpoints and the
+deformation network that owns it are untouched; the lookup itself -- per scale six grid_samples, five products, a concat, and
+their backward -- is one HIP launch each way (`emd_hexplane_forward/backward`).  No CPU path."""
+import ctypes as C
+import itertools
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+PAIRS = list(itertools.combinations(range(4), 2))
+
+
+class _HexLookup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, times, aabb, res, *planes):
+        if pts.device.type != "cuda":
+            raise L.EmdError("HexPlane lookup needs tensors on a ROCm device; there is no CPU path")
+        lib = L.load()
+        S = len(planes) // 6
+        Cc = planes[0].shape[1]
+        N = pts.shape[0]
+        pts_c, times_c = pts.detach().contiguous().float(), times.detach().reshape(-1).contiguous().float()
+        # channel-last copies: a tap becomes one contiguous C x 4-byte row
+        cl = [p.detach()[0].permute(1, 2, 0).contiguous().float() for p in planes]
+        a = L.EmdHexArgs()
+        a.num_points, a.channels, a.num_scales = N, Cc, S
+        for s in range(S):
+            for k in range(4):
+                a.res[s][k] = res[s][k]
+            for p in range(6):
+                a.planes[s][p] = cl[s * 6 + p].data_ptr()
+        a.pts, a.times = pts_c.data_ptr(), times_c.data_ptr()
+        ab = aabb.detach().reshape(-1).to("cpu", torch.float32).tolist()
+        for k in range(6):
+            a.aabb[k] = ab[k]
+        out = torch.empty(N, S * Cc, device=pts.device, dtype=torch.float32)
+        a.out = out.data_ptr()
+        L.check(lib.emd_hexplane_forward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_hexplane_forward")
+        ctx.args, ctx.keep = a, (pts_c, times_c, cl)
+        ctx.shapes = [tuple(p.shape) for p in planes]
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = L.load()
+        a = ctx.args
+        S, Cc = a.num_scales, a.channels
+        g_out = g_out.contiguous().float()
+        g = L.EmdHexGrads()
+        g.dL_dout = g_out.data_ptr()
+        need_planes = any(ctx.needs_input_grad[4:])
+        gcl = []
+        if need_planes:
+            flat = torch.zeros(sum(int(np.prod(s)) for s in ctx.shapes), device=g_out.device, dtype=torch.float32)   # one fill
+            off = 0
+            for i, shp in enumerate(ctx.shapes):
+                n = int(np.prod(shp))
+                gcl.append(flat[off:off + n].view(shp[2], shp[3], shp[1]))
+                g.dL_dplanes[i // 6][i % 6] = gcl[-1].data_ptr()
+                off += n
+        d_pts = torch.empty(a.num_points, 3, device=g_out.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        g.dL_dpts = L.ptr(d_pts)
+        L.check(lib.emd_hexplane_backward(C.byref(a), C.byref(g), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                "emd_hexplane_backward")
+        grads = [t.permute(2, 0, 1)[None].contiguous() for t in gcl] if need_planes else [None] * len(ctx.shapes)
+        return (d_pts, None, None, None, *grads)
+
+
+def init_grid_param(grid_nd, in_dim, out_dim, reso, a=0.1, b=0.5):
+    """S3Gaussian/scene/hexplane.py:48-70"""
+    assert in_dim == len(reso) and grid_nd == 2 and in_dim == 4, "the HIP lookup implements the 4-D, plane (2-D) configuration"
+    grid_coefs = nn.ParameterList()
+    for coo_comb in PAIRS:
+        coef = nn.Parameter(torch.empty([1, out_dim] + [reso[cc] for cc in coo_comb[::-1]]))
+        if 3 in coo_comb:
+            nn.init.ones_(coef)            # time planes start at 1
+        else:
+            nn.init.uniform_(coef, a=a, b=b)
+        grid_coefs.append(coef)
+    return grid_coefs
+
+
+class HexPlaneField(nn.Module):
+    """S3Gaussian/scene/hexplane.py:112-183"""
+
+    def __init__(self, bounds, planeconfig, multires):
+        super().__init__()
+        aabb = torch.tensor([[bounds, bounds, bounds], [-bounds, -bounds, -bounds]], dtype=torch.float32)
+        self.aabb = nn.Parameter(aabb, requires_grad=False)
+        self.grid_config = [planeconfig]
+        self.multiscale_res_multipliers = multires
+        self.concat_features = True
+        self.grids = nn.ModuleList()
+        self.feat_dim = 0
+        self._res = []
+        for res in self.multiscale_res_multipliers:
+            config = self.grid_config[0].copy()
+            config["resolution"] = [r * res for r in config["resolution"][:3]] + config["resolution"][3:]
+            gp = init_grid_param(config["grid_dimensions"], config["input_coordinate_dim"], config["output_coordinate_dim"],
+                                 config["resolution"])
+            self.feat_dim += gp[-1].shape[1]
+            self.grids.append(gp)
+            self._res.append(list(config["resolution"]))
+
+    @property
+    def get_aabb(self):
+        return self.aabb[0], self.aabb[1]
+
+    def set_aabb(self, xyz_max, xyz_min):
+        aabb = torch.from_numpy(np.array([xyz_max, xyz_min], dtype=np.float32)).to(self.aabb.device)
+        self.aabb = nn.Parameter(aabb, requires_grad=False)
+
+    def get_density(self, pts, timestamps=None):
+        pts = pts.reshape(-1, pts.shape[-1])
+        planes = [p for gp in self.grids for p in gp]
+        return _HexLookup.apply(pts, timestamps.reshape(-1, 1), self.aabb, self._res, *planes)
+
+    def forward(self, pts, timestamps=None):
+        return self.get_density(pts, timestamps)

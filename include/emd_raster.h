@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 7
+#define EMD_ABI_VERSION 8
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -256,6 +256,30 @@ typedef struct EmdLossArgs {
 
 size_t emd_image_loss_workspace(int height, int width);
 int emd_image_loss(const EmdLossArgs* args, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* ---- HexPlane feature lookup -------------------------------------------------------------
+ * Replaces HexPlaneField.get_density / interpolate_ms_features (S3Gaussian/scene/hexplane.py:18-110,150-183): for every
+ * scale the product over the six coordinate planes (xy, xz, xt, yz, yt, zt) of a bilinear, align_corners, border-padded
+ * grid_sample, concatenated over scales.  Planes are passed CHANNEL-LAST: [res_h][res_w][C]. */
+#define EMD_HEX_MAX_SCALES 8
+typedef struct EmdHexArgs {
+    int32_t num_points, channels, num_scales, reserved;
+    int32_t res[EMD_HEX_MAX_SCALES][4];          /* per scale: resolution along x, y, z, t */
+    const float* planes[EMD_HEX_MAX_SCALES][6];  /* per scale: planes of the pairs (0,1),(0,2),(0,3),(1,2),(1,3),(2,3), [res[b]][res[a]][C] */
+    const float* pts;                            /* [N,3] */
+    const float* times;                          /* [N] */
+    float aabb[6];                               /* aabb[0] (3 floats) then aabb[1] (3 floats), as HexPlaneField stores them */
+    float* out;                                  /* [N, num_scales * C] (forward) */
+} EmdHexArgs;
+
+typedef struct EmdHexGrads {
+    const float* dL_dout;                        /* [N, num_scales * C] */
+    float* dL_dplanes[EMD_HEX_MAX_SCALES][6];    /* channel-last like planes; ZEROED BY THE CALLER, accumulated with float atomics; may be NULL */
+    float* dL_dpts;                              /* [N,3] or NULL */
+} EmdHexGrads;
+
+int emd_hexplane_forward(const EmdHexArgs* args, void* hip_stream);
+int emd_hexplane_backward(const EmdHexArgs* args, const EmdHexGrads* grads, void* hip_stream);
 
 int emd_abi_version(void);
 const char* emd_last_error(void);

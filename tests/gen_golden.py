@@ -22,6 +22,8 @@ Fixtures (all fp32):
                     recorded too)           S3Gaussian/scene/sky_cubemap.py:41-87, gaussian_renderer/__init__.py:299-301
   s3g_loss.npz      l1_loss, ssim, compute_depth("l2"), the sky BCE and the total of train.py:226-363 with their
                     gradients w.r.t. image / depth / weight      S3Gaussian/utils/loss_utils.py:21-98, train.py:226-363
+  s3g_hexplane.npz  HexPlaneField.forward (multi-scale product of six bilinear plane lookups) with gradients w.r.t. every
+                    plane and the points           S3Gaussian/scene/hexplane.py:18-183
   or_envlight.npz   EnvLight.forward with the same stand-in                OmniRe/models/modules.py:174-208
   or_rigid.npz      RigidNodes.transform_means / transform_quats / opacity mask (+ gradients), train and
                     test-interpolation branches, non-zero track heads  OmniRe/models/nodes/rigid.py:42-46,150-246,478-615
@@ -346,6 +348,40 @@ def gen_s3g_loss():
     unload(["utils", "scene", "arguments", "gaussian_renderer"])
 
 
+def gen_s3g_hexplane():
+    sys.path.insert(0, os.path.join(REF, "S3Gaussian"))
+    with _CpuMode():
+        import importlib.util                       # scene/__init__.py pulls in CUDA-only modules; the file itself needs only torch
+        spec = importlib.util.spec_from_file_location("ref_hexplane", os.path.join(REF, "S3Gaussian", "scene", "hexplane.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        HexPlaneField = mod.HexPlaneField
+        torch.manual_seed(600)
+        cfg = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 8, "resolution": [6, 5, 7, 4]}
+        field = HexPlaneField(1.6, cfg, [1, 2])
+        field.set_aabb([2.0, 1.5, 1.0], [-1.0, -1.5, -0.5])
+        g = torch.Generator().manual_seed(601)
+        for gp in field.grids:
+            for prm in gp:
+                prm.data = torch.rand(prm.shape, generator=g) + 0.25
+        N = 300
+        pts = (torch.rand(N, 3, generator=g) * torch.tensor([3.6, 3.6, 2.0]) + torch.tensor([-1.3, -1.8, -0.75]))   # some outside the box: border
+        pts.requires_grad_(True)
+        t = torch.rand(N, 1, generator=g) * 2.4 - 1.2                                                               # some outside [-1, 1]
+        feat = field(pts, t)
+        gout = torch.randn(feat.shape, generator=g)
+        (feat * gout).sum().backward()
+        out = dict(aabb=field.aabb.data, pts=pts.data, times=t, feat=feat, gout=gout, g_pts=pts.grad, multires=np.array([1, 2]),
+                   resolution=np.array(cfg["resolution"]), channels=8)
+        for s, gp in enumerate(field.grids):
+            for p, prm in enumerate(gp):
+                out[f"plane_{s}_{p}"] = prm.data
+                out[f"g_plane_{s}_{p}"] = prm.grad
+        save("s3g_hexplane.npz", **out)
+    sys.path.pop(0)
+    unload(["utils", "scene", "arguments", "gaussian_renderer"])
+
+
 def gen_or_envlight():
     sys.path.insert(0, os.path.join(REF, "OmniRe"))
     import nvdiffrast.torch as dr
@@ -494,6 +530,7 @@ if __name__ == "__main__":
     gen_s3g_render()
     gen_s3g_sky()
     gen_s3g_loss()
+    gen_s3g_hexplane()
     print("OmniRe:")
     gen_omnire()
     gen_or_envlight()
