@@ -141,6 +141,8 @@ def main():
     from emd_amd.model import StreetGaussians, render, l1_loss
 
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("EMD_BENCH_SHARE_GPU"):        # functional test of the N > 1 path on a 1-GPU box (with EMD_DP_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)              # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local)
     rank, world, local = dp.init_from_env()

@@ -1,0 +1,33 @@
+"""-m gpu: the N > 1 path of bench.py (per-rank cameras, gradient all-reduce, barriers, max-over-ranks timing, one JSON line
+from rank 0) run as TWO ranks on the one GPU of the test box: torch.distributed.run + EMD_BENCH_SHARE_GPU=1 + the gloo backend
+(RCCL cannot put two ranks on one device).  Functional check only; the numbers mean nothing."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_two_ranks_share_one_gpu():
+    env = dict(os.environ, EMD_BENCH_SHARE_GPU="1", EMD_DP_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--gaussians", "60000", "--height", "128", "--width", "192"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]            # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["views_per_step"] == 2 and d["config"]["parallelism"] == "view-parallel dp2"
