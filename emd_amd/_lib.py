@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 TILE = 16
 ACTOR_STRIDE = 12
 BWD_STRIDE = 12
@@ -62,7 +62,8 @@ class EmdBwdArgs(C.Structure):
                 ("bwd_ws", _f), ("bwd_bytes", C.c_size_t),
                 ("dL_dmeans3D", _f), ("dL_dmeans2D", _f), ("dL_dmeans2D_abs", _f), ("dL_dshs", _f),
                 ("dL_dcolors", _f), ("dL_dopacities", _f), ("dL_dscales", _f), ("dL_drotations", _f),
-                ("dL_dcov3D", _f), ("dL_dactor_pose", _f), ("dL_dresidual_dx", _f), ("dL_dresidual_dq", _f)]
+                ("dL_dcov3D", _f), ("dL_dactor_pose", _f), ("dL_dresidual_dx", _f), ("dL_dresidual_dq", _f),
+                ("dL_dsh_color", _f)]
 
 
 SKY_CLAMP01, SKY_BLEND_S3G, SKY_BLEND_ADD, SKY_INTERLEAVED = 1, 2, 4, 8
@@ -104,7 +105,7 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_raster_backward", "emd_raster_export_binning", "emd_raster_export_geometry",
                     "emd_motion_forward", "emd_motion_backward", "emd_sh_forward", "emd_sh_backward",
                     "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward", "emd_actor_pose_forward", "emd_actor_pose_backward", "emd_l1_loss",
-                    "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss", "emd_hexplane_forward", "emd_hexplane_backward")
+                    "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss", "emd_hexplane_forward", "emd_hexplane_backward", "emd_sh_grad_from_factors")
 PROF_STAGES = 8
 
 _lib = None
@@ -151,6 +152,8 @@ def load():
     lib.emd_image_loss_workspace.argtypes = [C.c_int, C.c_int]
     lib.emd_image_loss_workspace.restype = C.c_size_t
     lib.emd_image_loss.argtypes = [C.POINTER(EmdLossArgs), C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.emd_sh_grad_from_factors.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(EmdMotion), C.c_void_p,
+                                             C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     lib.emd_hexplane_forward.argtypes = [C.POINTER(EmdHexArgs), C.c_void_p]
     lib.emd_hexplane_backward.argtypes = [C.POINTER(EmdHexArgs), C.POINTER(EmdHexGrads), C.c_void_p]
     lib.emd_sky_forward.argtypes = [C.POINTER(EmdSkyArgs), C.c_void_p]

@@ -73,6 +73,8 @@ int emd_launch_motion_backward(int n, const float* means, const float* quats, co
 int emd_launch_sh_forward(int n, int deg, int M, const float* dirs, const float* coeffs, float* rgb, hipStream_t st);
 int emd_launch_sh_backward(int n, int deg, int M, const float* dirs, const float* coeffs, const float* g_rgb,
                            float* d_coeffs, float* d_dirs, hipStream_t st);
+int emd_launch_sh_grad_from_factors(int n, int V, int deg, int M, const float* means, const EmdMotion& mo, const float* campos,
+                                    const float* gc, float scale, float* d_shs, hipStream_t st);
 int emd_launch_actor_pose_forward(int A, const float* q, const float* t, const uint8_t* valid, const float* dt, const float* dq,
                                   float* pose, hipStream_t st);
 int emd_launch_actor_pose_backward(int A, const float* q, const float* dt, const float* dq, const float* g_pose, float* d_q,
@@ -255,6 +257,7 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     pb.dL_dshs = a->dL_dshs; pb.dL_dcolors = a->dL_dcolors; pb.dL_dopacities = a->dL_dopacities;
     pb.dL_dscales = a->dL_dscales; pb.dL_drotations = a->dL_drotations; pb.dL_dcov3D = a->dL_dcov3D;
     pb.dL_dactor_pose = a->dL_dactor_pose; pb.dL_dresidual_dx = a->dL_dresidual_dx; pb.dL_dresidual_dq = a->dL_dresidual_dq;
+    pb.dL_dsh_color = a->dL_dsh_color;
     emd_prof_switch(PROF_RENDER_BWD, PROF_PREPROCESS_BWD, st);
     rc = emd_launch_preprocess_backward(pb, st);
     emd_prof_end(PROF_PREPROCESS_BWD, st);
@@ -327,6 +330,20 @@ int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* d
         emd_set_error("sh_backward: bad argument (n=%d degree=%d K=%d)", n, degree, sh_coeffs); return EMD_ERR_INVALID;
     }
     return emd_launch_sh_backward(n, degree, sh_coeffs, dirs, coeffs, dL_drgb, dL_dcoeffs, dL_ddirs, (hipStream_t)hip_stream);
+}
+
+int emd_sh_grad_from_factors(int32_t n, int32_t num_views, int32_t degree, int32_t sh_coeffs, const float* means3D,
+                             const EmdMotion* motion, const float* campos, const float* sh_color_grads, float scale,
+                             float* dL_dshs, void* hip_stream) {
+    if (n < 0 || num_views < 1 || degree < 0 || degree > 3 || sh_coeffs < (degree + 1) * (degree + 1) || sh_coeffs > 16 ||
+        (n > 0 && (!means3D || !campos || !sh_color_grads || !dL_dshs))) {
+        emd_set_error("sh_grad_from_factors: bad argument"); return EMD_ERR_INVALID;
+    }
+    EmdMotion mo;
+    memset(&mo, 0, sizeof(mo));
+    if (motion) mo = *motion;
+    return emd_launch_sh_grad_from_factors(n, num_views, degree, sh_coeffs, means3D, mo, campos, sh_color_grads, scale, dL_dshs,
+                                           (hipStream_t)hip_stream);
 }
 
 int emd_actor_pose_forward(int32_t num_actors, const float* q_f, const float* t_f, const uint8_t* valid, const float* dt,

@@ -169,6 +169,6 @@ struct PreBwdArgs {
     GeomWs g;
     const float* grad_rec;  // [N][EMD_BWD_STRIDE]
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dmeans2D_abs, *dL_dshs, *dL_dcolors, *dL_dopacities, *dL_dscales,
-        *dL_drotations, *dL_dcov3D, *dL_dactor_pose, *dL_dresidual_dx, *dL_dresidual_dq;
+        *dL_drotations, *dL_dcov3D, *dL_dactor_pose, *dL_dresidual_dx, *dL_dresidual_dq, *dL_dsh_color;
 };
 int emd_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t st);     // preprocess.hip

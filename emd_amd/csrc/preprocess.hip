@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
             q_norm = fmaxf(quat_norm(qr), 1e-12f);
             q[0] = qr[0] / q_norm; q[1] = qr[1] / q_norm; q[2] = qr[2] / q_norm; q[3] = qr[3] / q_norm;
         }
-        float gcol[3] = {0.f, 0.f, 0.f};
+        float gcol[3] = {0.f, 0.f, 0.f}, sh_gc[3] = {0.f, 0.f, 0.f};
         if (visible) {
             const float4* gr = (const float4*)(a.grad_rec + (size_t)i * EMD_BWD_STRIDE);
             const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2];
@@ -554,6 +554,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
                 float gc[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) gc[ch] = ((bits >> ch) & 1u) ? 0.f : gcol[ch];
+                sh_gc[0] = gc[0]; sh_gc[1] = gc[1]; sh_gc[2] = gc[2];
                 const int deg = S.sh_degree;
                 const int K = (deg + 1) * (deg + 1);
                 float bs[16];
@@ -678,6 +679,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
         }
         if (a.dL_dmeans2D) { a.dL_dmeans2D[3 * i] = gm2[0]; a.dL_dmeans2D[3 * i + 1] = gm2[1]; a.dL_dmeans2D[3 * i + 2] = 0.f; }
         if (a.dL_dmeans2D_abs) { a.dL_dmeans2D_abs[2 * i] = gabs[0]; a.dL_dmeans2D_abs[2 * i + 1] = gabs[1]; }
+        if (a.dL_dsh_color) { a.dL_dsh_color[3 * i] = sh_gc[0]; a.dL_dsh_color[3 * i + 1] = sh_gc[1]; a.dL_dsh_color[3 * i + 2] = sh_gc[2]; }
         if (a.dL_dcolors) { a.dL_dcolors[3 * i] = gcol[0]; a.dL_dcolors[3 * i + 1] = gcol[1]; a.dL_dcolors[3 * i + 2] = gcol[2]; }
         if (a.dL_dcov3D) {
 #pragma unroll
@@ -790,6 +792,44 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sh_backward(int n, int deg, int M
         d_dirs[3 * i + 1] = (gd[1] - d[1] * dot) / nn;
         d_dirs[3 * i + 2] = (gd[2] - d[2] * dot) / nn;
     }
+}
+
+// Dense, view-averaged SH gradient from the per-view rank-one factors (emd_sh_grad_from_factors): one Gaussian per lane,
+// rows leave through LDS as coalesced dwordx4 stores like K8's.
+__global__ void __launch_bounds__(EMD_BLOCK) k_sh_grad_from_factors(int n, int V, int deg, const float* __restrict__ means,
+                                                                    EmdMotion mo, const float* __restrict__ campos,
+                                                                    const float* __restrict__ gc, float scale,
+                                                                    float* __restrict__ d_shs) {
+    __shared__ float4 s_sh[EMD_BLOCK * SH_ROW4];
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    float acc[48];
+#pragma unroll
+    for (int k = 0; k < 48; k++) acc[k] = 0.f;
+    if (i < n) {
+        float m[3], qd[4], od;
+        if (mo.actor_id || mo.residual_dx) motion_point(i, means, nullptr, nullptr, mo, m, qd, &od, false);
+        else { m[0] = means[3 * i]; m[1] = means[3 * i + 1]; m[2] = means[3 * i + 2]; }
+        const int K = (deg + 1) * (deg + 1);
+        for (int v = 0; v < V; v++) {
+            const float* g = gc + ((size_t)v * n + i) * 3;
+            const float g0 = g[0], g1 = g[1], g2 = g[2];
+            if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;          // not visible in view v
+            float d[3] = {m[0] - campos[3 * v], m[1] - campos[3 * v + 1], m[2] - campos[3 * v + 2]};
+            const float nn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+            d[0] /= nn; d[1] /= nn; d[2] /= nn;
+            float bs[16];
+            sh_basis(deg, d, bs);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < K) { acc[3 * k] += bs[k] * g0; acc[3 * k + 1] += bs[k] * g1; acc[3 * k + 2] += bs[k] * g2; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++)
+        s_sh[threadIdx.x * SH_ROW4 + j] = make_float4(acc[4 * j] * scale, acc[4 * j + 1] * scale, acc[4 * j + 2] * scale, acc[4 * j + 3] * scale);
+    __syncthreads();
+    sh_block_store<EMD_BLOCK>(d_shs, n, s_sh);
 }
 
 __global__ void __launch_bounds__(EMD_BLOCK) k_export_geometry(int N, const float4* rec, const uint2* binrec,
@@ -972,6 +1012,16 @@ int emd_launch_sh_backward(int n, int deg, int M, const float* dirs, const float
     if (n <= 0) return EMD_OK;
     hipLaunchKernelGGL(k_sh_backward, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, deg, M, dirs,
                        coeffs, g_rgb, d_coeffs, d_dirs);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_sh_grad_from_factors(int n, int V, int deg, int M, const float* means, const EmdMotion& mo, const float* campos,
+                                    const float* gc, float scale, float* d_shs, hipStream_t st) {
+    if (n <= 0) return EMD_OK;
+    if (M != 16) { emd_set_error("sh_grad_from_factors: the staged row store needs sh_coeffs == 16"); return EMD_ERR_INVALID; }
+    hipLaunchKernelGGL(k_sh_grad_from_factors, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, V, deg, means, mo, campos,
+                       gc, scale, d_shs);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

@@ -57,6 +57,55 @@ def allreduce_gradients(params, average=True):
             g.div_(w_)
 
 
+def sh_grad_from_factors(means3D, campos, sh_color_grads, sh_degree, sh_coeffs=16, actor_ids=None, actor_pose=None, residual_dx=None,
+                         scale=1.0):
+    """dL/dshs [N,sh_coeffs,3] = scale * sum_v basis(normalize(world_mean - campos[v])) (x) sh_color_grads[v]   (one HIP launch).
+    means3D [N,3]; campos [V,3]; sh_color_grads [V,N,3] (GaussianRasterizer.last_sh_color_grad of every view)."""
+    import ctypes as C
+    from . import _lib as L
+    from .rasterizer import _fill_motion
+    if means3D.device.type != "cuda":
+        raise L.EmdError("sh_grad_from_factors needs tensors on a ROCm device; there is no CPU path")
+    N, V = means3D.shape[0], campos.shape[0]
+    means3D, campos, g = means3D.detach().contiguous().float(), campos.detach().contiguous().float(), sh_color_grads.contiguous().float()
+    assert g.shape == (V, N, 3)
+    mo = L.EmdMotion()
+    ids = None if actor_ids is None else actor_ids.to(torch.int32).contiguous()          # (kept alive until the launch is queued)
+    pose = None if actor_pose is None else actor_pose.detach().contiguous().float()
+    rdx = None if residual_dx is None else residual_dx.detach().contiguous().float()
+    _fill_motion(mo, ids, pose, rdx, None)
+    out = torch.empty(N, sh_coeffs, 3, device=means3D.device, dtype=torch.float32)
+    L.check(L.load().emd_sh_grad_from_factors(N, V, int(sh_degree), int(sh_coeffs), means3D.data_ptr(), C.byref(mo), campos.data_ptr(),
+                                              g.data_ptr(), float(scale), out.data_ptr(),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_sh_grad_from_factors")
+    return out
+
+
+def exchange_sh_gradient(sh_param, means3D, campos_local, sh_degree, actor_ids=None, actor_pose=None, residual_dx=None, average=True):
+    """View-parallel replacement of the all-reduce of the SH gradient (81 % of the gradient bytes): dL/dshs of a view is the
+    outer product of the SH basis of its view direction and a per-Gaussian colour gradient, so each rank all-gathers the
+    [N,3] factors (GaussianRasterizer.last_sh_color_grad, published by the backward when RasterConfig.factored_sh_grad is set)
+    and the camera centres -- 12 bytes per Gaussian and rank instead of 192 -- and rebuilds the same dense, averaged gradient
+    locally.  Needs the world-space means to be identical on all ranks (same timestamp), which view-parallel steps have.
+    Sets sh_param.grad."""
+    from .rasterizer import GaussianRasterizer
+    g_local = GaussianRasterizer.last_sh_color_grad
+    if g_local is None:
+        raise RuntimeError("no SH colour-gradient factor: set RasterConfig.factored_sh_grad before the backward pass")
+    W = world_size()
+    if W == 1:
+        g_all, campos = g_local[None], campos_local.reshape(1, 3).to(g_local.device)
+    else:
+        N = g_local.shape[0]
+        g_cat = torch.empty(W * N, 3, device=g_local.device, dtype=g_local.dtype)      # ranks concatenated along dim 0
+        dist.all_gather_into_tensor(g_cat, g_local.contiguous())
+        g_all = g_cat.view(W, N, 3)
+        campos = torch.empty(W, 3, device=g_local.device, dtype=torch.float32)
+        dist.all_gather_into_tensor(campos, campos_local.reshape(1, 3).to(g_local.device, torch.float32).contiguous())
+    sh_param.grad = sh_grad_from_factors(means3D, campos, g_all, sh_degree, sh_param.shape[1], actor_ids, actor_pose, residual_dx,
+                                         scale=(1.0 / W) if average else 1.0).view_as(sh_param)
+
+
 def reduce_densification_stats(grad_norm_accum, denom, max_radii2D):
     """Cross-view reduction of the per-view densification statistics (norms taken per view, before reduction)."""
     if world_size() == 1:

@@ -70,7 +70,7 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         means3D=model._xyz, means2D=screenspace_points, shs=model._features, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, raw_params=fuse_activations, **kw)
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
-            "depth": depth, "weight": weight, "normal": normal}
+            "depth": depth, "weight": weight, "normal": normal, "actor_pose": kw.get("actor_pose")}
 
 
 def raster_settings_for(cam, bg, sh_degree, scaling_modifier=1.0, debug=False):

@@ -47,6 +47,8 @@ class RasterConfig:
     min_capacity = 1 << 16
     absgrad = False           # also accumulate sum |d/d mean2D| (read from GaussianRasterizer.last_absgrad)
     clamp_rgb01 = False       # OmniRe colour clamp
+    factored_sh_grad = False  # view-parallel DP: the backward leaves dL/dshs out and publishes the [N,3] factor instead
+                              # (GaussianRasterizer.last_sh_color_grad); emd_amd.dp rebuilds the dense, view-averaged gradient
 
 
 _capacity_hint = {}
@@ -197,7 +199,9 @@ class _Rasterize(torch.autograd.Function):
         g_alpha = None if g_alpha is None else g_alpha.contiguous().float()
         g_normal = None if (g_normal is None or not (flags & L.FLAG_NORMAL)) else g_normal.contiguous().float()
         d_means3D, d_means2D = z(N, 3), z(N, 3)
-        d_shs = z(N, M, 3) if has_shs else None
+        factored = has_shs and RasterConfig.factored_sh_grad
+        d_shs = z(N, M, 3) if (has_shs and not factored) else None
+        d_shc = z(N, 3) if factored else None
         d_col = z(N, 3) if has_col else None
         d_op = z(*opacities.shape)
         d_sc = z(N, 3) if has_sr else None
@@ -228,15 +232,18 @@ class _Rasterize(torch.autograd.Function):
         b.dL_dshs, b.dL_dcolors, b.dL_dopacities = L.ptr(d_shs), L.ptr(d_col), d_op.data_ptr()
         b.dL_dscales, b.dL_drotations, b.dL_dcov3D = L.ptr(d_sc), L.ptr(d_rot), L.ptr(d_cov)
         b.dL_dactor_pose, b.dL_dresidual_dx, b.dL_dresidual_dq = L.ptr(d_pose), L.ptr(d_rdx), L.ptr(d_rdq)
+        b.dL_dsh_color = L.ptr(d_shc)
         L.check(lib.emd_raster_backward(C.byref(b), _stream()), "emd_raster_backward")
         if d_abs is not None:
             GaussianRasterizer.last_absgrad = d_abs
+        GaussianRasterizer.last_sh_color_grad = d_shc       # None unless RasterConfig.factored_sh_grad
         return (d_means3D, d_means2D, d_shs, d_col, d_op, d_sc, d_rot, d_cov, d_pose, d_rdx, d_rdq, None, None, None, None)
 
 
 class GaussianRasterizer(nn.Module):
     _last = None
     last_absgrad = None
+    last_sh_color_grad = None
 
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 8
+#define EMD_ABI_VERSION 9
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -195,6 +195,10 @@ typedef struct EmdBwdArgs {
     float* dL_dactor_pose;        /* [A, EMD_ACTOR_STRIDE], zeroed by the library */
     float* dL_dresidual_dx;       /* [N,3] */
     float* dL_dresidual_dq;       /* [N,4] */
+    float* dL_dsh_color;          /* [N,3] or NULL: the clamp-masked dL/d(SH colour) of every Gaussian (0 when not visible). With it
+                                   * dL_dshs may be NULL: dL/dshs[n][k][c] = basis_k(view direction) * dL_dsh_color[n][c] is rank one and is
+                                   * rebuilt (and summed over views) by emd_sh_grad_from_factors -- 12 bytes per Gaussian to exchange
+                                   * between GPUs instead of 192 */
 } EmdBwdArgs;
 
 /* ---- sky cube map + final blend -------------------------------------------------
@@ -321,6 +325,14 @@ int emd_sh_forward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* di
                    const float* coeffs /*[N,K,3]*/, float* rgb /*[N,3]*/, void* hip_stream);
 int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* dirs, const float* coeffs,
                     const float* dL_drgb, float* dL_dcoeffs, float* dL_ddirs /*or NULL*/, void* hip_stream);
+
+/* Dense SH-coefficient gradient from per-view factors (view-parallel data parallelism):
+ *   dL_dshs[n][k][c] = scale * sum_v basis_k(normalize(world_mean_n - campos[v])) * sh_color_grads[v][n][c]      k < (degree+1)^2
+ * with world_mean_n the mean after the explicit-motion transform (motion may be NULL: static scene).  Every rank gathers
+ * the [N,3] factors and the camera centres of all views and rebuilds the same dense, averaged gradient locally. */
+int emd_sh_grad_from_factors(int32_t n, int32_t num_views, int32_t degree, int32_t sh_coeffs, const float* means3D,
+                             const EmdMotion* motion, const float* campos /*[V,3]*/, const float* sh_color_grads /*[V,N,3]*/,
+                             float scale, float* dL_dshs /*[N,sh_coeffs,3]*/, void* hip_stream);
 
 /* Per-frame actor pose table, training branch of RigidNodes.transform_means / transform_quats
  * (OmniRe/models/nodes/rigid.py:499-503,519-532,547-566): pose[a] = (normalize(q_f[a]), t_f[a] + dt[a], valid[a],

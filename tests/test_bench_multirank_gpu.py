@@ -31,3 +31,12 @@ def test_bench_two_ranks_share_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["views_per_step"] == 2 and d["config"]["parallelism"] == "view-parallel dp2"
+
+
+def test_factored_sh_exchange_equals_dense_allreduce_two_ranks():
+    env = dict(os.environ, EMD_BENCH_SHARE_GPU="1", EMD_DP_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_factored_check.py")]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    assert any(l.startswith("OK ") for l in p.stdout.splitlines()), p.stdout[-1500:]

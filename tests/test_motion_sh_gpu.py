@@ -139,3 +139,32 @@ def test_fused_l1_loss_matches_torch():
         (out * 2.5).backward()
         torch.testing.assert_close(out, ref.detach(), rtol=2e-5, atol=1e-7)
         torch.testing.assert_close(a.grad, gref, rtol=1e-6, atol=0)
+
+
+def test_factored_sh_gradient_equals_dense_average():
+    """View-parallel SH-gradient exchange (emd_amd.dp): the dense dL/dshs of two views, averaged, equals the gradient rebuilt
+    from the two [N,3] colour-gradient factors and the two camera centres -- with the fused explicit motion in front."""
+    import numpy as np
+    import torch
+    from emd_amd import dp
+    from emd_amd.rasterizer import GaussianRasterizer, RasterConfig
+    from tests.helpers import make_case, run_hip
+    dev = torch.device("cuda", 0)
+    dense, factors, campos, case0 = [], [], [], None
+    for yaw in (0.0, 25.0):
+        case = make_case(n=3000, H=64, W=96, seed=77, motion=True, yaw=yaw)
+        case0 = case0 or case
+        dense.append(run_hip(case, backward=True)["grads"]["shs"])
+        RasterConfig.factored_sh_grad = True
+        try:
+            out = run_hip(case, backward=True)
+        finally:
+            RasterConfig.factored_sh_grad = False
+        assert out["grads"]["shs"] is None                       # the dense tensor is never written in this mode
+        factors.append(GaussianRasterizer.last_sh_color_grad.clone())
+        campos.append(torch.as_tensor(case["cam"].camera_center, dtype=torch.float32).reshape(3))
+    expect = 0.5 * (dense[0] + dense[1])
+    got = dp.sh_grad_from_factors(case0["means3D"].to(dev), torch.stack(campos).to(dev), torch.stack(factors), case0["sh_degree"], 16,
+                                  actor_ids=case0["actor_ids"].to(dev), actor_pose=case0["actor_pose"].to(dev), scale=0.5).cpu().numpy()
+    assert np.count_nonzero(expect) > 1000
+    np.testing.assert_allclose(got, expect, rtol=2e-5, atol=1e-7 * float(np.abs(expect).max()) + 1e-12)
