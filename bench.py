@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-count", action="store_true", help="read the duplicate count back every forward (reference behaviour)")
     ap.add_argument("--no-normal", action="store_true", help="skip the normal image (unused by the training loss)")
+    ap.add_argument("--factored-sh", action="store_true", help="use the multi-GPU SH-gradient factor exchange at any world size (1 GPU: measures its local cost)")
     args = ap.parse_args()
 
     from emd_amd import dp, scenes, _lib
@@ -159,15 +160,16 @@ def main():
     target = torch.rand(3, H, W, generator=g3).to(dev)
 
     RasterConfig.compute_normal = not args.no_normal
-    RasterConfig.factored_sh_grad = world > 1
+    RasterConfig.factored_sh_grad = world > 1 or args.factored_sh
     RasterConfig.no_sync = not args.sync_count
-    cams = {}
+    cams, campos_dev = {}, {}
 
     def cam_for(step):
         # frame of the 50-frame clip; rank r looks through rig camera r at that timestamp
         f, c = step % num_frames, rank % len(scenes.RIG_YAWS)
         if (f, c) not in cams:
             cams[(f, c)] = scenes.rig_camera(f, c, H, W)
+            campos_dev[(f, c)] = cams[(f, c)].camera_center.to(dev)      # once per camera: no per-step host-to-device copy
         return f, cams[(f, c)]
 
     def one_step(step):
@@ -177,17 +179,19 @@ def main():
         out = render(model, cam, bg, frame=f)
         loss = l1_loss(out["render"], target)
         loss.backward()
-        if world > 1:
+        if RasterConfig.factored_sh_grad:
             # SH gradient (81 % of the gradient bytes): exchange the rank-one factors, 12 B per Gaussian and rank instead of
             # all-reducing 192 B per Gaussian; everything else: in-place RCCL all-reduce (emd_amd/dp.py)
-            dp.exchange_sh_gradient(model._features, model._xyz, cam.camera_center, model.active_sh_degree,
-                                    actor_ids=model.actor_id if model.has_actors else None, actor_pose=out["actor_pose"])
-            dp.allreduce_gradients([p for p in params if p is not model._features])
+            dp.exchange_sh_gradient(model._features, model._xyz, campos_dev[(f, rank % len(scenes.RIG_YAWS))], model.active_sh_degree,
+                                    actor_ids=model.actor_id if model.has_actors else None, actor_pose=out["actor_pose"],
+                                    also_allreduce=params)
         return out
 
     # Size the binning workspace once, with synchronising forwards over the clip (the duplicate count D moves with
     # the ego pose and the actors); afterwards the async path never reads D back.  Overflow of any timed step is
     # checked after the timed region from the per-step device status words.
+    for s_ in range(num_frames):          # the clip's cameras are dataset state: built (and their centres uploaded) before timing
+        cam_for(s_)
     RasterConfig.no_sync = False
     out = one_step(0)
     st = GaussianRasterizer.last_status()

@@ -81,29 +81,45 @@ def sh_grad_from_factors(means3D, campos, sh_color_grads, sh_degree, sh_coeffs=1
     return out
 
 
-def exchange_sh_gradient(sh_param, means3D, campos_local, sh_degree, actor_ids=None, actor_pose=None, residual_dx=None, average=True):
+def exchange_sh_gradient(sh_param, means3D, campos_local, sh_degree, actor_ids=None, actor_pose=None, residual_dx=None, average=True,
+                         also_allreduce=None):
     """View-parallel replacement of the all-reduce of the SH gradient (81 % of the gradient bytes): dL/dshs of a view is the
     outer product of the SH basis of its view direction and a per-Gaussian colour gradient, so each rank all-gathers the
     [N,3] factors (GaussianRasterizer.last_sh_color_grad, published by the backward when RasterConfig.factored_sh_grad is set)
     and the camera centres -- 12 bytes per Gaussian and rank instead of 192 -- and rebuilds the same dense, averaged gradient
     locally.  Needs the world-space means to be identical on all ranks (same timestamp), which view-parallel steps have.
-    Sets sh_param.grad."""
+    Sets sh_param.grad.  `also_allreduce`: the other parameters; their gradients are all-reduced (averaged) in place, issued
+    right behind the gathers so that the local rebuild overlaps them."""
     from .rasterizer import GaussianRasterizer
     g_local = GaussianRasterizer.last_sh_color_grad
     if g_local is None:
         raise RuntimeError("no SH colour-gradient factor: set RasterConfig.factored_sh_grad before the backward pass")
     W = world_size()
+    works, others = [], []
     if W == 1:
         g_all, campos = g_local[None], campos_local.reshape(1, 3).to(g_local.device)
     else:
         N = g_local.shape[0]
         g_cat = torch.empty(W * N, 3, device=g_local.device, dtype=g_local.dtype)      # ranks concatenated along dim 0
-        dist.all_gather_into_tensor(g_cat, g_local.contiguous())
-        g_all = g_cat.view(W, N, 3)
         campos = torch.empty(W, 3, device=g_local.device, dtype=torch.float32)
-        dist.all_gather_into_tensor(campos, campos_local.reshape(1, 3).to(g_local.device, torch.float32).contiguous())
+        gathers = [dist.all_gather_into_tensor(g_cat, g_local.contiguous(), async_op=True),
+                   dist.all_gather_into_tensor(campos, campos_local.reshape(1, 3).to(g_local.device, torch.float32).contiguous(), async_op=True)]
+        if also_allreduce is not None:
+            others = [p.grad for p in also_allreduce if p is not sh_param and p.grad is not None]
+            others.sort(key=lambda g: -g.numel())
+            gloo = dist.get_backend() == "gloo"
+            op = dist.ReduceOp.SUM if (gloo or not average) else dist.ReduceOp.AVG
+            works = [dist.all_reduce(g, op=op, async_op=True) for g in others]
+        for w in gathers:
+            w.wait()
+        g_all = g_cat.view(W, N, 3)
     sh_param.grad = sh_grad_from_factors(means3D, campos, g_all, sh_degree, sh_param.shape[1], actor_ids, actor_pose, residual_dx,
                                          scale=(1.0 / W) if average else 1.0).view_as(sh_param)
+    for w in works:
+        w.wait()
+    if works and average and dist.get_backend() == "gloo":
+        for g in others:
+            g.div_(float(W))
 
 
 def reduce_densification_stats(grad_norm_accum, denom, max_radii2D):
