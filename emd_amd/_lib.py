@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 TILE = 16
 ACTOR_STRIDE = 12
 BWD_STRIDE = 12
@@ -105,7 +105,7 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_raster_backward", "emd_raster_export_binning", "emd_raster_export_geometry",
                     "emd_motion_forward", "emd_motion_backward", "emd_sh_forward", "emd_sh_backward",
                     "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward", "emd_actor_pose_forward", "emd_actor_pose_backward", "emd_l1_loss",
-                    "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss", "emd_hexplane_forward", "emd_hexplane_backward", "emd_sh_grad_from_factors")
+                    "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss", "emd_hexplane_forward", "emd_hexplane_backward", "emd_sh_grad_from_factors", "emd_densification_stats")
 PROF_STAGES = 8
 
 _lib = None
@@ -154,6 +154,7 @@ def load():
     lib.emd_image_loss.argtypes = [C.POINTER(EmdLossArgs), C.c_void_p, C.c_size_t, C.c_void_p]
     lib.emd_sh_grad_from_factors.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(EmdMotion), C.c_void_p,
                                              C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    lib.emd_densification_stats.argtypes = [C.c_int32] + [C.c_void_p] * 6
     lib.emd_hexplane_forward.argtypes = [C.POINTER(EmdHexArgs), C.c_void_p]
     lib.emd_hexplane_backward.argtypes = [C.POINTER(EmdHexArgs), C.POINTER(EmdHexGrads), C.c_void_p]
     lib.emd_sky_forward.argtypes = [C.POINTER(EmdSkyArgs), C.c_void_p]

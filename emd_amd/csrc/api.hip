@@ -75,6 +75,8 @@ int emd_launch_sh_backward(int n, int deg, int M, const float* dirs, const float
                            float* d_coeffs, float* d_dirs, hipStream_t st);
 int emd_launch_sh_grad_from_factors(int n, int V, int deg, int M, const float* means, const EmdMotion& mo, const float* campos,
                                     const float* gc, float scale, float* d_shs, hipStream_t st);
+int emd_launch_densification_stats(int n, const int32_t* radii, const float* g2d, float* accum, float* denom, float* max_radii,
+                                   hipStream_t st);
 int emd_launch_actor_pose_forward(int A, const float* q, const float* t, const uint8_t* valid, const float* dt, const float* dq,
                                   float* pose, hipStream_t st);
 int emd_launch_actor_pose_backward(int A, const float* q, const float* dt, const float* dq, const float* g_pose, float* d_q,
@@ -344,6 +346,12 @@ int emd_sh_grad_from_factors(int32_t n, int32_t num_views, int32_t degree, int32
     if (motion) mo = *motion;
     return emd_launch_sh_grad_from_factors(n, num_views, degree, sh_coeffs, means3D, mo, campos, sh_color_grads, scale, dL_dshs,
                                            (hipStream_t)hip_stream);
+}
+
+int emd_densification_stats(int32_t n, const int32_t* radii, const float* dL_dmeans2D, float* grad_accum, float* denom,
+                            float* max_radii2D, void* hip_stream) {
+    if (n < 0 || (n > 0 && (!radii || !dL_dmeans2D))) { emd_set_error("densification_stats: bad argument"); return EMD_ERR_INVALID; }
+    return emd_launch_densification_stats(n, radii, dL_dmeans2D, grad_accum, denom, max_radii2D, (hipStream_t)hip_stream);
 }
 
 int emd_actor_pose_forward(int32_t num_actors, const float* q_f, const float* t_f, const uint8_t* valid, const float* dt,

@@ -832,6 +832,23 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sh_grad_from_factors(int n, int V
     sh_block_store<EMD_BLOCK>(d_shs, n, s_sh);
 }
 
+// Densification statistics of one view, in place and without the boolean-mask indexing (= a device-to-host sync) of the
+// reference: for every visible Gaussian  accum += |dL/dmean2D.xy|, denom += 1, max_radii = max(max_radii, radius)
+// (S3Gaussian/scene/gaussian_model.py:728-730, train.py:403-406).
+__global__ void __launch_bounds__(EMD_BLOCK) k_densification_stats(int n, const int32_t* __restrict__ radii,
+                                                                   const float* __restrict__ g2d /*[N,3]*/,
+                                                                   float* __restrict__ accum, float* __restrict__ denom,
+                                                                   float* __restrict__ max_radii) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float gx = g2d[3 * i], gy = g2d[3 * i + 1];
+    if (accum) accum[i] += sqrtf(gx * gx + gy * gy);
+    if (denom) denom[i] += 1.f;
+    if (max_radii) max_radii[i] = fmaxf(max_radii[i], (float)r);
+}
+
 __global__ void __launch_bounds__(EMD_BLOCK) k_export_geometry(int N, const float4* rec, const uint2* binrec,
                                                                float* means2D, float* depths, float* conic_opacity,
                                                                float* rgb, float* normal, uint32_t* tiles_touched) {
@@ -1022,6 +1039,15 @@ int emd_launch_sh_grad_from_factors(int n, int V, int deg, int M, const float* m
     if (M != 16) { emd_set_error("sh_grad_from_factors: the staged row store needs sh_coeffs == 16"); return EMD_ERR_INVALID; }
     hipLaunchKernelGGL(k_sh_grad_from_factors, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, V, deg, means, mo, campos,
                        gc, scale, d_shs);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+int emd_launch_densification_stats(int n, const int32_t* radii, const float* g2d, float* accum, float* denom, float* max_radii,
+                                   hipStream_t st) {
+    if (n <= 0) return EMD_OK;
+    hipLaunchKernelGGL(k_densification_stats, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, radii, g2d, accum, denom,
+                       max_radii);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

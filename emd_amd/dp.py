@@ -131,6 +131,23 @@ def reduce_densification_stats(grad_norm_accum, denom, max_radii2D):
     dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX)
 
 
+def add_densification_stats(viewspace_points_grad, radii, xyz_gradient_accum, denom, max_radii2D):
+    """In-place update of the three per-Gaussian densification statistics for one view in ONE launch and without the
+    boolean-mask indexing of the reference (gaussian_model.py:728-730, train.py:403-406), which costs a host sync per step:
+    where radii > 0:  xyz_gradient_accum += |grad.xy|, denom += 1, max_radii2D = max(max_radii2D, radii)."""
+    import ctypes as C
+    from . import _lib as L
+    if radii.device.type != "cuda":
+        raise L.EmdError("add_densification_stats needs tensors on a ROCm device; there is no CPU path")
+    g = viewspace_points_grad.contiguous().float()
+    r = radii.contiguous().to(torch.int32)
+    for t in (xyz_gradient_accum, denom, max_radii2D):
+        assert t is None or (t.is_contiguous() and t.dtype == torch.float32 and t.numel() == r.numel())
+    L.check(L.load().emd_densification_stats(r.numel(), r.data_ptr(), g.data_ptr(), L.ptr(xyz_gradient_accum), L.ptr(denom),
+                                             L.ptr(max_radii2D), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            "emd_densification_stats")
+
+
 def densification_stats(viewspace_points_grad, radii):
     """Per-view statistics exactly as S3Gaussian/scene/gaussian_model.py:728-730 and train.py:406 compute them."""
     vis = radii > 0

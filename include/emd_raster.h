@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 9
+#define EMD_ABI_VERSION 10
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -333,6 +333,12 @@ int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* d
 int emd_sh_grad_from_factors(int32_t n, int32_t num_views, int32_t degree, int32_t sh_coeffs, const float* means3D,
                              const EmdMotion* motion, const float* campos /*[V,3]*/, const float* sh_color_grads /*[V,N,3]*/,
                              float scale, float* dL_dshs /*[N,sh_coeffs,3]*/, void* hip_stream);
+
+/* Densification statistics of one view (the per-step part): for every Gaussian with radii > 0
+ * grad_accum += |dL_dmeans2D.xy|, denom += 1, max_radii2D = max(max_radii2D, radii), in place -- gaussian_model.py:728-730 and
+ * train.py:403-406 without their boolean-mask indexing (a host sync per step).  Any of the three outputs may be NULL. */
+int emd_densification_stats(int32_t n, const int32_t* radii, const float* dL_dmeans2D /*[N,3]*/, float* grad_accum /*[N]*/,
+                            float* denom /*[N]*/, float* max_radii2D /*[N]*/, void* hip_stream);
 
 /* Per-frame actor pose table, training branch of RigidNodes.transform_means / transform_quats
  * (OmniRe/models/nodes/rigid.py:499-503,519-532,547-566): pose[a] = (normalize(q_f[a]), t_f[a] + dt[a], valid[a],

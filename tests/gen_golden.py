@@ -24,6 +24,8 @@ Fixtures (all fp32):
                     gradients w.r.t. image / depth / weight      S3Gaussian/utils/loss_utils.py:21-98, train.py:226-363
   s3g_hexplane.npz  HexPlaneField.forward (multi-scale product of six bilinear plane lookups) with gradients w.r.t. every
                     plane and the points           S3Gaussian/scene/hexplane.py:18-183
+  s3g_densify.npz   add_densification_stats + the max_radii2D update of the training loop over three views
+                                                   S3Gaussian/scene/gaussian_model.py:728-730, train.py:403-406
   or_envlight.npz   EnvLight.forward with the same stand-in                OmniRe/models/modules.py:174-208
   or_rigid.npz      RigidNodes.transform_means / transform_quats / opacity mask (+ gradients), train and
                     test-interpolation branches, non-zero track heads  OmniRe/models/nodes/rigid.py:42-46,150-246,478-615
@@ -382,6 +384,33 @@ def gen_s3g_hexplane():
     unload(["utils", "scene", "arguments", "gaussian_renderer"])
 
 
+def gen_s3g_densify():
+    sys.path.insert(0, os.path.join(REF, "S3Gaussian"))
+    sys.modules["utils.tcnn_modules"] = _Stub("utils.tcnn_modules")
+    with _CpuMode():
+        from arguments.gaussian_options import BaseOptions
+        from scene.gaussian_model import GaussianModel
+        pc = GaussianModel(BaseOptions())
+        N = 500
+        g = torch.Generator().manual_seed(700)
+        pc.xyz_gradient_accum = torch.rand(N, 1, generator=g)
+        pc.denom = torch.randint(0, 5, (N, 1), generator=g).float()
+        pc.max_radii2D = torch.randint(0, 30, (N,), generator=g).float()
+        out = dict(accum0=pc.xyz_gradient_accum.clone(), denom0=pc.denom.clone(), maxr0=pc.max_radii2D.clone())
+        for v in range(3):
+            grad = torch.randn(N, 3, generator=g) * 1e-3
+            radii = torch.randint(-1, 40, (N,), generator=g).clamp(min=0).to(torch.int32)
+            radii[torch.rand(N, generator=g) < 0.3] = 0
+            vis = radii > 0
+            pc.max_radii2D[vis] = torch.max(pc.max_radii2D[vis], radii[vis])             # train.py:405
+            pc.add_densification_stats(grad, vis)                                         # train.py:406
+            out.update({f"grad{v}": grad, f"radii{v}": radii})
+        out.update(accum=pc.xyz_gradient_accum, denom=pc.denom, maxr=pc.max_radii2D)
+        save("s3g_densify.npz", **out)
+    sys.path.pop(0)
+    unload(["utils", "scene", "arguments", "gaussian_renderer"])
+
+
 def gen_or_envlight():
     sys.path.insert(0, os.path.join(REF, "OmniRe"))
     import nvdiffrast.torch as dr
@@ -531,6 +560,7 @@ if __name__ == "__main__":
     gen_s3g_sky()
     gen_s3g_loss()
     gen_s3g_hexplane()
+    gen_s3g_densify()
     print("OmniRe:")
     gen_omnire()
     gen_or_envlight()

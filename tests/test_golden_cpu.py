@@ -158,3 +158,22 @@ def test_render_glue_matches_reference_render(stage):
         np.testing.assert_allclose(b[k].numpy(), z[f"{stage}_{k}"], rtol=1e-6, atol=1e-6, err_msg=k)
     if stage == "fine":
         assert np.abs(z["fine_means3D"] - z["coarse_means3D"]).max() > 1e-4, "the deformation must have been exercised"
+
+
+def test_densification_stats_formula_matches_reference():
+    """dp.densification_stats (the per-view statistics reduced across ranks) against the reference's add_densification_stats +
+    max_radii2D update accumulated over three views (tests/golden/s3g_densify.npz)."""
+    import os
+    import numpy as np
+    import torch
+    from emd_amd import dp
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "s3g_densify.npz"))
+    accum, denom, maxr = torch.from_numpy(g["accum0"]).clone(), torch.from_numpy(g["denom0"]).clone(), torch.from_numpy(g["maxr0"]).clone()
+    for v in range(3):
+        gn, dn, mr = dp.densification_stats(torch.from_numpy(g[f"grad{v}"]), torch.from_numpy(g[f"radii{v}"]))
+        accum += gn
+        denom += dn
+        maxr = torch.maximum(maxr, mr)
+    np.testing.assert_allclose(accum.numpy(), g["accum"], rtol=1e-6)
+    np.testing.assert_array_equal(denom.numpy(), g["denom"])
+    np.testing.assert_array_equal(maxr.numpy(), g["maxr"])

@@ -168,3 +168,22 @@ def test_factored_sh_gradient_equals_dense_average():
                                   actor_ids=case0["actor_ids"].to(dev), actor_pose=case0["actor_pose"].to(dev), scale=0.5).cpu().numpy()
     assert np.count_nonzero(expect) > 1000
     np.testing.assert_allclose(got, expect, rtol=2e-5, atol=1e-7 * float(np.abs(expect).max()) + 1e-12)
+
+
+def test_fused_densification_stats_match_reference_golden():
+    """emd_densification_stats (one launch, no boolean-mask indexing) over three views against the statistics the reference's
+    add_densification_stats / max_radii2D lines produced (tests/golden/s3g_densify.npz)."""
+    import os
+    import numpy as np
+    import torch
+    from emd_amd import dp
+    dev = torch.device("cuda", 0)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "s3g_densify.npz"))
+    accum = torch.from_numpy(g["accum0"]).to(dev).contiguous()
+    denom = torch.from_numpy(g["denom0"]).to(dev).contiguous()
+    maxr = torch.from_numpy(g["maxr0"]).to(dev).contiguous()
+    for v in range(3):
+        dp.add_densification_stats(torch.from_numpy(g[f"grad{v}"]).to(dev), torch.from_numpy(g[f"radii{v}"]).to(dev), accum, denom, maxr)
+    np.testing.assert_allclose(accum.cpu().numpy(), g["accum"], rtol=1e-6)
+    np.testing.assert_array_equal(denom.cpu().numpy(), g["denom"])
+    np.testing.assert_array_equal(maxr.cpu().numpy(), g["maxr"])
