@@ -24,19 +24,11 @@ struct RenderDims {
     float bg[3];
 };
 
-// blockIdx -> (tile, quadrant).  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one), so the
-// four quadrant waves of a tile and runs of XCD_CHUNK horizontally adjacent tiles are handed to the same XCD:
-// they read the same Gaussian records, which then stay in that XCD's L2.  Fine-grained interleave (not one band per
-// XCD) keeps the load of sky rows and ground rows spread over all XCDs.  Speed only, never correctness; the grid is
-// 4 x the tile count padded to a multiple of 8 * XCD_CHUNK and surplus workgroups exit.
+// blockIdx -> (tile, quadrant).  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one).  The tiles are
+// taken from `order` (descending list length, binning.hip) at position tl * 8 + xcd, so every XCD works through the order
+// front to back and the four quadrant waves of a tile share an XCD: they read the same Gaussian records, which stay in that
+// XCD's L2.  Speed only, never correctness; the grid is 4 x the tile count padded to a multiple of 32 and surplus workgroups exit.
 #define XCD_CHUNK 4
-__device__ __forceinline__ uint32_t xcd_quadrant_block(uint32_t b, uint32_t* quad) {
-    const uint32_t xcd = b % 8, k = b / 8, tl = k >> 2;
-    *quad = k & 3u;
-    return ((tl / XCD_CHUNK) * 8 + xcd) * XCD_CHUNK + (tl % XCD_CHUNK);
-}
-// The same with the tiles taken from `order` (descending list length, binning.hip): position tl * 8 + xcd of the order,
-// so every XCD works through the order front to back and the four quadrant waves of a tile still share an XCD.
 __device__ __forceinline__ uint32_t ordered_quadrant_block(uint32_t b, uint32_t T, const uint32_t* __restrict__ order, uint32_t* quad) {
     const uint32_t xcd = b % 8, k = b / 8, tl = k >> 2;
     *quad = k & 3u;
