@@ -1,0 +1,72 @@
+"""An S3Gaussian-style training step assembled from every HIP piece of this repository at the headline size (2 M Gaussians,
+32 actors, 1066 x 1600): fused-motion rasterizer -> sky cube map (1024^2 faces) + blend -> L1 + depth L2 + D-SSIM + sky BCE ->
+backward to all Gaussian parameters, actor poses and the cube map -> per-view densification statistics.  (The bench.py metric is
+the L1-only step of BASELINE.json; this is the same step with the reference's full loss and sky model.)  One JSON line.
+    python profiles/bench_full_step.py > profiles/r01_full_step.json"""
+import json
+import sys
+import time
+import types
+
+import torch
+
+sys.path.insert(0, ".")
+from emd_amd import dp, scenes, RasterConfig, GaussianRasterizer  # noqa: E402
+from emd_amd import rasterizer as _rz  # noqa: E402
+from emd_amd.loss import image_loss  # noqa: E402
+from emd_amd.model import StreetGaussians, render  # noqa: E402
+from emd_amd.sky import SkyCubeMap, composite_s3g  # noqa: E402
+
+dev = torch.device("cuda", 0)
+N, H, W, F = 2_000_000, 1066, 1600, 50
+scene = scenes.add_actors(scenes.make_static_scene(N, seed=0), num_actors=32, pts_per_actor=5000, num_frames=F, seed=1)
+model = StreetGaussians(scene, dev)
+params = list(model.parameters())
+sky = SkyCubeMap(types.SimpleNamespace(sky_resolution=1024, sky_white_background=False, white_background=False), device=dev)
+g = torch.Generator().manual_seed(3)
+gt = torch.rand(3, H, W, generator=g).to(dev)
+gt_depth = (torch.rand(1, H, W, generator=g) * 90).to(dev)
+sky_mask = (torch.rand(1, H, W, generator=g) < 0.2).to(dev)
+not_sky = ~sky_mask
+accum, denom, maxr = (torch.zeros(N, device=dev) for _ in range(3))
+cams, skycams = {}, {}
+for f in range(F):
+    cam = scenes.rig_camera(f, 0, H, W)
+    K = torch.tensor([[W / (2 * cam.tanfovx), 0, W / 2], [0, H / (2 * cam.tanfovy), H / 2], [0, 0, 1]], dtype=torch.float32)
+    cams[f] = cam
+    skycams[f] = types.SimpleNamespace(image_height=H, image_width=W, intrinsic=K.to(dev), world_view_transform=cam.world_view_transform.to(dev))
+bg = torch.zeros(3)
+
+
+def step(s):
+    f = s % F
+    for p in params:
+        p.grad = None
+    sky.sky_cube_map.grad = None
+    out = render(model, cams[f], bg, frame=f)
+    image, _ = composite_s3g(sky, skycams[f], out["render"], out["weight"])
+    loss, _ = image_loss(image, gt, out["depth"], gt_depth, not_sky, out["weight"], sky_mask)
+    loss.backward()
+    dp.add_densification_stats(out["viewspace_points"].grad, out["radii"], accum, denom, maxr)
+
+
+RasterConfig.no_sync = False
+dmax = 0
+for f in range(0, F, 7):
+    with torch.no_grad():
+        render(model, cams[f], bg, frame=f)
+    dmax = max(dmax, GaussianRasterizer.last_status()["num_rendered"])
+_rz._capacity_hint[(dev.index, H, W)] = int(dmax * 1.3) + 1024
+RasterConfig.no_sync = True
+for s in range(10):
+    step(s)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+K_STEPS = 50
+for s in range(K_STEPS):
+    step(10 + s)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(json.dumps({"op": "S3G-style step: raster (fused motion) + sky cube map + blend + L1/depth/D-SSIM/sky-BCE + backward + densification stats",
+                  "gaussians": N, "height": H, "width": W, "steps": K_STEPS, "ms_per_step": round(dt / K_STEPS * 1e3, 4),
+                  "iters_per_s": round(K_STEPS / dt, 1)}))
