@@ -7,7 +7,7 @@
 // backward, with a dozen image-sized temporaries; here:
 //   k_loss_pointwise   one pass over the pixels: L1 term and its gradient, depth term (valid mask, clamp, squared error,
 //                      valid count; gradient left un-normalised), sky BCE term and gradient; block sums -> 5 atomics
-//   k_ssim_forward     16x16 output tile per workgroup and channel: 26x26 halo of both images in LDS (zero padding),
+//   k_ssim_forward     32x32 output tile per workgroup and channel: 42x42 halo of both images in LDS (zero padding),
 //                      separable 11-tap Gaussian (horizontal then vertical, in LDS) of x, y, x^2, y^2, xy; SSIM map value
 //                      summed; the three partial derivatives d map / d mu1, d sigma1^2, d sigma12 stored for the backward
 //   k_ssim_backward    same tiling: dL/dx = conv(dmu1) + 2 x conv(dsigma1^2) + y conv(dsigma12), scaled by
@@ -26,8 +26,9 @@ namespace {
 #define SUM_SLOTS 64
 #define SUM_AT(q) ((q) * SUM_SLOTS)
 #define SS_R 5                       // window radius (11 taps)
-#define SS_T 16                      // output tile
-#define SS_H (SS_T + 2 * SS_R)       // 26
+#define SS_T 32                      // output tile: 32 x 32 pixels per 256-thread workgroup, 4 vertically adjacent outputs per thread
+#define SS_H (SS_T + 2 * SS_R)       // 42
+#define SS_V 4                       // (the vertical pass shares 14 of its 4 x 11 window reads between the four outputs)
 
 struct Win { float w[11]; };
 
@@ -127,32 +128,49 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_ssim_forward(EmdLossArgs a, Win w
         hz[0][ly][lx] = m1; hz[1][ly][lx] = m2; hz[2][ly][lx] = xx; hz[3][ly][lx] = yy; hz[4][ly][lx] = xy;
     }
     __syncthreads();
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int x = x0 + lx, y = y0 + ly;
+    const int lx = threadIdx.x & 31, lyb = (threadIdx.x >> 5) * SS_V;
+    const int x = x0 + lx;
     float val = 0.f;
-    if (x < W && y < H) {
-        float mu1 = 0.f, mu2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+    float acc[SS_V][5];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = win.w[k];
-            mu1 += w * hz[0][ly + k][lx]; mu2 += w * hz[1][ly + k][lx]; xx += w * hz[2][ly + k][lx];
-            yy += w * hz[3][ly + k][lx]; xy += w * hz[4][ly + k][lx];
+    for (int j = 0; j < SS_V; j++)
+#pragma unroll
+        for (int m = 0; m < 5; m++) acc[j][m] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 10 + SS_V; r++) {          // input row lyb + r feeds output j with tap r - j
+        float v[5];
+#pragma unroll
+        for (int m = 0; m < 5; m++) v[m] = hz[m][lyb + r][lx];
+#pragma unroll
+        for (int j = 0; j < SS_V; j++) {
+            if (r - j >= 0 && r - j < 11) {
+                const float w = win.w[r - j];
+#pragma unroll
+                for (int m = 0; m < 5; m++) acc[j][m] += w * v[m];
+            }
         }
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = xx - mu1s, s2 = yy - mu2s, s12 = xy - mu12;
-        const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1s + mu2s + C1, D = s1 + s2 + C2;
-        val = (A * B) / (Cc * D);
-        if (dmaps) {
-            // d map / d mu1 (through mu1^2, mu1 mu2 everywhere they occur), d map / d sigma1^2, d map / d sigma12
-            const float dm_dmu1 = (mu2 * 2.f * B) / (Cc * D) - (mu2 * 2.f * A) / (Cc * D) - (mu1 * 2.f * A * B) / (Cc * Cc * D) +
-                                  (mu1 * 2.f * A * B) / (Cc * D * D);
-            const float dm_ds1 = -(A * B) / (Cc * D * D);
-            const float dm_ds12 = (2.f * A) / (Cc * D);
-            const size_t q = (size_t)y * W + x;
-            dmaps[(0 * 3 + c) * HW + q] = dm_dmu1;
-            dmaps[(1 * 3 + c) * HW + q] = dm_ds1;
-            dmaps[(2 * 3 + c) * HW + q] = dm_ds12;
+    }
+#pragma unroll
+    for (int j = 0; j < SS_V; j++) {
+        const int y = y0 + lyb + j;
+        if (x < W && y < H) {
+            const float mu1 = acc[j][0], mu2 = acc[j][1], xx = acc[j][2], yy = acc[j][3], xy = acc[j][4];
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = xx - mu1s, s2 = yy - mu2s, s12 = xy - mu12;
+            const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1s + mu2s + C1, D = s1 + s2 + C2;
+            val += (A * B) / (Cc * D);
+            if (dmaps) {
+                // d map / d mu1 (through mu1^2, mu1 mu2 everywhere they occur), d map / d sigma1^2, d map / d sigma12
+                const float dm_dmu1 = (mu2 * 2.f * B) / (Cc * D) - (mu2 * 2.f * A) / (Cc * D) - (mu1 * 2.f * A * B) / (Cc * Cc * D) +
+                                      (mu1 * 2.f * A * B) / (Cc * D * D);
+                const float dm_ds1 = -(A * B) / (Cc * D * D);
+                const float dm_ds12 = (2.f * A) / (Cc * D);
+                const size_t q = (size_t)y * W + x;
+                dmaps[(0 * 3 + c) * HW + q] = dm_dmu1;
+                dmaps[(1 * 3 + c) * HW + q] = dm_ds1;
+                dmaps[(2 * 3 + c) * HW + q] = dm_ds12;
+            }
         }
     }
     val = block_sum(val, s4);
@@ -182,19 +200,30 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_ssim_backward(EmdLossArgs a, Win 
         hz[0][ly][lx] = t0; hz[1][ly][lx] = t1; hz[2][ly][lx] = t2;
     }
     __syncthreads();
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int x = x0 + lx, y = y0 + ly;
-    if (x < W && y < H) {
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    const int lx = threadIdx.x & 31, lyb = (threadIdx.x >> 5) * SS_V;
+    const int x = x0 + lx;
+    float acc[SS_V][3];
 #pragma unroll
-        for (int k = 0; k < 11; k++) { const float w = win.w[k]; t0 += w * hz[0][ly + k][lx]; t1 += w * hz[1][ly + k][lx]; t2 += w * hz[2][ly + k][lx]; }
-        const size_t q = (size_t)y * W + x;
-        const float xv = a.image[c * HW + q], yv = a.gt[c * HW + q];
-        const float scale = -a.lambda_dssim / (float)(3 * HW);          // d (lambda (1 - mean map)) / d map
-        if (a.dL_dimage) a.dL_dimage[c * HW + q] += scale * (t0 + 2.f * xv * t1 + yv * t2);
-        if (c == 0 && a.dL_ddepth && a.depth && a.gt_depth && a.lambda_depth != 0.f) {
-            const float cnt = s_cnt;
-            a.dL_ddepth[q] = cnt > 0.f ? a.dL_ddepth[q] * (a.lambda_depth / cnt) : 0.f;
+    for (int j = 0; j < SS_V; j++) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 10 + SS_V; r++) {
+        const float v0 = hz[0][lyb + r][lx], v1 = hz[1][lyb + r][lx], v2 = hz[2][lyb + r][lx];
+#pragma unroll
+        for (int j = 0; j < SS_V; j++) {
+            if (r - j >= 0 && r - j < 11) { const float w = win.w[r - j]; acc[j][0] += w * v0; acc[j][1] += w * v1; acc[j][2] += w * v2; }
+        }
+    }
+    const float scale = -a.lambda_dssim / (float)(3 * HW);          // d (lambda (1 - mean map)) / d map
+    const float cnt = s_cnt;
+#pragma unroll
+    for (int j = 0; j < SS_V; j++) {
+        const int y = y0 + lyb + j;
+        if (x < W && y < H) {
+            const size_t q = (size_t)y * W + x;
+            const float xv = a.image[c * HW + q], yv = a.gt[c * HW + q];
+            if (a.dL_dimage) a.dL_dimage[c * HW + q] += scale * (acc[j][0] + 2.f * xv * acc[j][1] + yv * acc[j][2]);
+            if (c == 0 && a.dL_ddepth && a.depth && a.gt_depth && a.lambda_depth != 0.f)
+                a.dL_ddepth[q] = cnt > 0.f ? a.dL_ddepth[q] * (a.lambda_depth / cnt) : 0.f;
         }
     }
 }
