@@ -65,25 +65,33 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32
 // Single workgroup: inclusive scan of the per-block tile counts in place, D / overflow / V into the status word, and for
 // every 2048-slot output block of the duplicate kernel the block of Gaussians that holds its first slot.
 #define DUP_SLOTS EMD_SORT_TILE
-__global__ void __launch_bounds__(EMD_BLOCK) k_scan_publish(uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ block_vis,
-                                                            uint32_t nb, uint64_t capacity, EmdStatus* __restrict__ status,
-                                                            uint32_t* __restrict__ slot_start, uint32_t n_slot_blocks) {
-    __shared__ uint32_t s[4];
+#define PUB_THREADS 1024
+#define PUB_ITEMS 8
+__global__ void __launch_bounds__(PUB_THREADS) k_scan_publish(uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ block_vis,
+                                                              uint32_t nb, uint64_t capacity, EmdStatus* __restrict__ status,
+                                                              uint32_t* __restrict__ slot_start, uint32_t n_slot_blocks) {
+    // 1024 threads x 8 values: the 7812 block totals of a 2 M scene are ONE trip (the 256-thread version walked them in 8
+    // dependent trips of load -> scan -> store, 15 us on the critical path of every forward)
+    __shared__ uint32_t s_w[PUB_THREADS / 64];
     uint32_t carry = 0, vis = 0;
-    for (uint32_t base = 0; base < nb; base += SCAN_TILE) {
-        const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
-        uint32_t v[SCAN_ITEMS], sum = 0;
+    for (uint32_t base = 0; base < nb; base += PUB_THREADS * PUB_ITEMS) {
+        const uint32_t i0 = base + threadIdx.x * PUB_ITEMS;
+        uint32_t v[PUB_ITEMS], sum = 0;
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; k++) {
+        for (int k = 0; k < PUB_ITEMS; k++) {
             v[k] = (i0 + k < nb) ? block_sums[i0 + k] : 0u;
             vis += (i0 + k < nb) ? block_vis[i0 + k] : 0u;
             sum += v[k];
         }
-        uint32_t total;
-        const uint32_t inc = block_scan_add_u32(sum, s, &total);
-        uint32_t run = carry + inc - sum;
+        const uint32_t inc = wave_scan_add_u32(sum);
+        __syncthreads();                                   // s_w free again (previous trip)
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+        for (uint32_t w = 0; w < PUB_THREADS / 64; w++) { const uint32_t t = s_w[w]; if (w < (threadIdx.x >> 6)) wbase += t; total += t; }
+        uint32_t run = carry + wbase + inc - sum;
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; k++) {
+        for (int k = 0; k < PUB_ITEMS; k++) {
             const uint32_t excl = run;
             run += v[k];
             if (i0 + k < nb) {
@@ -95,9 +103,14 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_scan_publish(uint32_t* __restrict
         }
         carry += total;
     }
-    uint32_t vtot;
-    block_scan_add_u32(vis, s, &vtot);
+    // visible count: wave sums, then the 16 partials
+    const uint32_t vinc = wave_scan_add_u32(vis);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = vinc;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        uint32_t vtot = 0;
+        for (uint32_t w = 0; w < PUB_THREADS / 64; w++) vtot += s_w[w];
         status->num_rendered = carry;
         status->overflow = ((uint64_t)carry > capacity) ? 1u : 0u;
         status->num_visible = vtot;
@@ -409,7 +422,7 @@ int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs
             hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, depth_sorted, perm, g.binrec, g.rect_s, g.cnt_s,
                                g.block_sums, g.block_vis, b.ranges, 0u);
             EMD_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(EMD_BLOCK), 0, st, g.block_sums, g.block_vis, (uint32_t)nb,
+            hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(PUB_THREADS), 0, st, g.block_sums, g.block_vis, (uint32_t)nb,
                                (uint64_t)(capacity > 0 ? capacity : 0), status, b.slot_start, 0u);
             EMD_LAUNCH_CHECK();
         }
@@ -422,7 +435,7 @@ int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs
     hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, depth_sorted, perm, g.binrec, g.rect_s, g.cnt_s,
                        g.block_sums, g.block_vis, b.ranges, (uint32_t)(2 * T));
     EMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(EMD_BLOCK), 0, st, g.block_sums, g.block_vis, (uint32_t)nb, (uint64_t)capacity,
+    hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(PUB_THREADS), 0, st, g.block_sums, g.block_vis, (uint32_t)nb, (uint64_t)capacity,
                        status, b.slot_start, nslot);
     EMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_duplicate, dim3(nslot), dim3(EMD_BLOCK), 0, st, N, gx, g.rect_s, g.cnt_s, perm, g.block_sums, b.slot_start,
