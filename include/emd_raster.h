@@ -201,6 +201,91 @@ typedef struct EmdBwdArgs {
                                    * between GPUs instead of 192 */
 } EmdBwdArgs;
 
+int emd_abi_version(void);
+const char* emd_last_error(void);
+
+/* out[0..3] = bytes of geom_ws, bin_ws, img_ws, bwd_ws */
+int emd_raster_workspace_size(const EmdDims* dims, size_t out[4]);
+
+int emd_raster_forward(EmdFwdArgs* args, void* hip_stream);
+int emd_raster_backward(const EmdBwdArgs* args, void* hip_stream);
+
+/* Copy binning state out for parity tests: sorted keys (tile<<32 | depth bits), sorted Gaussian ids,
+ * per-tile [start,end) ranges.  Any output may be NULL.  keys/ids hold num_rendered entries.
+ * The sort itself moves (tile id, Gaussian id) pairs of Gaussians pre-ordered by depth; the 64-bit keys of the
+ * reference are rebuilt here from the tile id and the depth bits kept per Gaussian in geom_ws. */
+int emd_raster_export_binning(const EmdDims* dims, const void* geom_ws, size_t geom_bytes, const void* bin_ws, size_t bin_bytes,
+                              int64_t num_rendered, uint64_t* keys, uint32_t* ids, uint32_t* ranges /*[T,2]*/,
+                              void* hip_stream);
+
+/* Copy per-Gaussian projection state out for parity tests.  Any output may be NULL. */
+int emd_raster_export_geometry(const EmdDims* dims, const void* geom_ws, size_t geom_bytes,
+                               float* means2D /*[N,2]*/, float* depths /*[N]*/, float* conic_opacity /*[N,4]*/,
+                               float* rgb /*[N,3]*/, float* normal /*[N,3]*/, uint32_t* tiles_touched /*[N]*/,
+                               void* hip_stream);
+
+/* Stand-alone explicit-motion transform (same arithmetic as the fused path):
+ *   world_mean = R(q_mean[a]) (mean + dx) + trans[a];  world_quat = q_rot[a] (x) normalize(quat + dq);
+ *   opacity_out = opacity * valid[a].  Outputs may be NULL. */
+int emd_motion_forward(int32_t n, const float* means, const float* quats, const float* opacities,
+                       const EmdMotion* motion, float* world_means, float* world_quats, float* opacities_out,
+                       void* hip_stream);
+int emd_motion_backward(int32_t n, const float* means, const float* quats, const float* opacities,
+                        const EmdMotion* motion, const float* dL_dworld_means, const float* dL_dworld_quats,
+                        const float* dL_dopacities_out, float* dL_dmeans, float* dL_dquats, float* dL_dopacities,
+                        float* dL_dactor_pose /*[A,12] zeroed here*/, float* dL_dresidual_dx, float* dL_dresidual_dq,
+                        void* hip_stream);
+
+/* Spherical harmonics colour (no +0.5, no clamp): rgb = SH_deg(dirs / |dirs|) . coeffs */
+int emd_sh_forward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* dirs /*[N,3]*/,
+                   const float* coeffs /*[N,K,3]*/, float* rgb /*[N,3]*/, void* hip_stream);
+int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* dirs, const float* coeffs,
+                    const float* dL_drgb, float* dL_dcoeffs, float* dL_ddirs /*or NULL*/, void* hip_stream);
+
+/* Dense SH-coefficient gradient from per-view factors (view-parallel data parallelism):
+ *   dL_dshs[n][k][c] = scale * sum_v basis_k(normalize(world_mean_n - campos[v])) * sh_color_grads[v][n][c]      k < (degree+1)^2
+ * with world_mean_n the mean after the explicit-motion transform (motion may be NULL: static scene).  Every rank gathers
+ * the [N,3] factors and the camera centres of all views and rebuilds the same dense, averaged gradient locally. */
+int emd_sh_grad_from_factors(int32_t n, int32_t num_views, int32_t degree, int32_t sh_coeffs, const float* means3D,
+                             const EmdMotion* motion, const float* campos /*[V,3]*/, const float* sh_color_grads /*[V,N,3]*/,
+                             float scale, float* dL_dshs /*[N,sh_coeffs,3]*/, void* hip_stream);
+
+/* Densification statistics of one view (SURVEY.md 8f rank 4, the per-step part): for every Gaussian with radii > 0
+ * grad_accum += |dL_dmeans2D.xy|, denom += 1, max_radii2D = max(max_radii2D, radii), in place -- gaussian_model.py:728-730 and
+ * train.py:403-406 without their boolean-mask indexing (a host sync per step).  Any of the three outputs may be NULL. */
+int emd_densification_stats(int32_t n, const int32_t* radii, const float* dL_dmeans2D /*[N,3]*/, float* grad_accum /*[N]*/,
+                            float* denom /*[N]*/, float* max_radii2D /*[N]*/, void* hip_stream);
+
+/* Per-frame actor pose table, training branch of RigidNodes.transform_means / transform_quats
+ * (OmniRe/models/nodes/rigid.py:499-503,519-532,547-566): pose[a] = (normalize(q_f[a]), t_f[a] + dt[a], valid[a],
+ * normalize(q_f[a] (x) dq[a])).  q_f [A,4] raw pose quaternions of the frame, t_f [A,3], valid [A] bytes or NULL,
+ * dt [A,3] / dq [A,4] learned track offsets or NULL (NaN rows are skipped as the reference does). */
+int emd_actor_pose_forward(int32_t num_actors, const float* q_f, const float* t_f, const uint8_t* valid, const float* dt,
+                           const float* dq, float* pose /*[A,12]*/, void* hip_stream);
+int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* dt, const float* dq, const float* dL_dpose,
+                            float* dL_dq_f, float* dL_dt_f, float* dL_ddt /*or NULL*/, float* dL_ddq /*or NULL*/,
+                            void* hip_stream);
+
+/* L1 photometric loss of the training step (S3Gaussian/utils/loss_utils.py:21-22, train.py:226):
+ * loss[0] = mean |a - b| over n elements, grad[i] = sign(a[i] - b[i]) / n (grad may be NULL).  One launch. */
+int emd_l1_loss(int64_t n, const float* a, const float* b, float* loss /*[1]*/, float* grad /*[n] or NULL*/, void* hip_stream);
+
+/* The activations exactly as EMD_FLAG_RAW_PARAMS applies them (exp, F.normalize, sigmoid); any pair may be NULL. */
+int emd_activations_forward(int32_t n, const float* log_scales, float* scales, const float* raw_quats, float* quats,
+                            const float* opacity_logits, float* opacities, void* hip_stream);
+
+/* Per-stage device timing with HIP events recorded on the caller's stream around each stage (bench.py's roofline
+ * leg).  Stages: see emd_profile_stage_name().  emd_profile_read synchronises on the recorded events, adds the
+ * elapsed milliseconds and launch counts per stage into ms[]/count[] (up to max_stages entries) and clears the
+ * recorded events; returns the number of stages. */
+#define EMD_PROF_STAGES 8
+int emd_profile_enable(int on);
+int emd_profile_read(double* ms, int64_t* count, int max_stages);
+const char* emd_profile_stage_name(int stage);
+
+
+/* ==== widening rows of the scope table, each behind the reference's own module surface ==== */
+
 /* ---- sky cube map + final blend -------------------------------------------------
  * Replaces S3Gaussian/scene/sky_cubemap.py:41-87 (SkyCubeMap.forward: get_rays_torch, mask, nvdiffrast dr.texture
  * 'linear'/'cube', clamp) with the blend of gaussian_renderer/__init__.py:299-301, and OmniRe/models/modules.py:174-208
@@ -284,88 +369,6 @@ typedef struct EmdHexGrads {
 
 int emd_hexplane_forward(const EmdHexArgs* args, void* hip_stream);
 int emd_hexplane_backward(const EmdHexArgs* args, const EmdHexGrads* grads, void* hip_stream);
-
-int emd_abi_version(void);
-const char* emd_last_error(void);
-
-/* out[0..3] = bytes of geom_ws, bin_ws, img_ws, bwd_ws */
-int emd_raster_workspace_size(const EmdDims* dims, size_t out[4]);
-
-int emd_raster_forward(EmdFwdArgs* args, void* hip_stream);
-int emd_raster_backward(const EmdBwdArgs* args, void* hip_stream);
-
-/* Copy binning state out for parity tests: sorted keys (tile<<32 | depth bits), sorted Gaussian ids,
- * per-tile [start,end) ranges.  Any output may be NULL.  keys/ids hold num_rendered entries.
- * The sort itself moves (tile id, Gaussian id) pairs of Gaussians pre-ordered by depth; the 64-bit keys of the
- * reference are rebuilt here from the tile id and the depth bits kept per Gaussian in geom_ws. */
-int emd_raster_export_binning(const EmdDims* dims, const void* geom_ws, size_t geom_bytes, const void* bin_ws, size_t bin_bytes,
-                              int64_t num_rendered, uint64_t* keys, uint32_t* ids, uint32_t* ranges /*[T,2]*/,
-                              void* hip_stream);
-
-/* Copy per-Gaussian projection state out for parity tests.  Any output may be NULL. */
-int emd_raster_export_geometry(const EmdDims* dims, const void* geom_ws, size_t geom_bytes,
-                               float* means2D /*[N,2]*/, float* depths /*[N]*/, float* conic_opacity /*[N,4]*/,
-                               float* rgb /*[N,3]*/, float* normal /*[N,3]*/, uint32_t* tiles_touched /*[N]*/,
-                               void* hip_stream);
-
-/* Stand-alone explicit-motion transform (same arithmetic as the fused path):
- *   world_mean = R(q_mean[a]) (mean + dx) + trans[a];  world_quat = q_rot[a] (x) normalize(quat + dq);
- *   opacity_out = opacity * valid[a].  Outputs may be NULL. */
-int emd_motion_forward(int32_t n, const float* means, const float* quats, const float* opacities,
-                       const EmdMotion* motion, float* world_means, float* world_quats, float* opacities_out,
-                       void* hip_stream);
-int emd_motion_backward(int32_t n, const float* means, const float* quats, const float* opacities,
-                        const EmdMotion* motion, const float* dL_dworld_means, const float* dL_dworld_quats,
-                        const float* dL_dopacities_out, float* dL_dmeans, float* dL_dquats, float* dL_dopacities,
-                        float* dL_dactor_pose /*[A,12] zeroed here*/, float* dL_dresidual_dx, float* dL_dresidual_dq,
-                        void* hip_stream);
-
-/* Spherical harmonics colour (no +0.5, no clamp): rgb = SH_deg(dirs / |dirs|) . coeffs */
-int emd_sh_forward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* dirs /*[N,3]*/,
-                   const float* coeffs /*[N,K,3]*/, float* rgb /*[N,3]*/, void* hip_stream);
-int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* dirs, const float* coeffs,
-                    const float* dL_drgb, float* dL_dcoeffs, float* dL_ddirs /*or NULL*/, void* hip_stream);
-
-/* Dense SH-coefficient gradient from per-view factors (view-parallel data parallelism):
- *   dL_dshs[n][k][c] = scale * sum_v basis_k(normalize(world_mean_n - campos[v])) * sh_color_grads[v][n][c]      k < (degree+1)^2
- * with world_mean_n the mean after the explicit-motion transform (motion may be NULL: static scene).  Every rank gathers
- * the [N,3] factors and the camera centres of all views and rebuilds the same dense, averaged gradient locally. */
-int emd_sh_grad_from_factors(int32_t n, int32_t num_views, int32_t degree, int32_t sh_coeffs, const float* means3D,
-                             const EmdMotion* motion, const float* campos /*[V,3]*/, const float* sh_color_grads /*[V,N,3]*/,
-                             float scale, float* dL_dshs /*[N,sh_coeffs,3]*/, void* hip_stream);
-
-/* Densification statistics of one view (SURVEY.md 8f rank 4, the per-step part): for every Gaussian with radii > 0
- * grad_accum += |dL_dmeans2D.xy|, denom += 1, max_radii2D = max(max_radii2D, radii), in place -- gaussian_model.py:728-730 and
- * train.py:403-406 without their boolean-mask indexing (a host sync per step).  Any of the three outputs may be NULL. */
-int emd_densification_stats(int32_t n, const int32_t* radii, const float* dL_dmeans2D /*[N,3]*/, float* grad_accum /*[N]*/,
-                            float* denom /*[N]*/, float* max_radii2D /*[N]*/, void* hip_stream);
-
-/* Per-frame actor pose table, training branch of RigidNodes.transform_means / transform_quats
- * (OmniRe/models/nodes/rigid.py:499-503,519-532,547-566): pose[a] = (normalize(q_f[a]), t_f[a] + dt[a], valid[a],
- * normalize(q_f[a] (x) dq[a])).  q_f [A,4] raw pose quaternions of the frame, t_f [A,3], valid [A] bytes or NULL,
- * dt [A,3] / dq [A,4] learned track offsets or NULL (NaN rows are skipped as the reference does). */
-int emd_actor_pose_forward(int32_t num_actors, const float* q_f, const float* t_f, const uint8_t* valid, const float* dt,
-                           const float* dq, float* pose /*[A,12]*/, void* hip_stream);
-int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* dt, const float* dq, const float* dL_dpose,
-                            float* dL_dq_f, float* dL_dt_f, float* dL_ddt /*or NULL*/, float* dL_ddq /*or NULL*/,
-                            void* hip_stream);
-
-/* L1 photometric loss of the training step (S3Gaussian/utils/loss_utils.py:21-22, train.py:226):
- * loss[0] = mean |a - b| over n elements, grad[i] = sign(a[i] - b[i]) / n (grad may be NULL).  One launch. */
-int emd_l1_loss(int64_t n, const float* a, const float* b, float* loss /*[1]*/, float* grad /*[n] or NULL*/, void* hip_stream);
-
-/* The activations exactly as EMD_FLAG_RAW_PARAMS applies them (exp, F.normalize, sigmoid); any pair may be NULL. */
-int emd_activations_forward(int32_t n, const float* log_scales, float* scales, const float* raw_quats, float* quats,
-                            const float* opacity_logits, float* opacities, void* hip_stream);
-
-/* Per-stage device timing with HIP events recorded on the caller's stream around each stage (bench.py's roofline
- * leg).  Stages: see emd_profile_stage_name().  emd_profile_read synchronises on the recorded events, adds the
- * elapsed milliseconds and launch counts per stage into ms[]/count[] (up to max_stages entries) and clears the
- * recorded events; returns the number of stages. */
-#define EMD_PROF_STAGES 8
-int emd_profile_enable(int on);
-int emd_profile_read(double* ms, int64_t* count, int max_stages);
-const char* emd_profile_stage_name(int stage);
 
 #ifdef __cplusplus
 }
