@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 TILE = 16
 ACTOR_STRIDE = 12
 BWD_STRIDE = 12
@@ -97,7 +97,13 @@ class EmdHexArgs(C.Structure):
 
 
 class EmdHexGrads(C.Structure):
-    _fields_ = [("dL_dout", _f), ("dL_dplanes", (_f * 6) * HEX_MAX_SCALES), ("dL_dpts", _f)]
+    _fields_ = [("dL_dout", _f), ("dL_dplanes", (_f * 6) * HEX_MAX_SCALES), ("dL_dpts", _f), ("dL_dtimes", _f)]
+
+
+class EmdDeformInArgs(C.Structure):
+    _fields_ = [("num_points", C.c_int32), ("num_freqs_x", C.c_int32), ("num_freqs_t", C.c_int32), ("embed_dim", C.c_int32),
+                ("ld", C.c_int32), ("reserved", C.c_int32), ("means", _f), ("point_ids", _f), ("inst_size", _f), ("inst_embed", _f),
+                ("t", _f), ("out", _f)]
 
 
 # every symbol include/emd_raster.h declares
@@ -105,7 +111,9 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_raster_backward", "emd_raster_export_binning", "emd_raster_export_geometry",
                     "emd_motion_forward", "emd_motion_backward", "emd_sh_forward", "emd_sh_backward",
                     "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward", "emd_actor_pose_forward", "emd_actor_pose_backward", "emd_l1_loss",
-                    "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss", "emd_hexplane_forward", "emd_hexplane_backward", "emd_sh_grad_from_factors", "emd_densification_stats")
+                    "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss", "emd_hexplane_forward", "emd_hexplane_backward", "emd_sh_grad_from_factors", "emd_densification_stats",
+                    "emd_temporal_embed_forward", "emd_temporal_embed_backward", "emd_deform_input_width", "emd_deform_input_forward",
+                    "emd_deform_input_backward")
 PROF_STAGES = 8
 
 _lib = None
@@ -157,6 +165,11 @@ def load():
     lib.emd_densification_stats.argtypes = [C.c_int32] + [C.c_void_p] * 6
     lib.emd_hexplane_forward.argtypes = [C.POINTER(EmdHexArgs), C.c_void_p]
     lib.emd_hexplane_backward.argtypes = [C.POINTER(EmdHexArgs), C.POINTER(EmdHexGrads), C.c_void_p]
+    lib.emd_temporal_embed_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_temporal_embed_backward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+    lib.emd_deform_input_width.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.emd_deform_input_forward.argtypes = [C.POINTER(EmdDeformInArgs), C.c_void_p]
+    lib.emd_deform_input_backward.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_sky_forward.argtypes = [C.POINTER(EmdSkyArgs), C.c_void_p]
     lib.emd_sky_backward.argtypes = [C.POINTER(EmdSkyBwdArgs), C.c_void_p]
     lib.emd_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]

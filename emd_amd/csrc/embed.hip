@@ -1,0 +1,224 @@
+// embed.hip -- the small embedding ops in front of the deformation MLPs.
+//
+//  k_temporal_embed     one row of the coarse-to-fine temporal embedding: the [rows, dim] table resized to k rows (bilinear,
+//                       align_corners) and sampled at time t (bilinear, align_corners, reflection padding), forward and
+//                       backward (table and t).  S3Gaussian/scene/deformation.py:208-221; the same construction per actor in
+//                       OmniRe/models/nodes/rigid.py:150-164.  The reference spends ~10 launches and an [N, dim] repeat on
+//                       it; the row is the same for every Gaussian, so it is computed once here and enters the first Linear
+//                       as a bias on the host side.
+//  k_deform_input       the input matrix of OmniRe's ConditionalDeformNetwork: per point the normalised position
+//                       x = mean / height(actor) * 2, its frequency encoding, the encoding of the frame time and the actor's
+//                       embedding row, written once as [N, ld] (OmniRe/models/nodes/deformable.py:35-47,
+//                       models/modules.py:318-366,430-437).  The reference builds it from 43 tensors and two concats.
+//  k_deform_input_bwd   gradient of that matrix back to the actor embedding table (positions and time are detached there).
+// Launch-latency / HBM-write bound; nothing here is reused.
+#include "common.h"
+
+namespace {
+
+// grid_sample coordinate: align_corners un-normalise, reflect over [0, size-1], clip; *mult = d(result)/d(coord)
+__device__ __forceinline__ float reflect_coord(float c, int size, float* mult) {
+    float v = ((c + 1.f) * 0.5f) * (float)(size - 1);
+    float m = 0.5f * (float)(size - 1);
+    if (size <= 1) { *mult = 0.f; return 0.f; }
+    const float span = (float)(size - 1);
+    if (v < 0.f) { v = -v; m = -m; }
+    const float extra = fmodf(v, span);
+    const int flips = (int)floorf(v / span);
+    if (flips & 1) { v = span - extra; m = -m; } else v = extra;
+    if (!(v > 0.f)) { v = 0.f; m = 0.f; }                       // clip_coordinates_set_grad
+    else if (!(v < span)) { v = span; m = 0.f; }
+    *mult = m;
+    return v;
+}
+
+// row r of the table resized to k rows (upsample_bilinear2d, align_corners): two source rows and their weights
+__device__ __forceinline__ void resized_row(int r, int k, int rows, int* h0, int* h1, float* l0, float* l1) {
+    const float scale = k > 1 ? (float)(rows - 1) / (float)(k - 1) : 0.f;
+    const float src = scale * (float)r;
+    *h0 = (int)src;
+    *h1 = *h0 + (*h0 < rows - 1 ? 1 : 0);
+    *l1 = src - (float)*h0;
+    *l0 = 1.f - *l1;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(EMD_WAVE) k_temporal_embed(const float* __restrict__ weight, int rows, int dim, int k,
+                                                              const float* __restrict__ t_ptr, float* __restrict__ out,
+                                                              const float* __restrict__ g_out, float* __restrict__ g_weight,
+                                                              float* __restrict__ g_t) {
+    // one wave per table (S3Gaussian has one; OmniRe keeps one per actor)
+    weight += (size_t)blockIdx.x * rows * dim;
+    if (out) out += (size_t)blockIdx.x * dim;
+    if (g_out) g_out += (size_t)blockIdx.x * dim;
+    if (g_weight) g_weight += (size_t)blockIdx.x * rows * dim;
+    const float t = t_ptr[0];
+    float my, mx;
+    const float iy = reflect_coord((t - 0.5f) * 2.f, k, &my);
+    const float y0f = floorf(iy);
+    const int y0 = (int)y0f, y1 = y0 + 1;
+    const float wy1 = iy - y0f, wy0 = 1.f - wy1;
+    int ha[2], hb[2];
+    float la[2], lb[2];
+    resized_row(min(y0, k - 1), k, rows, &ha[0], &hb[0], &la[0], &lb[0]);
+    resized_row(min(y1, k - 1), k, rows, &ha[1], &hb[1], &la[1], &lb[1]);
+    const bool in1 = y1 <= k - 1;                                // the row past the end contributes nothing
+    float dt_acc = 0.f;
+    for (int j = threadIdx.x; j < dim; j += EMD_WAVE) {
+        // the reference samples column j at x = (j / (dim-1) - 0.5) * 2, which un-normalises to j up to rounding
+        const float gx = dim > 1 ? ((float)j / (float)(dim - 1) - 0.5f) * 2.f : -1.f;
+        const float ix = reflect_coord(gx, dim, &mx);
+        const float x0f = floorf(ix);
+        const int x0 = (int)x0f, x1 = x0 + 1;
+        const float wx1 = ix - x0f, wx0 = 1.f - wx1;
+        const bool inx1 = x1 <= dim - 1;
+        float v[2][2];                                           // [row 0/1][col 0/1] of the resized table
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            v[r][0] = la[r] * weight[ha[r] * dim + x0] + lb[r] * weight[hb[r] * dim + x0];
+            v[r][1] = inx1 ? la[r] * weight[ha[r] * dim + x1] + lb[r] * weight[hb[r] * dim + x1] : 0.f;
+        }
+        if (!in1) v[1][0] = v[1][1] = 0.f;
+        if (!BWD) {
+            out[j] = v[0][0] * (wx0 * wy0) + v[0][1] * (wx1 * wy0) + v[1][0] * (wx0 * wy1) + v[1][1] * (wx1 * wy1);
+        } else {
+            const float g = g_out[j];
+            if (g_weight) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    if (r == 1 && !in1) continue;
+                    const float wy = r ? wy1 : wy0;
+                    atomicAdd(g_weight + ha[r] * dim + x0, g * wx0 * wy * la[r]);
+                    atomicAdd(g_weight + hb[r] * dim + x0, g * wx0 * wy * lb[r]);
+                    if (inx1) {
+                        atomicAdd(g_weight + ha[r] * dim + x1, g * wx1 * wy * la[r]);
+                        atomicAdd(g_weight + hb[r] * dim + x1, g * wx1 * wy * lb[r]);
+                    }
+                }
+            }
+            // d out / d iy = (row1 - row0) interpolated along x
+            dt_acc += g * ((v[1][0] - v[0][0]) * wx0 + (v[1][1] - v[0][1]) * wx1);
+        }
+    }
+    if (BWD && g_t) {
+        for (int off = 32; off; off >>= 1) dt_acc += __shfl_xor(dt_acc, off);
+        if (threadIdx.x == 0) atomicAdd(g_t, dt_acc * my * 2.f);   // y = (t - 0.5) * 2
+    }
+}
+
+// column c of one row of the encoder input: [x(3), {sin(x f), cos(x f)}_f (3 each), t, {sin(t f), cos(t f)}_f, embed(E)]
+__global__ void __launch_bounds__(EMD_BLOCK) k_deform_input(EmdDeformInArgs a) {
+    const int dx = 3 * (1 + 2 * a.num_freqs_x), dt = 1 + 2 * a.num_freqs_t, width = dx + dt + a.embed_dim;
+    const size_t total = (size_t)a.num_points * width;
+    for (size_t idx = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * EMD_BLOCK) {
+        const size_t n = idx / width;
+        const int c = (int)(idx - n * width);
+        const size_t id = a.point_ids ? (size_t)a.point_ids[n] : n;   // no ids: per-point rows (the network called directly)
+        float v;
+        if (c < dx) {
+            const int comp = c % 3, blk = c / 3;                 // blk 0: identity; 2f+1: sin, 2f+2: cos of frequency 2^f
+            float x = a.means[3 * n + comp];
+            if (a.inst_size) x = x / a.inst_size[3 * id + 2] * 2.f;
+            if (blk == 0) v = x;
+            else {
+                const float arg = x * (float)(1 << ((blk - 1) >> 1));
+                v = ((blk - 1) & 1) ? cosf(arg) : sinf(arg);
+            }
+        } else if (c < dx + dt) {
+            const int blk = c - dx;
+            const float t = a.t[0];
+            if (blk == 0) v = t;
+            else {
+                const float arg = t * (float)(1 << ((blk - 1) >> 1));
+                v = ((blk - 1) & 1) ? cosf(arg) : sinf(arg);
+            }
+        } else {
+            v = a.inst_embed[id * a.embed_dim + (c - dx - dt)];
+        }
+        a.out[n * a.ld + c] = v;
+    }
+}
+
+// d embed[id] += d input[n, col0 : col0+E]; points of one actor are contiguous in the reference (create_from_pcd concatenates per
+// instance), so a thread walks a chunk of points and flushes one atomic per run of equal ids
+#define DEF_CHUNK 128
+__global__ void __launch_bounds__(EMD_WAVE) k_deform_input_bwd(int n, int E, int ld, int col0, const int32_t* __restrict__ ids,
+                                                                const float* __restrict__ g_in, float* __restrict__ g_embed) {
+    const int e = threadIdx.x;
+    if (e >= E) return;
+    const int lo = blockIdx.x * DEF_CHUNK, hi = min(n, lo + DEF_CHUNK);
+    int cur = -1;
+    float acc = 0.f;
+    for (int i = lo; i < hi; i++) {
+        const int id = ids[i];
+        if (id != cur) {
+            if (cur >= 0) atomicAdd(g_embed + (size_t)cur * E + e, acc);
+            cur = id; acc = 0.f;
+        }
+        acc += g_in[(size_t)i * ld + col0 + e];
+    }
+    if (cur >= 0) atomicAdd(g_embed + (size_t)cur * E + e, acc);
+}
+
+int check_te(const float* weight, int tables, int rows, int dim, int k, const float* t, const char* who) {
+    if (!weight || !t) { emd_set_error("%s: null table / time", who); return EMD_ERR_INVALID; }
+    if (tables < 1 || rows < 1 || dim < 1 || k < 1) { emd_set_error("%s: bad sizes tables=%d rows=%d dim=%d k=%d", who, tables, rows, dim, k); return EMD_ERR_INVALID; }
+    return EMD_OK;
+}
+
+}  // namespace
+
+extern "C" int emd_temporal_embed_forward(const float* weight, int tables, int rows, int dim, int k, const float* t, float* out,
+                                          void* hip_stream) {
+    int rc = check_te(weight, tables, rows, dim, k, t, "temporal_embed_forward");
+    if (rc) return rc;
+    if (!out) { emd_set_error("temporal_embed_forward: null output"); return EMD_ERR_INVALID; }
+    hipLaunchKernelGGL(k_temporal_embed<false>, dim3(tables), dim3(EMD_WAVE), 0, (hipStream_t)hip_stream, weight, rows, dim, k, t, out,
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+extern "C" int emd_temporal_embed_backward(const float* weight, int tables, int rows, int dim, int k, const float* t,
+                                           const float* dL_dout, float* dL_dweight, float* dL_dt, void* hip_stream) {
+    int rc = check_te(weight, tables, rows, dim, k, t, "temporal_embed_backward");
+    if (rc) return rc;
+    if (!dL_dout) { emd_set_error("temporal_embed_backward: null gradient"); return EMD_ERR_INVALID; }
+    hipLaunchKernelGGL(k_temporal_embed<true>, dim3(tables), dim3(EMD_WAVE), 0, (hipStream_t)hip_stream, weight, rows, dim, k, t,
+                       (float*)nullptr, dL_dout, dL_dweight, dL_dt);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+extern "C" int emd_deform_input_width(int num_freqs_x, int num_freqs_t, int embed_dim) {
+    return 3 * (1 + 2 * num_freqs_x) + (1 + 2 * num_freqs_t) + embed_dim;
+}
+
+extern "C" int emd_deform_input_forward(const EmdDeformInArgs* a, void* hip_stream) {
+    if (!a) { emd_set_error("deform_input_forward: null args"); return EMD_ERR_INVALID; }
+    const int width = emd_deform_input_width(a->num_freqs_x, a->num_freqs_t, a->embed_dim);
+    if (a->num_points < 0 || a->num_freqs_x < 0 || a->num_freqs_x > 24 || a->num_freqs_t < 0 || a->num_freqs_t > 24 || a->embed_dim < 0 ||
+        a->ld < width) { emd_set_error("deform_input_forward: bad sizes"); return EMD_ERR_INVALID; }
+    if (a->num_points == 0) return EMD_OK;
+    if (!a->means || !a->t || !a->out || (a->embed_dim > 0 && !a->inst_embed)) {
+        emd_set_error("deform_input_forward: null pointer"); return EMD_ERR_INVALID;
+    }
+    const size_t total = (size_t)a->num_points * width;
+    const unsigned blocks = (unsigned)((total + EMD_BLOCK - 1) / EMD_BLOCK < 65536 ? (total + EMD_BLOCK - 1) / EMD_BLOCK : 65536);
+    hipLaunchKernelGGL(k_deform_input, dim3(blocks), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, *a);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+extern "C" int emd_deform_input_backward(int num_points, int embed_dim, int ld, int col0, const int32_t* point_ids, const float* dL_din,
+                                         float* dL_dembed, void* hip_stream) {
+    if (num_points < 0 || embed_dim < 0 || embed_dim > EMD_WAVE || col0 < 0 || ld < col0 + embed_dim) {
+        emd_set_error("deform_input_backward: bad sizes (embed_dim <= 64)"); return EMD_ERR_INVALID;
+    }
+    if (num_points == 0 || embed_dim == 0) return EMD_OK;
+    if (!point_ids || !dL_din || !dL_dembed) { emd_set_error("deform_input_backward: null pointer"); return EMD_ERR_INVALID; }
+    hipLaunchKernelGGL(k_deform_input_bwd, dim3((unsigned)((num_points + DEF_CHUNK - 1) / DEF_CHUNK)), dim3(EMD_WAVE), 0,
+                       (hipStream_t)hip_stream, num_points, embed_dim, ld, col0, point_ids, dL_din, dL_dembed);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}

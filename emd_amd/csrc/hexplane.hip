@@ -61,7 +61,8 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrad
 #pragma unroll
     for (int k = 0; k < 3; k++) q[k] = (a.pts[3 * n + k] - a.aabb[k]) * (2.f / (a.aabb[3 + k] - a.aabb[k])) - 1.f;
     q[3] = a.times[n];
-    float dq[3] = {0.f, 0.f, 0.f};
+    float dq[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_dq = BWD && (g.dL_dpts || g.dL_dtimes);
     for (int s = 0; s < S; s++) {
         float f[6];
         Bilin t[6];
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrad
                     atomicAdd(gp + ((size_t)b.y1 * W + b.x0) * C + c, gi * ((1.f - b.fx) * b.fy));
                     atomicAdd(gp + ((size_t)b.y1 * W + b.x1) * C + c, gi * (b.fx * b.fy));
                 }
-                if (g.dL_dpts && ax < 3) {      // (the time coordinate takes no gradient)
+                if (want_dq) {
                     const float* pl = a.planes[s][p];
                     const float nw = pl[((size_t)b.y0 * W + b.x0) * C + c], ne = pl[((size_t)b.y0 * W + b.x1) * C + c];
                     const float sw = pl[((size_t)b.y1 * W + b.x0) * C + c], se = pl[((size_t)b.y1 * W + b.x1) * C + c];
@@ -108,18 +109,21 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrad
                     const float dix = (ne - nw) * (1.f - b.fy) + (se - sw) * b.fy;
                     const float diy = (sw - nw) * (1.f - b.fx) + (se - ne) * b.fx;
                     dq[ax] += gi * dix * b.cx;
-                    if (ay < 3) dq[ay] += gi * diy * b.cy;
+                    dq[ay] += gi * diy * b.cy;
                 }
             }
         }
     }
-    if (BWD && g.dL_dpts) {
-        // sum over the C channel lanes of the point, then through normalize_aabb
+    if (want_dq) {
+        // sum over the C channel lanes of the point, then through normalize_aabb (the time coordinate is used as given)
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < 4; k++) {
             float v = dq[k];
             for (int off = C >> 1; off; off >>= 1) v += __shfl_xor(v, off, C);
-            if (c == 0) g.dL_dpts[3 * n + k] = v * (2.f / (a.aabb[3 + k] - a.aabb[k]));
+            if (c == 0) {
+                if (k < 3) { if (g.dL_dpts) g.dL_dpts[3 * n + k] = v * (2.f / (a.aabb[3 + k] - a.aabb[k])); }
+                else if (g.dL_dtimes) g.dL_dtimes[n] = v;
+            }
         }
     }
 }

@@ -36,14 +36,14 @@ class _HexLookup(torch.autograd.Function):
             for p in range(6):
                 a.planes[s][p] = cl[s * 6 + p].data_ptr()
         a.pts, a.times = pts_c.data_ptr(), times_c.data_ptr()
-        ab = aabb.detach().reshape(-1).to("cpu", torch.float32).tolist()
         for k in range(6):
-            a.aabb[k] = ab[k]
+            a.aabb[k] = aabb[k]
         out = torch.empty(N, S * Cc, device=pts.device, dtype=torch.float32)
         a.out = out.data_ptr()
         L.check(lib.emd_hexplane_forward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_hexplane_forward")
         ctx.args, ctx.keep = a, (pts_c, times_c, cl)
         ctx.shapes = [tuple(p.shape) for p in planes]
+        ctx.times_shape = tuple(times.shape)
         return out
 
     @staticmethod
@@ -66,10 +66,12 @@ class _HexLookup(torch.autograd.Function):
                 off += n
         d_pts = torch.empty(a.num_points, 3, device=g_out.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         g.dL_dpts = L.ptr(d_pts)
+        d_times = torch.empty(ctx.times_shape, device=g_out.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        g.dL_dtimes = L.ptr(d_times)
         L.check(lib.emd_hexplane_backward(C.byref(a), C.byref(g), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                 "emd_hexplane_backward")
-        grads = [t.permute(2, 0, 1)[None].contiguous() for t in gcl] if need_planes else [None] * len(ctx.shapes)
-        return (d_pts, None, None, None, *grads)
+        grads = [t.permute(2, 0, 1)[None] for t in gcl] if need_planes else [None] * len(ctx.shapes)   # channel-last, like the planes
+        return (d_pts, d_times, None, None, *grads)
 
 
 def init_grid_param(grid_nd, in_dim, out_dim, reso, a=0.1, b=0.5):
@@ -77,12 +79,13 @@ def init_grid_param(grid_nd, in_dim, out_dim, reso, a=0.1, b=0.5):
     assert in_dim == len(reso) and grid_nd == 2 and in_dim == 4, "the HIP lookup implements the 4-D, plane (2-D) configuration"
     grid_coefs = nn.ParameterList()
     for coo_comb in PAIRS:
-        coef = nn.Parameter(torch.empty([1, out_dim] + [reso[cc] for cc in coo_comb[::-1]]))
+        coef = torch.empty([1, out_dim] + [reso[cc] for cc in coo_comb[::-1]])
         if 3 in coo_comb:
             nn.init.ones_(coef)            # time planes start at 1
         else:
             nn.init.uniform_(coef, a=a, b=b)
-        grid_coefs.append(coef)
+        # reference shape [1, C, res_h, res_w] and values, channel-last MEMORY: the lookup's tap rows are views, not per-step copies
+        grid_coefs.append(nn.Parameter(coef.contiguous(memory_format=torch.channels_last)))
     return grid_coefs
 
 
@@ -116,10 +119,17 @@ class HexPlaneField(nn.Module):
         aabb = torch.from_numpy(np.array([xyz_max, xyz_min], dtype=np.float32)).to(self.aabb.device)
         self.aabb = nn.Parameter(aabb, requires_grad=False)
 
+    def _aabb_host(self):
+        # six floats for the args struct; re-read from the device only when the parameter was written (set_aabb, load_state_dict)
+        key = (id(self.aabb), self.aabb._version)
+        if getattr(self, "_aabb_key", None) != key:
+            self._aabb_key, self._aabb_list = key, self.aabb.detach().reshape(-1).to("cpu", torch.float32).tolist()
+        return self._aabb_list
+
     def get_density(self, pts, timestamps=None):
         pts = pts.reshape(-1, pts.shape[-1])
         planes = [p for gp in self.grids for p in gp]
-        return _HexLookup.apply(pts, timestamps.reshape(-1, 1), self.aabb, self._res, *planes)
+        return _HexLookup.apply(pts, timestamps.reshape(-1, 1), self._aabb_host(), self._res, *planes)
 
     def forward(self, pts, timestamps=None):
         return self.get_density(pts, timestamps)

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 10
+#define EMD_ABI_VERSION 11
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -365,10 +365,44 @@ typedef struct EmdHexGrads {
     const float* dL_dout;                        /* [N, num_scales * C] */
     float* dL_dplanes[EMD_HEX_MAX_SCALES][6];    /* channel-last like planes; ZEROED BY THE CALLER, accumulated with float atomics; may be NULL */
     float* dL_dpts;                              /* [N,3] or NULL */
+    float* dL_dtimes;                            /* [N] or NULL (reaches the reference's time_offset parameter, deformation.py:325-328) */
 } EmdHexGrads;
 
 int emd_hexplane_forward(const EmdHexArgs* args, void* hip_stream);
 int emd_hexplane_backward(const EmdHexArgs* args, const EmdHexGrads* grads, void* hip_stream);
+
+/* ---- embedding ops in front of the deformation MLPs (rows a3, a12, a15) ---------------------
+ * emd_temporal_embed_*: one row of the coarse-to-fine temporal embedding -- each of the num_tables [rows, dim] tables resized
+ *   to k rows (bilinear, align_corners) and sampled at time t[0] (bilinear, align_corners, reflection padding) -> out
+ *   [num_tables, dim].  Replaces
+ *   Deformation.get_temporal_embed (S3Gaussian/scene/deformation.py:208-221) and RigidNodes.get_temporal_embed
+ *   (OmniRe/models/nodes/rigid.py:150-164).  t is a DEVICE scalar (no host sync).  The backward ACCUMULATES into dL_dweight
+ *   [rows, dim] and dL_dt [1] (either may be NULL); the caller zeroes them.
+ * emd_deform_input_*: the input matrix of OmniRe's ConditionalDeformNetwork (models/modules.py:411-457 with get_embedder
+ *   :318-366, fed by DeformableNodes.get_deformation, models/nodes/deformable.py:35-47): row n =
+ *   [x, sin(x 2^0), cos(x 2^0), ..., t, sin(t 2^0), ..., embed[id(n)]] with x = means[n] / inst_size[id(n)][2] * 2.
+ *   The backward ACCUMULATES columns [col0, col0 + embed_dim) of dL_din into dL_dembed [A, embed_dim] (positions and the time
+ *   are detached in the reference). */
+int emd_temporal_embed_forward(const float* weight, int num_tables, int rows, int dim, int k, const float* t, float* out,
+                               void* hip_stream);
+int emd_temporal_embed_backward(const float* weight, int num_tables, int rows, int dim, int k, const float* t, const float* dL_dout,
+                                float* dL_dweight, float* dL_dt, void* hip_stream);
+
+typedef struct EmdDeformInArgs {
+    int32_t num_points, num_freqs_x, num_freqs_t, embed_dim;
+    int32_t ld, reserved;                        /* row stride of out in floats (>= emd_deform_input_width) */
+    const float* means;                          /* [N,3] local means */
+    const int32_t* point_ids;                    /* [N] actor of each point; NULL: row n of inst_size / inst_embed belongs to point n */
+    const float* inst_size;                      /* [A,3] actor box sizes (height = [.,2]); NULL: means are used as given */
+    const float* inst_embed;                     /* [A, embed_dim] */
+    const float* t;                              /* device scalar: normalised time of the frame */
+    float* out;                                  /* [N, ld] */
+} EmdDeformInArgs;
+
+int emd_deform_input_width(int num_freqs_x, int num_freqs_t, int embed_dim);
+int emd_deform_input_forward(const EmdDeformInArgs* args, void* hip_stream);
+int emd_deform_input_backward(int num_points, int embed_dim, int ld, int col0, const int32_t* point_ids, const float* dL_din,
+                              float* dL_dembed, void* hip_stream);
 
 #ifdef __cplusplus
 }

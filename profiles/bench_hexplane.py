@@ -9,8 +9,25 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
+import itertools  # noqa: E402
+
+import torch.nn.functional as F  # noqa: E402
+
 from emd_amd.hexplane import HexPlaneField  # noqa: E402
-from oracle import hexplane_oracle as ho   # noqa: E402  (grid_sample formulation = what the reference runs)
+
+
+def grid_sample_formulation(pts, timestamps, aabb, planes):
+    """The lookup as the reference's PyTorch code issues it (scene/hexplane.py:18-110,150-183): per scale six F.grid_sample
+    launches, five products, then a concat -- the "what it replaces" timing."""
+    q = torch.cat(((pts - aabb[0]) * (2.0 / (aabb[1] - aabb[0])) - 1.0, timestamps), dim=-1)
+    outs = []
+    for scale in planes:
+        feat = 1.0
+        for grid, pair in zip(scale, itertools.combinations(range(4), 2)):
+            interp = F.grid_sample(grid, q[:, list(pair)].view(1, 1, -1, 2), align_corners=True, mode="bilinear", padding_mode="border")
+            feat = feat * interp.view(grid.shape[1], -1).t()
+        outs.append(feat)
+    return torch.cat(outs, dim=-1)
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 dev = torch.device("cuda", 0)
@@ -40,7 +57,7 @@ def run(fn, n):
 
 
 hip = lambda: field(pts, t)
-ref = lambda: ho.hexplane_features(pts, t, field.aabb, [[p for p in gp] for gp in field.grids])
+ref = lambda: grid_sample_formulation(pts, t, field.aabb, [[p for p in gp] for gp in field.grids])
 run(hip, 2)
 hf, hb = run(hip, 10)
 run(ref, 1)

@@ -10,8 +10,11 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
+import math  # noqa: E402
+
+import torch.nn.functional as F  # noqa: E402
+
 from emd_amd.loss import image_loss  # noqa: E402
-from oracle import loss_oracle as lo  # noqa: E402  (the reference's formulas, run on the GPU as the "what it replaces" timing)
 
 dev = torch.device("cuda", 0)
 H, W = 1066, 1600
@@ -42,34 +45,36 @@ def run(fn, n):
 hip = lambda: image_loss(image, gt, depth, gt_depth, mask, weight, sky)[0]
 
 
-def torch_ref():
-    win = lo.window_1d().to(dev)
-    lo.window_1d = lambda *a, **k: win.cpu()          # oracle builds the window on CPU; keep its formulas, move inputs
-    return lo.loss_tail(image, gt, depth, gt_depth, mask, weight, sky)[0]
+def pytorch_formulation():
+    """The same loss written with stock PyTorch ops in the order train.py:226-363 / utils/loss_utils.py:21-98 issue them
+    (the "what it replaces" timing; the window is built once, on the device)."""
+    g1 = torch.tensor([math.exp(-(x - 5) ** 2 / (2 * 1.5 ** 2)) for x in range(11)])
+    g1 = (g1 / g1.sum()).unsqueeze(1)
+    win = g1.mm(g1.t())[None, None].expand(3, 1, 11, 11).contiguous().to(dev)
+
+    def loss():
+        l1 = (image - gt).abs().mean()
+        p, q = (depth * mask).squeeze(), (gt_depth * mask).squeeze()
+        valid = (q > 0.01) & (q < 80.0)
+        ld = ((torch.clamp(p[valid] / 80.0, 0.0, 1.0) - torch.clamp(q[valid] / 80.0, 0.0, 1.0)) ** 2).mean()
+        conv = lambda t: F.conv2d(t, win, padding=5, groups=3)
+        x, y = image[None], gt[None]
+        mu1, mu2 = conv(x), conv(y)
+        s1, s2, s12 = conv(x * x) - mu1 * mu1, conv(y * y) - mu2 * mu2, conv(x * y) - mu1 * mu2
+        ssim = (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
+        w = torch.clamp(weight, min=1e-6, max=1.0 - 1e-6)
+        bce = torch.where(sky, -torch.log(1 - w), -torch.log(w)).mean()
+        return l1 + 0.5 * ld + 0.2 * (1.0 - ssim) + 0.05 * bce
+    return loss
 
 
 run(hip, 5)
 t_hip = run(hip, 50)
 try:
-    import oracle.loss_oracle as _lo
-    _orig = _lo.ssim
-
-    def ssim_dev(a, b, size=11):
-        C = a.shape[-3]
-        w1 = _lo.window_1d(size).unsqueeze(1)
-        win = w1.mm(w1.t()).float()[None, None].expand(C, 1, size, size).contiguous().to(a.device)
-        import torch.nn.functional as F
-        x, y = a[None], b[None]
-        conv = lambda t: F.conv2d(t, win, padding=size // 2, groups=C)
-        mu1, mu2 = conv(x), conv(y)
-        s1, s2, s12 = conv(x * x) - mu1 * mu1, conv(y * y) - mu2 * mu2, conv(x * y) - mu1 * mu2
-        m = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
-        return m.mean()
-    _lo.ssim = ssim_dev
-    ref = lambda: _lo.loss_tail(image, gt, depth, gt_depth, mask, weight, sky)[0]
+    ref = pytorch_formulation()
     run(ref, 3)
     t_ref = run(ref, 10)
-except Exception as e:      # MIOpen may not serve the grouped 11x11 convolution
+except Exception:      # MIOpen may not serve the grouped 11x11 convolution
     t_ref = None
 P = H * W
 print(json.dumps({"op": "image-loss tail: L1 + depth L2 + D-SSIM 11x11 + sky BCE, values and all gradients (autograd glue included)",

@@ -26,6 +26,10 @@ Fixtures (all fp32):
                     plane and the points           S3Gaussian/scene/hexplane.py:18-183
   s3g_densify.npz   add_densification_stats + the max_radii2D update of the training loop over three views
                                                    S3Gaussian/scene/gaussian_model.py:728-730, train.py:403-406
+  s3g_deform.npz    deform_network.forward (HexPlane + coarse-to-fine temporal embedding + heads + apply_deform), its state_dict,
+                    outputs and gradients, under the run-script flags and with every head on     S3Gaussian/scene/deformation.py:187-527
+  or_deform.npz     DeformableNodes.get_deformation through ConditionalDeformNetwork (+ gradients)
+                                                   OmniRe/models/nodes/deformable.py:35-47, models/modules.py:318-366,411-457
   or_envlight.npz   EnvLight.forward with the same stand-in                OmniRe/models/modules.py:174-208
   or_rigid.npz      RigidNodes.transform_means / transform_quats / opacity mask (+ gradients), train and
                     test-interpolation branches, non-zero track heads  OmniRe/models/nodes/rigid.py:42-46,150-246,478-615
@@ -101,7 +105,8 @@ def save(name, **arrs):
             v = v.astype(np.float32)
         clean[k] = v
     np.savez_compressed(os.path.join(OUT, name), **clean)
-    print(f"  wrote {name}: " + ", ".join(f"{k}{list(v.shape)}" for k, v in clean.items()))
+    listing = ", ".join(f"{k}{list(v.shape)}" for k, v in clean.items()) if len(clean) <= 40 else f"{len(clean)} arrays"
+    print(f"  wrote {name}: " + listing)
 
 
 def gen_s3g():
@@ -384,6 +389,82 @@ def gen_s3g_hexplane():
     unload(["utils", "scene", "arguments", "gaussian_renderer"])
 
 
+def gen_s3g_deform():
+    """deform_network.forward of the reference on CPU (run-script flags, default feat_head), with gradients."""
+    sys.path.insert(0, os.path.join(REF, "S3Gaussian"))
+    sys.modules["utils.tcnn_modules"] = _Stub("utils.tcnn_modules")
+    with _CpuMode():
+        from arguments.gaussian_options import BaseOptions
+        from scene.deformation import deform_network
+        out = {}
+        # two option sets: the run script's, and one with every head on and HexPlane features in the fine pass too
+        for tag, flags, it, cam_no, t0 in (("run", dict(no_ds=True, no_dr=True, no_fine_hexplane_features=True), 9000, 1, 0.37),
+                                           ("full", dict(), 21000, 2, 0.93)):
+            args = BaseOptions()
+            for k, v in flags.items():
+                setattr(args, k, v)
+            # small planes and tables keep the fixture small; the layer structure is the reference's
+            args.kplanes_config = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 8, "resolution": [6, 5, 7, 9]}
+            args.multires = [1, 2]
+            args.min_embeddings, args.max_embeddings, args.temporal_embedding_dim, args.c2f_temporal_iter = 6, 20, 8, 25000
+            torch.manual_seed(700)
+            net = deform_network(args)
+            net.deformation_net.set_aabb([3.0, 2.0, 1.5], [-1.0, -2.0, -0.5])
+            g = torch.Generator().manual_seed(701)
+            for n_, prm in net.named_parameters():
+                if "grid" in n_:
+                    prm.data = torch.rand(prm.shape, generator=g) + 0.25
+                elif "time_offset" in n_:
+                    prm.data = torch.tensor([[0.0], [0.031], [-0.96]])      # cam 2 at t0 = 0.93 lands below 0: reflection branch
+                elif n_.endswith("deformation_net.weight"):
+                    prm.data = torch.randn(prm.shape, generator=g) * 0.3
+                else:
+                    prm.data = torch.randn(prm.shape, generator=g) * (0.25 if prm.dim() > 1 else 0.05)
+            N = 96
+            point = (torch.rand(N, 3, generator=g) * torch.tensor([4.4, 4.4, 2.4]) + torch.tensor([-1.2, -2.2, -0.7])).requires_grad_(True)
+            scales = torch.randn(N, 3, generator=g).requires_grad_(True)
+            rotations = torch.randn(N, 4, generator=g).requires_grad_(True)
+            opacity = torch.randn(N, 1, generator=g).requires_grad_(True)
+            shs = torch.randn(N, 16, 3, generator=g).requires_grad_(True)
+            emb = (torch.randn(N, 4, generator=g) * 0.5).requires_grad_(True)
+            times = torch.full((N, 1), t0)
+            res = net(point, scales, rotations, opacity, shs, times, emb, it, cam_no, 0.1, True)
+            names = ("point", "scales", "rotations", "opacity", "shs")
+            gouts = [torch.randn(r.shape, generator=g) for r in res[:5]]
+            loss = sum((r * go).sum() for r, go in zip(res[:5], gouts))
+            dd = res[5]
+            gfeat = {}
+            for lvl in ("coarse", "fine"):
+                if dd[lvl]["feat"] is not None:
+                    gfeat[lvl] = torch.randn(dd[lvl]["feat"].shape, generator=g)
+                    loss = loss + (dd[lvl]["feat"] * gfeat[lvl]).sum()
+            loss.backward()
+            out.update({f"{tag}_in_{n_}": v.data for n_, v in zip(names, (point, scales, rotations, opacity, shs))})
+            out.update({f"{tag}_in_emb": emb.data, f"{tag}_in_times": times, f"{tag}_iter": it, f"{tag}_cam_no": cam_no})
+            out.update({f"{tag}_out_{n_}": r for n_, r in zip(names, res[:5])})
+            out.update({f"{tag}_gout_{n_}": go for n_, go in zip(names, gouts)})
+            out.update({f"{tag}_g_{n_}": v.grad for n_, v in zip(names + ("emb",), (point, scales, rotations, opacity, shs, emb))})
+            for lvl in ("coarse", "fine"):
+                for k, v in dd[lvl].items():
+                    if v is not None:
+                        out[f"{tag}_ddict_{lvl}_{k}"] = v
+                if lvl in gfeat:
+                    out[f"{tag}_gfeat_{lvl}"] = gfeat[lvl]
+            for k, v in net.state_dict().items():
+                out[f"{tag}_sd_{k}"] = v
+            for n_, prm in net.named_parameters():
+                out[f"{tag}_gsd_{n_}"] = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+            for k in ("no_ds", "no_dr", "no_fine_hexplane_features", "feat_head", "min_embeddings", "max_embeddings",
+                      "temporal_embedding_dim", "c2f_temporal_iter"):
+                out[f"{tag}_opt_{k}"] = int(getattr(args, k))
+            out[f"{tag}_opt_multires"] = np.array(args.multires)
+            out[f"{tag}_opt_resolution"] = np.array(args.kplanes_config["resolution"])
+            out[f"{tag}_opt_channels"] = args.kplanes_config["output_coordinate_dim"]
+        save("s3g_deform.npz", **out)
+    sys.path.pop(0)
+    unload(["utils", "scene", "arguments", "gaussian_renderer"])
+
+
 def gen_s3g_densify():
     sys.path.insert(0, os.path.join(REF, "S3Gaussian"))
     sys.modules["utils.tcnn_modules"] = _Stub("utils.tcnn_modules")
@@ -429,6 +510,47 @@ def gen_or_envlight():
         assert rec[0]["filter_mode"] == "linear" and rec[0]["boundary_mode"] == "cube"
         save("or_envlight.npz", base=env.base.data, viewdirs=viewdirs, lookup_dirs=rec[0]["dirs"].reshape(-1, 3), light=light,
              rgb=rgb, opacity=opacity, blended=blended, to_opengl=env.to_opengl)
+    sys.path.pop(0)
+    unload(["models", "utils", "datasets"])
+
+
+def gen_or_deform():
+    """ConditionalDeformNetwork and DeformableNodes.get_deformation of the reference on CPU, with gradients."""
+    sys.path.insert(0, os.path.join(REF, "OmniRe"))
+    with _CpuMode():
+        from models.modules import ConditionalDeformNetwork
+        from models.nodes.deformable import DeformableNodes
+        torch.manual_seed(800)
+        E, A, per = 16, 3, 30
+        net = ConditionalDeformNetwork(D=8, W=32, input_ch=3, embed_dim=E, x_multires=10, t_multires=10, deform_quat=True, deform_scale=False)
+        g = torch.Generator().manual_seed(801)
+        for prm in net.parameters():
+            prm.data = torch.randn(prm.shape, generator=g) * (0.2 if prm.dim() > 1 else 0.05)
+        node = types.SimpleNamespace()
+        node.point_ids = torch.arange(A).repeat_interleave(per)[:, None]
+        node.instances_embedding = torch.rand(A, E, generator=g).requires_grad_(True)
+        node.instances_size = torch.tensor([[0.6, 0.5, 1.7], [0.7, 0.6, 1.85], [1.8, 0.6, 1.2]])
+        node.normalized_timestamps = torch.linspace(0, 1, 7)
+        node.cur_frame = 4
+        node.deform_network = net
+        means = ((torch.rand(A * per, 3, generator=g) - 0.5) * torch.tensor([0.6, 0.5, 1.7])).requires_grad_(True)
+        dxyz, dquat, dscale = DeformableNodes.get_deformation(node, means)
+        assert dscale is None
+        gx, gq = torch.randn(dxyz.shape, generator=g), torch.randn(dquat.shape, generator=g)
+        ((dxyz * gx).sum() + (dquat * gq).sum()).backward()
+        assert means.grad is None                                   # local_means.data: detached in the reference
+        out = dict(means=means.data, point_ids=node.point_ids[:, 0].to(torch.int32), inst_size=node.instances_size,
+                   inst_embed=node.instances_embedding.data, t=node.normalized_timestamps[node.cur_frame], dxyz=dxyz, dquat=dquat, gx=gx, gq=gq,
+                   g_inst_embed=node.instances_embedding.grad, D=8, W=32, embed_dim=E, x_multires=10, t_multires=10)
+        # the encoder input the reference built (first layer's input), recomputed from its own embedders
+        x = means.data / node.instances_size[node.point_ids[:, 0]][:, 2:3] * 2
+        tt = node.normalized_timestamps[node.cur_frame].unsqueeze(0).repeat(A * per, 1)
+        out["h0"] = torch.cat([net.embed_fn(x), net.embed_time_fn(tt), node.instances_embedding.data[node.point_ids[:, 0]]], -1)
+        for k, v in net.state_dict().items():
+            out[f"sd_{k}"] = v
+        for n_, prm in net.named_parameters():
+            out[f"gsd_{n_}"] = prm.grad
+        save("or_deform.npz", **out)
     sys.path.pop(0)
     unload(["models", "utils", "datasets"])
 
@@ -561,6 +683,8 @@ if __name__ == "__main__":
     gen_s3g_loss()
     gen_s3g_hexplane()
     gen_s3g_densify()
+    gen_s3g_deform()
     print("OmniRe:")
     gen_omnire()
     gen_or_envlight()
+    gen_or_deform()

@@ -54,13 +54,18 @@ def test_hexplane_vs_oracle(N, C, res, multires):
     gout = torch.randn(N, C * len(multires))
     p0 = pts.clone().requires_grad_(True)
     planes0 = [[prm.detach().cpu().clone().requires_grad_(True) for prm in gp] for gp in field.grids]
-    f0 = ho.hexplane_features(p0, t, field.aabb.detach().cpu(), planes0)
+    t0 = t.clone().requires_grad_(True)
+    f0 = ho.hexplane_features(p0, t0, field.aabb.detach().cpu(), planes0)
     (f0 * gout).sum().backward()
     p1 = pts.to(dev).requires_grad_(True)
-    f1 = field(p1, t.to(dev))
+    t1 = t.to(dev).requires_grad_(True)
+    f1 = field(p1, t1)
     (f1 * gout.to(dev)).sum().backward()
     np.testing.assert_allclose(f1.detach().cpu().numpy(), f0.detach().numpy(), rtol=2e-6, atol=1e-7)
     _close(p1.grad, p0.grad.numpy(), "pts")
+    _close(t1.grad, t0.grad.numpy(), "times")          # reaches the reference's time_offset parameter
+    # the planes live channel-last in memory (the lookup's tap rows are views), in the reference's [1, C, H, W] shape
+    assert all(prm.is_contiguous(memory_format=torch.channels_last) and prm.grad.shape == prm.shape for gp in field.grids for prm in gp)
     for s, gp in enumerate(field.grids):
         for p, prm in enumerate(gp):
             _close(prm.grad, planes0[s][p].grad.numpy(), f"plane {s} {p}")
