@@ -93,7 +93,7 @@ HEX_MAX_SCALES = 8
 class EmdHexArgs(C.Structure):
     _fields_ = [("num_points", C.c_int32), ("channels", C.c_int32), ("num_scales", C.c_int32), ("reserved", C.c_int32),
                 ("res", (C.c_int32 * 4) * HEX_MAX_SCALES), ("planes", (_f * 6) * HEX_MAX_SCALES), ("pts", _f), ("times", _f),
-                ("aabb", C.c_float * 6), ("out", _f)]
+                ("aabb", C.c_float * 6), ("out", _f), ("order", _f)]
 
 
 class EmdHexGrads(C.Structure):

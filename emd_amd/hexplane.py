@@ -18,7 +18,7 @@ PAIRS = list(itertools.combinations(range(4), 2))
 
 class _HexLookup(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pts, times, aabb, res, *planes):
+    def forward(ctx, pts, times, aabb, res, order, *planes):
         if pts.device.type != "cuda":
             raise L.EmdError("HexPlane lookup needs tensors on a ROCm device; there is no CPU path")
         lib = L.load()
@@ -36,12 +36,13 @@ class _HexLookup(torch.autograd.Function):
             for p in range(6):
                 a.planes[s][p] = cl[s * 6 + p].data_ptr()
         a.pts, a.times = pts_c.data_ptr(), times_c.data_ptr()
+        a.order = L.ptr(order)                    # visiting order (int32 permutation) or None
         for k in range(6):
             a.aabb[k] = aabb[k]
         out = torch.empty(N, S * Cc, device=pts.device, dtype=torch.float32)
         a.out = out.data_ptr()
         L.check(lib.emd_hexplane_forward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_hexplane_forward")
-        ctx.args, ctx.keep = a, (pts_c, times_c, cl)
+        ctx.args, ctx.keep = a, (pts_c, times_c, cl, order)
         ctx.shapes = [tuple(p.shape) for p in planes]
         ctx.times_shape = tuple(times.shape)
         return out
@@ -54,7 +55,7 @@ class _HexLookup(torch.autograd.Function):
         g_out = g_out.contiguous().float()
         g = L.EmdHexGrads()
         g.dL_dout = g_out.data_ptr()
-        need_planes = any(ctx.needs_input_grad[4:])
+        need_planes = any(ctx.needs_input_grad[5:])
         gcl = []
         if need_planes:
             flat = torch.zeros(sum(int(np.prod(s)) for s in ctx.shapes), device=g_out.device, dtype=torch.float32)   # one fill
@@ -71,7 +72,7 @@ class _HexLookup(torch.autograd.Function):
         L.check(lib.emd_hexplane_backward(C.byref(a), C.byref(g), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                 "emd_hexplane_backward")
         grads = [t.permute(2, 0, 1)[None] for t in gcl] if need_planes else [None] * len(ctx.shapes)   # channel-last, like the planes
-        return (d_pts, d_times, None, None, *grads)
+        return (d_pts, d_times, None, None, None, *grads)
 
 
 def init_grid_param(grid_nd, in_dim, out_dim, reso, a=0.1, b=0.5):
@@ -89,8 +90,24 @@ def init_grid_param(grid_nd, in_dim, out_dim, reso, a=0.1, b=0.5):
     return grid_coefs
 
 
+def morton_order(pts, aabb, bits=10):
+    """int32 permutation that visits the points along a Z-order curve of their box-normalised positions (10 bits per axis)."""
+    with torch.no_grad():
+        q = ((pts.detach() - aabb[0]) / (aabb[1] - aabb[0])).clamp_(0.0, 1.0).mul_(float(2 ** bits - 1)).to(torch.int64)
+
+        def spread(v):                                  # abcdefghij -> a00b00c00d00e00f00g00h00i00j
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        return key.argsort().to(torch.int32)
+
+
 class HexPlaneField(nn.Module):
     """S3Gaussian/scene/hexplane.py:112-183"""
+    reorder_every = 64        # lookups between refreshes of the cached visiting order (positions drift slowly; any order is correct)
+    reorder_min_points = 8192
 
     def __init__(self, bounds, planeconfig, multires):
         super().__init__()
@@ -129,7 +146,20 @@ class HexPlaneField(nn.Module):
     def get_density(self, pts, timestamps=None):
         pts = pts.reshape(-1, pts.shape[-1])
         planes = [p for gp in self.grids for p in gp]
-        return _HexLookup.apply(pts, timestamps.reshape(-1, 1), self._aabb_host(), self._res, *planes)
+        return _HexLookup.apply(pts, timestamps.reshape(-1, 1), self._aabb_host(), self._res, self._visiting_order(pts), *planes)
+
+    def _visiting_order(self, pts):
+        """Morton order of the points, cached across steps: with it 256 consecutive points share plane cells, and the backward
+        aggregates their gradients in LDS before they reach HBM (hexplane.hip).  Purely a speed matter: every order gives the
+        same sums up to float rounding, so a stale order (Gaussians moved, or were replaced at equal count) is harmless."""
+        n = pts.shape[0]
+        if n < self.reorder_min_points or pts.device.type != "cuda":
+            return None
+        cache = getattr(self, "_order_cache", None)
+        if cache is None or cache[0] != n or cache[1] >= self.reorder_every or cache[2].device != pts.device:
+            cache = self._order_cache = [n, 0, morton_order(pts, self.aabb)]
+        cache[1] += 1
+        return cache[2]
 
     def forward(self, pts, timestamps=None):
         return self.get_density(pts, timestamps)

@@ -359,6 +359,10 @@ typedef struct EmdHexArgs {
     const float* times;                          /* [N] */
     float aabb[6];                               /* aabb[0] (3 floats) then aabb[1] (3 floats), as HexPlaneField stores them */
     float* out;                                  /* [N, num_scales * C] (forward) */
+    const int32_t* order;                        /* [N] a permutation of the points, or NULL: the order the kernels visit them in.
+                                                    A spatially coherent one (e.g. Morton order of pts) lets the backward
+                                                    aggregate the plane gradients in LDS before they reach HBM; results are
+                                                    the same up to the order of the float sums. */
 } EmdHexArgs;
 
 typedef struct EmdHexGrads {

@@ -69,3 +69,58 @@ def test_hexplane_vs_oracle(N, C, res, multires):
     for s, gp in enumerate(field.grids):
         for p, prm in enumerate(gp):
             _close(prm.grad, planes0[s][p].grad.numpy(), f"plane {s} {p}")
+
+
+@pytest.mark.parametrize("C,layout", [(32, "morton"), (32, "random_order"), (16, "morton"), (32, "clustered"), (32, "same_time")])
+def test_hexplane_aggregating_backward(C, layout):
+    """The LDS-aggregating backward (taken when a visiting order is given) against the oracle: Morton order (windows hit), an
+    arbitrary permutation (almost every tap falls back to the direct atomic), points piled into a few cells, one shared time."""
+    from emd_amd.hexplane import HexPlaneField, _HexLookup, morton_order
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(C + len(layout))
+    N, res, multires = 30011, [16, 12, 10, 6], [1, 2, 4]
+    cfg = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": C, "resolution": res}
+    field = HexPlaneField(1.6, cfg, multires).to(dev)
+    for gp in field.grids:
+        for prm in gp:
+            prm.data = torch.rand_like(prm) + 0.3
+    pts = torch.rand(N, 3, generator=g) * 3.6 - 1.8
+    if layout == "clustered":
+        pts = torch.randn(N, 3, generator=g) * 0.02 + torch.tensor([0.3, -0.7, 1.1])
+    t = torch.full((N, 1), 0.21) if layout == "same_time" else torch.rand(N, 1, generator=g) * 2.2 - 1.1
+    gout = torch.randn(N, C * len(multires), generator=g)
+    p0, t0 = pts.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    planes0 = [[prm.detach().cpu().clone().requires_grad_(True) for prm in gp] for gp in field.grids]
+    f0 = ho.hexplane_features(p0, t0, field.aabb.detach().cpu(), planes0)
+    (f0 * gout).sum().backward()
+    p1, t1 = pts.to(dev).requires_grad_(True), t.to(dev).requires_grad_(True)
+    order = torch.randperm(N, generator=g).to(torch.int32).to(dev) if layout == "random_order" else morton_order(p1, field.aabb)
+    assert sorted(order.cpu().tolist()) == list(range(N))
+    planes = [p for gp in field.grids for p in gp]
+    f1 = _HexLookup.apply(p1, t1, field._aabb_host(), field._res, order, *planes)
+    (f1 * gout.to(dev)).sum().backward()
+    np.testing.assert_allclose(f1.detach().cpu().numpy(), f0.detach().numpy(), rtol=2e-6, atol=1e-7)
+    _close(p1.grad, p0.grad.numpy(), "pts")
+    _close(t1.grad, t0.grad.numpy(), "times")
+    for s, gp in enumerate(field.grids):
+        for p, prm in enumerate(gp):
+            _close(prm.grad, planes0[s][p].grad.numpy(), f"plane {s} {p}")
+
+
+def test_hexplane_field_caches_visiting_order():
+    from emd_amd.hexplane import HexPlaneField
+    dev = torch.device("cuda", 0)
+    cfg = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32, "resolution": [8, 8, 8, 4]}
+    field = HexPlaneField(1.6, cfg, [1, 2]).to(dev)
+    field.reorder_every = 3
+    pts = torch.rand(10000, 3, device=dev) * 3 - 1.5
+    t = torch.zeros(10000, 1, device=dev)
+    field(pts, t)
+    first = field._order_cache[2]
+    field(pts, t); field(pts, t)
+    assert field._order_cache[2] is first                      # reused
+    field(pts, t)
+    assert field._order_cache[2] is not first                  # refreshed after reorder_every lookups
+    field(pts[:9000], t[:9000])
+    assert field._order_cache[0] == 9000                       # and whenever the number of points changes
+    assert field._visiting_order(pts[:100]) is None            # small inputs use the plain kernels
