@@ -273,7 +273,7 @@ def main():
                                              "rebuilt locally; RCCL all-reduce (AVG) of the remaining 44 B per Gaussian + actor poses")},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:      # the CPU leg is timed on rank 0 of the 1-GPU run only
             res["cpu_baseline"] = cpu_baseline(scene, cam_for(0)[1])
         print(json.dumps(res))
     if world > 1:

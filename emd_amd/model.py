@@ -45,8 +45,11 @@ class StreetGaussians(torch.nn.Module):
         return actor_pose_table(self.instances_quats, self.instances_trans, self.instances_fv, frame)
 
 
-def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activations=True):
-    """The reference render() restricted to the hot path; returns the dict the training loop consumes."""
+def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activations=True, deformation=None, embeddings=None,
+           iteration=None, time=None):
+    """The reference render() restricted to the hot path; returns the dict the training loop consumes.
+    `deformation` (an emd_amd.deformation.deform_network) switches on the "fine" stage of gaussian_renderer/__init__.py:86-96:
+    the residuals of the self-supervised EMD network are added to the raw parameters before the activations."""
     dev = model._xyz.device
     # the reference's zero "screen-space points" leaf that only collects dL/dmean2D: the zeros are never written, so one
     # cached buffer per model serves every step (a fresh leaf view each time, no 24 MB fill launch)
@@ -56,21 +59,26 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
     screenspace_points = z.detach().requires_grad_(True)
     rs = raster_settings_for(cam, bg, model.active_sh_degree, 1.0, debug)
     rasterizer = GaussianRasterizer(raster_settings=rs)
-    if fuse_activations:
-        # the three activations of the reference run inside K1 / K8 (raw_params), not as ~25 separate torch launches
-        scales, rotations, opacity = model._scaling, model._rotation, model._opacity
-    else:
-        scales = torch.exp(model._scaling)
-        rotations = F.normalize(model._rotation)
-        opacity = torch.sigmoid(model._opacity)
+    means3D, scales, rotations, opacity, shs, ddict = model._xyz, model._scaling, model._rotation, model._opacity, model._features, None
+    if deformation is not None:
+        t = float(getattr(cam, "time", 0.0) if time is None else time)
+        times_sel = torch.full((means3D.shape[0], 1), t, device=dev, dtype=torch.float32)
+        means3D, scales, rotations, opacity, shs, ddict = deformation(
+            means3D, scales, rotations, opacity, shs, times_sel, embeddings, iteration, int(getattr(cam, "cam_no", 0)),
+            getattr(cam, "time_diff", 0.0), True)
+    if not fuse_activations:
+        # (fused: the three activations of the reference run inside K1 / K8 (raw_params), not as ~25 separate torch launches)
+        scales = torch.exp(scales)
+        rotations = F.normalize(rotations)
+        opacity = torch.sigmoid(opacity)
     kw = {}
     if model.has_actors:
         kw = dict(actor_ids=model.actor_id, actor_pose=model.actor_pose(frame))
     image, depth, normal, weight, radii, _ = rasterizer(
-        means3D=model._xyz, means2D=screenspace_points, shs=model._features, colors_precomp=None, opacities=opacity,
+        means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, raw_params=fuse_activations, **kw)
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
-            "depth": depth, "weight": weight, "normal": normal, "actor_pose": kw.get("actor_pose")}
+            "depth": depth, "weight": weight, "normal": normal, "actor_pose": kw.get("actor_pose"), "ddict": ddict}
 
 
 def raster_settings_for(cam, bg, sh_degree, scaling_modifier=1.0, debug=False):

@@ -2,7 +2,11 @@
 32 actors, 1066 x 1600): fused-motion rasterizer -> sky cube map (1024^2 faces) + blend -> L1 + depth L2 + D-SSIM + sky BCE ->
 backward to all Gaussian parameters, actor poses and the cube map -> per-view densification statistics.  (The bench.py metric is
 the L1-only step of BASELINE.json; this is the same step with the reference's full loss and sky model.)  One JSON line.
-    python profiles/bench_full_step.py > profiles/r01_full_step.json"""
+    python profiles/bench_full_step.py > profiles/r01_full_step.json
+    python profiles/bench_full_step.py --fine > profiles/r01_full_step_fine.json
+--fine: the "fine" stage of S3Gaussian's training (train.py after coarse_iterations): no actors, the self-supervised EMD
+deformation network (HexPlane 4 x 6 planes x 32 channels, temporal table, heads dx / do / dshs / feat; run-script flags) runs in
+front of the rasterizer on all 2 M Gaussians and is trained through it, plus the residual regularisers of train.py."""
 import json
 import sys
 import time
@@ -18,10 +22,24 @@ from emd_amd.model import StreetGaussians, render  # noqa: E402
 from emd_amd.sky import SkyCubeMap, composite_s3g  # noqa: E402
 
 dev = torch.device("cuda", 0)
+FINE = "--fine" in sys.argv
 N, H, W, F = 2_000_000, 1066, 1600, 50
-scene = scenes.add_actors(scenes.make_static_scene(N, seed=0), num_actors=32, pts_per_actor=5000, num_frames=F, seed=1)
+scene = scenes.make_static_scene(N, seed=0)
+if not FINE:
+    scene = scenes.add_actors(scene, num_actors=32, pts_per_actor=5000, num_frames=F, seed=1)
 model = StreetGaussians(scene, dev)
 params = list(model.parameters())
+deform = embeddings = None
+if FINE:
+    from emd_amd.deformation import DeformOptions, deform_network  # noqa: E402
+    torch.manual_seed(5)
+    deform = deform_network(DeformOptions()).to(dev)
+    deform.deformation_net.set_aabb([120.0, 30.0, 10.0], [0.0, -30.0, -2.0])
+    for n_, p_ in deform.named_parameters():          # non-zero heads so that the residuals (and their gradients) are live
+        if p_.dim() > 1 and "grid" not in n_:
+            p_.data.mul_(0.05)
+    embeddings = torch.nn.Parameter(torch.zeros(N, 4, device=dev))
+    params += list(deform.parameters()) + [embeddings]
 sky = SkyCubeMap(types.SimpleNamespace(sky_resolution=1024, sky_white_background=False, white_background=False), device=dev)
 g = torch.Generator().manual_seed(3)
 gt = torch.rand(3, H, W, generator=g).to(dev)
@@ -43,9 +61,13 @@ def step(s):
     for p in params:
         p.grad = None
     sky.sky_cube_map.grad = None
-    out = render(model, cams[f], bg, frame=f)
+    out = render(model, cams[f], bg, frame=f, deformation=deform, embeddings=embeddings, iteration=12000 + s, time=f / (F - 1))
     image, _ = composite_s3g(sky, skycams[f], out["render"], out["weight"])
     loss, _ = image_loss(image, gt, out["depth"], gt_depth, not_sky, out["weight"], sky_mask)
+    if FINE:                                           # residual regularisers (train.py: lambda_dx / do / dshs on both levels)
+        for lvl in ("coarse", "fine"):
+            d = out["ddict"][lvl]
+            loss = loss + 0.001 * (d["dx"].abs().mean() + d["do"].abs().mean() + d["dshs"].abs().mean())
     loss.backward()
     dp.add_densification_stats(out["viewspace_points"].grad, out["radii"], accum, denom, maxr)
 
@@ -54,7 +76,7 @@ RasterConfig.no_sync = False
 dmax = 0
 for f in range(0, F, 7):
     with torch.no_grad():
-        render(model, cams[f], bg, frame=f)
+        render(model, cams[f], bg, frame=f, deformation=deform, embeddings=embeddings, iteration=12000, time=f / (F - 1))
     dmax = max(dmax, GaussianRasterizer.last_status()["num_rendered"])
 _rz._capacity_hint[(dev.index, H, W)] = int(dmax * 1.3) + 1024
 RasterConfig.no_sync = True
@@ -67,6 +89,9 @@ for s in range(K_STEPS):
     step(10 + s)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(json.dumps({"op": "S3G-style step: raster (fused motion) + sky cube map + blend + L1/depth/D-SSIM/sky-BCE + backward + densification stats",
+op = "S3G-style step: raster (fused motion) + sky cube map + blend + L1/depth/D-SSIM/sky-BCE + backward + densification stats"
+if FINE:
+    op = "S3G fine-stage step: EMD deformation network (HexPlane + temporal table + heads) -> raster -> sky + blend -> full loss + residual regularisers -> backward to Gaussians, planes, table, heads -> densification stats"
+print(json.dumps({"op": op,
                   "gaussians": N, "height": H, "width": W, "steps": K_STEPS, "ms_per_step": round(dt / K_STEPS * 1e3, 4),
                   "iters_per_s": round(K_STEPS / dt, 1)}))
