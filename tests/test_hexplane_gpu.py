@@ -124,3 +124,27 @@ def test_hexplane_field_caches_visiting_order():
     field(pts[:9000], t[:9000])
     assert field._order_cache[0] == 9000                       # and whenever the number of points changes
     assert field._visiting_order(pts[:100]) is None            # small inputs use the plain kernels
+
+
+def test_channel_last_planes_train_and_load_reference_checkpoints():
+    """The planes are nn.Parameters of the reference's shape stored channel-last: an optimiser step works on them, a contiguous
+    (reference) state_dict loads into them, and what they save loads back into a contiguous copy."""
+    from emd_amd.hexplane import HexPlaneField
+    dev = torch.device("cuda", 0)
+    cfg = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32, "resolution": [8, 6, 4, 3]}
+    field = HexPlaneField(1.6, cfg, [1, 2]).to(dev)
+    ref_sd = {k: torch.rand_like(v).contiguous() for k, v in field.state_dict().items()}      # what a reference checkpoint holds
+    field.load_state_dict(ref_sd, strict=True)
+    assert all(p.is_contiguous(memory_format=torch.channels_last) for gp in field.grids for p in gp)
+    for k, v in field.state_dict().items():
+        assert torch.equal(v.contiguous(), ref_sd[k])
+    opt = torch.optim.Adam(field.parameters(), lr=1e-2)
+    pts = torch.rand(9000, 3, device=dev) * 3 - 1.5
+    before = [p.detach().clone() for gp in field.grids for p in gp]
+    for _ in range(2):
+        opt.zero_grad()
+        field(pts, torch.full((9000, 1), 0.3, device=dev)).square().mean().backward()
+        opt.step()
+    after = [p for gp in field.grids for p in gp]
+    assert all((a - b).abs().max() > 0 for a, b in zip(after, before))
+    assert all(p.is_contiguous(memory_format=torch.channels_last) for p in after)
