@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 TILE = 16
 ACTOR_STRIDE = 12
 BWD_STRIDE = 12
@@ -106,6 +106,19 @@ class EmdDeformInArgs(C.Structure):
                 ("t", _f), ("out", _f)]
 
 
+ADAM_MAX_TENSORS = 32
+
+
+class EmdAdamTensor(C.Structure):
+    _fields_ = [("param", _f), ("grad", _f), ("exp_avg", _f), ("exp_avg_sq", _f), ("numel", C.c_int64), ("step_size", C.c_float),
+                ("bias_correction2_sqrt", C.c_float), ("one_minus_beta1", C.c_float), ("beta2", C.c_float), ("one_minus_beta2", C.c_float),
+                ("eps", C.c_float)]
+
+
+class EmdAdamArgs(C.Structure):
+    _fields_ = [("num_tensors", C.c_int32), ("reserved", C.c_int32), ("tensors", EmdAdamTensor * ADAM_MAX_TENSORS)]
+
+
 # every symbol include/emd_raster.h declares
 EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_size", "emd_raster_forward",
                     "emd_raster_backward", "emd_raster_export_binning", "emd_raster_export_geometry",
@@ -113,7 +126,7 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward", "emd_actor_pose_forward", "emd_actor_pose_backward", "emd_l1_loss",
                     "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss", "emd_hexplane_forward", "emd_hexplane_backward", "emd_sh_grad_from_factors", "emd_densification_stats",
                     "emd_temporal_embed_forward", "emd_temporal_embed_backward", "emd_deform_input_width", "emd_deform_input_forward",
-                    "emd_deform_input_backward")
+                    "emd_deform_input_backward", "emd_adam_step")
 PROF_STAGES = 8
 
 _lib = None
@@ -170,6 +183,7 @@ def load():
     lib.emd_deform_input_width.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.emd_deform_input_forward.argtypes = [C.POINTER(EmdDeformInArgs), C.c_void_p]
     lib.emd_deform_input_backward.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_adam_step.argtypes = [C.POINTER(EmdAdamArgs), C.c_void_p]
     lib.emd_sky_forward.argtypes = [C.POINTER(EmdSkyArgs), C.c_void_p]
     lib.emd_sky_backward.argtypes = [C.POINTER(EmdSkyBwdArgs), C.c_void_p]
     lib.emd_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 11
+#define EMD_ABI_VERSION 12
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -407,6 +407,30 @@ int emd_deform_input_width(int num_freqs_x, int num_freqs_t, int embed_dim);
 int emd_deform_input_forward(const EmdDeformInArgs* args, void* hip_stream);
 int emd_deform_input_backward(int num_points, int embed_dim, int ld, int col0, const int32_t* point_ids, const float* dL_din,
                               float* dL_dembed, void* hip_stream);
+
+/* ---- Adam over all parameter tensors in one launch ---------------------------------------
+ * Replaces optimizer.step() of `torch.optim.Adam(l, lr=0.0, eps=1e-15)` (S3Gaussian/scene/gaussian_model.py:188-201,
+ * train.py:428; OmniRe builds the same optimiser per class, models/trainers/base.py:213-253): per element
+ *   m = m + (1-beta1)(g-m);  v = v beta2 + (1-beta2) g g;  p = p - step_size * m / (sqrt(v) / bias_correction2_sqrt + eps)
+ * in torch.optim.Adam's operation order, in place.  The caller supplies the step-dependent scalars (computed in double, as torch
+ * does): step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t).  param / grad / exp_avg / exp_avg_sq of one
+ * tensor must share one memory layout (they are walked as flat arrays of `numel` floats). */
+#define EMD_ADAM_MAX_TENSORS 32
+typedef struct EmdAdamTensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+    float step_size, bias_correction2_sqrt, one_minus_beta1, beta2, one_minus_beta2, eps;
+} EmdAdamTensor;
+
+typedef struct EmdAdamArgs {
+    int32_t num_tensors, reserved;
+    EmdAdamTensor tensors[EMD_ADAM_MAX_TENSORS];
+} EmdAdamArgs;
+
+int emd_adam_step(const EmdAdamArgs* args, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,9 @@ the L1-only step of BASELINE.json; this is the same step with the reference's fu
     python profiles/bench_full_step.py --fine > profiles/r01_full_step_fine.json
 --fine: the "fine" stage of S3Gaussian's training (train.py after coarse_iterations): no actors, the self-supervised EMD
 deformation network (HexPlane 4 x 6 planes x 32 channels, temporal table, heads dx / do / dshs / feat; run-script flags) runs in
-front of the rasterizer on all 2 M Gaussians and is trained through it, plus the residual regularisers of train.py."""
+front of the rasterizer on all 2 M Gaussians and is trained through it, plus the residual regularisers of train.py.
+--adam / --torch-adam: also take the optimiser step (train.py:428) with emd_amd.optim.Adam / torch.optim.Adam over the groups of
+gaussian_model.py:188-199 (per-group learning rates, eps 1e-15)."""
 import json
 import sys
 import time
@@ -40,6 +42,18 @@ if FINE:
             p_.data.mul_(0.05)
     embeddings = torch.nn.Parameter(torch.zeros(N, 4, device=dev))
     params += list(deform.parameters()) + [embeddings]
+optimizer = None
+if "--adam" in sys.argv or "--torch-adam" in sys.argv:
+    from emd_amd.optim import Adam  # noqa: E402
+    groups = [{"params": [model._xyz], "lr": 1.6e-4, "name": "xyz"}, {"params": [model._features], "lr": 2.5e-3, "name": "f"},
+              {"params": [model._opacity], "lr": 0.05, "name": "opacity"}, {"params": [model._scaling], "lr": 5e-3, "name": "scaling"},
+              {"params": [model._rotation], "lr": 1e-3, "name": "rotation"}]
+    if model.has_actors:
+        groups.append({"params": [model.instances_quats, model.instances_trans], "lr": 1e-5, "name": "ins_pose"})
+    if FINE:
+        groups += [{"params": deform.get_mlp_parameters(), "lr": 1.6e-5, "name": "deformation"},
+                   {"params": deform.get_grid_parameters(), "lr": 1.6e-4, "name": "grid"}, {"params": [embeddings], "lr": 2.5e-3, "name": "embedding"}]
+    optimizer = (Adam if "--adam" in sys.argv else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
 sky = SkyCubeMap(types.SimpleNamespace(sky_resolution=1024, sky_white_background=False, white_background=False), device=dev)
 g = torch.Generator().manual_seed(3)
 gt = torch.rand(3, H, W, generator=g).to(dev)
@@ -70,6 +84,8 @@ def step(s):
             loss = loss + 0.001 * (d["dx"].abs().mean() + d["do"].abs().mean() + d["dshs"].abs().mean())
     loss.backward()
     dp.add_densification_stats(out["viewspace_points"].grad, out["radii"], accum, denom, maxr)
+    if optimizer is not None:
+        optimizer.step()
 
 
 RasterConfig.no_sync = False
@@ -92,6 +108,8 @@ dt = time.perf_counter() - t0
 op = "S3G-style step: raster (fused motion) + sky cube map + blend + L1/depth/D-SSIM/sky-BCE + backward + densification stats"
 if FINE:
     op = "S3G fine-stage step: EMD deformation network (HexPlane + temporal table + heads) -> raster -> sky + blend -> full loss + residual regularisers -> backward to Gaussians, planes, table, heads -> densification stats"
+if optimizer is not None:
+    op += " -> optimiser step (" + ("emd_amd.optim.Adam" if "--adam" in sys.argv else "torch.optim.Adam") + ")"
 print(json.dumps({"op": op,
                   "gaussians": N, "height": H, "width": W, "steps": K_STEPS, "ms_per_step": round(dt / K_STEPS * 1e3, 4),
                   "iters_per_s": round(K_STEPS / dt, 1)}))

@@ -28,6 +28,8 @@ Fixtures (all fp32):
                                                    S3Gaussian/scene/gaussian_model.py:728-730, train.py:403-406
   s3g_deform.npz    deform_network.forward (HexPlane + coarse-to-fine temporal embedding + heads + apply_deform), its state_dict,
                     outputs and gradients, under the run-script flags and with every head on     S3Gaussian/scene/deformation.py:187-527
+  s3g_adam.npz      the optimiser GaussianModel.training_setup builds (torch.optim.Adam, eps 1e-15, ten named groups) stepped over six
+                    iterations with seeded gradients and update_learning_rate      S3Gaussian/scene/gaussian_model.py:181-243, train.py:195,428
   or_deform.npz     DeformableNodes.get_deformation through ConditionalDeformNetwork (+ gradients)
                                                    OmniRe/models/nodes/deformable.py:35-47, models/modules.py:318-366,411-457
   or_envlight.npz   EnvLight.forward with the same stand-in                OmniRe/models/modules.py:174-208
@@ -465,6 +467,67 @@ def gen_s3g_deform():
     unload(["utils", "scene", "arguments", "gaussian_renderer"])
 
 
+def gen_s3g_adam():
+    """The reference's optimiser (GaussianModel.training_setup) and learning-rate schedule over a few iterations, on CPU."""
+    sys.path.insert(0, os.path.join(REF, "S3Gaussian"))
+    sys.modules["utils.tcnn_modules"] = _Stub("utils.tcnn_modules")
+    with _CpuMode():
+        from arguments.gaussian_options import BaseOptions
+        from scene.gaussian_model import GaussianModel
+        args = BaseOptions()
+        for k in ("no_ds", "no_dr", "no_fine_hexplane_features"):
+            setattr(args, k, True)
+        args.kplanes_config = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 4, "resolution": [4, 4, 4, 3]}
+        args.multires = [1]
+        args.sky_resolution = 4
+        args.net_width, args.feat_head = 8, False          # small layers keep the fixture small; the groups are the reference's
+        torch.manual_seed(900)
+        pc = GaussianModel(args)
+        N = 37
+        g = torch.Generator().manual_seed(901)
+        P = torch.nn.Parameter
+        pc._xyz = P(torch.randn(N, 3, generator=g))
+        pc._features_dc = P(torch.randn(N, 1, 3, generator=g))
+        pc._features_rest = P(torch.randn(N, 15, 3, generator=g) * 0.1)
+        pc._scaling = P(torch.randn(N, 3, generator=g))
+        pc._rotation = P(torch.randn(N, 4, generator=g))
+        pc._opacity = P(torch.randn(N, 1, generator=g))
+        pc._embedding = P(torch.randn(N, 4, generator=g) * 0.1)
+        pc.spatial_lr_scale = 5.0
+        pc.training_setup(args)
+        opt = pc.optimizer
+        out = dict(eps=opt.defaults["eps"], beta1=opt.defaults["betas"][0], beta2=opt.defaults["betas"][1],
+                   group_names=np.array([gr["name"] for gr in opt.param_groups]))
+        for gr in opt.param_groups:
+            out[f"init_{gr['name']}"] = torch.cat([p.data.reshape(-1) for p in gr["params"]])
+            out[f"count_{gr['name']}"] = len(gr["params"])
+        iters = [0, 1, 2, 700, 701, 9000]
+        out["iters"] = np.array(iters)
+        for k, it in enumerate(iters):
+            pc.update_learning_rate(it)
+            out[f"lr_{k}"] = np.array([gr["lr"] for gr in opt.param_groups], dtype=np.float64)
+            for gr in opt.param_groups:
+                gs = []
+                for p in gr["params"]:
+                    p.grad = torch.randn(p.shape, generator=g) * (10.0 ** float(torch.randint(-4, 1, (1,), generator=g)))
+                    gs.append(p.grad.reshape(-1))
+                out[f"grad_{k}_{gr['name']}"] = torch.cat(gs)
+            opt.step()
+        for gr in opt.param_groups:
+            out[f"final_{gr['name']}"] = torch.cat([p.data.reshape(-1) for p in gr["params"]])
+            out[f"exp_avg_{gr['name']}"] = torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in gr["params"]])
+            out[f"exp_avg_sq_{gr['name']}"] = torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in gr["params"]])
+        # the schedule arguments training_setup derived (the builder's expon_lr must reproduce lr_k from them)
+        for k in ("position_lr_init", "position_lr_final", "position_lr_delay_mult", "position_lr_max_steps", "deformation_lr_init",
+                  "deformation_lr_final", "deformation_lr_delay_mult", "grid_lr_init", "grid_lr_final", "feature_lr", "opacity_lr",
+                  "scaling_lr", "rotation_lr", "sky_cube_map_lr_init", "sky_cube_map_lr_final", "sky_cube_map_max_steps"):
+            out[f"arg_{k}"] = float(getattr(args, k))
+        out["spatial_lr_scale"] = 5.0
+        save("s3g_adam.npz", **out)
+    sys.path.pop(0)
+    unload(["utils", "scene", "arguments", "gaussian_renderer"])
+
+
 def gen_s3g_densify():
     sys.path.insert(0, os.path.join(REF, "S3Gaussian"))
     sys.modules["utils.tcnn_modules"] = _Stub("utils.tcnn_modules")
@@ -684,6 +747,7 @@ if __name__ == "__main__":
     gen_s3g_hexplane()
     gen_s3g_densify()
     gen_s3g_deform()
+    gen_s3g_adam()
     print("OmniRe:")
     gen_omnire()
     gen_or_envlight()

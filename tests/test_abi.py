@@ -38,9 +38,9 @@ def test_struct_layout_matches_c():
     prog = r'''
 #include <stdio.h>
 #include "emd_raster.h"
-int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(EmdSettings), sizeof(EmdMotion), sizeof(EmdDims),
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(EmdSettings), sizeof(EmdMotion), sizeof(EmdDims),
  sizeof(EmdFwdArgs), sizeof(EmdBwdArgs), sizeof(EmdStatus), sizeof(EmdSkyArgs), sizeof(EmdSkyBwdArgs), sizeof(EmdLossArgs),
- sizeof(EmdHexArgs), sizeof(EmdHexGrads), sizeof(EmdDeformInArgs));return 0;}
+ sizeof(EmdHexArgs), sizeof(EmdHexGrads), sizeof(EmdDeformInArgs), sizeof(EmdAdamTensor), sizeof(EmdAdamArgs));return 0;}
 '''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
@@ -52,7 +52,7 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeo
                          C.sizeof(L.EmdBwdArgs)]
     assert sizes[5] == 16
     assert sizes[6:] == [C.sizeof(L.EmdSkyArgs), C.sizeof(L.EmdSkyBwdArgs), C.sizeof(L.EmdLossArgs), C.sizeof(L.EmdHexArgs),
-                         C.sizeof(L.EmdHexGrads), C.sizeof(L.EmdDeformInArgs)]
+                         C.sizeof(L.EmdHexGrads), C.sizeof(L.EmdDeformInArgs), C.sizeof(L.EmdAdamTensor), C.sizeof(L.EmdAdamArgs)]
 
 
 def test_workspace_size_host_only():
