@@ -53,6 +53,16 @@ __device__ __forceinline__ float sample(const float* __restrict__ pl, const Bili
     return nw * ((1.f - t.fx) * (1.f - t.fy)) + ne * (t.fx * (1.f - t.fy)) + sw * ((1.f - t.fx) * t.fy) + se * (t.fx * t.fy);
 }
 
+// the sample and its slopes d/d(ix), d/d(iy) (already times the border-clip masks) from one read of the four corners
+__device__ __forceinline__ float sample_slopes(const float* __restrict__ pl, const Bilin& t, int W, int C, int c, float& dix, float& diy) {
+    const float nw = pl[((size_t)t.y0 * W + t.x0) * C + c], ne = pl[((size_t)t.y0 * W + t.x1) * C + c];
+    const float sw = pl[((size_t)t.y1 * W + t.x0) * C + c], se = pl[((size_t)t.y1 * W + t.x1) * C + c];
+    // the clamped neighbour (x1 == x0 at the border) contributes no slope there: its weight is 0 and cx = 0
+    dix = ((ne - nw) * (1.f - t.fy) + (se - sw) * t.fy) * t.cx;
+    diy = ((sw - nw) * (1.f - t.fx) + (se - ne) * t.fx) * t.cy;
+    return nw * ((1.f - t.fx) * (1.f - t.fy)) + ne * (t.fx * (1.f - t.fy)) + sw * ((1.f - t.fx) * t.fy) + se * (t.fx * t.fy);
+}
+
 template <bool BWD>
 __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrads g) {
     const int C = a.channels, S = a.num_scales;
@@ -67,7 +77,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrad
     float dq[4] = {0.f, 0.f, 0.f, 0.f};
     const bool want_dq = BWD && (g.dL_dpts || g.dL_dtimes);
     for (int s = 0; s < S; s++) {
-        float f[6];
+        float f[6], dix[6], diy[6];
         Bilin t[6];
 #pragma unroll
         for (int p = 0; p < 6; p++) {
@@ -75,7 +85,8 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrad
             pair_axes(p, ax, ay);
             const int W = a.res[s][ax], H = a.res[s][ay];
             t[p] = bilin(q[ax], q[ay], W, H);
-            f[p] = sample(a.planes[s][p], t[p], W, C, c);
+            if (BWD && want_dq) f[p] = sample_slopes(a.planes[s][p], t[p], W, C, c, dix[p], diy[p]);   // one read of the corners serves both
+            else f[p] = sample(a.planes[s][p], t[p], W, C, c);
         }
         if (!BWD) {
             float prod = 1.f;
@@ -105,14 +116,8 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrad
                     atomicAdd(gp + ((size_t)b.y1 * W + b.x1) * C + c, gi * (b.fx * b.fy));
                 }
                 if (want_dq) {
-                    const float* pl = a.planes[s][p];
-                    const float nw = pl[((size_t)b.y0 * W + b.x0) * C + c], ne = pl[((size_t)b.y0 * W + b.x1) * C + c];
-                    const float sw = pl[((size_t)b.y1 * W + b.x0) * C + c], se = pl[((size_t)b.y1 * W + b.x1) * C + c];
-                    // the clamped neighbour (x1 == x0 at the border) contributes no slope there: its weight is 0 and cx = 0
-                    const float dix = (ne - nw) * (1.f - b.fy) + (se - sw) * b.fy;
-                    const float diy = (sw - nw) * (1.f - b.fx) + (se - ne) * b.fx;
-                    dq[ax] += gi * dix * b.cx;
-                    dq[ay] += gi * diy * b.cy;
+                    dq[ax] += gi * dix[p];
+                    dq[ay] += gi * diy[p];
                 }
             }
         }
@@ -206,13 +211,14 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS) k_hexplane_bwd_agg(EmdHexArgs
 #pragma unroll
             for (int k = 0; k < 3; k++) q[k] = (a.pts[3 * n + k] - a.aabb[k]) * (2.f / (a.aabb[3 + k] - a.aabb[k])) - 1.f;
             q[3] = a.times[n];
-            float f[6], dq[4] = {0.f, 0.f, 0.f, 0.f};
+            float f[6], dix[6], diy[6], dq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int p = 0; p < 6; p++) {
                 int ax, ay;
                 pair_axes(p, ax, ay);
                 const Bilin b = bilin(q[ax], q[ay], a.res[s][ax], a.res[s][ay]);
-                f[p] = sample(a.planes[s][p], b, a.res[s][ax], C, c);
+                if (want_dq) f[p] = sample_slopes(a.planes[s][p], b, a.res[s][ax], C, c, dix[p], diy[p]);
+                else f[p] = sample(a.planes[s][p], b, a.res[s][ax], C, c);
             }
             const float go = g.dL_dout[(size_t)n * (S * C) + s * C + c];
             float pre[7], suf[7];
@@ -245,11 +251,8 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS) k_hexplane_bwd_agg(EmdHexArgs
                         }
                 }
                 if (want_dq) {
-                    const float* pl = a.planes[s][p];
-                    const float nw = pl[((size_t)b.y0 * W + b.x0) * C + c], ne = pl[((size_t)b.y0 * W + b.x1) * C + c];
-                    const float sw = pl[((size_t)b.y1 * W + b.x0) * C + c], se = pl[((size_t)b.y1 * W + b.x1) * C + c];
-                    dq[ax] += gi * ((ne - nw) * (1.f - b.fy) + (se - sw) * b.fy) * b.cx;
-                    dq[ay] += gi * ((sw - nw) * (1.f - b.fx) + (se - ne) * b.fx) * b.cy;
+                    dq[ax] += gi * dix[p];
+                    dq[ay] += gi * diy[p];
                 }
             }
             if (want_dq) {
