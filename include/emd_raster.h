@@ -19,6 +19,17 @@
  *   emd_sh_forward / emd_sh_backward
  *                        <- gsplat spherical_harmonics(...)   OmniRe/models/nodes/rigid.py:584
  *
+ * and, further down, the callers either side of that path, each with its own block comment:
+ *   emd_sky_forward / backward          <- SkyCubeMap.forward + blend    S3Gaussian/scene/sky_cubemap.py:41-87, gaussian_renderer/__init__.py:299-301
+ *                                          EnvLight.forward              OmniRe/models/modules.py:174-208
+ *   emd_image_loss                      <- l1 + D-SSIM + depth + sky BCE S3Gaussian/utils/loss_utils.py:21-98, train.py:226-363
+ *   emd_hexplane_forward / backward     <- HexPlaneField.get_density     S3Gaussian/scene/hexplane.py:18-183
+ *   emd_temporal_embed_forward/backward <- get_temporal_embed            S3Gaussian/scene/deformation.py:208-221, OmniRe/models/nodes/rigid.py:150-164
+ *   emd_deform_input_forward/backward   <- get_embedder + get_deformation OmniRe/models/modules.py:318-366, nodes/deformable.py:35-47
+ *   emd_densification_stats             <- add_densification_stats       S3Gaussian/scene/gaussian_model.py:728-730, train.py:403-406
+ *   emd_adam_step                       <- optimizer.step()              S3Gaussian/scene/gaussian_model.py:188-201, train.py:428
+ *   emd_sh_grad_from_factors            (multi-GPU: rebuilds the SH gradient from all-gathered rank-one factors; no reference counterpart)
+ *
  * Conventions
  *   - plain C, no C++ types, no exceptions across the ABI; every pointer is a DEVICE
  *     pointer to contiguous fp32/int32 memory unless marked "host".
