@@ -65,6 +65,8 @@ class _TemporalEmbed(torch.autograd.Function):
             raise L.EmdError("temporal_embed needs tensors on a ROCm device; there is no CPU path")
         w = weight.detach().contiguous().float()
         tt = t.detach().reshape(-1)[:1].contiguous().float()
+        if tt.numel() == 0:
+            raise L.EmdError("temporal_embed: empty time tensor (the reference indexes t[0, 0], deformation.py:213)")
         tables = 1 if w.dim() == 2 else w.shape[0]
         rows, dim = w.shape[-2:]
         out = torch.empty(w.shape[:-2] + (dim,), device=w.device, dtype=torch.float32)

@@ -215,3 +215,19 @@ def test_deform_input_vs_oracle_unsorted_ids():
     np.testing.assert_allclose(h1.detach().cpu().numpy(), h0.detach().numpy(), rtol=0, atol=5e-6)
     np.testing.assert_allclose(h1.detach().cpu().numpy()[:, :9], h0.detach().numpy()[:, :9], rtol=1e-6, atol=1e-6)
     _close(e1.grad, e0.grad.numpy(), "embed grad")
+
+
+def test_deform_edge_sizes():
+    """One Gaussian works; zero Gaussians fail loudly (the reference indexes t[0, 0]); an empty encoder input is a no-op."""
+    from emd_amd import _lib as L
+    from emd_amd.deformation import DeformOptions, _DeformInput, deform_network
+    dev = torch.device("cuda", 0)
+    opt = DeformOptions(multires=[1], kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 8, "resolution": [4, 4, 4, 3]})
+    net = deform_network(opt).to(dev)
+    one = lambda *shape: torch.randn(*shape, device=dev)
+    out = net(one(1, 3), one(1, 3), one(1, 4), one(1, 1), one(1, 16, 3), torch.full((1, 1), 0.5, device=dev), one(1, 4), 100, 0, 0.1, True)
+    assert out[0].shape == (1, 3) and out[4].shape == (1, 16, 3) and all(torch.isfinite(o).all() for o in out[:5])
+    with pytest.raises(L.EmdError):
+        net(one(0, 3), one(0, 3), one(0, 4), one(0, 1), one(0, 16, 3), torch.zeros(0, 1, device=dev), one(0, 4), 100, 0, 0.1, True)
+    h0 = _DeformInput.apply(one(0, 3), torch.zeros(0, dtype=torch.int32, device=dev), one(2, 3), one(2, 16), torch.zeros(1, device=dev), 10, 10)
+    assert h0.shape == (0, 100)
