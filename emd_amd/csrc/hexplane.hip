@@ -40,23 +40,47 @@ __device__ __forceinline__ Bilin bilin(float cx, float cy, int W, int H) {
     return b;
 }
 
+// One axis of a tap.  A scale has four axes (x, y, z, t) and six planes that pair them: the un-normalise / clip / floor work is
+// done once per axis and shared by the three planes the axis takes part in (both lookup kernels are VALU-issue-bound --
+// rocprofv3 SQ_INSTS_VALU x 4 cycles fills the forward's whole run time -- and every lane of a point repeats this arithmetic).
+struct Tap1 { int i0, i1; float f, ds; };
+__device__ __forceinline__ Tap1 tap1(float coord, int size) {
+    Tap1 t;
+    float idx;
+    unnormalize(coord, size, idx, t.ds);
+    const float i0 = floorf(idx);
+    t.f = idx - i0;
+    t.i0 = (int)i0;
+    t.i1 = min(t.i0 + 1, size - 1);                                  // the out-of-range neighbour has weight 0
+    return t;
+}
+__device__ __forceinline__ Bilin make_bilin(const Tap1& tx, const Tap1& ty) {
+    Bilin b;
+    b.x0 = tx.i0; b.x1 = tx.i1; b.fx = tx.f; b.cx = tx.ds;
+    b.y0 = ty.i0; b.y1 = ty.i1; b.fy = ty.f; b.cy = ty.ds;
+    return b;
+}
+
 // plane pair p of (0,1),(0,2),(0,3),(1,2),(1,3),(2,3): first index -> width axis, second -> height axis
 __device__ __forceinline__ void pair_axes(int p, int& a, int& b) {
     const int A[6] = {0, 0, 0, 1, 1, 2}, B[6] = {1, 2, 3, 2, 3, 3};
     a = A[p]; b = B[p];
 }
 
+// element offset of tap (x, y), channel c, in a channel-last plane (32-bit: a plane holds < 2^31 floats, checked on the host)
+__device__ __forceinline__ uint32_t tap_at(int x, int y, int W, int C, int c) { return ((uint32_t)y * (uint32_t)W + (uint32_t)x) * (uint32_t)C + (uint32_t)c; }
+
 __device__ __forceinline__ float sample(const float* __restrict__ pl, const Bilin& t, int W, int C, int c) {
-    const float nw = pl[((size_t)t.y0 * W + t.x0) * C + c], ne = pl[((size_t)t.y0 * W + t.x1) * C + c];
-    const float sw = pl[((size_t)t.y1 * W + t.x0) * C + c], se = pl[((size_t)t.y1 * W + t.x1) * C + c];
+    const float nw = pl[tap_at(t.x0, t.y0, W, C, c)], ne = pl[tap_at(t.x1, t.y0, W, C, c)];
+    const float sw = pl[tap_at(t.x0, t.y1, W, C, c)], se = pl[tap_at(t.x1, t.y1, W, C, c)];
     // grid_sampler_2d: nw * (1-fx)(1-fy) + ne * fx (1-fy) + sw * (1-fx) fy + se * fx fy
     return nw * ((1.f - t.fx) * (1.f - t.fy)) + ne * (t.fx * (1.f - t.fy)) + sw * ((1.f - t.fx) * t.fy) + se * (t.fx * t.fy);
 }
 
 // the sample and its slopes d/d(ix), d/d(iy) (already times the border-clip masks) from one read of the four corners
 __device__ __forceinline__ float sample_slopes(const float* __restrict__ pl, const Bilin& t, int W, int C, int c, float& dix, float& diy) {
-    const float nw = pl[((size_t)t.y0 * W + t.x0) * C + c], ne = pl[((size_t)t.y0 * W + t.x1) * C + c];
-    const float sw = pl[((size_t)t.y1 * W + t.x0) * C + c], se = pl[((size_t)t.y1 * W + t.x1) * C + c];
+    const float nw = pl[tap_at(t.x0, t.y0, W, C, c)], ne = pl[tap_at(t.x1, t.y0, W, C, c)];
+    const float sw = pl[tap_at(t.x0, t.y1, W, C, c)], se = pl[tap_at(t.x1, t.y1, W, C, c)];
     // the clamped neighbour (x1 == x0 at the border) contributes no slope there: its weight is 0 and cx = 0
     dix = ((ne - nw) * (1.f - t.fy) + (se - sw) * t.fy) * t.cx;
     diy = ((sw - nw) * (1.f - t.fx) + (se - ne) * t.fx) * t.cy;
@@ -79,12 +103,15 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrad
     for (int s = 0; s < S; s++) {
         float f[6], dix[6], diy[6];
         Bilin t[6];
+        Tap1 axis[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) axis[k] = tap1(q[k], a.res[s][k]);
 #pragma unroll
         for (int p = 0; p < 6; p++) {
             int ax, ay;
             pair_axes(p, ax, ay);
-            const int W = a.res[s][ax], H = a.res[s][ay];
-            t[p] = bilin(q[ax], q[ay], W, H);
+            const int W = a.res[s][ax];
+            t[p] = make_bilin(axis[ax], axis[ay]);
             if (BWD && want_dq) f[p] = sample_slopes(a.planes[s][p], t[p], W, C, c, dix[p], diy[p]);   // one read of the corners serves both
             else f[p] = sample(a.planes[s][p], t[p], W, C, c);
         }
@@ -110,10 +137,10 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrad
                 const Bilin& b = t[p];
                 float* gp = g.dL_dplanes[s][p];
                 if (gp && gi != 0.f) {
-                    atomicAdd(gp + ((size_t)b.y0 * W + b.x0) * C + c, gi * ((1.f - b.fx) * (1.f - b.fy)));
-                    atomicAdd(gp + ((size_t)b.y0 * W + b.x1) * C + c, gi * (b.fx * (1.f - b.fy)));
-                    atomicAdd(gp + ((size_t)b.y1 * W + b.x0) * C + c, gi * ((1.f - b.fx) * b.fy));
-                    atomicAdd(gp + ((size_t)b.y1 * W + b.x1) * C + c, gi * (b.fx * b.fy));
+                    atomicAdd(gp + tap_at(b.x0, b.y0, W, C, c), gi * ((1.f - b.fx) * (1.f - b.fy)));
+                    atomicAdd(gp + tap_at(b.x1, b.y0, W, C, c), gi * (b.fx * (1.f - b.fy)));
+                    atomicAdd(gp + tap_at(b.x0, b.y1, W, C, c), gi * ((1.f - b.fx) * b.fy));
+                    atomicAdd(gp + tap_at(b.x1, b.y1, W, C, c), gi * (b.fx * b.fy));
                 }
                 if (want_dq) {
                     dq[ax] += gi * dix[p];
@@ -212,11 +239,14 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS) k_hexplane_bwd_agg(EmdHexArgs
             for (int k = 0; k < 3; k++) q[k] = (a.pts[3 * n + k] - a.aabb[k]) * (2.f / (a.aabb[3 + k] - a.aabb[k])) - 1.f;
             q[3] = a.times[n];
             float f[6], dix[6], diy[6], dq[4] = {0.f, 0.f, 0.f, 0.f};
+            Tap1 axis[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) axis[k] = tap1(q[k], a.res[s][k]);
 #pragma unroll
             for (int p = 0; p < 6; p++) {
                 int ax, ay;
                 pair_axes(p, ax, ay);
-                const Bilin b = bilin(q[ax], q[ay], a.res[s][ax], a.res[s][ay]);
+                const Bilin b = make_bilin(axis[ax], axis[ay]);
                 if (want_dq) f[p] = sample_slopes(a.planes[s][p], b, a.res[s][ax], C, c, dix[p], diy[p]);
                 else f[p] = sample(a.planes[s][p], b, a.res[s][ax], C, c);
             }
@@ -234,7 +264,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS) k_hexplane_bwd_agg(EmdHexArgs
                 win_shape(p, wbase, wx, wy);
                 const int W = a.res[s][ax];
                 const float gi = go * (pre[p] * suf[p + 1]);
-                const Bilin b = bilin(q[ax], q[ay], W, a.res[s][ay]);   // recomputed (a few VALU ops) rather than kept live for six planes
+                const Bilin b = make_bilin(axis[ax], axis[ay]);
                 float* gp = g.dL_dplanes[s][p];
                 if (gp && gi != 0.f) {
                     const int ox = anc[2 * p], oy = anc[2 * p + 1];
@@ -247,7 +277,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS) k_hexplane_bwd_agg(EmdHexArgs
                             const float v = gi * (wxs[i] * wys[j]);
                             const int cx = xs[i] - ox, cy = ys[j] - oy;
                             if ((unsigned)cx < (unsigned)wx && (unsigned)cy < (unsigned)wy) lds_add_f32(&win[(wbase + cy * wx + cx) * C + c], v);
-                            else atomicAdd(gp + ((size_t)ys[j] * W + xs[i]) * C + c, v);
+                            else atomicAdd(gp + tap_at(xs[i], ys[j], W, C, c), v);
                         }
                 }
                 if (want_dq) {
@@ -284,7 +314,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS) k_hexplane_bwd_agg(EmdHexArgs
             pair_axes(p, ax, ay);
             win_shape(p, wbase, wx, wy);
             const int local = cell - wbase, x = anc[2 * p] + local % wx, y = anc[2 * p + 1] + local / wx;
-            atomicAdd(g.dL_dplanes[s][p] + ((size_t)y * a.res[s][ax] + x) * C + c, v);   // (only cells a tap reached are non-zero)
+            atomicAdd(g.dL_dplanes[s][p] + tap_at(x, y, a.res[s][ax], C, c), v);   // (only cells a tap reached are non-zero)
         }
         __syncthreads();
     }
@@ -309,6 +339,10 @@ int check_hex(const EmdHexArgs* a, const char* who) {
         for (int p = 0; p < 6; p++) {
             if (!a->planes[s][p]) { emd_set_error("%s: plane %d of scale %d is null", who, p, s); return EMD_ERR_INVALID; }
             if (a->res[s][0] < 1 || a->res[s][1] < 1 || a->res[s][2] < 1 || a->res[s][3] < 1) { emd_set_error("%s: bad resolution", who); return EMD_ERR_INVALID; }
+            const int A_[6] = {0, 0, 0, 1, 1, 2}, B_[6] = {1, 2, 3, 2, 3, 3};
+            if ((int64_t)a->res[s][A_[p]] * a->res[s][B_[p]] * C >= ((int64_t)1 << 31)) {       // the kernels index a plane with 32 bits
+                emd_set_error("%s: plane %d of scale %d holds 2^31 floats or more", who, p, s); return EMD_ERR_INVALID;
+            }
         }
     return EMD_OK;
 }

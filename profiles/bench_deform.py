@@ -84,31 +84,47 @@ def reference_formulation():
 
 
 def run(fn, n):
+    """-> (forward ms, backward ms, ms per step): the split from events around each half with a sync per step (the forward's
+    includes whatever the host takes to issue its ~60 launches), the step time from n steps issued back to back."""
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     tf = tb = 0.0
-    for _ in range(n):
+
+    def one(split):
         for t_ in (point, opacity, shs, emb):
             t_.grad = None
         for p in net.parameters():
             p.grad = None
-        e[0].record()
+        if split:
+            e[0].record()
         loss = fn()
-        e[1].record()
+        if split:
+            e[1].record()
         loss.backward()
-        e[2].record()
-        torch.cuda.synchronize()
-        tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
-    return tf / n, tb / n
+        if split:
+            e[2].record()
+            torch.cuda.synchronize()
+            return e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+    for _ in range(n):
+        a, b = one(True)
+        tf += a; tb += b
+    torch.cuda.synchronize()
+    e[0].record()
+    for _ in range(n):
+        one(False)
+    e[1].record()
+    torch.cuda.synchronize()
+    return tf / n, tb / n, e[0].elapsed_time(e[1]) / n
 
 
 run(hip_step, 2)
-hf, hb = run(hip_step, 10)
+hf, hb, hstep = run(hip_step, 10)
 # parity of the two formulations on the spot (values of the loss and of the table / offset gradients)
 lv = float(hip_step())
 ref = reference_formulation()
 lr = float(ref())
 run(ref, 1)
-rf, rb = run(ref, 3)
+rf, rb, rstep = run(ref, 3)
 print(json.dumps({"op": "S3Gaussian deform_network forward / backward, reference configuration, run-script flags", "N": N,
-                  "hip_path_forward_ms": round(hf, 3), "hip_path_backward_ms": round(hb, 3), "reference_formulation_forward_ms": round(rf, 3),
+                  "hip_path_step_ms": round(hstep, 3), "hip_path_forward_ms": round(hf, 3), "hip_path_backward_ms": round(hb, 3),
+                  "reference_formulation_step_ms": round(rstep, 3), "reference_formulation_forward_ms": round(rf, 3),
                   "reference_formulation_backward_ms": round(rb, 3), "loss_hip_path": lv, "loss_reference_formulation": lr}))
