@@ -32,6 +32,8 @@ Fixtures (all fp32):
                     iterations with seeded gradients and update_learning_rate      S3Gaussian/scene/gaussian_model.py:181-243, train.py:195,428
   or_deform.npz     DeformableNodes.get_deformation through ConditionalDeformNetwork (+ gradients)
                                                    OmniRe/models/nodes/deformable.py:35-47, models/modules.py:318-366,411-457
+  or_nodes.npz      RigidNodes.get_gaussians and DeformableNodes.get_gaussians (+ gradients), with a recording stand-in for the absent gsplat
+                    spherical_harmonics             OmniRe/models/nodes/rigid.py:570-615, models/nodes/deformable.py:49-114
   or_envlight.npz   EnvLight.forward with the same stand-in                OmniRe/models/modules.py:174-208
   or_rigid.npz      RigidNodes.transform_means / transform_quats / opacity mask (+ gradients), train and
                     test-interpolation branches, non-zero track heads  OmniRe/models/nodes/rigid.py:42-46,150-246,478-615
@@ -618,6 +620,98 @@ def gen_or_deform():
     unload(["models", "utils", "datasets"])
 
 
+def gen_or_nodes():
+    """RigidNodes.get_gaussians and DeformableNodes.get_gaussians of the reference on CPU (+ gradients).  The absent gsplat
+    `spherical_harmonics` is a recording stand-in that evaluates oracle/torch_ref.eval_sh on the arguments the reference passes."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import torch_ref as tr
+    sys.path.pop(0)
+    sys.path.insert(0, os.path.join(REF, "OmniRe"))
+    import pytorch3d.transforms as p3t
+    p3t.matrix_to_quaternion = lambda M: _matrix_to_quaternion(M).reshape(*M.shape[:-2], 4)
+    sh_calls = []
+
+    def sh_standin(degree, dirs, coeffs):
+        sh_calls.append(dict(degree=int(degree), dirs_requires_grad=bool(dirs.requires_grad)))
+        return tr.eval_sh(int(degree), coeffs.transpose(1, 2), dirs)
+
+    with _CpuMode():
+        from models.gaussians import basics
+        basics.matrix_to_quaternion = p3t.matrix_to_quaternion
+        import models.nodes.rigid as rigid_mod
+        import models.nodes.deformable as deform_mod
+        rigid_mod.matrix_to_quaternion = p3t.matrix_to_quaternion
+        rigid_mod.spherical_harmonics = deform_mod.spherical_harmonics = sh_standin
+        g = torch.Generator().manual_seed(950)
+        F_, A, P = 6, 3, 30
+        c2w = torch.eye(4)
+        c2w[:3, 3] = torch.tensor([2.0, -1.0, 1.6])
+        cam = types.SimpleNamespace(camtoworlds=c2w)
+        out = dict(camera_center=c2w[:3, 3].clone(), num_frames=F_)
+        for cls_name, cls in (("rigid", rigid_mod.RigidNodes), ("deformable", deform_mod.DeformableNodes)):
+            ctrl = _Cfg(sh_degree=3, gaussian_embedding_dim=4, temporal_embedding_dim=32, no_gaussian_embedding_dim=False,
+                        no_temporal_embedding_dim=False, no_coarse_deform=False, no_fine_deform=False, no_c2f_temporal_embedding=False,
+                        min_embeddings=30, max_embeddings=150, c2f_temporal_iter=25000, no_apply_embed_shs=True, no_apply_embed_track=False,
+                        sh_degree_interval=1000, use_deformgs_for_nonrigid=True, use_deformgs_after=100, stop_optimizing_canonical_xyz=True)
+            ctrl.get = lambda k, d=None, c=ctrl: dict.get(c, k, d)
+            nets = _Cfg(D=4, W=32, embed_dim=8, x_multires=6, t_multires=4, deform_quat=True, deform_scale=False)
+            torch.manual_seed(951)
+            node = cls(class_name=cls_name, ctrl=ctrl, reg=_Cfg(), networks=nets, scene_scale=30.0, scene_origin=torch.zeros(3),
+                       num_train_images=10, device=torch.device("cpu"))
+            inst = {}
+            for a in range(A):
+                yaw = torch.linspace(0.2 * (a + 1), 0.2 * (a + 1) + 0.4, F_)
+                poses = torch.eye(4).repeat(F_, 1, 1)
+                poses[:, 0, 0], poses[:, 0, 1], poses[:, 1, 0], poses[:, 1, 1] = torch.cos(yaw), -torch.sin(yaw), torch.sin(yaw), torch.cos(yaw)
+                poses[:, :3, 3] = torch.stack([8.0 + 3 * a + torch.arange(F_) * 0.5, torch.full((F_,), -2.0 + 2 * a), torch.full((F_,), 0.9)], 1)
+                fv = torch.ones(F_, dtype=torch.bool)
+                if a == 2:
+                    fv[3] = False
+                size = torch.tensor([0.7 + 0.1 * a, 0.6, 1.7 + 0.05 * a])
+                inst[a] = dict(class_name="ped", pts=(torch.rand(P, 3, generator=g) - 0.5) * size, colors=torch.rand(P, 3, generator=g), poses=poses,
+                               size=size, frame_info=fv, num_pts=P)
+            node.create_from_pcd(inst)
+            node.register_normalized_timestamps(torch.linspace(0, 1, F_))
+            node._features_rest.data.normal_(0, 0.2, generator=g)
+            node._quats.data = torch.randn(node._quats.shape, generator=g)
+            node._opacities.data = torch.randn(node._opacities.shape, generator=g)
+            node.instances_quats.data += 0.05 * torch.randn(node.instances_quats.shape, generator=g)
+            if cls_name == "deformable":
+                for prm in node.deform_network.parameters():
+                    prm.data = torch.randn(prm.shape, generator=g) * (0.15 if prm.dim() > 1 else 0.03)
+            node.step, node.cur_frame, node.in_test_set = 12000, 3, False
+            sh_calls.clear()
+            gs = node.get_gaussians(cam)
+            gouts = {k: torch.randn(v.shape, generator=g) for k, v in gs.items()}
+            sum((gs[k] * gouts[k]).sum() for k in gs).backward()
+            pre = cls_name + "_"
+            out.update({pre + "means": node._means.data, pre + "quats": node._quats.data, pre + "opacity_logits": node._opacities.data,
+                        pre + "log_scales": node._scales.data, pre + "features_dc": node._features_dc.data, pre + "features_rest": node._features_rest.data,
+                        pre + "point_ids": node.point_ids[:, 0].to(torch.int32), pre + "instances_quats": node.instances_quats.data,
+                        pre + "instances_trans": node.instances_trans.data, pre + "instances_fv": node.instances_fv, pre + "frame": node.cur_frame,
+                        pre + "step": node.step, pre + "instances_size": node.instances_size, pre + "sh_degree_used": sh_calls[0]["degree"],
+                        pre + "sh_dirs_requires_grad": int(sh_calls[0]["dirs_requires_grad"])})
+            for k, v in gs.items():
+                out[pre + "out" + k] = v
+                out[pre + "gout" + k] = gouts[k]
+            for name in ("_means", "_quats", "_opacities", "_scales", "_features_dc", "_features_rest", "instances_quats", "instances_trans"):
+                gr = getattr(node, name).grad
+                out[pre + "grad" + name] = gr if gr is not None else torch.zeros_like(getattr(node, name))
+            if cls_name == "deformable":
+                out[pre + "instances_embedding"] = node.instances_embedding.data
+                out[pre + "grad_instances_embedding"] = node.instances_embedding.grad
+                out[pre + "t"] = node.normalized_timestamps[node.cur_frame]
+                for k, v in node.deform_network.state_dict().items():
+                    out[pre + "sd_" + k] = v
+                for n_, prm in node.deform_network.named_parameters():
+                    out[pre + "gsd_" + n_] = prm.grad
+                for k, v in nets.items():
+                    out[pre + "net_" + k] = int(v)
+        save("or_nodes.npz", **out)
+    sys.path.pop(0)
+    unload(["models", "utils", "datasets"])
+
+
 def _matrix_to_quaternion(M):
     """Stand-in for pytorch3d.transforms.matrix_to_quaternion (only used at RigidNodes init, rigid.py:271)."""
     M = M.reshape(-1, 3, 3)
@@ -752,3 +846,4 @@ if __name__ == "__main__":
     gen_omnire()
     gen_or_envlight()
     gen_or_deform()
+    gen_or_nodes()
