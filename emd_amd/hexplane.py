@@ -153,7 +153,9 @@ class HexPlaneField(nn.Module):
         aggregates their gradients in LDS before they reach HBM (hexplane.hip).  Purely a speed matter: every order gives the
         same sums up to float rounding, so a stale order (Gaussians moved, or were replaced at equal count) is harmless."""
         n = pts.shape[0]
-        if n < self.reorder_min_points or pts.device.type != "cuda":
+        # the aggregating backward exists for 16 and 32 channels; the direct-atomic kernel is SLOWER on ordered points (many CUs
+        # queue on the same cache lines), so other widths keep the caller's order
+        if n < self.reorder_min_points or pts.device.type != "cuda" or self.grids[0][0].shape[1] not in (16, 32):
             return None
         cache = getattr(self, "_order_cache", None)
         if cache is None or cache[0] != n or cache[1] >= self.reorder_every or cache[2].device != pts.device:
