@@ -11,8 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from emd_amd import dp, scenes, RasterConfig  # noqa: E402
 from emd_amd.model import StreetGaussians, render, l1_loss  # noqa: E402
 
-torch.cuda.set_device(0)
-dev = torch.device("cuda", 0)
+local = 0 if os.environ.get("EMD_BENCH_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))   # one rank per GPU over RCCL
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
 rank, world, _ = dp.init_from_env()
 N, H, W = 40000, 96, 128
 scene = scenes.add_actors(scenes.make_static_scene(N, seed=0), num_actors=4, pts_per_actor=2000, num_frames=6, seed=1)

@@ -40,3 +40,22 @@ def test_factored_sh_exchange_equals_dense_allreduce_two_ranks():
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
     assert any(l.startswith("OK ") for l in p.stdout.splitlines()), p.stdout[-1500:]
+
+
+def test_bench_and_factored_exchange_over_rccl_when_two_gpus_are_present():
+    """On a node with >= 2 GPUs: the same two checks over the real RCCL backend, one rank per GPU (skipped on 1-GPU boxes)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("EMD_BENCH_SHARE_GPU", "EMD_DP_BACKEND")}
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    p = subprocess.run(launch + ["--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                                 "--no-cpu-baseline", "--gaussians", "60000", "--height", "128", "--width", "192"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    p = subprocess.run(launch + ["--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_factored_check.py")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    assert any(l.startswith("OK ") for l in p.stdout.splitlines()), p.stdout[-1500:]
