@@ -267,18 +267,29 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS) k_hexplane_bwd_agg(EmdHexArgs
                 const Bilin b = make_bilin(axis[ax], axis[ay]);
                 float* gp = g.dL_dplanes[s][p];
                 if (gp && gi != 0.f) {
-                    const int ox = anc[2 * p], oy = anc[2 * p + 1];
-                    const int xs[2] = {b.x0, b.x1}, ys[2] = {b.y0, b.y1};
-                    const float wxs[2] = {1.f - b.fx, b.fx}, wys[2] = {1.f - b.fy, b.fy};
+                    const int cx0 = b.x0 - anc[2 * p], cy0 = b.y0 - anc[2 * p + 1], cx1 = b.x1 - anc[2 * p], cy1 = b.y1 - anc[2 * p + 1];
+                    const float w00 = gi * ((1.f - b.fx) * (1.f - b.fy)), w10 = gi * (b.fx * (1.f - b.fy));
+                    const float w01 = gi * ((1.f - b.fx) * b.fy), w11 = gi * (b.fx * b.fy);
+                    if ((unsigned)cx1 < (unsigned)wx && (unsigned)cy1 < (unsigned)wy && cx0 >= 0 && cy0 >= 0) {
+                        // the whole 2 x 2 footprint lies in the window (the anchor is the block's smallest tap, so c*0 >= 0): one
+                        // address, three strides (0 where the neighbour was clamped onto the same cell at the border; its weight is 0)
+                        float* w0 = &win[(wbase + cy0 * wx + cx0) * C + c];
+                        const int sx = (cx1 - cx0) * C, sy = (cy1 - cy0) * wx * C;
+                        lds_add_f32(w0, w00);
+                        lds_add_f32(w0 + sx, w10);
+                        lds_add_f32(w0 + sy, w01);
+                        lds_add_f32(w0 + sy + sx, w11);
+                    } else {
+                        const int xs[2] = {b.x0, b.x1}, ys[2] = {b.y0, b.y1}, cxs[2] = {cx0, cx1}, cys[2] = {cy0, cy1};
+                        const float ws[4] = {w00, w10, w01, w11};
 #pragma unroll
-                    for (int j = 0; j < 2; j++)
+                        for (int j = 0; j < 2; j++)
 #pragma unroll
-                        for (int i = 0; i < 2; i++) {
-                            const float v = gi * (wxs[i] * wys[j]);
-                            const int cx = xs[i] - ox, cy = ys[j] - oy;
-                            if ((unsigned)cx < (unsigned)wx && (unsigned)cy < (unsigned)wy) lds_add_f32(&win[(wbase + cy * wx + cx) * C + c], v);
-                            else atomicAdd(gp + tap_at(xs[i], ys[j], W, C, c), v);
-                        }
+                            for (int i = 0; i < 2; i++) {
+                                if ((unsigned)cxs[i] < (unsigned)wx && (unsigned)cys[j] < (unsigned)wy) lds_add_f32(&win[(wbase + cys[j] * wx + cxs[i]) * C + c], ws[2 * j + i]);
+                                else atomicAdd(gp + tap_at(xs[i], ys[j], W, C, c), ws[2 * j + i]);
+                            }
+                    }
                 }
                 if (want_dq) {
                     dq[ax] += gi * dix[p];
