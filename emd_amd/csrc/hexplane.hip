@@ -163,6 +163,57 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrad
     }
 }
 
+// ---- forward, two-phase ---------------------------------------------------------------------------------------------------
+// With lane = channel every lane of a point repeats the point's scalar work (un-normalise, clip, floor, tap offsets, bilinear
+// weights: ~125 of the ~220 VALU instructions per two points and scale), and the one-phase kernel above is VALU-issue-bound.
+// Here a workgroup takes 64 points; per scale, phase A gives one THREAD to each (point, plane) pair, which writes the four tap
+// offsets and weights to LDS; phase B is the lane = channel gather, reading them back as broadcast LDS loads: 4 loads, 4 FMAs and
+// a few adds per plane.
+#define HEX_F2_POINTS 64
+__global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd2(EmdHexArgs a) {
+    __shared__ uint4 s_off[HEX_F2_POINTS * 6];          // element offsets of the 2 x 2 taps (without the channel)
+    __shared__ float4 s_w[HEX_F2_POINTS * 6];           // their bilinear weights
+    __shared__ int s_n[HEX_F2_POINTS];
+    const int C = a.channels, S = a.num_scales, tid = threadIdx.x;
+    const int group = tid / C, c = tid % C, groups = EMD_BLOCK / C;
+    const long first = (long)blockIdx.x * HEX_F2_POINTS;
+    const int count = (int)min((long)HEX_F2_POINTS, (long)a.num_points - first);
+    if (tid < HEX_F2_POINTS) s_n[tid] = tid < count ? (a.order ? a.order[first + tid] : (int)(first + tid)) : 0;
+    __syncthreads();
+    for (int s = 0; s < S; s++) {
+        // phase A: item = (point, plane)
+        for (int item = tid; item < HEX_F2_POINTS * 6; item += EMD_BLOCK) {
+            const int j = item / 6, p = item - 6 * j;
+            if (j >= count) continue;
+            const long n = s_n[j];
+            int ax, ay;
+            pair_axes(p, ax, ay);
+            const float qx = (a.pts[3 * n + ax] - a.aabb[ax]) * (2.f / (a.aabb[3 + ax] - a.aabb[ax])) - 1.f;     // ax < 3 always
+            const float qy = ay < 3 ? (a.pts[3 * n + ay] - a.aabb[ay]) * (2.f / (a.aabb[3 + ay] - a.aabb[ay])) - 1.f : a.times[n];
+            const int W = a.res[s][ax];
+            const Tap1 tx = tap1(qx, W), ty = tap1(qy, a.res[s][ay]);
+            s_off[item] = make_uint4(tap_at(tx.i0, ty.i0, W, C, 0), tap_at(tx.i1, ty.i0, W, C, 0), tap_at(tx.i0, ty.i1, W, C, 0),
+                                     tap_at(tx.i1, ty.i1, W, C, 0));
+            // grid_sampler_2d: nw * (1-fx)(1-fy) + ne * fx (1-fy) + sw * (1-fx) fy + se * fx fy
+            s_w[item] = make_float4((1.f - tx.f) * (1.f - ty.f), tx.f * (1.f - ty.f), (1.f - tx.f) * ty.f, tx.f * ty.f);
+        }
+        __syncthreads();
+        // phase B: lane = channel
+        for (int j = group; j < count; j += groups) {
+            float prod = 1.f;
+#pragma unroll
+            for (int p = 0; p < 6; p++) {
+                const uint4 o = s_off[j * 6 + p];
+                const float4 w = s_w[j * 6 + p];
+                const float* __restrict__ pl = a.planes[s][p] + c;
+                prod = prod * (pl[o.x] * w.x + pl[o.y] * w.y + pl[o.z] * w.z + pl[o.w] * w.w);
+            }
+            a.out[(size_t)s_n[j] * (S * C) + s * C + c] = prod;
+        }
+        __syncthreads();
+    }
+}
+
 
 // ---- backward with in-LDS aggregation -----------------------------------------------------------------------------------
 // The plain backward issues one row of float atomics per tap (N x 24 planes x 4 taps); the L2 atomic units retire roughly
@@ -365,11 +416,8 @@ extern "C" int emd_hexplane_forward(const EmdHexArgs* a, void* hip_stream) {
     if (rc) return rc;
     if (!a->out) { emd_set_error("hexplane_forward: null output"); return EMD_ERR_INVALID; }
     if (a->num_points == 0) return EMD_OK;
-    const int per_block = EMD_BLOCK / a->channels;
-    EmdHexGrads g;
-    memset((void*)&g, 0, sizeof(g));
-    hipLaunchKernelGGL(k_hexplane<false>, dim3((unsigned)((a->num_points + per_block - 1) / per_block)), dim3(EMD_BLOCK), 0,
-                       (hipStream_t)hip_stream, *a, g);
+    hipLaunchKernelGGL(k_hexplane_fwd2, dim3((unsigned)((a->num_points + HEX_F2_POINTS - 1) / HEX_F2_POINTS)), dim3(EMD_BLOCK), 0,
+                       (hipStream_t)hip_stream, *a);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }
