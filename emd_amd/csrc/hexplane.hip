@@ -7,7 +7,9 @@
 // consecutive lanes (lane = channel): every tap is one coalesced C x 4-byte read, the product over the six planes and
 // the concat over scales happen in registers, and the backward scatters C consecutive floats per tap (the row shape
 // float atomics like).  One launch forward, one backward, for all scales.
-// HBM / L2-bound gather-scatter; no reuse to exploit beyond the caches (points arrive unordered).
+// Three kernels: k_hexplane_fwd2 (two-phase forward, at the L2 -> CU gather rate), k_hexplane_bwd_agg (backward that aggregates
+// plane gradients in LDS over a spatially coherent visiting order; VALU-issue-bound) and k_hexplane_bwd (direct float atomics,
+// bound by the L2 atomic units; used when no order is given).
 #include <limits.h>
 #include <string.h>
 
@@ -87,8 +89,8 @@ __device__ __forceinline__ float sample_slopes(const float* __restrict__ pl, con
     return nw * ((1.f - t.fx) * (1.f - t.fy)) + ne * (t.fx * (1.f - t.fy)) + sw * ((1.f - t.fx) * t.fy) + se * (t.fx * t.fy);
 }
 
-template <bool BWD>
-__global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrads g) {
+// direct-atomic backward: one row of float atomics per tap (used when the caller gives no visiting order)
+__global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_bwd(EmdHexArgs a, EmdHexGrads g) {
     const int C = a.channels, S = a.num_scales;
     const int group = threadIdx.x / C, c = threadIdx.x % C, per_block = EMD_BLOCK / C;
     const long slot = (long)blockIdx.x * per_block + group;
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrad
     for (int k = 0; k < 3; k++) q[k] = (a.pts[3 * n + k] - a.aabb[k]) * (2.f / (a.aabb[3 + k] - a.aabb[k])) - 1.f;
     q[3] = a.times[n];
     float dq[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool want_dq = BWD && (g.dL_dpts || g.dL_dtimes);
+    const bool want_dq = g.dL_dpts || g.dL_dtimes;
     for (int s = 0; s < S; s++) {
         float f[6], dix[6], diy[6];
         Bilin t[6];
@@ -112,15 +114,10 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane(EmdHexArgs a, EmdHexGrad
             pair_axes(p, ax, ay);
             const int W = a.res[s][ax];
             t[p] = make_bilin(axis[ax], axis[ay]);
-            if (BWD && want_dq) f[p] = sample_slopes(a.planes[s][p], t[p], W, C, c, dix[p], diy[p]);   // one read of the corners serves both
+            if (want_dq) f[p] = sample_slopes(a.planes[s][p], t[p], W, C, c, dix[p], diy[p]);   // one read of the corners serves both
             else f[p] = sample(a.planes[s][p], t[p], W, C, c);
         }
-        if (!BWD) {
-            float prod = 1.f;
-#pragma unroll
-            for (int p = 0; p < 6; p++) prod = prod * f[p];
-            a.out[(size_t)n * (S * C) + s * C + c] = prod;
-        } else {
+        {
             const float go = g.dL_dout[(size_t)n * (S * C) + s * C + c];
             float pre[7], suf[7];
             pre[0] = 1.f; suf[6] = 1.f;
@@ -432,7 +429,7 @@ extern "C" int emd_hexplane_backward(const EmdHexArgs* a, const EmdHexGrads* g, 
     else if (a->order && a->channels == 16) launch_bwd_agg<16>(a, g, (hipStream_t)hip_stream);
     else {
         const int per_block = EMD_BLOCK / a->channels;
-        hipLaunchKernelGGL(k_hexplane<true>, dim3((unsigned)((a->num_points + per_block - 1) / per_block)), dim3(EMD_BLOCK), 0,
+        hipLaunchKernelGGL(k_hexplane_bwd, dim3((unsigned)((a->num_points + per_block - 1) / per_block)), dim3(EMD_BLOCK), 0,
                            (hipStream_t)hip_stream, *a, *g);
     }
     EMD_LAUNCH_CHECK();
