@@ -48,7 +48,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, "golden")
+OUT = os.environ.get("EMD_GOLDEN_OUT") or os.path.join(HERE, "golden")     # (the regeneration test writes elsewhere)
 REF = "/root/reference"
 
 ABSENT = {"diff_gauss", "plyfile", "simple_knn", "open3d", "nvdiffrast", "cv2", "imageio", "tkinter", "tinycudann",
