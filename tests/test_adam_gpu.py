@@ -122,3 +122,20 @@ def test_adam_refuses_cpu_and_unsupported_options():
     p.grad = torch.ones(3)
     with pytest.raises(L.EmdError):
         Adam([p]).step()
+
+
+def test_adam_full_size_against_torch():
+    """The largest parameter of the headline configuration (2 M x 16 x 3 SH coefficients, 96 M elements) over three steps."""
+    from emd_amd.optim import Adam
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    p0 = torch.randn(2_000_000, 16, 3, device=dev, generator=gen)
+    a, b = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
+    o1, o2 = Adam([{"params": [a], "lr": 2.5e-3}], lr=0.0, eps=1e-15), torch.optim.Adam([{"params": [b], "lr": 2.5e-3}], lr=0.0, eps=1e-15)
+    for _ in range(3):
+        gr = torch.randn(p0.shape, device=dev, generator=gen)
+        a.grad, b.grad = gr, gr.clone()
+        o1.step(); o2.step()
+    d = (a.detach() - b.detach()).abs().max()
+    assert float(d) <= 2e-6 * float(b.detach().abs().max()), float(d)
+    assert float((o1.state[a]["exp_avg_sq"] - o2.state[b]["exp_avg_sq"]).abs().max()) <= 2e-6 * float(o2.state[b]["exp_avg_sq"].max())

@@ -148,3 +148,34 @@ def test_channel_last_planes_train_and_load_reference_checkpoints():
     after = [p for gp in field.grids for p in gp]
     assert all((a - b).abs().max() > 0 for a, b in zip(after, before))
     assert all(p.is_contiguous(memory_format=torch.channels_last) for p in after)
+
+
+def test_hexplane_full_size_partition_of_unity():
+    """2 M points, the reference's plane configuration: with every plane constant (value v_p) the features are the product of the
+    constants whatever the taps (bilinear weights sum to one), and the gradient of plane p sums to  sum(gout) * prod_{q != p} v_q  --
+    no tap lost or counted twice by the aggregating backward, its windows, fallbacks and flushes, at the headline size."""
+    from emd_amd.hexplane import HexPlaneField
+    from emd_amd.scenes import make_static_scene
+    dev = torch.device("cuda", 0)
+    cfg = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32, "resolution": [64, 64, 64, 25]}
+    field = HexPlaneField(1.6, cfg, [1, 2, 4, 8]).to(dev)
+    field.set_aabb([120.0, 30.0, 10.0], [0.0, -30.0, -2.0])
+    vals = [1.25, 0.5, 2.0, 0.75, 1.5, 0.8]
+    for gp in field.grids:
+        for prm, v in zip(gp, vals):
+            prm.data.fill_(v)
+    N = 2_000_000
+    pts = make_static_scene(N).means.to(dev)
+    feat = field(pts, torch.full((N, 1), 0.37, device=dev))
+    want = float(np.prod(vals))
+    assert feat.shape == (N, 128) and float((feat.detach() - want).abs().max()) <= 4e-6 * want
+    gout = torch.rand(N, 128, generator=torch.Generator().manual_seed(0)).to(dev)
+    feat.backward(gout)
+    assert field._order_cache is not None                       # the Morton order / aggregating kernel was used
+    for s, gp in enumerate(field.grids):
+        total = float(gout[:, s * 32:(s + 1) * 32].double().sum())
+        for p, prm in enumerate(gp):
+            expect = total * want / vals[p]
+            got = float(prm.grad.double().sum())
+            assert abs(got - expect) <= 2e-5 * abs(expect), (s, p, got, expect)
+            assert float(prm.grad.min()) >= 0.0                 # non-negative contributions only
