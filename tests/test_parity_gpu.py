@@ -256,3 +256,58 @@ def test_parity_at_bench_resolution():
     hip = run_hip(case, backward=True)
     compare_forward(hip, orc, tol=IMAGE_TOL)
     compare_backward(hip, orc, rtol=GRAD_RTOL)
+
+
+def test_one_rasterizer_object_called_three_times_in_one_graph():
+    """The reference re-invokes the same rasterizer object up to nine times per render() -- main pass, feature passes with
+    colors_precomp, decomposition passes on a boolean-mask subset (gaussian_renderer/__init__.py:145,172,247) -- and
+    back-propagates through all of them at once.  The calls must not disturb each other's saved state: images equal the
+    single-call images bit for bit, and the gradients of the shared tensors equal the sum of the single-call gradients."""
+    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer, RasterConfig
+    case = make_case(n=6000, H=80, W=112, seed=77)
+    cam, dev = case["cam"], torch.device("cuda", 0)
+    rs = GaussianRasterizationSettings(image_height=case["H"], image_width=case["W"], tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                                       bg=case["bg"].to(dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(dev),
+                                       projmatrix=cam.full_proj_transform.to(dev), sh_degree=case["sh_degree"],
+                                       campos=cam.camera_center.to(dev), prefiltered=False, debug=False)
+    RasterConfig.compute_normal = True
+    gen = torch.Generator().manual_seed(5)
+    feat0 = torch.rand(case["N"], 3, generator=gen)
+    mask = (torch.arange(case["N"]) % 3 == 0).to(dev)
+    G = [torch.randn(3, case["H"], case["W"], generator=gen).to(dev) for _ in range(3)]
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+
+    def leaves():
+        t = {k: case[k].to(dev).clone().requires_grad_(True) for k in names}
+        t["feat"] = feat0.to(dev).clone().requires_grad_(True)
+        t["means2D"] = torch.zeros(case["N"], 3, device=dev, requires_grad=True)
+        return t
+
+    def call(rast, t, which):
+        common = dict(opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], cov3Ds_precomp=None, extra_attrs=None)
+        if which == 0:
+            return rast(means3D=t["means3D"], means2D=t["means2D"], shs=t["shs"], colors_precomp=None, **common)[0]
+        if which == 1:
+            return rast(means3D=t["means3D"], means2D=t["means2D"], shs=None, colors_precomp=t["feat"], **common)[0]
+        return rast(means3D=t["means3D"][mask], means2D=t["means2D"][mask], shs=t["shs"][mask], colors_precomp=None,
+                    opacities=t["opacities"][mask], scales=t["scales"][mask], rotations=t["rotations"][mask], cov3Ds_precomp=None,
+                    extra_attrs=None)[0]
+
+    singles, sums = [], None
+    for w in range(3):
+        t = leaves()
+        img = call(GaussianRasterizer(rs), t, w)
+        (img * G[w]).sum().backward()
+        singles.append(img.detach())
+        gr = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in t.items()}
+        sums = gr if sums is None else {k: sums[k] + gr[k] for k in gr}
+    t = leaves()
+    rast = GaussianRasterizer(rs)                              # ONE object
+    imgs = [call(rast, t, w) for w in range(3)]
+    sum((imgs[w] * G[w]).sum() for w in range(3)).backward()
+    for w in range(3):
+        assert torch.equal(imgs[w].detach(), singles[w]), w
+    for k, v in t.items():
+        ref = sums[k]
+        err = float((v.grad - ref).abs().max())
+        assert err <= 1e-4 * max(float(ref.abs().max()), 1e-12), (k, err)
