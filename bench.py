@@ -270,7 +270,7 @@ def main():
                        "parallelism": f"view-parallel dp{world}", "count_readback": bool(args.sync_count),
                        "gradient_exchange": ("none (1 GPU)" if world == 1 else
                                              "SH gradient as rank-one factors: all-gather of 12 B per Gaussian and rank, dense average "
-                                             "rebuilt locally; RCCL all-reduce (AVG) of the remaining 44 B per Gaussian + actor poses")},
+                                             "rebuilt locally; one RCCL all-reduce (AVG) of the remaining 44 B per Gaussian (one slab) + actor poses")},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:      # the CPU leg is timed on rank 0 of the 1-GPU run only

@@ -106,6 +106,15 @@ def exchange_sh_gradient(sh_param, means3D, campos_local, sh_degree, actor_ids=N
                    dist.all_gather_into_tensor(campos, campos_local.reshape(1, 3).to(g_local.device, torch.float32).contiguous(), async_op=True)]
         if also_allreduce is not None:
             others = [p.grad for p in also_allreduce if p is not sh_param and p.grad is not None]
+            # the rasterizer hands out its four small gradients as views of one slab (44 B per Gaussian): when autograd kept those
+            # views as the parameters' .grad, one collective over the slab replaces four
+            slab = GaussianRasterizer.last_grad_slab
+            if slab is not None:
+                base = slab.untyped_storage().data_ptr()
+                inside = [g for g in others if g.untyped_storage().data_ptr() == base]
+                if inside and sum(g.numel() for g in inside) == slab.numel():
+                    others = [g for g in others if g.untyped_storage().data_ptr() != base] + [slab]
+            exchange_sh_gradient.last_num_allreduce = len(others)
             others.sort(key=lambda g: -g.numel())
             gloo = dist.get_backend() == "gloo"
             op = dist.ReduceOp.SUM if (gloo or not average) else dist.ReduceOp.AVG

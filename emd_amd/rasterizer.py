@@ -198,14 +198,23 @@ class _Rasterize(torch.autograd.Function):
         g_depth = None if g_depth is None else g_depth.contiguous().float()
         g_alpha = None if g_alpha is None else g_alpha.contiguous().float()
         g_normal = None if (g_normal is None or not (flags & L.FLAG_NORMAL)) else g_normal.contiguous().float()
-        d_means3D, d_means2D = z(N, 3), z(N, 3)
+        d_means2D = z(N, 3)
+        # the four small per-Gaussian gradients of the usual call (means, scales, rotations, opacities: 44 B per Gaussian) are carved
+        # from ONE buffer: view-parallel training all-reduces that slab with a single collective (dp.exchange_sh_gradient)
+        slab = None
+        if has_sr and opacities.numel() == N:
+            slab = z(N * 11)
+            d_means3D, d_sc_, d_rot_, d_op_ = slab[:3 * N].view(N, 3), slab[3 * N:6 * N].view(N, 3), slab[6 * N:10 * N].view(N, 4), \
+                slab[10 * N:].view(opacities.shape)
+        else:
+            d_means3D = z(N, 3)
         factored = has_shs and RasterConfig.factored_sh_grad
         d_shs = z(N, M, 3) if (has_shs and not factored) else None
         d_shc = z(N, 3) if factored else None
         d_col = z(N, 3) if has_col else None
-        d_op = z(*opacities.shape)
-        d_sc = z(N, 3) if has_sr else None
-        d_rot = z(N, 4) if has_sr else None
+        d_op = d_op_ if slab is not None else z(*opacities.shape)
+        d_sc = (d_sc_ if slab is not None else z(N, 3)) if has_sr else None
+        d_rot = (d_rot_ if slab is not None else z(N, 4)) if has_sr else None
         d_cov = z(N, 6) if has_cov else None
         d_pose = z(*actor_pose.shape) if has_pose else None
         d_rdx = z(N, 3) if has_rdx else None
@@ -237,6 +246,7 @@ class _Rasterize(torch.autograd.Function):
         if d_abs is not None:
             GaussianRasterizer.last_absgrad = d_abs
         GaussianRasterizer.last_sh_color_grad = d_shc       # None unless RasterConfig.factored_sh_grad
+        GaussianRasterizer.last_grad_slab = slab
         return (d_means3D, d_means2D, d_shs, d_col, d_op, d_sc, d_rot, d_cov, d_pose, d_rdx, d_rdq, None, None, None, None)
 
 
@@ -244,6 +254,7 @@ class GaussianRasterizer(nn.Module):
     _last = None
     last_absgrad = None
     last_sh_color_grad = None
+    last_grad_slab = None
 
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()

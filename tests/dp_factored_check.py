@@ -36,10 +36,20 @@ step(False)
 dense = model._features.grad.clone()
 dist.all_reduce(dense, op=dist.ReduceOp.SUM)
 dense /= world
+small = {}
+for name in ("_xyz", "_scaling", "_rotation", "_opacity"):          # reference for the other gradients: plain dense all-reduce
+    gsm = getattr(model, name).grad.clone()
+    dist.all_reduce(gsm, op=dist.ReduceOp.SUM)
+    small[name] = gsm / world
 out = step(True)
 assert model._features.grad is None
 dp.exchange_sh_gradient(model._features, model._xyz, cam.camera_center, model.active_sh_degree, actor_ids=model.actor_id,
-                        actor_pose=out["actor_pose"])
+                        actor_pose=out["actor_pose"], also_allreduce=list(model.parameters()))
+# the four small per-Gaussian gradients travelled as ONE slab (+ the two actor-pose tables): three collectives, not six
+assert dp.exchange_sh_gradient.last_num_allreduce == 3, dp.exchange_sh_gradient.last_num_allreduce
+for name, want in small.items():
+    got = getattr(model, name).grad
+    assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item() + 1e-12, name
 diff = (model._features.grad - dense).abs().max().item()
 ref = dense.abs().max().item()
 assert diff <= 2e-5 * ref + 1e-12, (diff, ref)
