@@ -263,7 +263,7 @@ __device__ __forceinline__ void sh_row_load(bool staged, const float4* s_sh, con
 // ---------------------------------------------------------------------------------------------------
 #define PRE_BLOCK 64
 __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(PreArgs a) {
-    __shared__ float4 s_sh[PRE_BLOCK * SH_ROW4];
+    __shared__ float4 s_sh[(PRE_BLOCK / 2) * SH_ROW4];       // half of the wave's rows at a time: 6.5 KB keeps four waves per SIMD
     const EmdSettings& S = a.s;
     const bool sh_staged = a.shs && a.M == 16;
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
@@ -336,16 +336,30 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(PreArgs a) {
         a.g.depth_key[i] = dkey;                         // key of the depth sort (invisible: sorts last)
     }
     const bool vis = touched != 0u;
+    float sh[48];
     if (sh_staged) {
+        // rows of the VISIBLE Gaussians only, in two halves of 32 rows: coalesced dwordx4 pieces into LDS, then each lane of the half
+        // takes its own row into registers
         const unsigned long long vmask = __ballot(vis);
         const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12;
         const float4* src = (const float4*)a.shs;
 #pragma unroll
-        for (int j = 0; j < 12; j++) {
-            const uint32_t idx = threadIdx.x + PRE_BLOCK * j, row = idx / 12;
-            if ((vmask >> row) & 1ull) s_sh[row * SH_ROW4 + (idx % 12)] = src[base4 + idx];
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const uint32_t idx = threadIdx.x + PRE_BLOCK * (6 * h + j), row = idx / 12;
+                if ((vmask >> row) & 1ull) s_sh[(row - 32 * h) * SH_ROW4 + (idx % 12)] = src[base4 + idx];
+            }
+            __syncthreads();
+            if ((int)(threadIdx.x >> 5) == h) {
+#pragma unroll
+                for (int j = 0; j < 12; j++) {
+                    const float4 t = s_sh[(threadIdx.x & 31) * SH_ROW4 + j];
+                    sh[4 * j] = t.x; sh[4 * j + 1] = t.y; sh[4 * j + 2] = t.z; sh[4 * j + 3] = t.w;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (vis) {
         float col[3];
@@ -360,8 +374,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(PreArgs a) {
             float bs[16];
             sh_basis(S.sh_degree, d, bs);
             const int K = (S.sh_degree + 1) * (S.sh_degree + 1);
-            float sh[48];
-            sh_row_load(sh_staged, s_sh, a.shs, i, a.M, K, sh);
+            if (!sh_staged) sh_row_load(false, nullptr, a.shs, i, a.M, K, sh);
             col[0] = col[1] = col[2] = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
