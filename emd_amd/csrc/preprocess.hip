@@ -511,7 +511,13 @@ __device__ __forceinline__ void reduce_pose_grad(int a_id, const float pose_g[12
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a) {
     const EmdSettings& S = a.s;
-    __shared__ float4 s_sh[EMD_BLOCK * SH_ROW4];      // staging of the dL/dshs rows only (coalesced copy-out)
+    // staging of the dL/dshs rows (coalesced copy-out), half of the block's rows at a time: 26 KB instead of 52 keeps five
+    // workgroup-waves per SIMD resident instead of three.  A row is the outer product basis[k] x gc[c]: the lane keeps the 19 factors
+    // and multiplies them out when its half is staged.
+    __shared__ float4 s_sh[(EMD_BLOCK / 2) * SH_ROW4];
+    float sh_b[16], sh_g[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; k++) sh_b[k] = 0.f;
     const bool sh_staged = a.shs && a.M == 16;
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
     const bool in_range = i < a.N;
@@ -580,16 +586,10 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
                 gd[1] = (j0.y * gc[0] + j1.y * gc[1]) + j2.y * gc[2];
                 gd[2] = (j0.z * gc[0] + j1.z * gc[1]) + j2.z * gc[2];
                 if (a.dL_dshs) {
-                    if (sh_staged) {          // own row only: overwrite the coefficients with their gradients
-                        float g48[48];
+                    if (sh_staged) {          // the factors of this Gaussian's row; multiplied out at staging time
 #pragma unroll
-                        for (int k = 0; k < 16; k++) {
-                            const float bk = k < K ? bs[k] : 0.f;
-                            g48[3 * k] = bk * gc[0]; g48[3 * k + 1] = bk * gc[1]; g48[3 * k + 2] = bk * gc[2];
-                        }
-#pragma unroll
-                        for (int j = 0; j < 12; j++)
-                            s_sh[threadIdx.x * SH_ROW4 + j] = make_float4(g48[4 * j], g48[4 * j + 1], g48[4 * j + 2], g48[4 * j + 3]);
+                        for (int k = 0; k < 16; k++) sh_b[k] = k < K ? bs[k] : 0.f;
+                        sh_g[0] = gc[0]; sh_g[1] = gc[1]; sh_g[2] = gc[2];
                     } else {
                         float* o = a.dL_dshs + (size_t)i * a.M * 3;
                         for (int k = 0; k < a.M; k++) {
@@ -683,8 +683,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
             }
         } else if (a.dL_dshs) {
             if (sh_staged) {
-#pragma unroll
-                for (int j = 0; j < 12; j++) s_sh[threadIdx.x * SH_ROW4 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                // (factors stay zero: a zero row)
             } else {
                 float* o = a.dL_dshs + (size_t)i * a.M * 3;
                 for (int k = 0; k < 3 * a.M; k++) o[k] = 0.f;
@@ -716,7 +715,29 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
         }
         if (a.dL_dopacities) a.dL_dopacities[i] = dopl;
     }
-    if (sh_staged && a.dL_dshs) { __syncthreads(); sh_block_store<EMD_BLOCK>(a.dL_dshs, a.N, s_sh); }
+    if (sh_staged && a.dL_dshs) {
+        const size_t lim4 = (size_t)a.N * 12;
+        float4* out = (float4*)a.dL_dshs;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if ((int)(threadIdx.x >> 7) == h) {
+                float g48[48];
+#pragma unroll
+                for (int k = 0; k < 16; k++) { g48[3 * k] = sh_b[k] * sh_g[0]; g48[3 * k + 1] = sh_b[k] * sh_g[1]; g48[3 * k + 2] = sh_b[k] * sh_g[2]; }
+#pragma unroll
+                for (int j = 0; j < 12; j++)
+                    s_sh[(threadIdx.x & 127) * SH_ROW4 + j] = make_float4(g48[4 * j], g48[4 * j + 1], g48[4 * j + 2], g48[4 * j + 3]);
+            }
+            __syncthreads();
+            const size_t base4 = ((size_t)blockIdx.x * EMD_BLOCK + 128 * h) * 12;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const uint32_t idx = threadIdx.x + EMD_BLOCK * j;
+                if (base4 + idx < lim4) out[base4 + idx] = s_sh[(idx / 12) * SH_ROW4 + (idx % 12)];
+            }
+            __syncthreads();
+        }
+    }
     if ((a.flags & EMD_FLAG_MOTION) && a.dL_dactor_pose) reduce_pose_grad(a_id, pose_g, a.dL_dactor_pose);
 }
 
