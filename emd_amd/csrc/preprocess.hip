@@ -224,35 +224,18 @@ __device__ __forceinline__ void sh_dir_jacobian(int deg, const float d[3], const
 
 // ---------------------------------------------------------------------------------------------------
 // SH rows through LDS.  shs is [N,16,3]: 192 contiguous bytes per Gaussian, so one-Gaussian-per-lane loads/stores
-// touch 64 different cache lines per instruction.  Instead the block moves its 256 rows (48 KiB, contiguous in HBM)
-// with fully coalesced dwordx4 accesses and each lane reads / writes its own row in LDS.  Rows are padded to
+// touch 64 different cache lines per instruction.  Instead the block moves its rows (contiguous in HBM) with fully
+// coalesced dwordx4 accesses and each lane reads / writes its own row in LDS -- HALF of the block's rows at a time, so that the
+// staging tile (6.5 KB per wave in K1, 26 KB per 256 threads in K8 and the factor rebuild) does not cap the resident waves: with
+// whole-block tiles K1 ran 3 waves per SIMD and 0.196 ms, with half tiles 4 and 0.154 ms.  Rows are padded to
 // 13 float4 (52 dwords): 52 t mod 64 takes 16 distinct multiples of 4, so a ds_read_b128 lane group is conflict-free.
 // ---------------------------------------------------------------------------------------------------
 #define SH_ROW4 13
-template <int BLK>
-__device__ __forceinline__ void sh_block_store(float* __restrict__ dst, int N, const float4* s_sh) {
-    const size_t base4 = (size_t)blockIdx.x * BLK * 12, lim4 = (size_t)N * 12;
-    float4* out = (float4*)dst;
+// this lane's 48 coefficients [k][c] into registers straight from HBM (the M != 16 path; M == 16 goes through the staging tile)
+__device__ __forceinline__ void sh_row_load(const float* __restrict__ shs, int i, int M, int K, float v[48]) {
+    const float* sh = shs + (size_t)i * M * 3;
 #pragma unroll
-    for (int j = 0; j < 12; j++) {
-        const uint32_t idx = threadIdx.x + BLK * j;
-        if (base4 + idx < lim4) out[base4 + idx] = s_sh[(idx / 12) * SH_ROW4 + (idx % 12)];
-    }
-}
-// this lane's 48 coefficients [k][c] into registers (staged row, or straight from HBM for M != 16)
-__device__ __forceinline__ void sh_row_load(bool staged, const float4* s_sh, const float* __restrict__ shs, int i, int M,
-                                            int K, float v[48]) {
-    if (staged) {
-#pragma unroll
-        for (int j = 0; j < 12; j++) {
-            const float4 t = s_sh[threadIdx.x * SH_ROW4 + j];
-            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
-        }
-    } else {
-        const float* sh = shs + (size_t)i * M * 3;
-#pragma unroll
-        for (int k = 0; k < 48; k++) v[k] = (k < 3 * K) ? sh[k] : 0.f;
-    }
+    for (int k = 0; k < 48; k++) v[k] = (k < 3 * K) ? sh[k] : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -374,7 +357,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(PreArgs a) {
             float bs[16];
             sh_basis(S.sh_degree, d, bs);
             const int K = (S.sh_degree + 1) * (S.sh_degree + 1);
-            if (!sh_staged) sh_row_load(false, nullptr, a.shs, i, a.M, K, sh);
+            if (!sh_staged) sh_row_load(a.shs, i, a.M, K, sh);
             col[0] = col[1] = col[2] = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -834,7 +817,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sh_grad_from_factors(int n, int V
                                                                     EmdMotion mo, const float* __restrict__ campos,
                                                                     const float* __restrict__ gc, float scale,
                                                                     float* __restrict__ d_shs) {
-    __shared__ float4 s_sh[EMD_BLOCK * SH_ROW4];
+    __shared__ float4 s_sh[(EMD_BLOCK / 2) * SH_ROW4];    // half of the block's rows at a time (26 KB: more resident waves)
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
     float acc[48];
 #pragma unroll
@@ -859,11 +842,24 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sh_grad_from_factors(int n, int V
             }
         }
     }
+    const size_t lim4 = (size_t)n * 12;
+    float4* out = (float4*)d_shs;
 #pragma unroll
-    for (int j = 0; j < 12; j++)
-        s_sh[threadIdx.x * SH_ROW4 + j] = make_float4(acc[4 * j] * scale, acc[4 * j + 1] * scale, acc[4 * j + 2] * scale, acc[4 * j + 3] * scale);
-    __syncthreads();
-    sh_block_store<EMD_BLOCK>(d_shs, n, s_sh);
+    for (int h = 0; h < 2; h++) {
+        if ((int)(threadIdx.x >> 7) == h) {
+#pragma unroll
+            for (int j = 0; j < 12; j++)
+                s_sh[(threadIdx.x & 127) * SH_ROW4 + j] = make_float4(acc[4 * j] * scale, acc[4 * j + 1] * scale, acc[4 * j + 2] * scale, acc[4 * j + 3] * scale);
+        }
+        __syncthreads();
+        const size_t base4 = ((size_t)blockIdx.x * EMD_BLOCK + 128 * h) * 12;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const uint32_t idx = threadIdx.x + EMD_BLOCK * j;
+            if (base4 + idx < lim4) out[base4 + idx] = s_sh[(idx / 12) * SH_ROW4 + (idx % 12)];
+        }
+        __syncthreads();
+    }
 }
 
 // Densification statistics of one view, in place and without the boolean-mask indexing (= a device-to-host sync) of the
