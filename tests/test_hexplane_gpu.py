@@ -179,3 +179,30 @@ def test_hexplane_full_size_partition_of_unity():
             got = float(prm.grad.double().sum())
             assert abs(got - expect) <= 2e-5 * abs(expect), (s, p, got, expect)
             assert float(prm.grad.min()) >= 0.0                 # non-negative contributions only
+
+
+def test_hexplane_tolerates_nonfinite_points():
+    """NaN / Inf coordinates (a diverged Gaussian) must not fault or poison the other points: grid_sample's border rule sends a
+    NaN coordinate to cell 0 (the comparison `!(v > 0)` is true for NaN), +-Inf to the borders; the other rows are unaffected."""
+    from emd_amd.hexplane import HexPlaneField
+    dev = torch.device("cuda", 0)
+    cfg = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32, "resolution": [8, 8, 8, 4]}
+    field = HexPlaneField(1.6, cfg, [1, 2]).to(dev)
+    for gp in field.grids:
+        for prm in gp:
+            prm.data = torch.rand_like(prm) + 0.3
+    g = torch.Generator().manual_seed(0)
+    N = 20000
+    pts = (torch.rand(N, 3, generator=g) * 3 - 1.5).to(dev)
+    t = torch.full((N, 1), 0.2, device=dev)
+    clean = field(pts, t).detach()
+    bad = pts.clone()
+    bad[5] = float("nan"); bad[77, 1] = float("inf"); bad[9000, 2] = float("-inf"); bad[12345, 0] = float("nan")
+    field._order_cache = None
+    out = field(bad.requires_grad_(True), t)
+    assert torch.isfinite(out).all()
+    rows = torch.ones(N, dtype=torch.bool, device=dev)
+    rows[[5, 77, 9000, 12345]] = False
+    assert torch.equal(out.detach()[rows], clean[rows])
+    out.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for gp in field.grids for p in gp)
