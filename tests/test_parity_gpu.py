@@ -311,3 +311,48 @@ def test_one_rasterizer_object_called_three_times_in_one_graph():
         ref = sums[k]
         err = float((v.grad - ref).abs().max())
         assert err <= 1e-4 * max(float(ref.abs().max()), 1e-12), (k, err)
+
+
+def test_nonfinite_gaussians_are_dropped_not_fatal():
+    """Gaussians with NaN / Inf parameters (a diverged optimisation step) must neither fault nor disturb the rest of the image: they
+    are invisible (radius 0), the image equals the image without them bit for bit, and the other Gaussians' gradients are unchanged."""
+    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer, RasterConfig
+    case = make_case(n=5000, H=80, W=112, seed=91)
+    cam, dev = case["cam"], torch.device("cuda", 0)
+    rs = GaussianRasterizationSettings(image_height=case["H"], image_width=case["W"], tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                                       bg=case["bg"].to(dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(dev),
+                                       projmatrix=cam.full_proj_transform.to(dev), sh_degree=case["sh_degree"],
+                                       campos=cam.camera_center.to(dev), prefiltered=False, debug=False)
+    RasterConfig.compute_normal = True
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    bad_rows = torch.tensor([3, 700, 1500, 2600, 4100])
+
+    def run(poison, keep):
+        t = {k: case[k].to(dev).clone() for k in names}
+        if poison:
+            t["means3D"][3, 0] = float("nan")
+            t["scales"][700] = float("inf")
+            t["rotations"][1500] = float("nan")
+            t["opacities"][2600] = float("nan")
+            t["means3D"][4100] = float("-inf")
+        t = {k: v[keep].requires_grad_(True) for k, v in t.items()}
+        means2D = torch.zeros(t["means3D"].shape[0], 3, device=dev, requires_grad=True)
+        img, depth, normal, alpha, radii, _ = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=means2D, shs=t["shs"], colors_precomp=None,
+                                                                     opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"],
+                                                                     cov3Ds_precomp=None, extra_attrs=None)
+        (img.sum() + depth.sum()).backward()
+        return img.detach(), radii, t
+
+    all_rows = torch.ones(case["N"], dtype=torch.bool)
+    good = all_rows.clone()
+    good[bad_rows] = False
+    img_p, radii_p, tp = run(True, all_rows.to(dev))
+    img_c, radii_c, tc = run(False, good.to(dev))
+    assert torch.isfinite(img_p).all()
+    assert (radii_p[torch.tensor([3, 700, 1500, 4100], device=dev)] == 0).all()      # poisoned geometry: culled; the NaN opacity
+    # leaves the footprint valid (radius from geometry) and is skipped per pixel by `alpha >= 1/255`, which NaN fails
+    assert torch.equal(img_p, img_c)
+    for k in names:
+        gp = tp[k].grad[good.to(dev)]
+        assert torch.isfinite(gp).all(), k
+        assert float((gp - tc[k].grad).abs().max()) <= 1e-5 * max(float(tc[k].grad.abs().max()), 1e-12), k
