@@ -41,12 +41,13 @@ __device__ __forceinline__ float block_sum(float v, float* s4) {
     return t;
 }
 
-// sums: [0] sum |x - y|   [1] sum ssim map   [2] sum depth sq. err   [3] valid depth count   [4] sum sky bce
+// sums: [0] sum |x - y|   [1] sum ssim map   [2] sum depth sq. err   [3] valid depth count   [4] sum sky bce   [5] sky pixel count
+#define NUM_SUMS 6
 __global__ void __launch_bounds__(EMD_BLOCK) k_loss_pointwise(EmdLossArgs a, float* __restrict__ sums) {
     __shared__ float s4[4];
     const size_t HW = (size_t)a.height * a.width;
     const size_t p = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x;
-    float l1 = 0.f, dsq = 0.f, dcnt = 0.f, sky = 0.f;
+    float l1 = 0.f, dsq = 0.f, dcnt = 0.f, sky = 0.f, skyn = 0.f;
     if (p < HW) {
         const float inv_n = 1.f / (float)(3 * HW);
 #pragma unroll
@@ -74,18 +75,22 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_loss_pointwise(EmdLossArgs a, flo
             const float w = fminf(fmaxf(w0, 1e-6f), 1.f - 1e-6f);
             const bool is_sky = a.sky_mask[p] != 0;
             sky = is_sky ? -logf(1.f - w) : -logf(w);
+            skyn = is_sky ? 1.f : 0.f;
+            // (the reference applies the term only when the mask holds at least one sky pixel, train.py:360: the gradient is
+            // zeroed by the second pass when the count turns out to be 0)
             if (a.dL_dweight) {
                 const bool pass = w0 >= 1e-6f && w0 <= 1.f - 1e-6f;
                 a.dL_dweight[p] = pass ? a.lambda_sky * (is_sky ? 1.f / (1.f - w) : -1.f / w) / (float)HW : 0.f;
             }
         }
     }
-    l1 = block_sum(l1, s4); dsq = block_sum(dsq, s4); dcnt = block_sum(dcnt, s4); sky = block_sum(sky, s4);
+    l1 = block_sum(l1, s4); dsq = block_sum(dsq, s4); dcnt = block_sum(dcnt, s4); sky = block_sum(sky, s4); skyn = block_sum(skyn, s4);
     if (threadIdx.x == 0) {
         const int slot = blockIdx.x & (SUM_SLOTS - 1);
         atomicAdd(sums + SUM_AT(0) + slot, l1);
         if (dcnt != 0.f) { atomicAdd(sums + SUM_AT(2) + slot, dsq); atomicAdd(sums + SUM_AT(3) + slot, dcnt); }
         if (sky != 0.f) atomicAdd(sums + SUM_AT(4) + slot, sky);
+        if (skyn != 0.f) atomicAdd(sums + SUM_AT(5) + slot, skyn);
     }
 }
 
@@ -181,13 +186,13 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_ssim_backward(EmdLossArgs a, Win 
                                                              const float* __restrict__ dmaps) {
     __shared__ float s0[SS_H][SS_H + 1], s1[SS_H][SS_H + 1], s2[SS_H][SS_H + 1];
     __shared__ float hz[3][SS_H][SS_T + 1];
-    __shared__ float s_cnt;
+    __shared__ float s_cnt, s_sky;
     const int H = a.height, W = a.width;
     const size_t HW = (size_t)H * W;
     const int tiles_x = (W + SS_T - 1) / SS_T;
     const int c = blockIdx.y;
     const int x0 = (int)(blockIdx.x % (unsigned)tiles_x) * SS_T, y0 = (int)(blockIdx.x / (unsigned)tiles_x) * SS_T;
-    if (threadIdx.x == 0) s_cnt = slot_sum(sums, 3);
+    if (threadIdx.x == 0) { s_cnt = slot_sum(sums, 3); s_sky = slot_sum(sums, 5); }
     load_halo(dmaps + (0 * 3 + c) * HW, H, W, x0, y0, s0);
     load_halo(dmaps + (1 * 3 + c) * HW, H, W, x0, y0, s1);
     load_halo(dmaps + (2 * 3 + c) * HW, H, W, x0, y0, s2);
@@ -214,7 +219,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_ssim_backward(EmdLossArgs a, Win 
         }
     }
     const float scale = -a.lambda_dssim / (float)(3 * HW);          // d (lambda (1 - mean map)) / d map
-    const float cnt = s_cnt;
+    const float cnt = s_cnt, skyn = s_sky;
 #pragma unroll
     for (int j = 0; j < SS_V; j++) {
         const int y = y0 + lyb + j;
@@ -224,17 +229,21 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_ssim_backward(EmdLossArgs a, Win 
             if (a.dL_dimage) a.dL_dimage[c * HW + q] += scale * (acc[j][0] + 2.f * xv * acc[j][1] + yv * acc[j][2]);
             if (c == 0 && a.dL_ddepth && a.depth && a.gt_depth && a.lambda_depth != 0.f)
                 a.dL_ddepth[q] = cnt > 0.f ? a.dL_ddepth[q] * (a.lambda_depth / cnt) : 0.f;
+            if (c == 0 && a.dL_dweight && a.weight && a.sky_mask && a.lambda_sky > 0.f && !(skyn > 0.f)) a.dL_dweight[q] = 0.f;
         }
     }
 }
 
-// no SSIM term: the depth gradient still needs its 1 / count
+// no SSIM term: the depth gradient still needs its 1 / count, the sky gradient its "any sky pixel at all" gate
 __global__ void __launch_bounds__(EMD_BLOCK) k_depth_normalize(EmdLossArgs a, const float* __restrict__ sums) {
     const size_t HW = (size_t)a.height * a.width;
     const size_t p = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x;
     if (p >= HW) return;
-    const float cnt = slot_sum(sums, 3);
-    a.dL_ddepth[p] = cnt > 0.f ? a.dL_ddepth[p] * (a.lambda_depth / cnt) : 0.f;
+    if (a.dL_ddepth && a.depth && a.lambda_depth != 0.f) {
+        const float cnt = slot_sum(sums, 3);
+        a.dL_ddepth[p] = cnt > 0.f ? a.dL_ddepth[p] * (a.lambda_depth / cnt) : 0.f;
+    }
+    if (a.dL_dweight && a.weight && a.sky_mask && a.lambda_sky > 0.f && !(slot_sum(sums, 5) > 0.f)) a.dL_dweight[p] = 0.f;
 }
 
 // losses: [0] total  [1] l1  [2] ssim  [3] depth  [4] sky
@@ -245,7 +254,7 @@ __global__ void k_loss_finalize(EmdLossArgs a, const float* __restrict__ sums, f
     const float l1 = slot_sum(sums, 0) / (3.f * HW);
     const float ss = a.lambda_dssim != 0.f ? slot_sum(sums, 1) / (3.f * HW) : 0.f;
     const float dp = cnt > 0.f ? slot_sum(sums, 2) / cnt : 0.f;
-    const float sk = slot_sum(sums, 4) / HW;
+    const float sk = slot_sum(sums, 5) > 0.f ? slot_sum(sums, 4) / HW : 0.f;      // train.py:360: skipped without sky pixels
     losses[1] = l1; losses[2] = ss; losses[3] = dp; losses[4] = sk;
     losses[0] = l1 + (a.lambda_dssim != 0.f ? a.lambda_dssim * (1.f - ss) : 0.f) + a.lambda_depth * dp + a.lambda_sky * sk;
 }
@@ -253,7 +262,7 @@ __global__ void k_loss_finalize(EmdLossArgs a, const float* __restrict__ sums, f
 }  // namespace
 
 extern "C" size_t emd_image_loss_workspace(int height, int width) {
-    return (size_t)9 * height * width * sizeof(float) + 5 * SUM_SLOTS * sizeof(float) + 256;   // 3 derivative maps x 3 channels + the sums
+    return (size_t)9 * height * width * sizeof(float) + NUM_SUMS * SUM_SLOTS * sizeof(float) + 256;   // 3 derivative maps x 3 channels + the sums
 }
 
 extern "C" int emd_image_loss(const EmdLossArgs* a, void* workspace, size_t workspace_bytes, void* hip_stream) {
@@ -265,8 +274,8 @@ extern "C" int emd_image_loss(const EmdLossArgs* a, void* workspace, size_t work
     hipStream_t st = (hipStream_t)hip_stream;
     const size_t HW = (size_t)a->height * a->width;
     float* sums = (float*)workspace;
-    float* dmaps = sums + 5 * SUM_SLOTS;
-    EMD_HIP_CHECK(hipMemsetAsync(sums, 0, 5 * SUM_SLOTS * sizeof(float), st));
+    float* dmaps = sums + NUM_SUMS * SUM_SLOTS;
+    EMD_HIP_CHECK(hipMemsetAsync(sums, 0, NUM_SUMS * SUM_SLOTS * sizeof(float), st));
     Win win;
     {   // loss_utils.py:56-58: exp(-(x - 5)^2 / (2 * 1.5^2)) normalised, built in double like Python, stored in float
         double g[11], s = 0.0;
@@ -287,7 +296,7 @@ extern "C" int emd_image_loss(const EmdLossArgs* a, void* workspace, size_t work
             hipLaunchKernelGGL(k_ssim_backward, dim3(tiles, 3), dim3(EMD_BLOCK), 0, st, *a, win, sums, dmaps);
             EMD_LAUNCH_CHECK();
         }
-    } else if (a->dL_ddepth && a->depth && a->lambda_depth != 0.f) {
+    } else if ((a->dL_ddepth && a->depth && a->lambda_depth != 0.f) || (a->dL_dweight && a->weight && a->lambda_sky > 0.f)) {
         hipLaunchKernelGGL(k_depth_normalize, dim3(pb), dim3(EMD_BLOCK), 0, st, *a, sums);
         EMD_LAUNCH_CHECK();
     }

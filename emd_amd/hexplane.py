@@ -135,11 +135,18 @@ class HexPlaneField(nn.Module):
     def set_aabb(self, xyz_max, xyz_min):
         aabb = torch.from_numpy(np.array([xyz_max, xyz_min], dtype=np.float32)).to(self.aabb.device)
         self.aabb = nn.Parameter(aabb, requires_grad=False)
+        self._aabb_key = None          # the host copy is stale (a new Parameter may reuse the id of the freed one)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._aabb_key = None
 
     def _aabb_host(self):
-        # six floats for the args struct; re-read from the device only when the parameter was written (set_aabb, load_state_dict)
-        key = (id(self.aabb), self.aabb._version)
-        if getattr(self, "_aabb_key", None) != key:
+        # six floats for the args struct; re-read from the device only when the parameter was written: set_aabb and
+        # load_state_dict invalidate explicitly, in-place writes bump _version, a replaced Parameter object changes the reference
+        key = (self.aabb, self.aabb._version)
+        old = getattr(self, "_aabb_key", None)
+        if old is None or old[0] is not key[0] or old[1] != key[1]:
             self._aabb_key, self._aabb_list = key, self.aabb.detach().reshape(-1).to("cpu", torch.float32).tolist()
         return self._aabb_list
 

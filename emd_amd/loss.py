@@ -28,16 +28,18 @@ class _ImageLoss(torch.autograd.Function):
         a.height, a.width = H, W
         a.image, a.gt = image_c.data_ptr(), gt_c.data_ptr()
         a.depth, a.gt_depth, a.mask = L.ptr(depth_c), L.ptr(gtd_c), L.ptr(mask_c)
+        if sky_c is None or weight_c is None:      # the sky term needs both (train.py:360); without it dL/dweight is zero
+            weight_c = sky_c = None
         a.weight, a.sky_mask = L.ptr(weight_c), L.ptr(sky_c)
         a.lambda_dssim, a.max_depth = lam_dssim, max_depth
         a.lambda_depth = lam_depth if depth is not None else 0.0
-        a.lambda_sky = lam_sky if weight is not None else 0.0
+        a.lambda_sky = lam_sky if weight_c is not None else 0.0
         losses = torch.empty(5, device=dev, dtype=torch.float32)
         a.losses = losses.data_ptr()
         need = ctx.needs_input_grad
         g_img = torch.empty_like(image_c) if need[0] else None
         g_dep = torch.empty_like(depth_c) if (depth is not None and need[2]) else None
-        g_wgt = torch.empty_like(weight_c) if (weight is not None and need[5]) else None
+        g_wgt = (torch.empty_like(weight_c) if weight_c is not None else torch.zeros_like(f(weight))) if (weight is not None and need[5]) else None
         a.dL_dimage, a.dL_ddepth, a.dL_dweight = L.ptr(g_img), L.ptr(g_dep), L.ptr(g_wgt)
         nbytes = lib.emd_image_loss_workspace(H, W)
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)

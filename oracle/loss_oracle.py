@@ -58,7 +58,8 @@ def loss_tail(image, gt, depth=None, gt_depth=None, mask=None, weight=None, sky_
     if lambda_dssim != 0:
         terms["ssim"] = ssim(image, gt)
         total = total + lambda_dssim * (1.0 - terms["ssim"])
-    if weight is not None and sky_mask is not None and lambda_sky > 0:
+    # train.py:360: `if args.lambda_sky > 0 and sky_mask is not None and sky_mask.sum() > 0`
+    if weight is not None and sky_mask is not None and lambda_sky > 0 and bool(sky_mask.sum() > 0):
         terms["sky"] = sky_bce(weight, sky_mask)
         total = total + lambda_sky * terms["sky"]
     return total, terms

@@ -242,6 +242,7 @@ int orc_preprocess(const OrcSettings* S, int N, int M, int flags, const float* m
     const int W = S->W, H = S->H;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const float fx = (float)W / (2.f * S->tanfovx), fy = (float)H / (2.f * S->tanfovy);
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < N; i++) {
         radii[i] = 0; tiles_touched[i] = 0;
         if (rect) { rect[4 * i] = rect[4 * i + 1] = rect[4 * i + 2] = rect[4 * i + 3] = 0; }
@@ -405,6 +406,8 @@ int orc_render_forward(const OrcSettings* S, int flags, const uint32_t* ranges, 
                        const float* normal, float* out_color, float* out_depth, float* out_normal, float* out_alpha,
                        uint32_t* n_contrib, float* final_T) {
     const int W = S->W, H = S->H, gx = (W + TILE - 1) / TILE;
+    /* pixels are independent: rows are dealt to the OpenMP threads (results do not depend on the thread count) */
+#pragma omp parallel for schedule(dynamic, 2)
     for (int py = 0; py < H; py++)
         for (int px = 0; px < W; px++) {
             int t = (py / TILE) * gx + px / TILE;
@@ -456,13 +459,15 @@ int orc_render_backward(const OrcSettings* S, int N, int flags, const uint32_t* 
                         float* g_normal) {
     const int W = S->W, H = S->H, gx = (W + TILE - 1) / TILE;
     const size_t HW = (size_t)H * W;
-    memset(g_mean2D, 0, sizeof(float) * 2 * N);
-    if (g_abs) memset(g_abs, 0, sizeof(float) * 2 * N);
-    memset(g_conic, 0, sizeof(float) * 3 * N);
-    memset(g_opacity, 0, sizeof(float) * N);
-    memset(g_rgb, 0, sizeof(float) * 3 * N);
-    memset(g_depth, 0, sizeof(float) * N);
-    if (g_normal) memset(g_normal, 0, sizeof(float) * 3 * N);
+    /* Per-(pixel, Gaussian) partial derivatives are evaluated in fp32 exactly as upstream does; they are SUMMED in
+     * double (15 accumulators per Gaussian) so that the result neither depends on the order in which the OpenMP
+     * threads reach a Gaussian nor carries the rounding of one particular fp32 summation order: the oracle is the
+     * exact sum of the fp32 partials, rounded once. */
+    enum { A_MX = 0, A_MY, A_AX, A_AY, A_CA, A_CB, A_CC, A_OP, A_R, A_G, A_B, A_D, A_N0, A_N1, A_N2, A_STRIDE };
+    double* acc = (double*)calloc((size_t)(N > 0 ? N : 1) * A_STRIDE, sizeof(double));
+    if (!acc) return -1;
+#define ACC(g, k, v) do { const double v_ = (double)(v); _Pragma("omp atomic") acc[(size_t)(g) * A_STRIDE + (k)] += v_; } while (0)
+#pragma omp parallel for schedule(dynamic, 2)
     for (int py = 0; py < H; py++)
         for (int px = 0; px < W; px++) {
             size_t pix = (size_t)py * W + px;
@@ -496,21 +501,21 @@ int orc_render_backward(const OrcSettings* S, int N, int flags, const uint32_t* 
                     accC[ch] = last_alpha * lastC[ch] + (1.f - last_alpha) * accC[ch];
                     lastC[ch] = c;
                     dL_da += (c - accC[ch]) * dC[ch];
-                    g_rgb[3 * g + ch] += w * dC[ch];
+                    ACC(g, A_R + ch, w * dC[ch]);
                 }
                 {
                     float z = depths[g];
                     accD = last_alpha * lastD + (1.f - last_alpha) * accD;
                     lastD = z;
                     dL_da += (z - accD) * dD;
-                    g_depth[g] += w * dD;
+                    ACC(g, A_D, w * dD);
                 }
                 if (flags & F_NORMAL) for (int ch = 0; ch < 3; ch++) {
                     float n = normal[3 * g + ch];
                     accN[ch] = last_alpha * lastN[ch] + (1.f - last_alpha) * accN[ch];
                     lastN[ch] = n;
                     dL_da += (n - accN[ch]) * dN[ch];
-                    if (g_normal) g_normal[3 * g + ch] += w * dN[ch];
+                    if (g_normal) ACC(g, A_N0 + ch, w * dN[ch]);
                 }
                 dL_da *= T;
                 last_alpha = alpha;
@@ -521,14 +526,27 @@ int orc_render_backward(const OrcSettings* S, int N, int flags, const uint32_t* 
                 float dG_ddx = -gdx * co[0] - gdy * co[1];
                 float dG_ddy = -gdy * co[2] - gdx * co[1];
                 float mx = dL_dG * dG_ddx, my = dL_dG * dG_ddy;
-                g_mean2D[2 * g] += mx; g_mean2D[2 * g + 1] += my;
-                if (g_abs) { g_abs[2 * g] += fabsf(mx); g_abs[2 * g + 1] += fabsf(my); }
-                g_conic[3 * g] += -0.5f * gdx * dx * dL_dG;
-                g_conic[3 * g + 1] += -gdx * dy * dL_dG;
-                g_conic[3 * g + 2] += -0.5f * gdy * dy * dL_dG;
-                g_opacity[g] += G * dL_da;
+                ACC(g, A_MX, mx); ACC(g, A_MY, my);
+                if (g_abs) { ACC(g, A_AX, fabsf(mx)); ACC(g, A_AY, fabsf(my)); }
+                ACC(g, A_CA, -0.5f * gdx * dx * dL_dG);
+                ACC(g, A_CB, -gdx * dy * dL_dG);
+                ACC(g, A_CC, -0.5f * gdy * dy * dL_dG);
+                ACC(g, A_OP, G * dL_da);
             }
         }
+#undef ACC
+#pragma omp parallel for schedule(static)
+    for (int g = 0; g < N; g++) {
+        const double* a = acc + (size_t)g * A_STRIDE;
+        g_mean2D[2 * g] = (float)a[A_MX]; g_mean2D[2 * g + 1] = (float)a[A_MY];
+        if (g_abs) { g_abs[2 * g] = (float)a[A_AX]; g_abs[2 * g + 1] = (float)a[A_AY]; }
+        g_conic[3 * g] = (float)a[A_CA]; g_conic[3 * g + 1] = (float)a[A_CB]; g_conic[3 * g + 2] = (float)a[A_CC];
+        g_opacity[g] = (float)a[A_OP];
+        g_rgb[3 * g] = (float)a[A_R]; g_rgb[3 * g + 1] = (float)a[A_G]; g_rgb[3 * g + 2] = (float)a[A_B];
+        g_depth[g] = (float)a[A_D];
+        if (g_normal) { g_normal[3 * g] = (float)a[A_N0]; g_normal[3 * g + 1] = (float)a[A_N1]; g_normal[3 * g + 2] = (float)a[A_N2]; }
+    }
+    free(acc);
     return 0;
 }
 
@@ -563,7 +581,10 @@ int orc_preprocess_backward(const OrcSettings* S, int N, int M, int flags, const
     const float* P = S->proj;
     const int W = S->W, H = S->H;
     const float fx = (float)W / (2.f * S->tanfovx), fy = (float)H / (2.f * S->tanfovy);
-    if (dL_dpose) memset(dL_dpose, 0, sizeof(float) * ACTOR_STRIDE * (size_t)A);
+    /* per-actor pose gradients: segmented sums over up to thousands of points, accumulated in double (order-free) */
+    double* pose_acc = dL_dpose ? (double*)calloc((size_t)(A > 0 ? A : 1) * ACTOR_STRIDE, sizeof(double)) : NULL;
+#define PACC(idx, v) do { const double v_ = (double)(v); _Pragma("omp atomic") pose_acc[idx] += v_; } while (0)
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < N; i++) {
         float dm[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, ds[3] = {0, 0, 0}, dop = 0.f, dc6[6] = {0, 0, 0, 0, 0, 0};
         if (dL_dmeans2D_out) dL_dmeans2D_out[3 * i] = dL_dmeans2D_out[3 * i + 1] = dL_dmeans2D_out[3 * i + 2] = 0.f;
@@ -734,10 +755,10 @@ int orc_preprocess_backward(const OrcSettings* S, int N, int M, int flags, const
             float dqm[4];
             dR_to_dq(Pp, dRm, dqm);
             if (dL_dpose) {
-                float* gp = dL_dpose + (size_t)a_id * ACTOR_STRIDE;
-                for (int k = 0; k < 4; k++) gp[k] += dqm[k];
-                for (int k = 0; k < 3; k++) gp[4 + k] += dm[k];
-                gp[7] += dop * opacities[i];
+                const size_t gp = (size_t)a_id * ACTOR_STRIDE;
+                for (int k = 0; k < 4; k++) PACC(gp + k, dqm[k]);
+                for (int k = 0; k < 3; k++) PACC(gp + 4 + k, dm[k]);
+                PACC(gp + 7, dop * opacities[i]);
             }
             float dql[4] = {0, 0, 0, 0};
             if (rotations) {
@@ -755,7 +776,7 @@ int orc_preprocess_backward(const OrcSettings* S, int N, int M, int flags, const
                 float dqa[4], dqb[4];
                 quat_mul(dp, bc, dqa);
                 quat_mul(ac, dp, dqb);
-                if (dL_dpose) for (int k = 0; k < 4; k++) dL_dpose[(size_t)a_id * ACTOR_STRIDE + 8 + k] += dqa[k];
+                if (dL_dpose) for (int k = 0; k < 4; k++) PACC((size_t)a_id * ACTOR_STRIDE + 8 + k, dqa[k]);
                 dnormalize(qn, n, dqb, dql);
             }
             if (dL_dmeans3D) memcpy(dL_dmeans3D + 3 * i, dl, 12);
@@ -770,6 +791,11 @@ int orc_preprocess_backward(const OrcSettings* S, int N, int M, int flags, const
             if (dL_drdq) memset(dL_drdq + 4 * i, 0, 16);
             if (dL_dopacities) dL_dopacities[i] = dop;
         }
+    }
+#undef PACC
+    if (dL_dpose) {
+        for (size_t k = 0; k < (size_t)A * ACTOR_STRIDE; k++) dL_dpose[k] = (float)pose_acc[k];
+        free(pose_acc);
     }
     return 0;
 }

@@ -66,3 +66,38 @@ def test_image_loss_vs_oracle(H, W, with_depth, with_sky, lam_dssim):
         _close_grad(d1.grad / 2.0, d0.grad.numpy(), "depth")
     if with_sky:
         _close_grad(w1.grad / 2.0, w0.grad.numpy(), "weight")
+
+
+@pytest.mark.parametrize("lam_dssim", [0.2, 0.0])
+def test_sky_term_skipped_without_sky_pixels(lam_dssim):
+    """S3Gaussian/train.py:360 applies the sky BCE only when the mask holds at least one sky pixel; and a weight image without a
+    mask (load_sky_mask off, train.py:219) takes no sky term at all.  Loss and dL/dweight must follow (zero gradient)."""
+    from emd_amd.loss import image_loss
+    dev = torch.device("cuda", 0)
+    H, W = 70, 90
+    gen = torch.Generator().manual_seed(3)
+    gt, image = torch.rand(3, H, W, generator=gen), torch.rand(3, H, W, generator=gen)
+    weight = torch.rand(1, H, W, generator=gen)
+    no_sky = torch.zeros(1, H, W, dtype=torch.bool)
+    kw = dict(lambda_dssim=lam_dssim, lambda_depth=0.5, lambda_sky=0.05)
+    i0, w0 = image.clone().requires_grad_(True), weight.clone().requires_grad_(True)
+    tot0, t0 = lo.loss_tail(i0, gt, None, None, None, w0, no_sky, **kw)
+    assert "sky" not in t0
+    for mask in (no_sky.to(dev), None):
+        i1, w1 = image.to(dev).requires_grad_(True), weight.to(dev).requires_grad_(True)
+        tot1, t1 = image_loss(i1, gt.to(dev), None, None, None, w1, mask, **kw)
+        tot1.backward()
+        np.testing.assert_allclose(tot1.item(), tot0.item(), rtol=1e-5)
+        assert t1["sky"].item() == 0.0
+        assert w1.grad is None or float(w1.grad.abs().max()) == 0.0
+    # one sky pixel switches the term on for the whole image
+    one = no_sky.clone()
+    one[0, 3, 4] = True
+    i0, w0 = image.clone().requires_grad_(True), weight.clone().requires_grad_(True)
+    tot0, t0 = lo.loss_tail(i0, gt, None, None, None, w0, one, **kw)
+    tot0.backward()
+    i1, w1 = image.to(dev).requires_grad_(True), weight.to(dev).requires_grad_(True)
+    tot1, t1 = image_loss(i1, gt.to(dev), None, None, None, w1, one.to(dev), **kw)
+    tot1.backward()
+    np.testing.assert_allclose(t1["sky"].item(), t0["sky"].item(), rtol=1e-5)
+    _close_grad(w1.grad, w0.grad.numpy(), "weight")

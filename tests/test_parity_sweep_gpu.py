@@ -5,7 +5,7 @@ import random
 
 import pytest
 
-from tests.helpers import GRAD_RTOL, IMAGE_TOL, compare_backward, compare_forward, make_case, run_hip, run_oracle
+from tests.helpers import IMAGE_TOL, compare_backward, compare_forward, make_case, run_hip, run_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -31,4 +31,4 @@ def test_random_scene(kw):
     orc = run_oracle(case, backward=True)
     hip = run_hip(case, backward=True)
     compare_forward(hip, orc, tol=IMAGE_TOL)
-    compare_backward(hip, orc, rtol=GRAD_RTOL)
+    compare_backward(hip, orc)
