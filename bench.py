@@ -35,11 +35,26 @@ PMC_STAGE_KERNELS = {"preprocess": ("k_preprocess",), "scan_duplicate": ("k_sort
                      "render_backward": ("k_render_backward_q",), "preprocess_backward": ("k_preprocess_backward",)}
 
 
+PMC_TRAFFIC_CSV = "r02_pmc_hbm_traffic.csv"
+PMC_VALU_CSV = "r02_pmc_valu.csv"
+
+
+def _pmc_path(name):
+    for cand in (name, name.replace("r02_", "r01_")):
+        path = os.path.join(ROOT, "profiles", cand)
+        if os.path.exists(path):
+            return path
+    return None
+
+
 def pmc_traffic(stage, passes):
-    """HBM-side bytes per iteration of `stage` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
+    """HBM-side bytes per iteration of `stage` from the COMMITTED PMC summary (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE, separate passes, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md; produced by
-    profiles/make_pmc_summary.py) -- collected on this exact workload; None when the summary is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.csv")
+    profiles/make_pmc_summary.py on this exact workload).  A file constant, NOT measured in this run: counters cannot be read
+    from inside the process; the JSON line says so ("static": true + the file).  None when the summary is missing."""
+    path = _pmc_path(PMC_TRAFFIC_CSV)
+    if path is None:
+        return None
     if not os.path.exists(path):
         return None
     tot = 0.0
@@ -59,20 +74,34 @@ def pmc_traffic(stage, passes):
     return tot or None
 
 
-def pmc_valu(stage):
-    """Fraction of the fp32 vector issue slots the stage's dominant kernel fills (profiles/r01_pmc_valu.csv: rocprofv3 --pmc
-    SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x duration of the same dispatch)); None when the summary is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_valu.csv")
-    if not os.path.exists(path):
+def issue_bound(stage, avg_ms):
+    """Secondary bound of the render kernels: the fraction of the MEASURED vector-issue capacity the stage's dominant kernel uses.
+    Instruction counts per launch come from the committed counter summary (rocprofv3 --pmc SQ_INSTS_VALU ..., static, like
+    `traffic`); the capacity per instruction class from profiles/microbench_issue_rate.hip as measured on MI355X
+    (profiles/r02_issue_rate_microbench.txt): a plain fp32 VALU instruction occupies its SIMD for 1.32 ns with 8 waves resident
+    (2.35 cycles at the 1.78 GHz the chip holds under that load -- not the 0.83 ns of "2 cycles at 2.4 GHz"), v_pk_* / DPP /
+    v_readlane 2.0 ns, transcendentals 3.4 ns.  Counters do not split the classes, so two fractions are given: every instruction
+    priced as a plain one (lower bound of the utilisation) and priced with the kernel's static instruction mix (from the ISA of
+    its inner loop)."""
+    path = _pmc_path(PMC_VALU_CSV)
+    if path is None:
         return None
+    mix = {"k_render_backward_q": 0.55, "k_render_forward_q": 0.12}          # fraction of 2-slot instructions (pk / DPP / readlane) in the inner loop
     names = PMC_STAGE_KERNELS.get(stage, ())
     for line in open(path):
         if line.startswith("#") or line.startswith("kernel,"):
             continue
         f = line.rstrip("\n").split(",")
         if f[0] in names:
-            return {"kernel": f[0], "SQ_INSTS_VALU": float(f[2]), "utilisation": float(f[-1]), "peak_Ginst_per_s": 614.4,
-                    "source": "profiles/r01_pmc_valu.csv"}
+            n = float(f[2])
+            plain_ns, wide_ns = 1.32, 2.0
+            lo = n * plain_ns / 1024.0 * 1e-6 / avg_ms
+            w = mix.get(f[0], 0.0)
+            hi = n * ((1 - w) * plain_ns + w * wide_ns) / 1024.0 * 1e-6 / avg_ms
+            return {"kernel": f[0], "SQ_INSTS_VALU_per_launch": n, "static": True, "source": "profiles/" + os.path.basename(path),
+                    "ceiling_source": "profiles/r02_issue_rate_microbench.txt", "ns_per_plain_valu_per_simd": plain_ns,
+                    "ns_per_pk_dpp_valu_per_simd": wide_ns, "issue_utilisation_all_plain": round(lo, 3),
+                    "issue_utilisation_with_mix": round(hi, 3), "wide_instruction_fraction": w}
     return None
 
 
@@ -92,35 +121,48 @@ def algorithmic_bytes(N, V, D, HW, T, C, p, residual=False, C_bwd=None):
     }
 
 
-def cpu_baseline(scene, cam, budget_s=15.0):
-    """The reference's pure-PyTorch projection + cov3D + SH forward on the host cores.
+def cpu_baseline(scene, cam, frame=0, budget_s=15.0):
+    """The reference's pure-PyTorch per-actor rigid transform (RigidNodes.transform_means / transform_quats, batched) +
+    projection + cov3D + SH forward on the host cores.
 
     Thread count: measured on the MI355X host (256 hardware threads), torch's intra-op pool is fastest at 64 threads
     for these element-wise ops (70 M Gaussians/s at N = 1 M) and collapses beyond 128 (profiles/r01_cpu_thread_scan.txt),
-    so min(cores, 64) threads are used and reported.
+    so min(cores, 64) threads are used; both numbers are reported.
     """
     from oracle import torch_ref
-    cores = min(os.cpu_count() or 1, 64)
+    from emd_amd.motion import build_actor_pose
+    avail = os.cpu_count() or 1
+    cores = min(avail, 64)
     torch.set_num_threads(cores)
     means, scales, rots, shs = scene.means, torch.exp(scene.log_scales), scene.quats, scene.shs
     V, Pm, cp = cam.world_view_transform, cam.full_proj_transform, cam.camera_center
+    has_actors = scene.actor_id is not None
+    pose = build_actor_pose(scene.actor_quats, scene.actor_trans, scene.actor_valid, frame) if has_actors else None
+
+    def one():
+        m, q = means, rots
+        if has_actors:       # explicit motion first, as the reference does (rigid.py:478-568), then the projection path
+            m, q, _ = torch_ref.motion_transform(means, rots, None, scene.actor_id, pose)
+        return torch_ref.reference_projection_cpu(m, scales, q, shs, V, Pm, cp, 3)
+
     times = []
     with torch.no_grad():
         for _ in range(2):   # warm-up (thread pool, allocator)
             t0 = time.perf_counter()
-            torch_ref.reference_projection_cpu(means, scales, rots, shs, V, Pm, cp, 3)
+            one()
             first = time.perf_counter() - t0
         reps = int(max(3, min(20, budget_s / max(first, 1e-3))))
         for _ in range(reps):
             t0 = time.perf_counter()
-            torch_ref.reference_projection_cpu(means, scales, rots, shs, V, Pm, cp, 3)
+            one()
             times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": 1.0 / med, "unit": "iters/s (projection+cov3D+SH forward stage only)", "cores": cores,
-            "kind": "port", "ms_per_call": med * 1e3, "gaussians_per_s": scene.N / med,
-            "sample": f"reference pure-PyTorch geom_transform_points + get_covariance + eval_sh(deg 3) forward, "
-                      f"N={scene.N}, fp32, median of {len(times)} calls after 2 warm-ups, {cores} torch threads"}
+    return {"value": 1.0 / med, "unit": "iters/s (rigid transform + projection + cov3D + SH forward stage only)", "cores": cores,
+            "cores_available": avail, "kind": "port", "ms_per_call": med * 1e3, "gaussians_per_s": scene.N / med,
+            "sample": f"reference pure-PyTorch per-actor rigid transform ({'32 actors' if has_actors else 'none'}) + geom_transform_points + "
+                      f"get_covariance + eval_sh(deg 3) forward, N={scene.N}, fp32, median of {len(times)} calls after 2 warm-ups, "
+                      f"{cores} torch threads of {avail} hardware threads"}
 
 
 def main():
@@ -135,10 +177,12 @@ def main():
     ap.add_argument("--sync-count", action="store_true", help="read the duplicate count back every forward (reference behaviour)")
     ap.add_argument("--no-normal", action="store_true", help="skip the normal image (unused by the training loss)")
     ap.add_argument("--factored-sh", action="store_true", help="use the multi-GPU SH-gradient factor exchange at any world size (1 GPU: measures its local cost)")
+    ap.add_argument("--no-track-heads", action="store_true", help="leave the learned per-actor track offsets out of the step")
+    ap.add_argument("--densify-stats", action="store_true", help="also accumulate the per-view densification statistics every step (one launch)")
     args = ap.parse_args()
 
     from emd_amd import dp, scenes, _lib
-    from emd_amd import RasterConfig, GaussianRasterizer
+    from emd_amd import RasterCall, RasterOptions
     from emd_amd.model import StreetGaussians, render, l1_loss
 
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -151,58 +195,71 @@ def main():
 
     N, H, W = args.gaussians, args.height, args.width
     num_frames, num_actors = 50, 32
+    num_cams = dp.rig_size(world)             # 1 / 2 / 4 cameras on 1 / 2 / 4 GPUs (rank <-> camera of one timestamp), 6 on 8 GPUs
     scene = scenes.add_actors(scenes.make_static_scene(N, seed=0), num_actors=num_actors, pts_per_actor=5000,
                               num_frames=num_frames, seed=1)
-    model = StreetGaussians(scene, dev)
+    model = StreetGaussians(scene, dev, track_heads=not args.no_track_heads)
     params = [p for p in model.parameters()]
     bg = torch.zeros(3)
     g3 = torch.Generator().manual_seed(3)
     target = torch.rand(3, H, W, generator=g3).to(dev)
 
-    RasterConfig.compute_normal = not args.no_normal
-    RasterConfig.factored_sh_grad = world > 1 or args.factored_sh
-    RasterConfig.no_sync = not args.sync_count
+    factored = world > 1 or args.factored_sh
+    # options of THIS run's rasterizer calls (an instance, handed to every call: nothing process-wide is written)
+    opts = RasterOptions(compute_normal=not args.no_normal, factored_sh_grad=factored, no_sync=not args.sync_count)
     cams, campos_dev = {}, {}
+    stats = None
+    if args.densify_stats:
+        stats = [torch.zeros(N, 1, device=dev), torch.zeros(N, 1, device=dev), torch.zeros(N, device=dev)]
 
     def cam_for(step):
-        # frame of the 50-frame clip; rank r looks through rig camera r at that timestamp
-        f, c = step % num_frames, rank % len(scenes.RIG_YAWS)
+        # views are ordered timestamp-major and dealt out by dp.view_for: every rank renders a DISTINCT (frame, camera);
+        # with 8 ranks on the 6-camera rig two ranks hold cameras of the next timestamp (dp.frame_and_camera)
+        f, c = dp.frame_and_camera(step, rank, world, num_frames, num_cams)
         if (f, c) not in cams:
             cams[(f, c)] = scenes.rig_camera(f, c, H, W)
             campos_dev[(f, c)] = cams[(f, c)].camera_center.to(dev)      # once per camera: no per-step host-to-device copy
-        return f, cams[(f, c)]
+        return f, c, cams[(f, c)]
 
-    def one_step(step):
-        f, cam = cam_for(step)
+    def one_step(step, options=opts):
+        f, c, cam = cam_for(step)
         for p in params:
             p.grad = None
-        out = render(model, cam, bg, frame=f)
+        rec = RasterCall()
+        xchg = None
+        if options.factored_sh_grad:
+            # SH gradient (81 % of the gradient bytes): rank-one factors, 12 B per Gaussian and rank instead of all-reducing
+            # 192 B per Gaussian; the collectives are issued from inside backward(), right behind K8 (emd_amd/dp.py)
+            xchg = dp.GradientExchange(campos_dev[(f, c)], actor_ids=model.actor_id if model.has_actors else None)
+            rec.on_backward = xchg.start
+        out = render(model, cam, bg, frame=f, iteration=step, options=options, record=rec)
+        if xchg is not None:
+            xchg.actor_pose = out["actor_pose"]
         loss = l1_loss(out["render"], target)
         loss.backward()
-        if RasterConfig.factored_sh_grad:
-            # SH gradient (81 % of the gradient bytes): exchange the rank-one factors, 12 B per Gaussian and rank instead of
-            # all-reducing 192 B per Gaussian; everything else: in-place RCCL all-reduce (emd_amd/dp.py)
-            dp.exchange_sh_gradient(model._features, model._xyz, campos_dev[(f, rank % len(scenes.RIG_YAWS))], model.active_sh_degree,
-                                    actor_ids=model.actor_id if model.has_actors else None, actor_pose=out["actor_pose"],
-                                    also_allreduce=params)
+        if xchg is not None:
+            xchg.finish(model._features, model._xyz, model.active_sh_degree, other_params=params)
+        elif world > 1:
+            dp.allreduce_gradients(params)
+        if stats is not None:
+            dp.add_densification_stats(out["viewspace_points"].grad, out["radii"], *stats)
         return out
 
     # Size the binning workspace once, with synchronising forwards over the clip (the duplicate count D moves with
     # the ego pose and the actors); afterwards the async path never reads D back.  Overflow of any timed step is
     # checked after the timed region from the per-step device status words.
-    for s_ in range(num_frames):          # the clip's cameras are dataset state: built (and their centres uploaded) before timing
+    for s_ in range(args.warmup + args.steps):          # the cameras are dataset state: built (and their centres uploaded) before timing
         cam_for(s_)
-    RasterConfig.no_sync = False
-    out = one_step(0)
-    st = GaussianRasterizer.last_status()
     from emd_amd import rasterizer as _rz
-    dmax = st["num_rendered"]
+    sync_opts = opts.replace(no_sync=False)
+    out = one_step(0, sync_opts)
+    dmax = out["raster_call"].last_status()["num_rendered"]
     with torch.no_grad():
-        for f in sorted(set(list(range(0, num_frames, 7)) + [num_frames - 1])):
-            render(model, cam_for(f)[1], bg, frame=f)
-            dmax = max(dmax, GaussianRasterizer.last_status()["num_rendered"])
+        for s_ in sorted(set(list(range(0, args.warmup + args.steps, 7)) + [args.warmup + args.steps - 1])):
+            f, c, cam = cam_for(s_)
+            o = render(model, cam, bg, frame=f, options=sync_opts)
+            dmax = max(dmax, o["raster_call"].last_status()["num_rendered"])
     _rz._capacity_hint[(dev.index, H, W)] = int(dmax * 1.3) + 1024
-    RasterConfig.no_sync = not args.sync_count
     statuses = []
     for s in range(args.warmup):
         one_step(s)
@@ -215,7 +272,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         out = one_step(args.warmup + s)
-        statuses.append(GaussianRasterizer._last["status"])
+        statuses.append(out["raster_call"].status)
     t_enqueue = time.perf_counter() - t0      # host time to enqueue the K steps (the GPU runs behind it)
     torch.cuda.synchronize()
     if world > 1:
@@ -227,13 +284,16 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
-    overflow = int(torch.stack(statuses)[:, 1].sum().item()) if statuses else 0
+    st_all = torch.stack(statuses).cpu().numpy().astype("int64") & 0xFFFFFFFF if statuses else None
+    overflow = int(st_all[:, 1].sum()) if statuses else 0
     assert overflow == 0, "binning workspace overflowed during the timed region"
 
     if rank == 0:
-        V, D = st["num_visible"], st["num_rendered"]
+        # V and D of EVERY timed step (device status words of rank 0's views), not of one frame
+        Ds, Vs = st_all[:, 0], st_all[:, 2]
+        D, V = float(Ds.mean()), float(Vs.mean())
         T = ((W + 15) // 16) * ((H + 15) // 16)
-        C = 7 if RasterConfig.compute_normal else 4
+        C = 7 if opts.compute_normal else 4
         passes = (max(T - 1, 1).bit_length() + 7) // 8            # radix passes over the D duplicates (tile bits)
         ab = algorithmic_bytes(N, V, D, H * W, T, C, passes, C_bwd=4)   # the L1 loss sends no gradient into the normal image
         stages = {}
@@ -245,17 +305,30 @@ def main():
         dom = max(stages, key=lambda k: stages[k]["ms"])
         kernel_ms = sum(v["ms"] for v in stages.values())
         total_alg = sum(ab.values())
+        full = (N, H, W) == (2_000_000, 1066, 1600)
+        traffic = pmc_traffic(dom, passes) if full else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic(dom, passes) if (N, H, W) == (2_000_000, 1066, 1600) else None,
-                    "traffic_source": "profiles/r01_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
-                    "secondary_bound": "fp32 vector issue rate: the render kernels are VALU-bound (DESIGN.md section 3)",
-                    "valu": pmc_valu(dom) if (N, H, W) == (2_000_000, 1066, 1600) else None,
+                    "traffic": traffic,
+                    "traffic_static": {"static": True, "source": None if _pmc_path(PMC_TRAFFIC_CSV) is None else "profiles/" + os.path.basename(_pmc_path(PMC_TRAFFIC_CSV)),
+                                       "note": "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the same command, bytes per launch; a committed file constant, not measured in this run"},
+                    "secondary_bound": "fp32 vector issue rate: the render kernels are issue-bound (DESIGN.md section 6)",
+                    "issue": issue_bound(dom, stages[dom]["ms"]) if full else None,
                     "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": stages[dom]["ms"],
+                    "per_step": {"steps": int(len(Ds)), "D_min": int(Ds.min()), "D_mean": round(D, 1), "D_max": int(Ds.max()),
+                                 "V_min": int(Vs.min()), "V_mean": round(V, 1), "V_max": int(Vs.max()),
+                                 "note": "duplicates D and visible Gaussians V of every timed step, read from the device status words after the timed region; algorithmic bytes use the means"},
                     "whole_iter": {"algorithmic_GB": round(total_alg / 1e9, 3), "kernel_ms": round(kernel_ms, 3),
                                    "GBps": round(total_alg / 1e9 / (kernel_ms * 1e-3), 1),
                                    "frac": round(total_alg / 1e9 / (kernel_ms * 1e-3) / HBM_PEAK_GBS, 4)},
                     "stages": stages}
+        if world == 1:
+            mapping = "1 GPU: camera 0 of frame (step mod 50)"
+        elif world == num_cams:
+            mapping = f"{world} GPUs: rank r <-> camera r of the {num_cams}-camera rig, all ranks of a step share one timestamp"
+        else:
+            mapping = (f"{world} GPUs on the {num_cams}-camera rig: view (step * {world} + rank) of the timestamp-major view list, i.e. "
+                       f"{world - num_cams} rank(s) per step render cameras of the NEXT timestamp; every rank renders a distinct view")
         res = {
             "metric": "train iters/s (fwd+bwd) @1066x1600, 2M Gaussians; 1/2/4/8 GPU",
             "value": world * args.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
@@ -263,18 +336,23 @@ def main():
             "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: 50-frame dynamic clip, per-actor rigid motion on 2M Gaussians "
-                                   "(32 actors x 5000), SH degree 3, one 1066x1600 view per GPU per step, L1 loss, "
-                                   "fwd+bwd to all 59 floats/Gaussian + actor poses",
-                       "gaussians": N, "height": H, "width": W, "visible_V": V, "duplicates_D": D, "tiles_T": T,
+                                   "(32 actors x 5000" + ("" if args.no_track_heads else ", learned per-actor track offsets") + "), SH degree 3, "
+                                   "one 1066x1600 view per GPU per step, L1 loss, fwd+bwd to all 59 floats/Gaussian + actor poses"
+                                   + ("" if args.no_track_heads else " + track heads"),
+                       "gaussians": N, "height": H, "width": W, "visible_V": round(V, 1), "duplicates_D": round(D, 1), "tiles_T": T,
                        "radix_passes_depth_on_N": 4, "radix_passes_tile_on_D": passes, "blended_channels_C": C, "views_per_step": world,
+                       "rig_cameras": num_cams, "rank_view_mapping": mapping, "track_heads": not args.no_track_heads,
+                       "densification_stats_in_step": bool(args.densify_stats),
                        "parallelism": f"view-parallel dp{world}", "count_readback": bool(args.sync_count),
                        "gradient_exchange": ("none (1 GPU)" if world == 1 else
-                                             "SH gradient as rank-one factors: all-gather of 12 B per Gaussian and rank, dense average "
-                                             "rebuilt locally; one RCCL all-reduce (AVG) of the remaining 44 B per Gaussian (one slab) + actor poses")},
+                                             "SH gradient as rank-one factors: all-gather of 12 B per Gaussian and rank + camera centres + per-view actor "
+                                             "pose tables, dense average rebuilt locally; one RCCL all-reduce (AVG) of the remaining 44 B per Gaussian "
+                                             "(one slab, started inside backward()) + actor poses / track heads")},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:      # the CPU leg is timed on rank 0 of the 1-GPU run only
-            res["cpu_baseline"] = cpu_baseline(scene, cam_for(0)[1])
+            f0, _, cam0 = cam_for(0)
+            res["cpu_baseline"] = cpu_baseline(scene, cam0, frame=f0)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()

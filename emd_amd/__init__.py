@@ -4,6 +4,6 @@ Only the hot path lives here: explicit-motion transform ->
 tile duplication + radix sort -> per-tile alpha compositing with SH colour, forward and backward, as
 hand-written HIP for gfx950 behind the C ABI of include/emd_raster.h.
 """
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, RasterConfig  # noqa: F401
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, RasterCall, RasterConfig, RasterOptions  # noqa: F401
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "RasterConfig"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "RasterCall", "RasterConfig", "RasterOptions"]

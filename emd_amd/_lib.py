@@ -10,13 +10,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
+SETTINGS_DEV_FLOATS = 38
 TILE = 16
 ACTOR_STRIDE = 12
 BWD_STRIDE = 12
 
 EMD_OK, EMD_ERR_INVALID, EMD_ERR_CAPACITY, EMD_ERR_HIP, EMD_ERR_WORKSPACE = 0, -1, -2, -3, -4
-FLAG_NORMAL, FLAG_MOTION, FLAG_ABSGRAD, FLAG_NO_SYNC, FLAG_CLAMP_RGB01, FLAG_RAW_PARAMS = 1, 2, 4, 8, 16, 32
+FLAG_NORMAL, FLAG_MOTION, FLAG_ABSGRAD, FLAG_NO_SYNC, FLAG_CLAMP_RGB01, FLAG_RAW_PARAMS, FLAG_SDEV_TANFOV = 1, 2, 4, 8, 16, 32, 64
 
 _f = C.c_void_p  # device pointers are passed as integers
 
@@ -47,7 +48,7 @@ class EmdFwdArgs(C.Structure):
                 ("out_color", _f), ("out_depth", _f), ("out_normal", _f), ("out_alpha", _f), ("radii", _f),
                 ("geom_ws", _f), ("geom_bytes", C.c_size_t), ("bin_ws", _f), ("bin_bytes", C.c_size_t),
                 ("img_ws", _f), ("img_bytes", C.c_size_t), ("status", _f),
-                ("num_rendered", C.c_int64), ("num_visible", C.c_int64)]
+                ("num_rendered", C.c_int64), ("num_visible", C.c_int64), ("settings_dev", _f)]
 
 
 class EmdBwdArgs(C.Structure):
@@ -63,7 +64,7 @@ class EmdBwdArgs(C.Structure):
                 ("dL_dmeans3D", _f), ("dL_dmeans2D", _f), ("dL_dmeans2D_abs", _f), ("dL_dshs", _f),
                 ("dL_dcolors", _f), ("dL_dopacities", _f), ("dL_dscales", _f), ("dL_drotations", _f),
                 ("dL_dcov3D", _f), ("dL_dactor_pose", _f), ("dL_dresidual_dx", _f), ("dL_dresidual_dq", _f),
-                ("dL_dsh_color", _f)]
+                ("dL_dsh_color", _f), ("settings_dev", _f)]
 
 
 SKY_CLAMP01, SKY_BLEND_S3G, SKY_BLEND_ADD, SKY_INTERLEAVED = 1, 2, 4, 8
@@ -173,8 +174,8 @@ def load():
     lib.emd_image_loss_workspace.argtypes = [C.c_int, C.c_int]
     lib.emd_image_loss_workspace.restype = C.c_size_t
     lib.emd_image_loss.argtypes = [C.POINTER(EmdLossArgs), C.c_void_p, C.c_size_t, C.c_void_p]
-    lib.emd_sh_grad_from_factors.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(EmdMotion), C.c_void_p,
-                                             C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    lib.emd_sh_grad_from_factors.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(EmdMotion), C.c_int32,
+                                             C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     lib.emd_densification_stats.argtypes = [C.c_int32] + [C.c_void_p] * 6
     lib.emd_hexplane_forward.argtypes = [C.POINTER(EmdHexArgs), C.c_void_p]
     lib.emd_hexplane_backward.argtypes = [C.POINTER(EmdHexArgs), C.POINTER(EmdHexGrads), C.c_void_p]

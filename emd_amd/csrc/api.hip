@@ -73,8 +73,8 @@ int emd_launch_motion_backward(int n, const float* means, const float* quats, co
 int emd_launch_sh_forward(int n, int deg, int M, const float* dirs, const float* coeffs, float* rgb, hipStream_t st);
 int emd_launch_sh_backward(int n, int deg, int M, const float* dirs, const float* coeffs, const float* g_rgb,
                            float* d_coeffs, float* d_dirs, hipStream_t st);
-int emd_launch_sh_grad_from_factors(int n, int V, int deg, int M, const float* means, const EmdMotion& mo, const float* campos,
-                                    const float* gc, float scale, float* d_shs, hipStream_t st);
+int emd_launch_sh_grad_from_factors(int n, int V, int deg, int M, const float* means, const EmdMotion& mo, int pose_per_view,
+                                    const float* campos, const float* gc, float scale, float* d_shs, hipStream_t st);
 int emd_launch_densification_stats(int n, const int32_t* radii, const float* g2d, float* accum, float* denom, float* max_radii,
                                    hipStream_t st);
 int emd_launch_actor_pose_forward(int A, const float* q, const float* t, const uint8_t* valid, const float* dt, const float* dq,
@@ -144,7 +144,7 @@ static int check_common(const EmdSettings& s, int N, int M, const float* means3D
     }
     if (s.sh_degree < 0 || s.sh_degree > 3) { emd_set_error("sh_degree %d not in 0..3", s.sh_degree); return EMD_ERR_INVALID; }
     if (shs && M < (s.sh_degree + 1) * (s.sh_degree + 1)) { emd_set_error("shs holds %d coefficients, degree %d needs %d", M, s.sh_degree, (s.sh_degree + 1) * (s.sh_degree + 1)); return EMD_ERR_INVALID; }
-    if (!(s.tanfovx > 0.f) || !(s.tanfovy > 0.f)) { emd_set_error("tanfov must be positive"); return EMD_ERR_INVALID; }
+    if (!(flags & EMD_FLAG_SDEV_TANFOV) && (!(s.tanfovx > 0.f) || !(s.tanfovy > 0.f))) { emd_set_error("tanfov must be positive"); return EMD_ERR_INVALID; }
     if (flags & EMD_FLAG_MOTION) {
         if (mo.actor_id && (!mo.actor_pose || mo.num_actors <= 0)) { emd_set_error("motion: actor_id given without actor_pose"); return EMD_ERR_INVALID; }
         if (cov) { emd_set_error("motion: cov3D_precomp cannot be combined with the fused motion transform"); return EMD_ERR_INVALID; }
@@ -165,6 +165,7 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
     }
     if ((a->flags & EMD_FLAG_NORMAL) && !a->out_normal) { emd_set_error("forward: EMD_FLAG_NORMAL without out_normal"); return EMD_ERR_INVALID; }
     if (a->bin_capacity < 0) { emd_set_error("forward: negative bin_capacity"); return EMD_ERR_INVALID; }
+    if ((a->flags & EMD_FLAG_SDEV_TANFOV) && !a->settings_dev) { emd_set_error("forward: EMD_FLAG_SDEV_TANFOV without settings_dev"); return EMD_ERR_INVALID; }
     const int gx = (a->s.image_width + EMD_TILE_X - 1) / EMD_TILE_X, gy = (a->s.image_height + EMD_TILE_Y - 1) / EMD_TILE_Y;
     GeomWs g; BinWs b; ImgWs im;
     emd_carve_geom(a->geom_ws, N, &g);
@@ -185,7 +186,7 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
     pa.s = a->s; pa.N = N; pa.M = a->sh_coeffs; pa.flags = a->flags;
     pa.means3D = a->means3D; pa.shs = a->shs; pa.colors_precomp = a->colors_precomp; pa.opacities = a->opacities;
     pa.scales = a->scales; pa.rotations = a->rotations; pa.cov3D_precomp = a->cov3D_precomp;
-    pa.motion = a->motion; pa.radii = a->radii; pa.g = g; pa.status = a->status;
+    pa.motion = a->motion; pa.radii = a->radii; pa.g = g; pa.status = a->status; pa.sdev = a->settings_dev;
     if (!(a->flags & EMD_FLAG_MOTION)) memset(&pa.motion, 0, sizeof(pa.motion));
     emd_prof_begin(PROF_PREPROCESS, st);
     rc = emd_launch_preprocess(pa, st);
@@ -208,7 +209,7 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
         }
     }
     emd_prof_switch(PROF_RANGES, PROF_RENDER_FWD, st);
-    rc = emd_launch_render_forward(a->s, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->out_alpha, st);
+    rc = emd_launch_render_forward(a->s, a->settings_dev, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->out_alpha, st);
     emd_prof_end(PROF_RENDER_FWD, st);
     if (rc) return rc;
     STAGE_SYNC("render_forward");
@@ -245,7 +246,7 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
         pose_grad_n = a->motion.num_actors * EMD_ACTOR_STRIDE;
     }
     emd_prof_switch(PROF_OTHER, PROF_RENDER_BWD, st);
-    rc = emd_launch_render_backward(a->s, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->dL_dcolor,
+    rc = emd_launch_render_backward(a->s, a->settings_dev, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->dL_dcolor,
                                     a->dL_ddepth, a->dL_dalpha, a->dL_dnormal, (float*)a->bwd_ws, pose_grad, pose_grad_n, st);
     if (rc) return rc;
     STAGE_SYNC("render_backward");
@@ -260,6 +261,7 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     pb.dL_dscales = a->dL_dscales; pb.dL_drotations = a->dL_drotations; pb.dL_dcov3D = a->dL_dcov3D;
     pb.dL_dactor_pose = a->dL_dactor_pose; pb.dL_dresidual_dx = a->dL_dresidual_dx; pb.dL_dresidual_dq = a->dL_dresidual_dq;
     pb.dL_dsh_color = a->dL_dsh_color;
+    pb.sdev = a->settings_dev;
     emd_prof_switch(PROF_RENDER_BWD, PROF_PREPROCESS_BWD, st);
     rc = emd_launch_preprocess_backward(pb, st);
     emd_prof_end(PROF_PREPROCESS_BWD, st);
@@ -335,8 +337,8 @@ int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* d
 }
 
 int emd_sh_grad_from_factors(int32_t n, int32_t num_views, int32_t degree, int32_t sh_coeffs, const float* means3D,
-                             const EmdMotion* motion, const float* campos, const float* sh_color_grads, float scale,
-                             float* dL_dshs, void* hip_stream) {
+                             const EmdMotion* motion, int32_t pose_per_view, const float* campos, const float* sh_color_grads,
+                             float scale, float* dL_dshs, void* hip_stream) {
     if (n < 0 || num_views < 1 || degree < 0 || degree > 3 || sh_coeffs < (degree + 1) * (degree + 1) || sh_coeffs > 16 ||
         (n > 0 && (!means3D || !campos || !sh_color_grads || !dL_dshs))) {
         emd_set_error("sh_grad_from_factors: bad argument"); return EMD_ERR_INVALID;
@@ -344,7 +346,7 @@ int emd_sh_grad_from_factors(int32_t n, int32_t num_views, int32_t degree, int32
     EmdMotion mo;
     memset(&mo, 0, sizeof(mo));
     if (motion) mo = *motion;
-    return emd_launch_sh_grad_from_factors(n, num_views, degree, sh_coeffs, means3D, mo, campos, sh_color_grads, scale, dL_dshs,
+    return emd_launch_sh_grad_from_factors(n, num_views, degree, sh_coeffs, means3D, mo, pose_per_view ? 1 : 0, campos, sh_color_grads, scale, dL_dshs,
                                            (hipStream_t)hip_stream);
 }
 

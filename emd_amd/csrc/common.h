@@ -147,15 +147,16 @@ struct PreArgs {
     int32_t* radii;
     GeomWs g;
     EmdStatus* status;
+    const float* sdev;       // device copy of bg / viewmatrix / projmatrix / campos (EmdFwdArgs.settings_dev) or null
 };
 int emd_launch_preprocess(const PreArgs& a, hipStream_t st);                 // preprocess.hip
 int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,
                        hipStream_t st);                                       // binning.hip
 int emd_launch_export_keys(int64_t D, const GeomWs& g, const BinWs& b, uint64_t* keys, hipStream_t st);  // binning.hip
-int emd_launch_render_forward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
+int emd_launch_render_forward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                               float* out_color, float* out_depth, float* out_normal, float* out_alpha,
                               hipStream_t st);                                 // render.hip
-int emd_launch_render_backward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
+int emd_launch_render_backward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                                const float* out_color, const float* out_depth, const float* out_normal,
                                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                                const float* dL_dnormal, float* grad_rec, float* zero_buf, int zero_n,
@@ -170,5 +171,18 @@ struct PreBwdArgs {
     const float* grad_rec;  // [N][EMD_BWD_STRIDE]
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dmeans2D_abs, *dL_dshs, *dL_dcolors, *dL_dopacities, *dL_dscales,
         *dL_drotations, *dL_dcov3D, *dL_dactor_pose, *dL_dresidual_dx, *dL_dresidual_dq, *dL_dsh_color;
+    const float* sdev;
 };
+
+// Camera-dependent settings from their device copy (uniform scalar loads), replacing the by-value fields.
+__device__ __forceinline__ void emd_settings_from_device(EmdSettings& S, const float* __restrict__ sdev, int flags) {
+    if (!sdev) return;
+    if (flags & EMD_FLAG_SDEV_TANFOV) { S.tanfovx = sdev[38]; S.tanfovy = sdev[39]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) S.bg[k] = sdev[k];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { S.viewmatrix[k] = sdev[3 + k]; S.projmatrix[k] = sdev[19 + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) S.campos[k] = sdev[35 + k];
+}
 int emd_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t st);     // preprocess.hip

@@ -247,7 +247,8 @@ __device__ __forceinline__ void sh_row_load(const float* __restrict__ shs, int i
 #define PRE_BLOCK 64
 __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_preprocess(PreArgs a) {
     __shared__ float4 s_sh[(PRE_BLOCK / 2) * SH_ROW4];       // half of the wave's rows at a time: 6.5 KB keeps four waves per SIMD
-    const EmdSettings& S = a.s;
+    EmdSettings S = a.s;
+    emd_settings_from_device(S, a.sdev, a.flags);
     const bool sh_staged = a.shs && a.M == 16;
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
     uint32_t touched = 0, rect = 0, dkey = 0xFFFFFFFFu;
@@ -493,7 +494,8 @@ __device__ __forceinline__ void reduce_pose_grad(int a_id, const float pose_g[12
 // K8
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a) {
-    const EmdSettings& S = a.s;
+    EmdSettings S = a.s;
+    emd_settings_from_device(S, a.sdev, a.flags);
     // staging of the dL/dshs rows (coalesced copy-out), half of the block's rows at a time: 26 KB instead of 52 keeps five
     // workgroup-waves per SIMD resident instead of three.  A row is the outer product basis[k] x gc[c]: the lane keeps the 19 factors
     // and multiplies them out when its half is staged.
@@ -814,7 +816,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sh_backward(int n, int deg, int M
 // Dense, view-averaged SH gradient from the per-view rank-one factors (emd_sh_grad_from_factors): one Gaussian per lane,
 // rows leave through LDS as coalesced dwordx4 stores like K8's.
 __global__ void __launch_bounds__(EMD_BLOCK) k_sh_grad_from_factors(int n, int V, int deg, const float* __restrict__ means,
-                                                                    EmdMotion mo, const float* __restrict__ campos,
+                                                                    EmdMotion mo, int pose_per_view, const float* __restrict__ campos,
                                                                     const float* __restrict__ gc, float scale,
                                                                     float* __restrict__ d_shs) {
     __shared__ float4 s_sh[(EMD_BLOCK / 2) * SH_ROW4];    // half of the block's rows at a time (26 KB: more resident waves)
@@ -827,10 +829,18 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sh_grad_from_factors(int n, int V
         if (mo.actor_id || mo.residual_dx) motion_point(i, means, nullptr, nullptr, mo, m, qd, &od, false);
         else { m[0] = means[3 * i]; m[1] = means[3 * i + 1]; m[2] = means[3 * i + 2]; }
         const int K = (deg + 1) * (deg + 1);
+        // views of different timestamps (6 cameras on 8 ranks): an actor's Gaussians sit at a different world position in every
+        // view, so the pose table is per view ([V][A][12]); static Gaussians keep the position computed above
+        const bool moving = pose_per_view && mo.actor_id && mo.actor_id[i] >= 0;
         for (int v = 0; v < V; v++) {
             const float* g = gc + ((size_t)v * n + i) * 3;
             const float g0 = g[0], g1 = g[1], g2 = g[2];
             if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;          // not visible in view v
+            if (moving && v > 0) {
+                EmdMotion mv = mo;
+                mv.actor_pose = mo.actor_pose + (size_t)v * mo.num_actors * EMD_ACTOR_STRIDE;
+                motion_point(i, means, nullptr, nullptr, mv, m, qd, &od, false);
+            }
             float d[3] = {m[0] - campos[3 * v], m[1] - campos[3 * v + 1], m[2] - campos[3 * v + 2]};
             const float nn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
             d[0] /= nn; d[1] /= nn; d[2] /= nn;
@@ -1063,11 +1073,11 @@ int emd_launch_sh_backward(int n, int deg, int M, const float* dirs, const float
     return EMD_OK;
 }
 
-int emd_launch_sh_grad_from_factors(int n, int V, int deg, int M, const float* means, const EmdMotion& mo, const float* campos,
-                                    const float* gc, float scale, float* d_shs, hipStream_t st) {
+int emd_launch_sh_grad_from_factors(int n, int V, int deg, int M, const float* means, const EmdMotion& mo, int pose_per_view,
+                                    const float* campos, const float* gc, float scale, float* d_shs, hipStream_t st) {
     if (n <= 0) return EMD_OK;
     if (M != 16) { emd_set_error("sh_grad_from_factors: the staged row store needs sh_coeffs == 16"); return EMD_ERR_INVALID; }
-    hipLaunchKernelGGL(k_sh_grad_from_factors, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, V, deg, means, mo, campos,
+    hipLaunchKernelGGL(k_sh_grad_from_factors, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, V, deg, means, mo, pose_per_view, campos,
                        gc, scale, d_shs);
     EMD_LAUNCH_CHECK();
     return EMD_OK;

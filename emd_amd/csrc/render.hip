@@ -22,6 +22,7 @@ namespace {
 struct RenderDims {
     int W, H, gx, gy;
     float bg[3];
+    const float* bg_dev;     // device copy of the background colour (EmdFwdArgs.settings_dev) or null
 };
 
 // blockIdx -> (tile, quadrant).  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one).  The tiles are
@@ -159,6 +160,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
     uint32_t quad;
     const uint32_t tile = ordered_quadrant_block(blockIdx.x, (uint32_t)(d.gx * d.gy), tile_order, &quad);
     if (tile >= (uint32_t)(d.gx * d.gy)) return;
+    const float bg0 = d.bg_dev ? d.bg_dev[0] : d.bg[0], bg1 = d.bg_dev ? d.bg_dev[1] : d.bg[1], bg2 = d.bg_dev ? d.bg_dev[2] : d.bg[2];
     const uint32_t lane = threadIdx.x, row = lane >> 4, l = lane & 15;
     const int qxi = (int)((tile % (uint32_t)d.gx) * EMD_TILE_X + (quad & 1) * 8), qyi = (int)((tile / (uint32_t)d.gx) * EMD_TILE_Y + (quad >> 1) * 8);
     const float qx0 = (float)qxi, qy0 = (float)qyi;
@@ -246,9 +248,9 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
     }
     if (inside) {
         const size_t HW = (size_t)d.H * d.W, pix = (size_t)py * d.W + px;
-        out_color[pix] = __builtin_fmaf(T, d.bg[0], C0);
-        out_color[HW + pix] = __builtin_fmaf(T, d.bg[1], C1);
-        out_color[2 * HW + pix] = __builtin_fmaf(T, d.bg[2], C2);
+        out_color[pix] = __builtin_fmaf(T, bg0, C0);
+        out_color[HW + pix] = __builtin_fmaf(T, bg1, C1);
+        out_color[2 * HW + pix] = __builtin_fmaf(T, bg2, C2);
         out_depth[pix] = Dz;
         if (NORMAL) { out_normal[pix] = N0; out_normal[HW + pix] = N1; out_normal[2 * HW + pix] = N2; }
         out_alpha[pix] = 1.f - T;
@@ -342,9 +344,10 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
         if (dL_ddepth) dD = dL_ddepth[pix];
         if (dL_dalpha) dA = dL_dalpha[pix];
         if (NORMAL && dL_dnormal) { dN0 = dL_dnormal[pix]; dN1 = dL_dnormal[HW + pix]; dN2 = dL_dnormal[2 * HW + pix]; }
-        const float bgdot = d.bg[0] * dC0 + d.bg[1] * dC1 + d.bg[2] * dC2;
-        float Stot = (out_color[pix] - Tf * d.bg[0]) * dC0 + (out_color[HW + pix] - Tf * d.bg[1]) * dC1 +
-                     (out_color[2 * HW + pix] - Tf * d.bg[2]) * dC2 + out_depth[pix] * dD;
+        const float bg0 = d.bg_dev ? d.bg_dev[0] : d.bg[0], bg1 = d.bg_dev ? d.bg_dev[1] : d.bg[1], bg2 = d.bg_dev ? d.bg_dev[2] : d.bg[2];
+        const float bgdot = bg0 * dC0 + bg1 * dC1 + bg2 * dC2;
+        float Stot = (out_color[pix] - Tf * bg0) * dC0 + (out_color[HW + pix] - Tf * bg1) * dC1 +
+                     (out_color[2 * HW + pix] - Tf * bg2) * dC2 + out_depth[pix] * dD;
         if (NORMAL && dL_dnormal) Stot += out_normal[pix] * dN0 + out_normal[HW + pix] * dN1 + out_normal[2 * HW + pix] * dN2;
         Q = Tf * (dA - bgdot) - Stot;
     }
@@ -498,8 +501,9 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
     if (head > 0) process_batch(head);
 }
 
-RenderDims make_dims(const EmdSettings& s) {
+RenderDims make_dims(const EmdSettings& s, const float* sdev) {
     RenderDims d;
+    d.bg_dev = sdev;
     d.W = s.image_width; d.H = s.image_height;
     d.gx = (d.W + EMD_TILE_X - 1) / EMD_TILE_X; d.gy = (d.H + EMD_TILE_Y - 1) / EMD_TILE_Y;
     d.bg[0] = s.bg[0]; d.bg[1] = s.bg[1]; d.bg[2] = s.bg[2];
@@ -508,10 +512,10 @@ RenderDims make_dims(const EmdSettings& s) {
 
 }  // namespace
 
-int emd_launch_render_forward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
+int emd_launch_render_forward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                               float* out_color, float* out_depth, float* out_normal, float* out_alpha,
                               hipStream_t st) {
-    const RenderDims d = make_dims(s);
+    const RenderDims d = make_dims(s, sdev);
     const int T = d.gx * d.gy;
     if (T <= 0) return EMD_OK;
     const uint32_t* pl = b.vals[b.sorted_buf];
@@ -525,11 +529,11 @@ int emd_launch_render_forward(const EmdSettings& s, int flags, const GeomWs& g, 
     return EMD_OK;
 }
 
-int emd_launch_render_backward(const EmdSettings& s, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
+int emd_launch_render_backward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                                const float* out_color, const float* out_depth, const float* out_normal,
                                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                                const float* dL_dnormal, float* grad_rec, float* zero_buf, int zero_n, hipStream_t st) {
-    const RenderDims d = make_dims(s);
+    const RenderDims d = make_dims(s, sdev);
     const int T = d.gx * d.gy;
     if (T <= 0) return EMD_OK;
     const uint32_t* pl = b.vals[b.sorted_buf];

@@ -5,8 +5,10 @@ The reference trains one view per step on one GPU (S3Gaussian/train.py:203; Omni
 at world_size 1 this module is a no-op and the step is the reference step.  Design:
   - parameters, actor tables and MLPs are replicated (2 M x 236 B = 472 MB << 288 GB);
   - step s, rank r renders view `views[(s * W + r) % len(views)]`; no collective on the data path until gradients;
-  - gradients are reduced per attribute tensor, in place, asynchronously, largest (SH, 192 N bytes) first, then
-    awaited together: no flatten / copy passes over the 472 MB slab;
+  - gradient exchange per step (`GradientExchange`): the SH gradient travels as rank-one factors (all-gather of 12 B per Gaussian
+    and rank + camera centres + per-view actor pose tables, dense gradient rebuilt locally), the four small per-Gaussian
+    gradients as ONE in-place all-reduce of the slab the rasterizer's backward carved them from, started from inside
+    backward(); `allreduce_gradients` is the plain dense path (no rasterizer record needed);
   - densification statistics are computed per view BEFORE reduction (gaussian_model.py:728-730; train.py:406):
     sum of ||d mean2D|| and of counts (SUM), max radii (MAX).
 """
@@ -57,10 +59,26 @@ def allreduce_gradients(params, average=True):
             g.div_(w_)
 
 
+def rig_size(world):
+    """Cameras of the synthetic rig used at `world` GPUs (BASELINE configs 3-5): 1 camera on 1 GPU, a 2- / 4-camera rig on 2 / 4
+    GPUs (config 4: rank r <-> camera r of the same timestamp), the 6-camera rig on 8 GPUs (config 5)."""
+    return min(max(int(world), 1), 6)
+
+
+def frame_and_camera(step, rank, world, num_frames, num_cams):
+    """(frame, camera) rendered by `rank` at `step`: views are ordered timestamp-major, `view = frame * num_cams + camera`, and
+    dealt out by `view_for`.  With `world == num_cams` (configs 3, 4) the ranks of a step hold the cameras of ONE timestamp; with 8
+    ranks on the 6-camera rig (config 5) ranks 6 and 7 take the first two cameras of the NEXT timestamp -- every rank renders a
+    distinct view, nobody idles, and the exchange below handles the mixed timestamps."""
+    v = view_for(step, rank, world, num_frames * num_cams)
+    return v // num_cams, v % num_cams
+
+
 def sh_grad_from_factors(means3D, campos, sh_color_grads, sh_degree, sh_coeffs=16, actor_ids=None, actor_pose=None, residual_dx=None,
                          scale=1.0):
-    """dL/dshs [N,sh_coeffs,3] = scale * sum_v basis(normalize(world_mean - campos[v])) (x) sh_color_grads[v]   (one HIP launch).
-    means3D [N,3]; campos [V,3]; sh_color_grads [V,N,3] (GaussianRasterizer.last_sh_color_grad of every view)."""
+    """dL/dshs [N,sh_coeffs,3] = scale * sum_v basis(normalize(world_mean_v - campos[v])) (x) sh_color_grads[v]   (one HIP launch).
+    means3D [N,3]; campos [V,3]; sh_color_grads [V,N,3] (RasterCall.sh_color_grad of every view); actor_pose [A,12] (all views
+    share a timestamp) or [V,A,12] (one pose table per view: mixed timestamps)."""
     import ctypes as C
     from . import _lib as L
     from .rasterizer import _fill_motion
@@ -72,67 +90,120 @@ def sh_grad_from_factors(means3D, campos, sh_color_grads, sh_degree, sh_coeffs=1
     mo = L.EmdMotion()
     ids = None if actor_ids is None else actor_ids.to(torch.int32).contiguous()          # (kept alive until the launch is queued)
     pose = None if actor_pose is None else actor_pose.detach().contiguous().float()
+    per_view = pose is not None and pose.dim() == 3
+    if per_view:
+        assert pose.shape[0] == V, "one pose table per view"
     rdx = None if residual_dx is None else residual_dx.detach().contiguous().float()
-    _fill_motion(mo, ids, pose, rdx, None)
+    _fill_motion(mo, ids, pose if not per_view else pose[0], rdx, None)
+    if per_view:
+        mo.actor_pose = pose.data_ptr()
     out = torch.empty(N, sh_coeffs, 3, device=means3D.device, dtype=torch.float32)
-    L.check(L.load().emd_sh_grad_from_factors(N, V, int(sh_degree), int(sh_coeffs), means3D.data_ptr(), C.byref(mo), campos.data_ptr(),
-                                              g.data_ptr(), float(scale), out.data_ptr(),
+    L.check(L.load().emd_sh_grad_from_factors(N, V, int(sh_degree), int(sh_coeffs), means3D.data_ptr(), C.byref(mo), 1 if per_view else 0,
+                                              campos.data_ptr(), g.data_ptr(), float(scale), out.data_ptr(),
                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_sh_grad_from_factors")
     return out
 
 
-def exchange_sh_gradient(sh_param, means3D, campos_local, sh_degree, actor_ids=None, actor_pose=None, residual_dx=None, average=True,
-                         also_allreduce=None):
-    """View-parallel replacement of the all-reduce of the SH gradient (81 % of the gradient bytes): dL/dshs of a view is the
-    outer product of the SH basis of its view direction and a per-Gaussian colour gradient, so each rank all-gathers the
-    [N,3] factors (GaussianRasterizer.last_sh_color_grad, published by the backward when RasterConfig.factored_sh_grad is set)
-    and the camera centres -- 12 bytes per Gaussian and rank instead of 192 -- and rebuilds the same dense, averaged gradient
-    locally.  Needs the world-space means to be identical on all ranks (same timestamp), which view-parallel steps have.
-    Sets sh_param.grad.  `also_allreduce`: the other parameters; their gradients are all-reduced (averaged) in place, issued
-    right behind the gathers so that the local rebuild overlaps them."""
-    from .rasterizer import GaussianRasterizer
-    g_local = GaussianRasterizer.last_sh_color_grad
-    if g_local is None:
-        raise RuntimeError("no SH colour-gradient factor: set RasterConfig.factored_sh_grad before the backward pass")
-    W = world_size()
-    works, others = [], []
-    if W == 1:
-        g_all, campos = g_local[None], campos_local.reshape(1, 3).to(g_local.device)
-    else:
-        N = g_local.shape[0]
-        g_cat = torch.empty(W * N, 3, device=g_local.device, dtype=g_local.dtype)      # ranks concatenated along dim 0
-        campos = torch.empty(W, 3, device=g_local.device, dtype=torch.float32)
-        gathers = [dist.all_gather_into_tensor(g_cat, g_local.contiguous(), async_op=True),
-                   dist.all_gather_into_tensor(campos, campos_local.reshape(1, 3).to(g_local.device, torch.float32).contiguous(), async_op=True)]
-        if also_allreduce is not None:
-            others = [p.grad for p in also_allreduce if p is not sh_param and p.grad is not None]
-            # the rasterizer hands out its four small gradients as views of one slab (44 B per Gaussian): when autograd kept those
-            # views as the parameters' .grad, one collective over the slab replaces four
-            slab = GaussianRasterizer.last_grad_slab
-            if slab is not None:
-                base = slab.untyped_storage().data_ptr()
-                inside = [g for g in others if g.untyped_storage().data_ptr() == base]
-                if inside and sum(g.numel() for g in inside) == slab.numel():
-                    others = [g for g in others if g.untyped_storage().data_ptr() != base] + [slab]
-            exchange_sh_gradient.last_num_allreduce = len(others)
+class GradientExchange:
+    """One step's gradient exchange of view-parallel training, driven by the rasterizer call's `RasterCall` record.
+
+    SH coefficients (192 of the 236 gradient bytes per Gaussian) are not all-reduced: dL/dshs of a view is the outer product of the
+    SH basis of its view direction and a per-Gaussian colour gradient, so every rank all-gathers the [N,3] factors
+    (`RasterCall.sh_color_grad`, published by a backward whose rasterizer was built with `factored_sh_grad=True`), the camera
+    centres and -- because the ranks of a step may hold different timestamps -- the per-view actor pose tables (A x 12 floats), and
+    rebuilds the same dense, view-averaged gradient locally (emd_sh_grad_from_factors).  Everything else is all-reduced in place:
+    the four small per-Gaussian gradients as ONE slab (`RasterCall.grad_slab`, 44 B per Gaussian).
+
+        xchg = GradientExchange(campos, actor_ids, actor_pose)        # this rank's view
+        rec = RasterCall(); rec.on_backward = xchg.start               # collectives start INSIDE backward(), right behind K8
+        ... render(record=rec) ... loss.backward()
+        xchg.finish(sh_param, means_param, sh_degree, other_params)    # rebuild + wait
+
+    World size 1: `start` does nothing and `finish` only rebuilds (the local cost of the factored path)."""
+
+    def __init__(self, campos_local, actor_ids=None, actor_pose=None, residual_dx=None, average=True):
+        self.campos_local, self.actor_ids, self.actor_pose, self.residual_dx = campos_local, actor_ids, actor_pose, residual_dx
+        self.average = average
+        self.rec = None
+        self._gathers, self._slab_work, self._g_cat, self._campos, self._poses = [], None, None, None, None
+        self.num_collectives = 0
+
+    def start(self, rec):
+        """Called by the rasterizer's backward (RasterCall.on_backward) as soon as K8 has been enqueued."""
+        self.rec = rec
+        g_local = rec.sh_color_grad
+        if g_local is None:
+            raise RuntimeError("no SH colour-gradient factor: build the rasterizer with factored_sh_grad=True")
+        W = world_size()
+        if W == 1:
+            return
+        dev, N = g_local.device, g_local.shape[0]
+        self._g_cat = torch.empty(W * N, 3, device=dev, dtype=g_local.dtype)       # ranks concatenated along dim 0
+        self._campos = torch.empty(W, 3, device=dev, dtype=torch.float32)
+        self._gathers = [dist.all_gather_into_tensor(self._g_cat, g_local.contiguous(), async_op=True),
+                         dist.all_gather_into_tensor(self._campos, self.campos_local.reshape(1, 3).to(dev, torch.float32).contiguous(),
+                                                     async_op=True)]
+        if self.actor_pose is not None:
+            A = self.actor_pose.shape[0]
+            self._poses = torch.empty(W * A, self.actor_pose.shape[1], device=dev, dtype=torch.float32)
+            self._gathers.append(dist.all_gather_into_tensor(self._poses, self.actor_pose.detach().float().contiguous(), async_op=True))
+        self.num_collectives = len(self._gathers)
+        if rec.grad_slab is not None:
+            gloo = dist.get_backend() == "gloo"
+            op = dist.ReduceOp.SUM if (gloo or not self.average) else dist.ReduceOp.AVG
+            self._slab_work = dist.all_reduce(rec.grad_slab, op=op, async_op=True)
+            self.num_collectives += 1
+
+    def finish(self, sh_param, means3D, sh_degree, other_params=()):
+        """Sets `sh_param.grad` (dense, view-averaged) and averages the gradients of `other_params` over the ranks in place."""
+        rec = self.rec
+        if rec is None:
+            raise RuntimeError("GradientExchange.finish before the backward pass ran (RasterCall.on_backward was not wired)")
+        W = world_size()
+        g_local = rec.sh_color_grad
+        works, others = [], []
+        if W == 1:
+            g_all, campos, pose = g_local[None], self.campos_local.reshape(1, 3).to(g_local.device), self.actor_pose
+        else:
+            N = g_local.shape[0]
+            slab = rec.grad_slab
+            lo = hi = None
+            if self._slab_work is not None:
+                lo, hi = slab.data_ptr(), slab.data_ptr() + slab.numel() * 4
+            for p in other_params:
+                if p is sh_param or p.grad is None:
+                    continue
+                g = p.grad
+                if lo is not None and lo <= g.data_ptr() < hi:
+                    continue                     # a view of the slab that is already being reduced (autograd kept it as .grad)
+                others.append(g)
             others.sort(key=lambda g: -g.numel())
             gloo = dist.get_backend() == "gloo"
-            op = dist.ReduceOp.SUM if (gloo or not average) else dist.ReduceOp.AVG
+            op = dist.ReduceOp.SUM if (gloo or not self.average) else dist.ReduceOp.AVG
             works = [dist.all_reduce(g, op=op, async_op=True) for g in others]
-        for w in gathers:
+            self.num_collectives += len(works)
+            for w in self._gathers:
+                w.wait()
+            g_all, campos = self._g_cat.view(W, N, 3), self._campos
+            pose = None if self._poses is None else self._poses.view(W, -1, self._poses.shape[1])
+        sh_param.grad = sh_grad_from_factors(means3D, campos, g_all, sh_degree, sh_param.shape[1], self.actor_ids, pose, self.residual_dx,
+                                             scale=(1.0 / W) if self.average else 1.0).view_as(sh_param)
+        if self._slab_work is not None:
+            self._slab_work.wait()
+        for w in works:
             w.wait()
-        g_all = g_cat.view(W, N, 3)
-    sh_param.grad = sh_grad_from_factors(means3D, campos, g_all, sh_degree, sh_param.shape[1], actor_ids, actor_pose, residual_dx,
-                                         scale=(1.0 / W) if average else 1.0).view_as(sh_param)
-    for w in works:
-        w.wait()
-    if works and average and dist.get_backend() == "gloo":
-        for g in others:
-            g.div_(float(W))
+        if W > 1 and self.average and dist.get_backend() == "gloo":
+            for g in others:
+                g.div_(float(W))
+            if self._slab_work is not None:
+                rec.grad_slab.div_(float(W))
 
 
 def reduce_densification_stats(grad_norm_accum, denom, max_radii2D):
-    """Cross-view reduction of the per-view densification statistics (norms taken per view, before reduction)."""
+    """Cross-view reduction of the densification statistics (norms taken per view, BEFORE reduction: gaussian_model.py:728-730).
+    SUM / SUM / MAX are associative, so each rank accumulates its own views locally (`add_densification_stats`, one launch per
+    step) and this reduction runs once right before a densification event (every `densification_interval` = 100 steps,
+    train.py:410), not every step: afterwards all ranks hold the statistics of all views and densify identically."""
     if world_size() == 1:
         return
     dist.all_reduce(grad_norm_accum, op=dist.ReduceOp.SUM)

@@ -24,8 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from .camera import projection_from_K
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, RasterConfig, _Rasterize
+from .rasterizer import GaussianRasterizationSettings, RasterCall, RasterConfig, _Rasterize
 
 
 class _SphericalHarmonics(torch.autograd.Function):
@@ -68,6 +67,35 @@ def spherical_harmonics(degrees_to_use, dirs, coeffs):
     return out.reshape(*shp, 3)
 
 
+_K_CONST = {}
+
+
+def _device_camera(vm, K, width, height, znear=0.01, zfar=100.0):
+    """viewmatrix (= W2C^T), full projection, camera centre and tan(fov / 2) of one gsplat camera, computed ON THE DEVICE from
+    the device-resident `viewmats[c]` / `Ks[c]` (OmniRe/models/trainers/base.py:399-400): no device-to-host copy.  Same
+    formulas and the same fp32 roundings as emd_amd.camera.projection_from_K / from_c2w_K."""
+    dev = vm.device
+    ck = (dev, int(width), int(height), float(znear), float(zfar))
+    if ck not in _K_CONST:
+        base = torch.zeros(4, 4)
+        base[2, 3] = 1.0                                   # P[3, 2] in column-vector form
+        base[2, 2] = zfar / (zfar - znear)
+        base[3, 2] = -(zfar * znear) / (zfar - znear)
+        _K_CONST[ck] = (base.to(dev), torch.tensor([0, 5, 8, 9], device=dev),            # flat indices of Pt[0,0], [1,1], [2,0], [2,1]
+                        torch.tensor([0.0, 0.0, float(width), float(height)], device=dev),
+                        torch.tensor([float(width), float(height), float(width), float(height)], device=dev))
+    base, idx, sub, size = _K_CONST[ck]
+    k4 = torch.stack([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])                              # fx, fy, cx, cy
+    vals = (2.0 * k4 - sub) / size                                                       # 2 fx / W, 2 fy / H, (2 cx - W) / W, (2 cy - H) / H
+    Pt = base.clone()
+    Pt.view(-1)[idx] = vals
+    wvt = vm.t().contiguous()
+    full = wvt @ Pt
+    campos = -(vm[:3, :3].t() @ vm[:3, 3])                                               # inverse of a rigid W2C
+    tanfov = size[:2] / (2.0 * k4[:2])
+    return wvt, full, campos, tanfov
+
+
 def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, near_plane=0.01, far_plane=1e10,
                   radius_clip=0.0, eps2d=0.3, sh_degree=None, packed=False, tile_size=16, backgrounds=None,
                   render_mode="RGB", sparse_grad=False, absgrad=False, rasterize_mode="classic", channel_chunk=32,
@@ -84,49 +112,47 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     dev = means.device
     quats_n = F.normalize(quats, dim=-1)
     opac = opacities.reshape(-1)
-    renders, alphas, radii_all = [], [], []
+    renders, alphas, radii_all, records = [], [], [], []
     # leaf grad sink: after backward `.grad` holds d L / d (pixel-space mean); `.absgrad` the sum of |.| (absgrad=True)
     means2d = torch.zeros(Cn, N, 2, device=dev, requires_grad=True)
     scale = torch.tensor([2.0 / width, 2.0 / height], device=dev)
     if absgrad:
         means2d.absgrad = torch.zeros(Cn, N, 2, device=dev)
-    old = (RasterConfig.compute_normal, RasterConfig.absgrad)
-    RasterConfig.compute_normal, RasterConfig.absgrad = False, bool(absgrad)
-    try:
-        for c in range(Cn):
-            vm = viewmats[c].detach().float()
-            K = Ks[c].detach().float().cpu()
-            wvt = vm.t().contiguous()
-            proj = projection_from_K(K, width, height).to(wvt.device)
-            full = wvt @ proj
-            campos = torch.linalg.inv(vm)[:3, 3]
-            bg = torch.zeros(3) if backgrounds is None else backgrounds[c].detach().float()
-            rs = GaussianRasterizationSettings(int(height), int(width), width / (2.0 * float(K[0, 0])), height / (2.0 * float(K[1, 1])),
-                                               bg, 1.0, wvt, full, 0 if sh_degree is None else int(sh_degree), campos, False, False)
-            # this rasterizer returns mean2D gradients scaled by (W/2, H/2) (diff_gauss convention): undo it here
-            sink = torch.cat([means2d[c] * scale, torch.zeros(N, 1, device=dev)], dim=1)
-            flags = (L.FLAG_ABSGRAD if absgrad else 0) | (L.FLAG_NO_SYNC if RasterConfig.no_sync else 0)
-            shs = colors.contiguous().float() if sh_degree is not None else None
-            col = None if sh_degree is not None else colors.contiguous().float()
-            color, depth, _n, alpha, radii = _Rasterize.apply(means.contiguous().float(), sink, shs, col, opac.contiguous().float(),
-                                                              scales.contiguous().float(), quats_n.contiguous(), None, None, None,
-                                                              None, None, rs, flags, float(near_plane))
-            if absgrad:
-                def _hook(g, c=c):
-                    means2d.absgrad[c] = GaussianRasterizer.last_absgrad * scale
-                    return g
-                sink.register_hook(_hook)
-            chans = []
-            if "RGB" in render_mode:
-                chans.append(color.permute(1, 2, 0))
-            if render_mode.endswith("ED"):
-                chans.append((depth / alpha.clamp(min=1e-10)).permute(1, 2, 0))
-            elif render_mode.endswith("D"):
-                chans.append(depth.permute(1, 2, 0))
-            renders.append(torch.cat(chans, dim=-1))
-            alphas.append(alpha.permute(1, 2, 0))
-            radii_all.append(radii)
-    finally:
-        RasterConfig.compute_normal, RasterConfig.absgrad = old
-    info = {"means2d": means2d, "radii": torch.stack(radii_all), "width": int(width), "height": int(height)}
+    # options of THESE calls (nothing process-wide is touched): no normal image, gsplat's near plane, absgrad as asked
+    opts = RasterConfig.replace(compute_normal=False, absgrad=bool(absgrad), near_plane=float(near_plane))
+    flags = (L.FLAG_ABSGRAD if absgrad else 0) | (L.FLAG_NO_SYNC if opts.no_sync else 0)
+    for c in range(Cn):
+        vm = viewmats[c].detach().float()
+        K = Ks[c].detach().float()
+        if vm.device.type == "cpu" or K.device.type == "cpu":
+            vm, K = vm.to(dev), K.to(dev)
+        wvt, full, campos, tanfov = _device_camera(vm, K, width, height)
+        bg = torch.zeros(3, device=dev) if backgrounds is None else backgrounds[c].detach().float()
+        rs = GaussianRasterizationSettings(int(height), int(width), tanfov[0], tanfov[1], bg, 1.0, wvt, full,
+                                           0 if sh_degree is None else int(sh_degree), campos, False, False)
+        # this rasterizer returns mean2D gradients scaled by (W/2, H/2) (diff_gauss convention): undo it here
+        sink = torch.cat([means2d[c] * scale, torch.zeros(N, 1, device=dev)], dim=1)
+        shs = colors.contiguous().float() if sh_degree is not None else None
+        col = None if sh_degree is not None else colors.contiguous().float()
+        rec = RasterCall()
+        color, depth, _n, alpha, radii = _Rasterize.apply(means.contiguous().float(), sink, shs, col, opac.contiguous().float(),
+                                                          scales.contiguous().float(), quats_n.contiguous(), None, None, None,
+                                                          None, None, rs, flags, opts, rec)
+        if absgrad:
+            def _hook(g, c=c, rec=rec):          # runs after this call's backward: its record holds this call's |grad| sums
+                means2d.absgrad[c] = rec.absgrad * scale
+                return g
+            sink.register_hook(_hook)
+        chans = []
+        if "RGB" in render_mode:
+            chans.append(color.permute(1, 2, 0))
+        if render_mode.endswith("ED"):
+            chans.append((depth / alpha.clamp(min=1e-10)).permute(1, 2, 0))
+        elif render_mode.endswith("D"):
+            chans.append(depth.permute(1, 2, 0))
+        renders.append(torch.cat(chans, dim=-1))
+        alphas.append(alpha.permute(1, 2, 0))
+        radii_all.append(radii)
+        records.append(rec)
+    info = {"means2d": means2d, "radii": torch.stack(radii_all), "width": int(width), "height": int(height), "raster_calls": records}
     return torch.stack(renders), torch.stack(alphas), info

@@ -19,7 +19,10 @@ from .scenes import GaussianScene
 class StreetGaussians(torch.nn.Module):
     """Parameter store in the reference's layout (S3Gaussian/scene/gaussian_model.py:54-71)."""
 
-    def __init__(self, scene: GaussianScene, device):
+    def __init__(self, scene: GaussianScene, device, track_heads=False, track_seed=7):
+        """`track_heads`: attach the learned per-actor track offsets (OmniRe/models/nodes/rigid.py:108-122,203-246: temporal
+        tables + four linear heads + a 4-d embedding per actor Gaussian).  The reference zero-initialises the heads; here they
+        get small seeded weights so that the offsets (and every gradient path through them) are non-trivial in benchmarks."""
         super().__init__()
         P = lambda t: torch.nn.Parameter(t.to(device).contiguous())
         self._xyz = P(scene.means)
@@ -33,23 +36,43 @@ class StreetGaussians(torch.nn.Module):
             self.instances_quats = P(scene.actor_quats)    # [F,A,4]
             self.instances_trans = P(scene.actor_trans)    # [F,A,3]
             self.register_buffer("instances_fv", scene.actor_valid.to(device))
+        self.track_heads = None
+        if self.has_actors and track_heads:
+            from .motion import TrackOffsetHeads
+            A = scene.actor_quats.shape[1]
+            g = torch.Generator().manual_seed(track_seed)
+            heads = TrackOffsetHeads(A)
+            with torch.no_grad():
+                for lin, sc in ((heads.track_trans_c, 0.05), (heads.track_trans_f, 0.05), (heads.track_rot_c, 0.01), (heads.track_rot_f, 0.01)):
+                    lin.weight.copy_(sc * torch.randn(lin.weight.shape, generator=g))
+            self.track_heads = heads.to(device)
+            dyn = (scene.actor_id >= 0).nonzero()[:, 0]
+            self.register_buffer("dyn_ids", scene.actor_id[dyn].to(device).long())
+            self._embeddings = P(0.1 * torch.randn(dyn.numel(), 4, generator=g))       # [n_dyn, 4] (gaussian_embedding_dim)
+            self.num_frames = scene.actor_quats.shape[0]
         self.active_sh_degree = 3
 
     @property
     def num_points(self):
         return self._xyz.shape[0]
 
-    def actor_pose(self, frame):
-        """[A,12] pose rows for one frame (track offsets would be added to q_rot / trans here)."""
+    def actor_pose(self, frame, step=0):
+        """[A,12] pose rows for one frame, with the learned track offsets (translation and rotation about z) when the model has
+        the heads: rigid.py:519-532,547-566."""
         from .motion import actor_pose_table
-        return actor_pose_table(self.instances_quats, self.instances_trans, self.instances_fv, frame)
+        tt = trq = None
+        if self.track_heads is not None:
+            tt, trq = self.track_heads(frame, self.num_frames, self._embeddings, self.dyn_ids, step)
+        return actor_pose_table(self.instances_quats, self.instances_trans, self.instances_fv, frame, tt, trq)
 
 
 def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activations=True, deformation=None, embeddings=None,
-           iteration=None, time=None):
+           iteration=None, time=None, options=None, record=None):
     """The reference render() restricted to the hot path; returns the dict the training loop consumes.
     `deformation` (an emd_amd.deformation.deform_network) switches on the "fine" stage of gaussian_renderer/__init__.py:86-96:
-    the residuals of the self-supervised EMD network are added to the raw parameters before the activations."""
+    the residuals of the self-supervised EMD network are added to the raw parameters before the activations.
+    `options` (emd_amd.RasterOptions) configures this call's rasterizer; `record` (emd_amd.RasterCall) receives its per-call state
+    (also returned as out["raster_call"])."""
     dev = model._xyz.device
     # the reference's zero "screen-space points" leaf that only collects dL/dmean2D: the zeros are never written, so one
     # cached buffer per model serves every step (a fresh leaf view each time, no 24 MB fill launch)
@@ -58,7 +81,7 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         z = model._zero_xyz = torch.zeros_like(model._xyz)
     screenspace_points = z.detach().requires_grad_(True)
     rs = raster_settings_for(cam, bg, model.active_sh_degree, 1.0, debug)
-    rasterizer = GaussianRasterizer(raster_settings=rs)
+    rasterizer = GaussianRasterizer(raster_settings=rs, options=options)
     means3D, scales, rotations, opacity, shs, ddict = model._xyz, model._scaling, model._rotation, model._opacity, model._features, None
     if deformation is not None:
         t = float(getattr(cam, "time", 0.0) if time is None else time)
@@ -73,12 +96,13 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         opacity = torch.sigmoid(opacity)
     kw = {}
     if model.has_actors:
-        kw = dict(actor_ids=model.actor_id, actor_pose=model.actor_pose(frame))
+        kw = dict(actor_ids=model.actor_id, actor_pose=model.actor_pose(frame, 0 if iteration is None else int(iteration)))
     image, depth, normal, weight, radii, _ = rasterizer(
         means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opacity,
-        scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, raw_params=fuse_activations, **kw)
+        scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, raw_params=fuse_activations, record=record, **kw)
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
-            "depth": depth, "weight": weight, "normal": normal, "actor_pose": kw.get("actor_pose"), "ddict": ddict}
+            "depth": depth, "weight": weight, "normal": normal, "actor_pose": kw.get("actor_pose"), "ddict": ddict,
+            "raster_call": rasterizer.last_call}
 
 
 def raster_settings_for(cam, bg, sh_degree, scaling_modifier=1.0, debug=False):

@@ -76,20 +76,30 @@ class TrackOffsetHeads(torch.nn.Module):
         return int(init_val + (final_val - init_val) * min(max(t, 0), until) / until)
 
     def temporal_embed(self, t, k):
-        """Row t (normalised, [0,1]) of every actor's table resized bilinearly to k rows (align_corners)."""
-        emb = F.interpolate(self.weight[:, None], size=(k, self.fdim), mode="bilinear", align_corners=True)[:, 0]  # [A,k,32]
-        y = float(t) * (k - 1)
-        y0 = min(max(int(y // 1), 0), k - 1)
-        y1 = min(y0 + 1, k - 1)
-        w = y - y0
-        return emb[:, y0] * (1 - w) + emb[:, y1] * w
+        """Row t (a 1-element DEVICE tensor, normalised to [0,1]) of every actor's table resized bilinearly to k rows and sampled
+        with reflection (rigid.py:150-164): ONE HIP launch for all actors (`emd_temporal_embed_forward`, one wave per table)."""
+        from .deformation import temporal_embed
+        return temporal_embed(self.weight, t, k)
+
+    def _time_tensor(self, frame, num_frames, device):
+        """normalised_frame = (frame - 0) / (num_frames - 1 - 0) (rigid.py:204,241) as a device tensor, without a per-step upload."""
+        tab = getattr(self, "_t_table", None)
+        if tab is None or tab.numel() != num_frames or tab.device != device:
+            tab = self._t_table = (torch.arange(num_frames, dtype=torch.float32) / max(num_frames - 1, 1)).to(device)
+        return tab[int(frame):int(frame) + 1]
 
     def forward(self, frame, num_frames, embeddings, point_ids, step):
-        """-> (track_trans [A,3], track_rot [A,4]).  embeddings [N,4]; point_ids [N] actor of every point."""
+        """-> (track_trans [A,3], track_rot [A,4]).  embeddings [N,4]; point_ids [N] actor of every point (device tensors)."""
+        if self.weight.device.type != "cuda":
+            raise L.EmdError("TrackOffsetHeads needs its parameters on a ROCm device; there is no CPU path "
+                             "(the checker's restatement is oracle/torch_ref.track_offsets)")
         A = self.weight.shape[0]
-        t = (frame - 0) / (num_frames - 1 - 0)
+        t = self._time_tensor(frame, num_frames, self.weight.device)
         ids = point_ids.long()
-        cnt = torch.zeros(A, device=embeddings.device).index_add_(0, ids, torch.ones_like(ids, dtype=embeddings.dtype))
+        cnt = getattr(self, "_cnt", None)
+        if cnt is None or getattr(self, "_cnt_key", None) != (ids.data_ptr(), ids.numel()):     # points per actor: constant between densifications
+            cnt = torch.zeros(A, device=embeddings.device).index_add_(0, ids, torch.ones_like(ids, dtype=embeddings.dtype))
+            self._cnt, self._cnt_key = cnt, (ids.data_ptr(), ids.numel())
         mean_emb = torch.zeros(A, self.edim, device=embeddings.device, dtype=embeddings.dtype).index_add_(0, ids, embeddings) / cnt[:, None]
         k_f = self.int_lininterp(step, self.min_embeddings, self.max_embeddings, self.c2f_temporal_iter)
         h_c = torch.cat([self.temporal_embed(t, self.min_embeddings), mean_emb], -1)

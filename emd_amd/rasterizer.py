@@ -11,10 +11,24 @@ Extension (EMD explicit motion fused into the projection kernel): the optional k
 OmniRe/models/nodes/rigid.py:478-568 (+ deformable.py:57-69) per Gaussian before projecting, and return
 gradients for `actor_pose` and the residuals.
 
+State and re-entrancy: options live on the rasterizer INSTANCE (`RasterOptions`, taken from the
+process-wide defaults `RasterConfig` when the object is built and never written by library code); everything a call
+produces beyond the reference's 6-tuple -- device status word, workspaces, and after the backward pass the absgrad sums,
+the SH colour-gradient factor and the gradient slab -- lives in a per-call `RasterCall` record (`rasterizer.last_call`, or
+the object passed as `record=`).  Nothing is kept in class attributes, so several rasterizer calls per step (the
+reference makes up to nine per render()) and calls on different streams do not see each other.
+
+Host synchronisation: with `no_sync` the forward never reads the duplicate count back, and camera settings that arrive
+as DEVICE tensors (as the reference passes them: `.cuda()` at gaussian_renderer/__init__.py:54-59) are handed to the
+kernels by pointer (`EmdFwdArgs.settings_dev`) instead of being copied to the host: such a call performs no
+device-to-host copy and no stream synchronisation at all.
+
 All compute happens in libemd_raster.so (hand-written HIP for gfx950) through the C ABI of
 include/emd_raster.h.  There is no CPU or eager fallback; a missing extension raises.
 """
 import ctypes as C
+import dataclasses
+import warnings
 from typing import NamedTuple, Optional
 
 import torch
@@ -38,60 +52,149 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
-class RasterConfig:
-    """Process-wide knobs of the binding (not part of the reference surface)."""
-    compute_normal = True     # composite the normal image (reference returns it; only used for visualisation)
-    near_plane = 0.2          # view-space z cull of the diff_gauss surface
-    no_sync = False           # True: never read the duplicate count back (overflow only visible via last_status())
-    capacity_margin = 1.25    # head-room applied to the last observed duplicate count
-    min_capacity = 1 << 16
-    absgrad = False           # also accumulate sum |d/d mean2D| (read from GaussianRasterizer.last_absgrad)
-    clamp_rgb01 = False       # OmniRe colour clamp
-    factored_sh_grad = False  # view-parallel DP: the backward leaves dL/dshs out and publishes the [N,3] factor instead
-                              # (GaussianRasterizer.last_sh_color_grad); emd_amd.dp rebuilds the dense, view-averaged gradient
+@dataclasses.dataclass
+class RasterOptions:
+    """Knobs of the binding that are not part of the reference surface (one copy per rasterizer instance)."""
+    compute_normal: bool = True     # composite the normal image (reference returns it; only used for visualisation)
+    near_plane: float = 0.2         # view-space z cull of the diff_gauss surface
+    no_sync: bool = False           # True: never read the duplicate count back (overflow surfaces lazily, see RasterCall)
+    capacity_margin: float = 1.25   # head-room applied to the last observed duplicate count
+    min_capacity: int = 1 << 16
+    absgrad: bool = False           # also accumulate sum |d/d mean2D| (RasterCall.absgrad and `means2D.absgrad`, as gsplat does)
+    clamp_rgb01: bool = False       # OmniRe colour clamp
+    factored_sh_grad: bool = False  # view-parallel DP: the backward leaves dL/dshs out and publishes the [N,3] factor instead
+                                    # (RasterCall.sh_color_grad); emd_amd.dp rebuilds the dense, view-averaged gradient
+
+    def replace(self, **kw):
+        return dataclasses.replace(self, **{k: v for k, v in kw.items() if v is not None})
 
 
+# process-wide DEFAULTS: read once when a GaussianRasterizer is constructed, never written by the library
+RasterConfig = RasterOptions()
+
+
+class RasterCall:
+    """Everything one forward (+ backward) call leaves behind besides the reference's outputs.
+    `on_backward` (optional callable) is invoked with the record by the backward pass right after its kernels have been
+    enqueued: view-parallel training starts its gradient collectives there (emd_amd.dp.GradientExchange.start)."""
+    __slots__ = ("status", "num_rendered", "num_visible", "geom_ws", "bin_ws", "img_ws", "sizes", "capacity", "N", "H", "W",
+                 "flags", "settings_dev", "absgrad", "sh_color_grad", "grad_slab", "on_backward")
+
+    def __init__(self):
+        for k in self.__slots__:
+            setattr(self, k, None)
+
+    def last_status(self):
+        """(num_rendered D, overflow, num_visible V) of this call's forward; synchronises."""
+        st = self.status.cpu().tolist()
+        return dict(num_rendered=st[0] & 0xFFFFFFFF, overflow=st[1], num_visible=st[2] & 0xFFFFFFFF)
+
+    def export_binning(self):
+        """Sorted keys (uint64 as int64 bit pattern), Gaussian ids and tile ranges of this call's forward."""
+        lib = L.load()
+        D = self.last_status()["num_rendered"]
+        dev = self.status.device
+        T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        keys = torch.empty(max(D, 1), device=dev, dtype=torch.int64)
+        ids = torch.empty(max(D, 1), device=dev, dtype=torch.int32)
+        ranges = torch.empty(T, 2, device=dev, dtype=torch.int32)
+        d = L.EmdDims(self.N, self.H, self.W, self.capacity, self.flags)
+        L.check(lib.emd_raster_export_binning(C.byref(d), self.geom_ws.data_ptr(), self.sizes[0], self.bin_ws.data_ptr(), self.sizes[1], D,
+                                              keys.data_ptr(), ids.data_ptr(), ranges.data_ptr(), _stream()), "emd_raster_export_binning")
+        return keys[:D], ids[:D], ranges
+
+    def export_geometry(self):
+        lib = L.load()
+        dev, N = self.status.device, self.N
+        e = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)
+        out = dict(means2D=e(N, 2), depths=e(N), conic_opacity=e(N, 4), rgb=e(N, 3),
+                   normal=e(N, 3) if self.flags & L.FLAG_NORMAL else None, tiles_touched=e(N, dt=torch.int32))
+        d = L.EmdDims(N, self.H, self.W, self.capacity, self.flags)
+        L.check(lib.emd_raster_export_geometry(C.byref(d), self.geom_ws.data_ptr(), self.sizes[0], out["means2D"].data_ptr(),
+                                               out["depths"].data_ptr(), out["conic_opacity"].data_ptr(), out["rgb"].data_ptr(),
+                                               L.ptr(out["normal"]), out["tiles_touched"].data_ptr(), _stream()),
+                "emd_raster_export_geometry")
+        return out
+
+
+# ---- binning-capacity hints ------------------------------------------------------------------------------------------------
+# A cache, not state: (device, H, W) -> a capacity that was large enough last time.  In no_sync mode the duplicate count of a
+# forward is never awaited; its status word is copied to pinned host memory asynchronously and looked at by a LATER forward
+# (when the copy's event has completed), which grows the hint and warns if a past call overflowed.
 _capacity_hint = {}
+_pending_status = {}          # key -> list of (pinned tensor, event, capacity)
+_MAX_PENDING = 16
 
 
-def _settings_host_values(rs):
-    """bg[3], viewmatrix[16], projmatrix[16], campos[3] as python floats.
+def _poll_pending(key, opts):
+    q = _pending_status.get(key)
+    if not q:
+        return
+    keep = []
+    for host, ev, cap in q:
+        if not ev.query():
+            keep.append((host, ev, cap))
+            continue
+        d, overflow = int(host[0]) & 0xFFFFFFFF, int(host[1])
+        need = int(d * opts.capacity_margin) + 1024
+        if overflow:
+            warnings.warn(f"emd_amd: an earlier no_sync rasterizer call overflowed its binning workspace ({d} (tile, Gaussian) pairs, "
+                          f"capacity {cap}): that image was blank and its gradients zero.  The capacity hint has been raised to {need}.",
+                          RuntimeWarning, stacklevel=3)
+        if overflow or need > _capacity_hint.get(key, 0):
+            _capacity_hint[key] = max(need, _capacity_hint.get(key, 0))
+    _pending_status[key] = keep[-_MAX_PENDING:]
 
-    The reference keeps these on the GPU (S3Gaussian/gaussian_renderer/__init__.py:54-59); they are packed and
-    brought to the host with ONE device-to-host copy per call (no caching by address: a recycled allocation
-    would alias a stale camera).  CPU tensors cost nothing.
-    """
-    parts = []
+
+def _watch_status(key, status, capacity):
+    host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+    host.copy_(status, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _pending_status.setdefault(key, []).append((host, ev, capacity))
+
+
+def _settings_values(rs):
+    """-> (bg[3], viewmatrix[16], projmatrix[16], campos[3] as python floats or None, device block or None).
+
+    CPU tensors / sequences are passed to the library by value.  If any of the four is a device tensor (the reference's call
+    site), all four are packed into ONE 38-float device block with a single small launch and passed by pointer: no
+    device-to-host copy, no synchronisation (EmdFwdArgs.settings_dev)."""
+    parts, dev = [], None
     for t, n in ((rs.bg, 3), (rs.viewmatrix, 16), (rs.projmatrix, 16), (rs.campos, 3)):
         if not isinstance(t, torch.Tensor):
             t = torch.as_tensor(t, dtype=torch.float32)
         t = t.detach().reshape(-1).to(torch.float32)
         if t.numel() != n:
             raise ValueError(f"expected {n} values, got {t.numel()}")
+        if t.device.type != "cpu":
+            dev = t.device
         parts.append(t)
-    if any(p.device.type != "cpu" for p in parts):
-        dev = next(p.device for p in parts if p.device.type != "cpu")
-        flat = torch.cat([p.to(dev) for p in parts]).cpu().tolist()
-    else:
+    tan_dev = isinstance(rs.tanfovx, torch.Tensor) and rs.tanfovx.device.type != "cpu"
+    if dev is None and not tan_dev:
         flat = torch.cat(parts).tolist()
-    return flat[0:3], flat[3:19], flat[19:35], flat[35:38]
+        return (flat[0:3], flat[3:19], flat[19:35], flat[35:38]), None
+    if tan_dev:          # cameras given as device-resident intrinsics (emd_amd.gsplat_api): tan(fov / 2) stays on the device as well
+        dev = rs.tanfovx.device
+        parts += [rs.tanfovx.detach().reshape(1).float(), rs.tanfovy.detach().reshape(1).float()]
+    return None, torch.cat([p.to(dev, non_blocking=True) for p in parts]).contiguous()
 
 
-def make_c_settings(rs: GaussianRasterizationSettings, near_plane=None) -> L.EmdSettings:
+def make_c_settings(rs: GaussianRasterizationSettings, near_plane=0.2):
+    """-> (EmdSettings by value, device block or None)."""
     s = L.EmdSettings()
-    bg, view, proj, campos = _settings_host_values(rs)
+    host, dev_block = _settings_values(rs)
     s.image_height, s.image_width = int(rs.image_height), int(rs.image_width)
-    s.tanfovx, s.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
-    s.bg[:] = bg
+    if dev_block is None or dev_block.numel() == L.SETTINGS_DEV_FLOATS:
+        s.tanfovx, s.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
     s.scale_modifier = float(rs.scale_modifier)
-    s.viewmatrix[:] = view
-    s.projmatrix[:] = proj
     s.sh_degree = int(rs.sh_degree)
-    s.campos[:] = campos
+    if host is not None:
+        s.bg[:], s.viewmatrix[:], s.projmatrix[:], s.campos[:] = host
     s.prefiltered = int(bool(rs.prefiltered))
     s.debug = int(bool(rs.debug))
-    s.near_plane = float(RasterConfig.near_plane if near_plane is None else near_plane)
-    return s
+    s.near_plane = float(near_plane)
+    return s, dev_block
 
 
 def _f32c(t, name, shape_tail=None):
@@ -119,14 +222,16 @@ def _fill_motion(m: L.EmdMotion, actor_ids, actor_pose, residual_dx, residual_dq
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose,
-                residual_dx, residual_dq, actor_ids, raster_settings, flags, near_plane):
+                residual_dx, residual_dq, actor_ids, raster_settings, flags, opts, rec):
         lib = L.load()
         dev = means3D.device
         if dev.type != "cuda":
             raise L.EmdError("GaussianRasterizer needs tensors on a ROCm device (cuda:N); there is no CPU path")
         N = means3D.shape[0]
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
-        cs = make_c_settings(raster_settings, near_plane)
+        cs, sdev = make_c_settings(raster_settings, opts.near_plane)
+        if sdev is not None and sdev.numel() == L.SETTINGS_DEV_FLOATS + 2:
+            flags |= L.FLAG_SDEV_TANFOV
         M = 0 if shs is None else int(shs.shape[1])
 
         out_color = torch.empty(3, H, W, device=dev, dtype=torch.float32)
@@ -138,7 +243,8 @@ class _Rasterize(torch.autograd.Function):
         status = torch.empty(4, device=dev, dtype=torch.int32)
 
         key = (dev.index, H, W)
-        capacity = max(int(_capacity_hint.get(key, 0)), RasterConfig.min_capacity, 4 * N if key not in _capacity_hint else 0)
+        _poll_pending(key, opts)
+        capacity = max(int(_capacity_hint.get(key, 0)), opts.min_capacity, 4 * N if key not in _capacity_hint else 0)
         a = L.EmdFwdArgs()
         while True:
             gb, bb, ib, _ = L.workspace_sizes(N, H, W, capacity, flags)
@@ -146,6 +252,7 @@ class _Rasterize(torch.autograd.Function):
             bin_ws = torch.empty(bb, device=dev, dtype=torch.uint8)
             img_ws = torch.empty(ib, device=dev, dtype=torch.uint8)
             a.s = cs
+            a.settings_dev = L.ptr(sdev)
             a.num_gaussians, a.sh_coeffs, a.flags, a.bin_capacity = N, M, flags, capacity
             a.means3D, a.shs, a.colors_precomp = L.ptr(means3D), L.ptr(shs), L.ptr(colors_precomp)
             a.opacities, a.scales, a.rotations = L.ptr(opacities), L.ptr(scales), L.ptr(rotations)
@@ -160,28 +267,31 @@ class _Rasterize(torch.autograd.Function):
             a.status = status.data_ptr()
             rc = lib.emd_raster_forward(C.byref(a), _stream())
             if rc == L.EMD_ERR_CAPACITY:
-                capacity = int(a.num_rendered * RasterConfig.capacity_margin) + 1024
+                capacity = int(a.num_rendered * opts.capacity_margin) + 1024
                 continue
             L.check(rc, "emd_raster_forward")
             break
         if a.num_rendered >= 0:
-            _capacity_hint[key] = max(int(a.num_rendered * RasterConfig.capacity_margin) + 1024, RasterConfig.min_capacity)
+            _capacity_hint[key] = max(int(a.num_rendered * opts.capacity_margin) + 1024, opts.min_capacity)
         else:
-            _capacity_hint[key] = capacity
+            _capacity_hint[key] = max(capacity, _capacity_hint.get(key, 0))
+            _watch_status(key, status, capacity)       # looked at by a later forward; never waited for
 
         ctx.cs, ctx.flags, ctx.capacity, ctx.N, ctx.M = cs, flags, capacity, N, M
         ctx.num_rendered = int(a.num_rendered)
         ctx.sizes = (gb, bb, ib)
+        ctx.opts, ctx.rec = opts, rec
+        ctx.means2D_ref = means2D if (flags & L.FLAG_ABSGRAD) else None      # gsplat convention: `.absgrad` is set on this tensor
         ctx.has = (shs is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None,
                    actor_pose is not None, residual_dx is not None, residual_dq is not None)
         ctx.save_for_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose,
                               residual_dx, residual_dq, actor_ids, radii, geom_ws, bin_ws, img_ws, status, out_color,
-                              out_depth, out_normal)
+                              out_depth, out_normal, sdev)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)   # unused outputs (normal, depth, alpha) arrive as None, not as zero images
-        GaussianRasterizer._last = dict(status=status, num_rendered=int(a.num_rendered), num_visible=int(a.num_visible),
-                                        geom_ws=geom_ws, bin_ws=bin_ws, img_ws=img_ws, sizes=(gb, bb, ib),
-                                        capacity=capacity, N=N, H=H, W=W, flags=flags)
+        rec.status, rec.num_rendered, rec.num_visible = status, int(a.num_rendered), int(a.num_visible)
+        rec.geom_ws, rec.bin_ws, rec.img_ws, rec.sizes, rec.capacity = geom_ws, bin_ws, img_ws, (gb, bb, ib), capacity
+        rec.N, rec.H, rec.W, rec.flags, rec.settings_dev = N, H, W, flags, sdev
         return out_color, out_depth, out_normal, out_alpha, radii
 
     @staticmethod
@@ -189,9 +299,9 @@ class _Rasterize(torch.autograd.Function):
         lib = L.load()
         (means3D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose, residual_dx,
          residual_dq, actor_ids, radii, geom_ws, bin_ws, img_ws, status, out_color, out_depth,
-         out_normal) = ctx.saved_tensors
+         out_normal, sdev) = ctx.saved_tensors
         dev = means3D.device
-        N, M, flags = ctx.N, ctx.M, ctx.flags
+        N, M, flags, opts, rec = ctx.N, ctx.M, ctx.flags, ctx.opts, ctx.rec
         has_shs, has_col, has_sr, has_cov, has_pose, has_rdx, has_rdq = ctx.has
         z = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         g_color = None if g_color is None else g_color.contiguous().float()
@@ -208,7 +318,7 @@ class _Rasterize(torch.autograd.Function):
                 slab[10 * N:].view(opacities.shape)
         else:
             d_means3D = z(N, 3)
-        factored = has_shs and RasterConfig.factored_sh_grad
+        factored = has_shs and opts.factored_sh_grad
         d_shs = z(N, M, 3) if (has_shs and not factored) else None
         d_shc = z(N, 3) if factored else None
         d_col = z(N, 3) if has_col else None
@@ -224,6 +334,7 @@ class _Rasterize(torch.autograd.Function):
 
         b = L.EmdBwdArgs()
         b.s = ctx.cs
+        b.settings_dev = L.ptr(sdev)
         b.num_gaussians, b.sh_coeffs, b.flags, b.bin_capacity, b.num_rendered = N, M, flags, ctx.capacity, ctx.num_rendered
         b.means3D, b.shs, b.colors_precomp = L.ptr(means3D), L.ptr(shs), L.ptr(colors_precomp)
         b.opacities, b.scales, b.rotations, b.cov3D_precomp = L.ptr(opacities), L.ptr(scales), L.ptr(rotations), L.ptr(cov3Ds_precomp)
@@ -243,35 +354,35 @@ class _Rasterize(torch.autograd.Function):
         b.dL_dactor_pose, b.dL_dresidual_dx, b.dL_dresidual_dq = L.ptr(d_pose), L.ptr(d_rdx), L.ptr(d_rdq)
         b.dL_dsh_color = L.ptr(d_shc)
         L.check(lib.emd_raster_backward(C.byref(b), _stream()), "emd_raster_backward")
-        if d_abs is not None:
-            GaussianRasterizer.last_absgrad = d_abs
-        GaussianRasterizer.last_sh_color_grad = d_shc       # None unless RasterConfig.factored_sh_grad
-        GaussianRasterizer.last_grad_slab = slab
-        return (d_means3D, d_means2D, d_shs, d_col, d_op, d_sc, d_rot, d_cov, d_pose, d_rdx, d_rdq, None, None, None, None)
+        rec.absgrad, rec.sh_color_grad, rec.grad_slab = d_abs, d_shc, slab
+        if d_abs is not None and ctx.means2D_ref is not None:
+            ctx.means2D_ref.absgrad = d_abs          # what gsplat's backward does with `means2d.absgrad`
+        if rec.on_backward is not None:
+            rec.on_backward(rec)
+        return (d_means3D, d_means2D, d_shs, d_col, d_op, d_sc, d_rot, d_cov, d_pose, d_rdx, d_rdq, None, None, None, None, None)
 
 
 class GaussianRasterizer(nn.Module):
-    _last = None
-    last_absgrad = None
-    last_sh_color_grad = None
-    last_grad_slab = None
-
-    def __init__(self, raster_settings: GaussianRasterizationSettings):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, options: Optional[RasterOptions] = None, **overrides):
+        """`options` (default: a snapshot of the process-wide `RasterConfig`) and keyword overrides of single fields
+        (compute_normal=, no_sync=, absgrad=, factored_sh_grad=, near_plane=, clamp_rgb01=, ...) belong to this instance."""
         super().__init__()
         self.raster_settings = raster_settings
+        self.options = dataclasses.replace(options if options is not None else RasterConfig).replace(**overrides)
+        self.last_call: Optional[RasterCall] = None
 
     def markVisible(self, positions):
         """Frustum test of the diff_gauss surface: view-space z > near plane."""
         with torch.no_grad():
             V = torch.as_tensor(self.raster_settings.viewmatrix, dtype=torch.float32, device=positions.device)
             z = positions @ V[:3, 2] + V[3, 2]
-            return z > RasterConfig.near_plane
+            return z > self.options.near_plane
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3Ds_precomp=None, extra_attrs=None, actor_ids: Optional[torch.Tensor] = None,
                 actor_pose: Optional[torch.Tensor] = None, residual_dx: Optional[torch.Tensor] = None,
-                residual_dq: Optional[torch.Tensor] = None, raw_params: bool = False):
-        rs = self.raster_settings
+                residual_dq: Optional[torch.Tensor] = None, raw_params: bool = False, record: Optional[RasterCall] = None):
+        rs, opts = self.raster_settings, self.options
         if (shs is None) == (colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
         if ((scales is None or rotations is None) and cov3Ds_precomp is None) or \
@@ -293,13 +404,13 @@ class GaussianRasterizer(nn.Module):
         rotations = _f32c(rotations, "rotations", (4,))
         cov3Ds_precomp = _f32c(cov3Ds_precomp, "cov3Ds_precomp", (6,))
         flags = 0
-        if RasterConfig.compute_normal:
+        if opts.compute_normal:
             flags |= L.FLAG_NORMAL
-        if RasterConfig.no_sync:
+        if opts.no_sync:
             flags |= L.FLAG_NO_SYNC
-        if RasterConfig.absgrad:
+        if opts.absgrad:
             flags |= L.FLAG_ABSGRAD
-        if RasterConfig.clamp_rgb01:
+        if opts.clamp_rgb01:
             flags |= L.FLAG_CLAMP_RGB01
         if raw_params:
             # scales / rotations / opacities are the raw parameters; exp / normalize / sigmoid
@@ -316,47 +427,19 @@ class GaussianRasterizer(nn.Module):
                 actor_pose = _f32c(actor_pose, "actor_pose")
             residual_dx = _f32c(residual_dx, "residual_dx", (3,))
             residual_dq = _f32c(residual_dq, "residual_dq", (4,))
+        rec = record if record is not None else RasterCall()
         color, depth, normal, alpha, radii = _Rasterize.apply(
             means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose, residual_dx,
-            residual_dq, actor_ids, rs, flags, None)
+            residual_dq, actor_ids, rs, flags, opts, rec)
+        self.last_call = rec
         return color, depth, normal, alpha, radii, None
 
-    # ---- introspection used by tests / bench (not part of the reference surface) --------------------------------
-    @classmethod
-    def last_status(cls):
-        """(num_rendered D, overflow, num_visible V) of the most recent forward; synchronises."""
-        st = cls._last["status"].cpu().tolist()
-        return dict(num_rendered=st[0] & 0xFFFFFFFF, overflow=st[1], num_visible=st[2] & 0xFFFFFFFF)
+    # ---- introspection of THIS object's most recent call (tests / bench; not part of the reference surface) -------------------
+    def last_status(self):
+        return self.last_call.last_status()
 
-    @classmethod
-    def export_binning(cls):
-        """Sorted keys (uint64 as int64 bit pattern), Gaussian ids and tile ranges of the most recent forward."""
-        lib = L.load()
-        last = cls._last
-        D = cls.last_status()["num_rendered"]
-        dev = last["status"].device
-        T = ((last["W"] + 15) // 16) * ((last["H"] + 15) // 16)
-        keys = torch.empty(max(D, 1), device=dev, dtype=torch.int64)
-        ids = torch.empty(max(D, 1), device=dev, dtype=torch.int32)
-        ranges = torch.empty(T, 2, device=dev, dtype=torch.int32)
-        d = L.EmdDims(last["N"], last["H"], last["W"], last["capacity"], last["flags"])
-        L.check(lib.emd_raster_export_binning(C.byref(d), last["geom_ws"].data_ptr(), last["sizes"][0],
-                                              last["bin_ws"].data_ptr(), last["sizes"][1], D, keys.data_ptr(),
-                                              ids.data_ptr(), ranges.data_ptr(), _stream()), "emd_raster_export_binning")
-        return keys[:D], ids[:D], ranges
+    def export_binning(self):
+        return self.last_call.export_binning()
 
-    @classmethod
-    def export_geometry(cls):
-        lib = L.load()
-        last = cls._last
-        dev, N = last["status"].device, last["N"]
-        e = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)
-        out = dict(means2D=e(N, 2), depths=e(N), conic_opacity=e(N, 4), rgb=e(N, 3),
-                   normal=e(N, 3) if last["flags"] & L.FLAG_NORMAL else None, tiles_touched=e(N, dt=torch.int32))
-        d = L.EmdDims(N, last["H"], last["W"], last["capacity"], last["flags"])
-        L.check(lib.emd_raster_export_geometry(C.byref(d), last["geom_ws"].data_ptr(), last["sizes"][0],
-                                               out["means2D"].data_ptr(), out["depths"].data_ptr(),
-                                               out["conic_opacity"].data_ptr(), out["rgb"].data_ptr(),
-                                               L.ptr(out["normal"]), out["tiles_touched"].data_ptr(), _stream()),
-                "emd_raster_export_geometry")
-        return out
+    def export_geometry(self):
+        return self.last_call.export_geometry()

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 12
+#define EMD_ABI_VERSION 13
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -74,9 +74,11 @@ enum {
     EMD_FLAG_NO_SYNC  = 1 << 3, /* never read the duplicate count back to the host; overflow is reported
                                    through EmdStatus.overflow only (graph-capturable path) */
     EMD_FLAG_CLAMP_RGB01 = 1 << 4, /* SH colour clamped to [0,1] (OmniRe, rigid.py:585) instead of >= 0 */
-    EMD_FLAG_RAW_PARAMS = 1 << 5   /* inputs are the raw parameters: scales = log-scales (exp applied here), rotations
+    EMD_FLAG_RAW_PARAMS = 1 << 5,  /* inputs are the raw parameters: scales = log-scales (exp applied here), rotations
                                       un-normalised (normalised here), opacities = logits (sigmoid here); gradients are
                                       returned w.r.t. the raw parameters.  Fuses S3Gaussian/gaussian_renderer/__init__.py:99-101 */
+    EMD_FLAG_SDEV_TANFOV = 1 << 6  /* settings_dev holds two more floats, tanfovx and tanfovy (cameras given as device-resident
+                                      intrinsics, OmniRe/models/trainers/base.py:399-400): they replace the by-value fields */
 };
 
 /* The 12 fields of GaussianRasterizationSettings (S3Gaussian/gaussian_renderer/__init__.py:49-62), by value. */
@@ -103,6 +105,7 @@ typedef struct EmdSettings {
  *   q_rot[4]   unit quaternion composed onto local quats (q_mean x track rot offset, rigid.py:562-566)
  */
 #define EMD_ACTOR_STRIDE 12
+#define EMD_SETTINGS_DEV_FLOATS 38
 
 typedef struct EmdMotion {
     const int32_t* actor_id;   /* [N]; -1 = static (identity) */
@@ -157,6 +160,12 @@ typedef struct EmdFwdArgs {
     /* host-side results (filled unless EMD_FLAG_NO_SYNC) */
     int64_t num_rendered;
     int64_t num_visible;
+    /* Optional DEVICE copy of the camera-dependent settings, EMD_SETTINGS_DEV_FLOATS floats laid out as
+     * bg[3], viewmatrix[16], projmatrix[16], campos[3] (+ tanfovx, tanfovy with EMD_FLAG_SDEV_TANFOV); NULL = use the by-value
+     * fields of `s`.  The reference keeps exactly
+     * these four on the GPU (`.cuda()` at S3Gaussian/gaussian_renderer/__init__.py:54-59): with this pointer its call site
+     * costs no device-to-host copy, so a forward with EMD_FLAG_NO_SYNC never touches the host. */
+    const float* settings_dev;
 } EmdFwdArgs;
 
 typedef struct EmdBwdArgs {
@@ -210,6 +219,7 @@ typedef struct EmdBwdArgs {
                                    * dL_dshs may be NULL: dL/dshs[n][k][c] = basis_k(view direction) * dL_dsh_color[n][c] is rank one and is
                                    * rebuilt (and summed over views) by emd_sh_grad_from_factors -- 12 bytes per Gaussian to exchange
                                    * between GPUs instead of 192 */
+    const float* settings_dev;    /* as in EmdFwdArgs (same buffer, kept alive by the caller) */
 } EmdBwdArgs;
 
 int emd_abi_version(void);
@@ -256,10 +266,13 @@ int emd_sh_backward(int32_t n, int32_t degree, int32_t sh_coeffs, const float* d
 /* Dense SH-coefficient gradient from per-view factors (view-parallel data parallelism):
  *   dL_dshs[n][k][c] = scale * sum_v basis_k(normalize(world_mean_n - campos[v])) * sh_color_grads[v][n][c]      k < (degree+1)^2
  * with world_mean_n the mean after the explicit-motion transform (motion may be NULL: static scene).  Every rank gathers
- * the [N,3] factors and the camera centres of all views and rebuilds the same dense, averaged gradient locally. */
+ * the [N,3] factors and the camera centres of all views and rebuilds the same dense, averaged gradient locally.
+ * pose_per_view != 0: the views belong to different timestamps (six cameras on eight ranks), motion->actor_pose is then
+ * [V, A, EMD_ACTOR_STRIDE] -- one gathered pose table per view -- and an actor's Gaussians are placed per view. */
 int emd_sh_grad_from_factors(int32_t n, int32_t num_views, int32_t degree, int32_t sh_coeffs, const float* means3D,
-                             const EmdMotion* motion, const float* campos /*[V,3]*/, const float* sh_color_grads /*[V,N,3]*/,
-                             float scale, float* dL_dshs /*[N,sh_coeffs,3]*/, void* hip_stream);
+                             const EmdMotion* motion, int32_t pose_per_view, const float* campos /*[V,3]*/,
+                             const float* sh_color_grads /*[V,N,3]*/, float scale, float* dL_dshs /*[N,sh_coeffs,3]*/,
+                             void* hip_stream);
 
 /* Densification statistics of one view (the per-step part): for every Gaussian with radii > 0
  * grad_accum += |dL_dmeans2D.xy|, denom += 1, max_radii2D = max(max_radii2D, radii), in place -- gaussian_model.py:728-730 and

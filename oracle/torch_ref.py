@@ -238,3 +238,39 @@ def render(S, sc_np, oracle_pre, oracle_bin, flags=0, dtype=torch.float64):
     out["means2D_pix"] = m2d
     out["visible"] = vis
     return out, L
+
+
+def track_offsets(weight, heads, frame, num_frames, embeddings, point_ids, step, min_embeddings=30, max_embeddings=150,
+                  c2f_temporal_iter=25000):
+    """CPU restatement of the per-actor learned track offsets (OmniRe/models/nodes/rigid.py:147-246), batched over actors:
+    weight [A, max_embeddings, D] temporal tables; heads = dict name -> (W, b) of track_rot_c/f [1, D+E], track_trans_c/f [3, D+E];
+    -> (track_trans [A,3], track_rot [A,4]).  TEST INFRASTRUCTURE: the checker of emd_amd.motion.TrackOffsetHeads."""
+    import torch.nn.functional as F
+    A, _, fdim = weight.shape
+
+    def temporal_embed(t, k):
+        emb = F.interpolate(weight[:, None], size=(k, fdim), mode="bilinear", align_corners=True)[:, 0]       # [A,k,D]
+        y = float(t) * (k - 1)
+        y0 = min(max(int(y // 1), 0), k - 1)
+        y1 = min(y0 + 1, k - 1)
+        w = y - y0
+        return emb[:, y0] * (1 - w) + emb[:, y1] * w
+
+    t = (frame - 0) / (num_frames - 1 - 0)
+    ids = point_ids.long()
+    cnt = torch.zeros(A).index_add_(0, ids, torch.ones_like(ids, dtype=embeddings.dtype))
+    mean_emb = torch.zeros(A, embeddings.shape[1], dtype=embeddings.dtype).index_add_(0, ids, embeddings) / cnt[:, None]
+    k_f = int(min_embeddings + (max_embeddings - min_embeddings) * min(max(step, 0), c2f_temporal_iter) / c2f_temporal_iter)
+    h_c = torch.cat([temporal_embed(t, min_embeddings), mean_emb], -1)
+    h_f = torch.cat([temporal_embed(t, k_f), mean_emb], -1)
+    lin = lambda name, h: h @ heads[name][0].t() + heads[name][1]
+    trans = lin("track_trans_c", h_c) + lin("track_trans_f", h_f)
+    th_c, th_f = lin("track_rot_c", h_c)[:, 0], lin("track_rot_f", h_f)[:, 0]
+    z = torch.zeros_like(th_c)
+    a = torch.stack([torch.cos(th_c), z, z, torch.sin(th_c)], -1)
+    b = torch.stack([torch.cos(th_f), z, z, torch.sin(th_f)], -1)
+    aw, ax, ay, az = a.unbind(-1)
+    bw, bx, by, bz = b.unbind(-1)
+    rot = torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                       aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], -1)
+    return trans, rot

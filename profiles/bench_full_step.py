@@ -17,7 +17,7 @@ import types
 import torch
 
 sys.path.insert(0, ".")
-from emd_amd import dp, scenes, RasterConfig, GaussianRasterizer  # noqa: E402
+from emd_amd import dp, scenes, RasterOptions  # noqa: E402
 from emd_amd import rasterizer as _rz  # noqa: E402
 from emd_amd.loss import image_loss  # noqa: E402
 from emd_amd.model import StreetGaussians, render  # noqa: E402
@@ -68,6 +68,7 @@ for f in range(F):
     cams[f] = cam
     skycams[f] = types.SimpleNamespace(image_height=H, image_width=W, intrinsic=K.to(dev), world_view_transform=cam.world_view_transform.to(dev))
 bg = torch.zeros(3)
+OPTS = [RasterOptions(no_sync=False)]
 
 
 def step(s):
@@ -75,7 +76,7 @@ def step(s):
     for p in params:
         p.grad = None
     sky.sky_cube_map.grad = None
-    out = render(model, cams[f], bg, frame=f, deformation=deform, embeddings=embeddings, iteration=12000 + s, time=f / (F - 1))
+    out = render(model, cams[f], bg, frame=f, deformation=deform, embeddings=embeddings, iteration=12000 + s, time=f / (F - 1), options=OPTS[0])
     image, _ = composite_s3g(sky, skycams[f], out["render"], out["weight"])
     loss, _ = image_loss(image, gt, out["depth"], gt_depth, not_sky, out["weight"], sky_mask)
     if FINE:                                           # residual regularisers (train.py: lambda_dx / do / dshs on both levels)
@@ -88,14 +89,13 @@ def step(s):
         optimizer.step()
 
 
-RasterConfig.no_sync = False
 dmax = 0
 for f in range(0, F, 7):
     with torch.no_grad():
-        render(model, cams[f], bg, frame=f, deformation=deform, embeddings=embeddings, iteration=12000, time=f / (F - 1))
-    dmax = max(dmax, GaussianRasterizer.last_status()["num_rendered"])
+        o = render(model, cams[f], bg, frame=f, deformation=deform, embeddings=embeddings, iteration=12000, time=f / (F - 1), options=OPTS[0])
+    dmax = max(dmax, o["raster_call"].last_status()["num_rendered"])
 _rz._capacity_hint[(dev.index, H, W)] = int(dmax * 1.3) + 1024
-RasterConfig.no_sync = True
+OPTS[0] = RasterOptions(no_sync=True)
 for s in range(10):
     step(s)
 torch.cuda.synchronize()

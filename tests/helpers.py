@@ -123,9 +123,9 @@ def run_oracle(case, backward=False):
     return out
 
 
-def run_hip(case, backward=False, device="cuda:0", absgrad=False):
+def run_hip(case, backward=False, device="cuda:0", absgrad=False, factored_sh_grad=False):
     """The product path: emd_amd.GaussianRasterizer -> C ABI -> HIP kernels."""
-    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer, RasterConfig
+    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer
     cam = case["cam"]
     dev = torch.device(device)
     d = lambda t, rg=backward: None if t is None else t.to(dev).clone().requires_grad_(rg and t.is_floating_point())
@@ -139,9 +139,7 @@ def run_hip(case, backward=False, device="cuda:0", absgrad=False):
              cov3Ds_precomp=d(case["cov3D_precomp"]), actor_pose=d(case["actor_pose"]),
              residual_dx=d(case["residual_dx"]), residual_dq=d(case["residual_dq"]))
     means2D = torch.zeros(case["N"], 3, device=dev, requires_grad=backward)
-    RasterConfig.absgrad = absgrad
-    RasterConfig.compute_normal = True
-    rast = GaussianRasterizer(rs)
+    rast = GaussianRasterizer(rs, compute_normal=True, absgrad=absgrad, factored_sh_grad=factored_sh_grad)   # options belong to this instance
     kw = {}
     if case["flags"] & co.F_MOTION:
         kw = dict(actor_ids=None if case["actor_ids"] is None else case["actor_ids"].to(dev), actor_pose=T["actor_pose"],
@@ -152,12 +150,12 @@ def run_hip(case, backward=False, device="cuda:0", absgrad=False):
                                                  cov3Ds_precomp=T["cov3Ds_precomp"], extra_attrs=None, **kw)
     out = dict(color=color.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(),
                normal=normal.detach().cpu().numpy(), alpha=alpha.detach().cpu().numpy(), radii=radii.cpu().numpy())
-    keys, ids, ranges = GaussianRasterizer.export_binning()
+    keys, ids, ranges = rast.export_binning()
     out["keys"] = keys.cpu().numpy().view(np.uint64)
     out["ids"] = ids.cpu().numpy().view(np.uint32)
     out["ranges"] = ranges.cpu().numpy().view(np.uint32)
-    out["status"] = GaussianRasterizer.last_status()
-    geo = GaussianRasterizer.export_geometry()
+    out["status"] = rast.last_status()
+    geo = rast.export_geometry()
     out["geo"] = {k: (None if v is None else v.cpu().numpy()) for k, v in geo.items()}
     if backward:
         tc = lambda a: torch.from_numpy(a).to(dev)
@@ -170,8 +168,9 @@ def run_hip(case, backward=False, device="cuda:0", absgrad=False):
                             cov3D=g(T["cov3Ds_precomp"]), actor_pose=g(T["actor_pose"]), residual_dx=g(T["residual_dx"]),
                             residual_dq=g(T["residual_dq"]))
         if absgrad:
-            out["grads"]["means2D_abs"] = GaussianRasterizer.last_absgrad.cpu().numpy()
-    RasterConfig.absgrad = False
+            out["grads"]["means2D_abs"] = rast.last_call.absgrad.cpu().numpy()
+            assert means2D.absgrad is rast.last_call.absgrad          # gsplat convention: also published on the grad sink
+    out["call"] = rast.last_call
     return out
 
 
@@ -256,7 +255,7 @@ def raw_params_parity(case, log_s, raw_q, logit, device="cuda:0", check_images_e
     contract and the images stay bit-exact; the oracle's gradients are chained through the activations in float64 numpy.
     Returns a dict of the per-tensor (worst element excess, rel L2) pairs."""
     import ctypes as C
-    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer, RasterConfig, _lib as L
+    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib as L
     dev = torch.device(device)
     N = case["N"]
     motion = case.get("actor_ids") is not None
@@ -289,11 +288,11 @@ def raw_params_parity(case, log_s, raw_q, logit, device="cuda:0", check_images_e
     if motion:
         pose = case["actor_pose"].to(dev).requires_grad_(True)
         kw = dict(actor_ids=case["actor_ids"].to(dev), actor_pose=pose)
-    RasterConfig.compute_normal = True
-    color, depth, normal, alpha, radii, _ = GaussianRasterizer(rs)(means3D=means, means2D=m2, shs=shs, opacities=logit, scales=log_s,
-                                                                  rotations=raw_q, raw_params=True, **kw)
-    keys, ids, ranges = GaussianRasterizer.export_binning()
-    st = GaussianRasterizer.last_status()
+    rast = GaussianRasterizer(rs, compute_normal=True)
+    color, depth, normal, alpha, radii, _ = rast(means3D=means, means2D=m2, shs=shs, opacities=logit, scales=log_s,
+                                                 rotations=raw_q, raw_params=True, **kw)
+    keys, ids, ranges = rast.export_binning()
+    st = rast.last_status()
     assert st["num_rendered"] == orc["bin"]["D"] and st["num_visible"] == int((orc["pre"]["radii"] > 0).sum())
     np.testing.assert_array_equal(radii.cpu().numpy(), orc["pre"]["radii"], err_msg="radii")
     np.testing.assert_array_equal(keys.cpu().numpy().view(np.uint64), orc["bin"]["keys"], err_msg="sorted keys")

@@ -30,12 +30,17 @@ def test_bench_two_ranks_share_one_gpu():
     assert len(lines) == 1, p.stdout[-2000:]            # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["views_per_step"] == 2 and d["config"]["parallelism"] == "view-parallel dp2"
+    assert d["config"]["views_per_step"] == 2 and d["config"]["parallelism"] == "view-parallel dp2" and d["config"]["rig_cameras"] == 2
 
 
-def test_factored_sh_exchange_equals_dense_allreduce_two_ranks():
+@pytest.mark.parametrize("ranks,mixed", [(2, False), (3, True)], ids=["2-ranks-one-timestamp", "3-ranks-mixed-timestamps"])
+def test_factored_sh_exchange_equals_dense_allreduce(ranks, mixed):
+    """The in-backward gradient exchange (SH factors + one slab) against the plain dense all-reduce; with three ranks on three
+    different timestamps the rebuild needs one gathered actor pose table per view (6 cameras on 8 GPUs, config 5)."""
     env = dict(os.environ, EMD_BENCH_SHARE_GPU="1", EMD_DP_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    if mixed:
+        env["EMD_DP_MIXED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_factored_check.py")]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
@@ -55,7 +60,9 @@ def test_bench_and_factored_exchange_over_rccl_when_two_gpus_are_present():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["value"] > 0
-    p = subprocess.run(launch + ["--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_factored_check.py")],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
-    assert any(l.startswith("OK ") for l in p.stdout.splitlines()), p.stdout[-1500:]
+    for mixed in (False, True):
+        e2 = dict(env, EMD_DP_MIXED="1") if mixed else env
+        p = subprocess.run(launch + ["--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_factored_check.py")],
+                           cwd=ROOT, env=e2, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+        assert any(l.startswith("OK ") for l in p.stdout.splitlines()), p.stdout[-1500:]

@@ -1,0 +1,152 @@
+"""-m gpu: re-entrancy and host-synchronisation behaviour of the drop-in boundary.
+
+  - options belong to the rasterizer instance and results to the call's record: two rasterizers on two streams plus three
+    calls of one object in one autograd graph (absgrad on one of them) must give exactly the single-call results;
+  - with device-resident camera settings (what the reference passes: `.cuda()` tensors, gaussian_renderer/__init__.py:54-59) and
+    `no_sync`, a forward + backward performs NO stream synchronisation and no device-to-host copy: run under
+    torch.cuda.set_sync_debug_mode("error"), which raises on any synchronising call."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import make_case
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _settings(case, dev=DEV):
+    from emd_amd import GaussianRasterizationSettings
+    cam = case["cam"]
+    return GaussianRasterizationSettings(image_height=case["H"], image_width=case["W"], tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                                         bg=case["bg"].to(dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(dev),
+                                         projmatrix=cam.full_proj_transform.to(dev), sh_degree=case["sh_degree"],
+                                         campos=cam.camera_center.to(dev), prefiltered=False, debug=False)
+
+
+def _leaves(case):
+    t = {k: case[k].to(DEV).clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    t["means2D"] = torch.zeros(case["N"], 3, device=DEV, requires_grad=True)
+    return t
+
+
+def _call(rast, t, **kw):
+    return rast(means3D=t["means3D"], means2D=t["means2D"], shs=t["shs"], colors_precomp=None, opacities=t["opacities"],
+                scales=t["scales"], rotations=t["rotations"], cov3Ds_precomp=None, extra_attrs=None, **kw)
+
+
+def test_two_streams_and_three_calls_in_one_graph_with_absgrad_on_one():
+    from emd_amd import GaussianRasterizer, RasterCall
+    case_a, case_b = make_case(n=6000, H=80, W=112, seed=3), make_case(n=5000, H=64, W=96, seed=4, yaw=20.0)
+    rs_a, rs_b = _settings(case_a), _settings(case_b)
+    gen = torch.Generator().manual_seed(1)
+    Ga = [torch.randn(3, case_a["H"], case_a["W"], generator=gen).to(DEV) for _ in range(3)]
+    Gb = torch.randn(3, case_b["H"], case_b["W"], generator=gen).to(DEV)
+
+    # single-call references
+    def single(rs, case, G, **opt):
+        t = _leaves(case)
+        r = GaussianRasterizer(rs, **opt)
+        img = _call(r, t)[0]
+        (img * G).sum().backward()
+        return img.detach(), {k: v.grad.clone() for k, v in t.items()}, r.last_call
+    ref_imgs, ref_grads = [], None
+    for w in range(3):
+        img, gr, call = single(rs_a, case_a, Ga[w], absgrad=(w == 1))
+        ref_imgs.append(img)
+        ref_grads = gr if ref_grads is None else {k: ref_grads[k] + gr[k] for k in gr}
+        if w == 1:
+            ref_abs = call.absgrad.clone()
+    ref_b_img, ref_b_grads, _ = single(rs_b, case_b, Gb)
+
+    # now: stream 1 runs three calls of ONE rasterizer object pair in one graph, stream 2 another rasterizer, interleaved
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ta, tb = _leaves(case_a), _leaves(case_b)
+    plain, with_abs = GaussianRasterizer(rs_a), GaussianRasterizer(rs_a, absgrad=True)
+    other = GaussianRasterizer(rs_b)
+    recs = [RasterCall() for _ in range(3)]
+    with torch.cuda.stream(s1):
+        i0 = _call(plain, ta, record=recs[0])[0]
+    with torch.cuda.stream(s2):
+        ib = _call(other, tb)[0]
+    with torch.cuda.stream(s1):
+        i1 = _call(with_abs, ta, record=recs[1])[0]
+        i2 = _call(plain, ta, record=recs[2])[0]
+        (sum((img * Ga[w]).sum() for w, img in enumerate((i0, i1, i2)))).backward()
+    with torch.cuda.stream(s2):
+        (ib * Gb).sum().backward()
+    torch.cuda.synchronize()
+    for w, img in enumerate((i0, i1, i2)):
+        assert torch.equal(img.detach(), ref_imgs[w]), w
+    assert torch.equal(ib.detach(), ref_b_img)
+    for k, v in ta.items():
+        err = float((v.grad - ref_grads[k]).abs().max())
+        assert err <= 1e-4 * max(float(ref_grads[k].abs().max()), 1e-12), (k, err)
+    for k, v in tb.items():
+        err = float((v.grad - ref_b_grads[k]).abs().max())
+        assert err <= 1e-5 * max(float(ref_b_grads[k].abs().max()), 1e-12), (k, err)
+    # absgrad: only the call that asked for it has it, and it is that call's own
+    assert recs[0].absgrad is None and recs[2].absgrad is None
+    err = float((recs[1].absgrad - ref_abs).abs().max())
+    assert err <= 1e-5 * float(ref_abs.abs().max()), err
+    assert plain.last_call is recs[2] and with_abs.last_call is recs[1]
+
+
+def test_reference_call_site_with_device_settings_never_synchronises():
+    """S3Gaussian/gaussian_renderer/__init__.py:49-62 builds the settings from CUDA tensors.  With `no_sync` such a call (forward and
+    backward, main pass + a colors_precomp feature pass as at :145-201) must not synchronise: sync-debug mode raises if it does."""
+    from emd_amd import GaussianRasterizer, rasterizer
+    case = make_case(n=8000, H=96, W=128, seed=11)
+    rs = _settings(case)                       # bg / viewmatrix / projmatrix / campos live on the device
+    t = _leaves(case)
+    feat = torch.rand(case["N"], 3, device=DEV, requires_grad=True)
+    G = torch.randn(3, case["H"], case["W"], device=DEV)
+    # a synchronising warm-up call sizes the binning workspace (capacity hint) and builds the reference result
+    warm = GaussianRasterizer(rs, no_sync=False)
+    ref = _call(warm, t)[0].detach().clone()
+    D = warm.last_status()["num_rendered"]
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        rast = GaussianRasterizer(rs, no_sync=True)
+        img = _call(rast, t)[0]
+        img_f = rast(means3D=t["means3D"], means2D=t["means2D"], shs=None, colors_precomp=feat, opacities=t["opacities"],
+                     scales=t["scales"], rotations=t["rotations"], cov3Ds_precomp=None, extra_attrs=None)[0]
+        ((img * G).sum() + (img_f * G).sum()).backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert torch.equal(img.detach(), ref)
+    assert rast.last_call.num_rendered == -1 and rast.last_call.settings_dev is not None      # count never read, settings by pointer
+    assert rast.last_call.last_status()["num_rendered"] == D
+    assert t["means3D"].grad is not None and feat.grad is not None and torch.isfinite(t["means3D"].grad).all()
+
+
+def test_no_sync_overflow_is_reported_by_a_later_call_and_heals():
+    """no_sync never waits for the duplicate count; an overflowing call yields a blank image.  Its status word is copied to pinned
+    memory asynchronously and examined by a later forward: that call warns and raises the capacity hint, so the NEXT call is right."""
+    import warnings
+    from emd_amd import GaussianRasterizer, rasterizer
+    case = make_case(n=6000, H=96, W=128, seed=41)
+    rs = _settings(case)
+    t = _leaves(case)
+    good = _call(GaussianRasterizer(rs, no_sync=False), t)[0].detach().clone()
+    key = (0, case["H"], case["W"])
+    rasterizer._pending_status.pop(key, None)
+    rasterizer._capacity_hint[key] = 64                       # far too small
+    r = GaussianRasterizer(rs, no_sync=True, min_capacity=64)
+    with torch.no_grad():
+        blank = _call(r, t)[0]
+        assert r.last_call.last_status()["overflow"] == 1 and not torch.equal(blank, good)
+        torch.cuda.synchronize()                              # (only so that the pinned copy has certainly landed for the test)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            second = _call(r, t)[0]                           # polls the earlier status: warns + raises the hint; this call may still be short
+            assert any("overflowed" in str(x.message) for x in w)
+        torch.cuda.synchronize()
+        third = _call(r, t)[0]
+        if not torch.equal(second, good):
+            torch.cuda.synchronize()
+            third = _call(r, t)[0]
+    assert torch.equal(third, good)

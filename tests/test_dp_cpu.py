@@ -76,3 +76,19 @@ def test_world_size_one_is_the_reference_step():
     vg = torch.tensor([[3.0, 4.0, 9.0], [1.0, 0.0, 0.0]])
     g, d, r = dp.densification_stats(vg, torch.tensor([5, 0], dtype=torch.int32))
     assert g[0, 0] == 5.0 and g[1, 0] == 0.0 and d[:, 0].tolist() == [1.0, 0.0] and r.tolist() == [5.0, 0.0]
+
+
+def test_bench_view_mapping_gives_every_rank_a_distinct_view():
+    """bench.py's (frame, camera) per rank = dp.frame_and_camera: distinct views inside every step at 1, 2, 4 and 8 GPUs, one
+    timestamp per step when the rig has as many cameras as there are ranks, two ranks on the next timestamp at 8 GPUs / 6 cameras."""
+    from emd_amd import dp
+    for world in (1, 2, 4, 8):
+        cams = dp.rig_size(world)
+        assert cams == {1: 1, 2: 2, 4: 4, 8: 6}[world]
+        for step in range(60):
+            views = [dp.frame_and_camera(step, r, world, 50, cams) for r in range(world)]
+            assert len(set(views)) == world, (world, step, views)
+            if world == cams:
+                assert len({f for f, _ in views}) == 1
+    v8 = [dp.frame_and_camera(0, r, 8, 50, 6) for r in range(8)]
+    assert v8 == [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (1, 0), (1, 1)]

@@ -80,14 +80,12 @@ def test_quaternion_algebra_matches_reference():
     np.testing.assert_allclose(motion.interpolate_quats(torch.tensor(o["qa"]), torch.tensor(o["qb"])).numpy(), o["interp"], atol=2e-6)
 
 
-def _heads_from_golden(z):
-    A = z["instances_quats"].shape[1]
-    h = motion.TrackOffsetHeads(A)
-    h.weight.data = torch.tensor(z["temporal_weight"])
-    for name in ("track_rot_c", "track_rot_f", "track_trans_c", "track_trans_f"):
-        getattr(h, name).weight.data = torch.tensor(z[name + "_w"])
-        getattr(h, name).bias.data = torch.tensor(z[name + "_b"])
-    return h
+def _heads_from_golden(z, requires_grad=False):
+    """The checker's restatement of the track-offset heads (oracle/torch_ref.track_offsets); the product's TrackOffsetHeads runs
+    on the GPU only and is checked against the same golden file in tests/test_motion_sh_gpu.py."""
+    weight = torch.tensor(z["temporal_weight"])
+    heads = {name: (torch.tensor(z[name + "_w"]), torch.tensor(z[name + "_b"])) for name in ("track_rot_c", "track_rot_f", "track_trans_c", "track_trans_f")}
+    return lambda frame, num_frames, emb, ids, step: tr.track_offsets(weight, heads, frame, num_frames, emb, ids, step)
 
 
 @pytest.mark.parametrize("tag", ["train", "train5", "test", "test_edge"])

@@ -8,7 +8,18 @@ import torch
 
 from emd_amd import gsplat_api, motion
 from oracle import cpu_oracle as co
-from tests.test_golden_cpu import _heads_from_golden, ld
+from tests.test_golden_cpu import ld
+
+
+def _heads_from_golden(z):
+    """The product's track-offset heads (HIP temporal-embedding rows, batched over actors) loaded with the golden file's weights."""
+    A = z["instances_quats"].shape[1]
+    h = motion.TrackOffsetHeads(A)
+    h.weight.data = torch.tensor(z["temporal_weight"])
+    for name in ("track_rot_c", "track_rot_f", "track_trans_c", "track_trans_f"):
+        getattr(h, name).weight.data = torch.tensor(z[name + "_w"])
+        getattr(h, name).bias.data = torch.tensor(z[name + "_b"])
+    return h
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -23,6 +34,9 @@ def test_hip_motion_forward_matches_reference(tag):
     ids = g("point_ids")
     with torch.no_grad():
         tt, trq = heads(frame, int(z["num_frames"]), g("embeddings"), ids, int(z["step"]))
+        # the heads themselves (one HIP launch per temporal row for all actors) against the reference's embedding_track_*_offset
+        np.testing.assert_allclose(tt.cpu().numpy(), z[f"{tag}_track_trans"], atol=2e-6)
+        np.testing.assert_allclose(trq.cpu().numpy(), z[f"{tag}_track_rot"], atol=2e-6)
         pose = motion.build_actor_pose(g("instances_quats"), g("instances_trans"), g("instances_fv"), frame, tt, trq, in_test)
         wm, wq, wo = motion.transform_gaussians(g("means"), g("quats"), torch.sigmoid(g("opacity_logits")), ids, pose)
     np.testing.assert_allclose(wm.cpu().numpy(), z[f"{tag}_world_means"], rtol=1e-6, atol=5e-6)
@@ -147,7 +161,6 @@ def test_factored_sh_gradient_equals_dense_average():
     import numpy as np
     import torch
     from emd_amd import dp
-    from emd_amd.rasterizer import GaussianRasterizer, RasterConfig
     from tests.helpers import make_case, run_hip
     dev = torch.device("cuda", 0)
     dense, factors, campos, case0 = [], [], [], None
@@ -155,13 +168,9 @@ def test_factored_sh_gradient_equals_dense_average():
         case = make_case(n=3000, H=64, W=96, seed=77, motion=True, yaw=yaw)
         case0 = case0 or case
         dense.append(run_hip(case, backward=True)["grads"]["shs"])
-        RasterConfig.factored_sh_grad = True
-        try:
-            out = run_hip(case, backward=True)
-        finally:
-            RasterConfig.factored_sh_grad = False
+        out = run_hip(case, backward=True, factored_sh_grad=True)
         assert out["grads"]["shs"] is None                       # the dense tensor is never written in this mode
-        factors.append(GaussianRasterizer.last_sh_color_grad.clone())
+        factors.append(out["call"].sh_color_grad.clone())        # published in THIS call's record
         campos.append(torch.as_tensor(case["cam"].camera_center, dtype=torch.float32).reshape(3))
     expect = 0.5 * (dense[0] + dense[1])
     got = dp.sh_grad_from_factors(case0["means3D"].to(dev), torch.stack(campos).to(dev), torch.stack(factors), case0["sh_degree"], 16,

@@ -118,7 +118,7 @@ def test_capacity_retry_and_determinism_of_forward():
     case = make_case(n=6000, H=96, W=128, seed=41)
     rasterizer._capacity_hint.clear()
     old = rasterizer.RasterConfig.min_capacity
-    rasterizer.RasterConfig.min_capacity = 16   # force the EMD_ERR_CAPACITY -> regrow -> retry path
+    rasterizer.RasterConfig.min_capacity = 16   # process-wide DEFAULT read when run_hip builds its rasterizer: forces EMD_ERR_CAPACITY -> regrow -> retry
     try:
         rasterizer._capacity_hint[(0, 96, 128)] = 16
         a = run_hip(case)
@@ -147,14 +147,15 @@ def test_round_trip_properties_full_size():
                 rotations=sc.quats)
     col = torch.rand(sc.N, 3, device=dev)
     c1, d1, _, a1, radii, _ = r(colors_precomp=col, **args)
-    keys, ids, ranges = GaussianRasterizer.export_binning()
+    first_call = r.last_call
+    keys, ids, ranges = r.export_binning()
     k = keys.cpu().numpy().view(np.uint64)
     assert np.all(k[1:] >= k[:-1]), "keys must be sorted"
     tiles = (k >> np.uint64(32)).astype(np.int64)
     rg = ranges.cpu().numpy().view(np.uint32).astype(np.int64)
     cnt = np.bincount(tiles, minlength=rg.shape[0])
     np.testing.assert_array_equal(rg[:, 1] - rg[:, 0], cnt)
-    assert int(radii.gt(0).sum()) == GaussianRasterizer.last_status()["num_visible"]
+    assert int(radii.gt(0).sum()) == first_call.last_status()["num_visible"]
     assert float(a1.min()) >= 0.0 and float(a1.max()) <= 1.0
     # linearity in colour: render(2 c) = 2 render(c) with bg = 0
     c2, _, _, a2, _, _ = r(colors_precomp=2 * col, **args)
@@ -246,14 +247,13 @@ def test_one_rasterizer_object_called_three_times_in_one_graph():
     colors_precomp, decomposition passes on a boolean-mask subset (gaussian_renderer/__init__.py:145,172,247) -- and
     back-propagates through all of them at once.  The calls must not disturb each other's saved state: images equal the
     single-call images bit for bit, and the gradients of the shared tensors equal the sum of the single-call gradients."""
-    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer, RasterConfig
+    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer
     case = make_case(n=6000, H=80, W=112, seed=77)
     cam, dev = case["cam"], torch.device("cuda", 0)
     rs = GaussianRasterizationSettings(image_height=case["H"], image_width=case["W"], tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
                                        bg=case["bg"].to(dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(dev),
                                        projmatrix=cam.full_proj_transform.to(dev), sh_degree=case["sh_degree"],
                                        campos=cam.camera_center.to(dev), prefiltered=False, debug=False)
-    RasterConfig.compute_normal = True
     gen = torch.Generator().manual_seed(5)
     feat0 = torch.rand(case["N"], 3, generator=gen)
     mask = (torch.arange(case["N"]) % 3 == 0).to(dev)
@@ -299,14 +299,13 @@ def test_one_rasterizer_object_called_three_times_in_one_graph():
 def test_nonfinite_gaussians_are_dropped_not_fatal():
     """Gaussians with NaN / Inf parameters (a diverged optimisation step) must neither fault nor disturb the rest of the image: they
     are invisible (radius 0), the image equals the image without them bit for bit, and the other Gaussians' gradients are unchanged."""
-    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer, RasterConfig
+    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer
     case = make_case(n=5000, H=80, W=112, seed=91)
     cam, dev = case["cam"], torch.device("cuda", 0)
     rs = GaussianRasterizationSettings(image_height=case["H"], image_width=case["W"], tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
                                        bg=case["bg"].to(dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(dev),
                                        projmatrix=cam.full_proj_transform.to(dev), sh_degree=case["sh_degree"],
                                        campos=cam.camera_center.to(dev), prefiltered=False, debug=False)
-    RasterConfig.compute_normal = True
     names = ("means3D", "shs", "opacities", "scales", "rotations")
     bad_rows = torch.tensor([3, 700, 1500, 2600, 4100])
 
