@@ -16,8 +16,9 @@ TILE = 16
 ACTOR_STRIDE = 12
 BWD_STRIDE = 12
 
-EMD_OK, EMD_ERR_INVALID, EMD_ERR_CAPACITY, EMD_ERR_HIP, EMD_ERR_WORKSPACE = 0, -1, -2, -3, -4
+EMD_OK, EMD_ERR_INVALID, EMD_ERR_CAPACITY, EMD_ERR_HIP, EMD_ERR_WORKSPACE, EMD_ERR_DEPTH_RANGE = 0, -1, -2, -3, -4, -5
 FLAG_NORMAL, FLAG_MOTION, FLAG_ABSGRAD, FLAG_NO_SYNC, FLAG_CLAMP_RGB01, FLAG_RAW_PARAMS, FLAG_SDEV_TANFOV = 1, 2, 4, 8, 16, 32, 64
+FLAG_WIDE_DEPTH_SORT = 128
 
 _f = C.c_void_p  # device pointers are passed as integers
 
@@ -107,6 +108,39 @@ class EmdDeformInArgs(C.Structure):
                 ("t", _f), ("out", _f)]
 
 
+DENSIFY_MODE_DENSIFY, DENSIFY_MODE_PRUNE = 0, 1
+DENSIFY_ROLE_COPY, DENSIFY_ROLE_XYZ, DENSIFY_ROLE_SCALING, DENSIFY_ROLE_STATE, DENSIFY_ROLE_ZERO = 0, 1, 2, 3, 4
+DENSIFY_MAX_TENSORS = 40
+
+
+class EmdDensifyArgs(C.Structure):
+    _fields_ = [("num_points", C.c_int32), ("mode", C.c_int32), ("scaling", _f), ("opacity", _f), ("grad_accum", _f), ("denom", _f),
+                ("max_radii2D", _f), ("extra_drop", _f), ("grad_threshold", C.c_float), ("percent_dense", C.c_float),
+                ("scene_extent", C.c_float), ("min_opacity", C.c_float), ("max_screen_size", C.c_float)]
+
+
+class EmdDensifyTensor(C.Structure):
+    _fields_ = [("src", _f), ("dst", _f), ("width", C.c_int32), ("role", C.c_int32)]
+
+
+class EmdDensifyGather(C.Structure):
+    _fields_ = [("num_out", C.c_int32), ("num_tensors", C.c_int32), ("mode", C.c_int32), ("num_split", C.c_int32), ("src", _f), ("kind", _f),
+                ("scaling", _f), ("rotation", _f), ("seed", C.c_uint64), ("samples", _f), ("split_rank", _f),
+                ("tensors", EmdDensifyTensor * DENSIFY_MAX_TENSORS)]
+
+
+class EmdTrackArgs(C.Structure):
+    _fields_ = [("num_actors", C.c_int32), ("rows", C.c_int32), ("dim", C.c_int32), ("embed_dim", C.c_int32), ("k_coarse", C.c_int32),
+                ("k_fine", C.c_int32), ("num_points", C.c_int32), ("reserved", C.c_int32), ("t", C.c_float), ("weight", _f),
+                ("embeddings", _f), ("point_ids", _f), ("count", _f), ("head_w", _f * 4), ("head_b", _f * 4), ("emb_sum", _f),
+                ("trans", _f), ("rot", _f)]
+
+
+class EmdTrackGrads(C.Structure):
+    _fields_ = [("g_trans", _f), ("g_rot", _f), ("d_weight", _f), ("d_embeddings", _f), ("d_head_w", _f * 4), ("d_head_b", _f * 4),
+                ("d_mean", _f)]
+
+
 ADAM_MAX_TENSORS = 32
 
 
@@ -127,7 +161,8 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward", "emd_actor_pose_forward", "emd_actor_pose_backward", "emd_l1_loss",
                     "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss", "emd_hexplane_forward", "emd_hexplane_backward", "emd_sh_grad_from_factors", "emd_densification_stats",
                     "emd_temporal_embed_forward", "emd_temporal_embed_backward", "emd_deform_input_width", "emd_deform_input_forward",
-                    "emd_deform_input_backward", "emd_adam_step")
+                    "emd_deform_input_backward", "emd_adam_step", "emd_track_heads_forward", "emd_track_heads_backward",
+                    "emd_densify_decide", "emd_densify_index", "emd_densify_split_rank", "emd_densify_gather")
 PROF_STAGES = 8
 
 _lib = None
@@ -185,6 +220,12 @@ def load():
     lib.emd_deform_input_forward.argtypes = [C.POINTER(EmdDeformInArgs), C.c_void_p]
     lib.emd_deform_input_backward.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_adam_step.argtypes = [C.POINTER(EmdAdamArgs), C.c_void_p]
+    lib.emd_densify_decide.argtypes = [C.POINTER(EmdDensifyArgs), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_densify_index.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_densify_split_rank.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.emd_densify_gather.argtypes = [C.POINTER(EmdDensifyGather), C.c_void_p]
+    lib.emd_track_heads_forward.argtypes = [C.POINTER(EmdTrackArgs), C.c_void_p]
+    lib.emd_track_heads_backward.argtypes = [C.POINTER(EmdTrackArgs), C.POINTER(EmdTrackGrads), C.c_void_p]
     lib.emd_sky_forward.argtypes = [C.POINTER(EmdSkyArgs), C.c_void_p]
     lib.emd_sky_backward.argtypes = [C.POINTER(EmdSkyBwdArgs), C.c_void_p]
     lib.emd_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]

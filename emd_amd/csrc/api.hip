@@ -192,7 +192,7 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
     rc = emd_launch_preprocess(pa, st);
     if (rc) return rc;
     STAGE_SYNC("preprocess");
-    rc = emd_launch_binning(a->s, N, g, b, a->bin_capacity, a->status, st);
+    rc = emd_launch_binning(a->s, a->flags, N, g, b, a->bin_capacity, a->status, st);
     if (rc) return rc;
     STAGE_SYNC("binning");
     a->num_rendered = -1;
@@ -203,6 +203,10 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
         EMD_HIP_CHECK(hipStreamSynchronize(st));
         a->num_rendered = hs.num_rendered;
         a->num_visible = hs.num_visible;
+        if (hs.overflow & 2u) {
+            emd_set_error("forward: a visible Gaussian lies beyond 65 536 x the near plane; repeat with EMD_FLAG_WIDE_DEPTH_SORT");
+            return EMD_ERR_DEPTH_RANGE;
+        }
         if (hs.overflow) {
             emd_set_error("forward: %u (tile, Gaussian) pairs exceed bin_capacity %lld", hs.num_rendered, (long long)a->bin_capacity);
             return EMD_ERR_CAPACITY;

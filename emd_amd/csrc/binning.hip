@@ -23,15 +23,18 @@
 //     LDS -- consecutive lanes write consecutive pairs (coalesced 4 B + 4 B stores) regardless of footprint size.
 //   - ranking inside a radix block is wave-ballot based (8 ballots per key give the set of lanes with the same digit;
 //     no LDS atomics in the ranking loop), which keeps every pass stable.
+#include <string.h>
+
 #include "common.h"
 #include "device_utils.h"
 
 namespace {
 
-// number of elements of a radix pass: a launch-time constant (Gaussian depth sort) or the device-side duplicate count
-struct SortN { const EmdStatus* status; uint32_t fixed; };
+// number of elements of a radix pass: a launch-time constant (first pass of the Gaussian depth sort), or a device-side count
+// (visible Gaussians after that pass; the duplicate count of the tile passes) that reads as 0 while the overflow word is set
+struct SortN { const uint32_t* count; const uint32_t* overflow; uint32_t fixed; };
 __device__ __forceinline__ uint32_t sort_n(const SortN& c) {
-    return c.status ? (c.status->overflow ? 0u : c.status->num_rendered) : c.fixed;
+    return c.count ? ((c.overflow && *c.overflow) ? 0u : *c.count) : c.fixed;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -43,7 +46,7 @@ __device__ __forceinline__ uint32_t sort_n(const SortN& c) {
 // ---------------------------------------------------------------------------------------------------
 // K2': tile rectangle and tile count of the Gaussians in depth order (one 8-byte gather each) + block totals
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32_t* __restrict__ depth_sorted,
+__global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32_t* __restrict__ num_sorted,
                                                              const uint32_t* __restrict__ perm,
                                                              const uint2* __restrict__ binrec,
                                                              uint32_t* __restrict__ rect_s, uint32_t* __restrict__ cnt_s,
@@ -52,7 +55,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32
     __shared__ uint32_t s_scan[4];
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
     uint2 br = make_uint2(0u, 0u);
-    if (i < N && depth_sorted[i] != 0xFFFFFFFFu) br = binrec[perm[i]];   // invisible Gaussians sort last, count 0
+    if (i < N && (uint32_t)i < *num_sorted) br = binrec[perm[i]];         // the depth sort kept the V visible Gaussians only
     if (i < N) { rect_s[i] = br.x; cnt_s[i] = br.y; }
     // empty tiles keep the range (0, 0): cleared here instead of by a separate memset launch
     for (uint32_t r = (uint32_t)i; r < n_ranges; r += gridDim.x * EMD_BLOCK) ranges[r] = 0u;
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(PUB_THREADS) k_scan_publish(uint32_t* __restri
         uint32_t vtot = 0;
         for (uint32_t w = 0; w < PUB_THREADS / 64; w++) vtot += s_w[w];
         status->num_rendered = carry;
-        status->overflow = ((uint64_t)carry > capacity) ? 1u : 0u;
+        status->overflow = (status->overflow & 2u) | (((uint64_t)carry > capacity) ? 1u : 0u);     // bit 1: depth range (set by the depth sort)
         status->num_visible = vtot;
         status->reserved = 0u;
     }
@@ -125,21 +128,29 @@ __global__ void __launch_bounds__(PUB_THREADS) k_scan_publish(uint32_t* __restri
 // Gaussians that own them (the nearest Gaussians cover thousands of tiles each and all sit at the front of the order, so
 // a Gaussian-block-per-workgroup split would leave a long tail).  Inside a Gaussian block the owner of a slot is found
 // by binary search over the block's exclusive offsets in LDS; consecutive lanes write consecutive pairs.
+// An output block of 2048 slots IS a block of the first tile-sort pass, so the digit histogram of that pass is built here, from
+// the tile ids while they are in registers (hist0: [bin][block], bin-major over the capacity block count): the pass's own
+// histogram launch (a second read of all D tile ids) is gone.
 __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const uint32_t* __restrict__ rect_s,
                                                          const uint32_t* __restrict__ cnt_s,
                                                          const uint32_t* __restrict__ perm,
                                                          const uint32_t* __restrict__ block_sums_inc,
                                                          const uint32_t* __restrict__ slot_start,
                                                          const EmdStatus* __restrict__ status,
-                                                         uint32_t* __restrict__ tkeys, uint32_t* __restrict__ vals) {
+                                                         uint32_t* __restrict__ tkeys, uint32_t* __restrict__ vals,
+                                                         uint32_t* __restrict__ hist0, uint32_t mask0, uint32_t nblocks_cap) {
     __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_excl[EMD_BLOCK];     // exclusive offsets inside the block
     __shared__ uint32_t s_rect[EMD_BLOCK];     // x0 | y0 << 10 | width << 20   (grid dims < 1024 tiles = 16K px)
     __shared__ uint32_t s_id[EMD_BLOCK];
-    if (status->overflow) return;
-    const uint32_t D = status->num_rendered;
+    __shared__ uint32_t s_h0[EMD_BLOCK];       // digit histogram of tile pass 0 (at most 8 bits per pass)
+    s_h0[threadIdx.x] = 0;
+    const uint32_t D = status->overflow ? 0u : status->num_rendered;
     const uint64_t S0l = (uint64_t)blockIdx.x * DUP_SLOTS;
-    if (S0l >= D) return;
+    if (S0l >= D) {                            // (uniform per block) nothing to write: the pass still reads this block's histogram column
+        if (hist0) hist0[(size_t)threadIdx.x * nblocks_cap + blockIdx.x] = 0u;
+        return;
+    }
     const uint32_t S0 = (uint32_t)S0l, S1 = (uint32_t)min((uint64_t)D, S0l + DUP_SLOTS);
     const uint32_t nb = ((uint32_t)N + EMD_BLOCK - 1) / EMD_BLOCK;
     for (uint32_t gb = slot_start[blockIdx.x]; gb < nb; gb++) {
@@ -170,34 +181,56 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
             const uint32_t r = s_rect[lo];
             const uint32_t w = r >> 20, x0 = r & 1023u, y0 = (r >> 10) & 1023u;
             const uint32_t ty = y0 + local / w, tx = x0 + local % w;
-            tkeys[eg] = ty * (uint32_t)gx + tx;
+            const uint32_t tile = ty * (uint32_t)gx + tx;
+            tkeys[eg] = tile;
             vals[eg] = s_id[lo];
+            atomicAdd(&s_h0[tile & mask0], 1u);
         }
         __syncthreads();   // LDS reused by the next block of Gaussians
     }
+    if (hist0) hist0[(size_t)threadIdx.x * nblocks_cap + blockIdx.x] = s_h0[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K4 radix pass on 32-bit keys with 32-bit values: (a) block histograms, (b) scan over [bin][block], (c) stable scatter
+// K4 radix pass on 32-bit keys with 32-bit values: (a) block histograms, (b) scan over [bin][block], (c) stable scatter.
+// BITS = 8 (256 digits: the tile passes, the wide depth sort) or 9 (512 digits: the usual three-pass depth sort).
+// `offset` is subtracted from every key before the digit is taken (depth bits relative to the near plane's).
+// FIRST (first pass of the depth sort): the value of element idx is idx itself, culled Gaussians (key 0xFFFFFFFF) are skipped --
+// they take part in neither the counts nor the scatter, so this stable pass also compacts the N Gaussians to the V visible
+// ones in index order, and block 0 publishes V for the later passes; keys that do not fit `range_bits` raise bit 1 of the
+// overflow word (the host then switches that camera to the wide sort, like a capacity overflow).
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(EMD_BLOCK) k_radix_hist(const uint32_t* __restrict__ keys, SortN cnt, int shift,
-                                                          uint32_t mask, uint32_t nblocks_cap, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t s_h[EMD_RADIX_BINS];
+template <int BITS, bool FIRST>
+__global__ void __launch_bounds__(EMD_BLOCK) k_radix_hist(const uint32_t* __restrict__ keys, SortN cnt, int shift, uint32_t mask, uint32_t offset,
+                                                          uint32_t nblocks_cap, uint32_t* __restrict__ hist, int range_bits,
+                                                          uint32_t* __restrict__ overflow_word) {
+    constexpr int BINS = 1 << BITS, PER = BINS / EMD_BLOCK;
+    __shared__ uint32_t s_h[BINS];
     const uint32_t D = sort_n(cnt);
     const uint32_t nblocks = (D + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
-    s_h[threadIdx.x] = 0;  // EMD_BLOCK == EMD_RADIX_BINS
+#pragma unroll
+    for (int k = 0; k < PER; k++) s_h[threadIdx.x + k * EMD_BLOCK] = 0;
     __syncthreads();
     if (blockIdx.x < nblocks) {
         const size_t base = (size_t)blockIdx.x * EMD_SORT_TILE;
+        bool wide = false;
 #pragma unroll
         for (int k = 0; k < EMD_SORT_ITEMS; k++) {
             size_t idx = base + (size_t)k * EMD_BLOCK + threadIdx.x;
-            if (idx < D) atomicAdd(&s_h[(keys[idx] >> shift) & mask], 1u);
+            if (idx < D) {
+                const uint32_t key = keys[idx];
+                if (FIRST && key == 0xFFFFFFFFu) continue;
+                const uint32_t rel = key - offset;
+                if (FIRST && range_bits < 32 && (rel >> range_bits)) wide = true;
+                atomicAdd(&s_h[(rel >> shift) & mask], 1u);
+            }
         }
+        if (FIRST && wide) atomicOr(overflow_word, 2u);
     }
     __syncthreads();
     // bin-major layout over the *capacity* block count so the scan length is launch-time constant
-    hist[(size_t)threadIdx.x * nblocks_cap + blockIdx.x] = s_h[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < PER; k++) hist[(size_t)(threadIdx.x + k * EMD_BLOCK) * nblocks_cap + blockIdx.x] = s_h[threadIdx.x + k * EMD_BLOCK];
 }
 
 // One workgroup per digit: inclusive scan of that digit's per-block counts (row `bin` of the bin-major table) in place.
@@ -220,17 +253,18 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scan_bins(uint32_t* __restr
     }
 }
 
-// vals_in == nullptr: the value of element idx is idx itself (first pass of the Gaussian depth sort)
+template <int BITS, bool FIRST>
 __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                              const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out,
                                                              uint32_t* __restrict__ vals_out, SortN cnt, int shift,
-                                                             uint32_t mask, uint32_t nblocks_cap,
-                                                             const uint32_t* __restrict__ hist_inc) {
+                                                             uint32_t mask, uint32_t offset, uint32_t nblocks_cap,
+                                                             const uint32_t* __restrict__ hist_inc, uint32_t* __restrict__ count_out) {
     // wave w of the block owns the contiguous slice [w*512, (w+1)*512) of the block's 2048 keys and walks it in
     // 8 rounds of 64 consecutive keys: order inside the block = (wave, round, lane) = memory order => stable.
-    __shared__ uint32_t s_cnt[4][EMD_RADIX_BINS];   // running per-wave digit counts, then per-wave bases
-    __shared__ uint32_t s_gbase[EMD_RADIX_BINS];
+    constexpr int BINS = 1 << BITS, PER = BINS / EMD_BLOCK;
+    __shared__ uint32_t s_cnt[4][BINS];   // running per-wave digit counts, then per-wave bases
+    __shared__ uint32_t s_gbase[BINS];
     __shared__ uint32_t s_keys[EMD_SORT_TILE];
     __shared__ uint32_t s_vals[EMD_SORT_TILE];
     __shared__ uint32_t s_scan[4];
@@ -239,7 +273,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __r
     if (blockIdx.x >= nblocks) return;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 4; k++) s_cnt[k][threadIdx.x] = 0;
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < PER; j++) s_cnt[k][threadIdx.x + j * EMD_BLOCK] = 0;
     __syncthreads();
     const size_t wbase = (size_t)blockIdx.x * EMD_SORT_TILE + (size_t)wave * (EMD_SORT_TILE / 4);
     uint32_t key[EMD_SORT_ITEMS];
@@ -248,19 +284,20 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __r
 #pragma unroll
     for (int k = 0; k < EMD_SORT_ITEMS; k++) {
         const size_t idx = wbase + (size_t)k * 64 + lane;
-        const bool valid = idx < D;
+        bool valid = idx < D;
         key[k] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        const uint32_t digit = (key[k] >> shift) & mask;
+        if (FIRST) valid = valid && key[k] != 0xFFFFFFFFu;          // culled Gaussian: dropped here
+        const uint32_t digit = ((key[k] - offset) >> shift) & mask;
         // lanes with the same digit (invalid lanes form their own class and are ignored)
         unsigned long long same = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < EMD_RADIX_BITS; b++) {
+        for (int b = 0; b < BITS; b++) {
             const unsigned long long bal = __ballot((digit >> b) & 1u);
             same &= ((digit >> b) & 1u) ? bal : ~bal;
         }
         const uint32_t before = (uint32_t)__popcll(same & lt_mask);
         const uint32_t prev = s_cnt[wave][digit];          // count from earlier rounds of this wave
-        rank[k] = prev + before;
+        rank[k] = valid ? prev + before : 0xFFFFFFFFu;
         // the highest lane of each class publishes the new count (wave-private row: no atomics, no race)
         const bool leader = valid && ((same >> lane) >> 1) == 0ull;
         __builtin_amdgcn_wave_barrier();
@@ -270,44 +307,60 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __r
     __syncthreads();
     // per-wave bases in the block's digit-sorted order + the block's global base for every digit
     {
-        const uint32_t d = threadIdx.x;
-        const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
-        // keys of digit d in earlier blocks (row-wise inclusive scan) + all keys of smaller digits (row totals)
-        const uint32_t* row = hist_inc + (size_t)d * nblocks_cap;
-        const uint32_t before = blockIdx.x ? row[blockIdx.x - 1] : 0u;
-        const uint32_t dtot = row[nblocks_cap - 1];
+        uint32_t c[PER][4], csum[PER], dtot[PER], before[PER];
+        uint32_t csum_t = 0, dtot_t = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const uint32_t d = threadIdx.x * PER + j;       // a thread owns PER consecutive digits
+#pragma unroll
+            for (int w = 0; w < 4; w++) c[j][w] = s_cnt[w][d];
+            csum[j] = c[j][0] + c[j][1] + c[j][2] + c[j][3];
+            // keys of digit d in earlier blocks (row-wise inclusive scan) + all keys of smaller digits (row totals)
+            const uint32_t* row = hist_inc + (size_t)d * nblocks_cap;
+            before[j] = blockIdx.x ? row[blockIdx.x - 1] : 0u;
+            dtot[j] = row[nblocks_cap - 1];
+            csum_t += csum[j]; dtot_t += dtot[j];
+        }
         uint32_t total;
-        const uint32_t g = (block_scan_add_u32(dtot, s_scan, &total) - dtot) + before;
-        const uint32_t c = c0 + c1 + c2 + c3;
-        const uint32_t bpre = block_scan_add_u32(c, s_scan, &total) - c;
-        s_gbase[d] = g - bpre;                   // global slot = s_gbase[digit] + position in block order
-        s_cnt[0][d] = bpre;
-        s_cnt[1][d] = bpre + c0;
-        s_cnt[2][d] = bpre + c0 + c1;
-        s_cnt[3][d] = bpre + c0 + c1 + c2;
+        uint32_t g = block_scan_add_u32(dtot_t, s_scan, &total) - dtot_t;
+        if (FIRST && count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = total;      // V: elements of the later passes
+        uint32_t bpre = block_scan_add_u32(csum_t, s_scan, &total) - csum_t;
+        __syncthreads();                                    // every thread has read its s_cnt columns
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const uint32_t d = threadIdx.x * PER + j;
+            s_gbase[d] = g + before[j] - bpre;              // global slot = s_gbase[digit] + position in block order
+            s_cnt[0][d] = bpre;
+            s_cnt[1][d] = bpre + c[j][0];
+            s_cnt[2][d] = bpre + c[j][0] + c[j][1];
+            s_cnt[3][d] = bpre + c[j][0] + c[j][1] + c[j][2];
+            g += dtot[j]; bpre += csum[j];
+        }
     }
     __syncthreads();
     // Reorder inside LDS first, then write: consecutive lanes hold consecutive output slots, so every digit run
     // leaves the block as one contiguous segment.  Scattering straight from registers wrote 4-byte fragments
     // of 256 different runs: 2.2x write amplification at the memory side (profiles/r01_pmc_hbm_traffic.csv).
+    uint32_t nvalid_w = 0;
 #pragma unroll
     for (int k = 0; k < EMD_SORT_ITEMS; k++) {
         const size_t idx = wbase + (size_t)k * 64 + lane;
-        if (idx < D) {
-            const uint32_t digit = (key[k] >> shift) & mask;
+        if (rank[k] != 0xFFFFFFFFu) {
+            const uint32_t digit = ((key[k] - offset) >> shift) & mask;
             const uint32_t pos = s_cnt[wave][digit] + rank[k];
             s_keys[pos] = key[k];
-            s_vals[pos] = vals_in ? vals_in[idx] : (uint32_t)idx;
+            s_vals[pos] = FIRST ? (uint32_t)idx : vals_in[idx];
+            nvalid_w++;
         }
     }
-    __syncthreads();
-    const uint32_t nvalid = min((uint32_t)EMD_SORT_TILE, D - blockIdx.x * (uint32_t)EMD_SORT_TILE);
+    uint32_t nvalid;
+    block_scan_add_u32(nvalid_w, s_scan, &nvalid);         // (ends with a barrier: the reordered tile is complete)
 #pragma unroll
     for (int k = 0; k < EMD_SORT_ITEMS; k++) {
         const uint32_t pos = threadIdx.x + (uint32_t)k * EMD_BLOCK;
         if (pos < nvalid) {
             const uint32_t kk = s_keys[pos];
-            const size_t dst = (size_t)s_gbase[(kk >> shift) & mask] + pos;
+            const size_t dst = (size_t)s_gbase[((kk - offset) >> shift) & mask] + pos;
             keys_out[dst] = kk;
             vals_out[dst] = s_vals[pos];
         }
@@ -376,50 +429,68 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_export_keys(size_t D, const uint3
     if (i < D) keys[i] = ((uint64_t)tkeys[i] << 32) | depth_key[vals[i]];
 }
 
-// one stable LSD pass over `n_cap` (launch bound) / sort_n(cnt) (actual) pairs
+// one stable LSD pass over `n_cap` (launch bound) / sort_n(cnt) (actual) pairs; `skip_hist`: the histogram was built by the producer
+template <int BITS, bool FIRST>
 int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, SortN cnt, size_t n_cap, int shift,
-               int bits, uint32_t* hist, hipStream_t st) {
+               int bits, uint32_t offset, uint32_t* hist, bool skip_hist, int range_bits, uint32_t* overflow_word, uint32_t* count_out,
+               hipStream_t st) {
     const uint32_t nsb = (uint32_t)((n_cap + EMD_SORT_TILE - 1) / EMD_SORT_TILE);
     const uint32_t mask = (1u << bits) - 1u;
-    hipLaunchKernelGGL(k_radix_hist, dim3(nsb), dim3(EMD_BLOCK), 0, st, kin, cnt, shift, mask, nsb, hist);
+    if (!skip_hist) {
+        hipLaunchKernelGGL((k_radix_hist<BITS, FIRST>), dim3(nsb), dim3(EMD_BLOCK), 0, st, kin, cnt, shift, mask, offset, nsb, hist, range_bits,
+                           overflow_word);
+        EMD_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_radix_scan_bins, dim3(1u << BITS), dim3(EMD_BLOCK), 0, st, hist, nsb);
     EMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_radix_scan_bins, dim3(1u << bits), dim3(EMD_BLOCK), 0, st, hist, nsb);
-    EMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_radix_scatter, dim3(nsb), dim3(EMD_BLOCK), 0, st, kin, vin, kout, vout, cnt, shift, mask, nsb, hist);
+    hipLaunchKernelGGL((k_radix_scatter<BITS, FIRST>), dim3(nsb), dim3(EMD_BLOCK), 0, st, kin, vin, kout, vout, cnt, shift, mask, offset, nsb, hist,
+                       count_out);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }
 
 }  // namespace
 
-int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,
+int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,
                        hipStream_t st) {
     const int gx = (s.image_width + EMD_TILE_X - 1) / EMD_TILE_X, gy = (s.image_height + EMD_TILE_Y - 1) / EMD_TILE_Y;
     const int T = gx * gy;
     if (gx >= 1024 || gy >= 1024) { emd_set_error("image too large: %d x %d tiles (max 1023)", gx, gy); return EMD_ERR_INVALID; }
     const int nb = (N + EMD_BLOCK - 1) / EMD_BLOCK;
     int rc;
-    // 1. Gaussians in depth order: depth_key -> gkeys[0] -> gkeys[1] -> gkeys[0] -> gkeys[1]
+    // 1. visible Gaussians in depth order.  The status word is cleared first: the depth passes may raise its overflow bit 1.
     emd_prof_switch(PROF_PREPROCESS, PROF_SORT, st);
+    EMD_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(EmdStatus), st));
+    EMD_HIP_CHECK(hipMemsetAsync(g.sort_count, 0, 16, st));
+    const bool wide = (flags & EMD_FLAG_WIDE_DEPTH_SORT) != 0;
+    const int depth_passes = wide ? EMD_DEPTH_PASSES_WIDE : EMD_DEPTH_PASSES_NARROW;
     if (N > 0) {
-        const SortN cn = {nullptr, (uint32_t)N};
-        const uint32_t* kin = g.depth_key;
-        const uint32_t* vin = nullptr;
-        for (int p = 0; p < EMD_DEPTH_PASSES; p++) {
-            rc = radix_pass(kin, vin, g.gkeys[p & 1], g.gvals[p & 1], cn, (size_t)N, p * EMD_RADIX_BITS, EMD_RADIX_BITS, g.ghist, st);
-            if (rc) return rc;
-            kin = g.gkeys[p & 1]; vin = g.gvals[p & 1];
+        const SortN c0 = {nullptr, nullptr, (uint32_t)N}, cv = {g.sort_count, nullptr, 0u};
+        uint32_t near_bits = 0;
+        if (!wide) { const float np = s.near_plane > 0.f ? s.near_plane : 0.f; memcpy(&near_bits, &np, 4); }
+        uint32_t* ovf = &status->overflow;
+        if (wide) {
+            rc = radix_pass<8, true>(g.depth_key, nullptr, g.gkeys[0], g.gvals[0], c0, (size_t)N, 0, 8, 0u, g.ghist, false, 32, ovf, g.sort_count, st);
+            for (int p = 1; p < depth_passes && !rc; p++)
+                rc = radix_pass<8, false>(g.gkeys[(p - 1) & 1], g.gvals[(p - 1) & 1], g.gkeys[p & 1], g.gvals[p & 1], cv, (size_t)N, 8 * p, 8, 0u,
+                                          g.ghist, false, 32, ovf, nullptr, st);
+        } else {
+            const int B = EMD_DEPTH_BITS_NARROW;
+            rc = radix_pass<EMD_DEPTH_BITS_NARROW, true>(g.depth_key, nullptr, g.gkeys[0], g.gvals[0], c0, (size_t)N, 0, B, near_bits, g.ghist, false,
+                                                         EMD_DEPTH_RANGE_NARROW, ovf, g.sort_count, st);
+            for (int p = 1; p < depth_passes && !rc; p++)
+                rc = radix_pass<EMD_DEPTH_BITS_NARROW, false>(g.gkeys[(p - 1) & 1], g.gvals[(p - 1) & 1], g.gkeys[p & 1], g.gvals[p & 1], cv, (size_t)N,
+                                                              B * p, B, near_bits, g.ghist, false, 32, ovf, nullptr, st);
         }
+        if (rc) return rc;
     }
-    const uint32_t* depth_sorted = g.gkeys[(EMD_DEPTH_PASSES - 1) & 1];
-    const uint32_t* perm = g.gvals[(EMD_DEPTH_PASSES - 1) & 1];
+    const uint32_t* perm = g.gvals[(depth_passes - 1) & 1];
     // 2. tile counts in that order, offsets, duplicate
     emd_prof_switch(PROF_SORT, PROF_DUPLICATE, st);
     if (N == 0 || capacity <= 0) {
-        EMD_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(EmdStatus), st));
         EMD_HIP_CHECK(hipMemsetAsync(b.ranges, 0, (size_t)T * 8, st));
         if (N > 0) {   // D and V are still reported (capacity 0 is how callers size the workspace)
-            hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, depth_sorted, perm, g.binrec, g.rect_s, g.cnt_s,
+            hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, g.sort_count, perm, g.binrec, g.rect_s, g.cnt_s,
                                g.block_sums, g.block_vis, b.ranges, 0u);
             EMD_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(PUB_THREADS), 0, st, g.block_sums, g.block_vis, (uint32_t)nb,
@@ -432,22 +503,24 @@ int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs
         return EMD_OK;
     }
     const uint32_t nslot = (uint32_t)(((size_t)capacity + DUP_SLOTS - 1) / DUP_SLOTS);
-    hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, depth_sorted, perm, g.binrec, g.rect_s, g.cnt_s,
+    hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, g.sort_count, perm, g.binrec, g.rect_s, g.cnt_s,
                        g.block_sums, g.block_vis, b.ranges, (uint32_t)(2 * T));
     EMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(PUB_THREADS), 0, st, g.block_sums, g.block_vis, (uint32_t)nb, (uint64_t)capacity,
                        status, b.slot_start, nslot);
     EMD_LAUNCH_CHECK();
+    const int passes = emd_tile_passes(T), bits = emd_tile_pass_bits(T);
+    // (the duplicate kernel also builds the digit histogram of the first tile pass: its 2048-slot output blocks are that pass's blocks)
     hipLaunchKernelGGL(k_duplicate, dim3(nslot), dim3(EMD_BLOCK), 0, st, N, gx, g.rect_s, g.cnt_s, perm, g.block_sums, b.slot_start,
-                       status, b.tkeys[0], b.vals[0]);
+                       status, b.tkeys[0], b.vals[0], passes > 0 ? b.hist : nullptr, passes > 0 ? (1u << bits) - 1u : 0u, nslot);
     EMD_LAUNCH_CHECK();
     // 3. stable partition by tile id
     emd_prof_switch(PROF_DUPLICATE, PROF_SORT, st);
-    const SortN cd = {status, 0u};
-    const int passes = emd_tile_passes(T), bits = emd_tile_pass_bits(T);
+    const SortN cd = {&status->num_rendered, &status->overflow, 0u};
     int cur = 0;
     for (int p = 0; p < passes; p++) {
-        rc = radix_pass(b.tkeys[cur], b.vals[cur], b.tkeys[cur ^ 1], b.vals[cur ^ 1], cd, (size_t)capacity, p * bits, bits, b.hist, st);
+        rc = radix_pass<8, false>(b.tkeys[cur], b.vals[cur], b.tkeys[cur ^ 1], b.vals[cur ^ 1], cd, (size_t)capacity, p * bits, bits, 0u, b.hist,
+                                  p == 0, 32, nullptr, nullptr, st);
         if (rc) return rc;
         cur ^= 1;
     }

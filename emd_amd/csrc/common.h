@@ -33,6 +33,7 @@ struct GeomWs {
     uint32_t* rect_s;        // [N] tile rectangle of the Gaussians in depth order
     uint32_t* cnt_s;         // [N] tiles touched of the Gaussians in depth order
     uint32_t* ghist;         // radix histograms of the depth sort [bins][ceil(N / sort tile)]
+    uint32_t* sort_count;    // [1] visible Gaussians V: published by the first depth pass (which compacts), read by the later ones
     uint32_t* block_sums;    // [ceil(N/256)] tile counts per block of depth-ordered Gaussians, inclusive-scanned in place
     uint32_t* block_vis;     // [ceil(N/256)] visible Gaussians per block
     size_t bytes;
@@ -68,9 +69,17 @@ static inline int emd_tile_bits(int num_tiles) {
     while ((1 << b) < num_tiles) b++;
     return b;
 }
-// Upstream key = tile_id << 32 | depth bits.  Sorted here as 4 radix passes over the depth bits of the N Gaussians,
+// Upstream key = tile_id << 32 | depth bits.  Sorted here as radix passes over the depth bits of the visible Gaussians,
 // then ceil(tile bits / 8) passes of equal width over the tile ids of the duplicates (binning.hip).
-#define EMD_DEPTH_PASSES (32 / EMD_RADIX_BITS)
+// Depth bits: a visible Gaussian lies beyond the near plane, and positive floats order like their bit patterns, so the sort runs on
+// (bits - bits(near plane)), which fits 27 bits for depths up to 65 536 x the near plane (13 km at 0.2 m): three passes of
+// nine bits.  A key outside that range raises bit 1 of EmdStatus.overflow and the caller repeats the call with
+// EMD_FLAG_WIDE_DEPTH_SORT: four passes of eight bits over all 32.
+#define EMD_DEPTH_BITS_NARROW 9
+#define EMD_DEPTH_PASSES_NARROW 3
+#define EMD_DEPTH_RANGE_NARROW (EMD_DEPTH_BITS_NARROW * EMD_DEPTH_PASSES_NARROW)
+#define EMD_DEPTH_PASSES_WIDE (32 / EMD_RADIX_BITS)
+#define EMD_DEPTH_BINS_MAX (1 << EMD_DEPTH_BITS_NARROW)
 static inline int emd_tile_passes(int num_tiles) { return (emd_tile_bits(num_tiles) + EMD_RADIX_BITS - 1) / EMD_RADIX_BITS; }
 static inline int emd_tile_pass_bits(int num_tiles) {
     const int p = emd_tile_passes(num_tiles);
@@ -90,7 +99,8 @@ static inline void emd_carve_geom(void* base, int N, GeomWs* w) {
     w->rect_s = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256);
     w->cnt_s = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256);
     size_t nsb = (n + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
-    w->ghist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_RADIX_BINS * 4, 256);
+    w->ghist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_DEPTH_BINS_MAX * 4, 256);
+    w->sort_count = (uint32_t*)(p + off); off = emd_align_up(off + 16, 256);
     size_t nb = (n + EMD_BLOCK - 1) / EMD_BLOCK;
     w->block_sums = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 1) * 4, 256);
     w->block_vis = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 1) * 4, 256);
@@ -150,7 +160,7 @@ struct PreArgs {
     const float* sdev;       // device copy of bg / viewmatrix / projmatrix / campos (EmdFwdArgs.settings_dev) or null
 };
 int emd_launch_preprocess(const PreArgs& a, hipStream_t st);                 // preprocess.hip
-int emd_launch_binning(const EmdSettings& s, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,
+int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,
                        hipStream_t st);                                       // binning.hip
 int emd_launch_export_keys(int64_t D, const GeomWs& g, const BinWs& b, uint64_t* keys, hipStream_t st);  // binning.hip
 int emd_launch_render_forward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,

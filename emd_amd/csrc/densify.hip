@@ -1,0 +1,204 @@
+// densify.hip -- adaptive density control on the SoA parameter + Adam-state buffers, on the device.
+//
+//   densify  = densify_and_clone + densify_and_split        S3Gaussian/scene/gaussian_model.py:515-603,696-701
+//   prune    = prune / prune_points                          S3Gaussian/scene/gaussian_model.py:441-479,683-695
+//   (OmniRe's per-class version of the same logic: models/gaussians/vanilla.py:206-376)
+//
+// The reference performs each of them with boolean-mask indexing (a device-to-host sync per mask), `torch.cat` / `repeat` on
+// every parameter and both Adam moments (~60 launches and as many temporaries), and draws the split samples from the global
+// CUDA generator (`torch.normal`, gaussian_model.py:543) -- a different stream on every rank.  Here one event is
+//   k_densify_decide   one pass over the N Gaussians: per point a code (keep / clone / split / drop) from the accumulated
+//                      statistics, the activated scale and opacity; three 0/1 columns for the caller's prefix sum
+//   [prefix sum of the three columns: the caller; ONE host read of the new point count]
+//   k_densify_index    for every OUTPUT row its source row and kind, in the reference's order:
+//                      survivors (in order), clones (in order), split samples replica 0 (in order), replica 1 (in order)
+//   k_densify_gather   one launch for ALL tensors (7 parameters + 14 Adam moments + statistics): output row <- source row;
+//                      the moments and statistics of new rows are zero; split samples get xyz = R(q) (std * n) + xyz with
+//                      n ~ N(0, 1) from Philox4x32-10 keyed by (seed, SOURCE Gaussian index, replica) -- identical on every
+//                      rank without communication -- and scaling = log(exp(s) / (0.8 * 2)).
+// HBM-bound: every surviving byte is read and written once.
+#include <string.h>
+
+#include "common.h"
+#include "device_utils.h"
+
+namespace {
+
+enum { CODE_KEEP = 1, CODE_CLONE = 2, CODE_SPLIT = 4 };
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_densify_decide(EmdDensifyArgs a, int32_t* __restrict__ code, int32_t* __restrict__ cols /*[3][N]*/) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i >= a.num_points) return;
+    const float s0 = expf(a.scaling[3 * i]), s1 = expf(a.scaling[3 * i + 1]), s2 = expf(a.scaling[3 * i + 2]);
+    const float smax = fmaxf(s0, fmaxf(s1, s2));
+    int c = CODE_KEEP;
+    if (a.mode == EMD_DENSIFY_MODE_DENSIFY) {
+        // grads = xyz_gradient_accum / denom, NaN -> 0 (gaussian_model.py:697-698); clone: small Gaussians, split: large ones
+        float g = a.grad_accum[i] / a.denom[i];
+        if (g != g) g = 0.f;
+        const bool hot = g >= a.grad_threshold;                       // (torch.norm of the [N,1] column = |g|; g >= 0)
+        const bool small_ = smax <= a.percent_dense * a.scene_extent;
+        if (hot && small_) c |= CODE_CLONE;
+        if (hot && !small_) c = CODE_SPLIT;                           // the original is removed after its two samples are appended
+    } else {
+        // prune (gaussian_model.py:683-692): opacity below the threshold, or -- once max_screen_size is set -- too large on screen or in
+        // the world
+        const float op = 1.f / (1.f + expf(-a.opacity[i]));
+        bool drop = op < a.min_opacity;
+        if (a.max_screen_size > 0.f) drop = drop || a.max_radii2D[i] > a.max_screen_size || smax > 0.1f * a.scene_extent;
+        if (a.extra_drop && a.extra_drop[i]) drop = true;
+        if (drop) c = 0;
+    }
+    code[i] = c;
+    const size_t N = (size_t)a.num_points;
+    cols[i] = (c & CODE_KEEP) ? 1 : 0;
+    cols[N + i] = (c & CODE_CLONE) ? 1 : 0;
+    cols[2 * N + i] = (c & CODE_SPLIT) ? 1 : 0;
+}
+
+// inc: inclusive prefix sums of the three columns; totals = last entries
+__global__ void __launch_bounds__(EMD_BLOCK) k_densify_index(int n, const int32_t* __restrict__ code, const int32_t* __restrict__ inc,
+                                                             int32_t* __restrict__ src, int32_t* __restrict__ kind) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = (size_t)n;
+    const int n_keep = inc[N - 1], n_clone = inc[2 * N - 1], n_split = inc[3 * N - 1];
+    const int c = code[i];
+    if (c & CODE_KEEP) { const int j = inc[i] - 1; src[j] = i; kind[j] = 0; }
+    if (c & CODE_CLONE) { const int j = n_keep + inc[N + i] - 1; src[j] = i; kind[j] = 1; }
+    if (c & CODE_SPLIT) {
+        const int r = inc[2 * N + i] - 1;
+        const int j0 = n_keep + n_clone + r, j1 = j0 + n_split;
+        src[j0] = i; kind[j0] = 2;
+        src[j1] = i; kind[j1] = 3;
+    }
+}
+
+// Philox4x32-10 (Salmon et al., SC'11): counter = (gaussian index, replica, 0, 0), key = (seed lo, seed hi)
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+// three standard normals of (seed, index, replica): Box-Muller on uniforms in (0, 1]
+__device__ __forceinline__ void normal3(uint64_t seed, uint32_t index, uint32_t rep, float n[3]) {
+    uint32_t r[4];
+    philox4x32_10(index, rep, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float u0 = ((float)(r[0] >> 8) + 1.f) * (1.f / 16777216.f), u1 = (float)(r[1] >> 8) * (1.f / 16777216.f);
+    const float u2 = ((float)(r[2] >> 8) + 1.f) * (1.f / 16777216.f), u3 = (float)(r[3] >> 8) * (1.f / 16777216.f);
+    const float ra = sqrtf(-2.f * logf(u0)), rb = sqrtf(-2.f * logf(u2));
+    n[0] = ra * cosf(6.28318530717958648f * u1);
+    n[1] = ra * sinf(6.28318530717958648f * u1);
+    n[2] = rb * cosf(6.28318530717958648f * u3);
+}
+
+// One launch for all tensors: blockIdx.y = tensor, grid-stride over its output elements.
+__global__ void __launch_bounds__(EMD_BLOCK) k_densify_gather(EmdDensifyGather g) {
+    const EmdDensifyTensor t = g.tensors[blockIdx.y];
+    const size_t total = (size_t)g.num_out * t.width;
+    for (size_t idx = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * EMD_BLOCK) {
+        const int j = (int)(idx / t.width), c = (int)(idx % t.width);
+        const int i = g.src[j], kd = g.kind[j];
+        float v;
+        if (t.role == EMD_DENSIFY_ROLE_STATE) v = kd == 0 ? t.src[(size_t)i * t.width + c] : 0.f;             // Adam moments of new rows: zero
+        else if (t.role == EMD_DENSIFY_ROLE_ZERO) v = (g.mode == EMD_DENSIFY_MODE_DENSIFY) ? 0.f : t.src[(size_t)i * t.width + c];   // statistics: reset by a densification
+        else {
+            v = t.src[(size_t)i * t.width + c];
+            if (kd >= 2) {
+                if (t.role == EMD_DENSIFY_ROLE_SCALING) v = logf(expf(v) / (0.8f * 2.f));
+                else if (t.role == EMD_DENSIFY_ROLE_XYZ) {
+                    // new_xyz = R(q) (std * n) + xyz, q normalised as build_rotation does (general_utils.py:245-266)
+                    float n[3];
+                    if (g.samples) { const float* s = g.samples + ((size_t)(kd - 2) * g.num_split + g.split_rank[j]) * 3; n[0] = s[0]; n[1] = s[1]; n[2] = s[2]; }
+                    else normal3(g.seed, (uint32_t)i, (uint32_t)(kd - 2), n);
+                    const float* sc = g.scaling + 3 * (size_t)i;
+                    const float* qq = g.rotation + 4 * (size_t)i;
+                    const float e0 = expf(sc[0]) * n[0], e1 = expf(sc[1]) * n[1], e2 = expf(sc[2]) * n[2];
+                    const float qn = sqrtf(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+                    const float r = qq[0] / qn, x = qq[1] / qn, y = qq[2] / qn, z = qq[3] / qn;
+                    float R0, R1, R2;
+                    if (c == 0) { R0 = 1.f - 2.f * (y * y + z * z); R1 = 2.f * (x * y - r * z); R2 = 2.f * (x * z + r * y); }
+                    else if (c == 1) { R0 = 2.f * (x * y + r * z); R1 = 1.f - 2.f * (x * x + z * z); R2 = 2.f * (y * z - r * x); }
+                    else { R0 = 2.f * (x * z - r * y); R1 = 2.f * (y * z + r * x); R2 = 1.f - 2.f * (x * x + y * y); }
+                    v = ((R0 * e0 + R1 * e1) + R2 * e2) + v;
+                }
+            }
+        }
+        t.dst[idx] = v;
+    }
+}
+
+// rank of every split output row among the split rows of its replica (needed only when the samples are supplied by the caller)
+__global__ void __launch_bounds__(EMD_BLOCK) k_densify_split_rank(int num_out, int n_keep, int n_clone, int n_split, int32_t* __restrict__ rank) {
+    const int j = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (j >= num_out) return;
+    const int base = n_keep + n_clone;
+    rank[j] = j < base ? 0 : (j - base) % (n_split > 0 ? n_split : 1);
+}
+
+}  // namespace
+
+extern "C" int emd_densify_decide(const EmdDensifyArgs* a, int32_t* code, int32_t* columns, void* hip_stream) {
+    if (!a || !code || !columns) { emd_set_error("densify_decide: null argument"); return EMD_ERR_INVALID; }
+    if (a->num_points < 0 || (a->mode != EMD_DENSIFY_MODE_DENSIFY && a->mode != EMD_DENSIFY_MODE_PRUNE)) { emd_set_error("densify_decide: bad mode / size"); return EMD_ERR_INVALID; }
+    if (a->num_points == 0) return EMD_OK;
+    if (!a->scaling || (a->mode == EMD_DENSIFY_MODE_DENSIFY && (!a->grad_accum || !a->denom)) ||
+        (a->mode == EMD_DENSIFY_MODE_PRUNE && (!a->opacity || (a->max_screen_size > 0.f && !a->max_radii2D)))) {
+        emd_set_error("densify_decide: null input for mode %d", a->mode); return EMD_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(k_densify_decide, dim3((a->num_points + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, *a, code, columns);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+extern "C" int emd_densify_index(int32_t num_points, int32_t num_out, const int32_t* code, const int32_t* inclusive_scans, int32_t* src,
+                                 int32_t* kind, void* hip_stream) {
+    if (num_points < 0 || num_out < 0 || (num_points > 0 && (!code || !inclusive_scans)) || (num_out > 0 && (!src || !kind))) {
+        emd_set_error("densify_index: bad argument"); return EMD_ERR_INVALID;
+    }
+    if (num_points == 0) return EMD_OK;
+    hipLaunchKernelGGL(k_densify_index, dim3((num_points + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, num_points, code,
+                       inclusive_scans, src, kind);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+extern "C" int emd_densify_gather(const EmdDensifyGather* g, void* hip_stream) {
+    if (!g) { emd_set_error("densify_gather: null args"); return EMD_ERR_INVALID; }
+    if (g->num_tensors < 0 || g->num_tensors > EMD_DENSIFY_MAX_TENSORS || g->num_out < 0) { emd_set_error("densify_gather: bad sizes"); return EMD_ERR_INVALID; }
+    if (g->num_out == 0 || g->num_tensors == 0) return EMD_OK;
+    if (!g->src || !g->kind) { emd_set_error("densify_gather: null index"); return EMD_ERR_INVALID; }
+    bool has_xyz = false;
+    size_t widest = 1;
+    for (int k = 0; k < g->num_tensors; k++) {
+        const EmdDensifyTensor& t = g->tensors[k];
+        if (!t.src || !t.dst || t.width <= 0) { emd_set_error("densify_gather: tensor %d: null pointer / bad width", k); return EMD_ERR_INVALID; }
+        if (t.role == EMD_DENSIFY_ROLE_XYZ) { has_xyz = true; if (t.width != 3) { emd_set_error("densify_gather: xyz width must be 3"); return EMD_ERR_INVALID; } }
+        if ((size_t)t.width > widest) widest = (size_t)t.width;
+    }
+    if (has_xyz && g->mode == EMD_DENSIFY_MODE_DENSIFY && (!g->scaling || !g->rotation)) { emd_set_error("densify_gather: split needs scaling and rotation"); return EMD_ERR_INVALID; }
+    if (g->samples && !g->split_rank) { emd_set_error("densify_gather: caller-supplied samples need split_rank"); return EMD_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t total = (size_t)g->num_out * widest;
+    unsigned blocks = (unsigned)((total + EMD_BLOCK - 1) / EMD_BLOCK);
+    if (blocks > 16384u) blocks = 16384u;
+    hipLaunchKernelGGL(k_densify_gather, dim3(blocks, (unsigned)g->num_tensors), dim3(EMD_BLOCK), 0, st, *g);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+extern "C" int emd_densify_split_rank(int32_t num_out, int32_t n_keep, int32_t n_clone, int32_t n_split, int32_t* rank, void* hip_stream) {
+    if (num_out < 0 || (num_out > 0 && !rank)) { emd_set_error("densify_split_rank: bad argument"); return EMD_ERR_INVALID; }
+    if (num_out == 0) return EMD_OK;
+    hipLaunchKernelGGL(k_densify_split_rank, dim3((num_out + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, num_out, n_keep,
+                       n_clone, n_split, rank);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}

@@ -12,6 +12,8 @@
 //                       models/modules.py:318-366,430-437).  The reference builds it from 43 tensors and two concats.
 //  k_deform_input_bwd   gradient of that matrix back to the actor embedding table (positions and time are detached there).
 // Launch-latency / HBM-write bound; nothing here is reused.
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -160,6 +162,150 @@ __global__ void __launch_bounds__(EMD_WAVE) k_deform_input_bwd(int n, int E, int
     if (cur >= 0) atomicAdd(g_embed + (size_t)cur * E + e, acc);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Learned per-actor track offsets (OmniRe/models/nodes/rigid.py:150-246), all actors, both levels, one launch each way.
+//   h_c = [TE_kc(t) of the actor's table, mean embedding of the actor's Gaussians],  h_f = [TE_kf(t), same mean]
+//   track_trans = W_tc h_c + b_tc + W_tf h_f + b_tf;   theta_c = w_rc . h_c + b_rc,  theta_f = w_rf . h_f + b_rf
+//   track_rot = (cos theta_c, 0, 0, sin theta_c) (x) (cos theta_f, 0, 0, sin theta_f)                      (theta, not theta / 2)
+// The reference spends ~40 launches per actor and loops over the actors in Python (rigid.py:520-562).  One wave per actor:
+// lane j < dim holds column j of both temporal rows, lanes dim .. dim+E-1 the mean embedding; the eight head outputs are
+// eight DPP wave sums.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct TeSample { int ha[2], hb[2]; float la[2], lb[2], wy0, wy1; bool in1; };
+
+__device__ __forceinline__ TeSample te_rows(float t, int k, int rows) {
+    TeSample s;
+    float my;
+    const float iy = reflect_coord((t - 0.5f) * 2.f, k, &my);
+    const float y0f = floorf(iy);
+    const int y0 = (int)y0f, y1 = y0 + 1;
+    s.wy1 = iy - y0f; s.wy0 = 1.f - s.wy1;
+    resized_row(min(y0, k - 1), k, rows, &s.ha[0], &s.hb[0], &s.la[0], &s.lb[0]);
+    resized_row(min(y1, k - 1), k, rows, &s.ha[1], &s.hb[1], &s.la[1], &s.lb[1]);
+    s.in1 = y1 <= k - 1;
+    return s;
+}
+
+// column j of the sampled row (same arithmetic as k_temporal_embed); with G != nullptr scatters g into the table gradient instead
+__device__ __forceinline__ float te_column(const float* __restrict__ weight, int dim, const TeSample& s, int j, float g, float* __restrict__ G) {
+    float mx;
+    const float gx = dim > 1 ? ((float)j / (float)(dim - 1) - 0.5f) * 2.f : -1.f;
+    const float ix = reflect_coord(gx, dim, &mx);
+    const float x0f = floorf(ix);
+    const int x0 = (int)x0f, x1 = x0 + 1;
+    const float wx1 = ix - x0f, wx0 = 1.f - wx1;
+    const bool inx1 = x1 <= dim - 1;
+    float out = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (r == 1 && !s.in1) continue;
+        const float wy = r ? s.wy1 : s.wy0;
+        if (!G) {
+            const float v0 = s.la[r] * weight[s.ha[r] * dim + x0] + s.lb[r] * weight[s.hb[r] * dim + x0];
+            const float v1 = inx1 ? s.la[r] * weight[s.ha[r] * dim + x1] + s.lb[r] * weight[s.hb[r] * dim + x1] : 0.f;
+            out += v0 * (wx0 * wy) + v1 * (wx1 * wy);
+        } else {
+            atomicAdd(G + s.ha[r] * dim + x0, g * wx0 * wy * s.la[r]);
+            atomicAdd(G + s.hb[r] * dim + x0, g * wx0 * wy * s.lb[r]);
+            if (inx1) {
+                atomicAdd(G + s.ha[r] * dim + x1, g * wx1 * wy * s.la[r]);
+                atomicAdd(G + s.hb[r] * dim + x1, g * wx1 * wy * s.lb[r]);
+            }
+        }
+    }
+    return out;
+}
+
+__device__ __forceinline__ float wave_sum_all(float v) {
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// per-actor sums of the point embeddings: a wave owns 64 consecutive points (one actor per wave in the reference's layout: a DPP
+// sum and E atomics per wave; a mixed wave falls back to per-point atomics)
+__global__ void __launch_bounds__(EMD_BLOCK) k_track_embed_sum(int n, int E, const float* __restrict__ emb, const int32_t* __restrict__ ids,
+                                                               float* __restrict__ sums) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    const int id = i < n ? ids[i] : -1;
+    const unsigned long long has = __ballot(id >= 0);
+    if (!has) return;
+    const int a0 = __builtin_amdgcn_readlane(id, __ffsll((long long)has) - 1);
+    const bool uniform = __ballot(id >= 0 && id != a0) == 0ull;
+    for (int e = 0; e < E; e++) {
+        const float v = id >= 0 ? emb[(size_t)i * E + e] : 0.f;
+        if (uniform) {
+            const float sum = wave_sum_all(v);
+            if ((threadIdx.x & 63) == 0) atomicAdd(sums + (size_t)a0 * E + e, sum);
+        } else if (id >= 0) atomicAdd(sums + (size_t)id * E + e, v);
+    }
+}
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_track_embed_bwd(int n, int E, const int32_t* __restrict__ ids, const float* __restrict__ count,
+                                                               const float* __restrict__ d_mean, float* __restrict__ d_emb) {
+    const size_t idx = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (idx >= (size_t)n * E) return;
+    const int i = (int)(idx / E), e = (int)(idx % E), id = ids[i];
+    d_emb[idx] = id >= 0 ? d_mean[(size_t)id * E + e] / count[id] : 0.f;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(EMD_WAVE) k_track_heads(EmdTrackArgs a, EmdTrackGrads g) {
+    const int act = blockIdx.x, lane = threadIdx.x, dim = a.dim, E = a.embed_dim, width = dim + E;
+    const float* w = a.weight + (size_t)act * a.rows * dim;
+    const TeSample sc = te_rows(a.t, a.k_coarse, a.rows), sf = te_rows(a.t, a.k_fine, a.rows);
+    float hc = 0.f, hf = 0.f;
+    if (lane < dim) { hc = te_column(w, dim, sc, lane, 0.f, nullptr); hf = te_column(w, dim, sf, lane, 0.f, nullptr); }
+    else if (lane < width) hc = hf = a.emb_sum[(size_t)act * E + (lane - dim)] / a.count[act];
+    // head rows: 0-2 trans_c, 3-5 trans_f, 6 rot_c, 7 rot_f
+    float out[8], wrow[8];
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        const int hd = o < 3 ? 0 : o < 6 ? 1 : o - 4, r = o < 3 ? o : o < 6 ? o - 3 : 0;
+        wrow[o] = lane < width ? a.head_w[hd][r * width + lane] : 0.f;
+        out[o] = wave_sum_all(wrow[o] * ((o < 3 || o == 6) ? hc : hf)) + a.head_b[hd][r];
+    }
+    const float cc = cosf(out[6]), scn = sinf(out[6]), cf = cosf(out[7]), sfn = sinf(out[7]);
+    const float ow = cc * cf - scn * sfn, oz = cc * sfn + scn * cf;          // quaternion_raw_multiply of two rotations about z
+    if (!BWD) {
+        if (lane == 0) {
+            a.trans[3 * act] = out[0] + out[3]; a.trans[3 * act + 1] = out[1] + out[4]; a.trans[3 * act + 2] = out[2] + out[5];
+            a.rot[4 * act] = ow; a.rot[4 * act + 1] = 0.f; a.rot[4 * act + 2] = 0.f; a.rot[4 * act + 3] = oz;
+        }
+        return;
+    }
+    // NaN gradients of an actor that is skipped in the pose table arrive as zeros from the pose kernel
+    const float gt0 = g.g_trans[3 * act], gt1 = g.g_trans[3 * act + 1], gt2 = g.g_trans[3 * act + 2];
+    const float gw = g.g_rot[4 * act], gz = g.g_rot[4 * act + 3];
+    const float dth = gw * (-oz) + gz * ow;                                  // d / d theta_c = d / d theta_f (the product depends on theta_c + theta_f)
+    const float go[8] = {gt0, gt1, gt2, gt0, gt1, gt2, dth, dth};
+    float dhc = 0.f, dhf = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        const int hd = o < 3 ? 0 : o < 6 ? 1 : o - 4, r = o < 3 ? o : o < 6 ? o - 3 : 0;
+        const bool coarse = o < 3 || o == 6;
+        if (lane < width) atomicAdd(g.d_head_w[hd] + r * width + lane, go[o] * (coarse ? hc : hf));
+        if (lane == 0) atomicAdd(g.d_head_b[hd] + r, go[o]);
+        if (coarse) dhc += go[o] * wrow[o]; else dhf += go[o] * wrow[o];
+    }
+    if (lane < dim) {
+        float* G = g.d_weight + (size_t)act * a.rows * dim;
+        te_column(w, dim, sc, lane, dhc, G);
+        te_column(w, dim, sf, lane, dhf, G);
+    } else if (lane < width) g.d_mean[(size_t)act * E + (lane - dim)] = dhc + dhf;
+}
+
+int check_track(const EmdTrackArgs* a, const char* who) {
+    if (!a) { emd_set_error("%s: null args", who); return EMD_ERR_INVALID; }
+    if (a->num_actors < 0 || a->rows < 1 || a->dim < 1 || a->embed_dim < 0 || a->dim + a->embed_dim > EMD_WAVE || a->k_coarse < 1 || a->k_fine < 1 ||
+        a->num_points < 0) { emd_set_error("%s: bad sizes (dim + embed_dim <= 64)", who); return EMD_ERR_INVALID; }
+    if (a->num_actors == 0) return EMD_OK;
+    if (!a->weight || !a->count || !a->emb_sum || (a->embed_dim > 0 && a->num_points > 0 && (!a->embeddings || !a->point_ids))) {
+        emd_set_error("%s: null pointer", who); return EMD_ERR_INVALID;
+    }
+    for (int h = 0; h < 4; h++) if (!a->head_w[h] || !a->head_b[h]) { emd_set_error("%s: null head parameter %d", who, h); return EMD_ERR_INVALID; }
+    return EMD_OK;
+}
+
 int check_te(const float* weight, int tables, int rows, int dim, int k, const float* t, const char* who) {
     if (!weight || !t) { emd_set_error("%s: null table / time", who); return EMD_ERR_INVALID; }
     if (tables < 1 || rows < 1 || dim < 1 || k < 1) { emd_set_error("%s: bad sizes tables=%d rows=%d dim=%d k=%d", who, tables, rows, dim, k); return EMD_ERR_INVALID; }
@@ -220,5 +366,44 @@ extern "C" int emd_deform_input_backward(int num_points, int embed_dim, int ld, 
     hipLaunchKernelGGL(k_deform_input_bwd, dim3((unsigned)((num_points + DEF_CHUNK - 1) / DEF_CHUNK)), dim3(EMD_WAVE), 0,
                        (hipStream_t)hip_stream, num_points, embed_dim, ld, col0, point_ids, dL_din, dL_dembed);
     EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+extern "C" int emd_track_heads_forward(const EmdTrackArgs* a, void* hip_stream) {
+    int rc = check_track(a, "track_heads_forward");
+    if (rc || a->num_actors == 0) return rc;
+    if (!a->trans || !a->rot) { emd_set_error("track_heads_forward: null output"); return EMD_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int E = a->embed_dim;
+    // (emb_sum arrives zero-filled: the caller's allocation is its zero fill -- one launch instead of a memset per buffer)
+    if (E > 0 && a->num_points > 0) {
+        hipLaunchKernelGGL(k_track_embed_sum, dim3((a->num_points + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, a->num_points, E,
+                           a->embeddings, a->point_ids, a->emb_sum);
+        EMD_LAUNCH_CHECK();
+    }
+    EmdTrackGrads none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL(k_track_heads<false>, dim3(a->num_actors), dim3(EMD_WAVE), 0, st, *a, none);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+extern "C" int emd_track_heads_backward(const EmdTrackArgs* a, const EmdTrackGrads* g, void* hip_stream) {
+    int rc = check_track(a, "track_heads_backward");
+    if (rc || a->num_actors == 0) return rc;
+    if (!g || !g->g_trans || !g->g_rot || !g->d_weight || !g->d_mean) { emd_set_error("track_heads_backward: null gradient pointer"); return EMD_ERR_INVALID; }
+    for (int h = 0; h < 4; h++) if (!g->d_head_w[h] || !g->d_head_b[h]) { emd_set_error("track_heads_backward: null head gradient %d", h); return EMD_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int E = a->embed_dim;
+    // d_weight, d_head_w[], d_head_b[] are accumulated into and arrive ZERO-FILLED from the caller (carved from one zeroed
+    // allocation: one fill launch instead of nine memsets); emb_sum still holds the forward's sums
+    hipLaunchKernelGGL(k_track_heads<true>, dim3(a->num_actors), dim3(EMD_WAVE), 0, st, *a, *g);
+    EMD_LAUNCH_CHECK();
+    if (g->d_embeddings && E > 0 && a->num_points > 0) {
+        const size_t total = (size_t)a->num_points * E;
+        hipLaunchKernelGGL(k_track_embed_bwd, dim3((unsigned)((total + EMD_BLOCK - 1) / EMD_BLOCK)), dim3(EMD_BLOCK), 0, st, a->num_points, E,
+                           a->point_ids, a->count, g->d_mean, g->d_embeddings);
+        EMD_LAUNCH_CHECK();
+    }
     return EMD_OK;
 }

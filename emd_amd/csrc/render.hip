@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
         const uint32_t pos = q_pos[sl];
         const uint32_t first_pos = readlane_u32(pos, 0);
         const v2f z2 = splat2(0.f);
-        v2f m0_2 = z2, m1x_2 = z2, m1y_2 = z2, m2xx_2 = z2, m2xy_2 = z2, m2yy_2 = z2, dz_2 = z2, r_2 = z2, g_2 = z2, b_2 = z2;
+        v2f m0_2 = z2, gx_2 = z2, gy_2 = z2, m2xx_2 = z2, m2xy_2 = z2, m2yy_2 = z2, dz_2 = z2, r_2 = z2, g_2 = z2, b_2 = z2;
         float a_ax = 0.f, a_ay = 0.f;
         for (int pp = 0; pp < EMD_WAVE / 2; pp++) {
             const uint32_t n_a = readlane_u32(my_n, 2 * pp), n_b = readlane_u32(my_n, 2 * pp + 1);
@@ -410,24 +410,27 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
             dL_da = (v2f){hit_a ? dL_da.x : 0.f, hit_b ? dL_da.y : 0.f};
             const v2f u = G * (splat2(g0.w) * dL_da);           // G dL/dG
             const v2f ux = u * dx, uy = u * splat2(dy);
-            m0_2 += u; m1x_2 += ux; m1y_2 += uy;
+            // d mean = -sum_pixels u Conic d, formed PER PIXEL (as upstream does) and not as -Conic (sum u d): for an elongated
+            // Gaussian the pixels that carry weight lie along its major axis, where A dx + B dy nearly cancels -- summing u dx and
+            // u dy separately and combining afterwards loses the anisotropy ratio in significant digits
+            const v2f tx = __builtin_elementwise_fma(splat2(g1.x), dx, splat2(g1.y * dy));
+            const v2f ty = __builtin_elementwise_fma(splat2(g1.y), dx, splat2(g1.z * dy));
+            const v2f ax = u * tx, ay = u * ty;
+            m0_2 += u; gx_2 += ax; gy_2 += ay;
             m2xx_2 += ux * dx; m2xy_2 += ux * splat2(dy); m2yy_2 += uy * splat2(dy);
-            if (ABS) {
-                const v2f ax = ux * splat2(g1.x) + uy * splat2(g1.y), ay = uy * splat2(g1.z) + ux * splat2(g1.y);
-                a_ax += fabsf(ax.x) + fabsf(ax.y); a_ay += fabsf(ay.x) + fabsf(ay.y);
-            }
+            if (ABS) { a_ax += fabsf(ax.x) + fabsf(ax.y); a_ay += fabsf(ay.x) + fabsf(ay.y); }
             dz_2 += w * (v2f){c2d.z, c2d.w};
             r_2 += w * (v2f){c01.x, c01.y}; g_2 += w * (v2f){c01.z, c01.w}; b_2 += w * (v2f){c2d.x, c2d.y};
             // lane 63 holds the batch totals: carry the running T and S of both pixels to the next batch
             if (lane == 63) s_pix[pp][2] = make_float4(cT.x * t_a, cT.y * t_b, Sk.x, Sk.y);
         }
-        const float m0 = m0_2.x + m0_2.y, m1x = m1x_2.x + m1x_2.y, m1y = m1y_2.x + m1y_2.y, m2xx = m2xx_2.x + m2xx_2.y,
+        const float m0 = m0_2.x + m0_2.y, gx = gx_2.x + gx_2.y, gy = gy_2.x + gy_2.y, m2xx = m2xx_2.x + m2xx_2.y,
                     m2xy = m2xy_2.x + m2xy_2.y, m2yy = m2yy_2.x + m2yy_2.y, a_dz = dz_2.x + dz_2.y, a_r = r_2.x + r_2.y,
                     a_g = g_2.x + g_2.y, a_b = b_2.x + b_2.y;
         // rows through LDS so that consecutive lanes add consecutive floats of one 48-byte accumulator row
         __syncthreads();   // every lane holds its record in registers: the lower half may be overwritten
         float4* row = reinterpret_cast<float4*>(s_stage + lane * EMD_BWD_STRIDE);
-        row[0] = make_float4(-(g1.x * m1x + g1.y * m1y), -(g1.z * m1y + g1.y * m1x), a_dz, m0 * __builtin_amdgcn_rcpf(g0.w));
+        row[0] = make_float4(-gx, -gy, a_dz, m0 * __builtin_amdgcn_rcpf(g0.w));
         row[1] = make_float4(-0.5f * m2xx, -m2xy, -0.5f * m2yy, a_r);
         row[2] = make_float4(a_g, a_b, ABS ? a_ax : 0.f, ABS ? a_ay : 0.f);
         __syncthreads();

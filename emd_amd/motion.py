@@ -75,41 +75,81 @@ class TrackOffsetHeads(torch.nn.Module):
     def int_lininterp(self, t, init_val, final_val, until):
         return int(init_val + (final_val - init_val) * min(max(t, 0), until) / until)
 
-    def temporal_embed(self, t, k):
-        """Row t (a 1-element DEVICE tensor, normalised to [0,1]) of every actor's table resized bilinearly to k rows and sampled
-        with reflection (rigid.py:150-164): ONE HIP launch for all actors (`emd_temporal_embed_forward`, one wave per table)."""
-        from .deformation import temporal_embed
-        return temporal_embed(self.weight, t, k)
-
-    def _time_tensor(self, frame, num_frames, device):
-        """normalised_frame = (frame - 0) / (num_frames - 1 - 0) (rigid.py:204,241) as a device tensor, without a per-step upload."""
-        tab = getattr(self, "_t_table", None)
-        if tab is None or tab.numel() != num_frames or tab.device != device:
-            tab = self._t_table = (torch.arange(num_frames, dtype=torch.float32) / max(num_frames - 1, 1)).to(device)
-        return tab[int(frame):int(frame) + 1]
-
     def forward(self, frame, num_frames, embeddings, point_ids, step):
-        """-> (track_trans [A,3], track_rot [A,4]).  embeddings [N,4]; point_ids [N] actor of every point (device tensors)."""
+        """-> (track_trans [A,3], track_rot [A,4]).  embeddings [n,4] of the actor Gaussians; point_ids [n] their actor (device
+        tensors).  One HIP launch (+ the per-actor embedding sums) forward and one backward for all actors and both levels
+        (`emd_track_heads_forward/backward`); no host synchronisation: the frame time is a by-value scalar."""
         if self.weight.device.type != "cuda":
             raise L.EmdError("TrackOffsetHeads needs its parameters on a ROCm device; there is no CPU path "
                              "(the checker's restatement is oracle/torch_ref.track_offsets)")
         A = self.weight.shape[0]
-        t = self._time_tensor(frame, num_frames, self.weight.device)
-        ids = point_ids.long()
-        cnt = getattr(self, "_cnt", None)
-        if cnt is None or getattr(self, "_cnt_key", None) != (ids.data_ptr(), ids.numel()):     # points per actor: constant between densifications
-            cnt = torch.zeros(A, device=embeddings.device).index_add_(0, ids, torch.ones_like(ids, dtype=embeddings.dtype))
-            self._cnt, self._cnt_key = cnt, (ids.data_ptr(), ids.numel())
-        mean_emb = torch.zeros(A, self.edim, device=embeddings.device, dtype=embeddings.dtype).index_add_(0, ids, embeddings) / cnt[:, None]
+        key = (point_ids.data_ptr(), point_ids.numel(), point_ids.dtype)
+        if getattr(self, "_ids_key", None) != key:             # ids as int32 + points per actor: constant between densifications
+            ids32 = point_ids.to(torch.int32).contiguous()
+            cnt = torch.zeros(A, device=ids32.device).index_add_(0, point_ids.long().clamp_min(0), (point_ids >= 0).float())
+            self._ids_key, self._ids32, self._cnt = key, ids32, cnt
+        t = float(frame) / float(max(num_frames - 1, 1))        # (frame - start_frame) / (end_frame - start_frame), rigid.py:204,241
         k_f = self.int_lininterp(step, self.min_embeddings, self.max_embeddings, self.c2f_temporal_iter)
-        h_c = torch.cat([self.temporal_embed(t, self.min_embeddings), mean_emb], -1)
-        h_f = torch.cat([self.temporal_embed(t, k_f), mean_emb], -1)
-        trans = self.track_trans_c(h_c) + self.track_trans_f(h_f)
-        th_c, th_f = self.track_rot_c(h_c)[:, 0], self.track_rot_f(h_f)[:, 0]
-        z = torch.zeros_like(th_c)
-        rot = quat_mult(torch.stack([torch.cos(th_c), z, z, torch.sin(th_c)], -1),
-                        torch.stack([torch.cos(th_f), z, z, torch.sin(th_f)], -1))
+        return _TrackHeads.apply(self.weight, embeddings, self.track_trans_c.weight, self.track_trans_c.bias, self.track_trans_f.weight,
+                                 self.track_trans_f.bias, self.track_rot_c.weight, self.track_rot_c.bias, self.track_rot_f.weight,
+                                 self.track_rot_f.bias, self._ids32, self._cnt, t, self.min_embeddings, k_f)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _TrackHeads(torch.autograd.Function):
+    @staticmethod
+    def _args(weight, emb, heads, ids32, cnt, t, k_c, k_f, emb_sum, trans, rot):
+        a = L.EmdTrackArgs()
+        a.num_actors, a.rows, a.dim = weight.shape
+        a.embed_dim, a.num_points = (emb.shape[1], emb.shape[0]) if emb is not None else (0, 0)
+        a.k_coarse, a.k_fine, a.t = int(k_c), int(k_f), float(t)
+        a.weight, a.embeddings, a.point_ids, a.count = weight.data_ptr(), L.ptr(emb), ids32.data_ptr(), cnt.data_ptr()
+        for h in range(4):
+            a.head_w[h], a.head_b[h] = heads[2 * h].data_ptr(), heads[2 * h + 1].data_ptr()
+        a.emb_sum, a.trans, a.rot = emb_sum.data_ptr(), L.ptr(trans), L.ptr(rot)
+        return a
+
+    @staticmethod
+    def forward(ctx, weight, emb, wtc, btc, wtf, btf, wrc, brc, wrf, brf, ids32, cnt, t, k_c, k_f):
+        dev = weight.device
+        c = lambda x: x.detach().contiguous().float()
+        weight_c, emb_c = c(weight), c(emb)
+        heads = [c(x) for x in (wtc, btc, wtf, btf, wrc, brc, wrf, brf)]
+        A, E = weight_c.shape[0], emb_c.shape[1]
+        if weight_c.shape[2] + E > 64 or any(h.shape[-1] != weight_c.shape[2] + E for h in heads[0::2]):
+            raise ValueError("track heads: temporal dim + embedding dim must be <= 64 and match the head widths")
+        emb_sum = torch.zeros(A, max(E, 1), device=dev)
+        trans, rot = torch.empty(A, 3, device=dev), torch.empty(A, 4, device=dev)
+        a = _TrackHeads._args(weight_c, emb_c, heads, ids32, cnt, t, k_c, k_f, emb_sum, trans, rot)
+        L.check(L.load().emd_track_heads_forward(C.byref(a), _stream()), "emd_track_heads_forward")
+        ctx.save_for_backward(weight_c, emb_c, ids32, cnt, emb_sum, *heads)
+        ctx.scal = (t, k_c, k_f)
         return trans, rot
+
+    @staticmethod
+    def backward(ctx, g_trans, g_rot):
+        weight, emb, ids32, cnt, emb_sum, *heads = ctx.saved_tensors
+        dev = weight.device
+        A, E = weight.shape[0], emb.shape[1]
+        z = lambda t_: torch.empty_like(t_)
+        g_trans = torch.zeros(A, 3, device=dev) if g_trans is None else g_trans.contiguous().float()
+        g_rot = torch.zeros(A, 4, device=dev) if g_rot is None else g_rot.contiguous().float()
+        # everything the kernel accumulates into comes from ONE zero-filled allocation
+        sizes = [weight.numel()] + [h.numel() for h in heads]
+        flat = torch.zeros(sum(sizes), device=dev)
+        parts = torch.split(flat, sizes)
+        d_weight, d_heads = parts[0].view_as(weight), [p.view_as(h) for p, h in zip(parts[1:], heads)]
+        d_emb, d_mean = z(emb), torch.empty(A, max(E, 1), device=dev)
+        a = _TrackHeads._args(weight, emb, heads, ids32, cnt, *ctx.scal, emb_sum, None, None)
+        g = L.EmdTrackGrads()
+        g.g_trans, g.g_rot, g.d_weight, g.d_embeddings, g.d_mean = g_trans.data_ptr(), g_rot.data_ptr(), d_weight.data_ptr(), d_emb.data_ptr(), d_mean.data_ptr()
+        for h in range(4):
+            g.d_head_w[h], g.d_head_b[h] = d_heads[2 * h].data_ptr(), d_heads[2 * h + 1].data_ptr()
+        L.check(L.load().emd_track_heads_backward(C.byref(a), C.byref(g), _stream()), "emd_track_heads_backward")
+        return (d_weight, d_emb, *d_heads, None, None, None, None, None)
 
 
 def build_actor_pose(instances_quats, instances_trans, instances_fv, cur_frame, track_trans=None, track_rot=None,
@@ -141,10 +181,6 @@ def build_actor_pose(instances_quats, instances_trans, instances_fv, cur_frame, 
     q_rot = quat_act(q_rot)
     valid = instances_fv[cur_frame].to(q_mean.dtype)[:, None]
     return torch.cat([q_mean, trans, valid, q_rot], dim=1).contiguous()
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 class _ActorPose(torch.autograd.Function):

@@ -122,6 +122,7 @@ class RasterCall:
 # forward is never awaited; its status word is copied to pinned host memory asynchronously and looked at by a LATER forward
 # (when the copy's event has completed), which grows the hint and warns if a past call overflowed.
 _capacity_hint = {}
+_wide_depth = set()           # keys whose depth range needs the four-pass sort (EMD_ERR_DEPTH_RANGE seen once)
 _pending_status = {}          # key -> list of (pinned tensor, event, capacity)
 _MAX_PENDING = 16
 
@@ -137,6 +138,11 @@ def _poll_pending(key, opts):
             continue
         d, overflow = int(host[0]) & 0xFFFFFFFF, int(host[1])
         need = int(d * opts.capacity_margin) + 1024
+        if overflow & 2:
+            warnings.warn("emd_amd: an earlier no_sync rasterizer call saw a visible Gaussian beyond 65 536 x the near plane (three-pass depth "
+                          "sort): that image was blank.  This camera size now uses the four-pass sort.", RuntimeWarning, stacklevel=3)
+            _wide_depth.add(key)
+            overflow &= ~2
         if overflow:
             warnings.warn(f"emd_amd: an earlier no_sync rasterizer call overflowed its binning workspace ({d} (tile, Gaussian) pairs, "
                           f"capacity {cap}): that image was blank and its gradients zero.  The capacity hint has been raised to {need}.",
@@ -244,6 +250,8 @@ class _Rasterize(torch.autograd.Function):
 
         key = (dev.index, H, W)
         _poll_pending(key, opts)
+        if key in _wide_depth:
+            flags |= L.FLAG_WIDE_DEPTH_SORT
         capacity = max(int(_capacity_hint.get(key, 0)), opts.min_capacity, 4 * N if key not in _capacity_hint else 0)
         a = L.EmdFwdArgs()
         while True:
@@ -266,6 +274,10 @@ class _Rasterize(torch.autograd.Function):
             a.img_ws, a.img_bytes = img_ws.data_ptr(), ib
             a.status = status.data_ptr()
             rc = lib.emd_raster_forward(C.byref(a), _stream())
+            if rc == L.EMD_ERR_DEPTH_RANGE and not (flags & L.FLAG_WIDE_DEPTH_SORT):
+                _wide_depth.add(key)
+                flags |= L.FLAG_WIDE_DEPTH_SORT
+                continue
             if rc == L.EMD_ERR_CAPACITY:
                 capacity = int(a.num_rendered * opts.capacity_margin) + 1024
                 continue

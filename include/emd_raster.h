@@ -64,7 +64,9 @@ enum {
     EMD_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, both/neither of shs & colors...) */
     EMD_ERR_CAPACITY = -2,  /* bin_capacity too small; EmdFwdArgs.num_rendered holds the needed count */
     EMD_ERR_HIP = -3,       /* a HIP runtime call or kernel launch failed */
-    EMD_ERR_WORKSPACE = -4  /* a workspace buffer is smaller than emd_raster_workspace_size() reports */
+    EMD_ERR_WORKSPACE = -4, /* a workspace buffer is smaller than emd_raster_workspace_size() reports */
+    EMD_ERR_DEPTH_RANGE = -5 /* a visible Gaussian lies more than 65 536 x the near plane away: the three-pass depth sort does not
+                                cover it; call again with EMD_FLAG_WIDE_DEPTH_SORT */
 };
 
 enum {
@@ -77,6 +79,8 @@ enum {
     EMD_FLAG_RAW_PARAMS = 1 << 5,  /* inputs are the raw parameters: scales = log-scales (exp applied here), rotations
                                       un-normalised (normalised here), opacities = logits (sigmoid here); gradients are
                                       returned w.r.t. the raw parameters.  Fuses S3Gaussian/gaussian_renderer/__init__.py:99-101 */
+    EMD_FLAG_WIDE_DEPTH_SORT = 1 << 7, /* sort the Gaussians by all 32 depth bits in four passes instead of by the 27 bits above the
+                                      near plane in three (needed only when depths exceed 65 536 x the near plane: EMD_ERR_DEPTH_RANGE) */
     EMD_FLAG_SDEV_TANFOV = 1 << 6  /* settings_dev holds two more floats, tanfovx and tanfovy (cameras given as device-resident
                                       intrinsics, OmniRe/models/trainers/base.py:399-400): they replace the by-value fields */
 };
@@ -118,7 +122,8 @@ typedef struct EmdMotion {
 /* Small device-side status block written by the forward pass. */
 typedef struct EmdStatus {
     uint32_t num_rendered;  /* D = sum of tiles touched */
-    uint32_t overflow;      /* 1 if D > bin_capacity (results invalid) */
+    uint32_t overflow;      /* bit 0: D > bin_capacity; bit 1: depth range beyond the three-pass sort (either: results invalid,
+                               the image is the background) */
     uint32_t num_visible;   /* V = Gaussians with radii > 0 */
     uint32_t reserved;
 } EmdStatus;
@@ -416,6 +421,38 @@ int emd_temporal_embed_forward(const float* weight, int num_tables, int rows, in
 int emd_temporal_embed_backward(const float* weight, int num_tables, int rows, int dim, int k, const float* t, const float* dL_dout,
                                 float* dL_dweight, float* dL_dt, void* hip_stream);
 
+/* Learned per-actor track offsets, all actors and both levels in one launch each way
+ * (embedding_track_trans_offset / embedding_track_rot_offset / query_coarse_to_fine / get_temporal_embed,
+ * OmniRe/models/nodes/rigid.py:150-246): see the block comment in csrc/embed.hip.  head_w[h] is [rows_h, dim + embed_dim]
+ * row-major, head_b[h] is [rows_h], h = 0 track_trans_c (3 rows), 1 track_trans_f (3), 2 track_rot_c (1), 3 track_rot_f (1). */
+typedef struct EmdTrackArgs {
+    int32_t num_actors, rows, dim, embed_dim;    /* temporal tables [A, rows, dim]; dim + embed_dim <= 64 */
+    int32_t k_coarse, k_fine, num_points, reserved;
+    float t;                                     /* normalised frame (frame - start) / (end - start), rigid.py:204,241 */
+    const float* weight;                         /* [A, rows, dim] */
+    const float* embeddings;                     /* [num_points, embed_dim] of the actor Gaussians */
+    const int32_t* point_ids;                    /* [num_points] actor of every point (-1: none) */
+    const float* count;                          /* [A] points per actor, as floats */
+    const float* head_w[4];
+    const float* head_b[4];
+    float* emb_sum;                              /* [A, embed_dim] scratch: per-actor embedding sums; ZERO-FILLED by the caller before forward, kept for backward */
+    float* trans;                                /* out [A,3] */
+    float* rot;                                  /* out [A,4] (w,x,y,z) */
+} EmdTrackArgs;
+
+typedef struct EmdTrackGrads {
+    const float* g_trans;                        /* [A,3] */
+    const float* g_rot;                          /* [A,4] */
+    float* d_weight;                             /* [A, rows, dim]; accumulated into: ZERO-FILLED by the caller, like d_head_w / d_head_b */
+    float* d_embeddings;                         /* [num_points, embed_dim] or NULL */
+    float* d_head_w[4];
+    float* d_head_b[4];
+    float* d_mean;                               /* [A, embed_dim] scratch */
+} EmdTrackGrads;
+
+int emd_track_heads_forward(const EmdTrackArgs* args, void* hip_stream);
+int emd_track_heads_backward(const EmdTrackArgs* args, const EmdTrackGrads* grads, void* hip_stream);
+
 typedef struct EmdDeformInArgs {
     int32_t num_points, num_freqs_x, num_freqs_t, embed_dim;
     int32_t ld, reserved;                        /* row stride of out in floats (>= emd_deform_input_width) */
@@ -431,6 +468,62 @@ int emd_deform_input_width(int num_freqs_x, int num_freqs_t, int embed_dim);
 int emd_deform_input_forward(const EmdDeformInArgs* args, void* hip_stream);
 int emd_deform_input_backward(int num_points, int embed_dim, int ld, int col0, const int32_t* point_ids, const float* dL_din,
                               float* dL_dembed, void* hip_stream);
+
+/* ---- Adaptive density control on the device ----------------------------------------------------
+ * densify = densify_and_clone + densify_and_split, prune = prune / prune_points of S3Gaussian/scene/gaussian_model.py:441-603,
+ * 683-701 (OmniRe: models/gaussians/vanilla.py:206-376), rewriting the SoA parameters, both Adam moments and the statistics in
+ * one gather launch -- see the block comment of csrc/densify.hip.  Call sequence of one event:
+ *   emd_densify_decide  -> code[N], columns[3][N] (0/1: survives, cloned, split)
+ *   [inclusive prefix sums of the three columns by the caller; num_out = keep + clone + 2 split: the event's one host read]
+ *   emd_densify_index   -> src[num_out], kind[num_out] (0 survivor, 1 clone, 2 / 3 split sample replica 0 / 1), in the
+ *                          reference's output order: survivors, clones, replica 0, replica 1
+ *   emd_densify_gather  -> every output tensor */
+enum { EMD_DENSIFY_MODE_DENSIFY = 0, EMD_DENSIFY_MODE_PRUNE = 1 };
+enum {
+    EMD_DENSIFY_ROLE_COPY = 0,     /* parameter copied row for row (features, opacity, rotation, embedding, deformation table ...) */
+    EMD_DENSIFY_ROLE_XYZ = 1,      /* means: split samples get R(q) (exp(scaling) * n) + xyz, n ~ N(0, 1)   gaussian_model.py:541-545 */
+    EMD_DENSIFY_ROLE_SCALING = 2,  /* log-scales: split samples get log(exp(s) / (0.8 * 2))                  gaussian_model.py:546 */
+    EMD_DENSIFY_ROLE_STATE = 3,    /* Adam moment: survivors keep theirs, new rows start at zero             gaussian_model.py:480-500 */
+    EMD_DENSIFY_ROLE_ZERO = 4      /* statistics: reset to zero by a densification (gaussian_model.py:526-530), carried by a prune */
+};
+
+typedef struct EmdDensifyArgs {
+    int32_t num_points, mode;
+    const float* scaling;          /* [N,3] log-scales */
+    const float* opacity;          /* [N] logits (prune) */
+    const float* grad_accum;       /* [N] xyz_gradient_accum (densify) */
+    const float* denom;            /* [N] (densify) */
+    const float* max_radii2D;      /* [N] (prune with max_screen_size > 0) */
+    const uint8_t* extra_drop;     /* [N] or NULL: additional rows to drop in prune mode (prune_points(mask) with a caller's mask) */
+    float grad_threshold, percent_dense, scene_extent;      /* densify */
+    float min_opacity, max_screen_size;                     /* prune; max_screen_size <= 0: the size tests are off */
+} EmdDensifyArgs;
+
+typedef struct EmdDensifyTensor {
+    const float* src;              /* [N, width] */
+    float* dst;                    /* [num_out, width] */
+    int32_t width, role;
+} EmdDensifyTensor;
+
+#define EMD_DENSIFY_MAX_TENSORS 40
+typedef struct EmdDensifyGather {
+    int32_t num_out, num_tensors, mode, num_split;
+    const int32_t* src;            /* [num_out] */
+    const int32_t* kind;           /* [num_out] */
+    const float* scaling;          /* [N,3] source log-scales  (split) */
+    const float* rotation;         /* [N,4] source quaternions (split) */
+    uint64_t seed;                 /* Philox key of the split samples: counter = (source Gaussian index, replica) -- the same samples on
+                                      every rank of a data-parallel job without communication */
+    const float* samples;          /* [2, num_split, 3] standard normals to use INSTEAD of Philox (tests: the reference's recorded draw) or NULL */
+    const int32_t* split_rank;     /* [num_out] rank of a split row inside its replica (emd_densify_split_rank); needed with `samples` */
+    EmdDensifyTensor tensors[EMD_DENSIFY_MAX_TENSORS];
+} EmdDensifyGather;
+
+int emd_densify_decide(const EmdDensifyArgs* args, int32_t* code /*[N]*/, int32_t* columns /*[3,N]*/, void* hip_stream);
+int emd_densify_index(int32_t num_points, int32_t num_out, const int32_t* code, const int32_t* inclusive_scans /*[3,N]*/, int32_t* src,
+                      int32_t* kind, void* hip_stream);
+int emd_densify_split_rank(int32_t num_out, int32_t n_keep, int32_t n_clone, int32_t n_split, int32_t* rank, void* hip_stream);
+int emd_densify_gather(const EmdDensifyGather* args, void* hip_stream);
 
 /* ---- Adam over all parameter tensors in one launch ---------------------------------------
  * Replaces optimizer.step() of `torch.optim.Adam(l, lr=0.0, eps=1e-15)` (S3Gaussian/scene/gaussian_model.py:188-201,

@@ -442,6 +442,9 @@ int orc_render_forward(const OrcSettings* S, int flags, const uint32_t* ranges, 
     return 0;
 }
 
+static int g_accumulate_fp32 = 0;
+void orc_set_accumulate_fp32(int on) { g_accumulate_fp32 = on; }
+
 /* ------------------------------------------------------------------------------------------------
  * K7: render backward (back-to-front replay).  [UPSTREAM render backward]
  * Per-Gaussian accumulators (zeroed here):
@@ -459,31 +462,51 @@ int orc_render_backward(const OrcSettings* S, int N, int flags, const uint32_t* 
                         float* g_normal) {
     const int W = S->W, H = S->H, gx = (W + TILE - 1) / TILE;
     const size_t HW = (size_t)H * W;
-    /* Per-(pixel, Gaussian) partial derivatives are evaluated in fp32 exactly as upstream does; they are SUMMED in
-     * double (15 accumulators per Gaussian) so that the result neither depends on the order in which the OpenMP
-     * threads reach a Gaussian nor carries the rounding of one particular fp32 summation order: the oracle is the
-     * exact sum of the fp32 partials, rounded once. */
+    /* The blend weights are the forward pass's fp32 values; the per-pixel recurrences built from them and the sums over
+     * pixels (15 accumulators per Gaussian) are evaluated in double, so that the result neither depends on the order in
+     * which the OpenMP threads reach a Gaussian nor carries the rounding of one particular fp32 evaluation order: the
+     * oracle is the derivative of the forward function as evaluated, rounded once at the end. */
     enum { A_MX = 0, A_MY, A_AX, A_AY, A_CA, A_CB, A_CC, A_OP, A_R, A_G, A_B, A_D, A_N0, A_N1, A_N2, A_STRIDE };
     double* acc = (double*)calloc((size_t)(N > 0 ? N : 1) * A_STRIDE, sizeof(double));
     if (!acc) return -1;
-#define ACC(g, k, v) do { const double v_ = (double)(v); _Pragma("omp atomic") acc[(size_t)(g) * A_STRIDE + (k)] += v_; } while (0)
-#pragma omp parallel for schedule(dynamic, 2)
+    /* orc_set_accumulate_fp32(1): sum the partials in fp32, sequentially in pixel order -- the arithmetic of an fp32 atomicAdd
+     * implementation in ONE particular order (diagnostic: how much of a deviation is summation order). */
+    const int acc32 = g_accumulate_fp32;
+#define ACC(g, k, v) do { if (acc32) { float* a_ = (float*)acc + (size_t)(g) * A_STRIDE + (k); *a_ += (v); } \
+                          else { const double v_ = (double)(v); _Pragma("omp atomic") acc[(size_t)(g) * A_STRIDE + (k)] += v_; } } while (0)
+#pragma omp parallel for schedule(dynamic, 2) if (!acc32)
     for (int py = 0; py < H; py++)
         for (int px = 0; px < W; px++) {
             size_t pix = (size_t)py * W + px;
             int t = (py / TILE) * gx + px / TILE;
-            const float Tf = final_T[pix];
-            float T = Tf;
+            uint32_t start = ranges[2 * t];
             float dC[3] = {0, 0, 0}, dD = 0.f, dA = 0.f, dN[3] = {0, 0, 0};
             if (dL_dcolor) for (int ch = 0; ch < 3; ch++) dC[ch] = dL_dcolor[ch * HW + pix];
             if (dL_ddepth) dD = dL_ddepth[pix];
             if (dL_dalpha) dA = dL_dalpha[pix];
             if (dL_dnormal && (flags & F_NORMAL)) for (int ch = 0; ch < 3; ch++) dN[ch] = dL_dnormal[ch * HW + pix];
-            float bgdot = (S->bg[0] * dC[0] + S->bg[1] * dC[1]) + S->bg[2] * dC[2];
+            const double bgdot = ((double)S->bg[0] * dC[0] + (double)S->bg[1] * dC[1]) + (double)S->bg[2] * dC[2];
+            /* The blend weights alpha_k are the fp32 values the forward pass used (same skip decisions, pinned exp); everything
+             * built FROM them -- the transmittance T_k, the colour behind each Gaussian, dL/dalpha -- is evaluated in double.
+             * Upstream rebuilds T_k in fp32 by repeated division from T_final; over a list thousands of entries deep that walk
+             * drifts by several 1e-6 relative exactly where the weights are largest (the front of the list), which would make
+             * this oracle LESS accurate than the kernel it checks (whose prefix product starts at the front).  The oracle is the
+             * derivative of the forward function as the forward pass evaluated it, not a replay of one fp32 summation order. */
+            double Tf = 1.0;
+            for (int64_t k = (int64_t)start; k < (int64_t)start + (int64_t)n_contrib[pix]; k++) {
+                uint32_t g = ids[k];
+                float dx = means2D[2 * g] - (float)px, dy = means2D[2 * g + 1] - (float)py;
+                const float* co = conic_opacity + 4 * g;
+                float power = gauss_power(co[0], co[1], co[2], dx, dy);
+                if (power > 0.f) continue;
+                float alpha = fminf(0.99f, co[3] * pinned_exp(power));
+                if (alpha < 1.f / 255.f) continue;
+                Tf *= 1.0 - (double)alpha;
+            }
+            double T = Tf;
             /* colour behind the current Gaussian, per unit of transmittance after it */
-            float accC[3] = {0, 0, 0}, accD = 0.f, accN[3] = {0, 0, 0};
-            float last_alpha = 0.f, lastC[3] = {0, 0, 0}, lastD = 0.f, lastN[3] = {0, 0, 0};
-            uint32_t start = ranges[2 * t];
+            double accC[3] = {0, 0, 0}, accD = 0.0, accN[3] = {0, 0, 0};
+            double last_alpha = 0.0, lastC[3] = {0, 0, 0}, lastD = 0.0, lastN[3] = {0, 0, 0};
             for (int64_t k = (int64_t)start + (int64_t)n_contrib[pix] - 1; k >= (int64_t)start; k--) {
                 uint32_t g = ids[k];
                 float dx = means2D[2 * g] - (float)px, dy = means2D[2 * g + 1] - (float)py;
@@ -493,26 +516,26 @@ int orc_render_backward(const OrcSettings* S, int N, int flags, const uint32_t* 
                 float G = pinned_exp(power);
                 float alpha = fminf(0.99f, co[3] * G);
                 if (alpha < 1.f / 255.f) continue;
-                T = T / (1.f - alpha);
-                float w = alpha * T; /* d out / d feature */
-                float dL_da = 0.f;
+                T = T / (1.0 - (double)alpha);
+                const double w = (double)alpha * T; /* d out / d feature */
+                double dL_da = 0.0;
                 for (int ch = 0; ch < 3; ch++) {
-                    float c = rgb[3 * g + ch];
-                    accC[ch] = last_alpha * lastC[ch] + (1.f - last_alpha) * accC[ch];
+                    double c = rgb[3 * g + ch];
+                    accC[ch] = last_alpha * lastC[ch] + (1.0 - last_alpha) * accC[ch];
                     lastC[ch] = c;
                     dL_da += (c - accC[ch]) * dC[ch];
                     ACC(g, A_R + ch, w * dC[ch]);
                 }
                 {
-                    float z = depths[g];
-                    accD = last_alpha * lastD + (1.f - last_alpha) * accD;
+                    double z = depths[g];
+                    accD = last_alpha * lastD + (1.0 - last_alpha) * accD;
                     lastD = z;
                     dL_da += (z - accD) * dD;
                     ACC(g, A_D, w * dD);
                 }
                 if (flags & F_NORMAL) for (int ch = 0; ch < 3; ch++) {
-                    float n = normal[3 * g + ch];
-                    accN[ch] = last_alpha * lastN[ch] + (1.f - last_alpha) * accN[ch];
+                    double n = normal[3 * g + ch];
+                    accN[ch] = last_alpha * lastN[ch] + (1.0 - last_alpha) * accN[ch];
                     lastN[ch] = n;
                     dL_da += (n - accN[ch]) * dN[ch];
                     if (g_normal) ACC(g, A_N0 + ch, w * dN[ch]);
@@ -520,24 +543,25 @@ int orc_render_backward(const OrcSettings* S, int N, int flags, const uint32_t* 
                 dL_da *= T;
                 last_alpha = alpha;
                 /* background and alpha image: both depend on T_final = prod (1 - alpha_i) */
-                dL_da += (Tf / (1.f - alpha)) * (dA - bgdot);
-                float dL_dG = co[3] * dL_da;
-                float gdx = G * dx, gdy = G * dy;
-                float dG_ddx = -gdx * co[0] - gdy * co[1];
-                float dG_ddy = -gdy * co[2] - gdx * co[1];
-                float mx = dL_dG * dG_ddx, my = dL_dG * dG_ddy;
+                dL_da += (Tf / (1.0 - (double)alpha)) * ((double)dA - bgdot);
+                const double dL_dG = (double)co[3] * dL_da;
+                const double gdx = (double)G * dx, gdy = (double)G * dy;
+                const double dG_ddx = -gdx * co[0] - gdy * co[1];
+                const double dG_ddy = -gdy * co[2] - gdx * co[1];
+                const double mx = dL_dG * dG_ddx, my = dL_dG * dG_ddy;
                 ACC(g, A_MX, mx); ACC(g, A_MY, my);
-                if (g_abs) { ACC(g, A_AX, fabsf(mx)); ACC(g, A_AY, fabsf(my)); }
-                ACC(g, A_CA, -0.5f * gdx * dx * dL_dG);
+                if (g_abs) { ACC(g, A_AX, fabs(mx)); ACC(g, A_AY, fabs(my)); }
+                ACC(g, A_CA, -0.5 * gdx * dx * dL_dG);
                 ACC(g, A_CB, -gdx * dy * dL_dG);
-                ACC(g, A_CC, -0.5f * gdy * dy * dL_dG);
-                ACC(g, A_OP, G * dL_da);
+                ACC(g, A_CC, -0.5 * gdy * dy * dL_dG);
+                ACC(g, A_OP, (double)G * dL_da);
             }
         }
 #undef ACC
 #pragma omp parallel for schedule(static)
     for (int g = 0; g < N; g++) {
-        const double* a = acc + (size_t)g * A_STRIDE;
+        double a[A_STRIDE];
+        for (int k = 0; k < A_STRIDE; k++) a[k] = acc32 ? (double)((const float*)acc)[(size_t)g * A_STRIDE + k] : acc[(size_t)g * A_STRIDE + k];
         g_mean2D[2 * g] = (float)a[A_MX]; g_mean2D[2 * g + 1] = (float)a[A_MY];
         if (g_abs) { g_abs[2 * g] = (float)a[A_AX]; g_abs[2 * g + 1] = (float)a[A_AY]; }
         g_conic[3 * g] = (float)a[A_CA]; g_conic[3 * g + 1] = (float)a[A_CB]; g_conic[3 * g + 2] = (float)a[A_CC];

@@ -28,6 +28,8 @@ Fixtures (all fp32):
                                                    S3Gaussian/scene/gaussian_model.py:728-730, train.py:403-406
   s3g_deform.npz    deform_network.forward (HexPlane + coarse-to-fine temporal embedding + heads + apply_deform), its state_dict,
                     outputs and gradients, under the run-script flags and with every head on     S3Gaussian/scene/deformation.py:187-527
+  s3g_surgery.npz   GaussianModel.densify (clone + split, recorded normal draw), prune, reset_opacity: parameters, Adam moments,
+                    statistics after each call; construct_list_of_attributes; capture() layout
   s3g_adam.npz      the optimiser GaussianModel.training_setup builds (torch.optim.Adam, eps 1e-15, ten named groups) stepped over six
                     iterations with seeded gradients and update_learning_rate      S3Gaussian/scene/gaussian_model.py:181-243, train.py:195,428
   or_deform.npz     DeformableNodes.get_deformation through ConditionalDeformNetwork (+ gradients)
@@ -557,6 +559,97 @@ def gen_s3g_densify():
     unload(["utils", "scene", "arguments", "gaussian_renderer"])
 
 
+def gen_s3g_surgery():
+    """The reference's adaptive density control on CPU: GaussianModel.densify (clone + split, with the torch.normal draw recorded),
+    prune and reset_opacity on a seeded model whose optimiser has taken two steps -- every parameter, both Adam moments of the seven
+    per-point groups, the statistics and the deformation table after each call -- plus construct_list_of_attributes() and the
+    layout of capture()."""
+    sys.path.insert(0, os.path.join(REF, "S3Gaussian"))
+    sys.modules["utils.tcnn_modules"] = _Stub("utils.tcnn_modules")
+    with _CpuMode():
+        from arguments.gaussian_options import BaseOptions
+        from scene.gaussian_model import GaussianModel
+        args = BaseOptions()
+        for k in ("no_ds", "no_dr", "no_fine_hexplane_features"):
+            setattr(args, k, True)
+        args.kplanes_config = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 4, "resolution": [4, 4, 4, 3]}
+        args.multires = [1]
+        args.sky_resolution = 4
+        args.net_width, args.feat_head = 8, False
+        torch.manual_seed(1200)
+        pc = GaussianModel(args)
+        N = 400
+        g = torch.Generator().manual_seed(1201)
+        P = torch.nn.Parameter
+        pc._xyz = P(torch.randn(N, 3, generator=g) * 5)
+        pc._features_dc = P(torch.randn(N, 1, 3, generator=g))
+        pc._features_rest = P(torch.randn(N, 15, 3, generator=g) * 0.1)
+        pc._scaling = P(torch.log(0.02 + 0.3 * torch.rand(N, 3, generator=g)))
+        pc._rotation = P(torch.randn(N, 4, generator=g))
+        pc._opacity = P(torch.randn(N, 1, generator=g) * 2.5)
+        pc._embedding = P(torch.randn(N, 4, generator=g) * 0.1)
+        pc._deformation_table = torch.rand(N, generator=g) > 0.3
+        pc.max_radii2D = torch.zeros(N)
+        pc.spatial_lr_scale = 5.0
+        pc.training_setup(args)
+        names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "embedding")
+        attr = dict(xyz="_xyz", f_dc="_features_dc", f_rest="_features_rest", opacity="_opacity", scaling="_scaling", rotation="_rotation",
+                    embedding="_embedding")
+        out = dict(attributes=np.array(pc.construct_list_of_attributes()), percent_dense=float(args.percent_dense))
+        for it in range(2):                                # two optimiser steps: non-trivial Adam moments
+            pc.update_learning_rate(it)
+            for n_ in names:
+                p = getattr(pc, attr[n_])
+                p.grad = torch.randn(p.shape, generator=g) * 1e-2
+            pc.optimizer.step()
+        pc.xyz_gradient_accum = torch.rand(N, 1, generator=g) * 1e-3
+        pc.denom = torch.randint(0, 4, (N, 1), generator=g).float()
+        pc.max_radii2D = torch.randint(0, 40, (N,), generator=g).float()
+
+        def snap(tag):
+            for n_ in names:
+                p = getattr(pc, attr[n_])
+                out[f"{tag}_{n_}"] = p.detach().clone()
+                st = pc.optimizer.state[p]
+                out[f"{tag}_m_{n_}"], out[f"{tag}_v_{n_}"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+            out[f"{tag}_accum"], out[f"{tag}_denom"], out[f"{tag}_maxr"] = pc.xyz_gradient_accum.clone(), pc.denom.clone(), pc.max_radii2D.clone()
+            out[f"{tag}_table"] = pc._deformation_table.clone()
+        snap("in")
+        extent, max_grad = 20.0, 2.0e-4                      # percent_dense * extent = 0.2: both the clone and the split branch fire
+        out["extent"], out["max_grad"] = extent, max_grad
+        rec = {}
+        real_normal = torch.normal
+
+        def recording_normal(mean, std, **kw):
+            z = torch.randn(std.shape, generator=g)
+            rec["z"] = z.clone()
+            return mean + std * z
+        torch.normal = recording_normal
+        try:
+            pc.densify(max_grad, 0.005, extent, None, 5, 5)
+        finally:
+            torch.normal = real_normal
+        out["normal_z"] = rec["z"]
+        snap("dens")
+        # between events the training loop accumulates statistics again (train.py:403-406)
+        M = pc._xyz.shape[0]
+        pc.max_radii2D = torch.randint(0, 40, (M,), generator=g).float()
+        pc.xyz_gradient_accum = torch.rand(M, 1, generator=g) * 1e-3
+        pc.denom = torch.randint(0, 4, (M, 1), generator=g).float()
+        out["prune_in_maxr"], out["prune_in_accum"], out["prune_in_denom"] = pc.max_radii2D.clone(), pc.xyz_gradient_accum.clone(), pc.denom.clone()
+        out["min_opacity"], out["max_screen_size"], out["prune_extent"] = 0.05, 20.0, 2.5     # 0.1 * 2.5: the world-size test fires too
+        pc.prune(max_grad, 0.05, 2.5, 20)
+        snap("prune")
+        pc.reset_opacity()
+        snap("reset")
+        cap = pc.capture()
+        out["capture_len"] = len(cap)
+        out["capture_kinds"] = np.array([type(c).__name__ for c in cap])
+        save("s3g_surgery.npz", **out)
+    sys.path.pop(0)
+    unload(["utils", "scene", "arguments", "gaussian_renderer"])
+
+
 def gen_or_envlight():
     sys.path.insert(0, os.path.join(REF, "OmniRe"))
     import nvdiffrast.torch as dr
@@ -842,6 +935,7 @@ if __name__ == "__main__":
     gen_s3g_densify()
     gen_s3g_deform()
     gen_s3g_adam()
+    gen_s3g_surgery()
     print("OmniRe:")
     gen_omnire()
     gen_or_envlight()

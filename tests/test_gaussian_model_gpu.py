@@ -1,0 +1,200 @@
+"""-m gpu: adaptive density control on the device (emd_amd.gaussian_model.GaussianModel: densify / prune / reset_opacity through
+emd_densify_*) against the reference's own GaussianModel methods run on CPU (tests/golden/s3g_surgery.npz: every parameter, both
+Adam moments, the statistics and the deformation table after each call, with the reference's torch.normal draw recorded), the
+Philox split samples, and a training loop that densifies and prunes unattended."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+G = os.path.join(os.path.dirname(__file__), "golden")
+NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "embedding")
+
+
+def _train_args(**kw):
+    a = types.SimpleNamespace(percent_dense=0.01, position_lr_init=1.6e-4, position_lr_final=1.6e-6, position_lr_delay_mult=0.01,
+                              position_lr_max_steps=30000, deformation_lr_init=1.6e-5, deformation_lr_final=1.6e-6, deformation_lr_delay_mult=0.01,
+                              grid_lr_init=1.6e-3, grid_lr_final=1.6e-5, feature_lr=2.5e-3, opacity_lr=0.05, scaling_lr=5e-3, rotation_lr=1e-3,
+                              sky_cube_map_lr_init=0.01, sky_cube_map_lr_final=1e-4, sky_cube_map_max_steps=30000)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def _model_from(z, tag):
+    from emd_amd.gaussian_model import GaussianModel
+    m = GaussianModel(sh_degree=3, gaussian_embedding_dim=4, device=DEV)
+    P = lambda k: torch.nn.Parameter(torch.tensor(z[f"{tag}_{k}"]).to(DEV).contiguous())
+    for n in NAMES:
+        setattr(m, m._ATTR[n], P(n))
+    m._deformation_table = torch.tensor(z[f"{tag}_table"]).to(DEV)
+    m.spatial_lr_scale = 5.0
+    m.training_setup(_train_args(percent_dense=float(z["percent_dense"])))
+    for n in NAMES:
+        p = getattr(m, m._ATTR[n])
+        m.optimizer.state[p] = {"step": torch.tensor(2.0), "exp_avg": torch.tensor(z[f"{tag}_m_{n}"]).to(DEV).contiguous(),
+                                "exp_avg_sq": torch.tensor(z[f"{tag}_v_{n}"]).to(DEV).contiguous()}
+    m.xyz_gradient_accum = torch.tensor(z[f"{tag}_accum"]).to(DEV).contiguous()
+    m.denom = torch.tensor(z[f"{tag}_denom"]).to(DEV).contiguous()
+    m.max_radii2D = torch.tensor(z[f"{tag}_maxr"]).to(DEV).contiguous()
+    return m
+
+
+def _check(m, z, tag, exact=True):
+    for n in NAMES:
+        p = getattr(m, m._ATTR[n])
+        got, ref = p.detach().cpu().numpy(), z[f"{tag}_{n}"]
+        assert got.shape == ref.shape, (tag, n, got.shape, ref.shape)
+        if exact and n not in ("xyz", "scaling"):
+            np.testing.assert_array_equal(got, ref, err_msg=f"{tag} {n}")
+        else:
+            np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-6, err_msg=f"{tag} {n}")
+        st = m.optimizer.state[p]
+        np.testing.assert_array_equal(st["exp_avg"].cpu().numpy(), z[f"{tag}_m_{n}"], err_msg=f"{tag} exp_avg {n}")
+        np.testing.assert_array_equal(st["exp_avg_sq"].cpu().numpy(), z[f"{tag}_v_{n}"], err_msg=f"{tag} exp_avg_sq {n}")
+        assert any(p is q for g_ in m.optimizer.param_groups for q in g_["params"]), n          # the optimiser holds the NEW leaf
+    np.testing.assert_array_equal(m.xyz_gradient_accum.cpu().numpy(), z[f"{tag}_accum"])
+    np.testing.assert_array_equal(m.denom.cpu().numpy(), z[f"{tag}_denom"])
+    np.testing.assert_array_equal(m.max_radii2D.cpu().numpy(), z[f"{tag}_maxr"])
+    np.testing.assert_array_equal(m._deformation_table.cpu().numpy(), z[f"{tag}_table"])
+
+
+def test_densify_prune_reset_match_the_reference_gaussian_model():
+    z = np.load(os.path.join(G, "s3g_surgery.npz"))
+    m = _model_from(z, "in")
+    ns = z["normal_z"].shape[0] // 2
+    samples = torch.tensor(z["normal_z"]).view(2, ns, 3)                       # the reference's draw: repeat(N=2) order = [replica][selected]
+    n_keep, n_clone, n_split = m.densify(float(z["max_grad"]), 0.005, float(z["extent"]), None, 5, 5, samples=samples)
+    assert n_split == ns and n_clone > 0 and n_keep + n_clone + 2 * n_split == z["dens_xyz"].shape[0]
+    _check(m, z, "dens")
+    # statistics accumulated between the events, then prune (opacity, screen size and world size criteria all fire)
+    m.max_radii2D = torch.tensor(z["prune_in_maxr"]).to(DEV)
+    m.xyz_gradient_accum = torch.tensor(z["prune_in_accum"]).to(DEV)
+    m.denom = torch.tensor(z["prune_in_denom"]).to(DEV)
+    m.prune(float(z["max_grad"]), float(z["min_opacity"]), float(z["prune_extent"]), float(z["max_screen_size"]))
+    assert m._xyz.shape[0] == z["prune_xyz"].shape[0] < z["dens_xyz"].shape[0]
+    _check(m, z, "prune")
+    m.reset_opacity()
+    for n in NAMES:
+        p = getattr(m, m._ATTR[n])
+        tol = dict(rtol=2e-6, atol=2e-6) if n == "opacity" else dict(rtol=0, atol=0)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), z[f"reset_{n}"], err_msg=n, **tol)
+        np.testing.assert_array_equal(m.optimizer.state[p]["exp_avg"].cpu().numpy(), z[f"reset_m_{n}"])
+        np.testing.assert_array_equal(m.optimizer.state[p]["exp_avg_sq"].cpu().numpy(), z[f"reset_v_{n}"])
+    # the optimiser still steps on the new leaves
+    for n in NAMES:
+        p = getattr(m, m._ATTR[n])
+        p.grad = torch.ones_like(p)
+    before = m._xyz.detach().clone()
+    m.update_learning_rate(3)
+    m.optimizer.step()
+    assert not torch.equal(before, m._xyz.detach())
+    cap = m.capture()
+    assert len(cap) == int(z["capture_len"]) == 16
+
+
+def test_philox_split_samples_are_rank_independent_and_standard_normal():
+    from emd_amd.gaussian_model import GaussianModel
+    g = torch.Generator().manual_seed(5)
+    N = 60000
+
+    def build(seed):
+        m = GaussianModel(device=DEV, densify_seed=seed)
+        m.create_from_tensors(torch.zeros(N, 3), torch.rand(N, 3, generator=torch.Generator().manual_seed(1)), torch.zeros(N, 1), spatial_lr_scale=1.0)
+        m.training_setup(_train_args())
+        m.xyz_gradient_accum = torch.ones(N, 1, device=DEV)                 # every Gaussian is "hot" and large (scale 1): all are split
+        m.denom = torch.ones(N, 1, device=DEV)
+        return m
+    a, b, c = build(11), build(11), build(12)
+    for m in (a, b, c):
+        k, cl, sp = m.densify(0.5, 0.005, 1.0, None)
+        assert (k, cl, sp) == (0, 0, N)
+    assert torch.equal(a._xyz, b._xyz), "same seed (another rank): identical samples without communication"
+    assert not torch.equal(a._xyz, c._xyz)
+    x = a._xyz.detach()                                                       # xyz = R(identity) (1 * n) + 0 = n
+    assert abs(float(x.mean())) < 0.01 and abs(float(x.std()) - 1.0) < 0.01
+    assert abs(float((x[:N] * x[N:]).mean())) < 0.01                          # the two replicas of a Gaussian are independent draws
+    assert torch.allclose(a._scaling, torch.full_like(a._scaling, float(np.log(1 / 1.6))), atol=1e-6)
+
+
+def test_training_loop_densifies_and_prunes_unattended():
+    """A config-5-style loop at small size: render -> L1 -> backward -> statistics -> Adam, with a densification every 50 steps, a
+    prune every 100 and an opacity reset at 150 -- no host-side masks, the point count moves, the loss falls."""
+    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer, RasterOptions, scenes
+    from emd_amd.gaussian_model import GaussianModel
+    from emd_amd.model import l1_loss
+    torch.manual_seed(0)
+    H, W, N = 96, 128, 6000
+    sc = scenes.make_static_scene(N, seed=3)
+    cam = scenes.small_camera(H, W)
+    means = sc.means.clone()
+    means[:, 0] = means[:, 0] * 0.25 + 1.0
+    means[:, 1] *= 0.3
+    means[:, 2] = means[:, 2] * 0.3 + 1.0
+    m = GaussianModel(device=DEV, densify_seed=1)
+    m.create_from_tensors(means, torch.rand(N, 3), sc.log_scales + 1.0, spatial_lr_scale=1.0)
+    m.active_sh_degree = 3
+    m.training_setup(_train_args(position_lr_init=1.6e-3))
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(9)).to(DEV) * 0.5 + 0.25
+    rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, torch.zeros(3, device=DEV), 1.0, cam.world_view_transform.to(DEV),
+                                       cam.full_proj_transform.to(DEV), 3, cam.camera_center.to(DEV), False, False)
+    opts = RasterOptions(compute_normal=False)
+    counts, losses = [m._xyz.shape[0]], []
+    for it in range(1, 201):
+        m.update_learning_rate(it)
+        sp = torch.zeros_like(m._xyz, requires_grad=True)
+        img, _, _, _, radii, _ = GaussianRasterizer(rs, options=opts)(means3D=m._xyz, means2D=sp, shs=m.get_features, opacities=m._opacity,
+                                                                      scales=m._scaling, rotations=m._rotation, raw_params=True)
+        loss = l1_loss(img, target)
+        loss.backward()
+        losses.append(float(loss))
+        with torch.no_grad():
+            m.add_densification_stats(sp.grad, radii)
+            if it % 50 == 0:
+                m.densify(2e-4, 0.005, 4.0, None)
+            if it % 100 == 0:
+                m.prune(2e-4, 0.005, 4.0, 20)
+            if it == 150:
+                m.reset_opacity()
+            m.optimizer.step()
+            m.optimizer.zero_grad(set_to_none=True)
+        counts.append(m._xyz.shape[0])
+    assert len(set(counts)) >= 3, counts[::25]                                  # grew and shrank
+    assert all(np.isfinite(losses)) and np.mean(losses[-10:]) < np.mean(losses[:10])
+    n = m._xyz.shape[0]
+    for t in (m._features_dc, m._features_rest, m._opacity, m._scaling, m._rotation, m._embedding, m.xyz_gradient_accum, m.denom, m.max_radii2D,
+              m._deformation_table):
+        assert t.shape[0] == n
+    for g_ in m.optimizer.param_groups:
+        st = m.optimizer.state[g_["params"][0]]
+        assert st["exp_avg"].shape == g_["params"][0].shape
+
+
+def test_ply_and_checkpoint_round_trip(tmp_path):
+    from emd_amd.gaussian_model import GaussianModel, read_ply
+    z = np.load(os.path.join(G, "s3g_surgery.npz"))
+    m = _model_from(z, "in")
+    path = str(tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply")
+    m.save_ply(path)
+    d = read_ply(path)
+    assert list(d.keys()) == [str(a) for a in z["attributes"]]                # the reference's construct_list_of_attributes()
+    m2 = GaussianModel(device=DEV)
+    m2.load_ply(path)
+    for n in NAMES:
+        assert torch.equal(getattr(m2, m2._ATTR[n]).detach(), getattr(m, m._ATTR[n]).detach()), n
+    assert m2.active_sh_degree == 3
+    ck = str(tmp_path / "chkpnt.pth")
+    torch.save((m.capture(), 123), ck)
+    model_args, it = torch.load(ck, weights_only=False)
+    m3 = GaussianModel(device=DEV)
+    m3.restore(model_args, _train_args(percent_dense=float(z["percent_dense"])))
+    assert it == 123
+    for n in NAMES:
+        p, q = getattr(m3, m3._ATTR[n]), getattr(m, m._ATTR[n])
+        assert torch.equal(p.detach(), q.detach())
+        assert torch.equal(m3.optimizer.state[p]["exp_avg"], m.optimizer.state[q]["exp_avg"])
+    assert torch.equal(m3.xyz_gradient_accum, m.xyz_gradient_accum)

@@ -196,3 +196,47 @@ def test_fused_densification_stats_match_reference_golden():
     np.testing.assert_allclose(accum.cpu().numpy(), g["accum"], rtol=1e-6)
     np.testing.assert_array_equal(denom.cpu().numpy(), g["denom"])
     np.testing.assert_array_equal(maxr.cpu().numpy(), g["maxr"])
+
+
+@pytest.mark.parametrize("frame,step", [(0, 0), (3, 12000), (4, 40000)])
+def test_fused_track_heads_match_the_checker_forward_and_backward(frame, step):
+    """emd_track_heads_forward/backward (all actors, both levels, one launch each way) against autograd through the checker's
+    restatement of rigid.py:150-246 (oracle/torch_ref.track_offsets, itself pinned by or_rigid.npz): offsets and the gradients of
+    the temporal tables, the point embeddings and all eight head tensors."""
+    from oracle import torch_ref as tr
+    z = ld("or_rigid.npz")
+    F_ = int(z["num_frames"])
+    heads = _heads_from_golden(z)
+    g = torch.Generator().manual_seed(frame + 1)
+    with torch.no_grad():                                   # larger head weights than the golden file's: well-conditioned gradients
+        for lin in (heads.track_trans_c, heads.track_trans_f, heads.track_rot_c, heads.track_rot_f):
+            lin.weight.copy_(0.3 * torch.randn(lin.weight.shape, generator=g))
+            lin.bias.copy_(0.1 * torch.randn(lin.bias.shape, generator=g))
+        heads.weight.copy_(0.5 * torch.randn(heads.weight.shape, generator=g))
+    emb = torch.tensor(z["embeddings"])
+    ids = torch.tensor(z["point_ids"].astype(np.int64))
+    A = heads.weight.shape[0]
+    gt, gr = torch.randn(A, 3, generator=g), torch.randn(A, 4, generator=g)
+    # checker (CPU autograd)
+    w0 = heads.weight.detach().clone().requires_grad_(True)
+    e0 = emb.clone().requires_grad_(True)
+    hp = {n: (getattr(heads, n).weight.detach().clone().requires_grad_(True), getattr(heads, n).bias.detach().clone().requires_grad_(True))
+          for n in ("track_rot_c", "track_rot_f", "track_trans_c", "track_trans_f")}
+    t0, r0 = tr.track_offsets(w0, hp, frame, F_, e0, ids, step)
+    ((t0 * gt).sum() + (r0 * gr).sum()).backward()
+    # product (GPU)
+    hd = heads.to(DEV)
+    e1 = emb.to(DEV).requires_grad_(True)
+    t1, r1 = hd(frame, F_, e1, ids.to(DEV), step)
+    ((t1 * gt.to(DEV)).sum() + (r1 * gr.to(DEV)).sum()).backward()
+    np.testing.assert_allclose(t1.detach().cpu().numpy(), t0.detach().numpy(), rtol=1e-5, atol=1e-5)     # 36-term fp32 dot products of O(1) terms
+    np.testing.assert_allclose(r1.detach().cpu().numpy(), r0.detach().numpy(), rtol=1e-5, atol=1e-5)
+
+    def close(a, b, what):
+        a, b = a.detach().cpu().numpy(), b.detach().numpy()
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max() + 1e-7, (what, np.abs(a - b).max(), np.abs(b).max())
+    close(hd.weight.grad, w0.grad, "temporal tables")
+    close(e1.grad, e0.grad, "embeddings")
+    for n in hp:
+        close(getattr(hd, n).weight.grad, hp[n][0].grad, n + ".weight")
+        close(getattr(hd, n).bias.grad, hp[n][1].grad, n + ".bias")

@@ -76,3 +76,4 @@ def test_oracle_alpha_and_background():
     case0["bg"] = torch.zeros(3)
     img0 = run_oracle(case0)["img"]
     np.testing.assert_allclose(img["color"] - img0["color"], img["final_T"][None] * case["bg"].numpy()[:, None, None], atol=1e-6)
+

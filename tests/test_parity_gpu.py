@@ -338,3 +338,27 @@ def test_nonfinite_gaussians_are_dropped_not_fatal():
         gp = tp[k].grad[good.to(dev)]
         assert torch.isfinite(gp).all(), k
         assert float((gp - tc[k].grad).abs().max()) <= 1e-5 * max(float(tc[k].grad.abs().max()), 1e-12), k
+
+
+def test_depth_beyond_the_three_pass_range_falls_back_to_the_wide_sort():
+    """The depth sort covers the 27 key bits above the near plane (depths up to 65 536 x near = 13 km) in three passes.  A visible
+    Gaussian farther away makes the call fail over to the four-pass sort over all 32 bits (EMD_ERR_DEPTH_RANGE -> retry with
+    EMD_FLAG_WIDE_DEPTH_SORT, remembered per camera size): the result is the oracle's, bit for bit, either way."""
+    from emd_amd import rasterizer
+    case = make_case(n=3000, H=64, W=96, seed=71)
+    m = case["means3D"]
+    m[10] = torch.tensor([20000.0, 0.0, 1.5])            # 20 km down the road, on the optical axis: visible (0.3 px dilation)
+    m[11] = torch.tensor([90000.0, 3.0, 1.5])
+    case["scales"][10:12] = 30.0
+    case["opacities"][10:12] = 0.9
+    key = (0, case["H"], case["W"])
+    rasterizer._wide_depth.discard(key)
+    orc = run_oracle(case, backward=True)
+    assert orc["pre"]["radii"][10] > 0 and orc["pre"]["radii"][11] > 0
+    hip = run_hip(case, backward=True)
+    assert key in rasterizer._wide_depth                   # the narrow sort reported the range, the wide one produced the result
+    compare_forward(hip, orc, tol=IMAGE_TOL)
+    compare_backward(hip, orc)
+    hip2 = run_hip(case, backward=False)                    # second call: wide from the start
+    np.testing.assert_array_equal(hip2["keys"], orc["bin"]["keys"])
+    rasterizer._wide_depth.discard(key)
