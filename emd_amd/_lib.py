@@ -10,7 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
+MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16
 ACTOR_STRIDE = 12
@@ -38,7 +39,7 @@ class EmdMotion(C.Structure):
 
 class EmdDims(C.Structure):
     _fields_ = [("num_gaussians", C.c_int32), ("image_height", C.c_int32), ("image_width", C.c_int32),
-                ("bin_capacity", C.c_int64), ("flags", C.c_int32)]
+                ("bin_capacity", C.c_int64), ("flags", C.c_int32), ("num_extra", C.c_int32)]
 
 
 class EmdFwdArgs(C.Structure):
@@ -49,7 +50,8 @@ class EmdFwdArgs(C.Structure):
                 ("out_color", _f), ("out_depth", _f), ("out_normal", _f), ("out_alpha", _f), ("radii", _f),
                 ("geom_ws", _f), ("geom_bytes", C.c_size_t), ("bin_ws", _f), ("bin_bytes", C.c_size_t),
                 ("img_ws", _f), ("img_bytes", C.c_size_t), ("status", _f),
-                ("num_rendered", C.c_int64), ("num_visible", C.c_int64), ("settings_dev", _f)]
+                ("num_rendered", C.c_int64), ("num_visible", C.c_int64), ("settings_dev", _f),
+                ("num_extra", C.c_int32), ("colors_extra", _f * 2), ("out_extra", _f * 2)]
 
 
 class EmdBwdArgs(C.Structure):
@@ -65,7 +67,8 @@ class EmdBwdArgs(C.Structure):
                 ("dL_dmeans3D", _f), ("dL_dmeans2D", _f), ("dL_dmeans2D_abs", _f), ("dL_dshs", _f),
                 ("dL_dcolors", _f), ("dL_dopacities", _f), ("dL_dscales", _f), ("dL_drotations", _f),
                 ("dL_dcov3D", _f), ("dL_dactor_pose", _f), ("dL_dresidual_dx", _f), ("dL_dresidual_dq", _f),
-                ("dL_dsh_color", _f), ("settings_dev", _f)]
+                ("dL_dsh_color", _f), ("settings_dev", _f),
+                ("num_extra", C.c_int32), ("colors_extra", _f * 2), ("out_extra", _f * 2), ("dL_dextra", _f * 2), ("dL_dcolors_extra", _f * 2)]
 
 
 SKY_CLAMP01, SKY_BLEND_S3G, SKY_BLEND_ADD, SKY_INTERLEAVED = 1, 2, 4, 8
@@ -259,8 +262,8 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def workspace_sizes(N, H, W, capacity, flags=0):
-    d = EmdDims(int(N), int(H), int(W), int(capacity), int(flags))
+def workspace_sizes(N, H, W, capacity, flags=0, num_extra=0):
+    d = EmdDims(int(N), int(H), int(W), int(capacity), int(flags), int(num_extra))
     out = (C.c_size_t * 4)()
     check(load().emd_raster_workspace_size(C.byref(d), out), "emd_raster_workspace_size")
     return tuple(int(x) for x in out)

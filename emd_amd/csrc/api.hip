@@ -128,7 +128,8 @@ int emd_raster_workspace_size(const EmdDims* dims, size_t out[4]) {
     emd_carve_bin(nullptr, dims->bin_capacity, gx * gy, &b);
     emd_carve_img(nullptr, dims->image_height, dims->image_width, &im);
     out[0] = g.bytes; out[1] = b.bytes; out[2] = im.bytes;
-    out[3] = (size_t)(dims->num_gaussians > 0 ? dims->num_gaussians : 1) * EMD_BWD_STRIDE * sizeof(float);
+    if (dims->num_extra < 0 || dims->num_extra > EMD_MAX_EXTRA) { emd_set_error("workspace_size: num_extra %d not in 0..%d", dims->num_extra, EMD_MAX_EXTRA); return EMD_ERR_INVALID; }
+    out[3] = (size_t)(dims->num_gaussians > 0 ? dims->num_gaussians : 1) * emd_bwd_stride(dims->num_extra) * sizeof(float);
     return EMD_OK;
 }
 
@@ -165,6 +166,9 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
     }
     if ((a->flags & EMD_FLAG_NORMAL) && !a->out_normal) { emd_set_error("forward: EMD_FLAG_NORMAL without out_normal"); return EMD_ERR_INVALID; }
     if (a->bin_capacity < 0) { emd_set_error("forward: negative bin_capacity"); return EMD_ERR_INVALID; }
+    if (a->num_extra < 0 || a->num_extra > EMD_MAX_EXTRA) { emd_set_error("forward: num_extra %d not in 0..%d", a->num_extra, EMD_MAX_EXTRA); return EMD_ERR_INVALID; }
+    for (int k = 0; k < a->num_extra; k++)
+        if (!a->colors_extra[k] || !a->out_extra[k]) { emd_set_error("forward: extra colour set %d: null colours / output", k); return EMD_ERR_INVALID; }
     if ((a->flags & EMD_FLAG_SDEV_TANFOV) && !a->settings_dev) { emd_set_error("forward: EMD_FLAG_SDEV_TANFOV without settings_dev"); return EMD_ERR_INVALID; }
     const int gx = (a->s.image_width + EMD_TILE_X - 1) / EMD_TILE_X, gy = (a->s.image_height + EMD_TILE_Y - 1) / EMD_TILE_Y;
     GeomWs g; BinWs b; ImgWs im;
@@ -213,7 +217,11 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
         }
     }
     emd_prof_switch(PROF_RANGES, PROF_RENDER_FWD, st);
-    rc = emd_launch_render_forward(a->s, a->settings_dev, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->out_alpha, st);
+    EmdExtra ex;
+    memset(&ex, 0, sizeof(ex));
+    ex.num = a->num_extra;
+    for (int k = 0; k < a->num_extra; k++) { ex.colors[k] = a->colors_extra[k]; ex.out[k] = a->out_extra[k]; }
+    rc = emd_launch_render_forward(a->s, a->settings_dev, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->out_alpha, &ex, st);
     emd_prof_end(PROF_RENDER_FWD, st);
     if (rc) return rc;
     STAGE_SYNC("render_forward");
@@ -235,7 +243,8 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     emd_carve_geom((void*)a->geom_ws, N, &g);
     emd_carve_bin((void*)a->bin_ws, a->bin_capacity, gx * gy, &b);
     emd_carve_img((void*)a->img_ws, a->s.image_height, a->s.image_width, &im);
-    const size_t need = (size_t)(N > 0 ? N : 1) * EMD_BWD_STRIDE * sizeof(float);
+    if (a->num_extra < 0 || a->num_extra > EMD_MAX_EXTRA) { emd_set_error("backward: num_extra %d not in 0..%d", a->num_extra, EMD_MAX_EXTRA); return EMD_ERR_INVALID; }
+    const size_t need = (size_t)(N > 0 ? N : 1) * emd_bwd_stride(a->num_extra) * sizeof(float);
     if (g.bytes > a->geom_bytes || b.bytes > a->bin_bytes || im.bytes > a->img_bytes || need > a->bwd_bytes) {
         emd_set_error("backward: workspace too small"); return EMD_ERR_WORKSPACE;
     }
@@ -250,8 +259,15 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
         pose_grad_n = a->motion.num_actors * EMD_ACTOR_STRIDE;
     }
     emd_prof_switch(PROF_OTHER, PROF_RENDER_BWD, st);
+    EmdExtra ex;
+    memset(&ex, 0, sizeof(ex));
+    ex.num = a->num_extra;
+    for (int k = 0; k < a->num_extra; k++) {
+        if (!a->colors_extra[k] || !a->out_extra[k]) { emd_set_error("backward: extra colour set %d: null colours / forward output", k); return EMD_ERR_INVALID; }
+        ex.colors[k] = a->colors_extra[k]; ex.out[k] = (float*)a->out_extra[k]; ex.dL_dout[k] = a->dL_dextra[k];
+    }
     rc = emd_launch_render_backward(a->s, a->settings_dev, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->dL_dcolor,
-                                    a->dL_ddepth, a->dL_dalpha, a->dL_dnormal, (float*)a->bwd_ws, pose_grad, pose_grad_n, st);
+                                    a->dL_ddepth, a->dL_dalpha, a->dL_dnormal, &ex, (float*)a->bwd_ws, pose_grad, pose_grad_n, st);
     if (rc) return rc;
     STAGE_SYNC("render_backward");
     PreBwdArgs pb;
@@ -266,6 +282,8 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     pb.dL_dactor_pose = a->dL_dactor_pose; pb.dL_dresidual_dx = a->dL_dresidual_dx; pb.dL_dresidual_dq = a->dL_dresidual_dq;
     pb.dL_dsh_color = a->dL_dsh_color;
     pb.sdev = a->settings_dev;
+    pb.bwd_stride = emd_bwd_stride(a->num_extra); pb.num_extra = a->num_extra;
+    for (int k = 0; k < EMD_MAX_EXTRA; k++) pb.dL_dextra[k] = k < a->num_extra ? a->dL_dcolors_extra[k] : nullptr;
     emd_prof_switch(PROF_RENDER_BWD, PROF_PREPROCESS_BWD, st);
     rc = emd_launch_preprocess_backward(pb, st);
     emd_prof_end(PROF_PREPROCESS_BWD, st);

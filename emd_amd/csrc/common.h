@@ -163,13 +163,22 @@ int emd_launch_preprocess(const PreArgs& a, hipStream_t st);                 // 
 int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,
                        hipStream_t st);                                       // binning.hip
 int emd_launch_export_keys(int64_t D, const GeomWs& g, const BinWs& b, uint64_t* keys, hipStream_t st);  // binning.hip
+// extra colour sets composited by the same list walk as the main colours (EmdFwdArgs.colors_extra ...)
+struct EmdExtra {
+    int num;
+    const float* colors[EMD_MAX_EXTRA];    // [N,3]
+    float* out[EMD_MAX_EXTRA];             // [3,H,W]
+    const float* dL_dout[EMD_MAX_EXTRA];   // [3,H,W] or null (backward)
+};
+// accumulator row of the render backward: EMD_BWD_STRIDE floats + (r, g, b, -) per extra colour set
+static inline int emd_bwd_stride(int num_extra) { return EMD_BWD_STRIDE + 4 * num_extra; }
 int emd_launch_render_forward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
-                              float* out_color, float* out_depth, float* out_normal, float* out_alpha,
+                              float* out_color, float* out_depth, float* out_normal, float* out_alpha, const EmdExtra* x,
                               hipStream_t st);                                 // render.hip
 int emd_launch_render_backward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                                const float* out_color, const float* out_depth, const float* out_normal,
                                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                               const float* dL_dnormal, float* grad_rec, float* zero_buf, int zero_n,
+                               const float* dL_dnormal, const EmdExtra* x, float* grad_rec, float* zero_buf, int zero_n,
                                hipStream_t st);  // render.hip (zero_buf: small table cleared by block 0 for K8)
 struct PreBwdArgs {
     EmdSettings s;
@@ -178,7 +187,9 @@ struct PreBwdArgs {
     EmdMotion motion;
     const int32_t* radii;
     GeomWs g;
-    const float* grad_rec;  // [N][EMD_BWD_STRIDE]
+    const float* grad_rec;  // [N][bwd_stride]
+    int bwd_stride, num_extra;
+    float* dL_dextra[EMD_MAX_EXTRA];   // [N,3] gradient of every extra colour set
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dmeans2D_abs, *dL_dshs, *dL_dcolors, *dL_dopacities, *dL_dscales,
         *dL_drotations, *dL_dcov3D, *dL_dactor_pose, *dL_dresidual_dx, *dL_dresidual_dq, *dL_dsh_color;
     const float* sdev;

@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
         }
         float gcol[3] = {0.f, 0.f, 0.f}, sh_gc[3] = {0.f, 0.f, 0.f};
         if (visible) {
-            const float4* gr = (const float4*)(a.grad_rec + (size_t)i * EMD_BWD_STRIDE);
+            const float4* gr = (const float4*)(a.grad_rec + (size_t)i * a.bwd_stride);
             const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2];
             const uint32_t bits = __float_as_uint(a.g.rec[(size_t)i * EMD_REC_F4 + 1].w);
             gm2[0] = g0.x; gm2[1] = g0.y;
@@ -678,6 +678,12 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a)
         if (a.dL_dmeans2D_abs) { a.dL_dmeans2D_abs[2 * i] = gabs[0]; a.dL_dmeans2D_abs[2 * i + 1] = gabs[1]; }
         if (a.dL_dsh_color) { a.dL_dsh_color[3 * i] = sh_gc[0]; a.dL_dsh_color[3 * i + 1] = sh_gc[1]; a.dL_dsh_color[3 * i + 2] = sh_gc[2]; }
         if (a.dL_dcolors) { a.dL_dcolors[3 * i] = gcol[0]; a.dL_dcolors[3 * i + 1] = gcol[1]; a.dL_dcolors[3 * i + 2] = gcol[2]; }
+        for (int k = 0; k < a.num_extra; k++) {           // extra colour sets: the accumulated dL/d colour is the gradient of the input itself
+            if (!a.dL_dextra[k]) continue;
+            float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (visible) gx = *(const float4*)(a.grad_rec + (size_t)i * a.bwd_stride + EMD_BWD_STRIDE + 4 * k);
+            a.dL_dextra[k][3 * i] = gx.x; a.dL_dextra[k][3 * i + 1] = gx.y; a.dL_dextra[k][3 * i + 2] = gx.z;
+        }
         if (a.dL_dcov3D) {
 #pragma unroll
             for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * i + k] = dc6[k];

@@ -23,6 +23,10 @@ struct RenderDims {
     int W, H, gx, gy;
     float bg[3];
     const float* bg_dev;     // device copy of the background colour (EmdFwdArgs.settings_dev) or null
+    // extra colour sets composited by the same list walk (EmdFwdArgs.colors_extra): [N,3] inputs, [3,H,W] outputs, no background
+    const float* xcol[EMD_MAX_EXTRA];
+    float* xout[EMD_MAX_EXTRA];
+    const float* xgrad[EMD_MAX_EXTRA];      // dL/d(extra image) [3,H,W] or null (backward)
 };
 
 // blockIdx -> (tile, quadrant).  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one).  The tiles are
@@ -146,7 +150,7 @@ __device__ __forceinline__ uint32_t quad_subblock_mask(const float4& r0, const f
     return (c0 && w0 ? 1u : 0u) | (c1 && w0 ? 2u : 0u) | (c0 && w1 ? 4u : 0u) | (c1 && w1 ? 8u : 0u);
 }
 
-template <bool NORMAL>
+template <bool NORMAL, int NX>
 __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ ranges,
                                                                const uint32_t* __restrict__ point_list,
                                                                const float4* __restrict__ rec, float* __restrict__ out_color,
@@ -156,6 +160,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
 #pragma clang fp contract(off)   // the forward image is a bit-exact contract: only the explicit fma calls below fuse
     __shared__ float4 s0[FQ_RING], s1[FQ_RING], s2[FQ_RING];
     __shared__ float4 s3[NORMAL ? FQ_RING : 1];
+    __shared__ float4 sx[NX ? NX : 1][NX ? FQ_RING : 1];       // extra colour sets: (r, g, b, -) per ring slot
     __shared__ uint8_t s_list[4][FQ_RING];
     uint32_t quad;
     const uint32_t tile = ordered_quadrant_block(blockIdx.x, (uint32_t)(d.gx * d.gy), tile_order, &quad);
@@ -170,14 +175,23 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
     const uint32_t start = ranges[2 * tile], n_tile = ranges[2 * tile + 1] - start;
     bool done = !inside;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+    float X[NX ? NX : 1][3];
+#pragma unroll
+    for (int k = 0; k < (NX ? NX : 1); k++) X[k][0] = X[k][1] = X[k][2] = 0.f;
     uint32_t last = 0;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 p0 = zero4, p1 = zero4, p2 = zero4, p3 = zero4;
+    float4 px_[NX ? NX : 1];
+#pragma unroll
+    for (int k = 0; k < (NX ? NX : 1); k++) px_[k] = zero4;
     if (lane < n_tile) {
-        const float4* r = rec + (size_t)point_list[start + lane] * EMD_REC_F4;
+        const uint32_t gid = point_list[start + lane];
+        const float4* r = rec + (size_t)gid * EMD_REC_F4;
         p0 = r[0]; p1 = r[1]; p2 = r[2];
         if (NORMAL) p3 = r[3];
+#pragma unroll
+        for (int k = 0; k < NX; k++) { const float* c = d.xcol[k] + 3 * (size_t)gid; px_[k] = make_float4(c[0], c[1], c[2], 0.f); }
     }
     uint32_t scanned = 0;
     while (scanned < n_tile) {
@@ -188,10 +202,16 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
             const uint32_t idx = scanned + lane;
             const float4 c0r = p0, c1r = p1, c3r = p3;
             float4 c2r = p2;
+            float4 cxr[NX ? NX : 1];
+#pragma unroll
+            for (int k = 0; k < NX; k++) cxr[k] = px_[k];
             if (idx + EMD_WAVE < n_tile) {
-                const float4* r = rec + (size_t)point_list[start + idx + EMD_WAVE] * EMD_REC_F4;
+                const uint32_t gid = point_list[start + idx + EMD_WAVE];
+                const float4* r = rec + (size_t)gid * EMD_REC_F4;
                 p0 = r[0]; p1 = r[1]; p2 = r[2];
                 if (NORMAL) p3 = r[3];
+#pragma unroll
+                for (int k = 0; k < NX; k++) { const float* c = d.xcol[k] + 3 * (size_t)gid; px_[k] = make_float4(c[0], c[1], c[2], 0.f); }
             }
             const uint32_t m4 = idx < n_tile ? quad_subblock_mask(c0r, c1r, qx0, qy0) : 0u;
             const unsigned long long bal = __ballot(m4 != 0u);
@@ -200,6 +220,8 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
                 c2r.w = __uint_as_float(idx + 1);           // 1-based position in the tile list
                 s0[slot] = c0r; s1[slot] = c1r; s2[slot] = c2r;
                 if (NORMAL) s3[slot] = c3r;
+#pragma unroll
+                for (int k = 0; k < NX; k++) sx[k][slot] = cxr[k];
             }
             const unsigned long long b0 = __ballot(m4 & 1u), b1 = __ballot(m4 & 2u), b2 = __ballot(m4 & 4u), b3 = __ballot(m4 & 8u);
             if (m4 & 1u) s_list[0][len0 + (uint32_t)__popcll(b0 & lt)] = (uint8_t)slot;
@@ -238,6 +260,11 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
                     const float4 g3 = s3[j];
                     N0 = __builtin_fmaf(g3.x, w, N0); N1 = __builtin_fmaf(g3.y, w, N1); N2 = __builtin_fmaf(g3.z, w, N2);
                 }
+#pragma unroll
+                for (int k = 0; k < NX; k++) {          // the same fma as the main colour: an extra set equals a separate call bit for bit
+                    const float4 gx = sx[k][j];
+                    X[k][0] = __builtin_fmaf(gx.x, w, X[k][0]); X[k][1] = __builtin_fmaf(gx.y, w, X[k][1]); X[k][2] = __builtin_fmaf(gx.z, w, X[k][2]);
+                }
                 T = take ? test_T : T;
                 last = take ? __float_as_uint(g2.w) : last;
                 done = done || stop;
@@ -253,6 +280,12 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
         out_color[2 * HW + pix] = __builtin_fmaf(T, bg2, C2);
         out_depth[pix] = Dz;
         if (NORMAL) { out_normal[pix] = N0; out_normal[HW + pix] = N1; out_normal[2 * HW + pix] = N2; }
+#pragma unroll
+        for (int k = 0; k < NX; k++) {           // colour + T_final * bg with the same bg, as a separate call with this colour set gives
+            d.xout[k][pix] = __builtin_fmaf(T, bg0, X[k][0]);
+            d.xout[k][HW + pix] = __builtin_fmaf(T, bg1, X[k][1]);
+            d.xout[k][2 * HW + pix] = __builtin_fmaf(T, bg2, X[k][2]);
+        }
         out_alpha[pix] = 1.f - T;
         final_T[pix] = T;
         n_contrib[pix] = last;
@@ -267,12 +300,14 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
 // v_add_f32_dpp per entry and wave) costs as much as all the arithmetic (measured: profiles/r01_ablation.txt).
 // Here the roles are swapped: a lane owns one list ENTRY of the wave's quadrant list, the wave loops over the 64
 // PIXELS of its quadrant, and the per-pixel recurrences become wave prefix scans in list order:
-//     T_k  = prod_{i<k} (1 - alpha_i)                 exclusive scan-product   (6 v_mul_f32_dpp + 1 wave_shr)
-//     S_k  = sum_{i<=k} g_i alpha_i T_i               inclusive scan-sum       (6 v_add_f32_dpp)
-//     dL/dalpha_k = g_k T_k + (Q + S_k) / (1 - alpha_k),   g = colour . dL/dC + depth dL/dD (+ normal . dL/dN),
-//     Q = T_final (dL/dalpha_img - bg . dL/dC) - S_total,  S_total from the forward outputs.
-// (algebraically the upstream gradient: sum_{i>k} g_i alpha_i T_i = S_total - S_k; no T / (1 - alpha)
-// reconstruction by division).  The ten derivative sums then accumulate in the lane's registers over the 64 pixels
+// The list is walked back to front, as upstream does, so lane 0 of a batch is its deepest entry:
+//     T_k  = T_final / prod_{i>=k} (1 - alpha_i)      inclusive scan-product of the reciprocals   (6 v_mul_f32_dpp)
+//     R_k  = sum_{i>k} g_i alpha_i T_i                exclusive scan-sum                          (6 v_add_f32_dpp + 1 wave_shr)
+//     dL/dalpha_k = g_k T_k + (Q - R_k) / (1 - alpha_k),   g = colour . dL/dC + depth dL/dD (+ normal . dL/dN),
+//     Q = T_final (dL/dalpha_img - bg . dL/dC).
+// Both running quantities shrink with the transmittance of the entry they are used for, so every (pixel, Gaussian) partial
+// carries a RELATIVE rounding error (a first version ran front to back with S_k = sum_{i<=k} and the forward image's total:
+// the difference total - S_k left an absolute error of eps x total on entries whose own weight was a thousandth of it).  The ten derivative sums then accumulate in the lane's registers over the 64 pixels
 // with no cross-lane traffic at all; per 64 (pixel, entry) pairs the wave spends 13 DPP ops instead of 60.
 // Running T and S per pixel are carried across batches of 64 entries in LDS (broadcast loads, one-lane store).
 // ---------------------------------------------------------------------------------------------------
@@ -290,8 +325,8 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
 // ---------------------------------------------------------------------------------------------------
 #define BQ_QUEUE 128
 
-template <bool NORMAL, bool ABS>
-__global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4))) k_render_backward_q(RenderDims d, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ ranges,
+template <bool NORMAL, bool ABS, int NX>
+__global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(NX ? 3 : 4))) k_render_backward_q(RenderDims d, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ point_list,
                                                                 const float4* __restrict__ rec,
                                                                 const float* __restrict__ final_T,
@@ -310,7 +345,9 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
         for (int i = threadIdx.x; i < zero_n; i += EMD_WAVE) zero_buf[i] = 0.f;
     // queue slot s lives in half s>>6: the gradient staging tile (64 rows x 12 floats = 3 KB) overlays the records of
     // the lower half, which are dead (held in registers) by the time a batch's gradients are staged.
-    constexpr int NR = NORMAL ? 4 : 3;
+    constexpr int NRB = NORMAL ? 4 : 3, NR = NRB + NX;           // record planes: r0, r1, r2 (, r3), one per extra colour set
+    constexpr int STRIDE = EMD_BWD_STRIDE + 4 * NX;             // accumulator row: 12 floats + (r, g, b, -) per extra set
+    constexpr int PB = NORMAL ? 6 : 4;                          // s_pix planes of the main call; two more per extra set
     __shared__ float4 q_rec[2][NR][EMD_WAVE];
     __shared__ uint32_t q_id[BQ_QUEUE], q_pos[BQ_QUEUE];
     float* const s_stage = reinterpret_cast<float*>(&q_rec[0][0][0]);
@@ -319,7 +356,8 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
     // Pixels are handled in horizontal pairs (a, b) = (2 pp, 2 pp + 1); every quantity is stored as the pair:
     //   [pp][0] = (dC0 a,b | dC1 a,b)  [pp][1] = (dC2 a,b | dD a,b)  [pp][2] = (running T a,b | running S a,b)
     //   [pp][3] = (Q a,b | -)          [pp][4] = (dN0 a,b | dN1 a,b) [pp][5] = (dN2 a,b | -)
-    __shared__ float4 s_pix[EMD_WAVE / 2][NORMAL ? 6 : 4];
+    //   [pp][PB + 2k] = (dX_k0 a,b | dX_k1 a,b)  [pp][PB + 2k + 1] = (dX_k2 a,b | -)     gradients of extra colour set k
+    __shared__ float4 s_pix[EMD_WAVE / 2][PB + 2 * NX];
 #define QREC(r, s) q_rec[(s) >> 6][r][(s) & 63]
     uint32_t quad;
     const uint32_t tile = ordered_quadrant_block(blockIdx.x, (uint32_t)(d.gx * d.gy), tile_order, &quad);
@@ -336,30 +374,37 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
     for (int off = 32; off; off >>= 1) wave_n = max(wave_n, (uint32_t)__shfl_xor((int)wave_n, off));
     wave_n = min(wave_n, end - start);       // deepest contributor of THIS quadrant
     if (wave_n == 0) return;
-    float dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dN0 = 0.f, dN1 = 0.f, dN2 = 0.f, Q = 0.f;
+    float dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dN0 = 0.f, dN1 = 0.f, dN2 = 0.f, Q = 0.f, Tf = 1.f;
+    float dX[NX ? NX : 1][3];
+#pragma unroll
+    for (int k = 0; k < (NX ? NX : 1); k++) dX[k][0] = dX[k][1] = dX[k][2] = 0.f;
     if (inside) {
-        const float Tf = final_T[pix];
+        Tf = final_T[pix];
         float dA = 0.f;
         if (dL_dcolor) { dC0 = dL_dcolor[pix]; dC1 = dL_dcolor[HW + pix]; dC2 = dL_dcolor[2 * HW + pix]; }
         if (dL_ddepth) dD = dL_ddepth[pix];
         if (dL_dalpha) dA = dL_dalpha[pix];
         if (NORMAL && dL_dnormal) { dN0 = dL_dnormal[pix]; dN1 = dL_dnormal[HW + pix]; dN2 = dL_dnormal[2 * HW + pix]; }
         const float bg0 = d.bg_dev ? d.bg_dev[0] : d.bg[0], bg1 = d.bg_dev ? d.bg_dev[1] : d.bg[1], bg2 = d.bg_dev ? d.bg_dev[2] : d.bg[2];
-        const float bgdot = bg0 * dC0 + bg1 * dC1 + bg2 * dC2;
-        float Stot = (out_color[pix] - Tf * bg0) * dC0 + (out_color[HW + pix] - Tf * bg1) * dC1 +
-                     (out_color[2 * HW + pix] - Tf * bg2) * dC2 + out_depth[pix] * dD;
-        if (NORMAL && dL_dnormal) Stot += out_normal[pix] * dN0 + out_normal[HW + pix] * dN1 + out_normal[2 * HW + pix] * dN2;
-        Q = Tf * (dA - bgdot) - Stot;
+        float bgdot = bg0 * dC0 + bg1 * dC1 + bg2 * dC2;
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            if (!d.xgrad[k]) continue;
+            dX[k][0] = d.xgrad[k][pix]; dX[k][1] = d.xgrad[k][HW + pix]; dX[k][2] = d.xgrad[k][2 * HW + pix];
+            bgdot += bg0 * dX[k][0] + bg1 * dX[k][1] + bg2 * dX[k][2];
+        }
+        Q = Tf * (dA - bgdot);              // background and alpha image: both depend on T_final = prod (1 - alpha_i)
     }
     {
         float* sp = reinterpret_cast<float*>(&s_pix[lane >> 1][0]) + (lane & 1);
         sp[0] = dC0; sp[2] = dC1; sp[4] = dC2; sp[6] = dD;
-        sp[8] = 1.f; sp[10] = 0.f;      // running transmittance / running S, carried across batches
+        sp[8] = Tf; sp[10] = 0.f;       // transmittance behind / weighted colour behind the entries processed so far (back to front)
         sp[12] = Q; sp[14] = 0.f;
         if (NORMAL) { sp[16] = dN0; sp[18] = dN1; sp[20] = dN2; sp[22] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < NX; k++) { float* sx_ = sp + 4 * (PB + 2 * k); sx_[0] = dX[k][0]; sx_[2] = dX[k][1]; sx_[4] = dX[k][2]; sx_[6] = 0.f; }
     }
     __syncthreads();
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // One batch: lane = queue slot.
@@ -369,14 +414,20 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
         const float4 g0 = QREC(0, sl), g1 = QREC(1, sl), g2 = QREC(2, sl);
         float4 g3 = zero4;
         if (NORMAL) g3 = QREC(3, sl);
+        float4 gxc[NX ? NX : 1];
+#pragma unroll
+        for (int k = 0; k < NX; k++) gxc[k] = QREC(NRB + k, sl);
+        v2f xr_2[NX ? NX : 1], xg_2[NX ? NX : 1], xb_2[NX ? NX : 1];
+#pragma unroll
+        for (int k = 0; k < (NX ? NX : 1); k++) xr_2[k] = xg_2[k] = xb_2[k] = splat2(0.f);
         const uint32_t pos = q_pos[sl];
-        const uint32_t first_pos = readlane_u32(pos, 0);
+        const uint32_t last_pos = readlane_u32(pos, (int)nb - 1);     // the queue runs back to front: lane nb-1 is the shallowest entry
         const v2f z2 = splat2(0.f);
         v2f m0_2 = z2, gx_2 = z2, gy_2 = z2, m2xx_2 = z2, m2xy_2 = z2, m2yy_2 = z2, dz_2 = z2, r_2 = z2, g_2 = z2, b_2 = z2;
         float a_ax = 0.f, a_ay = 0.f;
         for (int pp = 0; pp < EMD_WAVE / 2; pp++) {
             const uint32_t n_a = readlane_u32(my_n, 2 * pp), n_b = readlane_u32(my_n, 2 * pp + 1);
-            if (max(n_a, n_b) <= first_pos) continue;            // both pixels terminated before this batch
+            if (max(n_a, n_b) <= last_pos) continue;             // both pixels terminated before the shallowest entry of this batch
             const float4 c01 = s_pix[pp][0], c2d = s_pix[pp][1], ts = s_pix[pp][2], qq = s_pix[pp][3];
             const float pxs = qx0 + (float)((2 * pp) & 7), pys = qy0 + (float)(pp >> 2);
             const float dy = g0.y - pys;
@@ -390,10 +441,13 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
             if (__ballot(hit_a || hit_b) == 0ull) continue;
             const v2f a = (v2f){hit_a ? alpha.x : 0.f, hit_b ? alpha.y : 0.f};
             const v2f om = splat2(1.f) - a;
-            float t_a = om.x, t_b = om.y;
+            const v2f inv = (v2f){__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+            // lane 0 is the DEEPEST entry of the batch.  T_k (in front of entry k) = T_behind / prod_{entries from k to the back} (1 - alpha):
+            // an inclusive prefix product of the reciprocals over the lanes, times the value carried from the batches behind
+            float t_a = inv.x, t_b = inv.y;
             wave_scan_mul2_f32_asm(t_a, t_b);
-            const v2f cT = (v2f){ts.x, ts.y}, cS = (v2f){ts.z, ts.w};
-            const v2f Tk = cT * (v2f){wave_shift_up1_f32(t_a, 1.f), wave_shift_up1_f32(t_b, 1.f)};
+            const v2f cT = (v2f){ts.x, ts.y}, cR = (v2f){ts.z, ts.w};
+            const v2f Tk = cT * (v2f){t_a, t_b};
             const v2f w = a * Tk;
             v2f g = splat2(g2.x) * (v2f){c01.x, c01.y} + splat2(g2.y) * (v2f){c01.z, c01.w} + splat2(g2.z) * (v2f){c2d.x, c2d.y} +
                     splat2(g0.z) * (v2f){c2d.z, c2d.w};
@@ -401,12 +455,19 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
                 const float4 n01 = s_pix[pp][4], n2 = s_pix[pp][5];
                 g += splat2(g3.x) * (v2f){n01.x, n01.y} + splat2(g3.y) * (v2f){n01.z, n01.w} + splat2(g3.z) * (v2f){n2.x, n2.y};
             }
+            float4 x01[NX ? NX : 1], x2_[NX ? NX : 1];
+#pragma unroll
+            for (int k = 0; k < NX; k++) {
+                x01[k] = s_pix[pp][PB + 2 * k]; x2_[k] = s_pix[pp][PB + 2 * k + 1];
+                g += splat2(gxc[k].x) * (v2f){x01[k].x, x01[k].y} + splat2(gxc[k].y) * (v2f){x01[k].z, x01[k].w} + splat2(gxc[k].z) * (v2f){x2_[k].x, x2_[k].y};
+            }
+            // R_k = sum over the entries BEHIND k of g_i alpha_i T_i: exclusive prefix sum over the lanes + the carried value
             const v2f gw = g * w;
             float s_a = gw.x, s_b = gw.y;
             wave_scan_add2_f32_asm(s_a, s_b);
-            const v2f Sk = cS + (v2f){s_a, s_b};
-            const v2f inv = (v2f){__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-            v2f dL_da = g * Tk + inv * ((v2f){qq.x, qq.y} + Sk);
+            const v2f Rk = cR + (v2f){wave_shift_up1_f32(s_a, 0.f), wave_shift_up1_f32(s_b, 0.f)};
+            // dL/dalpha_k = g_k T_k - R_k / (1 - alpha_k) + T_final (dL/dalpha_img - bg . dL/dC) / (1 - alpha_k)
+            v2f dL_da = g * Tk + inv * ((v2f){qq.x, qq.y} - Rk);
             dL_da = (v2f){hit_a ? dL_da.x : 0.f, hit_b ? dL_da.y : 0.f};
             const v2f u = G * (splat2(g0.w) * dL_da);           // G dL/dG
             const v2f ux = u * dx, uy = u * splat2(dy);
@@ -421,80 +482,100 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
             if (ABS) { a_ax += fabsf(ax.x) + fabsf(ax.y); a_ay += fabsf(ay.x) + fabsf(ay.y); }
             dz_2 += w * (v2f){c2d.z, c2d.w};
             r_2 += w * (v2f){c01.x, c01.y}; g_2 += w * (v2f){c01.z, c01.w}; b_2 += w * (v2f){c2d.x, c2d.y};
-            // lane 63 holds the batch totals: carry the running T and S of both pixels to the next batch
-            if (lane == 63) s_pix[pp][2] = make_float4(cT.x * t_a, cT.y * t_b, Sk.x, Sk.y);
+#pragma unroll
+            for (int k = 0; k < NX; k++) {
+                xr_2[k] += w * (v2f){x01[k].x, x01[k].y}; xg_2[k] += w * (v2f){x01[k].z, x01[k].w}; xb_2[k] += w * (v2f){x2_[k].x, x2_[k].y};
+            }
+            // lane 63 holds the batch totals: carry the transmittance and the weighted colour in front of this batch to the next one
+            if (lane == 63) s_pix[pp][2] = make_float4(cT.x * t_a, cT.y * t_b, cR.x + s_a, cR.y + s_b);
         }
         const float m0 = m0_2.x + m0_2.y, gx = gx_2.x + gx_2.y, gy = gy_2.x + gy_2.y, m2xx = m2xx_2.x + m2xx_2.y,
                     m2xy = m2xy_2.x + m2xy_2.y, m2yy = m2yy_2.x + m2yy_2.y, a_dz = dz_2.x + dz_2.y, a_r = r_2.x + r_2.y,
                     a_g = g_2.x + g_2.y, a_b = b_2.x + b_2.y;
         // rows through LDS so that consecutive lanes add consecutive floats of one 48-byte accumulator row
         __syncthreads();   // every lane holds its record in registers: the lower half may be overwritten
-        float4* row = reinterpret_cast<float4*>(s_stage + lane * EMD_BWD_STRIDE);
+        float4* row = reinterpret_cast<float4*>(s_stage + lane * STRIDE);
         row[0] = make_float4(-gx, -gy, a_dz, m0 * __builtin_amdgcn_rcpf(g0.w));
         row[1] = make_float4(-0.5f * m2xx, -m2xy, -0.5f * m2yy, a_r);
         row[2] = make_float4(a_g, a_b, ABS ? a_ax : 0.f, ABS ? a_ay : 0.f);
+#pragma unroll
+        for (int k = 0; k < NX; k++) row[3 + k] = make_float4(xr_2[k].x + xr_2[k].y, xg_2[k].x + xg_2[k].y, xb_2[k].x + xb_2[k].y, 0.f);
         __syncthreads();
-        for (uint32_t idx = lane; idx < nb * EMD_BWD_STRIDE; idx += EMD_WAVE) {
-            const uint32_t e = idx / EMD_BWD_STRIDE, v = idx % EMD_BWD_STRIDE;
+        for (uint32_t idx = lane; idx < nb * STRIDE; idx += EMD_WAVE) {
+            const uint32_t e = idx / STRIDE, v = idx % STRIDE;
             const float val = s_stage[idx];
-            if (val != 0.f) atomicAdd(grad_rec + (size_t)q_id[e] * EMD_BWD_STRIDE + v, val);
+            if (val != 0.f) atomicAdd(grad_rec + (size_t)q_id[e] * STRIDE + v, val);
         }
         __syncthreads();
     };
 
+    // The list is walked BACK TO FRONT (from the deepest contributor of this quadrant), 64 entries per step.
     // Software pipeline of the list scan: Gaussian ids three steps ahead, records two steps ahead of the step being
     // queued, so the dependent id -> record gather (two L2 round trips) is off the critical path of a wave that shares
     // its SIMD with only ~3 others.
     uint32_t head = 0;
-    auto load_id = [&](uint32_t i) -> uint32_t { return i < wave_n ? point_list[start + i] : 0u; };
+    const int steps = (int)((wave_n + EMD_WAVE - 1) / EMD_WAVE);
+    auto step_idx = [&](int st_) -> int { return (steps - 1 - st_) * EMD_WAVE + (int)lane; };      // list position of this lane in step st_
+    auto in_list = [&](int i) -> bool { return i >= 0 && (uint32_t)i < wave_n; };
+    auto load_id = [&](int i) -> uint32_t { return in_list(i) ? point_list[start + (uint32_t)i] : 0u; };
     float4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4, b0 = zero4, b1 = zero4, b2 = zero4, b3 = zero4;
-    uint32_t idA = load_id(lane), idB = load_id(EMD_WAVE + lane), idC = load_id(2 * EMD_WAVE + lane);
-    if (lane < wave_n) {
+    float4 ax_[NX ? NX : 1], bx_[NX ? NX : 1];
+#pragma unroll
+    for (int k = 0; k < (NX ? NX : 1); k++) ax_[k] = bx_[k] = zero4;
+    auto load_extra = [&](uint32_t id, float4* o) {
+#pragma unroll
+        for (int k = 0; k < NX; k++) { const float* c = d.xcol[k] + 3 * (size_t)id; o[k] = make_float4(c[0], c[1], c[2], 0.f); }
+    };
+    uint32_t idA = load_id(step_idx(0)), idB = load_id(step_idx(1)), idC = load_id(step_idx(2));
+    if (in_list(step_idx(0))) {
         const float4* r = rec + (size_t)idA * EMD_REC_F4;
         a0 = r[0]; a1 = r[1]; a2 = r[2];
         if (NORMAL) a3 = r[3];
+        load_extra(idA, ax_);
     }
-    if (EMD_WAVE + lane < wave_n) {
+    if (in_list(step_idx(1))) {
         const float4* r = rec + (size_t)idB * EMD_REC_F4;
         b0 = r[0]; b1 = r[1]; b2 = r[2];
         if (NORMAL) b3 = r[3];
+        load_extra(idB, bx_);
     }
-    for (uint32_t base = 0; base < wave_n; base += EMD_WAVE) {
-        const uint32_t idx = base + lane;
+    const unsigned long long gt = (lane == 63) ? 0ull : (~0ull << (lane + 1));      // lanes above this one = deeper list positions of the step
+    for (int st_ = 0; st_ < steps; st_++) {
+        const int idx = step_idx(st_);
         const float4 c0r = a0, c1r = a1, c2r = a2, c3r = a3;
+        float4 cxr[NX ? NX : 1];
+#pragma unroll
+        for (int k = 0; k < NX; k++) { cxr[k] = ax_[k]; ax_[k] = bx_[k]; }
         const uint32_t cid = idA;
         a0 = b0; a1 = b1; a2 = b2; a3 = b3; idA = idB;
         idB = idC;
-        if (idx + 2 * EMD_WAVE < wave_n) {
+        if (in_list(step_idx(st_ + 2))) {
             const float4* r = rec + (size_t)idB * EMD_REC_F4;
             b0 = r[0]; b1 = r[1]; b2 = r[2];
             if (NORMAL) b3 = r[3];
+            load_extra(idB, bx_);
         }
-        idC = load_id(idx + 3 * EMD_WAVE);
-        const bool keep = idx < wave_n && ((quadrant_mask(c0r, c1r, tile_x0, tile_y0) >> quad) & 1u);
+        idC = load_id(step_idx(st_ + 3));
+        const bool keep = in_list(idx) && ((quadrant_mask(c0r, c1r, tile_x0, tile_y0) >> quad) & 1u);
         const unsigned long long bal = __ballot(keep);
         if (keep) {
-            const uint32_t slot = head + (uint32_t)__popcll(bal & lt);
+            const uint32_t slot = head + (uint32_t)__popcll(bal & gt);          // deepest first: the queue order is descending list position
             QREC(0, slot) = c0r; QREC(1, slot) = c1r; QREC(2, slot) = c2r;
             if (NORMAL) QREC(3, slot) = c3r;
-            q_id[slot] = cid; q_pos[slot] = idx;
+#pragma unroll
+            for (int k = 0; k < NX; k++) QREC(NRB + k, slot) = cxr[k];
+            q_id[slot] = cid; q_pos[slot] = (uint32_t)idx;
         }
         head += (uint32_t)__popcll(bal);
         __syncthreads();
         if (head >= EMD_WAVE) {
             process_batch(EMD_WAVE);
             const uint32_t rest = head - EMD_WAVE;
-            float4 t0 = zero4, t1 = zero4, t2 = zero4, t3 = zero4;
-            uint32_t ti = 0, tp = 0;
+            // the upper half of the queue moves down (half 0 is dead: process_batch ended with a barrier; the halves do not overlap)
             if (lane < rest) {
-                t0 = q_rec[1][0][lane]; t1 = q_rec[1][1][lane]; t2 = q_rec[1][2][lane];
-                if (NORMAL) t3 = q_rec[1][3][lane];
-                ti = q_id[EMD_WAVE + lane]; tp = q_pos[EMD_WAVE + lane];
-            }
-            __syncthreads();
-            if (lane < rest) {
-                q_rec[0][0][lane] = t0; q_rec[0][1][lane] = t1; q_rec[0][2][lane] = t2;
-                if (NORMAL) q_rec[0][3][lane] = t3;
+#pragma unroll
+                for (int r = 0; r < NR; r++) { const float4 v = q_rec[1][r][lane]; q_rec[0][r][lane] = v; }
+                const uint32_t ti = q_id[EMD_WAVE + lane], tp = q_pos[EMD_WAVE + lane];
                 q_id[lane] = ti; q_pos[lane] = tp;
             }
             head = rest;
@@ -504,30 +585,39 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(4
     if (head > 0) process_batch(head);
 }
 
-RenderDims make_dims(const EmdSettings& s, const float* sdev) {
+RenderDims make_dims(const EmdSettings& s, const float* sdev, const EmdExtra* x) {
     RenderDims d;
     d.bg_dev = sdev;
     d.W = s.image_width; d.H = s.image_height;
     d.gx = (d.W + EMD_TILE_X - 1) / EMD_TILE_X; d.gy = (d.H + EMD_TILE_Y - 1) / EMD_TILE_Y;
     d.bg[0] = s.bg[0]; d.bg[1] = s.bg[1]; d.bg[2] = s.bg[2];
+    for (int k = 0; k < EMD_MAX_EXTRA; k++) {
+        const bool on = x && k < x->num;
+        d.xcol[k] = on ? x->colors[k] : nullptr;
+        d.xout[k] = on ? x->out[k] : nullptr;
+        d.xgrad[k] = on ? x->dL_dout[k] : nullptr;
+    }
     return d;
 }
 
 }  // namespace
 
 int emd_launch_render_forward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
-                              float* out_color, float* out_depth, float* out_normal, float* out_alpha,
+                              float* out_color, float* out_depth, float* out_normal, float* out_alpha, const EmdExtra* x,
                               hipStream_t st) {
-    const RenderDims d = make_dims(s, sdev);
+    const RenderDims d = make_dims(s, sdev, x);
     const int T = d.gx * d.gy;
     if (T <= 0) return EMD_OK;
     const uint32_t* pl = b.vals[b.sorted_buf];
-    if (flags & EMD_FLAG_NORMAL)
-        hipLaunchKernelGGL(k_render_forward_q<true>, dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec, out_color,
-                           out_depth, out_normal, out_alpha, im.final_T, im.n_contrib);
-    else
-        hipLaunchKernelGGL(k_render_forward_q<false>, dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec, out_color,
-                           out_depth, out_normal, out_alpha, im.final_T, im.n_contrib);
+    const int nx = x ? x->num : 0;
+#define LAUNCH_FWD(N_, X_)                                                                                                          \
+    hipLaunchKernelGGL((k_render_forward_q<N_, X_>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec, \
+                       out_color, out_depth, out_normal, out_alpha, im.final_T, im.n_contrib)
+    const bool nrm = (flags & EMD_FLAG_NORMAL) != 0;
+    if (nx == 0) { if (nrm) LAUNCH_FWD(true, 0); else LAUNCH_FWD(false, 0); }
+    else if (nx == 1) { if (nrm) LAUNCH_FWD(true, 1); else LAUNCH_FWD(false, 1); }
+    else { if (nrm) LAUNCH_FWD(true, 2); else LAUNCH_FWD(false, 2); }
+#undef LAUNCH_FWD
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }
@@ -535,20 +625,26 @@ int emd_launch_render_forward(const EmdSettings& s, const float* sdev, int flags
 int emd_launch_render_backward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                                const float* out_color, const float* out_depth, const float* out_normal,
                                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                               const float* dL_dnormal, float* grad_rec, float* zero_buf, int zero_n, hipStream_t st) {
-    const RenderDims d = make_dims(s, sdev);
+                               const float* dL_dnormal, const EmdExtra* x, float* grad_rec, float* zero_buf, int zero_n, hipStream_t st) {
+    const RenderDims d = make_dims(s, sdev, x);
     const int T = d.gx * d.gy;
     if (T <= 0) return EMD_OK;
     const uint32_t* pl = b.vals[b.sorted_buf];
     const bool nrm = (flags & EMD_FLAG_NORMAL) && dL_dnormal && out_normal, ab = flags & EMD_FLAG_ABSGRAD;
-#define LAUNCH_BWD(N_, A_)                                                                                          \
-    hipLaunchKernelGGL((k_render_backward_q<N_, A_>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec,   \
+    const int nx = x ? x->num : 0;
+#define LAUNCH_BWD(N_, A_, X_)                                                                                          \
+    hipLaunchKernelGGL((k_render_backward_q<N_, A_, X_>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec,   \
                        im.final_T, im.n_contrib, out_color, out_depth, out_normal, dL_dcolor, dL_ddepth, dL_dalpha,    \
                        dL_dnormal, grad_rec, zero_buf, zero_n)
-    if (nrm && ab) LAUNCH_BWD(true, true);
-    else if (nrm) LAUNCH_BWD(true, false);
-    else if (ab) LAUNCH_BWD(false, true);
-    else LAUNCH_BWD(false, false);
+#define LAUNCH_BWD_X(X_)                                   \
+    if (nrm && ab) LAUNCH_BWD(true, true, X_);             \
+    else if (nrm) LAUNCH_BWD(true, false, X_);             \
+    else if (ab) LAUNCH_BWD(false, true, X_);              \
+    else LAUNCH_BWD(false, false, X_)
+    if (nx == 0) { LAUNCH_BWD_X(0); }
+    else if (nx == 1) { LAUNCH_BWD_X(1); }
+    else { LAUNCH_BWD_X(2); }
+#undef LAUNCH_BWD_X
 #undef LAUNCH_BWD
     EMD_LAUNCH_CHECK();
     return EMD_OK;

@@ -137,7 +137,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         rec = RasterCall()
         color, depth, _n, alpha, radii = _Rasterize.apply(means.contiguous().float(), sink, shs, col, opac.contiguous().float(),
                                                           scales.contiguous().float(), quats_n.contiguous(), None, None, None,
-                                                          None, None, rs, flags, opts, rec)
+                                                          None, None, rs, flags, opts, rec)[:5]
         if absgrad:
             def _hook(g, c=c, rec=rec):          # runs after this call's backward: its record holds this call's |grad| sums
                 means2d.absgrad[c] = rec.absgrad * scale

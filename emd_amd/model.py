@@ -67,12 +67,15 @@ class StreetGaussians(torch.nn.Module):
 
 
 def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activations=True, deformation=None, embeddings=None,
-           iteration=None, time=None, options=None, record=None):
+           iteration=None, time=None, options=None, record=None, render_feat=False):
     """The reference render() restricted to the hot path; returns the dict the training loop consumes.
     `deformation` (an emd_amd.deformation.deform_network) switches on the "fine" stage of gaussian_renderer/__init__.py:86-96:
     the residuals of the self-supervised EMD network are added to the raw parameters before the activations.
     `options` (emd_amd.RasterOptions) configures this call's rasterizer; `record` (emd_amd.RasterCall) receives its per-call state
-    (also returned as out["raster_call"])."""
+    (also returned as out["raster_call"]).
+    `render_feat` (with a deformation network that has the feature head): the reference's two feature passes
+    (`colors_precomp = ddict["coarse"]["feat"]` / `["fine"]["feat"]`, gaussian_renderer/__init__.py:170-201) as extra colour
+    sets of the SAME rasterizer call -> out["feat_c"], out["feat_f"]: one projection, one sort, one list walk instead of three."""
     dev = model._xyz.device
     # the reference's zero "screen-space points" leaf that only collects dL/dmean2D: the zeros are never written, so one
     # cached buffer per model serves every step (a fresh leaf view each time, no 24 MB fill launch)
@@ -95,14 +98,23 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         rotations = F.normalize(rotations)
         opacity = torch.sigmoid(opacity)
     kw = {}
+    feat_sets = []
+    if render_feat and ddict is not None:
+        feat_sets = [(lvl, ddict[lvl]["feat"]) for lvl in ("coarse", "fine") if ddict.get(lvl) is not None and ddict[lvl].get("feat") is not None]
+        if feat_sets:
+            kw["colors_extra"] = [f for _, f in feat_sets]
     if model.has_actors:
-        kw = dict(actor_ids=model.actor_id, actor_pose=model.actor_pose(frame, 0 if iteration is None else int(iteration)))
-    image, depth, normal, weight, radii, _ = rasterizer(
+        kw.update(actor_ids=model.actor_id, actor_pose=model.actor_pose(frame, 0 if iteration is None else int(iteration)))
+    image, depth, normal, weight, radii, extra = rasterizer(
         means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, raw_params=fuse_activations, record=record, **kw)
-    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
-            "depth": depth, "weight": weight, "normal": normal, "actor_pose": kw.get("actor_pose"), "ddict": ddict,
-            "raster_call": rasterizer.last_call}
+    out = {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+           "depth": depth, "weight": weight, "normal": normal, "actor_pose": kw.get("actor_pose"), "ddict": ddict,
+           "raster_call": rasterizer.last_call, "rasterizer": rasterizer,
+           "boundary": dict(means3D=means3D, opacities=opacity, scales=scales, rotations=rotations, shs=shs, raw_params=fuse_activations)}
+    for (lvl, _), img in zip(feat_sets, extra or []):
+        out["feat_c" if lvl == "coarse" else "feat_f"] = img
+    return out
 
 
 def raster_settings_for(cam, bg, sh_degree, scaling_modifier=1.0, debug=False):

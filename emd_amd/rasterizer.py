@@ -62,6 +62,7 @@ class RasterOptions:
     min_capacity: int = 1 << 16
     absgrad: bool = False           # also accumulate sum |d/d mean2D| (RasterCall.absgrad and `means2D.absgrad`, as gsplat does)
     clamp_rgb01: bool = False       # OmniRe colour clamp
+    keep_render_grads: bool = False  # tests: keep the per-Gaussian accumulator rows of the render backward (RasterCall.render_grads, [N, 12+])
     factored_sh_grad: bool = False  # view-parallel DP: the backward leaves dL/dshs out and publishes the [N,3] factor instead
                                     # (RasterCall.sh_color_grad); emd_amd.dp rebuilds the dense, view-averaged gradient
 
@@ -78,7 +79,7 @@ class RasterCall:
     `on_backward` (optional callable) is invoked with the record by the backward pass right after its kernels have been
     enqueued: view-parallel training starts its gradient collectives there (emd_amd.dp.GradientExchange.start)."""
     __slots__ = ("status", "num_rendered", "num_visible", "geom_ws", "bin_ws", "img_ws", "sizes", "capacity", "N", "H", "W",
-                 "flags", "settings_dev", "absgrad", "sh_color_grad", "grad_slab", "on_backward")
+                 "flags", "settings_dev", "absgrad", "sh_color_grad", "grad_slab", "on_backward", "render_grads")
 
     def __init__(self):
         for k in self.__slots__:
@@ -228,7 +229,7 @@ def _fill_motion(m: L.EmdMotion, actor_ids, actor_pose, residual_dx, residual_dq
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose,
-                residual_dx, residual_dq, actor_ids, raster_settings, flags, opts, rec):
+                residual_dx, residual_dq, actor_ids, raster_settings, flags, opts, rec, extra0=None, extra1=None):
         lib = L.load()
         dev = means3D.device
         if dev.type != "cuda":
@@ -247,6 +248,8 @@ class _Rasterize(torch.autograd.Function):
             torch.zeros(3, H, W, device=dev, dtype=torch.float32)
         radii = torch.empty(N, device=dev, dtype=torch.int32)
         status = torch.empty(4, device=dev, dtype=torch.int32)
+        extras = [e for e in (extra0, extra1) if e is not None]
+        out_extra = [torch.empty(3, H, W, device=dev, dtype=torch.float32) for _ in extras]
 
         key = (dev.index, H, W)
         _poll_pending(key, opts)
@@ -255,7 +258,7 @@ class _Rasterize(torch.autograd.Function):
         capacity = max(int(_capacity_hint.get(key, 0)), opts.min_capacity, 4 * N if key not in _capacity_hint else 0)
         a = L.EmdFwdArgs()
         while True:
-            gb, bb, ib, _ = L.workspace_sizes(N, H, W, capacity, flags)
+            gb, bb, ib, _ = L.workspace_sizes(N, H, W, capacity, flags, len(extras))
             geom_ws = torch.empty(gb, device=dev, dtype=torch.uint8)
             bin_ws = torch.empty(bb, device=dev, dtype=torch.uint8)
             img_ws = torch.empty(ib, device=dev, dtype=torch.uint8)
@@ -273,6 +276,9 @@ class _Rasterize(torch.autograd.Function):
             a.bin_ws, a.bin_bytes = bin_ws.data_ptr(), bb
             a.img_ws, a.img_bytes = img_ws.data_ptr(), ib
             a.status = status.data_ptr()
+            a.num_extra = len(extras)
+            for k, (e, o) in enumerate(zip(extras, out_extra)):
+                a.colors_extra[k], a.out_extra[k] = e.data_ptr(), o.data_ptr()
             rc = lib.emd_raster_forward(C.byref(a), _stream())
             if rc == L.EMD_ERR_DEPTH_RANGE and not (flags & L.FLAG_WIDE_DEPTH_SORT):
                 _wide_depth.add(key)
@@ -296,22 +302,26 @@ class _Rasterize(torch.autograd.Function):
         ctx.means2D_ref = means2D if (flags & L.FLAG_ABSGRAD) else None      # gsplat convention: `.absgrad` is set on this tensor
         ctx.has = (shs is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None,
                    actor_pose is not None, residual_dx is not None, residual_dq is not None)
+        ctx.num_extra = len(extras)
         ctx.save_for_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose,
                               residual_dx, residual_dq, actor_ids, radii, geom_ws, bin_ws, img_ws, status, out_color,
-                              out_depth, out_normal, sdev)
+                              out_depth, out_normal, sdev, *extras, *out_extra)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)   # unused outputs (normal, depth, alpha) arrive as None, not as zero images
         rec.status, rec.num_rendered, rec.num_visible = status, int(a.num_rendered), int(a.num_visible)
         rec.geom_ws, rec.bin_ws, rec.img_ws, rec.sizes, rec.capacity = geom_ws, bin_ws, img_ws, (gb, bb, ib), capacity
         rec.N, rec.H, rec.W, rec.flags, rec.settings_dev = N, H, W, flags, sdev
-        return out_color, out_depth, out_normal, out_alpha, radii
+        return (out_color, out_depth, out_normal, out_alpha, radii, *out_extra)
 
     @staticmethod
-    def backward(ctx, g_color, g_depth, g_normal, g_alpha, _g_radii):
+    def backward(ctx, g_color, g_depth, g_normal, g_alpha, _g_radii, *g_extra):
         lib = L.load()
+        nx = ctx.num_extra
+        saved = ctx.saved_tensors
         (means3D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose, residual_dx,
          residual_dq, actor_ids, radii, geom_ws, bin_ws, img_ws, status, out_color, out_depth,
-         out_normal, sdev) = ctx.saved_tensors
+         out_normal, sdev) = saved[:20]
+        extras, out_extra = saved[20:20 + nx], saved[20 + nx:20 + 2 * nx]
         dev = means3D.device
         N, M, flags, opts, rec = ctx.N, ctx.M, ctx.flags, ctx.opts, ctx.rec
         has_shs, has_col, has_sr, has_cov, has_pose, has_rdx, has_rdq = ctx.has
@@ -342,7 +352,9 @@ class _Rasterize(torch.autograd.Function):
         d_rdx = z(N, 3) if has_rdx else None
         d_rdq = z(N, 4) if has_rdq else None
         d_abs = z(N, 2) if flags & L.FLAG_ABSGRAD else None
-        bwd_ws = torch.empty(max(N, 1) * L.BWD_STRIDE, device=dev, dtype=torch.float32)
+        bwd_ws = torch.empty(max(N, 1) * (L.BWD_STRIDE + 4 * nx), device=dev, dtype=torch.float32)
+        g_extra = [None if g is None else g.contiguous().float() for g in g_extra]
+        d_extra = [z(N, 3) for _ in range(nx)]
 
         b = L.EmdBwdArgs()
         b.s = ctx.cs
@@ -365,13 +377,19 @@ class _Rasterize(torch.autograd.Function):
         b.dL_dscales, b.dL_drotations, b.dL_dcov3D = L.ptr(d_sc), L.ptr(d_rot), L.ptr(d_cov)
         b.dL_dactor_pose, b.dL_dresidual_dx, b.dL_dresidual_dq = L.ptr(d_pose), L.ptr(d_rdx), L.ptr(d_rdq)
         b.dL_dsh_color = L.ptr(d_shc)
+        b.num_extra = nx
+        for k in range(nx):
+            b.colors_extra[k], b.out_extra[k] = extras[k].data_ptr(), out_extra[k].data_ptr()
+            b.dL_dextra[k], b.dL_dcolors_extra[k] = L.ptr(g_extra[k]), d_extra[k].data_ptr()
         L.check(lib.emd_raster_backward(C.byref(b), _stream()), "emd_raster_backward")
         rec.absgrad, rec.sh_color_grad, rec.grad_slab = d_abs, d_shc, slab
+        rec.render_grads = bwd_ws.view(max(N, 1), -1) if opts.keep_render_grads else None
         if d_abs is not None and ctx.means2D_ref is not None:
             ctx.means2D_ref.absgrad = d_abs          # what gsplat's backward does with `means2d.absgrad`
         if rec.on_backward is not None:
             rec.on_backward(rec)
-        return (d_means3D, d_means2D, d_shs, d_col, d_op, d_sc, d_rot, d_cov, d_pose, d_rdx, d_rdq, None, None, None, None, None)
+        d_x = d_extra + [None] * (2 - nx)
+        return (d_means3D, d_means2D, d_shs, d_col, d_op, d_sc, d_rot, d_cov, d_pose, d_rdx, d_rdq, None, None, None, None, None, d_x[0], d_x[1])
 
 
 class GaussianRasterizer(nn.Module):
@@ -393,7 +411,12 @@ class GaussianRasterizer(nn.Module):
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3Ds_precomp=None, extra_attrs=None, actor_ids: Optional[torch.Tensor] = None,
                 actor_pose: Optional[torch.Tensor] = None, residual_dx: Optional[torch.Tensor] = None,
-                residual_dq: Optional[torch.Tensor] = None, raw_params: bool = False, record: Optional[RasterCall] = None):
+                residual_dq: Optional[torch.Tensor] = None, raw_params: bool = False, record: Optional[RasterCall] = None,
+                colors_extra=None):
+        """`colors_extra`: up to two more colour sets [N,3] composited by the SAME call -- the reference's feature passes
+        (`colors_precomp = ddict["coarse"/"fine"]["feat"]`, gaussian_renderer/__init__.py:170-201) without their second and third
+        projection, sort and list walk.  Their images [3,H,W] are returned as a list in the sixth slot of the result (the
+        reference's `extra`); each equals the colour image of a separate call with that colour set, bit for bit."""
         rs, opts = self.raster_settings, self.options
         if (shs is None) == (colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
@@ -440,11 +463,17 @@ class GaussianRasterizer(nn.Module):
             residual_dx = _f32c(residual_dx, "residual_dx", (3,))
             residual_dq = _f32c(residual_dq, "residual_dq", (4,))
         rec = record if record is not None else RasterCall()
-        color, depth, normal, alpha, radii = _Rasterize.apply(
+        extras = [] if colors_extra is None else [_f32c(e, "colors_extra", (3,)) for e in colors_extra]
+        if len(extras) > L.MAX_EXTRA:
+            raise ValueError(f"at most {L.MAX_EXTRA} extra colour sets per call")
+        if any(e.shape[0] != N for e in extras):
+            raise ValueError("colors_extra must hold one colour per Gaussian")
+        extras += [None] * (2 - len(extras))
+        color, depth, normal, alpha, radii, *x_imgs = _Rasterize.apply(
             means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose, residual_dx,
-            residual_dq, actor_ids, rs, flags, opts, rec)
+            residual_dq, actor_ids, rs, flags, opts, rec, extras[0], extras[1])
         self.last_call = rec
-        return color, depth, normal, alpha, radii, None
+        return color, depth, normal, alpha, radii, (list(x_imgs) if x_imgs else None)
 
     # ---- introspection of THIS object's most recent call (tests / bench; not part of the reference surface) -------------------
     def last_status(self):

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 13
+#define EMD_ABI_VERSION 14
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -110,6 +110,7 @@ typedef struct EmdSettings {
  */
 #define EMD_ACTOR_STRIDE 12
 #define EMD_SETTINGS_DEV_FLOATS 38
+#define EMD_MAX_EXTRA 2          /* extra colour sets composited by one call (S3Gaussian renders feat_c and feat_f) */
 
 typedef struct EmdMotion {
     const int32_t* actor_id;   /* [N]; -1 = static (identity) */
@@ -134,6 +135,7 @@ typedef struct EmdDims {
     int32_t image_width;
     int64_t bin_capacity;   /* max (tile, Gaussian) pairs the binning workspace can hold */
     int32_t flags;
+    int32_t num_extra;      /* extra colour sets of the call (sizes bwd_ws) */
 } EmdDims;
 
 typedef struct EmdFwdArgs {
@@ -171,6 +173,13 @@ typedef struct EmdFwdArgs {
      * these four on the GPU (`.cuda()` at S3Gaussian/gaussian_renderer/__init__.py:54-59): with this pointer its call site
      * costs no device-to-host copy, so a forward with EMD_FLAG_NO_SYNC never touches the host. */
     const float* settings_dev;
+    /* Extra colour sets: the reference's "fine" stage renders the same Gaussians two more times with colors_precomp = ddict["coarse"]["feat"]
+     * and ddict["fine"]["feat"] (S3Gaussian/gaussian_renderer/__init__.py:170-201).  With num_extra > 0 those images come out of THIS
+     * call: one projection, one sort, one walk over every tile list; out_extra[k] equals, bit for bit, the colour image of a separate
+     * call with colors_precomp = colors_extra[k]. */
+    int32_t num_extra;                       /* 0 .. EMD_MAX_EXTRA */
+    const float* colors_extra[EMD_MAX_EXTRA];  /* [N,3] each */
+    float* out_extra[EMD_MAX_EXTRA];           /* [3,H,W] each */
 } EmdFwdArgs;
 
 typedef struct EmdBwdArgs {
@@ -204,7 +213,7 @@ typedef struct EmdBwdArgs {
     const float* dL_ddepth;       /* [1,H,W] */
     const float* dL_dalpha;       /* [1,H,W] */
     const float* dL_dnormal;      /* [3,H,W]  (propagated to the blended normal only) */
-    /* scratch for backward: [N, EMD_BWD_STRIDE] floats, zeroed by the library */
+    /* scratch for backward: [N, 12 + 4 num_extra] floats, zeroed by the library */
     void* bwd_ws;  size_t bwd_bytes;
     /* outgoing gradients (NULL = not wanted) */
     float* dL_dmeans3D;           /* [N,3] */
@@ -225,6 +234,13 @@ typedef struct EmdBwdArgs {
                                    * rebuilt (and summed over views) by emd_sh_grad_from_factors -- 12 bytes per Gaussian to exchange
                                    * between GPUs instead of 192 */
     const float* settings_dev;    /* as in EmdFwdArgs (same buffer, kept alive by the caller) */
+    /* extra colour sets (see EmdFwdArgs): forward inputs / outputs again, incoming and outgoing gradients; bwd_ws then holds
+     * [N, 12 + 4 num_extra] floats (emd_raster_workspace_size with EmdDims.num_extra) */
+    int32_t num_extra;
+    const float* colors_extra[EMD_MAX_EXTRA];
+    const float* out_extra[EMD_MAX_EXTRA];
+    const float* dL_dextra[EMD_MAX_EXTRA];        /* [3,H,W] or NULL */
+    float* dL_dcolors_extra[EMD_MAX_EXTRA];       /* [N,3] or NULL */
 } EmdBwdArgs;
 
 int emd_abi_version(void);

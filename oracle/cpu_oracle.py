@@ -174,7 +174,9 @@ def forward(S, sc, flags=0):
     return pre, b, img
 
 
-def backward(S, sc, pre, binning, img, dL_dcolor=None, dL_ddepth=None, dL_dalpha=None, dL_dnormal=None, flags=0):
+def render_backward(S, sc, pre, binning, img, dL_dcolor=None, dL_ddepth=None, dL_dalpha=None, dL_dnormal=None, flags=0):
+    """K7: per-Gaussian sums of the per-(pixel, Gaussian) partial derivatives -> dict(mean2D[N,2] (pixel units), abs[N,2], conic[N,3],
+    opacity[N], rgb[N,3], depth[N], normal[N,3])."""
     N = sc.N
     dL_dcolor = _f32(dL_dcolor); dL_ddepth = _f32(dL_ddepth); dL_dalpha = _f32(dL_dalpha); dL_dnormal = _f32(dL_dnormal)
     g = dict(mean2D=np.zeros((N, 2), np.float32), abs=np.zeros((N, 2), np.float32),
@@ -186,6 +188,13 @@ def backward(S, sc, pre, binning, img, dL_dcolor=None, dL_ddepth=None, dL_dalpha
                               _p(img["n_contrib"]), _p(img["final_T"]), _p(dL_dcolor), _p(dL_ddepth), _p(dL_dalpha),
                               _p(dL_dnormal), _p(g["mean2D"]), _p(g["abs"]), _p(g["conic"]), _p(g["opacity"]),
                               _p(g["rgb"]), _p(g["depth"]), _p(g["normal"]))
+    return g
+
+
+def preprocess_backward(S, sc, pre, g, flags=0):
+    """K8: chain the render gradients `g` (as render_backward returns them) to the inputs."""
+    N = sc.N
+    g = {k: np.ascontiguousarray(v, np.float32) for k, v in g.items()}
     M, A = sc.M, sc.A
     out = dict(means3D=np.zeros((N, 3), np.float32), means2D=np.zeros((N, 3), np.float32),
                shs=np.zeros((N, M, 3), np.float32) if M else None,
@@ -206,3 +215,7 @@ def backward(S, sc, pre, binning, img, dL_dcolor=None, dL_ddepth=None, dL_dalpha
     out["render_grads"] = g
     out["actor_pose"] = out["actor_pose"][:A]
     return out
+
+
+def backward(S, sc, pre, binning, img, dL_dcolor=None, dL_ddepth=None, dL_dalpha=None, dL_dnormal=None, flags=0):
+    return preprocess_backward(S, sc, pre, render_backward(S, sc, pre, binning, img, dL_dcolor, dL_ddepth, dL_dalpha, dL_dnormal, flags), flags)

@@ -7,6 +7,9 @@ the L1-only step of BASELINE.json; this is the same step with the reference's fu
 --fine: the "fine" stage of S3Gaussian's training (train.py after coarse_iterations): no actors, the self-supervised EMD
 deformation network (HexPlane 4 x 6 planes x 32 channels, temporal table, heads dx / do / dshs / feat; run-script flags) runs in
 front of the rasterizer on all 2 M Gaussians and is trained through it, plus the residual regularisers of train.py.
+--feat (with --fine): the reference's default feature head (feat_head=True, arguments/gaussian_options.py:163): the two feature
+images rendered as extra colour sets of the main rasterizer call (one binning, three colour sets) and an L2 loss on each;
+--feat-separate: the same step issued the way the reference issues it, as three rasterizer calls.
 --adam / --torch-adam: also take the optimiser step (train.py:428) with emd_amd.optim.Adam / torch.optim.Adam over the groups of
 gaussian_model.py:188-199 (per-group learning rates, eps 1e-15)."""
 import json
@@ -25,6 +28,8 @@ from emd_amd.sky import SkyCubeMap, composite_s3g  # noqa: E402
 
 dev = torch.device("cuda", 0)
 FINE = "--fine" in sys.argv
+FEAT_SEP = "--feat-separate" in sys.argv
+FEAT = FINE and ("--feat" in sys.argv or FEAT_SEP)
 N, H, W, F = 2_000_000, 1066, 1600, 50
 scene = scenes.make_static_scene(N, seed=0)
 if not FINE:
@@ -58,6 +63,7 @@ sky = SkyCubeMap(types.SimpleNamespace(sky_resolution=1024, sky_white_background
 g = torch.Generator().manual_seed(3)
 gt = torch.rand(3, H, W, generator=g).to(dev)
 gt_depth = (torch.rand(1, H, W, generator=g) * 90).to(dev)
+gt_feat = torch.rand(3, H, W, generator=g).to(dev)
 sky_mask = (torch.rand(1, H, W, generator=g) < 0.2).to(dev)
 not_sky = ~sky_mask
 accum, denom, maxr = (torch.zeros(N, device=dev) for _ in range(3))
@@ -76,13 +82,22 @@ def step(s):
     for p in params:
         p.grad = None
     sky.sky_cube_map.grad = None
-    out = render(model, cams[f], bg, frame=f, deformation=deform, embeddings=embeddings, iteration=12000 + s, time=f / (F - 1), options=OPTS[0])
+    out = render(model, cams[f], bg, frame=f, deformation=deform, embeddings=embeddings, iteration=12000 + s, time=f / (F - 1), options=OPTS[0],
+                 render_feat=FEAT and not FEAT_SEP)
+    if FEAT and FEAT_SEP:        # the reference's three calls: main pass above + one call per feature set, same rasterizer object
+        bd, dd = out["boundary"], out["ddict"]
+        base = dict(means3D=bd["means3D"], means2D=out["viewspace_points"], opacities=bd["opacities"], scales=bd["scales"],
+                    rotations=bd["rotations"], raw_params=bd["raw_params"])
+        out["feat_c"] = out["rasterizer"](shs=None, colors_precomp=dd["coarse"]["feat"], **base)[0]
+        out["feat_f"] = out["rasterizer"](shs=None, colors_precomp=dd["fine"]["feat"], **base)[0]
     image, _ = composite_s3g(sky, skycams[f], out["render"], out["weight"])
     loss, _ = image_loss(image, gt, out["depth"], gt_depth, not_sky, out["weight"], sky_mask)
     if FINE:                                           # residual regularisers (train.py: lambda_dx / do / dshs on both levels)
         for lvl in ("coarse", "fine"):
             d = out["ddict"][lvl]
             loss = loss + 0.001 * (d["dx"].abs().mean() + d["do"].abs().mean() + d["dshs"].abs().mean())
+    if FEAT:
+        loss = loss + 0.001 * (((out["feat_c"] - gt_feat) ** 2).mean() + ((out["feat_f"] - gt_feat) ** 2).mean())
     loss.backward()
     dp.add_densification_stats(out["viewspace_points"].grad, out["radii"], accum, denom, maxr)
     if optimizer is not None:
@@ -106,7 +121,11 @@ for s in range(K_STEPS):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 op = "S3G-style step: raster (fused motion) + sky cube map + blend + L1/depth/D-SSIM/sky-BCE + backward + densification stats"
-if FINE:
+if FEAT:
+    op = ("S3G fine-stage step with the feature head, THREE rasterizer calls as the reference issues them: " if FEAT_SEP else
+          "S3G fine-stage step with the feature head, main + feat_c + feat_f as ONE rasterizer call (one binning, three colour sets): ") + \
+        "EMD deformation network -> raster -> sky + blend -> full loss + feature L2 + residual regularisers -> backward -> densification stats"
+elif FINE:
     op = "S3G fine-stage step: EMD deformation network (HexPlane + temporal table + heads) -> raster -> sky + blend -> full loss + residual regularisers -> backward to Gaussians, planes, table, heads -> densification stats"
 if optimizer is not None:
     op += " -> optimiser step (" + ("emd_amd.optim.Adam" if "--adam" in sys.argv else "torch.optim.Adam") + ")"

@@ -150,3 +150,56 @@ def test_no_sync_overflow_is_reported_by_a_later_call_and_heals():
             torch.cuda.synchronize()
             third = _call(r, t)[0]
     assert torch.equal(third, good)
+
+
+@pytest.mark.parametrize("n_extra", [1, 2])
+def test_one_binning_many_colour_sets(n_extra):
+    """The reference's fine stage calls the rasterizer three times with the same Gaussians: main pass, colors_precomp = coarse feat,
+    colors_precomp = fine feat (gaussian_renderer/__init__.py:145-201).  `colors_extra` serves the feature passes from the main
+    call's projection, sort and list walk: every extra image equals the separate call's image BIT FOR BIT (and the oracle's), and
+    the gradients equal those of the three separate calls / the sum of three oracle backward passes."""
+    from emd_amd import GaussianRasterizer
+    from tests.helpers import run_oracle, assert_grad_close
+    case = make_case(n=7000, H=96, W=128, seed=23)
+    rs = _settings(case)
+    gen = torch.Generator().manual_seed(2)
+    feats = [torch.rand(case["N"], 3, generator=gen) for _ in range(n_extra)]
+    G = [torch.randn(3, case["H"], case["W"], generator=gen) for _ in range(1 + n_extra)]
+    Gd, Ga = 0.1 * torch.randn(1, case["H"], case["W"], generator=gen), torch.randn(1, case["H"], case["W"], generator=gen)
+    # (a) separate calls, as the reference issues them
+    t = _leaves(case)
+    f_sep = [f.to(DEV).clone().requires_grad_(True) for f in feats]
+    r = GaussianRasterizer(rs)
+    img, depth, _, alpha, _, _ = _call(r, t)
+    imgs_sep = [r(means3D=t["means3D"], means2D=t["means2D"], shs=None, colors_precomp=f, opacities=t["opacities"], scales=t["scales"],
+                  rotations=t["rotations"], cov3Ds_precomp=None, extra_attrs=None)[0] for f in f_sep]
+    loss = (img * G[0].to(DEV)).sum() + (depth * Gd.to(DEV)).sum() + (alpha * Ga.to(DEV)).sum() + sum((i * g.to(DEV)).sum() for i, g in zip(imgs_sep, G[1:]))
+    loss.backward()
+    # (b) one call
+    t1 = _leaves(case)
+    f_one = [f.to(DEV).clone().requires_grad_(True) for f in feats]
+    r1 = GaussianRasterizer(rs)
+    img1, depth1, _, alpha1, _, extra = _call(r1, t1, colors_extra=f_one)
+    assert isinstance(extra, list) and len(extra) == n_extra
+    assert torch.equal(img1, img) and torch.equal(depth1, depth) and torch.equal(alpha1, alpha)
+    for a, b in zip(extra, imgs_sep):
+        assert torch.equal(a.detach(), b.detach())
+    loss1 = (img1 * G[0].to(DEV)).sum() + (depth1 * Gd.to(DEV)).sum() + (alpha1 * Ga.to(DEV)).sum() + sum((i * g.to(DEV)).sum() for i, g in zip(extra, G[1:]))
+    loss1.backward()
+    # (c) the oracle: three forward / backward passes, gradients of the shared inputs summed
+    case_o = dict(case, dL_dcolor=G[0].numpy(), dL_ddepth=Gd.numpy(), dL_dalpha=Ga.numpy())
+    orc = run_oracle(case_o, backward=True)
+    total = {k: np.asarray(orc["grads"][k], np.float64).copy() for k in ("means3D", "means2D", "opacities", "scales", "rotations")}
+    for k, f in enumerate(feats):
+        case_f = dict(case, shs=None, colors_precomp=f, dL_dcolor=G[1 + k].numpy(), dL_ddepth=None, dL_dalpha=None)
+        of = run_oracle(case_f, backward=True)
+        got_img = extra[k].detach().cpu().numpy()
+        assert int((got_img.view(np.uint32) != of["img"]["color"].view(np.uint32)).sum()) == 0, "extra image differs from the oracle's"
+        assert_grad_close(f_one[k].grad.cpu().numpy(), of["grads"]["colors"], f"colors_extra[{k}]")
+        assert_grad_close(f_one[k].grad.cpu().numpy(), f_sep[k].grad.cpu().numpy(), f"colors_extra[{k}] vs separate call")
+        for name in total:
+            total[name] += np.asarray(of["grads"][name], np.float64).reshape(total[name].shape)
+    from tests.helpers import END2END_ATOL_FRAC
+    for name in total:          # (scales / rotations: end-to-end floor of the ill-conditioned conic -> covariance chain, tests/helpers.py)
+        assert_grad_close(t1[name].grad.cpu().numpy(), total[name], name, atol_frac=END2END_ATOL_FRAC if name in ("scales", "rotations") else None)
+    assert_grad_close(t1["shs"].grad.cpu().numpy(), orc["grads"]["shs"], "shs")
