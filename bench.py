@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--factored-sh", action="store_true", help="use the multi-GPU SH-gradient factor exchange at any world size (1 GPU: measures its local cost)")
     ap.add_argument("--no-track-heads", action="store_true", help="leave the learned per-actor track offsets out of the step")
     ap.add_argument("--densify-stats", action="store_true", help="also accumulate the per-view densification statistics every step (one launch)")
+    ap.add_argument("--eager", action="store_true", help="issue every step from Python instead of replaying it from a hipGraph (1 GPU)")
     args = ap.parse_args()
 
     from emd_amd import dp, scenes, _lib
@@ -260,32 +261,104 @@ def main():
             o = render(model, cam, bg, frame=f, options=sync_opts)
             dmax = max(dmax, o["raster_call"].last_status()["num_rendered"])
     _rz._capacity_hint[(dev.index, H, W)] = int(dmax * 1.3) + 1024
-    statuses = []
+    # ---- the step as a hipGraph (1 GPU): the ~45 launches of a step are captured once and replayed; everything that changes from
+    # step to step (camera matrices, frame index, frame time) lives in device buffers selected by ONE device index `sel`, rewritten
+    # before every replay.  The host then spends ~20 us per step instead of ~1-2 ms of Python + launch calls, i.e. the run is
+    # GPU-bound whatever the host is doing.  (--eager, or a failed capture, issues the same step from Python.)
+    total_steps = args.warmup + args.steps
+    graph = None
+    out = o = None          # no autograd graph of an eager step may be alive at capture time (its AccumulateGrad nodes are bound to the eager stream)
+    status_log = torch.zeros(max(total_steps, 1), 4, dtype=torch.int32, device=dev)
+    if world == 1 and not args.eager and opts.no_sync:
+        try:
+            import types
+            views = [cam_for(s_) for s_ in range(total_steps)]
+            blocks = torch.stack([torch.cat([bg.reshape(-1).float(), c_.world_view_transform.reshape(-1), c_.full_proj_transform.reshape(-1),
+                                             c_.camera_center.reshape(-1)]) for _, _, c_ in views]).to(dev)            # [steps, 38]
+            frame_of = torch.tensor([f_ for f_, _, _ in views], dtype=torch.int32, device=dev)
+            sel = torch.zeros(1, dtype=torch.int64, device=dev)
+            cam0 = views[0][2]
+
+            def graph_body():
+                for p in params:
+                    p.grad = None
+                blk = blocks.index_select(0, sel)[0]
+                frame_dev = frame_of.index_select(0, sel)
+                cam_g = types.SimpleNamespace(image_height=H, image_width=W, tanfovx=cam0.tanfovx, tanfovy=cam0.tanfovy,
+                                              world_view_transform=blk[3:19].view(4, 4), full_proj_transform=blk[19:35].view(4, 4),
+                                              camera_center=blk[35:38])
+                o = render(model, cam_g, blk[0:3], frame=frame_dev, iteration=0, options=opts)
+                l1_loss(o["render"], target).backward()
+                if stats is not None:
+                    dp.add_densification_stats(o["viewspace_points"].grad, o["radii"], *stats)
+                status_log.index_copy_(0, sel, o["raster_call"].status.view(1, 4))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for i_ in range(3):
+                    sel.fill_(i_)
+                    graph_body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                graph_body()
+            torch.cuda.synchronize()
+        except Exception as e:          # capture is an optimisation of the host side only: fall back to issuing the step from Python
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+
+    def timed_step(step):
+        if graph is not None:
+            sel.fill_(step)
+            graph.replay()
+        else:
+            o = one_step(step)
+            status_log[step].copy_(o["raster_call"].status)
+
     for s in range(args.warmup):
-        one_step(s)
+        timed_step(s)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
-    _lib.profile_enable(True)
-    _lib.profile_read()
+    if graph is None:
+        _lib.profile_enable(True)
+        _lib.profile_read()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        out = one_step(args.warmup + s)
-        statuses.append(out["raster_call"].status)
+        timed_step(args.warmup + s)
     t_enqueue = time.perf_counter() - t0      # host time to enqueue the K steps (the GPU runs behind it)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    stage_region = "the timed region"
+    if graph is not None:
+        # Per-stage HIP events are recorded by host code, which does not run when a graph is replayed: the stage durations of the
+        # roofline block come from the SAME steps issued eagerly right after the timed region (same kernels, same inputs).
+        n_prof = min(args.steps, 20)
+        _lib.profile_enable(True)
+        _lib.profile_read()
+        for s in range(n_prof):
+            one_step(args.warmup + s)
+        torch.cuda.synchronize()
+        stage_region = f"{n_prof} eager repetitions of the timed steps, run right after the timed region (graph replays execute no host-side event records)"
+        prof_steps = n_prof
+    else:
+        prof_steps = args.steps
     prof = _lib.profile_read()
     _lib.profile_enable(False)
+    if graph is not None:          # release the captured graph and its memory pool explicitly, in a quiet state
+        torch.cuda.synchronize()
+        graph.reset()
+        graph = "released"
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
-    st_all = torch.stack(statuses).cpu().numpy().astype("int64") & 0xFFFFFFFF if statuses else None
-    overflow = int(st_all[:, 1].sum()) if statuses else 0
+    st_all = status_log[args.warmup:args.warmup + args.steps].cpu().numpy().astype("int64") & 0xFFFFFFFF
+    overflow = int(st_all[:, 1].sum())
     assert overflow == 0, "binning workspace overflowed during the timed region"
 
     if rank == 0:
@@ -299,7 +372,7 @@ def main():
         stages = {}
         for name, (ms, cnt) in prof.items():
             if cnt and name in ab:
-                avg = ms / args.steps                                # per iteration (a stage may open twice per step)
+                avg = ms / prof_steps                                # per iteration (a stage may open twice per step)
                 stages[name] = {"ms": round(avg, 4), "alg_GB": round(ab[name] / 1e9, 4),
                                 "GBps": round(ab[name] / 1e9 / (avg * 1e-3), 1)}
         dom = max(stages, key=lambda k: stages[k]["ms"])
@@ -315,6 +388,7 @@ def main():
                     "secondary_bound": "fp32 vector issue rate: the render kernels are issue-bound (DESIGN.md section 6)",
                     "issue": issue_bound(dom, stages[dom]["ms"]) if full else None,
                     "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": stages[dom]["ms"],
+                    "stage_durations_measured_over": stage_region,
                     "per_step": {"steps": int(len(Ds)), "D_min": int(Ds.min()), "D_mean": round(D, 1), "D_max": int(Ds.max()),
                                  "V_min": int(Vs.min()), "V_mean": round(V, 1), "V_max": int(Vs.max()),
                                  "note": "duplicates D and visible Gaussians V of every timed step, read from the device status words after the timed region; algorithmic bytes use the means"},
@@ -343,6 +417,7 @@ def main():
                        "radix_passes_depth_on_N": 4, "radix_passes_tile_on_D": passes, "blended_channels_C": C, "views_per_step": world,
                        "rig_cameras": num_cams, "rank_view_mapping": mapping, "track_heads": not args.no_track_heads,
                        "densification_stats_in_step": bool(args.densify_stats),
+                       "step_issue": "hipGraph replay (one capture, device-resident per-step inputs)" if graph is not None else "eager (Python issues every launch)",
                        "parallelism": f"view-parallel dp{world}", "count_readback": bool(args.sync_count),
                        "gradient_exchange": ("none (1 GPU)" if world == 1 else
                                              "SH gradient as rank-one factors: all-gather of 12 B per Gaussian and rank + camera centres + per-view actor "
@@ -353,7 +428,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:      # the CPU leg is timed on rank 0 of the 1-GPU run only
             f0, _, cam0 = cam_for(0)
             res["cpu_baseline"] = cpu_baseline(scene, cam0, frame=f0)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16
@@ -134,8 +134,8 @@ class EmdDensifyGather(C.Structure):
 
 class EmdTrackArgs(C.Structure):
     _fields_ = [("num_actors", C.c_int32), ("rows", C.c_int32), ("dim", C.c_int32), ("embed_dim", C.c_int32), ("k_coarse", C.c_int32),
-                ("k_fine", C.c_int32), ("num_points", C.c_int32), ("reserved", C.c_int32), ("t", C.c_float), ("weight", _f),
-                ("embeddings", _f), ("point_ids", _f), ("count", _f), ("head_w", _f * 4), ("head_b", _f * 4), ("emb_sum", _f),
+                ("k_fine", C.c_int32), ("num_points", C.c_int32), ("reserved", C.c_int32), ("t", C.c_float), ("t_dev", _f), ("weight", _f),
+                ("embeddings", _f), ("point_ids", _f), ("count", _f), ("segment_start", _f), ("head_w", _f * 4), ("head_b", _f * 4), ("emb_sum", _f),
                 ("trans", _f), ("rot", _f)]
 
 
@@ -205,8 +205,8 @@ def load():
     lib.emd_sh_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_sh_backward.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6
     lib.emd_activations_forward.argtypes = [C.c_int32] + [C.c_void_p] * 7
-    lib.emd_actor_pose_forward.argtypes = [C.c_int32] + [C.c_void_p] * 7
-    lib.emd_actor_pose_backward.argtypes = [C.c_int32] + [C.c_void_p] * 9
+    lib.emd_actor_pose_forward.argtypes = [C.c_int32] + [C.c_void_p] * 8
+    lib.emd_actor_pose_backward.argtypes = [C.c_int32] + [C.c_void_p] * 10
     lib.emd_l1_loss.argtypes = [C.c_int64] + [C.c_void_p] * 5
     lib.emd_profile_enable.argtypes = [C.c_int]
     lib.emd_image_loss_workspace.argtypes = [C.c_int, C.c_int]

@@ -78,9 +78,9 @@ int emd_launch_sh_grad_from_factors(int n, int V, int deg, int M, const float* m
 int emd_launch_densification_stats(int n, const int32_t* radii, const float* g2d, float* accum, float* denom, float* max_radii,
                                    hipStream_t st);
 int emd_launch_actor_pose_forward(int A, const float* q, const float* t, const uint8_t* valid, const float* dt, const float* dq,
-                                  float* pose, hipStream_t st);
+                                  float* pose, const int32_t* frame_dev, hipStream_t st);
 int emd_launch_actor_pose_backward(int A, const float* q, const float* dt, const float* dq, const float* g_pose, float* d_q,
-                                   float* d_t, float* d_dt, float* d_dq, hipStream_t st);
+                                   float* d_t, float* d_dt, float* d_dq, const int32_t* frame_dev, hipStream_t st);
 int emd_launch_l1_loss(size_t n, const float* a, const float* b, float* loss, float* grad, hipStream_t st);
 int emd_launch_activations(int n, const float* ls, float* sc, const float* rq, float* q, const float* lo, float* o, hipStream_t st);
 int emd_launch_export_geometry(int N, const GeomWs& g, float* means2D, float* depths, float* conic_opacity, float* rgb,
@@ -379,15 +379,15 @@ int emd_densification_stats(int32_t n, const int32_t* radii, const float* dL_dme
 }
 
 int emd_actor_pose_forward(int32_t num_actors, const float* q_f, const float* t_f, const uint8_t* valid, const float* dt,
-                           const float* dq, float* pose, void* hip_stream) {
+                           const float* dq, float* pose, const int32_t* frame_dev, void* hip_stream) {
     if (num_actors < 0 || (num_actors > 0 && (!q_f || !t_f || !pose))) { emd_set_error("actor_pose_forward: bad argument"); return EMD_ERR_INVALID; }
-    return emd_launch_actor_pose_forward(num_actors, q_f, t_f, valid, dt, dq, pose, (hipStream_t)hip_stream);
+    return emd_launch_actor_pose_forward(num_actors, q_f, t_f, valid, dt, dq, pose, frame_dev, (hipStream_t)hip_stream);
 }
 
 int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* dt, const float* dq, const float* dL_dpose,
-                            float* dL_dq_f, float* dL_dt_f, float* dL_ddt, float* dL_ddq, void* hip_stream) {
+                            float* dL_dq_f, float* dL_dt_f, float* dL_ddt, float* dL_ddq, const int32_t* frame_dev, void* hip_stream) {
     if (num_actors < 0 || (num_actors > 0 && (!q_f || !dL_dpose || !dL_dq_f || !dL_dt_f))) { emd_set_error("actor_pose_backward: bad argument"); return EMD_ERR_INVALID; }
-    return emd_launch_actor_pose_backward(num_actors, q_f, dt, dq, dL_dpose, dL_dq_f, dL_dt_f, dL_ddt, dL_ddq, (hipStream_t)hip_stream);
+    return emd_launch_actor_pose_backward(num_actors, q_f, dt, dq, dL_dpose, dL_dq_f, dL_dt_f, dL_ddt, dL_ddq, frame_dev, (hipStream_t)hip_stream);
 }
 
 int emd_l1_loss(int64_t n, const float* a, const float* b, float* loss, float* grad, void* hip_stream) {

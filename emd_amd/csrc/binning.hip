@@ -117,7 +117,6 @@ __global__ void __launch_bounds__(PUB_THREADS) k_scan_publish(uint32_t* __restri
         status->num_rendered = carry;
         status->overflow = (status->overflow & 2u) | (((uint64_t)carry > capacity) ? 1u : 0u);     // bit 1: depth range (set by the depth sort)
         status->num_visible = vtot;
-        status->reserved = 0u;
     }
 }
 
@@ -461,23 +460,23 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
     // 1. visible Gaussians in depth order.  The status word is cleared first: the depth passes may raise its overflow bit 1.
     emd_prof_switch(PROF_PREPROCESS, PROF_SORT, st);
     EMD_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(EmdStatus), st));
-    EMD_HIP_CHECK(hipMemsetAsync(g.sort_count, 0, 16, st));
+    uint32_t* const sort_count = &status->reserved;          // V after the first (compacting) depth pass lives in the status block: one memset
     const bool wide = (flags & EMD_FLAG_WIDE_DEPTH_SORT) != 0;
     const int depth_passes = wide ? EMD_DEPTH_PASSES_WIDE : EMD_DEPTH_PASSES_NARROW;
     if (N > 0) {
-        const SortN c0 = {nullptr, nullptr, (uint32_t)N}, cv = {g.sort_count, nullptr, 0u};
+        const SortN c0 = {nullptr, nullptr, (uint32_t)N}, cv = {sort_count, nullptr, 0u};
         uint32_t near_bits = 0;
         if (!wide) { const float np = s.near_plane > 0.f ? s.near_plane : 0.f; memcpy(&near_bits, &np, 4); }
         uint32_t* ovf = &status->overflow;
         if (wide) {
-            rc = radix_pass<8, true>(g.depth_key, nullptr, g.gkeys[0], g.gvals[0], c0, (size_t)N, 0, 8, 0u, g.ghist, false, 32, ovf, g.sort_count, st);
+            rc = radix_pass<8, true>(g.depth_key, nullptr, g.gkeys[0], g.gvals[0], c0, (size_t)N, 0, 8, 0u, g.ghist, false, 32, ovf, sort_count, st);
             for (int p = 1; p < depth_passes && !rc; p++)
                 rc = radix_pass<8, false>(g.gkeys[(p - 1) & 1], g.gvals[(p - 1) & 1], g.gkeys[p & 1], g.gvals[p & 1], cv, (size_t)N, 8 * p, 8, 0u,
                                           g.ghist, false, 32, ovf, nullptr, st);
         } else {
             const int B = EMD_DEPTH_BITS_NARROW;
             rc = radix_pass<EMD_DEPTH_BITS_NARROW, true>(g.depth_key, nullptr, g.gkeys[0], g.gvals[0], c0, (size_t)N, 0, B, near_bits, g.ghist, false,
-                                                         EMD_DEPTH_RANGE_NARROW, ovf, g.sort_count, st);
+                                                         EMD_DEPTH_RANGE_NARROW, ovf, sort_count, st);
             for (int p = 1; p < depth_passes && !rc; p++)
                 rc = radix_pass<EMD_DEPTH_BITS_NARROW, false>(g.gkeys[(p - 1) & 1], g.gvals[(p - 1) & 1], g.gkeys[p & 1], g.gvals[p & 1], cv, (size_t)N,
                                                               B * p, B, near_bits, g.ghist, false, 32, ovf, nullptr, st);
@@ -490,7 +489,7 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
     if (N == 0 || capacity <= 0) {
         EMD_HIP_CHECK(hipMemsetAsync(b.ranges, 0, (size_t)T * 8, st));
         if (N > 0) {   // D and V are still reported (capacity 0 is how callers size the workspace)
-            hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, g.sort_count, perm, g.binrec, g.rect_s, g.cnt_s,
+            hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.rect_s, g.cnt_s,
                                g.block_sums, g.block_vis, b.ranges, 0u);
             EMD_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(PUB_THREADS), 0, st, g.block_sums, g.block_vis, (uint32_t)nb,
@@ -503,7 +502,7 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
         return EMD_OK;
     }
     const uint32_t nslot = (uint32_t)(((size_t)capacity + DUP_SLOTS - 1) / DUP_SLOTS);
-    hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, g.sort_count, perm, g.binrec, g.rect_s, g.cnt_s,
+    hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.rect_s, g.cnt_s,
                        g.block_sums, g.block_vis, b.ranges, (uint32_t)(2 * T));
     EMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(PUB_THREADS), 0, st, g.block_sums, g.block_vis, (uint32_t)nb, (uint64_t)capacity,

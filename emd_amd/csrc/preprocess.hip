@@ -942,7 +942,12 @@ __device__ __forceinline__ bool any_nan(const float* v, int n) {
 
 __global__ void k_actor_pose_forward(int A, const float* __restrict__ q_f, const float* __restrict__ t_f,
                                      const uint8_t* __restrict__ valid, const float* __restrict__ dt,
-                                     const float* __restrict__ dq, float* __restrict__ pose) {
+                                     const float* __restrict__ dq, float* __restrict__ pose, const int32_t* __restrict__ frame_dev) {
+    if (frame_dev) {        // q_f / t_f / valid are the whole [F, A, .] tables and the frame index lives on the device (hipGraph replay)
+        const size_t f = (size_t)frame_dev[0];
+        q_f += f * A * 4; t_f += f * A * 3;
+        if (valid) valid += f * A;
+    }
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= A) return;
     const float q[4] = {q_f[4 * a], q_f[4 * a + 1], q_f[4 * a + 2], q_f[4 * a + 3]};
@@ -962,7 +967,8 @@ __global__ void k_actor_pose_forward(int A, const float* __restrict__ q_f, const
 __global__ void k_actor_pose_backward(int A, const float* __restrict__ q_f, const float* __restrict__ dt,
                                       const float* __restrict__ dq, const float* __restrict__ g_pose,
                                       float* __restrict__ d_q_f, float* __restrict__ d_t_f, float* __restrict__ d_dt,
-                                      float* __restrict__ d_dq) {
+                                      float* __restrict__ d_dq, const int32_t* __restrict__ frame_dev) {
+    if (frame_dev) { const size_t f = (size_t)frame_dev[0]; q_f += f * A * 4; d_q_f += f * A * 4; d_t_f += f * A * 3; }
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= A) return;
     const float* G = g_pose + (size_t)a * EMD_ACTOR_STRIDE;
@@ -1115,17 +1121,17 @@ int emd_launch_activations(int n, const float* ls, float* sc, const float* rq, f
 }
 
 int emd_launch_actor_pose_forward(int A, const float* q, const float* t, const uint8_t* valid, const float* dt, const float* dq,
-                                  float* pose, hipStream_t st) {
+                                  float* pose, const int32_t* frame_dev, hipStream_t st) {
     if (A <= 0) return EMD_OK;
-    hipLaunchKernelGGL(k_actor_pose_forward, dim3((A + 63) / 64), dim3(64), 0, st, A, q, t, valid, dt, dq, pose);
+    hipLaunchKernelGGL(k_actor_pose_forward, dim3((A + 63) / 64), dim3(64), 0, st, A, q, t, valid, dt, dq, pose, frame_dev);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }
 
 int emd_launch_actor_pose_backward(int A, const float* q, const float* dt, const float* dq, const float* g_pose, float* d_q,
-                                   float* d_t, float* d_dt, float* d_dq, hipStream_t st) {
+                                   float* d_t, float* d_dt, float* d_dq, const int32_t* frame_dev, hipStream_t st) {
     if (A <= 0) return EMD_OK;
-    hipLaunchKernelGGL(k_actor_pose_backward, dim3((A + 63) / 64), dim3(64), 0, st, A, q, dt, dq, g_pose, d_q, d_t, d_dt, d_dq);
+    hipLaunchKernelGGL(k_actor_pose_backward, dim3((A + 63) / 64), dim3(64), 0, st, A, q, dt, dq, g_pose, d_q, d_t, d_dt, d_dq, frame_dev);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

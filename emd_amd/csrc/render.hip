@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
 #define BQ_QUEUE 128
 
 template <bool NORMAL, bool ABS, int NX>
-__global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(NX ? 3 : 4))) k_render_backward_q(RenderDims d, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ ranges,
+__global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(NX == 0 ? 4 : NX == 1 ? 3 : 2))) k_render_backward_q(RenderDims d, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ point_list,
                                                                 const float4* __restrict__ rec,
                                                                 const float* __restrict__ final_T,

@@ -87,12 +87,21 @@ class TrackOffsetHeads(torch.nn.Module):
         if getattr(self, "_ids_key", None) != key:             # ids as int32 + points per actor: constant between densifications
             ids32 = point_ids.to(torch.int32).contiguous()
             cnt = torch.zeros(A, device=ids32.device).index_add_(0, point_ids.long().clamp_min(0), (point_ids >= 0).float())
-            self._ids_key, self._ids32, self._cnt = key, ids32, cnt
-        t = float(frame) / float(max(num_frames - 1, 1))        # (frame - start_frame) / (end_frame - start_frame), rigid.py:204,241
+            # the reference stores an actor's points contiguously: then segment starts replace the atomics of the embedding sums
+            # (checked once per point set, i.e. once per densification: the only host read of this module)
+            seg = None
+            if ids32.numel() > 0 and bool((ids32[1:] >= ids32[:-1]).all()) and int(ids32[0]) >= 0:
+                seg = torch.searchsorted(ids32, torch.arange(A + 1, device=ids32.device, dtype=torch.int32)).to(torch.int32).contiguous()
+            self._ids_key, self._ids32, self._cnt, self._seg = key, ids32, cnt, seg
+        # (frame - start_frame) / (end_frame - start_frame), rigid.py:204,241; a device frame index keeps the time on the device
+        if isinstance(frame, torch.Tensor):
+            t = frame.to(torch.float32) / float(max(num_frames - 1, 1))
+        else:
+            t = float(frame) / float(max(num_frames - 1, 1))
         k_f = self.int_lininterp(step, self.min_embeddings, self.max_embeddings, self.c2f_temporal_iter)
         return _TrackHeads.apply(self.weight, embeddings, self.track_trans_c.weight, self.track_trans_c.bias, self.track_trans_f.weight,
                                  self.track_trans_f.bias, self.track_rot_c.weight, self.track_rot_c.bias, self.track_rot_f.weight,
-                                 self.track_rot_f.bias, self._ids32, self._cnt, t, self.min_embeddings, k_f)
+                                 self.track_rot_f.bias, self._ids32, self._cnt, self._seg, t, self.min_embeddings, k_f)
 
 
 def _stream():
@@ -101,19 +110,24 @@ def _stream():
 
 class _TrackHeads(torch.autograd.Function):
     @staticmethod
-    def _args(weight, emb, heads, ids32, cnt, t, k_c, k_f, emb_sum, trans, rot):
+    def _args(weight, emb, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, trans, rot):
         a = L.EmdTrackArgs()
         a.num_actors, a.rows, a.dim = weight.shape
         a.embed_dim, a.num_points = (emb.shape[1], emb.shape[0]) if emb is not None else (0, 0)
-        a.k_coarse, a.k_fine, a.t = int(k_c), int(k_f), float(t)
+        a.k_coarse, a.k_fine = int(k_c), int(k_f)
+        if isinstance(t, torch.Tensor):
+            a.t, a.t_dev = 0.0, t.data_ptr()
+        else:
+            a.t, a.t_dev = float(t), None
         a.weight, a.embeddings, a.point_ids, a.count = weight.data_ptr(), L.ptr(emb), ids32.data_ptr(), cnt.data_ptr()
+        a.segment_start = L.ptr(seg)
         for h in range(4):
             a.head_w[h], a.head_b[h] = heads[2 * h].data_ptr(), heads[2 * h + 1].data_ptr()
         a.emb_sum, a.trans, a.rot = emb_sum.data_ptr(), L.ptr(trans), L.ptr(rot)
         return a
 
     @staticmethod
-    def forward(ctx, weight, emb, wtc, btc, wtf, btf, wrc, brc, wrf, brf, ids32, cnt, t, k_c, k_f):
+    def forward(ctx, weight, emb, wtc, btc, wtf, btf, wrc, brc, wrf, brf, ids32, cnt, seg, t, k_c, k_f):
         dev = weight.device
         c = lambda x: x.detach().contiguous().float()
         weight_c, emb_c = c(weight), c(emb)
@@ -121,12 +135,12 @@ class _TrackHeads(torch.autograd.Function):
         A, E = weight_c.shape[0], emb_c.shape[1]
         if weight_c.shape[2] + E > 64 or any(h.shape[-1] != weight_c.shape[2] + E for h in heads[0::2]):
             raise ValueError("track heads: temporal dim + embedding dim must be <= 64 and match the head widths")
-        emb_sum = torch.zeros(A, max(E, 1), device=dev)
+        emb_sum = (torch.empty if seg is not None else torch.zeros)(A, max(E, 1), device=dev)
         trans, rot = torch.empty(A, 3, device=dev), torch.empty(A, 4, device=dev)
-        a = _TrackHeads._args(weight_c, emb_c, heads, ids32, cnt, t, k_c, k_f, emb_sum, trans, rot)
+        a = _TrackHeads._args(weight_c, emb_c, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, trans, rot)
         L.check(L.load().emd_track_heads_forward(C.byref(a), _stream()), "emd_track_heads_forward")
         ctx.save_for_backward(weight_c, emb_c, ids32, cnt, emb_sum, *heads)
-        ctx.scal = (t, k_c, k_f)
+        ctx.scal, ctx.seg = (t, k_c, k_f), seg
         return trans, rot
 
     @staticmethod
@@ -143,13 +157,13 @@ class _TrackHeads(torch.autograd.Function):
         parts = torch.split(flat, sizes)
         d_weight, d_heads = parts[0].view_as(weight), [p.view_as(h) for p, h in zip(parts[1:], heads)]
         d_emb, d_mean = z(emb), torch.empty(A, max(E, 1), device=dev)
-        a = _TrackHeads._args(weight, emb, heads, ids32, cnt, *ctx.scal, emb_sum, None, None)
+        a = _TrackHeads._args(weight, emb, heads, ids32, cnt, ctx.seg, *ctx.scal, emb_sum, None, None)
         g = L.EmdTrackGrads()
         g.g_trans, g.g_rot, g.d_weight, g.d_embeddings, g.d_mean = g_trans.data_ptr(), g_rot.data_ptr(), d_weight.data_ptr(), d_emb.data_ptr(), d_mean.data_ptr()
         for h in range(4):
             g.d_head_w[h], g.d_head_b[h] = d_heads[2 * h].data_ptr(), d_heads[2 * h + 1].data_ptr()
         L.check(L.load().emd_track_heads_backward(C.byref(a), C.byref(g), _stream()), "emd_track_heads_backward")
-        return (d_weight, d_emb, *d_heads, None, None, None, None, None)
+        return (d_weight, d_emb, *d_heads, None, None, None, None, None, None)
 
 
 def build_actor_pose(instances_quats, instances_trans, instances_fv, cur_frame, track_trans=None, track_rot=None,
@@ -184,18 +198,29 @@ def build_actor_pose(instances_quats, instances_trans, instances_fv, cur_frame, 
 
 
 class _ActorPose(torch.autograd.Function):
+    """`frame`: python int, or a 1-element int32 DEVICE tensor (the row is then selected inside the kernels: the call can be replayed
+    from a hipGraph for another frame by rewriting that tensor)."""
+
     @staticmethod
     def forward(ctx, instances_quats, instances_trans, instances_fv, frame, track_trans, track_rot):
         lib = L.load()
         if instances_quats.device.type != "cuda":
             raise L.EmdError("actor_pose_table needs tensors on a ROCm device; there is no CPU path")
-        q_f, t_f = instances_quats[frame].contiguous(), instances_trans[frame].contiguous()
-        valid = None if instances_fv is None else instances_fv[frame].contiguous().view(torch.uint8)   # bool bytes, no copy kernel
-        A = q_f.shape[0]
+        on_dev = isinstance(frame, torch.Tensor)
+        if on_dev:
+            if frame.dtype != torch.int32 or frame.device != instances_quats.device:
+                raise ValueError("a device frame index must be an int32 tensor on the tables' device")
+            q_f, t_f = instances_quats.detach().contiguous(), instances_trans.detach().contiguous()
+            valid = None if instances_fv is None else instances_fv.contiguous().view(torch.uint8)
+            A = q_f.shape[1]
+        else:
+            q_f, t_f = instances_quats[frame].contiguous(), instances_trans[frame].contiguous()
+            valid = None if instances_fv is None else instances_fv[frame].contiguous().view(torch.uint8)   # bool bytes, no copy kernel
+            A = q_f.shape[0]
         pose = torch.empty(A, L.ACTOR_STRIDE, device=q_f.device, dtype=torch.float32)
         L.check(lib.emd_actor_pose_forward(A, q_f.data_ptr(), t_f.data_ptr(), L.ptr(valid), L.ptr(track_trans), L.ptr(track_rot),
-                                           pose.data_ptr(), _stream()), "emd_actor_pose_forward")
-        ctx.frame, ctx.shapes = int(frame), (instances_quats.shape, instances_trans.shape)
+                                           pose.data_ptr(), frame.data_ptr() if on_dev else None, _stream()), "emd_actor_pose_forward")
+        ctx.frame, ctx.shapes = (frame if on_dev else int(frame)), (instances_quats.shape, instances_trans.shape)
         ctx.save_for_backward(q_f, track_trans, track_rot)
         return pose
 
@@ -203,15 +228,17 @@ class _ActorPose(torch.autograd.Function):
     def backward(ctx, g_pose):
         lib = L.load()
         q_f, track_trans, track_rot = ctx.saved_tensors
-        A = q_f.shape[0]
+        on_dev = isinstance(ctx.frame, torch.Tensor)
+        A = q_f.shape[1] if on_dev else q_f.shape[0]
         nq, nt = ctx.shapes[0].numel(), ctx.shapes[1].numel()
         flat = torch.zeros(nq + nt, device=q_f.device, dtype=torch.float32)          # one fill for both dense clip gradients
         d_q, d_t = flat[:nq].view(ctx.shapes[0]), flat[nq:].view(ctx.shapes[1])
         d_dt = torch.empty_like(track_trans) if track_trans is not None else None
         d_dq = torch.empty_like(track_rot) if track_rot is not None else None
+        dq_row, dt_row = (d_q, d_t) if on_dev else (d_q[ctx.frame], d_t[ctx.frame])
         L.check(lib.emd_actor_pose_backward(A, q_f.data_ptr(), L.ptr(track_trans), L.ptr(track_rot), g_pose.contiguous().data_ptr(),
-                                            d_q[ctx.frame].data_ptr(), d_t[ctx.frame].data_ptr(), L.ptr(d_dt), L.ptr(d_dq),
-                                            _stream()), "emd_actor_pose_backward")
+                                            dq_row.data_ptr(), dt_row.data_ptr(), L.ptr(d_dt), L.ptr(d_dq),
+                                            ctx.frame.data_ptr() if on_dev else None, _stream()), "emd_actor_pose_backward")
         return d_q, d_t, None, None, d_dt, d_dq
 
 
@@ -219,7 +246,8 @@ def actor_pose_table(instances_quats, instances_trans, instances_fv, frame, trac
     """[A,12] pose table of one training frame in ONE HIP launch (and one for its backward): same result as
     `build_actor_pose(..., in_test_set=False)`; the test-time interpolation branch stays in `build_actor_pose`."""
     c = lambda t: None if t is None else t.contiguous().float()
-    return _ActorPose.apply(instances_quats, instances_trans, instances_fv, int(frame), c(track_trans), c(track_rot))
+    return _ActorPose.apply(instances_quats, instances_trans, instances_fv, frame if isinstance(frame, torch.Tensor) else int(frame),
+                            c(track_trans), c(track_rot))
 
 
 class _MotionTransform(torch.autograd.Function):

@@ -124,20 +124,31 @@ class RasterCall:
 # (when the copy's event has completed), which grows the hint and warns if a past call overflowed.
 _capacity_hint = {}
 _wide_depth = set()           # keys whose depth range needs the four-pass sort (EMD_ERR_DEPTH_RANGE seen once)
-_pending_status = {}          # key -> list of (pinned tensor, event, capacity)
-_MAX_PENDING = 16
+_watch = {}                   # key -> ring of pinned status copies in flight
+_WATCH_SLOTS = 32
+
+
+class _WatchRing:
+    """A fixed ring of pinned 16-byte buffers + events, allocated ONCE per (device, H, W): the steady state of a no_sync training
+    loop allocates nothing (a fresh pinned allocation per call costs a hipHostMalloc whenever the host runs ahead of the GPU)."""
+
+    def __init__(self):
+        self.buf = torch.empty(_WATCH_SLOTS, 4, dtype=torch.int32, pin_memory=True)
+        self.events = [torch.cuda.Event() for _ in range(_WATCH_SLOTS)]
+        self.pending = [False] * _WATCH_SLOTS
+        self.caps = [0] * _WATCH_SLOTS
+        self.next = 0
 
 
 def _poll_pending(key, opts):
-    q = _pending_status.get(key)
-    if not q:
+    ring = _watch.get(key)
+    if ring is None:
         return
-    keep = []
-    for host, ev, cap in q:
-        if not ev.query():
-            keep.append((host, ev, cap))
+    for i in range(_WATCH_SLOTS):
+        if not ring.pending[i] or not ring.events[i].query():
             continue
-        d, overflow = int(host[0]) & 0xFFFFFFFF, int(host[1])
+        ring.pending[i] = False
+        d, overflow, cap = int(ring.buf[i, 0]) & 0xFFFFFFFF, int(ring.buf[i, 1]), ring.caps[i]
         need = int(d * opts.capacity_margin) + 1024
         if overflow & 2:
             warnings.warn("emd_amd: an earlier no_sync rasterizer call saw a visible Gaussian beyond 65 536 x the near plane (three-pass depth "
@@ -150,15 +161,21 @@ def _poll_pending(key, opts):
                           RuntimeWarning, stacklevel=3)
         if overflow or need > _capacity_hint.get(key, 0):
             _capacity_hint[key] = max(need, _capacity_hint.get(key, 0))
-    _pending_status[key] = keep[-_MAX_PENDING:]
 
 
 def _watch_status(key, status, capacity):
-    host = torch.empty(4, dtype=torch.int32, pin_memory=True)
-    host.copy_(status, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    _pending_status.setdefault(key, []).append((host, ev, capacity))
+    """Copy this call's status word to pinned memory asynchronously; a LATER forward looks at it (never waited for).  When all
+    ring slots are still in flight (host far ahead of the GPU) the call is simply not watched: the next one will be."""
+    ring = _watch.get(key)
+    if ring is None:
+        ring = _watch[key] = _WatchRing()
+    i = ring.next
+    if ring.pending[i]:
+        return
+    ring.buf[i].copy_(status, non_blocking=True)
+    ring.events[i].record()
+    ring.pending[i], ring.caps[i] = True, capacity
+    ring.next = (i + 1) % _WATCH_SLOTS
 
 
 def _settings_values(rs):
@@ -252,7 +269,11 @@ class _Rasterize(torch.autograd.Function):
         out_extra = [torch.empty(3, H, W, device=dev, dtype=torch.float32) for _ in extras]
 
         key = (dev.index, H, W)
-        _poll_pending(key, opts)
+        capturing = torch.cuda.is_current_stream_capturing()       # hipGraph capture: nothing host-side may depend on this call's results
+        if capturing and not opts.no_sync:
+            raise L.EmdError("a rasterizer call captured into a hipGraph must be built with no_sync=True (the duplicate count cannot be read back)")
+        if not capturing:
+            _poll_pending(key, opts)
         if key in _wide_depth:
             flags |= L.FLAG_WIDE_DEPTH_SORT
         capacity = max(int(_capacity_hint.get(key, 0)), opts.min_capacity, 4 * N if key not in _capacity_hint else 0)
@@ -293,7 +314,8 @@ class _Rasterize(torch.autograd.Function):
             _capacity_hint[key] = max(int(a.num_rendered * opts.capacity_margin) + 1024, opts.min_capacity)
         else:
             _capacity_hint[key] = max(capacity, _capacity_hint.get(key, 0))
-            _watch_status(key, status, capacity)       # looked at by a later forward; never waited for
+            if not capturing:
+                _watch_status(key, status, capacity)       # looked at by a later forward; never waited for
 
         ctx.cs, ctx.flags, ctx.capacity, ctx.N, ctx.M = cs, flags, capacity, N, M
         ctx.num_rendered = int(a.num_rendered)

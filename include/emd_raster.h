@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 14
+#define EMD_ABI_VERSION 15
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -126,7 +126,7 @@ typedef struct EmdStatus {
     uint32_t overflow;      /* bit 0: D > bin_capacity; bit 1: depth range beyond the three-pass sort (either: results invalid,
                                the image is the background) */
     uint32_t num_visible;   /* V = Gaussians with radii > 0 */
-    uint32_t reserved;
+    uint32_t reserved;      /* internal: visible Gaussians as counted by the depth sort's compacting first pass (== num_visible) */
 } EmdStatus;
 
 typedef struct EmdDims {
@@ -304,12 +304,14 @@ int emd_densification_stats(int32_t n, const int32_t* radii, const float* dL_dme
 /* Per-frame actor pose table, training branch of RigidNodes.transform_means / transform_quats
  * (OmniRe/models/nodes/rigid.py:499-503,519-532,547-566): pose[a] = (normalize(q_f[a]), t_f[a] + dt[a], valid[a],
  * normalize(q_f[a] (x) dq[a])).  q_f [A,4] raw pose quaternions of the frame, t_f [A,3], valid [A] bytes or NULL,
- * dt [A,3] / dq [A,4] learned track offsets or NULL (NaN rows are skipped as the reference does). */
+ * dt [A,3] / dq [A,4] learned track offsets or NULL (NaN rows are skipped as the reference does).
+ * frame_dev (optional): a DEVICE int32 holding the frame index; q_f / t_f / valid (and dL_dq_f / dL_dt_f) are then the whole
+ * [F, A, .] tables and the row is selected on the device -- the call is then replayable from a hipGraph with a new frame. */
 int emd_actor_pose_forward(int32_t num_actors, const float* q_f, const float* t_f, const uint8_t* valid, const float* dt,
-                           const float* dq, float* pose /*[A,12]*/, void* hip_stream);
+                           const float* dq, float* pose /*[A,12]*/, const int32_t* frame_dev, void* hip_stream);
 int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* dt, const float* dq, const float* dL_dpose,
                             float* dL_dq_f, float* dL_dt_f, float* dL_ddt /*or NULL*/, float* dL_ddq /*or NULL*/,
-                            void* hip_stream);
+                            const int32_t* frame_dev, void* hip_stream);
 
 /* L1 photometric loss of the training step (S3Gaussian/utils/loss_utils.py:21-22, train.py:226):
  * loss[0] = mean |a - b| over n elements, grad[i] = sign(a[i] - b[i]) / n (grad may be NULL).  One launch. */
@@ -445,10 +447,13 @@ typedef struct EmdTrackArgs {
     int32_t num_actors, rows, dim, embed_dim;    /* temporal tables [A, rows, dim]; dim + embed_dim <= 64 */
     int32_t k_coarse, k_fine, num_points, reserved;
     float t;                                     /* normalised frame (frame - start) / (end - start), rigid.py:204,241 */
+    const float* t_dev;                          /* optional DEVICE copy of t (overrides it): hipGraph replay with a new frame */
     const float* weight;                         /* [A, rows, dim] */
     const float* embeddings;                     /* [num_points, embed_dim] of the actor Gaussians */
     const int32_t* point_ids;                    /* [num_points] actor of every point (-1: none) */
     const float* count;                          /* [A] points per actor, as floats */
+    const int32_t* segment_start;                /* [A+1] or NULL: point_ids are sorted and actor a owns points [start[a], start[a+1]) -- the
+                                                    sums are then formed without atomics and emb_sum need not be zero-filled */
     const float* head_w[4];
     const float* head_b[4];
     float* emb_sum;                              /* [A, embed_dim] scratch: per-actor embedding sums; ZERO-FILLED by the caller before forward, kept for backward */

@@ -133,7 +133,7 @@ def test_no_sync_overflow_is_reported_by_a_later_call_and_heals():
     t = _leaves(case)
     good = _call(GaussianRasterizer(rs, no_sync=False), t)[0].detach().clone()
     key = (0, case["H"], case["W"])
-    rasterizer._pending_status.pop(key, None)
+    rasterizer._watch.pop(key, None)
     rasterizer._capacity_hint[key] = 64                       # far too small
     r = GaussianRasterizer(rs, no_sync=True, min_capacity=64)
     with torch.no_grad():
@@ -199,7 +199,83 @@ def test_one_binning_many_colour_sets(n_extra):
         assert_grad_close(f_one[k].grad.cpu().numpy(), f_sep[k].grad.cpu().numpy(), f"colors_extra[{k}] vs separate call")
         for name in total:
             total[name] += np.asarray(of["grads"][name], np.float64).reshape(total[name].shape)
-    from tests.helpers import END2END_ATOL_FRAC
+    from tests.helpers import END2END_ATOL_FRAC, END2END_REL_L2
     for name in total:          # (scales / rotations: end-to-end floor of the ill-conditioned conic -> covariance chain, tests/helpers.py)
-        assert_grad_close(t1[name].grad.cpu().numpy(), total[name], name, atol_frac=END2END_ATOL_FRAC if name in ("scales", "rotations") else None)
+        loose = name in ("scales", "rotations")
+        assert_grad_close(t1[name].grad.cpu().numpy(), total[name], name, atol_frac=END2END_ATOL_FRAC if loose else None, rel_l2=END2END_REL_L2 if loose else None)
     assert_grad_close(t1["shs"].grad.cpu().numpy(), orc["grads"]["shs"], "shs")
+
+
+def test_step_replayed_from_a_hip_graph_equals_the_eager_step():
+    """bench.py replays the whole step (pose table with learned track offsets -> fused-motion rasterizer -> L1 -> backward) from ONE
+    captured hipGraph; camera, frame index and frame time are device-resident inputs selected by a device index.  A replay for
+    another view must give exactly the eager step of that view: image bit for bit, every gradient."""
+    import types
+    from emd_amd import RasterOptions, scenes
+    from emd_amd.model import StreetGaussians, l1_loss, render
+    N, H, W, F = 30000, 96, 128, 6
+    scene = scenes.add_actors(scenes.make_static_scene(N, seed=0), num_actors=4, pts_per_actor=2000, num_frames=F, seed=1)
+    model = StreetGaussians(scene, DEV, track_heads=True)
+    params = list(model.parameters())
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(3)).to(DEV)
+    bg = torch.zeros(3)
+    views = [(f, c, scenes.rig_camera(f, c, H, W)) for f, c in ((0, 0), (3, 1), (5, 2), (2, 0))]
+    opts = RasterOptions(no_sync=True)
+
+    def eager(i):
+        f, c, cam = views[i]
+        for p in params:
+            p.grad = None
+        o = render(model, cam, bg, frame=f, iteration=0, options=opts)
+        l1_loss(o["render"], target).backward()
+        return o["render"].detach().clone(), [None if p.grad is None else p.grad.detach().clone() for p in params]
+    # a synchronising call sizes the binning workspace for all views
+    from emd_amd import rasterizer as rz
+    dmax = 0
+    for f, c, cam in views:
+        with torch.no_grad():
+            o = render(model, cam, bg, frame=f, iteration=0, options=opts.replace(no_sync=False))
+        dmax = max(dmax, o["raster_call"].last_status()["num_rendered"])
+    rz._capacity_hint[(DEV.index, H, W)] = int(dmax * 1.3) + 1024
+    ref = [eager(i) for i in range(len(views))]
+    blocks = torch.stack([torch.cat([bg, c_.world_view_transform.reshape(-1), c_.full_proj_transform.reshape(-1), c_.camera_center.reshape(-1)])
+                          for _, _, c_ in views]).to(DEV)
+    frame_of = torch.tensor([f for f, _, _ in views], dtype=torch.int32, device=DEV)
+    sel = torch.zeros(1, dtype=torch.int64, device=DEV)
+    cam0 = views[0][2]
+    out = {}
+
+    def body():
+        for p in params:
+            p.grad = None
+        blk = blocks.index_select(0, sel)[0]
+        cam_g = types.SimpleNamespace(image_height=H, image_width=W, tanfovx=cam0.tanfovx, tanfovy=cam0.tanfovy,
+                                      world_view_transform=blk[3:19].view(4, 4), full_proj_transform=blk[19:35].view(4, 4), camera_center=blk[35:38])
+        o = render(model, cam_g, blk[0:3], frame=frame_of.index_select(0, sel), iteration=0, options=opts)
+        l1_loss(o["render"], target).backward()
+        out["img"] = o["render"].detach()          # (no reference to the autograd graph may outlive the body: its AccumulateGrad nodes are bound to a stream)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        body()
+    for i in (1, 3, 0, 2):
+        sel.fill_(i)
+        g.replay()
+        torch.cuda.synchronize()
+        img_ref, grads_ref = ref[i]
+        assert torch.equal(out["img"].detach(), img_ref), f"view {i}: replayed image differs from the eager one"
+        for p, gr in zip(params, grads_ref):
+            if gr is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0
+                continue
+            err = float((p.grad - gr).abs().max())
+            bad = ((p.grad - gr).abs() > 2e-5 * max(float(gr.abs().max()), 1e-12))
+            names = [n for n, q in model.named_parameters() if q is p]
+            assert err <= 2e-5 * max(float(gr.abs().max()), 1e-12), (i, names, tuple(p.shape), err, int(bad.sum()), bad.nonzero()[:5].tolist(),
+                                                                     p.grad[bad][:5].tolist(), gr[bad][:5].tolist())
