@@ -65,6 +65,33 @@ void emd_prof_switch(int ended, int started, hipStream_t st) {
     g_prof_open[started] = e;
 }
 
+namespace {
+__global__ void __launch_bounds__(EMD_BLOCK) k_zero_words(uint32_t* __restrict__ p, size_t head, size_t quads, size_t words) {
+    // [0, head) single words up to 16-byte alignment, then `quads` uint4 stores, then the tail words
+    const size_t i = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x, stride = (size_t)gridDim.x * EMD_BLOCK;
+    if (i < head) p[i] = 0u;
+    uint4* q = (uint4*)(p + head);
+    for (size_t k = i; k < quads; k += stride) q[k] = make_uint4(0u, 0u, 0u, 0u);
+    const size_t tail0 = head + quads * 4;
+    if (tail0 + i < words && i < 4) p[tail0 + i] = 0u;
+}
+}  // namespace
+
+int emd_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (!p || bytes == 0) return EMD_OK;
+    if (((uintptr_t)p & 3) || (bytes & 3)) { emd_set_error("emd_zero_async: pointer / size not a multiple of 4 bytes"); return EMD_ERR_INVALID; }
+    const size_t words = bytes / 4;
+    size_t head = ((16 - ((uintptr_t)p & 15)) & 15) / 4;
+    if (head > words) head = words;
+    const size_t quads = (words - head) / 4;
+    size_t blocks = (quads + EMD_BLOCK - 1) / EMD_BLOCK;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)blocks), dim3(EMD_BLOCK), 0, st, (uint32_t*)p, head, quads, words);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
 int emd_launch_motion_forward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
                               float* wm, float* wq, float* wo, hipStream_t st);
 int emd_launch_motion_backward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
@@ -251,7 +278,7 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     if ((a->flags & EMD_FLAG_ABSGRAD) && !a->dL_dmeans2D_abs) { emd_set_error("backward: EMD_FLAG_ABSGRAD without dL_dmeans2D_abs"); return EMD_ERR_INVALID; }
     const bool dbg = a->s.debug != 0;
     emd_prof_begin(PROF_OTHER, st);
-    EMD_HIP_CHECK(hipMemsetAsync(a->bwd_ws, 0, need, st));
+    { int zrc = emd_zero_async(a->bwd_ws, need, st); if (zrc) return zrc; }
     float* pose_grad = nullptr;       // accumulated by K8 with atomics; cleared by K7's first workgroup
     int pose_grad_n = 0;
     if ((a->flags & EMD_FLAG_MOTION) && a->dL_dactor_pose && a->motion.num_actors > 0) {
@@ -336,7 +363,7 @@ int emd_motion_backward(int32_t n, const float* means, const float* quats, const
     if (motion->actor_id && (!motion->actor_pose || motion->num_actors <= 0)) { emd_set_error("motion_backward: actor_id without actor_pose"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     if (dL_dactor_pose && motion->num_actors > 0)
-        EMD_HIP_CHECK(hipMemsetAsync(dL_dactor_pose, 0, (size_t)motion->num_actors * EMD_ACTOR_STRIDE * sizeof(float), st));
+        { int zrc = emd_zero_async(dL_dactor_pose, (size_t)motion->num_actors * EMD_ACTOR_STRIDE * sizeof(float), st); if (zrc) return zrc; }
     return emd_launch_motion_backward(n, means, quats, opacities, *motion, dL_dworld_means, dL_dworld_quats,
                                       dL_dopacities_out, dL_dmeans, dL_dquats, dL_dopacities, dL_dactor_pose,
                                       dL_dresidual_dx, dL_dresidual_dq, st);

@@ -459,7 +459,7 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
     int rc;
     // 1. visible Gaussians in depth order.  The status word is cleared first: the depth passes may raise its overflow bit 1.
     emd_prof_switch(PROF_PREPROCESS, PROF_SORT, st);
-    EMD_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(EmdStatus), st));
+    { int zrc = emd_zero_async(status, sizeof(EmdStatus), st); if (zrc) return zrc; }
     uint32_t* const sort_count = &status->reserved;          // V after the first (compacting) depth pass lives in the status block: one memset
     const bool wide = (flags & EMD_FLAG_WIDE_DEPTH_SORT) != 0;
     const int depth_passes = wide ? EMD_DEPTH_PASSES_WIDE : EMD_DEPTH_PASSES_NARROW;
@@ -487,7 +487,7 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
     // 2. tile counts in that order, offsets, duplicate
     emd_prof_switch(PROF_SORT, PROF_DUPLICATE, st);
     if (N == 0 || capacity <= 0) {
-        EMD_HIP_CHECK(hipMemsetAsync(b.ranges, 0, (size_t)T * 8, st));
+        { int zrc = emd_zero_async(b.ranges, (size_t)T * 8, st); if (zrc) return zrc; }
         if (N > 0) {   // D and V are still reported (capacity 0 is how callers size the workspace)
             hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.rect_s, g.cnt_s,
                                g.block_sums, g.block_vis, b.ranges, 0u);

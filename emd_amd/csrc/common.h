@@ -142,6 +142,11 @@ void emd_set_error(const char* fmt, ...);
     } while (0)
 #define EMD_LAUNCH_CHECK() EMD_HIP_CHECK(hipGetLastError())
 
+// Zero `bytes` (a multiple of 4, `p` 4-byte aligned) with a KERNEL on `st` (api.hip).  Not hipMemsetAsync: a memset node captured into a
+// hipGraph on ROCm 7.2 / gfx950 replays with a corrupt 16-byte fill pattern from the second replay on (every fourth word of the
+// destination came back as garbage: tests/test_boundary_gpu.py's graph test caught it), and a kernel node costs the same.
+int emd_zero_async(void* p, size_t bytes, hipStream_t st);
+
 // ---- per-stage HIP-event timing (api.hip); no-ops unless emd_profile_enable(1) ------------------------------
 enum { PROF_PREPROCESS = 0, PROF_DUPLICATE, PROF_SORT, PROF_RANGES, PROF_RENDER_FWD, PROF_RENDER_BWD, PROF_PREPROCESS_BWD, PROF_OTHER };
 void emd_prof_begin(int stage, hipStream_t st);

@@ -275,7 +275,7 @@ extern "C" int emd_image_loss(const EmdLossArgs* a, void* workspace, size_t work
     const size_t HW = (size_t)a->height * a->width;
     float* sums = (float*)workspace;
     float* dmaps = sums + NUM_SUMS * SUM_SLOTS;
-    EMD_HIP_CHECK(hipMemsetAsync(sums, 0, NUM_SUMS * SUM_SLOTS * sizeof(float), st));
+    { int zrc = emd_zero_async(sums, NUM_SUMS * SUM_SLOTS * sizeof(float), st); if (zrc) return zrc; }
     Win win;
     {   // loss_utils.py:56-58: exp(-(x - 5)^2 / (2 * 1.5^2)) normalised, built in double like Python, stored in float
         double g[11], s = 0.0;

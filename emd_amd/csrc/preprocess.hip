@@ -1137,7 +1137,7 @@ int emd_launch_actor_pose_backward(int A, const float* q, const float* dt, const
 }
 
 int emd_launch_l1_loss(size_t n, const float* a, const float* b, float* loss, float* grad, hipStream_t st) {
-    EMD_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), st));
+    { int zrc = emd_zero_async(loss, sizeof(float), st); if (zrc) return zrc; }
     if (n == 0) return EMD_OK;
     size_t blocks = (n / 4 + EMD_BLOCK - 1) / EMD_BLOCK;
     if (blocks > 512) blocks = 512;     // one same-address float atomic per block: 2048 of them serialised for ~20 us

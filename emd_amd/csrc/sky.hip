@@ -279,7 +279,7 @@ extern "C" int emd_sky_backward(const EmdSkyBwdArgs* b, void* hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
     const size_t P = (size_t)b->f.height * b->f.width;
     if (b->dL_dcube)
-        EMD_HIP_CHECK(hipMemsetAsync(b->dL_dcube, 0, (size_t)6 * b->f.resolution * b->f.resolution * 3 * sizeof(float), st));
+        { int zrc = emd_zero_async(b->dL_dcube, (size_t)6 * b->f.resolution * b->f.resolution * 3 * sizeof(float), st); if (zrc) return zrc; }
     const unsigned grid = b->f.height > 1 ? (unsigned)(((b->f.width + 15) / 16) * ((b->f.height + 15) / 16))
                                           : (unsigned)((P + EMD_BLOCK - 1) / EMD_BLOCK);
     hipLaunchKernelGGL(k_sky_backward, dim3(grid), dim3(EMD_BLOCK), 0, st, *b);
