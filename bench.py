@@ -65,11 +65,7 @@ def pmc_traffic(stage, passes):
         name = f[0]
         if name in PMC_STAGE_KERNELS.get(stage, ()):
             per_launch = (float(f[3]) + float(f[4])) * 1e6        # fetch_MB_x2 + write_MB
-            launches = 1
-            if name.endswith("[N]"):
-                launches = 4 + (passes if "scan_bins" in name else 0)      # depth passes (+ the tile passes' scans)
-            elif name.endswith("[D]"):
-                launches = passes
+            launches = float(f[5]) if len(f) > 5 else 1.0           # launches per iteration, counted by make_pmc_summary.py
             tot += per_launch * launches
     return tot or None
 
@@ -112,8 +108,9 @@ def algorithmic_bytes(N, V, D, HW, T, C, p, residual=False, C_bwd=None):
         "preprocess": 68 * N + (12 * N if residual else 0) + V * (216 + 4 * Cf),
         # depth-ordered Gaussians -> (rect, count) gather, scan, (tile id, Gaussian id) pairs
         "scan_duplicate": 28 * N + 8 * V + 8 * D,
-        # 4 passes over the N (depth, id) pairs + p passes over the D (tile, id) pairs, 8 B read + 8 B written each
-        "radix_sort": 4 * 16 * N + p * 16 * D,
+        # depth sort: the first pass reads the N depth keys and writes the V visible (key, id) pairs, two more passes over those
+        # pairs; then p passes over the D (tile, id) pairs -- 8 B read + 8 B written per element and pass
+        "radix_sort": 4 * N + 8 * V + 2 * 16 * V + p * 16 * D,
         "tile_ranges": 4 * D + 8 * T,
         "render_forward": D * (4 + 24 + 4 * Cf) + HW * (4 * (Cf + 1) + 8),
         "render_backward": D * (28 + 4 * C) + HW * (4 * (C + 1) + 8) + V * (24 + 4 * C),
@@ -414,7 +411,8 @@ def main():
                                    "one 1066x1600 view per GPU per step, L1 loss, fwd+bwd to all 59 floats/Gaussian + actor poses"
                                    + ("" if args.no_track_heads else " + track heads"),
                        "gaussians": N, "height": H, "width": W, "visible_V": round(V, 1), "duplicates_D": round(D, 1), "tiles_T": T,
-                       "radix_passes_depth_on_N": 4, "radix_passes_tile_on_D": passes, "blended_channels_C": C, "views_per_step": world,
+                       "radix_passes_depth": "3 x 9 bits above the near plane: first over the N keys (compacting to V), two over the V pairs",
+                       "radix_passes_tile_on_D": passes, "blended_channels_C": C, "views_per_step": world,
                        "rig_cameras": num_cams, "rank_view_mapping": mapping, "track_heads": not args.no_track_heads,
                        "densification_stats_in_step": bool(args.densify_stats),
                        "step_issue": "hipGraph replay (one capture, device-resident per-step inputs)" if graph is not None else "eager (Python issues every launch)",

@@ -5,15 +5,19 @@
 // duplicate through every radix pass.  The depth bits of a key are a property of the GAUSSIAN, not of the duplicate, so
 // the least-significant 32 bits of the LSD sort can be done BEFORE duplicating, on N (depth, id) pairs instead of
 // D (key, id) triples (D ~ 3.8 V on the bench scene):
-//     1. stable LSD radix sort of the N Gaussians by depth bits (4 passes over 8 B pairs; invisible ones sort last),
+//     1. stable LSD radix sort of the VISIBLE Gaussians by depth: the keys are (depth bits - bits(near plane)), non-negative floats
+//        order like their bit patterns, so 3 passes of 9 bits cover depths up to ~2^13 x near (EMD_ERR_DEPTH_RANGE -> the caller
+//        retries with EMD_FLAG_WIDE_DEPTH_SORT: 4 passes of 8 bits on the raw bits).  The first pass reads the N keys, drops the
+//        culled ones (0xFFFFFFFF) and publishes V; the other two run over V (key, id) pairs,
 //     2. gather the tile rectangle / tile count of each Gaussian in that order, scan, duplicate: the duplicates appear
-//        ordered by (depth, Gaussian id) and carry only (tile id, Gaussian id),
+//        ordered by (depth, Gaussian id) and carry only (tile id, Gaussian id); the duplicate kernel also builds the digit
+//        histogram of the first tile pass,
 //     3. stable LSD radix sort of the D pairs by the ceil(log2(tiles)) tile bits (2 passes for up to 64 K tiles).
 // A stable sort by a low key followed by a stable sort by a high key IS the LSD sort of the concatenated key, and the
 // initial order is the Gaussian index in both formulations, so the final order is bit-for-bit the order of the upstream
 // sort of the 64-bit keys: (tile, depth bits, Gaussian id).  emd_raster_export_binning rebuilds the 64-bit keys from
-// (tile id, depth bits of the Gaussian) for the parity tests.  Bytes through the radix passes on the bench scene:
-// 6 x 24 B x 5.7 M = 820 MB before, 4 x 16 B x 2 M + 2 x 16 B x 5.7 M = 310 MB now.
+// (tile id, depth bits of the Gaussian) for the parity tests.  Bytes through the radix passes on the bench scene
+// (N = 2 M, V = 1.06 M, D = 4.6 M): 6 x 24 B x 4.6 M = 670 MB upstream, 4 N + 8 V + 2 x 16 V + 2 x 16 D = 200 MB here.
 //
 // Design for gfx950:
 //   - the duplicate count D stays on the device (EmdStatus.num_rendered); every kernel here is launched on the

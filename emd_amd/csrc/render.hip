@@ -2,16 +2,21 @@
 // [UPSTREAM K6/K7; call site S3Gaussian/gaussian_renderer/__init__.py:145-155,
 //  outputs consumed at :158-168,299-301 and S3Gaussian/train.py:226-368]
 //
-// Work decomposition (wave64):
-//   - one 256-thread workgroup per 16x16 tile; each of its 4 waves owns an 8x8 pixel quadrant (spatially compact,
-//     so "no lane of this wave is touched by Gaussian j" is common and whole waves skip work on a ballot);
-//   - the tile's depth-sorted list is staged through LDS 256 entries at a time: lane t gathers the 48/64-byte
-//     projected record of entry t (3-4 dwordx4 loads from one half cache line), then every lane walks the staged
-//     chunk with broadcast LDS reads;
-//   - K7 walks the same list back to front.  Per-(pixel, Gaussian) partial derivatives are reduced across the wave
-//     with DPP row shifts/broadcasts (6 v_add_f32_dpp per value, no LDS traffic), lane 63 of each wave adds the
-//     wave sums into an LDS accumulator row for the staged chunk, and after the chunk one lane per entry issues
-//     the global float atomics: at most one atomic row per (Gaussian, tile) instead of one per (Gaussian, pixel).
+// Work decomposition (wave64), both kernels wave-autonomous -- no workgroup barrier anywhere:
+//   - one 64-thread workgroup (= one wave) per 8x8-pixel quadrant of a 16x16 tile; blockIdx -> (position in the longest-first
+//     tile order, quadrant) keeps the four quadrant waves of a tile on one XCD (ordered_quadrant_block below);
+//   - the wave scans the tile's depth-sorted list itself, 64 entries per step (records prefetched ahead), applies the
+//     exact-conservative footprint culling below and keeps the survivors in an LDS queue;
+//   - K6 (k_render_forward_q): the four 16-lane DPP rows of the wave own the quadrant's four 4x4 sub-blocks; each row drains
+//     the byte list of its sub-block with the pinned exp / FMA compositing arithmetic -- lane = pixel,
+//     front to back, early exit per quadrant; up to EMD_MAX_EXTRA further colour sets ride along in the same walk;
+//   - K7 (k_render_backward_q): lane = list ENTRY, the wave loops over the quadrant's 64 pixels (two per iteration in packed
+//     fp32).  A batch of 64 queued entries is laid out BACK TO FRONT (lane 0 = deepest): the transmittance in front of entry k
+//     is T_final times the inclusive prefix product of 1 / (1 - alpha) over the lanes, the colour behind it the exclusive prefix
+//     sum of g alpha T (two 6-step DPP scans per pixel), so every quantity is built up from the small end and carries a RELATIVE
+//     rounding error (the front-to-back form subtracted running sums from totals: absolute error, visible in the deepest
+//     entries' gradients).  Per-entry derivative sums accumulate in registers as moments of u = G dL/dG; after its batches the
+//     lane adds ONE 48-byte row (+16 B per extra colour set) to its Gaussian with global float atomics.
 #include <stdlib.h>
 
 #include "common.h"

@@ -4,7 +4,8 @@ gradients averaged with an RCCL all-reduce over xGMI (torch.distributed backend 
 The reference trains one view per step on one GPU (S3Gaussian/train.py:203; OmniRe/models/trainers/base.py:411);
 at world_size 1 this module is a no-op and the step is the reference step.  Design:
   - parameters, actor tables and MLPs are replicated (2 M x 236 B = 472 MB << 288 GB);
-  - step s, rank r renders view `views[(s * W + r) % len(views)]`; no collective on the data path until gradients;
+  - step s, rank r renders view (s * W + r) of the timestamp-major view list (`frame_and_camera`: a rig's cameras of one timestamp
+    first, surplus ranks take cameras of the next timestamp); every rank a distinct view; no collective on the data path until gradients;
   - gradient exchange per step (`GradientExchange`): the SH gradient travels as rank-one factors (all-gather of 12 B per Gaussian
     and rank + camera centres + per-view actor pose tables, dense gradient rebuilt locally), the four small per-Gaussian
     gradients as ONE in-place all-reduce of the slab the rasterizer's backward carved them from, started from inside

@@ -38,11 +38,15 @@ def main(d):
     print("# KiB per dispatch averaged over dispatches, in MB.  fetch_MB_x2 = gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md);")
     print("# WRITE_SIZE is exact for 16 B/lane stores and float atomics.  Infinity-Cache hits are counted: fabric traffic, an upper bound on HBM.")
     print("# k_radix_*[N]: passes of the Gaussian depth sort (grid over N), [D]: passes of the tile sort (grid over the duplicate capacity).")
-    print("kernel,calls,fetch_MB_raw,fetch_MB_x2,write_MB")
+    print("# per_iter: launches of the kernel per training iteration (calls / calls of k_preprocess, resp. of k_render_backward_q for backward kernels)")
+    print("kernel,calls,fetch_MB_raw,fetch_MB_x2,write_MB,per_iter")
+    n_fwd, n_bwd = max(len(f.get("k_preprocess", [])), 1), max(len(f.get("k_render_backward_q", [])), 1)
     for k in sorted(set(f) | set(w)):
         fm = sum(f.get(k, [0])) / max(len(f.get(k, [0])), 1) * 1024 / 1e6
         wm = sum(w.get(k, [0])) / max(len(w.get(k, [0])), 1) * 1024 / 1e6
-        print(f"{k},{len(f.get(k, []))},{fm:.1f},{2 * fm:.1f},{wm:.1f}")
+        bwd = "backward" in k or k.endswith("_bwd") or k == "k_l1_loss"
+        calls = len(f.get(k, []))
+        print(f"{k},{calls},{fm:.1f},{2 * fm:.1f},{wm:.1f},{calls / (n_bwd if bwd else n_fwd):.2f}")
 
 
 if __name__ == "__main__":
