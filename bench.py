@@ -232,11 +232,12 @@ def main():
             rec.on_backward = xchg.start
         out = render(model, cam, bg, frame=f, iteration=step, options=options, record=rec)
         if xchg is not None:
-            xchg.actor_pose = out["actor_pose"]
+            xchg.actor_pose = None if out["actor_pose"] is None else out["actor_pose"].detach()   # (no reference into the autograd graph)
         loss = l1_loss(out["render"], target)
         loss.backward()
         if xchg is not None:
             xchg.finish(model._features, model._xyz, model.active_sh_degree, other_params=params)
+            rec.on_backward = None
         elif world > 1:
             dp.allreduce_gradients(params)
         if stats is not None:
@@ -258,15 +259,18 @@ def main():
             o = render(model, cam, bg, frame=f, options=sync_opts)
             dmax = max(dmax, o["raster_call"].last_status()["num_rendered"])
     _rz._capacity_hint[(dev.index, H, W)] = int(dmax * 1.3) + 1024
-    # ---- the step as a hipGraph (1 GPU): the ~45 launches of a step are captured once and replayed; everything that changes from
+    # ---- the step as a hipGraph: the ~45 launches of a step are captured once and replayed; everything that changes from
     # step to step (camera matrices, frame index, frame time) lives in device buffers selected by ONE device index `sel`, rewritten
     # before every replay.  The host then spends ~20 us per step instead of ~1-2 ms of Python + launch calls, i.e. the run is
     # GPU-bound whatever the host is doing.  (--eager, or a failed capture, issues the same step from Python.)
     total_steps = args.warmup + args.steps
     graph = None
     out = o = None          # no autograd graph of an eager step may be alive at capture time (its AccumulateGrad nodes are bound to the eager stream)
+    import gc
+    gc.collect()            # ... including graphs held only by reference cycles (RasterCall <-> GradientExchange)
     status_log = torch.zeros(max(total_steps, 1), 4, dtype=torch.int32, device=dev)
-    if world == 1 and not args.eager and opts.no_sync:
+    gstate = {}
+    if not args.eager and opts.no_sync:
         try:
             import types
             views = [cam_for(s_) for s_ in range(total_steps)]
@@ -284,11 +288,15 @@ def main():
                 cam_g = types.SimpleNamespace(image_height=H, image_width=W, tanfovx=cam0.tanfovx, tanfovy=cam0.tanfovy,
                                               world_view_transform=blk[3:19].view(4, 4), full_proj_transform=blk[19:35].view(4, 4),
                                               camera_center=blk[35:38])
-                o = render(model, cam_g, blk[0:3], frame=frame_dev, iteration=0, options=opts)
+                rec_g = RasterCall()
+                o = render(model, cam_g, blk[0:3], frame=frame_dev, iteration=0, options=opts, record=rec_g)
                 l1_loss(o["render"], target).backward()
                 if stats is not None:
                     dp.add_densification_stats(o["viewspace_points"].grad, o["radii"], *stats)
                 status_log.index_copy_(0, sel, o["raster_call"].status.view(1, 4))
+                # what the gradient exchange of a multi-GPU step reads after the replay: graph-static tensors
+                gstate["rec"], gstate["campos"] = rec_g, blk[35:38]
+                gstate["pose"] = None if o["actor_pose"] is None else o["actor_pose"].detach()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -298,7 +306,9 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            # (multi-rank: the process group's watchdog thread polls events while we capture; "thread_local" keeps its calls from
+            #  invalidating the capture -- nothing of the exchange is captured)
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="global" if world == 1 else "thread_local"):
                 graph_body()
             torch.cuda.synchronize()
         except Exception as e:          # capture is an optimisation of the host side only: fall back to issuing the step from Python
@@ -309,6 +319,14 @@ def main():
         if graph is not None:
             sel.fill_(step)
             graph.replay()
+            if opts.factored_sh_grad:
+                # the exchange is issued behind the replay (RCCL collectives are not captured): what follows K8 inside the graph is
+                # ~20 us of pose / track-head backward, so nothing is lost against starting it from inside backward()
+                xchg = dp.GradientExchange(gstate["campos"], actor_ids=model.actor_id if model.has_actors else None, actor_pose=gstate["pose"])
+                xchg.start(gstate["rec"])
+                xchg.finish(model._features, model._xyz, model.active_sh_degree, other_params=params)
+            elif world > 1:
+                dp.allreduce_gradients(params)
         else:
             o = one_step(step)
             status_log[step].copy_(o["raster_call"].status)
@@ -415,7 +433,8 @@ def main():
                        "radix_passes_tile_on_D": passes, "blended_channels_C": C, "views_per_step": world,
                        "rig_cameras": num_cams, "rank_view_mapping": mapping, "track_heads": not args.no_track_heads,
                        "densification_stats_in_step": bool(args.densify_stats),
-                       "step_issue": "hipGraph replay (one capture, device-resident per-step inputs)" if graph is not None else "eager (Python issues every launch)",
+                       "step_issue": ("hipGraph replay (one capture, device-resident per-step inputs" + ("; the gradient exchange is issued behind each replay)" if world > 1 else ")"))
+                                     if graph is not None else "eager (Python issues every launch)",
                        "parallelism": f"view-parallel dp{world}", "count_readback": bool(args.sync_count),
                        "gradient_exchange": ("none (1 GPU)" if world == 1 else
                                              "SH gradient as rank-one factors: all-gather of 12 B per Gaussian and rank + camera centres + per-view actor "

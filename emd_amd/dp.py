@@ -123,7 +123,8 @@ class GradientExchange:
     World size 1: `start` does nothing and `finish` only rebuilds (the local cost of the factored path)."""
 
     def __init__(self, campos_local, actor_ids=None, actor_pose=None, residual_dx=None, average=True):
-        self.campos_local, self.actor_ids, self.actor_pose, self.residual_dx = campos_local, actor_ids, actor_pose, residual_dx
+        self.campos_local, self.actor_ids, self.residual_dx = campos_local, actor_ids, residual_dx
+        self.actor_pose = None if actor_pose is None else actor_pose.detach()       # values only: no reference into an autograd graph
         self.average = average
         self.rec = None
         self._gathers, self._slab_work, self._g_cat, self._campos, self._poses = [], None, None, None, None

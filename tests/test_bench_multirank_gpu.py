@@ -31,6 +31,7 @@ def test_bench_two_ranks_share_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["views_per_step"] == 2 and d["config"]["parallelism"] == "view-parallel dp2" and d["config"]["rig_cameras"] == 2
+    assert d["config"]["step_issue"].startswith("hipGraph replay"), d["config"]["step_issue"]     # N > 1 is issued like N = 1
 
 
 @pytest.mark.parametrize("ranks,mixed", [(2, False), (3, True)], ids=["2-ranks-one-timestamp", "3-ranks-mixed-timestamps"])
