@@ -359,6 +359,11 @@ def raw_params_parity(case, log_s, raw_q, logit, device="cuda:0", check_images_e
     if motion:
         pose = case["actor_pose"].to(dev).requires_grad_(True)
         kw = dict(actor_ids=case["actor_ids"].to(dev), actor_pose=pose)
+    rdx = rdq = None
+    if case.get("residual_dx") is not None:          # the learned deformation residual (deformable.py:35-47) as an input of K1
+        rdx = kw["residual_dx"] = case["residual_dx"].to(dev).requires_grad_(True)
+    if case.get("residual_dq") is not None:
+        rdq = kw["residual_dq"] = case["residual_dq"].to(dev).requires_grad_(True)
     rast = GaussianRasterizer(rs, compute_normal=True, keep_render_grads=True)
     color, depth, normal, alpha, radii, _ = rast(means3D=means, means2D=m2, shs=shs, opacities=logit, scales=log_s,
                                                  rotations=raw_q, raw_params=True, **kw)
@@ -395,6 +400,9 @@ def raw_params_parity(case, log_s, raw_q, logit, device="cuda:0", check_images_e
         e["raw_quats"] = (gq - qu * (qu * gq).sum(1, keepdims=True)) / nrm
         if motion:
             e["raw_quats"][dyn.numpy()] = g["rotations"][dyn.numpy()]      # the oracle already differentiates the in-transform normalisation
+        for k_ in ("residual_dx", "residual_dq"):
+            if g.get(k_) is not None:
+                e[k_] = g[k_]
         return e
     go = orc["grads"]
     # (a) the render backward alone, (b) the projection backward on the kernel's own render gradients, (c) end to end
@@ -415,5 +423,12 @@ def raw_params_parity(case, log_s, raw_q, logit, device="cuda:0", check_images_e
     res["shs"] = assert_grad_close(shs.grad.cpu().numpy(), go["shs"], "shs", rtol)
     if motion:
         res["actor_pose"] = assert_pose_close(pose.grad.cpu().numpy(), go["actor_pose"], go, orc["scene"])
+    if rdx is not None:
+        res["residual_dx"] = assert_grad_close(rdx.grad.cpu().numpy(), go["residual_dx"], "residual_dx", rtol)
+    if rdq is not None:
+        if rtol is None:
+            assert_grad_close(rdq.grad.cpu().numpy(), k8["residual_dq"], "projection backward on the kernel's own render gradients: residual_dq")
+        res["residual_dq"] = assert_grad_close(rdq.grad.cpu().numpy(), go["residual_dq"], "residual_dq", rtol, atol_frac=END2END_ATOL_FRAC,
+                                               rel_l2=END2END_REL_L2)
     res["D"], res["V"] = orc["bin"]["D"], st["num_visible"]
     return res

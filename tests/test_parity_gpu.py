@@ -177,7 +177,7 @@ def test_fused_activations_raw_params(motion):
     raw_params_parity(case, log_s, raw_q, logit)
 
 
-def _bench_scene_case(n, frame, cam_idx=0, actors=True, seed_grad=17):
+def _bench_scene_case(n, frame, cam_idx=0, actors=True, seed_grad=17, num_actors=32, residual=False):
     """bench.py's scene (emd_amd.scenes) as a parity case at 1066 x 1600, raw parameters."""
     from emd_amd import scenes
     from emd_amd.motion import build_actor_pose
@@ -185,7 +185,7 @@ def _bench_scene_case(n, frame, cam_idx=0, actors=True, seed_grad=17):
     sc = scenes.make_static_scene(n, seed=0)
     pose = None
     if actors:
-        sc = scenes.add_actors(sc, num_actors=32, pts_per_actor=5000, num_frames=50, seed=1)
+        sc = scenes.add_actors(sc, num_actors=num_actors, pts_per_actor=5000, num_frames=50, seed=1)
         pose = build_actor_pose(sc.actor_quats, sc.actor_trans, sc.actor_valid, frame)
     case = dict(N=n, H=H, W=W, sh_degree=3, bg=torch.zeros(3), cam=scenes.rig_camera(frame, cam_idx, H, W), means3D=sc.means,
                 opacities=None, scales=None, rotations=None, shs=sc.shs, colors_precomp=None, cov3D_precomp=None,
@@ -195,6 +195,11 @@ def _bench_scene_case(n, frame, cam_idx=0, actors=True, seed_grad=17):
     case["dL_dcolor"] = g.standard_normal((3, H, W)).astype(np.float32)
     case["dL_ddepth"] = (0.01 * g.standard_normal((1, H, W))).astype(np.float32)
     case["dL_dalpha"] = g.standard_normal((1, H, W)).astype(np.float32)
+    if residual:        # the learned per-Gaussian deformation residual as K1 / K8 consume it (positions for all, rotations for actor points)
+        tg = torch.Generator().manual_seed(seed_grad + 1)
+        case["residual_dx"] = 0.02 * torch.randn(n, 3, generator=tg)
+        if actors:
+            case["residual_dq"] = 0.02 * torch.randn(n, 4, generator=tg)
     return case, sc
 
 
@@ -217,6 +222,27 @@ def test_full_size_config2_dynamic_2M(frame):
     res = raw_params_parity(case, sc.log_scales, sc.quats, sc.opacity_logits)
     assert res["V"] > 1_000_000 and res["D"] > 4_000_000, res
     print("config2 frame", frame, res)
+
+
+def test_full_size_config4_rank_workload_2M_with_deformation_residual():
+    """What ONE rank of BASELINE configs[3] (4-camera rig, 2 M Gaussians + deformation residual, view-parallel on 4 GPUs) computes:
+    camera 2 of the rig at frame 10, the residual as an input of the fused transform (gradients back to it).  The multi-GPU part
+    of that configuration (the gradient exchange) is covered by tests/test_bench_multirank_gpu.py."""
+    from tests.helpers import raw_params_parity
+    case, sc = _bench_scene_case(2_000_000, frame=10, cam_idx=2, actors=True, residual=True)
+    res = raw_params_parity(case, sc.log_scales, sc.quats, sc.opacity_logits)
+    assert res["V"] > 100_000 and "residual_dx" in res and "residual_dq" in res, res
+    print("config4 rank workload", res)
+
+
+def test_full_size_config5_rank_workload_3M():
+    """What one rank of BASELINE configs[4] (6-camera rig, 3 M Gaussians, 8 GPUs) computes per step: camera 5 of the rig, 3 M
+    Gaussians of which 48 x 5000 ride on actors (densification, the other half of that configuration: tests/test_gaussian_model_gpu.py)."""
+    from tests.helpers import raw_params_parity
+    case, sc = _bench_scene_case(3_000_000, frame=30, cam_idx=5, actors=True, num_actors=48)
+    res = raw_params_parity(case, sc.log_scales, sc.quats, sc.opacity_logits)
+    assert res["V"] > 100_000, res
+    print("config5 rank workload", res)
 
 
 def test_parity_at_bench_resolution():
