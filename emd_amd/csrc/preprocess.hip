@@ -493,7 +493,7 @@ __device__ __forceinline__ void reduce_pose_grad(int a_id, const float pose_g[12
 // ---------------------------------------------------------------------------------------------------
 // K8
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(EMD_BLOCK) k_preprocess_backward(PreBwdArgs a) {
+__global__ void __launch_bounds__(EMD_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_preprocess_backward(PreBwdArgs a) {
     EmdSettings S = a.s;
     emd_settings_from_device(S, a.sdev, a.flags);
     // staging of the dL/dshs rows (coalesced copy-out), half of the block's rows at a time: 26 KB instead of 52 keeps five
