@@ -43,8 +43,9 @@ __device__ __forceinline__ Bilin bilin(float cx, float cy, int W, int H) {
 }
 
 // One axis of a tap.  A scale has four axes (x, y, z, t) and six planes that pair them: the un-normalise / clip / floor work is
-// done once per axis and shared by the three planes the axis takes part in (both lookup kernels are VALU-issue-bound --
-// rocprofv3 SQ_INSTS_VALU x 4 cycles fills the forward's whole run time -- and every lane of a point repeats this arithmetic).
+// done once per axis and shared by the three planes the axis takes part in (both lookup kernels are VALU-heavy -- at the measured
+// 2.35 cycles per plain wave instruction, profiles/r02_issue_rate_microbench.txt, rocprofv3's SQ_INSTS_VALU fills ~60 % of the
+// forward's run time -- and every lane of a point repeats this arithmetic).
 struct Tap1 { int i0, i1; float f, ds; };
 __device__ __forceinline__ Tap1 tap1(float coord, int size) {
     Tap1 t;
