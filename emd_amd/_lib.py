@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16
@@ -144,6 +144,27 @@ class EmdTrackGrads(C.Structure):
                 ("d_mean", _f)]
 
 
+MLP_MAX_BRANCHES = 6
+
+
+class EmdMlpTrunk(C.Structure):
+    _fields_ = [("num_points", C.c_int32), ("ka", C.c_int32), ("kb", C.c_int32), ("ld_w", C.c_int32), ("col_a", C.c_int32),
+                ("col_b", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32), ("xa", _f), ("xb", _f), ("w", _f), ("b", _f), ("h", _f)]
+
+
+class EmdMlpTrunkGrads(C.Structure):
+    _fields_ = [("num_gh", C.c_int32), ("reserved", C.c_int32), ("g_h", _f * MLP_MAX_BRANCHES), ("d_xa", _f), ("d_xb", _f), ("d_w", _f), ("d_b", _f)]
+
+
+class EmdMlpBranch(C.Structure):
+    _fields_ = [("num_points", C.c_int32), ("depth", C.c_int32), ("relu_input", C.c_int32), ("out_dim", C.c_int32), ("h", _f),
+                ("w_hidden", _f * 2), ("b_hidden", _f * 2), ("w_out", _f), ("b_out", _f), ("out", _f)]
+
+
+class EmdMlpBranchGrads(C.Structure):
+    _fields_ = [("g_out", _f), ("g_h", _f), ("d_w_hidden", _f * 2), ("d_b_hidden", _f * 2), ("d_w_out", _f), ("d_b_out", _f)]
+
+
 ADAM_MAX_TENSORS = 32
 
 
@@ -165,7 +186,8 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss", "emd_hexplane_forward", "emd_hexplane_backward", "emd_sh_grad_from_factors", "emd_densification_stats",
                     "emd_temporal_embed_forward", "emd_temporal_embed_backward", "emd_deform_input_width", "emd_deform_input_forward",
                     "emd_deform_input_backward", "emd_adam_step", "emd_track_heads_forward", "emd_track_heads_backward",
-                    "emd_densify_decide", "emd_densify_index", "emd_densify_split_rank", "emd_densify_gather")
+                    "emd_densify_decide", "emd_densify_index", "emd_densify_split_rank", "emd_densify_gather",
+                    "emd_mlp_trunk_forward", "emd_mlp_trunk_backward", "emd_mlp_branch_forward", "emd_mlp_branch_backward")
 PROF_STAGES = 8
 
 _lib = None
@@ -227,6 +249,10 @@ def load():
     lib.emd_densify_index.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_densify_split_rank.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.emd_densify_gather.argtypes = [C.POINTER(EmdDensifyGather), C.c_void_p]
+    lib.emd_mlp_trunk_forward.argtypes = [C.POINTER(EmdMlpTrunk), C.c_void_p]
+    lib.emd_mlp_trunk_backward.argtypes = [C.POINTER(EmdMlpTrunk), C.POINTER(EmdMlpTrunkGrads), C.c_void_p]
+    lib.emd_mlp_branch_forward.argtypes = [C.POINTER(EmdMlpBranch), C.c_void_p]
+    lib.emd_mlp_branch_backward.argtypes = [C.POINTER(EmdMlpBranch), C.POINTER(EmdMlpBranchGrads), C.c_void_p]
     lib.emd_track_heads_forward.argtypes = [C.POINTER(EmdTrackArgs), C.c_void_p]
     lib.emd_track_heads_backward.argtypes = [C.POINTER(EmdTrackArgs), C.POINTER(EmdTrackGrads), C.c_void_p]
     lib.emd_sky_forward.argtypes = [C.POINTER(EmdSkyArgs), C.c_void_p]

@@ -1,0 +1,610 @@
+// mlp.hip -- the width-64 MLPs of the EMD deformation network as fused fp32-MFMA kernels.
+//
+//   trunk   h = b + W[:, a-block] xa + W[:, b-block] xb                 S3Gaussian/scene/deformation.py:100-112,254-296 (feature_out,
+//           (xa = HexPlane features [N,128] or nothing, xb = the per-Gaussian embedding [N,4]; the temporal row is the same for
+//           every Gaussian and arrives folded into b)                   defor_depth = 1: one Linear)
+//   branch  out = W_o act(W_2 act(W_1 in + b_1) + b_2) + b_o             :113-185,298-337 (pos / scales / rotations / opacity / shs
+//           in = relu(h) for the deformation heads (one hidden layer),    heads: nn.Sequential(ReLU, Linear, ReLU, Linear); dino_head:
+//           in = h for the feature head (two hidden layers)               Linear, ReLU, Linear, ReLU, Linear on the un-rectified h)
+//
+// The reference runs these as ~12 cuBLAS GEMMs per level plus one element-wise launch per bias / ReLU / slice, forward and backward;
+// over 2 M Gaussians the [N, 64..192] intermediates cross HBM ~40 times per step.  Here a wave owns 32 Gaussians and keeps every
+// intermediate in registers:
+//   * `v_mfma_f32_32x32x2_f32` (exact fp32: a k-ordered fmaf chain) with the DATA ROWS on the N dimension: A = weights [out feature x k]
+//     from LDS (one ds_read_b128 per four MFMAs, row stride 68 = 4 x odd floats: conflict-free), B = activations [k x row].  The
+//     accumulator tile of a layer (lane = row, registers = features 8(v/4) + 4(lane/32) + v%4) IS the B operand of the next layer, register v
+//     for k-step v -- the contraction order is free, so the weights are simply read in the same permuted k order: no lane movement,
+//     no LDS round trip between layers.  The backward's data path (W^T g) reads the same LDS weights column-wise.
+//   * weight gradients dW[o][i] = sum_rows g[o][row] act[i][row] contract over the rows, i.e. over the LANE index of both tiles: each
+//     tile takes one wave-private trip through LDS (16 ds_write_b32, 4 ds_read_b128) that leaves it with lane = feature and its 16
+//     registers = the data rows 16(lane/32) .. +15, which is an MFMA operand again; dW accumulates in registers over all tiles of the
+//     wave and is added to HBM once per wave with float atomics.  Bias gradients are the row sums of the same fragments.
+//   * the ReLU masks, bias adds and the sum over the heads' contributions to dL/dh ride in registers.
+// HBM traffic per Gaussian and level: x (528 B) + h (256 B) + outputs forward; h, g_out, one g_h per branch, g_x backward.
+// Bound: fp32 MFMA (157 TFLOP/s); no kernel here waits on HBM.
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MLP_W 64          // layer width
+#define WS 68             // LDS row stride of a [.][64] weight matrix (floats): 4 x odd -> conflict-free ds_read_b128 across 16 rows
+#define TS 36             // LDS row stride of a transposed 32 x 32 tile
+#define MLP_THREADS 256
+#define MLP_WAVES (MLP_THREADS / 64)
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int v = 0; v < 16; v++) z[v] = 0.f;
+    return z;
+}
+__device__ __forceinline__ f32x16 relu16(f32x16 t) {
+#pragma unroll
+    for (int v = 0; v < 16; v++) t[v] = fmaxf(t[v], 0.f);
+    return t;
+}
+// g where y > 0, else 0
+__device__ __forceinline__ f32x16 mask16(f32x16 g, f32x16 y) {
+#pragma unroll
+    for (int v = 0; v < 16; v++) g[v] = y[v] > 0.f ? g[v] : 0.f;
+    return g;
+}
+
+// ---- global <-> tile (lane = (r = row, hh), register v = feature c0 + 8 (v / 4) + 4 hh + v % 4) -------------------------------------
+// wide: ld and c0 multiples of 4, the whole 32-feature tile inside the row
+__device__ __forceinline__ f32x16 load_tile(const float* __restrict__ src, size_t ld, size_t row, bool ok, int c0, int hh) {
+    f32x16 t;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) q = *(const float4*)(src + row * ld + c0 + 8 * a + 4 * hh);
+        t[4 * a] = q.x; t[4 * a + 1] = q.y; t[4 * a + 2] = q.z; t[4 * a + 3] = q.w;
+    }
+    return t;
+}
+// any width: features >= width read as 0
+__device__ __forceinline__ f32x16 load_tile_narrow(const float* __restrict__ src, int width, size_t row, bool ok, int c0, int hh) {
+    f32x16 t;
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+        const int f = c0 + 8 * (v >> 2) + 4 * hh + (v & 3);
+        t[v] = (ok && f < width) ? src[row * (size_t)width + f] : 0.f;
+    }
+    return t;
+}
+__device__ __forceinline__ void store_tile(float* __restrict__ dst, size_t ld, size_t row, bool ok, int c0, int hh, f32x16 t) {
+    if (!ok) return;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+        *(float4*)(dst + row * ld + c0 + 8 * a + 4 * hh) = make_float4(t[4 * a], t[4 * a + 1], t[4 * a + 2], t[4 * a + 3]);
+}
+__device__ __forceinline__ void store_tile_narrow(float* __restrict__ dst, int width, size_t row, bool ok, int c0, int hh, f32x16 t) {
+    if (!ok) return;
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+        const int f = c0 + 8 * (v >> 2) + 4 * hh + (v & 3);
+        if (f < width) dst[row * (size_t)width + f] = t[v];
+    }
+}
+
+// bias as the initial accumulator: register v of lane half hh holds feature c0 + 8 (v / 4) + 4 hh + v % 4
+__device__ __forceinline__ f32x16 bias_tile(const float* __restrict__ b_lds, int c0, int hh) {
+    f32x16 t;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const float4 q = *(const float4*)(b_lds + c0 + 8 * a + 4 * hh);
+        t[4 * a] = q.x; t[4 * a + 1] = q.y; t[4 * a + 2] = q.z; t[4 * a + 3] = q.w;
+    }
+    return t;
+}
+
+// out[to] += W[32 to + r][k] in[k]: KT input tiles, NT output tiles; W in LDS, row stride `stride`, first input column `k0`
+template <int KT, int NT>
+__device__ __forceinline__ void layer_fwd(f32x16 (&acc)[NT], const f32x16 (&in)[KT], const float* __restrict__ W, int stride, int k0, int r, int hh) {
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            float4 w[NT];
+#pragma unroll
+            for (int to = 0; to < NT; to++) w[to] = *(const float4*)(W + (32 * to + r) * stride + k0 + 32 * kt + 8 * a + 4 * hh);
+#pragma unroll
+            for (int to = 0; to < NT; to++) {
+                acc[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[to].x, in[kt][4 * a], acc[to], 0, 0, 0);
+                acc[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[to].y, in[kt][4 * a + 1], acc[to], 0, 0, 0);
+                acc[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[to].z, in[kt][4 * a + 2], acc[to], 0, 0, 0);
+                acc[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[to].w, in[kt][4 * a + 3], acc[to], 0, 0, 0);
+            }
+        }
+}
+
+// gin[ti] += sum_k W[k][c0 + 32 ti + r] g[k]  (W^T g): GT tiles of g (the layer's output features), NT tiles of its input features
+template <int GT, int NT>
+__device__ __forceinline__ void layer_bwd(f32x16 (&acc)[NT], const f32x16 (&g)[GT], const float* __restrict__ W, int stride, int c0, int r, int hh) {
+#pragma unroll
+    for (int kt = 0; kt < GT; kt++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            const int k = 32 * kt + 8 * (v >> 2) + 4 * hh + (v & 3);
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++)
+                acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(W[k * stride + c0 + 32 * ti + r], g[kt][v], acc[ti], 0, 0, 0);
+        }
+}
+
+// ---- transposed fragments for the weight gradients -------------------------------------------------------------------------------
+// tile (lane = row, registers = features) -> fragment (lane r = feature, registers = the 16 rows 16 hh .. 16 hh + 15) through the wave's
+// private LDS scratch.  LDS serves the DS instructions of one wave in order, so the reads see the writes; the fences only pin the
+// compiler's order.
+__device__ __forceinline__ f32x16 transpose_tile(f32x16 t, float* __restrict__ T, int r, int hh) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int v = 0; v < 16; v++) T[(8 * (v >> 2) + 4 * hh + (v & 3)) * TS + r] = t[v];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f32x16 f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float4 q = *(const float4*)(T + r * TS + 16 * hh + 4 * i);
+        f[4 * i] = q.x; f[4 * i + 1] = q.y; f[4 * i + 2] = q.z; f[4 * i + 3] = q.w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return f;
+}
+__device__ __forceinline__ float frag_sum(f32x16 f) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; v++) s += f[v];
+    return s;
+}
+// dW[32 to + o][32 ti + i] += sum_rows gf[o][row] af[i][row]: both operands as fragments; the k-step s pairs row s (lanes 0-31)
+// with row 16 + s (lanes 32-63) on both sides
+__device__ __forceinline__ f32x16 outer_acc(f32x16 acc, f32x16 gf, f32x16 af) {
+#pragma unroll
+    for (int s = 0; s < 16; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[s], af[s], acc, 0, 0, 0);
+    return acc;
+}
+// accumulator tile D[o][i] (lane r = i, register v = o = 8 (v / 4) + 4 hh + v % 4) -> dW[(o0 + o) * ld + i0 + i], bounded
+__device__ __forceinline__ void flush_dw(float* __restrict__ dW, int ld, int o0, int i0, int rows, int cols, f32x16 acc, int r, int hh) {
+    if (!dW || i0 + r >= cols) return;
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+        const int o = o0 + 8 * (v >> 2) + 4 * hh + (v & 3);
+        if (o < rows) unsafeAtomicAdd(dW + (size_t)o * ld + i0 + r, acc[v]);
+    }
+}
+// per-lane bias-gradient partials (lane r = feature of the tile, both halves hold half of the rows) -> db[o0 + r]
+__device__ __forceinline__ void flush_db(float* __restrict__ db, int o0, int rows, float part, int r) {
+    if (db && o0 + r < rows) unsafeAtomicAdd(db + o0 + r, part);
+}
+
+// stage a [rows, cols] block of a row-major matrix (row stride ld, first column col0) into LDS [rows_pad][stride], zero padded
+__device__ __forceinline__ void stage_matrix(float* __restrict__ dst, int stride, int rows_pad, int cols_pad, const float* __restrict__ src, int ld, int col0,
+                                             int rows, int cols) {
+    for (int idx = threadIdx.x; idx < rows_pad * cols_pad; idx += MLP_THREADS) {
+        const int rr = idx / cols_pad, c = idx - rr * cols_pad;
+        dst[rr * stride + c] = (src && rr < rows && c < cols) ? src[(size_t)rr * ld + col0 + c] : 0.f;
+    }
+}
+__device__ __forceinline__ void stage_vector(float* __restrict__ dst, int n_pad, const float* __restrict__ src, int n) {
+    for (int idx = threadIdx.x; idx < n_pad; idx += MLP_THREADS) dst[idx] = (src && idx < n) ? src[idx] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// branch: [relu] -> Linear(64, 64) -> relu [-> Linear(64, 64) -> relu] -> Linear(64, out_dim)
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LDS (floats): W1 [64][WS] | W2 [64][WS] (DEPTH 2) | Wo [32 NTO][WS] | b1 [64] | b2 [64] | bo [64] | scratch [waves][32][TS] (backward)
+template <int DEPTH, int NTO>
+struct BranchLds {
+    static constexpr int w1 = 0;
+    static constexpr int w2 = w1 + 64 * WS;
+    static constexpr int wo = w2 + (DEPTH == 2 ? 64 * WS : 0);
+    static constexpr int b1 = wo + 32 * NTO * WS;
+    static constexpr int b2 = b1 + 64;
+    static constexpr int bo = b2 + 64;
+    static constexpr int scratch = bo + 64;
+    static constexpr int fwd_floats = scratch;
+    static constexpr int bwd_floats = scratch + MLP_WAVES * 32 * TS;
+};
+
+template <int DEPTH, int NTO>
+__device__ __forceinline__ void branch_stage(float* lds, const EmdMlpBranch& a) {
+    typedef BranchLds<DEPTH, NTO> L;
+    stage_matrix(lds + L::w1, WS, 64, 64, a.w_hidden[0], 64, 0, 64, 64);
+    if (DEPTH == 2) stage_matrix(lds + L::w2, WS, 64, 64, a.w_hidden[1], 64, 0, 64, 64);
+    stage_matrix(lds + L::wo, WS, 32 * NTO, 64, a.w_out, 64, 0, a.out_dim, 64);
+    stage_vector(lds + L::b1, 64, a.b_hidden[0], 64);
+    stage_vector(lds + L::b2, 64, DEPTH == 2 ? a.b_hidden[1] : nullptr, 64);
+    stage_vector(lds + L::bo, 64, a.b_out, a.out_dim);
+    __syncthreads();
+}
+
+template <int DEPTH, int NTO>
+__global__ void __launch_bounds__(MLP_THREADS) k_mlp_branch_fwd(EmdMlpBranch a) {
+    typedef BranchLds<DEPTH, NTO> L;
+    extern __shared__ float lds[];
+    branch_stage<DEPTH, NTO>(lds, a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
+    const bool wide_out = (a.out_dim & 3) == 0;
+    for (size_t tile = (size_t)blockIdx.x * MLP_WAVES + wave; tile < tiles; tile += (size_t)gridDim.x * MLP_WAVES) {
+        const size_t row = tile * 32 + r;
+        const bool ok = row < N;
+        f32x16 x[2] = {load_tile(a.h, 64, row, ok, 0, hh), load_tile(a.h, 64, row, ok, 32, hh)};
+        if (a.relu_input) { x[0] = relu16(x[0]); x[1] = relu16(x[1]); }
+        f32x16 m[2] = {bias_tile(lds + L::b1, 0, hh), bias_tile(lds + L::b1, 32, hh)};
+        layer_fwd<2, 2>(m, x, lds + L::w1, WS, 0, r, hh);
+        m[0] = relu16(m[0]); m[1] = relu16(m[1]);
+        if (DEPTH == 2) {
+            f32x16 m2[2] = {bias_tile(lds + L::b2, 0, hh), bias_tile(lds + L::b2, 32, hh)};
+            layer_fwd<2, 2>(m2, m, lds + L::w2, WS, 0, r, hh);
+            m[0] = relu16(m2[0]); m[1] = relu16(m2[1]);
+        }
+        f32x16 o[NTO];
+#pragma unroll
+        for (int t = 0; t < NTO; t++) o[t] = bias_tile(lds + L::bo, 32 * t, hh);
+        layer_fwd<2, NTO>(o, m, lds + L::wo, WS, 0, r, hh);
+#pragma unroll
+        for (int t = 0; t < NTO; t++) {
+            // (a wide tile may still hang over the row's end: out_dim = 48 -> the second tile holds features 32..47)
+            if (wide_out && 32 * t + 32 <= a.out_dim) store_tile(a.out, a.out_dim, row, ok, 32 * t, hh, o[t]);
+            else store_tile_narrow(a.out, a.out_dim, row, ok, 32 * t, hh, o[t]);
+        }
+    }
+}
+
+template <int DEPTH, int NTO>
+__global__ void __launch_bounds__(MLP_THREADS) k_mlp_branch_bwd(EmdMlpBranch a, EmdMlpBranchGrads g) {
+    typedef BranchLds<DEPTH, NTO> L;
+    extern __shared__ float lds[];
+    branch_stage<DEPTH, NTO>(lds, a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    float* T = lds + L::scratch + wave * 32 * TS;
+    const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
+    const bool wide_out = (a.out_dim & 3) == 0;
+    f32x16 dW1[2][2], dW2[2][2], dWo[NTO][2];
+    float db1[2] = {0.f, 0.f}, db2[2] = {0.f, 0.f}, dbo[NTO];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) { dW1[i][j] = zero16(); dW2[i][j] = zero16(); }
+#pragma unroll
+    for (int t = 0; t < NTO; t++) { dWo[t][0] = zero16(); dWo[t][1] = zero16(); dbo[t] = 0.f; }
+
+    for (size_t tile = (size_t)blockIdx.x * MLP_WAVES + wave; tile < tiles; tile += (size_t)gridDim.x * MLP_WAVES) {
+        const size_t row = tile * 32 + r;
+        const bool ok = row < N;
+        // ---- recompute the forward
+        f32x16 hin[2] = {load_tile(a.h, 64, row, ok, 0, hh), load_tile(a.h, 64, row, ok, 32, hh)};
+        f32x16 x[2] = {hin[0], hin[1]};
+        if (a.relu_input) { x[0] = relu16(x[0]); x[1] = relu16(x[1]); }
+        f32x16 m1[2] = {bias_tile(lds + L::b1, 0, hh), bias_tile(lds + L::b1, 32, hh)};
+        layer_fwd<2, 2>(m1, x, lds + L::w1, WS, 0, r, hh);
+        m1[0] = relu16(m1[0]); m1[1] = relu16(m1[1]);
+        f32x16 m2[2];
+        if (DEPTH == 2) {
+            m2[0] = bias_tile(lds + L::b2, 0, hh); m2[1] = bias_tile(lds + L::b2, 32, hh);
+            layer_fwd<2, 2>(m2, m1, lds + L::w2, WS, 0, r, hh);
+            m2[0] = relu16(m2[0]); m2[1] = relu16(m2[1]);
+        }
+        f32x16 (&last)[2] = DEPTH == 2 ? m2 : m1;          // the activation that feeds the output layer
+        // ---- output layer
+        f32x16 go[NTO];
+#pragma unroll
+        for (int t = 0; t < NTO; t++)
+            go[t] = (wide_out && 32 * t + 32 <= a.out_dim) ? load_tile(g.g_out, a.out_dim, row, ok, 32 * t, hh)
+                                                           : load_tile_narrow(g.g_out, a.out_dim, row, ok, 32 * t, hh);
+        f32x16 gl[2] = {zero16(), zero16()};
+        layer_bwd<NTO, 2>(gl, go, lds + L::wo, WS, 0, r, hh);
+        gl[0] = mask16(gl[0], last[0]); gl[1] = mask16(gl[1], last[1]);
+        {   // dWo += go (x) last, dbo += rowsum(go)
+            f32x16 af[2] = {transpose_tile(last[0], T, r, hh), transpose_tile(last[1], T, r, hh)};
+#pragma unroll
+            for (int t = 0; t < NTO; t++) {
+                const f32x16 gf = transpose_tile(go[t], T, r, hh);
+                dbo[t] += frag_sum(gf);
+                dWo[t][0] = outer_acc(dWo[t][0], gf, af[0]);
+                dWo[t][1] = outer_acc(dWo[t][1], gf, af[1]);
+            }
+        }
+        // ---- second hidden layer (feature head)
+        f32x16 g1[2];
+        if (DEPTH == 2) {
+            g1[0] = zero16(); g1[1] = zero16();
+            layer_bwd<2, 2>(g1, gl, lds + L::w2, WS, 0, r, hh);
+            g1[0] = mask16(g1[0], m1[0]); g1[1] = mask16(g1[1], m1[1]);
+            f32x16 af[2] = {transpose_tile(m1[0], T, r, hh), transpose_tile(m1[1], T, r, hh)};
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const f32x16 gf = transpose_tile(gl[t], T, r, hh);
+                db2[t] += frag_sum(gf);
+                dW2[t][0] = outer_acc(dW2[t][0], gf, af[0]);
+                dW2[t][1] = outer_acc(dW2[t][1], gf, af[1]);
+            }
+        } else {
+            g1[0] = gl[0]; g1[1] = gl[1];
+        }
+        // ---- first hidden layer
+        f32x16 gx[2] = {zero16(), zero16()};
+        layer_bwd<2, 2>(gx, g1, lds + L::w1, WS, 0, r, hh);
+        if (a.relu_input) { gx[0] = mask16(gx[0], hin[0]); gx[1] = mask16(gx[1], hin[1]); }
+        store_tile(g.g_h, 64, row, ok, 0, hh, gx[0]);
+        store_tile(g.g_h, 64, row, ok, 32, hh, gx[1]);
+        {
+            f32x16 af[2] = {transpose_tile(x[0], T, r, hh), transpose_tile(x[1], T, r, hh)};
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const f32x16 gf = transpose_tile(g1[t], T, r, hh);
+                db1[t] += frag_sum(gf);
+                dW1[t][0] = outer_acc(dW1[t][0], gf, af[0]);
+                dW1[t][1] = outer_acc(dW1[t][1], gf, af[1]);
+            }
+        }
+    }
+    // ---- one atomic add per accumulator element and wave
+#pragma unroll
+    for (int to = 0; to < 2; to++) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++) {
+            flush_dw(g.d_w_hidden[0], 64, 32 * to, 32 * ti, 64, 64, dW1[to][ti], r, hh);
+            if (DEPTH == 2) flush_dw(g.d_w_hidden[1], 64, 32 * to, 32 * ti, 64, 64, dW2[to][ti], r, hh);
+        }
+        flush_db(g.d_b_hidden[0], 32 * to, 64, db1[to], r);
+        if (DEPTH == 2) flush_db(g.d_b_hidden[1], 32 * to, 64, db2[to], r);
+    }
+#pragma unroll
+    for (int t = 0; t < NTO; t++) {
+        flush_dw(g.d_w_out, 64, 32 * t, 0, a.out_dim, 64, dWo[t][0], r, hh);
+        flush_dw(g.d_w_out, 64, 32 * t, 32, a.out_dim, 64, dWo[t][1], r, hh);
+        flush_db(g.d_b_out, 32 * t, a.out_dim, dbo[t], r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// trunk: h = b + W[:, col_a : col_a + ka] xa + W[:, col_b : col_b + kb] xb           (ka = 32 KTA, kb <= 8)
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LDS: Wa [64][SA] | Wb [64][12] | b [64] | scratch (backward)
+template <int KTA>
+struct TrunkLds {
+    static constexpr int SA = 32 * KTA + 4;                 // 4 x odd
+    static constexpr int wa = 0;
+    static constexpr int wb = wa + (KTA ? 64 * SA : 0);
+    static constexpr int b = wb + 64 * 12;
+    static constexpr int scratch = b + 64;
+    static constexpr int fwd_floats = scratch;
+    static constexpr int bwd_floats = scratch + MLP_WAVES * 32 * TS;
+};
+
+template <int KTA>
+__device__ __forceinline__ void trunk_stage(float* lds, const EmdMlpTrunk& a) {
+    typedef TrunkLds<KTA> L;
+    if (KTA) stage_matrix(lds + L::wa, L::SA, 64, 32 * KTA, a.w, a.ld_w, a.col_a, 64, a.ka);
+    stage_matrix(lds + L::wb, 12, 64, 8, a.kb > 0 ? a.w : nullptr, a.ld_w, a.col_b, 64, a.kb);
+    stage_vector(lds + L::b, 64, a.b, 64);
+    __syncthreads();
+}
+
+// the xb block as ONE k-chunk of 8: register j of lane half hh holds xb[row][4 hh + j]
+__device__ __forceinline__ void load_xb(const float* __restrict__ xb, int kb, size_t row, bool ok, int hh, float (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int c = 4 * hh + j;
+        v[j] = (ok && xb && c < kb) ? xb[row * (size_t)kb + c] : 0.f;
+    }
+}
+
+template <int KTA>
+__device__ __forceinline__ void trunk_forward_tile(const EmdMlpTrunk& a, const float* lds, size_t row, bool ok, int r, int hh, f32x16 (&xa)[KTA ? KTA : 1],
+                                                   float (&xb)[4], f32x16 (&h)[2]) {
+    typedef TrunkLds<KTA> L;
+    h[0] = bias_tile(lds + L::b, 0, hh); h[1] = bias_tile(lds + L::b, 32, hh);
+    if (KTA) {
+#pragma unroll
+        for (int t = 0; t < KTA; t++) xa[t] = load_tile(a.xa, a.ka, row, ok, 32 * t, hh);
+        layer_fwd<(KTA ? KTA : 1), 2>(h, xa, lds + L::wa, L::SA, 0, r, hh);
+    }
+    load_xb(a.xb, a.kb, row, ok, hh, xb);
+#pragma unroll
+    for (int to = 0; to < 2; to++) {
+        const float4 w = *(const float4*)(lds + L::wb + (32 * to + r) * 12 + 4 * hh);
+        h[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, xb[0], h[to], 0, 0, 0);
+        h[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, xb[1], h[to], 0, 0, 0);
+        h[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xb[2], h[to], 0, 0, 0);
+        h[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xb[3], h[to], 0, 0, 0);
+    }
+}
+
+template <int KTA>
+__global__ void __launch_bounds__(MLP_THREADS) k_mlp_trunk_fwd(EmdMlpTrunk a) {
+    extern __shared__ float lds[];
+    trunk_stage<KTA>(lds, a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
+    for (size_t tile = (size_t)blockIdx.x * MLP_WAVES + wave; tile < tiles; tile += (size_t)gridDim.x * MLP_WAVES) {
+        const size_t row = tile * 32 + r;
+        const bool ok = row < N;
+        f32x16 xa[KTA ? KTA : 1], h[2];
+        float xb[4];
+        trunk_forward_tile<KTA>(a, lds, row, ok, r, hh, xa, xb, h);
+        store_tile(a.h, 64, row, ok, 0, hh, h[0]);
+        store_tile(a.h, 64, row, ok, 32, hh, h[1]);
+    }
+}
+
+template <int KTA>
+__global__ void __launch_bounds__(MLP_THREADS) k_mlp_trunk_bwd(EmdMlpTrunk a, EmdMlpTrunkGrads g) {
+    typedef TrunkLds<KTA> L;
+    extern __shared__ float lds[];
+    trunk_stage<KTA>(lds, a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    float* T = lds + L::scratch + wave * 32 * TS;
+    const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
+    f32x16 dWa[2][KTA ? KTA : 1], dWb[2];
+    float db[2] = {0.f, 0.f};
+#pragma unroll
+    for (int to = 0; to < 2; to++) {
+        dWb[to] = zero16();
+#pragma unroll
+        for (int t = 0; t < (KTA ? KTA : 1); t++) dWa[to][t] = zero16();
+    }
+    for (size_t tile = (size_t)blockIdx.x * MLP_WAVES + wave; tile < tiles; tile += (size_t)gridDim.x * MLP_WAVES) {
+        const size_t row = tile * 32 + r;
+        const bool ok = row < N;
+        // dL/dh: the sum of the branches' contributions
+        f32x16 gh[2] = {zero16(), zero16()};
+        for (int k = 0; k < g.num_gh; k++) {
+            const f32x16 p0 = load_tile(g.g_h[k], 64, row, ok, 0, hh), p1 = load_tile(g.g_h[k], 64, row, ok, 32, hh);
+#pragma unroll
+            for (int v = 0; v < 16; v++) { gh[0][v] += p0[v]; gh[1][v] += p1[v]; }
+        }
+        const f32x16 gf[2] = {transpose_tile(gh[0], T, r, hh), transpose_tile(gh[1], T, r, hh)};
+        db[0] += frag_sum(gf[0]); db[1] += frag_sum(gf[1]);
+        if (KTA) {
+            if (g.d_xa) {
+                f32x16 gx[KTA ? KTA : 1];
+#pragma unroll
+                for (int t = 0; t < KTA; t++) gx[t] = zero16();
+                layer_bwd<2, (KTA ? KTA : 1)>(gx, gh, lds + L::wa, L::SA, 0, r, hh);
+#pragma unroll
+                for (int t = 0; t < KTA; t++) store_tile(g.d_xa, a.ka, row, ok, 32 * t, hh, gx[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < KTA; t++) {
+                const f32x16 af = transpose_tile(load_tile(a.xa, a.ka, row, ok, 32 * t, hh), T, r, hh);
+                dWa[0][t] = outer_acc(dWa[0][t], gf[0], af);
+                dWa[1][t] = outer_acc(dWa[1][t], gf[1], af);
+            }
+        }
+        if (a.kb > 0) {
+            // xb as a tile: feature c = 8 (v / 4) + 4 hh + v % 4 < kb <= 8 lives in registers 0..3
+            float xb[4];
+            load_xb(a.xb, a.kb, row, ok, hh, xb);
+            f32x16 xt = zero16();
+            xt[0] = xb[0]; xt[1] = xb[1]; xt[2] = xb[2]; xt[3] = xb[3];
+            const f32x16 af = transpose_tile(xt, T, r, hh);
+            dWb[0] = outer_acc(dWb[0], gf[0], af);
+            dWb[1] = outer_acc(dWb[1], gf[1], af);
+            if (g.d_xb) {
+                // d xb[c] = sum_k Wb[k][c] gh[k]: one tile whose features c >= 8 are zero (Wb is stored [64][12], columns 8..11 zero)
+                f32x16 gx = zero16();
+#pragma unroll
+                for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                    for (int v = 0; v < 16; v++) {
+                        const int k = 32 * kt + 8 * (v >> 2) + 4 * hh + (v & 3);
+                        const float w = r < 8 ? lds[L::wb + k * 12 + r] : 0.f;
+                        gx = __builtin_amdgcn_mfma_f32_32x32x2f32(w, gh[kt][v], gx, 0, 0, 0);
+                    }
+                if (ok) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int c = 4 * hh + j;
+                        if (c < a.kb) g.d_xb[row * (size_t)a.kb + c] = gx[j];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int to = 0; to < 2; to++) {
+        if (KTA) {
+#pragma unroll
+            for (int t = 0; t < KTA; t++) flush_dw(g.d_w ? g.d_w + a.col_a : nullptr, a.ld_w, 32 * to, 32 * t, 64, a.ka, dWa[to][t], r, hh);
+        }
+        if (a.kb > 0) flush_dw(g.d_w ? g.d_w + a.col_b : nullptr, a.ld_w, 32 * to, 0, 64, a.kb, dWb[to], r, hh);
+        flush_db(g.d_b, 32 * to, 64, db[to], r);
+    }
+}
+
+unsigned mlp_grid(int num_points) {
+    const size_t tiles = ((size_t)num_points + 31) / 32;
+    const size_t wgs = (tiles + MLP_WAVES - 1) / MLP_WAVES;
+    return (unsigned)(wgs < 256 ? (wgs ? wgs : 1) : 256);          // persistent: one workgroup per CU (the LDS holds the weights)
+}
+
+int check_branch(const EmdMlpBranch* a, const char* who) {
+    if (!a) { emd_set_error("%s: null args", who); return EMD_ERR_INVALID; }
+    if (a->num_points < 0 || (a->depth != 1 && a->depth != 2) || a->out_dim < 1 || a->out_dim > 64) {
+        emd_set_error("%s: bad sizes (depth 1..2, out_dim 1..64)", who); return EMD_ERR_INVALID;
+    }
+    if (a->num_points == 0) return EMD_OK;
+    if (!a->h || !a->w_hidden[0] || !a->b_hidden[0] || !a->w_out || !a->b_out || (a->depth == 2 && (!a->w_hidden[1] || !a->b_hidden[1]))) {
+        emd_set_error("%s: null pointer", who); return EMD_ERR_INVALID;
+    }
+    if (((uintptr_t)a->h & 15)) { emd_set_error("%s: h must be 16-byte aligned", who); return EMD_ERR_INVALID; }
+    return EMD_OK;
+}
+
+int check_trunk(const EmdMlpTrunk* a, const char* who) {
+    if (!a) { emd_set_error("%s: null args", who); return EMD_ERR_INVALID; }
+    if (a->num_points < 0 || (a->ka != 0 && a->ka != 128) || a->kb < 0 || a->kb > 8 || a->ka + a->kb == 0 || a->ld_w < a->ka + a->kb ||
+        a->col_a < 0 || a->col_b < 0 || a->col_a + a->ka > a->ld_w || a->col_b + a->kb > a->ld_w) {
+        emd_set_error("%s: bad sizes (ka 0 or 128, kb <= 8)", who); return EMD_ERR_INVALID;
+    }
+    if (a->num_points == 0) return EMD_OK;
+    if (!a->w || !a->b || !a->h || (a->ka && !a->xa) || (a->kb && !a->xb)) { emd_set_error("%s: null pointer", who); return EMD_ERR_INVALID; }
+    if (((uintptr_t)a->h & 15) || (a->ka && ((uintptr_t)a->xa & 15))) { emd_set_error("%s: xa / h must be 16-byte aligned", who); return EMD_ERR_INVALID; }
+    return EMD_OK;
+}
+
+template <typename K, typename... Args>
+int mlp_launch(K kernel, int floats, int num_points, hipStream_t st, Args... args) {
+    const size_t bytes = (size_t)floats * sizeof(float);
+    if (bytes > 64 * 1024) EMD_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(kernel, dim3(mlp_grid(num_points)), dim3(MLP_THREADS), bytes, st, args...);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+}  // namespace
+
+extern "C" int emd_mlp_branch_forward(const EmdMlpBranch* a, void* hip_stream) {
+    int rc = check_branch(a, "mlp_branch_forward");
+    if (rc || a->num_points == 0) return rc;
+    if (!a->out) { emd_set_error("mlp_branch_forward: null output"); return EMD_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int nto = a->out_dim > 32 ? 2 : 1;
+    if (a->depth == 1 && nto == 1) return mlp_launch(k_mlp_branch_fwd<1, 1>, BranchLds<1, 1>::fwd_floats, a->num_points, st, *a);
+    if (a->depth == 1) return mlp_launch(k_mlp_branch_fwd<1, 2>, BranchLds<1, 2>::fwd_floats, a->num_points, st, *a);
+    if (nto == 1) return mlp_launch(k_mlp_branch_fwd<2, 1>, BranchLds<2, 1>::fwd_floats, a->num_points, st, *a);
+    return mlp_launch(k_mlp_branch_fwd<2, 2>, BranchLds<2, 2>::fwd_floats, a->num_points, st, *a);
+}
+
+extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranchGrads* g, void* hip_stream) {
+    int rc = check_branch(a, "mlp_branch_backward");
+    if (rc || a->num_points == 0) return rc;
+    if (!g || !g->g_out || !g->g_h) { emd_set_error("mlp_branch_backward: null gradient pointer"); return EMD_ERR_INVALID; }
+    if (((uintptr_t)g->g_h & 15)) { emd_set_error("mlp_branch_backward: g_h must be 16-byte aligned"); return EMD_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int nto = a->out_dim > 32 ? 2 : 1;
+    if (a->depth == 1 && nto == 1) return mlp_launch(k_mlp_branch_bwd<1, 1>, BranchLds<1, 1>::bwd_floats, a->num_points, st, *a, *g);
+    if (a->depth == 1) return mlp_launch(k_mlp_branch_bwd<1, 2>, BranchLds<1, 2>::bwd_floats, a->num_points, st, *a, *g);
+    if (nto == 1) return mlp_launch(k_mlp_branch_bwd<2, 1>, BranchLds<2, 1>::bwd_floats, a->num_points, st, *a, *g);
+    return mlp_launch(k_mlp_branch_bwd<2, 2>, BranchLds<2, 2>::bwd_floats, a->num_points, st, *a, *g);
+}
+
+extern "C" int emd_mlp_trunk_forward(const EmdMlpTrunk* a, void* hip_stream) {
+    int rc = check_trunk(a, "mlp_trunk_forward");
+    if (rc || a->num_points == 0) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (a->ka) return mlp_launch(k_mlp_trunk_fwd<4>, TrunkLds<4>::fwd_floats, a->num_points, st, *a);
+    return mlp_launch(k_mlp_trunk_fwd<0>, TrunkLds<0>::fwd_floats, a->num_points, st, *a);
+}
+
+extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGrads* g, void* hip_stream) {
+    int rc = check_trunk(a, "mlp_trunk_backward");
+    if (rc || a->num_points == 0) return rc;
+    if (!g || g->num_gh < 1 || g->num_gh > EMD_MLP_MAX_BRANCHES) { emd_set_error("mlp_trunk_backward: 1..%d gradient contributions", EMD_MLP_MAX_BRANCHES); return EMD_ERR_INVALID; }
+    for (int k = 0; k < g->num_gh; k++)
+        if (!g->g_h[k] || ((uintptr_t)g->g_h[k] & 15)) { emd_set_error("mlp_trunk_backward: g_h[%d] null or unaligned", k); return EMD_ERR_INVALID; }
+    if (g->d_xa && ((uintptr_t)g->d_xa & 15)) { emd_set_error("mlp_trunk_backward: d_xa must be 16-byte aligned"); return EMD_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (a->ka) return mlp_launch(k_mlp_trunk_bwd<4>, TrunkLds<4>::bwd_floats, a->num_points, st, *a, *g);
+    return mlp_launch(k_mlp_trunk_bwd<0>, TrunkLds<0>::bwd_floats, a->num_points, st, *a, *g);
+}

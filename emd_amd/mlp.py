@@ -1,0 +1,118 @@
+"""One level of the EMD deformation network's MLPs (trunk + heads) on the fused fp32-MFMA kernels of csrc/mlp.hip.
+
+    h     = b_eff + W0[:, col_a : col_a + ka] xa + W0[:, col_b : col_b + kb] xb                 (Deformation.feature_out, defor_depth = 1)
+    out_k = W_out act(... act(W_1 in_k + b_1) ...) + b_out,  in_k = relu(h) (deformation heads) or h (dino_head)
+
+S3Gaussian/scene/deformation.py:100-185 (construction), 254-337 (use).  `level_mlp` is ONE autograd node: its backward runs one
+kernel per head (each writes its own contribution to dL/dh and accumulates its weight gradients) and one for the trunk (sums the
+contributions, writes dL/dxa, dL/dxb, accumulates dW0) -- no intermediate [N, 64..192] tensor and no element-wise launch exists in
+either direction.  There is no CPU path (the checker's restatement is oracle/deform_oracle.py)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+WIDTH = 64
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def eligible(ka, kb, hidden_shapes, out_dims):
+    """The shapes csrc/mlp.hip serves: width 64 everywhere, ka in {0, 128}, kb <= 8, out_dim <= 64, at most six heads."""
+    return (ka in (0, 128) and 0 <= kb <= 8 and ka + kb > 0 and all(tuple(s) == (WIDTH, WIDTH) for s in hidden_shapes) and
+            all(1 <= o <= 64 for o in out_dims) and 1 <= len(out_dims) <= L.MLP_MAX_BRANCHES)
+
+
+class _LevelMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, xa, xb, w0, b_eff, *params):
+        """spec = (col_a, col_b, ((relu_input, depth, out_dim), ...)); params = per branch: (w_h, b_h) x depth, w_out, b_out."""
+        lib = L.load()
+        col_a, col_b, branches = spec
+        dev = w0.device
+        if dev.type != "cuda":
+            raise L.EmdError("level_mlp needs tensors on a ROCm device; there is no CPU path")
+        f = lambda t: None if t is None else t.detach().contiguous().float()
+        xa_c, xb_c, w0_c, b_c = f(xa), f(xb), f(w0), f(b_eff)
+        params_c = [f(p) for p in params]
+        N = (xa_c if xa_c is not None else xb_c).shape[0]
+        h = torch.empty(N, WIDTH, device=dev, dtype=torch.float32)
+        t = L.EmdMlpTrunk()
+        t.num_points, t.ka, t.kb, t.ld_w = N, 0 if xa_c is None else xa_c.shape[1], 0 if xb_c is None else xb_c.shape[1], w0_c.shape[1]
+        t.col_a, t.col_b = int(col_a), int(col_b)
+        t.xa, t.xb, t.w, t.b, t.h = L.ptr(xa_c), L.ptr(xb_c), w0_c.data_ptr(), b_c.data_ptr(), h.data_ptr()
+        L.check(lib.emd_mlp_trunk_forward(C.byref(t), _stream()), "emd_mlp_trunk_forward")
+        outs, structs, i = [], [], 0
+        for relu_input, depth, out_dim in branches:
+            b = L.EmdMlpBranch()
+            b.num_points, b.depth, b.relu_input, b.out_dim, b.h = N, depth, 1 if relu_input else 0, out_dim, h.data_ptr()
+            for d in range(depth):
+                b.w_hidden[d], b.b_hidden[d] = params_c[i].data_ptr(), params_c[i + 1].data_ptr()
+                i += 2
+            b.w_out, b.b_out = params_c[i].data_ptr(), params_c[i + 1].data_ptr()
+            i += 2
+            out = torch.empty(N, out_dim, device=dev, dtype=torch.float32)
+            b.out = out.data_ptr()
+            L.check(lib.emd_mlp_branch_forward(C.byref(b), _stream()), "emd_mlp_branch_forward")
+            outs.append(out)
+            structs.append(b)
+        ctx.spec, ctx.trunk, ctx.structs, ctx.N = spec, t, structs, N
+        ctx.has = (xa is not None, xb is not None)
+        ctx.save_for_backward(xa_c, xb_c, w0_c, b_c, h, *params_c)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g_outs):
+        lib = L.load()
+        xa_c, xb_c, w0_c, b_c, h, *params_c = ctx.saved_tensors
+        col_a, col_b, branches = ctx.spec
+        N, dev = ctx.N, w0_c.device
+        # every accumulated gradient is carved from ONE zero-filled allocation
+        sizes = [w0_c.numel(), b_c.numel()] + [p.numel() for p in params_c]
+        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        parts = torch.split(flat, sizes)
+        d_w0, d_b = parts[0].view_as(w0_c), parts[1].view_as(b_c)
+        d_params = [p.view_as(q) for p, q in zip(parts[2:], params_c)]
+        g_hs, i = [], 0
+        for (relu_input, depth, out_dim), b, g_out in zip(branches, ctx.structs, g_outs):
+            n_par = 2 * depth + 2
+            if g_out is not None:
+                g_out = g_out.contiguous().float()
+                g = L.EmdMlpBranchGrads()
+                g_h = torch.empty(N, WIDTH, device=dev, dtype=torch.float32)
+                g.g_out, g.g_h = g_out.data_ptr(), g_h.data_ptr()
+                for d in range(depth):
+                    g.d_w_hidden[d], g.d_b_hidden[d] = d_params[i + 2 * d].data_ptr(), d_params[i + 2 * d + 1].data_ptr()
+                g.d_w_out, g.d_b_out = d_params[i + 2 * depth].data_ptr(), d_params[i + 2 * depth + 1].data_ptr()
+                L.check(lib.emd_mlp_branch_backward(C.byref(b), C.byref(g), _stream()), "emd_mlp_branch_backward")
+                g_hs.append(g_h)
+            i += n_par
+        d_xa = d_xb = None
+        if g_hs:
+            tg = L.EmdMlpTrunkGrads()
+            tg.num_gh = len(g_hs)
+            for k, g_h in enumerate(g_hs):
+                tg.g_h[k] = g_h.data_ptr()
+            if ctx.has[0] and ctx.needs_input_grad[1]:
+                d_xa = torch.empty_like(xa_c)
+            if ctx.has[1] and ctx.needs_input_grad[2]:
+                d_xb = torch.empty_like(xb_c)
+            tg.d_xa, tg.d_xb, tg.d_w, tg.d_b = L.ptr(d_xa), L.ptr(d_xb), d_w0.data_ptr(), d_b.data_ptr()
+            L.check(lib.emd_mlp_trunk_backward(C.byref(ctx.trunk), C.byref(tg), _stream()), "emd_mlp_trunk_backward")
+        return (None, d_xa, d_xb, d_w0, d_b, *d_params)
+
+
+def level_mlp(xa, xb, w0, b_eff, col_a, col_b, branches):
+    """`branches`: list of (relu_input, [(w_hidden, b_hidden), ...], (w_out, b_out)); returns the list of head outputs [N, out_dim].
+    `xa` [N,128] or None, `xb` [N,kb <= 8] or None; `w0` is the first layer's full weight [64, ld] whose column blocks starting at
+    `col_a` / `col_b` multiply xa / xb; `b_eff` [64] is its bias plus whatever is constant over the Gaussians."""
+    spec, params = [], []
+    for relu_input, hidden, (w_out, b_out) in branches:
+        spec.append((bool(relu_input), len(hidden), int(w_out.shape[0])))
+        for w, b in hidden:
+            params += [w, b]
+        params += [w_out, b_out]
+    return list(_LevelMLP.apply((int(col_a), int(col_b), tuple(spec)), xa, xb, w0, b_eff, *params))

@@ -24,6 +24,7 @@
  *                                          EnvLight.forward              OmniRe/models/modules.py:174-208
  *   emd_image_loss                      <- l1 + D-SSIM + depth + sky BCE S3Gaussian/utils/loss_utils.py:21-98, train.py:226-363
  *   emd_hexplane_forward / backward     <- HexPlaneField.get_density     S3Gaussian/scene/hexplane.py:18-183
+ *   emd_mlp_trunk / emd_mlp_branch      <- feature_out + *_deform heads + dino_head  S3Gaussian/scene/deformation.py:100-185,254-337
  *   emd_temporal_embed_forward/backward <- get_temporal_embed            S3Gaussian/scene/deformation.py:208-221, OmniRe/models/nodes/rigid.py:150-164
  *   emd_deform_input_forward/backward   <- get_embedder + get_deformation OmniRe/models/modules.py:318-366, nodes/deformable.py:35-47
  *   emd_densification_stats             <- add_densification_stats       S3Gaussian/scene/gaussian_model.py:728-730, train.py:403-406
@@ -53,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 15
+#define EMD_ABI_VERSION 16
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -489,6 +490,62 @@ int emd_deform_input_width(int num_freqs_x, int num_freqs_t, int embed_dim);
 int emd_deform_input_forward(const EmdDeformInArgs* args, void* hip_stream);
 int emd_deform_input_backward(int num_points, int embed_dim, int ld, int col0, const int32_t* point_ids, const float* dL_din,
                               float* dL_dembed, void* hip_stream);
+
+/* ---- The width-64 MLPs of the EMD deformation network as fused fp32-MFMA kernels -------------------
+ * Deformation.feature_out (defor_depth = 1) + the pos / scales / rotations / opacity / shs heads + dino_head of
+ * S3Gaussian/scene/deformation.py:100-185,254-337: see the block comment of csrc/mlp.hip.  One trunk call and one branch call per
+ * head replace ~12 GEMMs and ~30 element-wise launches per level and direction; every intermediate stays in registers.
+ *   trunk   h = b + w[:, col_a : col_a + ka] xa + w[:, col_b : col_b + kb] xb      (ka = 0 or 128, kb <= 8; b = the layer's bias +
+ *           the contribution of the temporal-embedding row, which is the same for every Gaussian)
+ *   branch  out = w_out act(... act(w_hidden[0] in + b_hidden[0]) ...) + b_out, `depth` hidden layers of width 64 with ReLU,
+ *           in = relu(h) when relu_input (the deformation heads: nn.Sequential(ReLU, Linear, ReLU, Linear)) else h (dino_head)
+ * Backward: each branch writes ITS contribution to dL/dh into its own [N,64] buffer (the ReLU mask of relu_input applied) and
+ * ACCUMULATES its weight / bias gradients with float atomics (the caller zero-fills them); the trunk sums the contributions,
+ * writes dL/dxa, dL/dxb and accumulates the xa / xb column blocks of d_w and d_b.  All matrices row-major fp32; xa, h, g_h, d_xa
+ * 16-byte aligned. */
+#define EMD_MLP_MAX_BRANCHES 6
+typedef struct EmdMlpTrunk {
+    int32_t num_points, ka, kb, ld_w;            /* ld_w: row stride of w (the nn.Linear weight [64, ld_w]) */
+    int32_t col_a, col_b, reserved0, reserved1;  /* first column of the xa / xb block inside w */
+    const float* xa;                             /* [N, ka] or NULL */
+    const float* xb;                             /* [N, kb] or NULL */
+    const float* w;                              /* [64, ld_w] */
+    const float* b;                              /* [64] effective bias */
+    float* h;                                    /* [N, 64] pre-activation: out (forward), in (backward) */
+} EmdMlpTrunk;
+
+typedef struct EmdMlpTrunkGrads {
+    int32_t num_gh, reserved;
+    const float* g_h[EMD_MLP_MAX_BRANCHES];      /* [N,64] each: summed */
+    float* d_xa;                                 /* [N, ka] or NULL */
+    float* d_xb;                                 /* [N, kb] or NULL */
+    float* d_w;                                  /* [64, ld_w] accumulated (xa / xb column blocks only) or NULL */
+    float* d_b;                                  /* [64] accumulated or NULL */
+} EmdMlpTrunkGrads;
+
+typedef struct EmdMlpBranch {
+    int32_t num_points, depth, relu_input, out_dim;   /* depth 1 or 2; out_dim 1..64 */
+    const float* h;                              /* [N,64] */
+    const float* w_hidden[2];                    /* [64,64] each */
+    const float* b_hidden[2];                    /* [64] */
+    const float* w_out;                          /* [out_dim,64] */
+    const float* b_out;                          /* [out_dim] */
+    float* out;                                  /* [N,out_dim] (forward) */
+} EmdMlpBranch;
+
+typedef struct EmdMlpBranchGrads {
+    const float* g_out;                          /* [N,out_dim] */
+    float* g_h;                                  /* [N,64] out */
+    float* d_w_hidden[2];                        /* accumulated; any may be NULL */
+    float* d_b_hidden[2];
+    float* d_w_out;
+    float* d_b_out;
+} EmdMlpBranchGrads;
+
+int emd_mlp_trunk_forward(const EmdMlpTrunk* args, void* hip_stream);
+int emd_mlp_trunk_backward(const EmdMlpTrunk* args, const EmdMlpTrunkGrads* grads, void* hip_stream);
+int emd_mlp_branch_forward(const EmdMlpBranch* args, void* hip_stream);
+int emd_mlp_branch_backward(const EmdMlpBranch* args, const EmdMlpBranchGrads* grads, void* hip_stream);
 
 /* ---- Adaptive density control on the device ----------------------------------------------------
  * densify = densify_and_clone + densify_and_split, prune = prune / prune_points of S3Gaussian/scene/gaussian_model.py:441-603,

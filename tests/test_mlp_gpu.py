@@ -1,0 +1,110 @@
+"""-m gpu: the fused fp32-MFMA MLP kernels (csrc/mlp.hip: trunk + heads of S3Gaussian/scene/deformation.py:100-185,254-337) against
+the same network written out in float64 torch: every head output, dL/dxa, dL/dxb and every weight / bias gradient."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _net(g, ka, kb, heads):
+    """heads: list of (relu_input, depth, out_dim).  Returns the parameters as float64 CPU leaves."""
+    P = lambda *s: (torch.randn(*s, generator=g, dtype=torch.float64) / (s[-1] ** 0.5)).requires_grad_(True)
+    ld = ka + 32 + kb                                         # [hex | temporal (folded into the bias) | embedding], as deformation.py lays it out
+    net = dict(w0=P(64, ld), b=P(64), col_a=0, col_b=ka + 32, branches=[])
+    for relu_input, depth, out_dim in heads:
+        hidden = [(P(64, 64), (0.1 * torch.randn(64, generator=g, dtype=torch.float64)).requires_grad_(True)) for _ in range(depth)]
+        net["branches"].append((relu_input, hidden, (P(out_dim, 64), (0.1 * torch.randn(out_dim, generator=g, dtype=torch.float64)).requires_grad_(True))))
+    return net
+
+
+def _reference(net, xa, xb, kink=None):
+    """`kink` (a list) receives the smallest |pre-activation| per row of every ReLU: a value at its kink (1e-8 happens) makes the float32
+    and float64 masks differ for that row -- a measure-zero disagreement, not an error; the test sends no gradient into such rows."""
+    ka = 0 if xa is None else xa.shape[1]
+    h = net["b"]
+    if xa is not None:
+        h = h + xa @ net["w0"][:, net["col_a"]:net["col_a"] + ka].t()
+    if xb is not None:
+        h = h + xb @ net["w0"][:, net["col_b"]:net["col_b"] + xb.shape[1]].t()
+    outs = []
+    for relu_input, hidden, (wo, bo) in net["branches"]:
+        x = torch.relu(h) if relu_input else h
+        if kink is not None and relu_input:
+            kink.append(h.detach().abs().min(dim=1).values)
+        for w, b in hidden:
+            pre = x @ w.t() + b
+            if kink is not None:
+                kink.append(pre.detach().abs().min(dim=1).values)
+            x = torch.relu(pre)
+        outs.append(x @ wo.t() + bo)
+    return outs
+
+
+def _leaves(net):
+    out = [net["w0"], net["b"]]
+    for _, hidden, (wo, bo) in net["branches"]:
+        for w, b in hidden:
+            out += [w, b]
+        out += [wo, bo]
+    return out
+
+
+@pytest.mark.parametrize("N,ka,kb,heads", [
+    (1000, 128, 4, [(True, 1, 3), (True, 1, 1), (True, 1, 48), (False, 2, 3)]),          # the coarse level of the reference configuration
+    (1000, 0, 4, [(True, 1, 3), (True, 1, 1), (True, 1, 48), (False, 2, 3)]),            # its fine level (no HexPlane features)
+    (37, 128, 8, [(True, 1, 4), (False, 1, 64), (True, 2, 33)]),                          # ragged tile, other widths
+    (70001, 128, 4, [(True, 1, 3), (True, 1, 48)]),                                       # many tiles per wave
+], ids=["coarse", "fine", "ragged", "70k"])
+def test_level_mlp_matches_float64(N, ka, kb, heads):
+    from emd_amd.mlp import level_mlp
+    g = torch.Generator().manual_seed(N + ka + kb)
+    net = _net(g, ka, kb, heads)
+    xa = torch.randn(N, ka, generator=g, dtype=torch.float64).requires_grad_(True) if ka else None
+    xb = torch.randn(N, kb, generator=g, dtype=torch.float64).requires_grad_(True)
+    gouts = [torch.randn(N, o, generator=g, dtype=torch.float64) for _, _, o in heads]
+    kink = []
+    ref = _reference(net, xa, xb, kink)
+    near = torch.stack(kink).min(dim=0).values < 1e-5          # rows with a ReLU at its kink: no gradient is sent into them
+    assert int(near.sum()) <= max(8, N // 20)
+    for go in gouts:
+        go[near] = 0.0
+    sum((r * go).sum() for r, go in zip(ref, gouts)).backward()
+    # the HIP path on float32 copies
+    c = lambda t: None if t is None else t.detach().to(DEV, torch.float32).requires_grad_(True)
+    hx, hb = c(xa), c(xb)
+    hnet = dict(w0=c(net["w0"]), b=c(net["b"]), col_a=net["col_a"], col_b=net["col_b"],
+                branches=[(ri, [(c(w), c(b)) for w, b in hid], (c(wo), c(bo))) for ri, hid, (wo, bo) in net["branches"]])
+    outs = level_mlp(hx, hb, hnet["w0"], hnet["b"], hnet["col_a"], hnet["col_b"], hnet["branches"])
+    for k, (o, r) in enumerate(zip(outs, ref)):
+        err = float((o.double().cpu() - r.detach()).abs().max())
+        assert err <= 2e-5 * max(1.0, float(r.abs().max())), ("output", k, err)
+    sum((o * go.to(DEV, torch.float32)).sum() for o, go in zip(outs, gouts)).backward()
+
+    def check(name, got, want):
+        scale = max(float(want.abs().max()), 1e-12)
+        err = float((got.double().cpu() - want).abs().max())
+        assert err <= 1e-4 * scale, (name, err, scale)
+    if xa is not None:
+        check("d_xa", hx.grad, xa.grad)
+    check("d_xb", hb.grad, xb.grad)
+    # the temporal columns of w0 are not the kernels' business (they reach the bias through addmv in the caller): compare the two blocks
+    dw0, rw0 = hnet["w0"].grad, net["w0"].grad
+    if ka:
+        check("d_w0[a]", dw0[:, :ka], rw0[:, :ka])
+    check("d_w0[b]", dw0[:, ka + 32:], rw0[:, ka + 32:])
+    assert float(dw0[:, ka:ka + 32].abs().max()) == 0.0
+    for k, (a, b) in enumerate(zip(_leaves(hnet)[1:], _leaves(net)[1:])):
+        check(f"param {k}", a.grad, b.grad)
+
+
+def test_unused_head_gets_no_gradient_and_costs_no_launch():
+    from emd_amd.mlp import level_mlp
+    g = torch.Generator().manual_seed(5)
+    net = _net(g, 128, 4, [(True, 1, 3), (False, 2, 3)])
+    c = lambda t: t.detach().to(DEV, torch.float32).requires_grad_(True)
+    xa, xb = torch.randn(500, 128, generator=g).to(DEV).requires_grad_(True), torch.randn(500, 4, generator=g).to(DEV).requires_grad_(True)
+    br = [(ri, [(c(w), c(b)) for w, b in hid], (c(wo), c(bo))) for ri, hid, (wo, bo) in net["branches"]]
+    outs = level_mlp(xa, xb, c(net["w0"]), c(net["b"]), 0, 160, br)
+    outs[0].sum().backward()
+    assert float(br[1][2][0].grad.abs().max()) == 0.0 and float(br[0][2][0].grad.abs().max()) > 0.0 and xa.grad is not None
