@@ -52,6 +52,7 @@ class DeformOptions:
         self.apply_coarse_dx = self.apply_final_dx = True
         self.direct_add_dx = self.direct_add_ds = self.direct_add_dr = self.direct_add_do = self.direct_add_dshs = True
         self.no_ds = self.no_dr = self.no_fine_hexplane_features = True          # run_dynamic_nvs.sh
+        self.fused_mlp = True        # (not a reference option) trunk + heads on the fused fp32-MFMA kernels of csrc/mlp.hip; False: rocBLAS GEMMs
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -314,13 +315,56 @@ class Deformation(nn.Module):
             out["feat"] = _apply(self.dino_head, hidden)
         return out
 
+    # ---- one level on the fused fp32-MFMA kernels (csrc/mlp.hip): trunk + every head, one autograd node
+    _HEADS = (("pos_deform", "no_dx", "dx"), ("scales_deform", "no_ds", "ds"), ("rotations_deform", "no_dr", "dr"),
+              ("opacity_deform", "no_do", "do"), ("shs_deform", "no_dshs", "dshs"))
+
+    def _level_fused(self, pts, time_emb, embeddings, coarse, it, num_down_emb):
+        """The same level as `_feature` + `_heads`, or None when the configuration is outside what the fused kernels serve (width 64,
+        defor_depth 1, 128 HexPlane features, an embedding of at most 8 values, at most six heads): the GEMM path then runs."""
+        from . import mlp
+        a = self.args
+        if not getattr(a, "fused_mlp", True) or self.D != 1 or self.W != mlp.WIDTH or pts.device.type != "cuda":
+            return None
+        suffix = "" if coarse else "_f"
+        lin = (self.feature_out if coarse else self.feature_out_f)[0]
+        use_hex = not (a.no_coarse_hexplane_features if coarse else a.no_fine_hexplane_features)
+        use_emb = not a.no_gaussian_embedding_dim and embeddings is not None
+        ka, kb = (self.grid.feat_dim if use_hex else 0), (embeddings.shape[1] if use_emb else 0)
+        heads = [(getattr(self, n + suffix), key) for n, off, key in self._HEADS if not getattr(a, off)]
+        branches = [(True, [(h[1].weight, h[1].bias)], (h[3].weight, h[3].bias)) for h, _ in heads]
+        if a.feat_head:
+            d = self.dino_head
+            branches.append((False, [(d[0].weight, d[0].bias), (d[2].weight, d[2].bias)], (d[4].weight, d[4].bias)))
+        hidden_shapes = [w.shape for _, hid, _ in branches for w, _ in hid]
+        if not branches or not mlp.eligible(ka, kb, hidden_shapes, [wo.shape[0] for _, _, (wo, _) in branches]):
+            return None
+        Wm, bias, col = lin.weight, lin.bias, ka
+        if not a.no_temporal_embedding_dim:
+            T = self.temporal_embedding_dim
+            te = temporal_embed(self.weight, time_emb.reshape(-1)[:1], self._num_rows(coarse, it, num_down_emb))
+            bias = torch.addmv(bias, Wm[:, col:col + T], te)           # the same row for every Gaussian: a bias, not N copies
+            col += T
+        xa = self.grid(pts[:, :3], time_emb[:, :1]) if use_hex else None
+        outs = mlp.level_mlp(xa, embeddings if use_emb else None, Wm, bias, 0, col, branches)
+        out = dict(dx=None, ds=None, dr=None, do=None, dshs=None, feat=None)
+        for (_, key), o in zip(heads, outs):
+            out[key] = o.reshape(o.shape[0], 16, 3) if key == "dshs" else o
+        if a.feat_head:
+            out["feat"] = outs[-1]
+        return out
+
     def forward(self, rays_pts_emb, time_emb=None, embeddings=None, is_coarse=True, iter=None, num_down_emb_c=30, num_down_emb_f=30,
                 apply_deform=True, time_diff=1.0, is_train=False):
         if time_emb is None:
             raise NotImplementedError("forward_static (static_mlp) is outside the hot-path scope")
         if not apply_deform:
             return None
-        hidden = self._feature(rays_pts_emb, time_emb, embeddings, is_coarse, iter, num_down_emb_c if is_coarse else num_down_emb_f)
+        n_rows = num_down_emb_c if is_coarse else num_down_emb_f
+        fused = self._level_fused(rays_pts_emb, time_emb, embeddings, is_coarse, iter, n_rows)
+        if fused is not None:
+            return fused
+        hidden = self._feature(rays_pts_emb, time_emb, embeddings, is_coarse, iter, n_rows)
         return self._heads(hidden, "" if is_coarse else "_f")
 
     def get_mlp_parameters(self):

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 sys.path.insert(0, ".")
 from emd_amd.deformation import DeformOptions, deform_network  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2_000_000
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 opt = DeformOptions()
@@ -118,13 +118,31 @@ def run(fn, n):
 
 run(hip_step, 2)
 hf, hb, hstep = run(hip_step, 10)
+if "--hip-only" in sys.argv:       # for rocprofv3 --kernel-trace: only the product path
+    print(json.dumps({"N": N, "hip_path_step_ms": round(hstep, 3), "hip_path_forward_ms": round(hf, 3), "hip_path_backward_ms": round(hb, 3)}))
+    sys.exit(0)
+# the same step with the trunk + heads as hipBLASLt GEMMs + element-wise launches (round 1's path) instead of the fused MFMA kernels
+opt.fused_mlp = False
+run(hip_step, 2)
+gf, gb, gstep = run(hip_step, 10)
+opt.fused_mlp = True
+geometry = "uniform"
+if "--street" in sys.argv:
+    # the bench scene's geometry (ground / facade sheets) instead of points uniform in the box: what the LDS
+    # aggregation of the HexPlane backward sees in training
+    from emd_amd import scenes
+    point = scenes.make_static_scene(N, seed=0).means.to(dev).requires_grad_(True)
+    geometry = "street scene (emd_amd.scenes.make_static_scene)"
+    run(hip_step, 2)
+    hf, hb, hstep = run(hip_step, 10)
 # parity of the two formulations on the spot (values of the loss and of the table / offset gradients)
 lv = float(hip_step())
 ref = reference_formulation()
 lr = float(ref())
 run(ref, 1)
 rf, rb, rstep = run(ref, 3)
-print(json.dumps({"op": "S3Gaussian deform_network forward / backward, reference configuration, run-script flags", "N": N,
+print(json.dumps({"op": "S3Gaussian deform_network forward / backward, reference configuration, run-script flags", "N": N, "points": geometry,
                   "hip_path_step_ms": round(hstep, 3), "hip_path_forward_ms": round(hf, 3), "hip_path_backward_ms": round(hb, 3),
+                  "gemm_path_step_ms": round(gstep, 3), "gemm_path_forward_ms": round(gf, 3), "gemm_path_backward_ms": round(gb, 3),
                   "reference_formulation_step_ms": round(rstep, 3), "reference_formulation_forward_ms": round(rf, 3),
                   "reference_formulation_backward_ms": round(rb, 3), "loss_hip_path": lv, "loss_reference_formulation": lr}))
