@@ -122,13 +122,14 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&acc)[NT], const f32x16 (&in)[
         }
 }
 
-// gin[ti] += sum_k W[k][c0 + 32 ti + r] g[k]  (W^T g): GT tiles of g (the layer's output features), NT tiles of its input features
-template <int GT, int NT>
+// gin[ti] += sum_k W[k][c0 + 32 ti + r] g[k]  (W^T g): GT tiles of g (the layer's output features), NT tiles of its input features.
+// NV < 16: only the first NV registers of a g tile are non-zero (a layer with at most NV / 2 outputs per tile: features 8 (v / 4) + 4 hh + v % 4)
+template <int GT, int NT, int NV = 16>
 __device__ __forceinline__ void layer_bwd(f32x16 (&acc)[NT], const f32x16 (&g)[GT], const float* __restrict__ W, int stride, int c0, int r, int hh) {
 #pragma unroll
     for (int kt = 0; kt < GT; kt++)
 #pragma unroll
-        for (int v = 0; v < 16; v++) {
+        for (int v = 0; v < NV; v++) {
             const int k = 32 * kt + 8 * (v >> 2) + 4 * hh + (v & 3);
 #pragma unroll
             for (int ti = 0; ti < NT; ti++)
@@ -233,10 +234,17 @@ __global__ void __launch_bounds__(MLP_THREADS) k_mlp_branch_fwd(EmdMlpBranch a) 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
     const bool wide_out = (a.out_dim & 3) == 0;
-    for (size_t tile = (size_t)blockIdx.x * MLP_WAVES + wave; tile < tiles; tile += (size_t)gridDim.x * MLP_WAVES) {
+    const size_t tile0 = (size_t)blockIdx.x * MLP_WAVES + wave, tstep = (size_t)gridDim.x * MLP_WAVES;
+    // the next tile's rows are loaded while this tile computes: one wave per SIMD has nothing else to hide the HBM latency behind
+    f32x16 nx[2] = {load_tile(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 0, hh), load_tile(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 32, hh)};
+    for (size_t tile = tile0; tile < tiles; tile += tstep) {
         const size_t row = tile * 32 + r;
         const bool ok = row < N;
-        f32x16 x[2] = {load_tile(a.h, 64, row, ok, 0, hh), load_tile(a.h, 64, row, ok, 32, hh)};
+        f32x16 x[2] = {nx[0], nx[1]};
+        {
+            const size_t nrow = (tile + tstep) * 32 + r;
+            nx[0] = load_tile(a.h, 64, nrow, nrow < N, 0, hh); nx[1] = load_tile(a.h, 64, nrow, nrow < N, 32, hh);
+        }
         if (a.relu_input) { x[0] = relu16(x[0]); x[1] = relu16(x[1]); }
         f32x16 m[2] = {bias_tile(lds + L::b1, 0, hh), bias_tile(lds + L::b1, 32, hh)};
         layer_fwd<2, 2>(m, x, lds + L::w1, WS, 0, r, hh);
@@ -277,11 +285,30 @@ __global__ void __launch_bounds__(MLP_THREADS) k_mlp_branch_bwd(EmdMlpBranch a, 
 #pragma unroll
     for (int t = 0; t < NTO; t++) { dWo[t][0] = zero16(); dWo[t][1] = zero16(); dbo[t] = 0.f; }
 
-    for (size_t tile = (size_t)blockIdx.x * MLP_WAVES + wave; tile < tiles; tile += (size_t)gridDim.x * MLP_WAVES) {
+    const size_t tile0 = (size_t)blockIdx.x * MLP_WAVES + wave, tstep = (size_t)gridDim.x * MLP_WAVES;
+    auto load_go = [&](size_t row_, bool ok_, int t) -> f32x16 {
+        return (wide_out && 32 * t + 32 <= a.out_dim) ? load_tile(g.g_out, a.out_dim, row_, ok_, 32 * t, hh)
+                                                      : load_tile_narrow(g.g_out, a.out_dim, row_, ok_, 32 * t, hh);
+    };
+    // the next tile's h and g_out are loaded while this tile computes (one wave per SIMD: nothing else hides the HBM latency)
+    f32x16 nh[2] = {load_tile(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 0, hh), load_tile(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 32, hh)};
+    f32x16 ngo[NTO];
+#pragma unroll
+    for (int t = 0; t < NTO; t++) ngo[t] = load_go(tile0 * 32 + r, tile0 * 32 + r < N, t);
+    for (size_t tile = tile0; tile < tiles; tile += tstep) {
         const size_t row = tile * 32 + r;
         const bool ok = row < N;
         // ---- recompute the forward
-        f32x16 hin[2] = {load_tile(a.h, 64, row, ok, 0, hh), load_tile(a.h, 64, row, ok, 32, hh)};
+        f32x16 hin[2] = {nh[0], nh[1]};
+        f32x16 go[NTO];
+#pragma unroll
+        for (int t = 0; t < NTO; t++) go[t] = ngo[t];
+        {
+            const size_t nrow = (tile + tstep) * 32 + r;
+            nh[0] = load_tile(a.h, 64, nrow, nrow < N, 0, hh); nh[1] = load_tile(a.h, 64, nrow, nrow < N, 32, hh);
+#pragma unroll
+            for (int t = 0; t < NTO; t++) ngo[t] = load_go(nrow, nrow < N, t);
+        }
         f32x16 x[2] = {hin[0], hin[1]};
         if (a.relu_input) { x[0] = relu16(x[0]); x[1] = relu16(x[1]); }
         f32x16 m1[2] = {bias_tile(lds + L::b1, 0, hh), bias_tile(lds + L::b1, 32, hh)};
@@ -295,13 +322,9 @@ __global__ void __launch_bounds__(MLP_THREADS) k_mlp_branch_bwd(EmdMlpBranch a, 
         }
         f32x16 (&last)[2] = DEPTH == 2 ? m2 : m1;          // the activation that feeds the output layer
         // ---- output layer
-        f32x16 go[NTO];
-#pragma unroll
-        for (int t = 0; t < NTO; t++)
-            go[t] = (wide_out && 32 * t + 32 <= a.out_dim) ? load_tile(g.g_out, a.out_dim, row, ok, 32 * t, hh)
-                                                           : load_tile_narrow(g.g_out, a.out_dim, row, ok, 32 * t, hh);
         f32x16 gl[2] = {zero16(), zero16()};
-        layer_bwd<NTO, 2>(gl, go, lds + L::wo, WS, 0, r, hh);
+        if (NTO == 1 && a.out_dim <= 8) layer_bwd<NTO, 2, 4>(gl, go, lds + L::wo, WS, 0, r, hh);      // dx / do / feat: 4 k-steps carry everything
+        else layer_bwd<NTO, 2>(gl, go, lds + L::wo, WS, 0, r, hh);
         gl[0] = mask16(gl[0], last[0]); gl[1] = mask16(gl[1], last[1]);
         {   // dWo += go (x) last, dbo += rowsum(go)
             f32x16 af[2] = {transpose_tile(last[0], T, r, hh), transpose_tile(last[1], T, r, hh)};
@@ -399,17 +422,12 @@ __device__ __forceinline__ void load_xb(const float* __restrict__ xb, int kb, si
     }
 }
 
+// this tile's xa / xb rows (already in registers) -> h
 template <int KTA>
-__device__ __forceinline__ void trunk_forward_tile(const EmdMlpTrunk& a, const float* lds, size_t row, bool ok, int r, int hh, f32x16 (&xa)[KTA ? KTA : 1],
-                                                   float (&xb)[4], f32x16 (&h)[2]) {
+__device__ __forceinline__ void trunk_forward_tile(const float* lds, int r, int hh, const f32x16 (&xa)[KTA ? KTA : 1], const float (&xb)[4], f32x16 (&h)[2]) {
     typedef TrunkLds<KTA> L;
     h[0] = bias_tile(lds + L::b, 0, hh); h[1] = bias_tile(lds + L::b, 32, hh);
-    if (KTA) {
-#pragma unroll
-        for (int t = 0; t < KTA; t++) xa[t] = load_tile(a.xa, a.ka, row, ok, 32 * t, hh);
-        layer_fwd<(KTA ? KTA : 1), 2>(h, xa, lds + L::wa, L::SA, 0, r, hh);
-    }
-    load_xb(a.xb, a.kb, row, ok, hh, xb);
+    if (KTA) layer_fwd<(KTA ? KTA : 1), 2>(h, xa, lds + L::wa, L::SA, 0, r, hh);
 #pragma unroll
     for (int to = 0; to < 2; to++) {
         const float4 w = *(const float4*)(lds + L::wb + (32 * to + r) * 12 + 4 * hh);
@@ -421,17 +439,39 @@ __device__ __forceinline__ void trunk_forward_tile(const EmdMlpTrunk& a, const f
 }
 
 template <int KTA>
+__device__ __forceinline__ void trunk_load_x(const EmdMlpTrunk& a, size_t row, bool ok, int hh, f32x16 (&xa)[KTA ? KTA : 1], float (&xb)[4]) {
+    if (KTA) {
+#pragma unroll
+        for (int t = 0; t < KTA; t++) xa[t] = load_tile(a.xa, a.ka, row, ok, 32 * t, hh);
+    }
+    load_xb(a.xb, a.kb, row, ok, hh, xb);
+}
+
+template <int KTA>
 __global__ void __launch_bounds__(MLP_THREADS) k_mlp_trunk_fwd(EmdMlpTrunk a) {
     extern __shared__ float lds[];
     trunk_stage<KTA>(lds, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
-    for (size_t tile = (size_t)blockIdx.x * MLP_WAVES + wave; tile < tiles; tile += (size_t)gridDim.x * MLP_WAVES) {
+    const size_t tile0 = (size_t)blockIdx.x * MLP_WAVES + wave, tstep = (size_t)gridDim.x * MLP_WAVES;
+    // the next tile's rows are loaded while this tile computes (one wave per SIMD: nothing else hides the HBM latency)
+    f32x16 nxa[KTA ? KTA : 1];
+    float nxb[4];
+    trunk_load_x<KTA>(a, tile0 * 32 + r, tile0 * 32 + r < N, hh, nxa, nxb);
+    for (size_t tile = tile0; tile < tiles; tile += tstep) {
         const size_t row = tile * 32 + r;
         const bool ok = row < N;
         f32x16 xa[KTA ? KTA : 1], h[2];
         float xb[4];
-        trunk_forward_tile<KTA>(a, lds, row, ok, r, hh, xa, xb, h);
+#pragma unroll
+        for (int t = 0; t < (KTA ? KTA : 1); t++) xa[t] = nxa[t];
+#pragma unroll
+        for (int j = 0; j < 4; j++) xb[j] = nxb[j];
+        {
+            const size_t nrow = (tile + tstep) * 32 + r;
+            trunk_load_x<KTA>(a, nrow, nrow < N, hh, nxa, nxb);
+        }
+        trunk_forward_tile<KTA>(lds, r, hh, xa, xb, h);
         store_tile(a.h, 64, row, ok, 0, hh, h[0]);
         store_tile(a.h, 64, row, ok, 32, hh, h[1]);
     }
@@ -453,7 +493,12 @@ __global__ void __launch_bounds__(MLP_THREADS) k_mlp_trunk_bwd(EmdMlpTrunk a, Em
 #pragma unroll
         for (int t = 0; t < (KTA ? KTA : 1); t++) dWa[to][t] = zero16();
     }
-    for (size_t tile = (size_t)blockIdx.x * MLP_WAVES + wave; tile < tiles; tile += (size_t)gridDim.x * MLP_WAVES) {
+    const size_t tile0 = (size_t)blockIdx.x * MLP_WAVES + wave, tstep = (size_t)gridDim.x * MLP_WAVES;
+    // xa / xb of the next tile travel while this one computes; the dL/dh contributions are summed at the top of the tile
+    f32x16 nxa[KTA ? KTA : 1];
+    float nxb[4];
+    trunk_load_x<KTA>(a, tile0 * 32 + r, tile0 * 32 + r < N, hh, nxa, nxb);
+    for (size_t tile = tile0; tile < tiles; tile += tstep) {
         const size_t row = tile * 32 + r;
         const bool ok = row < N;
         // dL/dh: the sum of the branches' contributions
@@ -462,6 +507,16 @@ __global__ void __launch_bounds__(MLP_THREADS) k_mlp_trunk_bwd(EmdMlpTrunk a, Em
             const f32x16 p0 = load_tile(g.g_h[k], 64, row, ok, 0, hh), p1 = load_tile(g.g_h[k], 64, row, ok, 32, hh);
 #pragma unroll
             for (int v = 0; v < 16; v++) { gh[0][v] += p0[v]; gh[1][v] += p1[v]; }
+        }
+        f32x16 xa[KTA ? KTA : 1];
+        float xb[4];
+#pragma unroll
+        for (int t = 0; t < (KTA ? KTA : 1); t++) xa[t] = nxa[t];
+#pragma unroll
+        for (int j = 0; j < 4; j++) xb[j] = nxb[j];
+        {
+            const size_t nrow = (tile + tstep) * 32 + r;
+            trunk_load_x<KTA>(a, nrow, nrow < N, hh, nxa, nxb);
         }
         const f32x16 gf[2] = {transpose_tile(gh[0], T, r, hh), transpose_tile(gh[1], T, r, hh)};
         db[0] += frag_sum(gf[0]); db[1] += frag_sum(gf[1]);
@@ -476,22 +531,20 @@ __global__ void __launch_bounds__(MLP_THREADS) k_mlp_trunk_bwd(EmdMlpTrunk a, Em
             }
 #pragma unroll
             for (int t = 0; t < KTA; t++) {
-                const f32x16 af = transpose_tile(load_tile(a.xa, a.ka, row, ok, 32 * t, hh), T, r, hh);
+                const f32x16 af = transpose_tile(xa[t], T, r, hh);
                 dWa[0][t] = outer_acc(dWa[0][t], gf[0], af);
                 dWa[1][t] = outer_acc(dWa[1][t], gf[1], af);
             }
         }
         if (a.kb > 0) {
             // xb as a tile: feature c = 8 (v / 4) + 4 hh + v % 4 < kb <= 8 lives in registers 0..3
-            float xb[4];
-            load_xb(a.xb, a.kb, row, ok, hh, xb);
             f32x16 xt = zero16();
             xt[0] = xb[0]; xt[1] = xb[1]; xt[2] = xb[2]; xt[3] = xb[3];
             const f32x16 af = transpose_tile(xt, T, r, hh);
             dWb[0] = outer_acc(dWb[0], gf[0], af);
             dWb[1] = outer_acc(dWb[1], gf[1], af);
             if (g.d_xb) {
-                // d xb[c] = sum_k Wb[k][c] gh[k]: one tile whose features c >= 8 are zero (Wb is stored [64][12], columns 8..11 zero)
+                // d xb[c] = sum_k Wb[k][c] gh[k]: one tile whose features c >= 8 are zero (Wb is stored [64][12], columns 8..11 unused)
                 f32x16 gx = zero16();
 #pragma unroll
                 for (int kt = 0; kt < 2; kt++)
