@@ -606,10 +606,18 @@ int check_trunk(const EmdMlpTrunk* a, const char* who) {
     return EMD_OK;
 }
 
-template <typename K, typename... Args>
-int mlp_launch(K kernel, int floats, int num_points, hipStream_t st, Args... args) {
+template <auto kernel, typename... Args>
+int mlp_launch(int floats, int num_points, hipStream_t st, Args... args) {
     const size_t bytes = (size_t)floats * sizeof(float);
-    if (bytes > 64 * 1024) EMD_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes > 64 * 1024) {
+        // once per kernel (this function template is instantiated per kernel: the kernel is its template argument): not a stream operation, so it is kept
+        // out of the per-launch path and out of any stream capture after the first call
+        static bool raised = false;
+        if (!raised) {
+            EMD_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            raised = true;
+        }
+    }
     hipLaunchKernelGGL(kernel, dim3(mlp_grid(num_points)), dim3(MLP_THREADS), bytes, st, args...);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
@@ -623,10 +631,10 @@ extern "C" int emd_mlp_branch_forward(const EmdMlpBranch* a, void* hip_stream) {
     if (!a->out) { emd_set_error("mlp_branch_forward: null output"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     const int nto = a->out_dim > 32 ? 2 : 1;
-    if (a->depth == 1 && nto == 1) return mlp_launch(k_mlp_branch_fwd<1, 1>, BranchLds<1, 1>::fwd_floats, a->num_points, st, *a);
-    if (a->depth == 1) return mlp_launch(k_mlp_branch_fwd<1, 2>, BranchLds<1, 2>::fwd_floats, a->num_points, st, *a);
-    if (nto == 1) return mlp_launch(k_mlp_branch_fwd<2, 1>, BranchLds<2, 1>::fwd_floats, a->num_points, st, *a);
-    return mlp_launch(k_mlp_branch_fwd<2, 2>, BranchLds<2, 2>::fwd_floats, a->num_points, st, *a);
+    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1>>(BranchLds<1, 1>::fwd_floats, a->num_points, st, *a);
+    if (a->depth == 1) return mlp_launch<k_mlp_branch_fwd<1, 2>>(BranchLds<1, 2>::fwd_floats, a->num_points, st, *a);
+    if (nto == 1) return mlp_launch<k_mlp_branch_fwd<2, 1>>(BranchLds<2, 1>::fwd_floats, a->num_points, st, *a);
+    return mlp_launch<k_mlp_branch_fwd<2, 2>>(BranchLds<2, 2>::fwd_floats, a->num_points, st, *a);
 }
 
 extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranchGrads* g, void* hip_stream) {
@@ -636,18 +644,18 @@ extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranch
     if (((uintptr_t)g->g_h & 15)) { emd_set_error("mlp_branch_backward: g_h must be 16-byte aligned"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     const int nto = a->out_dim > 32 ? 2 : 1;
-    if (a->depth == 1 && nto == 1) return mlp_launch(k_mlp_branch_bwd<1, 1>, BranchLds<1, 1>::bwd_floats, a->num_points, st, *a, *g);
-    if (a->depth == 1) return mlp_launch(k_mlp_branch_bwd<1, 2>, BranchLds<1, 2>::bwd_floats, a->num_points, st, *a, *g);
-    if (nto == 1) return mlp_launch(k_mlp_branch_bwd<2, 1>, BranchLds<2, 1>::bwd_floats, a->num_points, st, *a, *g);
-    return mlp_launch(k_mlp_branch_bwd<2, 2>, BranchLds<2, 2>::bwd_floats, a->num_points, st, *a, *g);
+    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1>>(BranchLds<1, 1>::bwd_floats, a->num_points, st, *a, *g);
+    if (a->depth == 1) return mlp_launch<k_mlp_branch_bwd<1, 2>>(BranchLds<1, 2>::bwd_floats, a->num_points, st, *a, *g);
+    if (nto == 1) return mlp_launch<k_mlp_branch_bwd<2, 1>>(BranchLds<2, 1>::bwd_floats, a->num_points, st, *a, *g);
+    return mlp_launch<k_mlp_branch_bwd<2, 2>>(BranchLds<2, 2>::bwd_floats, a->num_points, st, *a, *g);
 }
 
 extern "C" int emd_mlp_trunk_forward(const EmdMlpTrunk* a, void* hip_stream) {
     int rc = check_trunk(a, "mlp_trunk_forward");
     if (rc || a->num_points == 0) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
-    if (a->ka) return mlp_launch(k_mlp_trunk_fwd<4>, TrunkLds<4>::fwd_floats, a->num_points, st, *a);
-    return mlp_launch(k_mlp_trunk_fwd<0>, TrunkLds<0>::fwd_floats, a->num_points, st, *a);
+    if (a->ka) return mlp_launch<k_mlp_trunk_fwd<4>>(TrunkLds<4>::fwd_floats, a->num_points, st, *a);
+    return mlp_launch<k_mlp_trunk_fwd<0>>(TrunkLds<0>::fwd_floats, a->num_points, st, *a);
 }
 
 extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGrads* g, void* hip_stream) {
@@ -658,6 +666,6 @@ extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGra
         if (!g->g_h[k] || ((uintptr_t)g->g_h[k] & 15)) { emd_set_error("mlp_trunk_backward: g_h[%d] null or unaligned", k); return EMD_ERR_INVALID; }
     if (g->d_xa && ((uintptr_t)g->d_xa & 15)) { emd_set_error("mlp_trunk_backward: d_xa must be 16-byte aligned"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
-    if (a->ka) return mlp_launch(k_mlp_trunk_bwd<4>, TrunkLds<4>::bwd_floats, a->num_points, st, *a, *g);
-    return mlp_launch(k_mlp_trunk_bwd<0>, TrunkLds<0>::bwd_floats, a->num_points, st, *a, *g);
+    if (a->ka) return mlp_launch<k_mlp_trunk_bwd<4>>(TrunkLds<4>::bwd_floats, a->num_points, st, *a, *g);
+    return mlp_launch<k_mlp_trunk_bwd<0>>(TrunkLds<0>::bwd_floats, a->num_points, st, *a, *g);
 }
