@@ -118,6 +118,7 @@ t0 = time.perf_counter()
 K_STEPS = 50
 for s in range(K_STEPS):
     step(10 + s)
+t_host = time.perf_counter() - t0          # the step is issued eagerly from Python: on a slow host THIS, not the GPU, sets the rate
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 op = "S3G-style step: raster (fused motion) + sky cube map + blend + L1/depth/D-SSIM/sky-BCE + backward + densification stats"
@@ -131,4 +132,5 @@ if optimizer is not None:
     op += " -> optimiser step (" + ("emd_amd.optim.Adam" if "--adam" in sys.argv else "torch.optim.Adam") + ")"
 print(json.dumps({"op": op,
                   "gaussians": N, "height": H, "width": W, "steps": K_STEPS, "ms_per_step": round(dt / K_STEPS * 1e3, 4),
-                  "iters_per_s": round(K_STEPS / dt, 1)}))
+                  "iters_per_s": round(K_STEPS / dt, 1), "host_enqueue_ms_per_step": round(t_host / K_STEPS * 1e3, 4),
+                  "host_bound": bool(t_host > 0.9 * dt)}))
