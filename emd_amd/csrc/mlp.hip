@@ -35,6 +35,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TS 36             // LDS row stride of a transposed 32 x 32 tile
 #define MLP_THREADS 256
 #define MLP_WAVES (MLP_THREADS / 64)
+// Two waves per SIMD (<= 256 registers each) where the accumulators allow it: a single wave exposes every LDS / HBM wait to the MFMA
+// pipe (measured: SQ_VALU_MFMA_BUSY_CYCLES = 45-59 % of the kernel time with one wave per SIMD).
+#ifndef MLP_FWD_WAVES
+#define MLP_FWD_WAVES 1
+#endif
+#ifndef MLP_BWD_WAVES
+#define MLP_BWD_WAVES 1
+#endif
+#define MLP_OCC(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -180,14 +189,58 @@ __device__ __forceinline__ void flush_dw(float* __restrict__ dW, int ld, int o0,
         if (o < rows) unsafeAtomicAdd(dW + (size_t)o * ld + i0 + r, acc[v]);
     }
 }
+// Sum an accumulator tile / a per-lane partial over the workgroup's waves through LDS (`buf`: (MLP_WAVES - 1) x 17 x 64 floats, the
+// transpose scratch after the tile loop); the total is valid in wave 0, which alone issues the atomics: a quarter of the traffic onto
+// the few thousand addresses every workgroup of the grid adds to at the same moment.
+__device__ __forceinline__ f32x16 wg_sum16(f32x16 acc, float* __restrict__ buf, int wave, int lane) {
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int v = 0; v < 16; v++) buf[((wave - 1) * 17 + v) * 64 + lane] = acc[v];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < MLP_WAVES - 1; w++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) acc[v] += buf[(w * 17 + v) * 64 + lane];
+    }
+    return acc;
+}
+__device__ __forceinline__ float wg_sum1(float x, float* __restrict__ buf, int wave, int lane) {
+    __syncthreads();
+    if (wave > 0) buf[((wave - 1) * 17 + 16) * 64 + lane] = x;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < MLP_WAVES - 1; w++) x += buf[(w * 17 + 16) * 64 + lane];
+    }
+    return x;
+}
+
 // per-lane bias-gradient partials (lane r = feature of the tile, both halves hold half of the rows) -> db[o0 + r]
 __device__ __forceinline__ void flush_db(float* __restrict__ db, int o0, int rows, float part, int r) {
     if (db && o0 + r < rows) unsafeAtomicAdd(db + o0 + r, part);
 }
 
-// stage a [rows, cols] block of a row-major matrix (row stride ld, first column col0) into LDS [rows_pad][stride], zero padded
+// stage a [rows, cols] block of a row-major matrix (row stride ld, first column col0) into LDS [rows_pad][stride], zero padded.
+// 16-byte pieces, four independent loads in flight per thread: the one-dword-at-a-time loop this replaces spent 30-50 us per launch
+// on dependent load -> write round trips, 15 % of a forward kernel.
 __device__ __forceinline__ void stage_matrix(float* __restrict__ dst, int stride, int rows_pad, int cols_pad, const float* __restrict__ src, int ld, int col0,
                                              int rows, int cols) {
+    const bool vec = src && !(cols & 3) && !(ld & 3) && !(col0 & 3) && !(cols_pad & 3) && !(stride & 3) && !((uintptr_t)src & 15);
+    if (vec) {
+        const int q = cols_pad >> 2, total = rows_pad * q;
+#pragma unroll 4
+        for (int idx = threadIdx.x; idx < total; idx += MLP_THREADS) {
+            const int rr = idx / q, c = (idx - rr * q) << 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr < rows && c < cols) v = *(const float4*)(src + (size_t)rr * ld + col0 + c);
+            *(float4*)(dst + rr * stride + c) = v;
+        }
+        return;
+    }
+#pragma unroll 4
     for (int idx = threadIdx.x; idx < rows_pad * cols_pad; idx += MLP_THREADS) {
         const int rr = idx / cols_pad, c = idx - rr * cols_pad;
         dst[rr * stride + c] = (src && rr < rows && c < cols) ? src[(size_t)rr * ld + col0 + c] : 0.f;
@@ -227,7 +280,7 @@ __device__ __forceinline__ void branch_stage(float* lds, const EmdMlpBranch& a) 
 }
 
 template <int DEPTH, int NTO>
-__global__ void __launch_bounds__(MLP_THREADS) k_mlp_branch_fwd(EmdMlpBranch a) {
+__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_FWD_WAVES) k_mlp_branch_fwd(EmdMlpBranch a) {
     typedef BranchLds<DEPTH, NTO> L;
     extern __shared__ float lds[];
     branch_stage<DEPTH, NTO>(lds, a);
@@ -268,7 +321,7 @@ __global__ void __launch_bounds__(MLP_THREADS) k_mlp_branch_fwd(EmdMlpBranch a) 
 }
 
 template <int DEPTH, int NTO>
-__global__ void __launch_bounds__(MLP_THREADS) k_mlp_branch_bwd(EmdMlpBranch a, EmdMlpBranchGrads g) {
+__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_branch_bwd(EmdMlpBranch a, EmdMlpBranchGrads g) {
     typedef BranchLds<DEPTH, NTO> L;
     extern __shared__ float lds[];
     branch_stage<DEPTH, NTO>(lds, a);
@@ -370,22 +423,35 @@ __global__ void __launch_bounds__(MLP_THREADS) k_mlp_branch_bwd(EmdMlpBranch a, 
             }
         }
     }
-    // ---- one atomic add per accumulator element and wave
+    // ---- workgroup sums, then one atomic add per accumulator element and workgroup
+    float* red = lds + L::scratch;
 #pragma unroll
     for (int to = 0; to < 2; to++) {
 #pragma unroll
         for (int ti = 0; ti < 2; ti++) {
-            flush_dw(g.d_w_hidden[0], 64, 32 * to, 32 * ti, 64, 64, dW1[to][ti], r, hh);
-            if (DEPTH == 2) flush_dw(g.d_w_hidden[1], 64, 32 * to, 32 * ti, 64, 64, dW2[to][ti], r, hh);
+            const f32x16 t1 = wg_sum16(dW1[to][ti], red, wave, lane);
+            if (wave == 0) flush_dw(g.d_w_hidden[0], 64, 32 * to, 32 * ti, 64, 64, t1, r, hh);
+            if (DEPTH == 2) {
+                const f32x16 t2 = wg_sum16(dW2[to][ti], red, wave, lane);
+                if (wave == 0) flush_dw(g.d_w_hidden[1], 64, 32 * to, 32 * ti, 64, 64, t2, r, hh);
+            }
         }
-        flush_db(g.d_b_hidden[0], 32 * to, 64, db1[to], r);
-        if (DEPTH == 2) flush_db(g.d_b_hidden[1], 32 * to, 64, db2[to], r);
+        const float b1s = wg_sum1(db1[to], red, wave, lane);
+        if (wave == 0) flush_db(g.d_b_hidden[0], 32 * to, 64, b1s, r);
+        if (DEPTH == 2) {
+            const float b2s = wg_sum1(db2[to], red, wave, lane);
+            if (wave == 0) flush_db(g.d_b_hidden[1], 32 * to, 64, b2s, r);
+        }
     }
 #pragma unroll
     for (int t = 0; t < NTO; t++) {
-        flush_dw(g.d_w_out, 64, 32 * t, 0, a.out_dim, 64, dWo[t][0], r, hh);
-        flush_dw(g.d_w_out, 64, 32 * t, 32, a.out_dim, 64, dWo[t][1], r, hh);
-        flush_db(g.d_b_out, 32 * t, a.out_dim, dbo[t], r);
+        const f32x16 o0 = wg_sum16(dWo[t][0], red, wave, lane), o1 = wg_sum16(dWo[t][1], red, wave, lane);
+        const float bos = wg_sum1(dbo[t], red, wave, lane);
+        if (wave == 0) {
+            flush_dw(g.d_w_out, 64, 32 * t, 0, a.out_dim, 64, o0, r, hh);
+            flush_dw(g.d_w_out, 64, 32 * t, 32, a.out_dim, 64, o1, r, hh);
+            flush_db(g.d_b_out, 32 * t, a.out_dim, bos, r);
+        }
     }
 }
 
@@ -448,7 +514,7 @@ __device__ __forceinline__ void trunk_load_x(const EmdMlpTrunk& a, size_t row, b
 }
 
 template <int KTA>
-__global__ void __launch_bounds__(MLP_THREADS) k_mlp_trunk_fwd(EmdMlpTrunk a) {
+__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_FWD_WAVES) k_mlp_trunk_fwd(EmdMlpTrunk a) {
     extern __shared__ float lds[];
     trunk_stage<KTA>(lds, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
@@ -478,7 +544,7 @@ __global__ void __launch_bounds__(MLP_THREADS) k_mlp_trunk_fwd(EmdMlpTrunk a) {
 }
 
 template <int KTA>
-__global__ void __launch_bounds__(MLP_THREADS) k_mlp_trunk_bwd(EmdMlpTrunk a, EmdMlpTrunkGrads g) {
+__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_trunk_bwd(EmdMlpTrunk a, EmdMlpTrunkGrads g) {
     typedef TrunkLds<KTA> L;
     extern __shared__ float lds[];
     trunk_stage<KTA>(lds, a);
@@ -564,21 +630,29 @@ __global__ void __launch_bounds__(MLP_THREADS) k_mlp_trunk_bwd(EmdMlpTrunk a, Em
             }
         }
     }
+    float* red = lds + L::scratch;
 #pragma unroll
     for (int to = 0; to < 2; to++) {
         if (KTA) {
 #pragma unroll
-            for (int t = 0; t < KTA; t++) flush_dw(g.d_w ? g.d_w + a.col_a : nullptr, a.ld_w, 32 * to, 32 * t, 64, a.ka, dWa[to][t], r, hh);
+            for (int t = 0; t < KTA; t++) {
+                const f32x16 sa = wg_sum16(dWa[to][t], red, wave, lane);
+                if (wave == 0) flush_dw(g.d_w ? g.d_w + a.col_a : nullptr, a.ld_w, 32 * to, 32 * t, 64, a.ka, sa, r, hh);
+            }
         }
-        if (a.kb > 0) flush_dw(g.d_w ? g.d_w + a.col_b : nullptr, a.ld_w, 32 * to, 0, 64, a.kb, dWb[to], r, hh);
-        flush_db(g.d_b, 32 * to, 64, db[to], r);
+        if (a.kb > 0) {
+            const f32x16 sb = wg_sum16(dWb[to], red, wave, lane);
+            if (wave == 0) flush_dw(g.d_w ? g.d_w + a.col_b : nullptr, a.ld_w, 32 * to, 0, 64, a.kb, sb, r, hh);
+        }
+        const float bs = wg_sum1(db[to], red, wave, lane);
+        if (wave == 0) flush_db(g.d_b, 32 * to, 64, bs, r);
     }
 }
 
-unsigned mlp_grid(int num_points) {
+unsigned mlp_grid(int num_points, int per_cu) {
     const size_t tiles = ((size_t)num_points + 31) / 32;
-    const size_t wgs = (tiles + MLP_WAVES - 1) / MLP_WAVES;
-    return (unsigned)(wgs < 256 ? (wgs ? wgs : 1) : 256);          // persistent: one workgroup per CU (the LDS holds the weights)
+    const size_t wgs = (tiles + MLP_WAVES - 1) / MLP_WAVES, cap = (size_t)256 * per_cu;
+    return (unsigned)(wgs < cap ? (wgs ? wgs : 1) : cap);          // persistent: `per_cu` workgroups per CU (their LDS holds the weights)
 }
 
 int check_branch(const EmdMlpBranch* a, const char* who) {
@@ -606,7 +680,7 @@ int check_trunk(const EmdMlpTrunk* a, const char* who) {
     return EMD_OK;
 }
 
-template <auto kernel, typename... Args>
+template <auto kernel, int PER_CU, typename... Args>
 int mlp_launch(int floats, int num_points, hipStream_t st, Args... args) {
     const size_t bytes = (size_t)floats * sizeof(float);
     if (bytes > 64 * 1024) {
@@ -618,7 +692,7 @@ int mlp_launch(int floats, int num_points, hipStream_t st, Args... args) {
             raised = true;
         }
     }
-    hipLaunchKernelGGL(kernel, dim3(mlp_grid(num_points)), dim3(MLP_THREADS), bytes, st, args...);
+    hipLaunchKernelGGL(kernel, dim3(mlp_grid(num_points, PER_CU)), dim3(MLP_THREADS), bytes, st, args...);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }
@@ -631,10 +705,10 @@ extern "C" int emd_mlp_branch_forward(const EmdMlpBranch* a, void* hip_stream) {
     if (!a->out) { emd_set_error("mlp_branch_forward: null output"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     const int nto = a->out_dim > 32 ? 2 : 1;
-    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1>>(BranchLds<1, 1>::fwd_floats, a->num_points, st, *a);
-    if (a->depth == 1) return mlp_launch<k_mlp_branch_fwd<1, 2>>(BranchLds<1, 2>::fwd_floats, a->num_points, st, *a);
-    if (nto == 1) return mlp_launch<k_mlp_branch_fwd<2, 1>>(BranchLds<2, 1>::fwd_floats, a->num_points, st, *a);
-    return mlp_launch<k_mlp_branch_fwd<2, 2>>(BranchLds<2, 2>::fwd_floats, a->num_points, st, *a);
+    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1>, MLP_FWD_WAVES>(BranchLds<1, 1>::fwd_floats, a->num_points, st, *a);
+    if (a->depth == 1) return mlp_launch<k_mlp_branch_fwd<1, 2>, MLP_FWD_WAVES>(BranchLds<1, 2>::fwd_floats, a->num_points, st, *a);
+    if (nto == 1) return mlp_launch<k_mlp_branch_fwd<2, 1>, MLP_FWD_WAVES>(BranchLds<2, 1>::fwd_floats, a->num_points, st, *a);
+    return mlp_launch<k_mlp_branch_fwd<2, 2>, MLP_FWD_WAVES>(BranchLds<2, 2>::fwd_floats, a->num_points, st, *a);
 }
 
 extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranchGrads* g, void* hip_stream) {
@@ -644,18 +718,18 @@ extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranch
     if (((uintptr_t)g->g_h & 15)) { emd_set_error("mlp_branch_backward: g_h must be 16-byte aligned"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     const int nto = a->out_dim > 32 ? 2 : 1;
-    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1>>(BranchLds<1, 1>::bwd_floats, a->num_points, st, *a, *g);
-    if (a->depth == 1) return mlp_launch<k_mlp_branch_bwd<1, 2>>(BranchLds<1, 2>::bwd_floats, a->num_points, st, *a, *g);
-    if (nto == 1) return mlp_launch<k_mlp_branch_bwd<2, 1>>(BranchLds<2, 1>::bwd_floats, a->num_points, st, *a, *g);
-    return mlp_launch<k_mlp_branch_bwd<2, 2>>(BranchLds<2, 2>::bwd_floats, a->num_points, st, *a, *g);
+    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1>, MLP_BWD_WAVES>(BranchLds<1, 1>::bwd_floats, a->num_points, st, *a, *g);
+    if (a->depth == 1) return mlp_launch<k_mlp_branch_bwd<1, 2>, MLP_BWD_WAVES>(BranchLds<1, 2>::bwd_floats, a->num_points, st, *a, *g);
+    if (nto == 1) return mlp_launch<k_mlp_branch_bwd<2, 1>, MLP_BWD_WAVES>(BranchLds<2, 1>::bwd_floats, a->num_points, st, *a, *g);
+    return mlp_launch<k_mlp_branch_bwd<2, 2>, MLP_BWD_WAVES>(BranchLds<2, 2>::bwd_floats, a->num_points, st, *a, *g);
 }
 
 extern "C" int emd_mlp_trunk_forward(const EmdMlpTrunk* a, void* hip_stream) {
     int rc = check_trunk(a, "mlp_trunk_forward");
     if (rc || a->num_points == 0) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
-    if (a->ka) return mlp_launch<k_mlp_trunk_fwd<4>>(TrunkLds<4>::fwd_floats, a->num_points, st, *a);
-    return mlp_launch<k_mlp_trunk_fwd<0>>(TrunkLds<0>::fwd_floats, a->num_points, st, *a);
+    if (a->ka) return mlp_launch<k_mlp_trunk_fwd<4>, MLP_FWD_WAVES>(TrunkLds<4>::fwd_floats, a->num_points, st, *a);
+    return mlp_launch<k_mlp_trunk_fwd<0>, MLP_FWD_WAVES>(TrunkLds<0>::fwd_floats, a->num_points, st, *a);
 }
 
 extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGrads* g, void* hip_stream) {
@@ -666,6 +740,6 @@ extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGra
         if (!g->g_h[k] || ((uintptr_t)g->g_h[k] & 15)) { emd_set_error("mlp_trunk_backward: g_h[%d] null or unaligned", k); return EMD_ERR_INVALID; }
     if (g->d_xa && ((uintptr_t)g->d_xa & 15)) { emd_set_error("mlp_trunk_backward: d_xa must be 16-byte aligned"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
-    if (a->ka) return mlp_launch<k_mlp_trunk_bwd<4>>(TrunkLds<4>::bwd_floats, a->num_points, st, *a, *g);
-    return mlp_launch<k_mlp_trunk_bwd<0>>(TrunkLds<0>::bwd_floats, a->num_points, st, *a, *g);
+    if (a->ka) return mlp_launch<k_mlp_trunk_bwd<4>, MLP_BWD_WAVES>(TrunkLds<4>::bwd_floats, a->num_points, st, *a, *g);
+    return mlp_launch<k_mlp_trunk_bwd<0>, MLP_BWD_WAVES>(TrunkLds<0>::bwd_floats, a->num_points, st, *a, *g);
 }
