@@ -126,13 +126,17 @@ __device__ __forceinline__ f32x16 bias_tile(const float* __restrict__ b_lds, int
     return t;
 }
 
-// out[to] += W[32 to + r][k] in[k]: KT input tiles, NT output tiles; W in LDS, row stride `stride`, first input column `k0`
-template <int KT, int NT>
+// out[to] += W[32 to + r][k] in[k]: KT input tiles, NT output tiles; W in LDS, row stride `stride`, first input column `k0`.
+// NA < 4: only the first NA 8-feature chunks of an input tile are non-zero.
+// The backward's data path is the same function on the TRANSPOSED weights (a second LDS image, [in][out]): reading W column-wise
+// instead needs one ds_read_b32 per MFMA, which a wave with a full register file cannot prefetch -- the matrix pipe then waits for an
+// LDS round trip per instruction (SQ_VALU_MFMA_BUSY_CYCLES was 53 % of the kernel time).
+template <int KT, int NT, int NA = 4>
 __device__ __forceinline__ void layer_fwd(f32x16 (&acc)[NT], const f32x16 (&in)[KT], const float* __restrict__ W, int stride, int k0, int r, int hh) {
 #pragma unroll
     for (int kt = 0; kt < KT; kt++)
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
+        for (int a = 0; a < NA; a++) {
             float4 w[NT];
 #pragma unroll
             for (int to = 0; to < NT; to++) w[to] = *(const float4*)(W + (32 * to + r) * stride + k0 + 32 * kt + 8 * a + 4 * hh);
@@ -143,21 +147,6 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&acc)[NT], const f32x16 (&in)[
                 acc[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[to].z, in[kt][4 * a + 2], acc[to], 0, 0, 0);
                 acc[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[to].w, in[kt][4 * a + 3], acc[to], 0, 0, 0);
             }
-        }
-}
-
-// gin[ti] += sum_k W[k][c0 + 32 ti + r] g[k]  (W^T g): GT tiles of g (the layer's output features), NT tiles of its input features.
-// NV < 16: only the first NV registers of a g tile are non-zero (a layer with at most NV / 2 outputs per tile: features 8 (v / 4) + 4 hh + v % 4)
-template <int GT, int NT, int NV = 16>
-__device__ __forceinline__ void layer_bwd(f32x16 (&acc)[NT], const f32x16 (&g)[GT], const float* __restrict__ W, int stride, int c0, int r, int hh) {
-#pragma unroll
-    for (int kt = 0; kt < GT; kt++)
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-            const int k = 32 * kt + 8 * (v >> 2) + 4 * hh + (v & 3);
-#pragma unroll
-            for (int ti = 0; ti < NT; ti++)
-                acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(W[k * stride + c0 + 32 * ti + r], g[kt][v], acc[ti], 0, 0, 0);
         }
 }
 
@@ -261,6 +250,15 @@ __device__ __forceinline__ void stage_matrix(float* __restrict__ dst, int stride
         dst[rr * stride + c] = (src && rr < rows && c < cols) ? src[(size_t)rr * ld + col0 + c] : 0.f;
     }
 }
+// the transposed image: dst[c][rr] = src[rr][col0 + c] for rr < rows, c < cols; zero elsewhere in [cols_pad][rows_pad]
+__device__ __forceinline__ void stage_matrix_t(float* __restrict__ dst, int stride, int rows_pad, int cols_pad, const float* __restrict__ src, int ld, int col0,
+                                               int rows, int cols) {
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < rows_pad * cols_pad; idx += MLP_THREADS) {
+        const int rr = idx / cols_pad, c = idx - rr * cols_pad;          // consecutive threads read consecutive source columns
+        dst[c * stride + rr] = (src && rr < rows && c < cols) ? src[(size_t)rr * ld + col0 + c] : 0.f;
+    }
+}
 __device__ __forceinline__ void stage_vector(float* __restrict__ dst, int n_pad, const float* __restrict__ src, int n) {
     for (int idx = threadIdx.x; idx < n_pad; idx += MLP_THREADS) dst[idx] = (src && idx < n) ? src[idx] : 0.f;
 }
@@ -277,14 +275,24 @@ struct BranchLds {
     static constexpr int b1 = wo + 32 * NTO * WS;
     static constexpr int b2 = b1 + 64;
     static constexpr int bo = b2 + 64;
-    static constexpr int scratch = bo + 64;
-    static constexpr int fwd_floats = scratch;
+    static constexpr int fwd_floats = bo + 64;
+    // backward only: the transposed images W1^T [64][WS], W2^T, Wo^T [64][WOT] and one transpose tile per wave
+    static constexpr int WOT = 32 * NTO + 4;
+    static constexpr int w1t = fwd_floats;
+    static constexpr int w2t = w1t + 64 * WS;
+    static constexpr int wot = w2t + (DEPTH == 2 ? 64 * WS : 0);
+    static constexpr int scratch = wot + 64 * WOT;
     static constexpr int bwd_floats = scratch + MLP_WAVES * 32 * TS;
 };
 
-template <int DEPTH, int NTO>
+template <int DEPTH, int NTO, bool BWD>
 __device__ __forceinline__ void branch_stage(float* lds, const EmdMlpBranch& a) {
     typedef BranchLds<DEPTH, NTO> L;
+    if (BWD) {
+        stage_matrix_t(lds + L::w1t, WS, 64, 64, a.w_hidden[0], 64, 0, 64, 64);
+        if (DEPTH == 2) stage_matrix_t(lds + L::w2t, WS, 64, 64, a.w_hidden[1], 64, 0, 64, 64);
+        stage_matrix_t(lds + L::wot, L::WOT, 32 * NTO, 64, a.w_out, 64, 0, a.out_dim, 64);
+    }
     stage_matrix(lds + L::w1, WS, 64, 64, a.w_hidden[0], 64, 0, 64, 64);
     if (DEPTH == 2) stage_matrix(lds + L::w2, WS, 64, 64, a.w_hidden[1], 64, 0, 64, 64);
     stage_matrix(lds + L::wo, WS, 32 * NTO, 64, a.w_out, 64, 0, a.out_dim, 64);
@@ -298,7 +306,7 @@ template <int DEPTH, int NTO>
 __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_FWD_WAVES) k_mlp_branch_fwd(EmdMlpBranch a) {
     typedef BranchLds<DEPTH, NTO> L;
     extern __shared__ float lds[];
-    branch_stage<DEPTH, NTO>(lds, a);
+    branch_stage<DEPTH, NTO, false>(lds, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
     const bool wide_out = (a.out_dim & 3) == 0;
@@ -339,7 +347,7 @@ template <int DEPTH, int NTO>
 __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_branch_bwd(EmdMlpBranch a, EmdMlpBranchGrads g) {
     typedef BranchLds<DEPTH, NTO> L;
     extern __shared__ float lds[];
-    branch_stage<DEPTH, NTO>(lds, a);
+    branch_stage<DEPTH, NTO, true>(lds, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     float* T = lds + L::scratch + wave * 32 * TS;
     const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
@@ -391,8 +399,8 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
         f32x16 (&last)[2] = DEPTH == 2 ? m2 : m1;          // the activation that feeds the output layer
         // ---- output layer
         f32x16 gl[2] = {zero16(), zero16()};
-        if (NTO == 1 && a.out_dim <= 8) layer_bwd<NTO, 2, 4>(gl, go, lds + L::wo, WS, 0, r, hh);      // dx / do / feat: 4 k-steps carry everything
-        else layer_bwd<NTO, 2>(gl, go, lds + L::wo, WS, 0, r, hh);
+        if (NTO == 1 && a.out_dim <= 8) layer_fwd<NTO, 2, 1>(gl, go, lds + L::wot, L::WOT, 0, r, hh);  // dx / do / feat: one 8-feature chunk carries everything
+        else layer_fwd<NTO, 2>(gl, go, lds + L::wot, L::WOT, 0, r, hh);
         gl[0] = mask16(gl[0], last[0]); gl[1] = mask16(gl[1], last[1]);
         {   // dWo += go (x) last, dbo += rowsum(go)
             f32x16 af[2] = {transpose_tile(last[0], T, r, hh), transpose_tile(last[1], T, r, hh)};
@@ -408,7 +416,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
         f32x16 g1[2];
         if (DEPTH == 2) {
             g1[0] = zero16(); g1[1] = zero16();
-            layer_bwd<2, 2>(g1, gl, lds + L::w2, WS, 0, r, hh);
+            layer_fwd<2, 2>(g1, gl, lds + L::w2t, WS, 0, r, hh);
             g1[0] = mask16(g1[0], m1[0]); g1[1] = mask16(g1[1], m1[1]);
             f32x16 af[2] = {transpose_tile(m1[0], T, r, hh), transpose_tile(m1[1], T, r, hh)};
 #pragma unroll
@@ -423,7 +431,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
         }
         // ---- first hidden layer
         f32x16 gx[2] = {zero16(), zero16()};
-        layer_bwd<2, 2>(gx, g1, lds + L::w1, WS, 0, r, hh);
+        layer_fwd<2, 2>(gx, g1, lds + L::w1t, WS, 0, r, hh);
         if (a.relu_input) { gx[0] = mask16(gx[0], hin[0]); gx[1] = mask16(gx[1], hin[1]); }
         store_tile(g.g_h, 64, row, ok, 0, hh, gx[0]);
         store_tile(g.g_h, 64, row, ok, 32, hh, gx[1]);
@@ -480,8 +488,11 @@ struct TrunkLds {
     static constexpr int wa = 0;
     static constexpr int wb = wa + (KTA ? 64 * SA : 0);
     static constexpr int b = wb + 64 * 12;
-    static constexpr int scratch = b + 64;
-    static constexpr int fwd_floats = scratch;
+    static constexpr int fwd_floats = b + 64;
+    // backward: only the transposed images Wa^T [32 KTA][WS], Wb^T [32][WS] (rows >= kb zero) and one transpose tile per wave
+    static constexpr int wat = 0;
+    static constexpr int wbt = wat + 32 * KTA * WS;
+    static constexpr int scratch = wbt + 32 * WS;
     static constexpr int bwd_floats = scratch + MLP_WAVES * 32 * TS;
 };
 
@@ -573,7 +584,9 @@ template <int KTA>
 __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_trunk_bwd(EmdMlpTrunk a, EmdMlpTrunkGrads g) {
     typedef TrunkLds<KTA> L;
     extern __shared__ float lds[];
-    trunk_stage<KTA>(lds, a);
+    if (KTA) stage_matrix_t(lds + L::wat, WS, 64, 32 * KTA, a.w, a.ld_w, a.col_a, 64, a.ka);
+    stage_matrix_t(lds + L::wbt, WS, 64, 32, a.kb > 0 ? a.w : nullptr, a.ld_w, a.col_b, 64, a.kb);
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     float* T = lds + L::scratch + wave * 32 * TS;
     const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
@@ -617,7 +630,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_trun
                 f32x16 gx[KTA ? KTA : 1];
 #pragma unroll
                 for (int t = 0; t < KTA; t++) gx[t] = zero16();
-                layer_bwd<2, (KTA ? KTA : 1)>(gx, gh, lds + L::wa, L::SA, 0, r, hh);
+                layer_fwd<2, (KTA ? KTA : 1)>(gx, gh, lds + L::wat, WS, 0, r, hh);
 #pragma unroll
                 for (int t = 0; t < KTA; t++) store_tile(g.d_xa, a.ka, row, ok, 32 * t, hh, gx[t]);
             }
@@ -636,16 +649,10 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_trun
             dWb[0] = outer_acc(dWb[0], gf[0], af);
             dWb[1] = outer_acc(dWb[1], gf[1], af);
             if (g.d_xb) {
-                // d xb[c] = sum_k Wb[k][c] gh[k]: one tile whose features c >= 8 are zero (Wb is stored [64][12], columns 8..11 unused)
-                f32x16 gx = zero16();
-#pragma unroll
-                for (int kt = 0; kt < 2; kt++)
-#pragma unroll
-                    for (int v = 0; v < 16; v++) {
-                        const int k = 32 * kt + 8 * (v >> 2) + 4 * hh + (v & 3);
-                        const float w = r < 8 ? lds[L::wb + k * 12 + r] : 0.f;
-                        gx = __builtin_amdgcn_mfma_f32_32x32x2f32(w, gh[kt][v], gx, 0, 0, 0);
-                    }
+                // d xb[c] = sum_k Wb[k][c] gh[k]: one tile whose features c >= kb are zero (the rows of Wb^T beyond kb are zero)
+                f32x16 gx1[1] = {zero16()};
+                layer_fwd<2, 1>(gx1, gh, lds + L::wbt, WS, 0, r, hh);
+                const f32x16 gx = gx1[0];
                 if (ok) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
