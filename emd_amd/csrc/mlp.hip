@@ -69,22 +69,26 @@ __device__ __forceinline__ f32x16 mask16(f32x16 g, f32x16 y) {
 // fall back to s_waitcnt vmcnt(0) at the join, which waits for the prefetch of the NEXT tile in every iteration (SQ_WAIT_ANY 15-25 %
 // of the wave time): the forward kernels gain 12-15 % from the straight form; the backward kernels, whose schedule is ruled by
 // register pressure, lose as much, so they keep the branch (both measured).
+// `width` (a multiple of 4): columns >= width do not exist and read as 0 (the last tile of a narrow xa)
 template <bool STRAIGHT = false>
-__device__ __forceinline__ f32x16 load_tile(const float* __restrict__ src, size_t ld, size_t row, bool ok, int c0, int hh) {
+__device__ __forceinline__ f32x16 load_tile(const float* __restrict__ src, size_t ld, size_t row, bool ok, int c0, int hh, int width = 1 << 30) {
     f32x16 t;
     if (STRAIGHT) {
-        const float* p = src + (ok ? row : 0) * ld + c0 + 4 * hh;
-        const float keep = ok ? 1.f : 0.f;
+        const float* p = src + (ok ? row : 0) * ld;
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-            const float4 q = *(const float4*)(p + 8 * a);
+            const int c = c0 + 8 * a + 4 * hh;
+            const bool in = c < width;
+            const float4 q = *(const float4*)(p + (in ? c : 0));
+            const float keep = (ok && in) ? 1.f : 0.f;
             t[4 * a] = q.x * keep; t[4 * a + 1] = q.y * keep; t[4 * a + 2] = q.z * keep; t[4 * a + 3] = q.w * keep;
         }
     } else {
 #pragma unroll
         for (int a = 0; a < 4; a++) {
+            const int c = c0 + 8 * a + 4 * hh;
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) q = *(const float4*)(src + row * ld + c0 + 8 * a + 4 * hh);
+            if (ok && c < width) q = *(const float4*)(src + row * ld + c);
             t[4 * a] = q.x; t[4 * a + 1] = q.y; t[4 * a + 2] = q.z; t[4 * a + 3] = q.w;
         }
     }
@@ -100,11 +104,13 @@ __device__ __forceinline__ f32x16 load_tile_narrow(const float* __restrict__ src
     }
     return t;
 }
-__device__ __forceinline__ void store_tile(float* __restrict__ dst, size_t ld, size_t row, bool ok, int c0, int hh, f32x16 t) {
+__device__ __forceinline__ void store_tile(float* __restrict__ dst, size_t ld, size_t row, bool ok, int c0, int hh, f32x16 t, int width = 1 << 30) {
     if (!ok) return;
 #pragma unroll
-    for (int a = 0; a < 4; a++)
-        *(float4*)(dst + row * ld + c0 + 8 * a + 4 * hh) = make_float4(t[4 * a], t[4 * a + 1], t[4 * a + 2], t[4 * a + 3]);
+    for (int a = 0; a < 4; a++) {
+        const int c = c0 + 8 * a + 4 * hh;
+        if (c < width) *(float4*)(dst + row * ld + c) = make_float4(t[4 * a], t[4 * a + 1], t[4 * a + 2], t[4 * a + 3]);
+    }
 }
 __device__ __forceinline__ void store_tile_narrow(float* __restrict__ dst, int width, size_t row, bool ok, int c0, int hh, f32x16 t) {
     if (!ok) return;
@@ -545,7 +551,7 @@ template <int KTA, bool STRAIGHT>
 __device__ __forceinline__ void trunk_load_x(const EmdMlpTrunk& a, size_t row, bool ok, int hh, f32x16 (&xa)[KTA ? KTA : 1], float (&xb)[4]) {
     if (KTA) {
 #pragma unroll
-        for (int t = 0; t < KTA; t++) xa[t] = load_tile<STRAIGHT>(a.xa, a.ka, row, ok, 32 * t, hh);
+        for (int t = 0; t < KTA; t++) xa[t] = load_tile<STRAIGHT>(a.xa, a.ka, row, ok, 32 * t, hh, a.ka);
     }
     load_xb<STRAIGHT>(a.xb, a.kb, row, ok, hh, xb);
 }
@@ -632,7 +638,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_trun
                 for (int t = 0; t < KTA; t++) gx[t] = zero16();
                 layer_fwd<2, (KTA ? KTA : 1)>(gx, gh, lds + L::wat, WS, 0, r, hh);
 #pragma unroll
-                for (int t = 0; t < KTA; t++) store_tile(g.d_xa, a.ka, row, ok, 32 * t, hh, gx[t]);
+                for (int t = 0; t < KTA; t++) store_tile(g.d_xa, a.ka, row, ok, 32 * t, hh, gx[t], a.ka);
             }
 #pragma unroll
             for (int t = 0; t < KTA; t++) {
@@ -703,9 +709,9 @@ int check_branch(const EmdMlpBranch* a, const char* who) {
 
 int check_trunk(const EmdMlpTrunk* a, const char* who) {
     if (!a) { emd_set_error("%s: null args", who); return EMD_ERR_INVALID; }
-    if (a->num_points < 0 || (a->ka != 0 && a->ka != 128) || a->kb < 0 || a->kb > 8 || a->ka + a->kb == 0 || a->ld_w < a->ka + a->kb ||
+    if (a->num_points < 0 || (a->ka < 0 || a->ka > 128 || (a->ka & 3)) || a->kb < 0 || a->kb > 8 || a->ka + a->kb == 0 || a->ld_w < a->ka + a->kb ||
         a->col_a < 0 || a->col_b < 0 || a->col_a + a->ka > a->ld_w || a->col_b + a->kb > a->ld_w) {
-        emd_set_error("%s: bad sizes (ka 0 or 128, kb <= 8)", who); return EMD_ERR_INVALID;
+        emd_set_error("%s: bad sizes (ka a multiple of 4 up to 128, kb <= 8)", who); return EMD_ERR_INVALID;
     }
     if (a->num_points == 0) return EMD_OK;
     if (!a->w || !a->b || !a->h || (a->ka && !a->xa) || (a->kb && !a->xb)) { emd_set_error("%s: null pointer", who); return EMD_ERR_INVALID; }
@@ -761,8 +767,13 @@ extern "C" int emd_mlp_trunk_forward(const EmdMlpTrunk* a, void* hip_stream) {
     int rc = check_trunk(a, "mlp_trunk_forward");
     if (rc || a->num_points == 0) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
-    if (a->ka) return mlp_launch<k_mlp_trunk_fwd<4>, MLP_FWD_WAVES>(TrunkLds<4>::fwd_floats, a->num_points, st, *a);
-    return mlp_launch<k_mlp_trunk_fwd<0>, MLP_FWD_WAVES>(TrunkLds<0>::fwd_floats, a->num_points, st, *a);
+    switch ((a->ka + 31) / 32) {            // input tiles of 32 columns (the last one zero-padded)
+        case 0: return mlp_launch<k_mlp_trunk_fwd<0>, MLP_FWD_WAVES>(TrunkLds<0>::fwd_floats, a->num_points, st, *a);
+        case 1: return mlp_launch<k_mlp_trunk_fwd<1>, MLP_FWD_WAVES>(TrunkLds<1>::fwd_floats, a->num_points, st, *a);
+        case 2: return mlp_launch<k_mlp_trunk_fwd<2>, MLP_FWD_WAVES>(TrunkLds<2>::fwd_floats, a->num_points, st, *a);
+        case 3: return mlp_launch<k_mlp_trunk_fwd<3>, MLP_FWD_WAVES>(TrunkLds<3>::fwd_floats, a->num_points, st, *a);
+        default: return mlp_launch<k_mlp_trunk_fwd<4>, MLP_FWD_WAVES>(TrunkLds<4>::fwd_floats, a->num_points, st, *a);
+    }
 }
 
 extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGrads* g, void* hip_stream) {
@@ -773,6 +784,11 @@ extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGra
         if (!g->g_h[k] || ((uintptr_t)g->g_h[k] & 15)) { emd_set_error("mlp_trunk_backward: g_h[%d] null or unaligned", k); return EMD_ERR_INVALID; }
     if (g->d_xa && ((uintptr_t)g->d_xa & 15)) { emd_set_error("mlp_trunk_backward: d_xa must be 16-byte aligned"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
-    if (a->ka) return mlp_launch<k_mlp_trunk_bwd<4>, MLP_BWD_WAVES>(TrunkLds<4>::bwd_floats, a->num_points, st, *a, *g);
-    return mlp_launch<k_mlp_trunk_bwd<0>, MLP_BWD_WAVES>(TrunkLds<0>::bwd_floats, a->num_points, st, *a, *g);
+    switch ((a->ka + 31) / 32) {
+        case 0: return mlp_launch<k_mlp_trunk_bwd<0>, MLP_BWD_WAVES>(TrunkLds<0>::bwd_floats, a->num_points, st, *a, *g);
+        case 1: return mlp_launch<k_mlp_trunk_bwd<1>, MLP_BWD_WAVES>(TrunkLds<1>::bwd_floats, a->num_points, st, *a, *g);
+        case 2: return mlp_launch<k_mlp_trunk_bwd<2>, MLP_BWD_WAVES>(TrunkLds<2>::bwd_floats, a->num_points, st, *a, *g);
+        case 3: return mlp_launch<k_mlp_trunk_bwd<3>, MLP_BWD_WAVES>(TrunkLds<3>::bwd_floats, a->num_points, st, *a, *g);
+        default: return mlp_launch<k_mlp_trunk_bwd<4>, MLP_BWD_WAVES>(TrunkLds<4>::bwd_floats, a->num_points, st, *a, *g);
+    }
 }

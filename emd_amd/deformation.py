@@ -321,7 +321,7 @@ class Deformation(nn.Module):
 
     def _level_fused(self, pts, time_emb, embeddings, coarse, it, num_down_emb):
         """The same level as `_feature` + `_heads`, or None when the configuration is outside what the fused kernels serve (width 64,
-        defor_depth 1, 128 HexPlane features, an embedding of at most 8 values, at most six heads): the GEMM path then runs."""
+        defor_depth 1, at most 128 HexPlane features, an embedding of at most 8 values, at most six heads): the GEMM path then runs."""
         from . import mlp
         a = self.args
         if not getattr(a, "fused_mlp", True) or self.D != 1 or self.W != mlp.WIDTH or pts.device.type != "cuda":

@@ -21,8 +21,8 @@ def _stream():
 
 
 def eligible(ka, kb, hidden_shapes, out_dims):
-    """The shapes csrc/mlp.hip serves: width 64 everywhere, ka in {0, 128}, kb <= 8, out_dim <= 64, at most six heads."""
-    return (ka in (0, 128) and 0 <= kb <= 8 and ka + kb > 0 and all(tuple(s) == (WIDTH, WIDTH) for s in hidden_shapes) and
+    """The shapes csrc/mlp.hip serves: width 64 everywhere, ka a multiple of 4 up to 128, kb <= 8, out_dim <= 64, at most six heads."""
+    return (0 <= ka <= 128 and ka % 4 == 0 and 0 <= kb <= 8 and ka + kb > 0 and all(tuple(s) == (WIDTH, WIDTH) for s in hidden_shapes) and
             all(1 <= o <= 64 for o in out_dims) and 1 <= len(out_dims) <= L.MLP_MAX_BRANCHES)
 
 

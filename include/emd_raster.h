@@ -495,7 +495,7 @@ int emd_deform_input_backward(int num_points, int embed_dim, int ld, int col0, c
  * Deformation.feature_out (defor_depth = 1) + the pos / scales / rotations / opacity / shs heads + dino_head of
  * S3Gaussian/scene/deformation.py:100-185,254-337: see the block comment of csrc/mlp.hip.  One trunk call and one branch call per
  * head replace ~12 GEMMs and ~30 element-wise launches per level and direction; every intermediate stays in registers.
- *   trunk   h = b + w[:, col_a : col_a + ka] xa + w[:, col_b : col_b + kb] xb      (ka = 0 or 128, kb <= 8; b = the layer's bias +
+ *   trunk   h = b + w[:, col_a : col_a + ka] xa + w[:, col_b : col_b + kb] xb      (ka a multiple of 4 up to 128, kb <= 8; b = the layer's bias +
  *           the contribution of the temporal-embedding row, which is the same for every Gaussian)
  *   branch  out = w_out act(... act(w_hidden[0] in + b_hidden[0]) ...) + b_out, `depth` hidden layers of width 64 with ReLU,
  *           in = relu(h) when relu_input (the deformation heads: nn.Sequential(ReLU, Linear, ReLU, Linear)) else h (dino_head)

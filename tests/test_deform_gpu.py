@@ -78,11 +78,19 @@ def _load_net(g, tag, dev):
     return net.to(dev)
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused-mlp", "gemm-path"])
 @pytest.mark.parametrize("tag", ["run", "full"])
-def test_deform_network_matches_reference_golden(tag):
+def test_deform_network_matches_reference_golden(tag, fused, monkeypatch):
+    """Both formulations of the trunk + heads against the reference's own outputs and gradients: the fused fp32-MFMA kernels
+    (csrc/mlp.hip, the default) and the hipBLASLt GEMM path (DeformOptions.fused_mlp = False)."""
+    from emd_amd import mlp
     dev = torch.device("cuda", 0)
     g = np.load(os.path.join(G, "s3g_deform.npz"))
     net = _load_net(g, tag, dev)
+    net.args.fused_mlp = fused
+    calls = []
+    real = mlp.level_mlp
+    monkeypatch.setattr(mlp, "level_mlp", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     ins = {n: torch.from_numpy(g[f"{tag}_in_{n}"]).to(dev).requires_grad_(True) for n in NAMES + ("emb",)}
     res = net(ins["point"], ins["scales"], ins["rotations"], ins["opacity"], ins["shs"], torch.from_numpy(g[f"{tag}_in_times"]).to(dev),
               ins["emb"], int(g[f"{tag}_iter"]), int(g[f"{tag}_cam_no"]), 0.1, True)
@@ -109,6 +117,7 @@ def test_deform_network_matches_reference_golden(tag):
         else:
             _close(got, want, f"grad {n}")
     assert np.abs(g[f"{tag}_gsd_deformation_net.time_offset"]).max() > 0
+    assert len(calls) == (2 if fused else 0)            # both levels really ran on the fused kernels / none did
 
 
 def test_deform_network_vs_oracle_default_sizes():

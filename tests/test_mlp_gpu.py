@@ -54,8 +54,10 @@ def _leaves(net):
     (1000, 128, 4, [(True, 1, 3), (True, 1, 1), (True, 1, 48), (False, 2, 3)]),          # the coarse level of the reference configuration
     (1000, 0, 4, [(True, 1, 3), (True, 1, 1), (True, 1, 48), (False, 2, 3)]),            # its fine level (no HexPlane features)
     (37, 128, 8, [(True, 1, 4), (False, 1, 64), (True, 2, 33)]),                          # ragged tile, other widths
+    (96, 16, 4, [(True, 1, 3), (True, 1, 3), (True, 1, 4), (True, 1, 1), (True, 1, 48), (False, 2, 3)]),   # the goldens' network: 16 HexPlane features, six heads
+    (500, 72, 5, [(True, 1, 7)]),                                                         # xa ends inside its third tile, odd embedding width
     (70001, 128, 4, [(True, 1, 3), (True, 1, 48)]),                                       # many tiles per wave
-], ids=["coarse", "fine", "ragged", "70k"])
+], ids=["coarse", "fine", "ragged", "golden-shape", "ka72", "70k"])
 def test_level_mlp_matches_float64(N, ka, kb, heads):
     from emd_amd.mlp import level_mlp
     g = torch.Generator().manual_seed(N + ka + kb)
