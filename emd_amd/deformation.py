@@ -13,7 +13,9 @@ is how a step is computed:
   * the heads share one ReLU of the hidden feature and one first-layer GEMM;
   * every Linear's weight gradient (an [out, in] result reduced over N ~ 10^6 rows) is computed as a split batched GEMM
     (`_TallLinear`): the stock heuristics run that shape on a handful of workgroups.
-The dense layers stay rocBLAS GEMMs ("stays PyTorch").  Options outside the run script's configuration that
+The trunk + heads of a level run as ONE autograd node on the fused fp32-MFMA kernels of csrc/mlp.hip (`emd_amd.mlp.level_mlp`) when the
+configuration fits them (width 64, defor_depth 1: the reference's); otherwise, or with `fused_mlp=False`, as the GEMMs described above.
+Options outside the run script's configuration that
 would need the absent tinycudann hash grid or the dense occupancy grid raise NotImplementedError.
 
 `ConditionalDeformNetwork` mirrors OmniRe/models/modules.py:411-457 (same parameters); `nonrigid_deformation` is

@@ -7,7 +7,7 @@ What one step does, with the reference line each piece restates:
   GaussianRasterizationSettings + rasterizer call S3Gaussian/gaussian_renderer/__init__.py:49-62,145-155
   L1 photometric loss                             S3Gaussian/train.py:226
   loss.backward()                                 S3Gaussian/train.py:366
-Parameters, optimiser and densification stay PyTorch (out of scope).
+(Parameter store with density control and on-disk formats: emd_amd/gaussian_model.py; optimiser: emd_amd/optim.py.)
 """
 import torch
 import torch.nn.functional as F
@@ -128,7 +128,7 @@ def raster_settings_for(cam, bg, sh_degree, scaling_modifier=1.0, debug=False):
 def apply_deform(point, scales, rotations, opacity, shs, ddict_c=None, ddict_f=None):
     """Final adds of the EMD deformation (S3Gaussian/scene/deformation.py:439-481) under the run-script flags
     (`no_ds`, `no_dr`: scales and rotations pass through; dx, do, dshs of the coarse and fine level are added).
-    The MLP / HexPlane that produce the residuals stay PyTorch."""
+    The network that produces the residuals: emd_amd/deformation.py (HexPlane lookup, temporal row and fused MLP kernels)."""
     for dd in (ddict_c, ddict_f):
         if dd is None:
             continue
