@@ -60,6 +60,7 @@ class _LevelMLP(torch.autograd.Function):
             outs.append(out)
             structs.append(b)
         ctx.spec, ctx.trunk, ctx.structs, ctx.N = spec, t, structs, N
+        ctx.set_materialize_grads(False)        # a head nobody uses costs no backward launch and leaves its parameters' .grad at None
         ctx.has = (xa is not None, xb is not None)
         ctx.save_for_backward(xa_c, xb_c, w0_c, b_c, h, *params_c)
         return tuple(outs)
@@ -77,8 +78,11 @@ class _LevelMLP(torch.autograd.Function):
         d_w0, d_b = parts[0].view_as(w0_c), parts[1].view_as(b_c)
         d_params = [p.view_as(q) for p, q in zip(parts[2:], params_c)]
         g_hs, i = [], 0
+        unused = set()               # parameters of heads whose output received no gradient: their gradient is None, as autograd would leave it
         for (relu_input, depth, out_dim), b, g_out in zip(branches, ctx.structs, g_outs):
             n_par = 2 * depth + 2
+            if g_out is None:
+                unused.update(range(i, i + n_par))
             if g_out is not None:
                 g_out = g_out.contiguous().float()
                 g = L.EmdMlpBranchGrads()
@@ -102,7 +106,9 @@ class _LevelMLP(torch.autograd.Function):
                 d_xb = torch.empty_like(xb_c)
             tg.d_xa, tg.d_xb, tg.d_w, tg.d_b = L.ptr(d_xa), L.ptr(d_xb), d_w0.data_ptr(), d_b.data_ptr()
             L.check(lib.emd_mlp_trunk_backward(C.byref(ctx.trunk), C.byref(tg), _stream()), "emd_mlp_trunk_backward")
-        return (None, d_xa, d_xb, d_w0, d_b, *d_params)
+        if not g_hs:
+            d_w0 = d_b = None
+        return (None, d_xa, d_xb, d_w0, d_b, *[None if k in unused else p for k, p in enumerate(d_params)])
 
 
 def level_mlp(xa, xb, w0, b_eff, col_a, col_b, branches):

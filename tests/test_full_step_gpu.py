@@ -56,3 +56,64 @@ def test_s3g_style_step_composes():
     dp.add_densification_stats(out["viewspace_points"].grad, out["radii"], accum, denom, maxr)
     vis = out["radii"] > 0
     assert torch.equal(denom.bool(), vis) and torch.all(maxr[vis] == out["radii"][vis].float()) and accum[vis].sum() > 0
+
+
+def test_fine_stage_trains_through_the_rasterizer():
+    """S3Gaussian's fine stage as a loop (train.py after coarse_iterations): the EMD deformation network (HexPlane + temporal row +
+    fused MLP kernels) in front of the rasterizer, trained through it with emd_amd.optim.Adam on the reference's parameter groups.
+    The photometric loss to a target rendered from displaced Gaussians must fall, every group must receive finite gradients, and the
+    first step's gradients must not depend on which formulation of the MLP ran (fused fp32-MFMA kernels vs hipBLASLt GEMMs)."""
+    from emd_amd import scenes
+    from emd_amd.deformation import DeformOptions, deform_network
+    from emd_amd.model import StreetGaussians, l1_loss, render
+    from emd_amd.optim import Adam
+    dev = torch.device("cuda", 0)
+    N, H, W, F = 20000, 96, 160, 4
+    scene = scenes.make_static_scene(N, seed=2)
+    model = StreetGaussians(scene, dev)
+    torch.manual_seed(3)
+    opt = DeformOptions()
+    deform = deform_network(opt).to(dev)
+    deform.deformation_net.set_aabb([120.0, 30.0, 10.0], [0.0, -30.0, -2.0])
+    for n_, p_ in deform.named_parameters():
+        if p_.dim() > 1 and "grid" not in n_:
+            p_.data.mul_(0.05)
+    emb = torch.nn.Parameter(0.1 * torch.randn(N, 4, device=dev))
+    cam = scenes.rig_camera(1, 0, H, W)
+    bg = torch.zeros(3)
+    with torch.no_grad():            # the target: the same scene with its Gaussians pushed half a metre sideways
+        model._xyz.data[:, 1] += 0.5
+        target = render(model, cam, bg, frame=0)["render"].clone()
+        model._xyz.data[:, 1] -= 0.5
+
+    def step_grads(fused):
+        opt.fused_mlp = fused
+        for p in list(deform.parameters()) + [emb]:
+            p.grad = None
+        out = render(model, cam, bg, frame=0, deformation=deform, embeddings=emb, iteration=12000, time=0.4)
+        l1_loss(out["render"], target).backward()
+        return {n: p.grad.clone() for n, p in deform.named_parameters() if p.grad is not None}, emb.grad.clone()
+    gf, ef = step_grads(True)
+    gg, eg = step_grads(False)
+    assert set(gf) == set(gg)
+    for n in gf:
+        scale = max(float(gg[n].abs().max()), 1e-12)
+        assert float((gf[n] - gg[n]).abs().max()) <= 2e-4 * scale, n
+    assert float((ef - eg).abs().max()) <= 2e-4 * max(float(eg.abs().max()), 1e-12)
+    opt.fused_mlp = True
+
+    groups = [{"params": deform.get_mlp_parameters(), "lr": 2e-3, "name": "deformation"},
+              {"params": deform.get_grid_parameters(), "lr": 2e-2, "name": "grid"}, {"params": [emb], "lr": 1e-2, "name": "embedding"}]
+    adam = Adam(groups, lr=0.0, eps=1e-15)
+    losses = []
+    for it in range(40):
+        adam.zero_grad(set_to_none=True)
+        out = render(model, cam, bg, frame=0, deformation=deform, embeddings=emb, iteration=12000 + it, time=0.4)
+        loss = l1_loss(out["render"], target)
+        loss.backward()
+        for g_ in groups:
+            for p in g_["params"]:
+                assert p.grad is None or bool(torch.isfinite(p.grad).all()), g_["name"]
+        adam.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.9 * losses[0], (losses[0], losses[-1])
