@@ -293,7 +293,7 @@ class Deformation(nn.Module):
             h = tall_linear(self.grid(pts[:, :3], time_emb[:, :1]), Wm[:, :self.grid.feat_dim], h)
         return _apply(trunk[1:], h)
 
-    def _heads(self, hidden, suffix):
+    def _heads(self, hidden, suffix, need_feat=True):
         a, W = self.args, self.W
         names = [n for n, off in (("pos_deform", a.no_dx), ("scales_deform", a.no_ds), ("rotations_deform", a.no_dr),
                                   ("opacity_deform", a.no_do), ("shs_deform", a.no_dshs)) if not off]
@@ -313,7 +313,7 @@ class Deformation(nn.Module):
                 col += width
             if out["dshs"] is not None:
                 out["dshs"] = out["dshs"].reshape(hidden.shape[0], 16, 3)
-        if a.feat_head:
+        if a.feat_head and need_feat:
             out["feat"] = _apply(self.dino_head, hidden)
         return out
 
@@ -321,7 +321,7 @@ class Deformation(nn.Module):
     _HEADS = (("pos_deform", "no_dx", "dx"), ("scales_deform", "no_ds", "ds"), ("rotations_deform", "no_dr", "dr"),
               ("opacity_deform", "no_do", "do"), ("shs_deform", "no_dshs", "dshs"))
 
-    def _level_fused(self, pts, time_emb, embeddings, coarse, it, num_down_emb):
+    def _level_fused(self, pts, time_emb, embeddings, coarse, it, num_down_emb, need_feat=True):
         """The same level as `_feature` + `_heads`, or None when the configuration is outside what the fused kernels serve (width 64,
         defor_depth 1, at most 128 HexPlane features, an embedding of at most 8 values, at most six heads): the GEMM path then runs."""
         from . import mlp
@@ -335,7 +335,8 @@ class Deformation(nn.Module):
         ka, kb = (self.grid.feat_dim if use_hex else 0), (embeddings.shape[1] if use_emb else 0)
         heads = [(getattr(self, n + suffix), key) for n, off, key in self._HEADS if not getattr(a, off)]
         branches = [(True, [(h[1].weight, h[1].bias)], (h[3].weight, h[3].bias)) for h, _ in heads]
-        if a.feat_head:
+        feat = a.feat_head and need_feat
+        if feat:
             d = self.dino_head
             branches.append((False, [(d[0].weight, d[0].bias), (d[2].weight, d[2].bias)], (d[4].weight, d[4].bias)))
         hidden_shapes = [w.shape for _, hid, _ in branches for w, _ in hid]
@@ -352,22 +353,24 @@ class Deformation(nn.Module):
         out = dict(dx=None, ds=None, dr=None, do=None, dshs=None, feat=None)
         for (_, key), o in zip(heads, outs):
             out[key] = o.reshape(o.shape[0], 16, 3) if key == "dshs" else o
-        if a.feat_head:
+        if feat:
             out["feat"] = outs[-1]
         return out
 
     def forward(self, rays_pts_emb, time_emb=None, embeddings=None, is_coarse=True, iter=None, num_down_emb_c=30, num_down_emb_f=30,
-                apply_deform=True, time_diff=1.0, is_train=False):
+                apply_deform=True, time_diff=1.0, is_train=False, need_feat=True):
+        """`need_feat=False` (not a reference argument): the caller will not read ddict["feat"], so the feature head is not evaluated
+        (its entry is None); the default evaluates it whenever `feat_head` is set, as the reference does."""
         if time_emb is None:
             raise NotImplementedError("forward_static (static_mlp) is outside the hot-path scope")
         if not apply_deform:
             return None
         n_rows = num_down_emb_c if is_coarse else num_down_emb_f
-        fused = self._level_fused(rays_pts_emb, time_emb, embeddings, is_coarse, iter, n_rows)
+        fused = self._level_fused(rays_pts_emb, time_emb, embeddings, is_coarse, iter, n_rows, need_feat)
         if fused is not None:
             return fused
         hidden = self._feature(rays_pts_emb, time_emb, embeddings, is_coarse, iter, n_rows)
-        return self._heads(hidden, "" if is_coarse else "_f")
+        return self._heads(hidden, "" if is_coarse else "_f", need_feat)
 
     def get_mlp_parameters(self):
         return [p for n, p in self.named_parameters() if "grid" not in n]
@@ -426,16 +429,16 @@ class deform_network(nn.Module):
         return point_f, scales_f, rot_f, opac_f, shs_f
 
     def forward(self, point, scales=None, rotations=None, opacity=None, shs=None, times_sel=None, embeddings=None, iter=None, cam_no=None,
-                time_diff=None, is_train=None):
+                time_diff=None, is_train=None, need_feat=True):
         net = self.deformation_net
         times_sel = net.forward_time_offset(times_sel, cam_no)
         ddict_c = net(point, times_sel, embeddings, is_coarse=True, iter=iter, num_down_emb_c=self.min_embeddings,
-                      apply_deform=not self.no_coarse_deform, time_diff=time_diff, is_train=is_train)
+                      apply_deform=not self.no_coarse_deform, time_diff=time_diff, is_train=is_train, need_feat=need_feat)
         pts = point
         if not self.no_coarse_deform and self.args.apply_coarse_dx:
             pts = point + ddict_c["dx"]
         ddict_f = net(pts, times_sel, embeddings, is_coarse=False, iter=iter, num_down_emb_f=self.min_embeddings,
-                      apply_deform=not self.no_fine_deform, time_diff=time_diff, is_train=is_train)
+                      apply_deform=not self.no_fine_deform, time_diff=time_diff, is_train=is_train, need_feat=need_feat)
         out = self.apply_deform(point, scales, rotations, opacity, shs, ddict_c, ddict_f)
         return (*out, {"coarse": ddict_c, "fine": ddict_f})
 

@@ -67,7 +67,7 @@ class StreetGaussians(torch.nn.Module):
 
 
 def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activations=True, deformation=None, embeddings=None,
-           iteration=None, time=None, options=None, record=None, render_feat=False):
+           iteration=None, time=None, options=None, record=None, render_feat=False, need_feat=True):
     """The reference render() restricted to the hot path; returns the dict the training loop consumes.
     `deformation` (an emd_amd.deformation.deform_network) switches on the "fine" stage of gaussian_renderer/__init__.py:86-96:
     the residuals of the self-supervised EMD network are added to the raw parameters before the activations.
@@ -75,7 +75,8 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
     (also returned as out["raster_call"]).
     `render_feat` (with a deformation network that has the feature head): the reference's two feature passes
     (`colors_precomp = ddict["coarse"]["feat"]` / `["fine"]["feat"]`, gaussian_renderer/__init__.py:170-201) as extra colour
-    sets of the SAME rasterizer call -> out["feat_c"], out["feat_f"]: one projection, one sort, one list walk instead of three."""
+    sets of the SAME rasterizer call -> out["feat_c"], out["feat_f"]: one projection, one sort, one list walk instead of three.
+    `need_feat=False` (with an emd_amd deform_network): nobody will read ddict[...]["feat"], so the feature head is not evaluated."""
     dev = model._xyz.device
     # the reference's zero "screen-space points" leaf that only collects dL/dmean2D: the zeros are never written, so one
     # cached buffer per model serves every step (a fresh leaf view each time, no 24 MB fill launch)
@@ -89,9 +90,11 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
     if deformation is not None:
         t = float(getattr(cam, "time", 0.0) if time is None else time)
         times_sel = torch.full((means3D.shape[0], 1), t, device=dev, dtype=torch.float32)
+        from .deformation import deform_network as _dn
+        extra_kw = {"need_feat": bool(need_feat or render_feat)} if isinstance(deformation, _dn) else {}
         means3D, scales, rotations, opacity, shs, ddict = deformation(
             means3D, scales, rotations, opacity, shs, times_sel, embeddings, iteration, int(getattr(cam, "cam_no", 0)),
-            getattr(cam, "time_diff", 0.0), True)
+            getattr(cam, "time_diff", 0.0), True, **extra_kw)
     if not fuse_activations:
         # (fused: the three activations of the reference run inside K1 / K8 (raw_params), not as ~25 separate torch launches)
         scales = torch.exp(scales)

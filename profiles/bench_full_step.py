@@ -83,7 +83,7 @@ def step(s):
         p.grad = None
     sky.sky_cube_map.grad = None
     out = render(model, cams[f], bg, frame=f, deformation=deform, embeddings=embeddings, iteration=12000 + s, time=f / (F - 1), options=OPTS[0],
-                 render_feat=FEAT and not FEAT_SEP)
+                 render_feat=FEAT and not FEAT_SEP, need_feat=FEAT)
     if FEAT and FEAT_SEP:        # the reference's three calls: main pass above + one call per feature set, same rasterizer object
         bd, dd = out["boundary"], out["ddict"]
         base = dict(means3D=bd["means3D"], means2D=out["viewspace_points"], opacities=bd["opacities"], scales=bd["scales"],
