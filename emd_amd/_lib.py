@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16
@@ -187,7 +187,8 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_temporal_embed_forward", "emd_temporal_embed_backward", "emd_deform_input_width", "emd_deform_input_forward",
                     "emd_deform_input_backward", "emd_adam_step", "emd_track_heads_forward", "emd_track_heads_backward",
                     "emd_densify_decide", "emd_densify_index", "emd_densify_split_rank", "emd_densify_gather",
-                    "emd_mlp_trunk_forward", "emd_mlp_trunk_backward", "emd_mlp_branch_forward", "emd_mlp_branch_backward")
+                    "emd_mlp_trunk_forward", "emd_mlp_trunk_backward", "emd_mlp_branch_forward", "emd_mlp_branch_backward",
+                    "emd_abs_mean_backward")
 PROF_STAGES = 8
 
 _lib = None
@@ -249,6 +250,7 @@ def load():
     lib.emd_densify_index.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_densify_split_rank.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.emd_densify_gather.argtypes = [C.POINTER(EmdDensifyGather), C.c_void_p]
+    lib.emd_abs_mean_backward.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_mlp_trunk_forward.argtypes = [C.POINTER(EmdMlpTrunk), C.c_void_p]
     lib.emd_mlp_trunk_backward.argtypes = [C.POINTER(EmdMlpTrunk), C.POINTER(EmdMlpTrunkGrads), C.c_void_p]
     lib.emd_mlp_branch_forward.argtypes = [C.POINTER(EmdMlpBranch), C.c_void_p]

@@ -92,6 +92,7 @@ int emd_zero_async(void* p, size_t bytes, hipStream_t st) {
     return EMD_OK;
 }
 
+int emd_launch_abs_mean_backward(size_t n, const float* x, const float* g, float* out, hipStream_t st);
 int emd_launch_motion_forward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
                               float* wm, float* wq, float* wo, hipStream_t st);
 int emd_launch_motion_backward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
@@ -418,8 +419,15 @@ int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* d
 }
 
 int emd_l1_loss(int64_t n, const float* a, const float* b, float* loss, float* grad, void* hip_stream) {
-    if (n < 0 || !loss || (n > 0 && (!a || !b))) { emd_set_error("l1_loss: bad argument"); return EMD_ERR_INVALID; }
+    if (n < 0 || !loss || (n > 0 && !a)) { emd_set_error("l1_loss: bad argument"); return EMD_ERR_INVALID; }
+    if (((uintptr_t)a & 15) || ((uintptr_t)b & 15) || ((uintptr_t)grad & 15)) { emd_set_error("l1_loss: a, b, grad must be 16-byte aligned"); return EMD_ERR_INVALID; }
     return emd_launch_l1_loss((size_t)n, a, b, loss, grad, (hipStream_t)hip_stream);
+}
+
+int emd_abs_mean_backward(int64_t n, const float* x, const float* g, float* grad, void* hip_stream) {
+    if (n < 0 || (n > 0 && (!x || !g || !grad))) { emd_set_error("abs_mean_backward: bad argument"); return EMD_ERR_INVALID; }
+    if (((uintptr_t)x & 15) || ((uintptr_t)grad & 15)) { emd_set_error("abs_mean_backward: x, grad must be 16-byte aligned"); return EMD_ERR_INVALID; }
+    return emd_launch_abs_mean_backward((size_t)n, x, g, grad, (hipStream_t)hip_stream);
 }
 
 int emd_activations_forward(int32_t n, const float* log_scales, float* scales, const float* raw_quats, float* quats,

@@ -1012,7 +1012,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_l1_loss(size_t n, const float* __
     float acc = 0.f;
     const size_t n4 = n / 4, stride = (size_t)gridDim.x * EMD_BLOCK;
     for (size_t i = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; i < n4; i += stride) {
-        const float4 x = ((const float4*)a)[i], y = ((const float4*)b)[i];
+        const float4 x = ((const float4*)a)[i], y = b ? ((const float4*)b)[i] : make_float4(0.f, 0.f, 0.f, 0.f);   // b == NULL: mean |a|
         const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
         acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
         if (grad) {
@@ -1021,7 +1021,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_l1_loss(size_t n, const float* __
         }
     }
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; i < n; i += stride) {
-        const float d = a[i] - b[i];
+        const float d = a[i] - (b ? b[i] : 0.f);
         acc += fabsf(d);
         if (grad) grad[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
     }
@@ -1031,7 +1031,30 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_l1_loss(size_t n, const float* __
     if (threadIdx.x == 0) atomicAdd(loss, ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) * inv_n);
 }
 
+// gradient of w * mean |x| with the upstream gradient g on the DEVICE: out[i] = sign(x[i]) * g[0] / n -- one pass, no host read of g
+__global__ void __launch_bounds__(EMD_BLOCK) k_abs_mean_backward(size_t n, const float* __restrict__ x, const float* __restrict__ g, float inv_n,
+                                                                 float* __restrict__ out) {
+    const float s = g[0] * inv_n;
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * EMD_BLOCK;
+    auto sg = [s](float d) { return d > 0.f ? s : (d < 0.f ? -s : 0.f); };
+    for (size_t i = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; i < n4; i += stride) {
+        const float4 v = ((const float4*)x)[i];
+        ((float4*)out)[i] = make_float4(sg(v.x), sg(v.y), sg(v.z), sg(v.w));
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; i < n; i += stride) out[i] = sg(x[i]);
+}
+
 }  // namespace
+
+int emd_launch_abs_mean_backward(size_t n, const float* x, const float* g, float* out, hipStream_t st) {
+    if (n == 0) return EMD_OK;
+    size_t blocks = (n / 4 + EMD_BLOCK - 1) / EMD_BLOCK;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_abs_mean_backward, dim3((unsigned)blocks), dim3(EMD_BLOCK), 0, st, n, x, g, 1.f / (float)n, out);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
 
 int emd_launch_preprocess(const PreArgs& a, hipStream_t st) {
     if (a.N <= 0) return EMD_OK;

@@ -172,6 +172,40 @@ class _L1Loss(torch.autograd.Function):
         return grad * g, None
 
 
+class _AbsMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        import ctypes as C
+        from . import _lib as L
+        if x.device.type != "cuda":
+            raise L.EmdError("abs_mean needs a tensor on a ROCm device; there is no CPU path")
+        xc = x.detach().contiguous().float()
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+        L.check(L.load().emd_l1_loss(xc.numel(), xc.data_ptr(), None, out.data_ptr(), None,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_l1_loss")
+        ctx.save_for_backward(xc)
+        ctx.shape = x.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        from . import _lib as L
+        (xc,) = ctx.saved_tensors
+        grad = torch.empty_like(xc)
+        gc = g.detach().reshape(1).float().contiguous()
+        L.check(L.load().emd_abs_mean_backward(xc.numel(), xc.data_ptr(), gc.data_ptr(), grad.data_ptr(),
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_abs_mean_backward")
+        return grad.view(ctx.shape)
+
+
+def abs_mean(x):
+    """mean |x| -- the residual regularisers of the fine stage, `torch.mean(torch.abs(ddict[level][key]))` of S3Gaussian/train.py:
+    242-310 -- in one launch forward (no |x| tensor) and one backward (sign(x) g / n with the upstream gradient read on the device)
+    instead of abs / mean / sign / mul / expand launches over tensors of up to 48 floats per Gaussian."""
+    return _AbsMean.apply(x)
+
+
 def l1_loss(network_output, gt):
     """mean |network_output - gt| (S3Gaussian/utils/loss_utils.py:21-22) and its gradient in one HIP launch."""
     return _L1Loss.apply(network_output.float(), gt.float())

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 16
+#define EMD_ABI_VERSION 17
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -315,8 +315,11 @@ int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* d
                             const int32_t* frame_dev, void* hip_stream);
 
 /* L1 photometric loss of the training step (S3Gaussian/utils/loss_utils.py:21-22, train.py:226):
- * loss[0] = mean |a - b| over n elements, grad[i] = sign(a[i] - b[i]) / n (grad may be NULL).  One launch. */
+ * loss[0] = mean |a - b| over n elements, grad[i] = sign(a[i] - b[i]) / n (grad may be NULL).  One launch.
+ * b == NULL: loss[0] = mean |a| -- the residual regularisers of the fine stage (the L1 norms of dx / do / dshs, S3Gaussian/train.py);
+ * emd_abs_mean_backward writes their gradient sign(x[i]) * g[0] / n with the upstream gradient g read on the device. */
 int emd_l1_loss(int64_t n, const float* a, const float* b, float* loss /*[1]*/, float* grad /*[n] or NULL*/, void* hip_stream);
+int emd_abs_mean_backward(int64_t n, const float* x, const float* g /*[1], device*/, float* grad /*[n]*/, void* hip_stream);
 
 /* The activations exactly as EMD_FLAG_RAW_PARAMS applies them (exp, F.normalize, sigmoid); any pair may be NULL. */
 int emd_activations_forward(int32_t n, const float* log_scales, float* scales, const float* raw_quats, float* quats,

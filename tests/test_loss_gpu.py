@@ -101,3 +101,20 @@ def test_sky_term_skipped_without_sky_pixels(lam_dssim):
     tot1.backward()
     np.testing.assert_allclose(t1["sky"].item(), t0["sky"].item(), rtol=1e-5)
     _close_grad(w1.grad, w0.grad.numpy(), "weight")
+
+
+def test_abs_mean_regulariser_matches_torch():
+    """mean |x| (the L1 residual regularisers of S3Gaussian/train.py:242-310) and its gradient under a non-trivial upstream gradient,
+    odd sizes included."""
+    import torch
+    from emd_amd.model import abs_mean
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(4)
+    for shape in ((1000, 16, 3), (777, 3), (5,), (4096, 1)):
+        x = torch.randn(*shape, generator=g)
+        x.view(-1)[::7] = 0.0                                       # sign(0) = 0
+        a, b = x.clone().to(dev).requires_grad_(True), x.clone().double().requires_grad_(True)
+        la, lb = 0.37 * abs_mean(a) + 1.0, 0.37 * b.abs().mean() + 1.0
+        la.backward(); lb.backward()
+        assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb))
+        assert float((a.grad.double().cpu() - b.grad).abs().max()) <= 1e-6 * float(b.grad.abs().max())
