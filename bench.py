@@ -35,12 +35,12 @@ PMC_STAGE_KERNELS = {"preprocess": ("k_preprocess",), "scan_duplicate": ("k_sort
                      "render_backward": ("k_render_backward_q",), "preprocess_backward": ("k_preprocess_backward",)}
 
 
-PMC_TRAFFIC_CSV = "r02_pmc_hbm_traffic.csv"
-PMC_VALU_CSV = "r02_pmc_valu.csv"
+PMC_TRAFFIC_CSV = "r03_pmc_hbm_traffic.csv"
+PMC_VALU_CSV = "r03_pmc_valu.csv"
 
 
 def _pmc_path(name):
-    for cand in (name, name.replace("r02_", "r01_")):
+    for cand in (name, name.replace("r03_", "r02_"), name.replace("r03_", "r01_")):
         path = os.path.join(ROOT, "profiles", cand)
         if os.path.exists(path):
             return path
@@ -134,6 +134,7 @@ def cpu_baseline(scene, cam, frame=0, budget_s=15.0):
     means, scales, rots, shs = scene.means, torch.exp(scene.log_scales), scene.quats, scene.shs
     V, Pm, cp = cam.world_view_transform, cam.full_proj_transform, cam.camera_center
     has_actors = scene.actor_id is not None
+    n_actors = int(scene.actor_quats.shape[1]) if has_actors else 0
     pose = build_actor_pose(scene.actor_quats, scene.actor_trans, scene.actor_valid, frame) if has_actors else None
 
     def one():
@@ -144,7 +145,7 @@ def cpu_baseline(scene, cam, frame=0, budget_s=15.0):
 
     times = []
     with torch.no_grad():
-        for _ in range(2):   # warm-up (thread pool, allocator)
+        for _ in range(3):   # warm-ups (thread pool, allocator), BASELINE.md section 2
             t0 = time.perf_counter()
             one()
             first = time.perf_counter() - t0
@@ -157,9 +158,34 @@ def cpu_baseline(scene, cam, frame=0, budget_s=15.0):
     med = times[len(times) // 2]
     return {"value": 1.0 / med, "unit": "iters/s (rigid transform + projection + cov3D + SH forward stage only)", "cores": cores,
             "cores_available": avail, "kind": "port", "ms_per_call": med * 1e3, "gaussians_per_s": scene.N / med,
-            "sample": f"reference pure-PyTorch per-actor rigid transform ({'32 actors' if has_actors else 'none'}) + geom_transform_points + "
-                      f"get_covariance + eval_sh(deg 3) forward, N={scene.N}, fp32, median of {len(times)} calls after 2 warm-ups, "
+            "sample": f"reference pure-PyTorch per-actor rigid transform ({str(n_actors) + ' actors' if has_actors else 'none'}) + geom_transform_points + "
+                      f"get_covariance + eval_sh(deg 3) forward, N={scene.N}, fp32, median of {len(times)} calls after 3 warm-ups, "
                       f"{cores} torch threads of {avail} hardware threads"}
+
+
+CONFIGS = {
+    0: dict(name="BASELINE configs[0]: 10k static Gaussians, 256x256, projection + SH forward (plumbing)", gaussians=10_000, height=256, width=256,
+            focal=272.0, actors=0, forward_only=True),
+    1: dict(name="BASELINE configs[1]: single static frame, 1M Gaussians, 1066x1600, fwd+bwd", gaussians=1_000_000, height=1066, width=1600,
+            focal=1700.0, actors=0, forward_only=False),
+    2: dict(name="BASELINE configs[2]: 50-frame dynamic clip, per-actor rigid motion on 2M Gaussians", gaussians=2_000_000, height=1066,
+            width=1600, focal=1700.0, actors=32, forward_only=False),
+}
+
+
+def select_step_inputs(sel, table, out_row, frames=None, frame_out=None, t_out=None, num_frames=1, k_sched=None, k_fine_out=None,
+                       status=None, status_log=None, prev_sel=None):
+    """emd_select_step_inputs: everything a replayed step reads at fixed device addresses, written by ONE launch."""
+    import ctypes as C
+    from emd_amd import _lib as L
+    a = L.EmdStepSelect()
+    a.sel, a.rows, a.row_floats = sel.data_ptr(), table.shape[0], table.shape[1]
+    a.table, a.out_row = table.data_ptr(), out_row.data_ptr()
+    a.frames, a.frame_out, a.t_out, a.num_frames = L.ptr(frames), L.ptr(frame_out), L.ptr(t_out), int(num_frames)
+    a.k_min, a.k_max, a.k_until = k_sched if k_sched is not None else (1, 1, 1)
+    a.steps, a.k_fine_out = None, L.ptr(k_fine_out)
+    a.status, a.status_log, a.prev_sel = L.ptr(status), L.ptr(status_log), L.ptr(prev_sel)
+    L.check(L.load().emd_select_step_inputs(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_select_step_inputs")
 
 
 def main():
@@ -167,9 +193,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--gaussians", type=int, default=2_000_000)
-    ap.add_argument("--height", type=int, default=1066)
-    ap.add_argument("--width", type=int, default=1600)
+    ap.add_argument("--config", type=int, default=2, choices=(0, 1, 2),
+                    help="BASELINE.json configs[k]: 0 = 10k static 256x256 (K1 forward next to the CPU leg), 1 = 1M static fwd+bwd, 2 = the headline (default)")
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--repeats", type=int, default=5, help="extra back-to-back repeats of the timed block after it (min / median / max reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-count", action="store_true", help="read the duplicate count back every forward (reference behaviour)")
     ap.add_argument("--no-normal", action="store_true", help="skip the normal image (unused by the training loss)")
@@ -177,11 +206,22 @@ def main():
     ap.add_argument("--no-track-heads", action="store_true", help="leave the learned per-actor track offsets out of the step")
     ap.add_argument("--densify-stats", action="store_true", help="also accumulate the per-view densification statistics every step (one launch)")
     ap.add_argument("--eager", action="store_true", help="issue every step from Python instead of replaying it from a hipGraph (1 GPU)")
+    ap.add_argument("--exchange-only", action="store_true",
+                    help="time ONLY the gradient exchange of a view-parallel step (GradientExchange.start + finish on a fixed backward's outputs): "
+                         "separates communication from compute in the 2/4/8-GPU runs")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.gaussians is None:
+        args.gaussians = cfg["gaussians"]
+    if args.height is None:
+        args.height = cfg["height"]
+    if args.width is None:
+        args.width = cfg["width"]
 
     from emd_amd import dp, scenes, _lib
     from emd_amd import RasterCall, RasterOptions
     from emd_amd.model import StreetGaussians, render, l1_loss
+    from emd_amd.motion import DeviceStep
 
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("EMD_BENCH_SHARE_GPU"):        # functional test of the N > 1 path on a 1-GPU box (with EMD_DP_BACKEND=gloo)
@@ -192,17 +232,19 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     N, H, W = args.gaussians, args.height, args.width
-    num_frames, num_actors = 50, 32
+    num_frames, num_actors = 50, cfg["actors"]
+    focal = cfg["focal"] * (W / cfg["width"])
     num_cams = dp.rig_size(world)             # 1 / 2 / 4 cameras on 1 / 2 / 4 GPUs (rank <-> camera of one timestamp), 6 on 8 GPUs
-    scene = scenes.add_actors(scenes.make_static_scene(N, seed=0), num_actors=num_actors, pts_per_actor=5000,
-                              num_frames=num_frames, seed=1)
-    model = StreetGaussians(scene, dev, track_heads=not args.no_track_heads)
+    scene = scenes.make_static_scene(N, seed=0)
+    if num_actors:
+        scene = scenes.add_actors(scene, num_actors=num_actors, pts_per_actor=5000, num_frames=num_frames, seed=1)
+    model = StreetGaussians(scene, dev, track_heads=bool(num_actors) and not args.no_track_heads)
     params = [p for p in model.parameters()]
     bg = torch.zeros(3)
     g3 = torch.Generator().manual_seed(3)
     target = torch.rand(3, H, W, generator=g3).to(dev)
 
-    factored = world > 1 or args.factored_sh
+    factored = world > 1 or args.factored_sh or args.exchange_only
     # options of THIS run's rasterizer calls (an instance, handed to every call: nothing process-wide is written)
     opts = RasterOptions(compute_normal=not args.no_normal, factored_sh_grad=factored, no_sync=not args.sync_count)
     cams, campos_dev = {}, {}
@@ -212,25 +254,30 @@ def main():
 
     def cam_for(step):
         # views are ordered timestamp-major and dealt out by dp.view_for: every rank renders a DISTINCT (frame, camera);
-        # with 8 ranks on the 6-camera rig two ranks hold cameras of the next timestamp (dp.frame_and_camera)
+        # with 8 ranks on the 6-camera rig two ranks hold cameras of the next timestamp (dp.frame_and_camera).
+        # Static configurations (0, 1) render one frame: "single static frame".
         f, c = dp.frame_and_camera(step, rank, world, num_frames, num_cams)
+        if not num_actors:
+            f = 0
         if (f, c) not in cams:
-            cams[(f, c)] = scenes.rig_camera(f, c, H, W)
+            cams[(f, c)] = scenes.rig_camera(f, c, H, W, fx=focal, fy=focal)
             campos_dev[(f, c)] = cams[(f, c)].camera_center.to(dev)      # once per camera: no per-step host-to-device copy
         return f, c, cams[(f, c)]
 
-    def one_step(step, options=opts):
+    def one_step(step, options=opts, record=None, backward=True):
         f, c, cam = cam_for(step)
         for p in params:
             p.grad = None
-        rec = RasterCall()
+        rec = record if record is not None else RasterCall()
         xchg = None
-        if options.factored_sh_grad:
+        if options.factored_sh_grad and backward:
             # SH gradient (81 % of the gradient bytes): rank-one factors, 12 B per Gaussian and rank instead of all-reducing
             # 192 B per Gaussian; the collectives are issued from inside backward(), right behind K8 (emd_amd/dp.py)
             xchg = dp.GradientExchange(campos_dev[(f, c)], actor_ids=model.actor_id if model.has_actors else None)
             rec.on_backward = xchg.start
         out = render(model, cam, bg, frame=f, iteration=step, options=options, record=rec)
+        if not backward:
+            return out
         if xchg is not None:
             xchg.actor_pose = None if out["actor_pose"] is None else out["actor_pose"].detach()   # (no reference into the autograd graph)
         loss = l1_loss(out["render"], target)
@@ -247,11 +294,12 @@ def main():
     # Size the binning workspace once, with synchronising forwards over the clip (the duplicate count D moves with
     # the ego pose and the actors); afterwards the async path never reads D back.  Overflow of any timed step is
     # checked after the timed region from the per-step device status words.
+    total_steps = args.warmup + args.steps * (1 + max(args.repeats, 0))
     for s_ in range(args.warmup + args.steps):          # the cameras are dataset state: built (and their centres uploaded) before timing
         cam_for(s_)
     from emd_amd import rasterizer as _rz
     sync_opts = opts.replace(no_sync=False)
-    out = one_step(0, sync_opts)
+    out = one_step(0, sync_opts, backward=not cfg["forward_only"])
     dmax = out["raster_call"].last_status()["num_rendered"]
     with torch.no_grad():
         for s_ in sorted(set(list(range(0, args.warmup + args.steps, 7)) + [args.warmup + args.steps - 1])):
@@ -259,41 +307,57 @@ def main():
             o = render(model, cam, bg, frame=f, options=sync_opts)
             dmax = max(dmax, o["raster_call"].last_status()["num_rendered"])
     _rz._capacity_hint[(dev.index, H, W)] = int(dmax * 1.3) + 1024
-    # ---- the step as a hipGraph: the ~45 launches of a step are captured once and replayed; everything that changes from
-    # step to step (camera matrices, frame index, frame time) lives in device buffers selected by ONE device index `sel`, rewritten
-    # before every replay.  The host then spends ~20 us per step instead of ~1-2 ms of Python + launch calls, i.e. the run is
-    # GPU-bound whatever the host is doing.  (--eager, or a failed capture, issues the same step from Python.)
-    total_steps = args.warmup + args.steps
+
+    if cfg["forward_only"]:
+        return bench_forward_only(args, cfg, scene, model, render, cam_for, bg, opts, _lib, N, H, W, rank)
+    if args.exchange_only:
+        return bench_exchange_only(args, dp, model, params, one_step, cam_for, campos_dev, N, rank, world, dev)
+
+    # ---- the step as a hipGraph: the launches of a step are captured once and replayed; everything that changes from
+    # step to step (camera block, frame index, frame time, coarse-to-fine level of the step) lives at fixed device addresses that
+    # ONE launch (emd_select_step_inputs) fills from device-resident tables for the row `sel` names.  The host then spends
+    # ~20 us per step instead of ~1-2 ms of Python + launch calls, i.e. the run is GPU-bound whatever the host is doing.
+    # (--eager, or a failed capture, issues the same step from Python.)
+    period = args.warmup + args.steps             # the repeats replay the timed views: row = warmup + (step - warmup) mod steps
     graph = None
     out = o = None          # no autograd graph of an eager step may be alive at capture time (its AccumulateGrad nodes are bound to the eager stream)
     import gc
     gc.collect()            # ... including graphs held only by reference cycles (RasterCall <-> GradientExchange)
-    status_log = torch.zeros(max(total_steps, 1), 4, dtype=torch.int32, device=dev)
+    status_log = torch.zeros(max(period, 1), 4, dtype=torch.int32, device=dev)
     gstate = {}
     if not args.eager and opts.no_sync:
         try:
             import types
-            views = [cam_for(s_) for s_ in range(total_steps)]
+            views = [cam_for(s_) for s_ in range(period)]
             blocks = torch.stack([torch.cat([bg.reshape(-1).float(), c_.world_view_transform.reshape(-1), c_.full_proj_transform.reshape(-1),
-                                             c_.camera_center.reshape(-1)]) for _, _, c_ in views]).to(dev)            # [steps, 38]
+                                             c_.camera_center.reshape(-1)]) for _, _, c_ in views]).to(dev).contiguous()            # [rows, 38]
             frame_of = torch.tensor([f_ for f_, _, _ in views], dtype=torch.int32, device=dev)
             sel = torch.zeros(1, dtype=torch.int64, device=dev)
+            prev_sel = torch.full((1,), -1, dtype=torch.int64, device=dev)
+            blk = torch.zeros(38, device=dev)
+            frame_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            t_dev = torch.zeros(1, device=dev)
+            kf_dev = torch.ones(1, dtype=torch.int32, device=dev)
+            status_static = torch.zeros(4, dtype=torch.int32, device=dev)          # the captured call's status words are copied here (graph-static address)
             cam0 = views[0][2]
+            th = model.track_heads
+            k_sched = (th.min_embeddings, th.max_embeddings, th.c2f_temporal_iter) if th is not None else None
 
             def graph_body():
                 for p in params:
                     p.grad = None
-                blk = blocks.index_select(0, sel)[0]
-                frame_dev = frame_of.index_select(0, sel)
+                # (the row index doubles as the training step of the coarse-to-fine schedule, as the eager step passes it)
+                select_step_inputs(sel, blocks, blk, frame_of, frame_dev, t_dev, num_frames, k_sched, kf_dev if th is not None else None,
+                                   status_static, status_log, prev_sel)
                 cam_g = types.SimpleNamespace(image_height=H, image_width=W, tanfovx=cam0.tanfovx, tanfovy=cam0.tanfovy,
                                               world_view_transform=blk[3:19].view(4, 4), full_proj_transform=blk[19:35].view(4, 4),
                                               camera_center=blk[35:38])
                 rec_g = RasterCall()
-                o = render(model, cam_g, blk[0:3], frame=frame_dev, iteration=0, options=opts, record=rec_g)
+                o = render(model, cam_g, blk[0:3], frame=frame_dev, iteration=DeviceStep(k_fine=kf_dev, t=t_dev), options=opts, record=rec_g)
                 l1_loss(o["render"], target).backward()
                 if stats is not None:
                     dp.add_densification_stats(o["viewspace_points"].grad, o["radii"], *stats)
-                status_log.index_copy_(0, sel, o["raster_call"].status.view(1, 4))
+                status_static.copy_(o["raster_call"].status)
                 # what the gradient exchange of a multi-GPU step reads after the replay: graph-static tensors
                 gstate["rec"], gstate["campos"] = rec_g, blk[35:38]
                 gstate["pose"] = None if o["actor_pose"] is None else o["actor_pose"].detach()
@@ -305,6 +369,7 @@ def main():
                     graph_body()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            prev_sel.fill_(-1)
             graph = torch.cuda.CUDAGraph()
             # (multi-rank: the process group's watchdog thread polls events while we capture; "thread_local" keeps its calls from
             #  invalidating the capture -- nothing of the exchange is captured)
@@ -315,39 +380,59 @@ def main():
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
 
+    def row_of(step):
+        return step if step < period else args.warmup + (step - args.warmup) % args.steps
+
     def timed_step(step):
         if graph is not None:
-            sel.fill_(step)
+            sel.fill_(row_of(step))
             graph.replay()
             if opts.factored_sh_grad:
                 # the exchange is issued behind the replay (RCCL collectives are not captured): what follows K8 inside the graph is
-                # ~20 us of pose / track-head backward, so nothing is lost against starting it from inside backward()
+                # one ~8 us launch of the actor chain's backward, so nothing is lost against starting it from inside backward()
                 xchg = dp.GradientExchange(gstate["campos"], actor_ids=model.actor_id if model.has_actors else None, actor_pose=gstate["pose"])
                 xchg.start(gstate["rec"])
                 xchg.finish(model._features, model._xyz, model.active_sh_degree, other_params=params)
             elif world > 1:
                 dp.allreduce_gradients(params)
         else:
-            o = one_step(step)
-            status_log[step].copy_(o["raster_call"].status)
+            o = one_step(row_of(step))
+            status_log[row_of(step)].copy_(o["raster_call"].status)
+
+    def timed_block(first, count):
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(count):
+            timed_step(first + s)
+        t_enq = time.perf_counter() - t0      # host time to enqueue the steps (the GPU runs behind it)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        return time.perf_counter() - t0, t_enq
 
     for s in range(args.warmup):
         timed_step(s)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
     if graph is None:
+        torch.cuda.synchronize()
         _lib.profile_enable(True)
         _lib.profile_read()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        timed_step(args.warmup + s)
-    t_enqueue = time.perf_counter() - t0      # host time to enqueue the K steps (the GPU runs behind it)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
+    dt, t_enqueue = timed_block(args.warmup, args.steps)
+    prof_timed = None
+    if graph is None:
+        prof_timed = _lib.profile_read()
+        _lib.profile_enable(False)
+    # ---- the same block again, `repeats` times back to back: spread of the measurement (`value` stays the first block)
+    rep = []
+    for r in range(max(args.repeats, 0)):
+        d_r, _ = timed_block(args.warmup + args.steps * (1 + r), args.steps)
+        rep.append(d_r / args.steps * 1e3)
+    if graph is not None:       # flush the status row of the last replay
+        sel.fill_(-1)
+        select_step_inputs(sel, blocks, blk, status=status_static, status_log=status_log, prev_sel=prev_sel)
+        torch.cuda.synchronize()
     stage_region = "the timed region"
     if graph is not None:
         # Per-stage HIP events are recorded by host code, which does not run when a graph is replayed: the stage durations of the
@@ -360,21 +445,37 @@ def main():
         torch.cuda.synchronize()
         stage_region = f"{n_prof} eager repetitions of the timed steps, run right after the timed region (graph replays execute no host-side event records)"
         prof_steps = n_prof
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
     else:
-        prof_steps = args.steps
-    prof = _lib.profile_read()
-    _lib.profile_enable(False)
+        prof_steps, prof = args.steps, prof_timed
+    # ---- pair statistics of the render backward (diagnostic instantiation of K7, a few of the timed views): evaluated vs contributing
+    pairs = None
+    if world == 1:
+        ps = torch.zeros(2, dtype=torch.int64, device=dev)
+        n_ps = min(args.steps, 5)
+        for s in range(n_ps):
+            rec_p = RasterCall()
+            rec_p.pair_stats = ps
+            one_step(args.warmup + s * max(args.steps // n_ps, 1), record=rec_p)
+        ev, hit = [int(x) for x in ps.cpu().tolist()]
+        pairs = {"evaluated_per_launch": ev / n_ps, "contributing_per_launch": hit / n_ps, "useful_fraction": round(hit / max(ev, 1), 4),
+                 "launches": n_ps, "note": "(pixel, list entry) pairs the lanes of k_render_backward_q evaluate / pairs with alpha >= 1/255 in front "
+                                           "of the pixel's last contributor; counting instantiation of the kernel (EmdBwdArgs.pair_stats), outside the timed region"}
     if graph is not None:          # release the captured graph and its memory pool explicitly, in a quiet state
         torch.cuda.synchronize()
         graph.reset()
         graph = "released"
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt] + [r_ * args.steps / 1e3 for r_ in rep], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+        vals = tmax.tolist()
+        dt, rep = float(vals[0]), [v / args.steps * 1e3 for v in vals[1:]]
     st_all = status_log[args.warmup:args.warmup + args.steps].cpu().numpy().astype("int64") & 0xFFFFFFFF
-    overflow = int(st_all[:, 1].sum())
+    overflow = int((st_all[:, 1] & 1).sum())
     assert overflow == 0, "binning workspace overflowed during the timed region"
+    assert int((st_all[:, 1] & 2).sum()) == 0, ("a timed step saw a visible Gaussian beyond 65 536 x the near plane with the three-pass depth sort: "
+                                                 "its image was blank (use RasterOptions(wide_depth_sort=True))")
 
     if rank == 0:
         # V and D of EVERY timed step (device status words of rank 0's views), not of one frame
@@ -393,7 +494,7 @@ def main():
         dom = max(stages, key=lambda k: stages[k]["ms"])
         kernel_ms = sum(v["ms"] for v in stages.values())
         total_alg = sum(ab.values())
-        full = (N, H, W) == (2_000_000, 1066, 1600)
+        full = (N, H, W, args.config) == (2_000_000, 1066, 1600, 2)
         traffic = pmc_traffic(dom, passes) if full else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 4),
@@ -402,6 +503,7 @@ def main():
                                        "note": "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the same command, bytes per launch; a committed file constant, not measured in this run"},
                     "secondary_bound": "fp32 vector issue rate: the render kernels are issue-bound (DESIGN.md section 6)",
                     "issue": issue_bound(dom, stages[dom]["ms"]) if full else None,
+                    "pairs": pairs,
                     "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": stages[dom]["ms"],
                     "stage_durations_measured_over": stage_region,
                     "per_step": {"steps": int(len(Ds)), "D_min": int(Ds.min()), "D_mean": round(D, 1), "D_max": int(Ds.max()),
@@ -412,28 +514,34 @@ def main():
                                    "frac": round(total_alg / 1e9 / (kernel_ms * 1e-3) / HBM_PEAK_GBS, 4)},
                     "stages": stages}
         if world == 1:
-            mapping = "1 GPU: camera 0 of frame (step mod 50)"
+            mapping = "1 GPU: camera 0 of frame (step mod 50)" if num_actors else "1 GPU: camera 0 of frame 0 (static scene)"
         elif world == num_cams:
             mapping = f"{world} GPUs: rank r <-> camera r of the {num_cams}-camera rig, all ranks of a step share one timestamp"
         else:
             mapping = (f"{world} GPUs on the {num_cams}-camera rig: view (step * {world} + rank) of the timestamp-major view list, i.e. "
                        f"{world - num_cams} rank(s) per step render cameras of the NEXT timestamp; every rank renders a distinct view")
+        heads_on = model.track_heads is not None
+        rep_sorted = sorted(rep)
         res = {
             "metric": "train iters/s (fwd+bwd) @1066x1600, 2M Gaussians; 1/2/4/8 GPU",
             "value": world * args.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "repeats_ms_per_step": None if not rep else {"n": len(rep), "min": round(rep_sorted[0], 4), "median": round(rep_sorted[len(rep) // 2], 4),
+                                                        "max": round(rep_sorted[-1], 4),
+                                                        "note": "the timed block replayed again back to back after it; `value` is the first block only"},
             "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 50-frame dynamic clip, per-actor rigid motion on 2M Gaussians "
-                                   "(32 actors x 5000" + ("" if args.no_track_heads else ", learned per-actor track offsets") + "), SH degree 3, "
-                                   "one 1066x1600 view per GPU per step, L1 loss, fwd+bwd to all 59 floats/Gaussian + actor poses"
-                                   + ("" if args.no_track_heads else " + track heads"),
+            "config": {"workload": cfg["name"] + (f" ({num_actors} actors x 5000" + (", learned per-actor track offsets" if heads_on else "") + ")" if num_actors else "")
+                                   + ", SH degree 3, one view per GPU per step, L1 loss, fwd+bwd to all 59 floats/Gaussian"
+                                   + (" + actor poses" if num_actors else "") + (" + track heads" if heads_on else ""),
+                       "baseline_config_index": args.config,
                        "gaussians": N, "height": H, "width": W, "visible_V": round(V, 1), "duplicates_D": round(D, 1), "tiles_T": T,
                        "radix_passes_depth": "3 x 9 bits above the near plane: first over the N keys (compacting to V), two over the V pairs",
                        "radix_passes_tile_on_D": passes, "blended_channels_C": C, "views_per_step": world,
-                       "rig_cameras": num_cams, "rank_view_mapping": mapping, "track_heads": not args.no_track_heads,
+                       "rig_cameras": num_cams, "rank_view_mapping": mapping, "track_heads": heads_on,
                        "densification_stats_in_step": bool(args.densify_stats),
-                       "step_issue": ("hipGraph replay (one capture, device-resident per-step inputs" + ("; the gradient exchange is issued behind each replay)" if world > 1 else ")"))
+                       "step_issue": ("hipGraph replay (one capture; camera block, frame, frame time and coarse-to-fine level selected on the device by one launch"
+                                      + ("; the gradient exchange is issued behind each replay)" if world > 1 else ")"))
                                      if graph is not None else "eager (Python issues every launch)",
                        "parallelism": f"view-parallel dp{world}", "count_readback": bool(args.sync_count),
                        "gradient_exchange": ("none (1 GPU)" if world == 1 else
@@ -447,6 +555,92 @@ def main():
             res["cpu_baseline"] = cpu_baseline(scene, cam0, frame=f0)
         print(json.dumps(res), flush=True)
     if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def bench_forward_only(args, cfg, scene, model, render, cam_for, bg, opts, _lib, N, H, W, rank):
+    """BASELINE configs[0]: the projection + SH forward (K1) next to the reference's pure-PyTorch CPU path at the same N
+    (BASELINE.md section 2, row 1).  `value` is the K1 kernel time; the whole forward (binning + compositing) is reported beside it."""
+    with torch.no_grad():
+        for s in range(args.warmup):
+            f, c, cam = cam_for(0)
+            render(model, cam, bg, frame=f, options=opts)
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
+        _lib.profile_read()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            f, c, cam = cam_for(0)
+            o = render(model, cam, bg, frame=f, options=opts)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    st = o["raster_call"].last_status()
+    V, D = st["num_visible"], st["num_rendered"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    C = 7 if opts.compute_normal else 4
+    ab = algorithmic_bytes(N, V, D, H * W, T, C, 1)
+    k1_ms = prof["preprocess"][0] / args.steps
+    fwd_ms = sum(ms for name, (ms, cnt) in prof.items() if cnt) / args.steps
+    if rank == 0:
+        res = {"metric": "projection + covariance + SH colour forward (K1) ms @256x256, 10k static Gaussians", "value": k1_ms, "unit": "ms",
+               "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": False,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": cfg["name"], "baseline_config_index": 0, "gaussians": N, "height": H, "width": W, "visible_V": V,
+                          "duplicates_D": D, "tiles_T": T, "whole_forward_kernel_ms": round(fwd_ms, 4),
+                          "note": "launch-latency bound at this size: ms_per_step is the host-issued forward (Python + ~25 launches)"},
+               "roofline": {"bound": "hbm", "kernel": "preprocess", "achieved": round(ab["preprocess"] / 1e9 / (k1_ms * 1e-3), 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(ab["preprocess"] / 1e9 / (k1_ms * 1e-3) / HBM_PEAK_GBS, 5), "traffic": None,
+                            "algorithmic_bytes_per_launch": ab["preprocess"], "avg_launch_ms": round(k1_ms, 5)}}
+        if not args.no_cpu_baseline:
+            f0, _, cam0 = cam_for(0)
+            res["cpu_baseline"] = cpu_baseline(scene, cam0, frame=f0)
+        print(json.dumps(res), flush=True)
+
+
+def bench_exchange_only(args, dp, model, params, one_step, cam_for, campos_dev, N, rank, world, dev):
+    """Only the gradient exchange of a view-parallel step: one backward produces the factors / slab, then GradientExchange.start +
+    finish are timed `steps` times on those buffers (on 1 GPU with a process group: the collectives run at world size 1)."""
+    from emd_amd import RasterCall
+    rec = RasterCall()
+    out = one_step(args.warmup, record=rec)            # (its own exchange ran once: buffers and communicators are warm)
+    f, c, cam = cam_for(args.warmup)
+    pose = None if out["actor_pose"] is None else out["actor_pose"].detach()
+
+    def exchange():
+        x = dp.GradientExchange(campos_dev[(f, c)], actor_ids=model.actor_id if model.has_actors else None, actor_pose=pose)
+        x.start(rec)
+        x.finish(model._features, model._xyz, model.active_sh_degree, other_params=params)
+        return x
+    for _ in range(max(args.warmup, 1)):
+        exchange()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = exchange()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        A = 0 if pose is None else int(pose.shape[0])
+        print(json.dumps({"metric": "gradient exchange ms per step (GradientExchange.start + finish only)", "value": dt / args.steps * 1e3, "unit": "ms",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "exchange only: all-reduce(AVG) of the 44 B/Gaussian slab + all-gather of the 12 B/Gaussian SH factors, camera "
+                                                 "centres and pose tables + local rebuild of dL/dshs + small all-reduces", "gaussians": N,
+                                     "collectives_per_step": x.num_collectives, "forced_at_world_1": bool(dp.force_exchange()),
+                                     "bytes_per_rank": {"slab_allreduce": 44 * N, "factor_allgather_sent": 12 * N,
+                                                        "factor_allgather_received": 12 * N * world, "pose_tables": 48 * A * world}}}), flush=True)
+    if world > 1 or torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

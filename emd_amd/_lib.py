@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16
@@ -68,7 +68,8 @@ class EmdBwdArgs(C.Structure):
                 ("dL_dcolors", _f), ("dL_dopacities", _f), ("dL_dscales", _f), ("dL_drotations", _f),
                 ("dL_dcov3D", _f), ("dL_dactor_pose", _f), ("dL_dresidual_dx", _f), ("dL_dresidual_dq", _f),
                 ("dL_dsh_color", _f), ("settings_dev", _f),
-                ("num_extra", C.c_int32), ("colors_extra", _f * 2), ("out_extra", _f * 2), ("dL_dextra", _f * 2), ("dL_dcolors_extra", _f * 2)]
+                ("num_extra", C.c_int32), ("colors_extra", _f * 2), ("out_extra", _f * 2), ("dL_dextra", _f * 2), ("dL_dcolors_extra", _f * 2),
+                ("pair_stats", _f)]
 
 
 SKY_CLAMP01, SKY_BLEND_S3G, SKY_BLEND_ADD, SKY_INTERLEAVED = 1, 2, 4, 8
@@ -134,7 +135,7 @@ class EmdDensifyGather(C.Structure):
 
 class EmdTrackArgs(C.Structure):
     _fields_ = [("num_actors", C.c_int32), ("rows", C.c_int32), ("dim", C.c_int32), ("embed_dim", C.c_int32), ("k_coarse", C.c_int32),
-                ("k_fine", C.c_int32), ("num_points", C.c_int32), ("reserved", C.c_int32), ("t", C.c_float), ("t_dev", _f), ("weight", _f),
+                ("k_fine", C.c_int32), ("num_points", C.c_int32), ("reserved", C.c_int32), ("t", C.c_float), ("t_dev", _f), ("k_fine_dev", _f), ("weight", _f),
                 ("embeddings", _f), ("point_ids", _f), ("count", _f), ("segment_start", _f), ("head_w", _f * 4), ("head_b", _f * 4), ("emb_sum", _f),
                 ("trans", _f), ("rot", _f)]
 
@@ -142,6 +143,22 @@ class EmdTrackArgs(C.Structure):
 class EmdTrackGrads(C.Structure):
     _fields_ = [("g_trans", _f), ("g_rot", _f), ("d_weight", _f), ("d_embeddings", _f), ("d_head_w", _f * 4), ("d_head_b", _f * 4),
                 ("d_mean", _f)]
+
+
+class EmdStepSelect(C.Structure):
+    _fields_ = [("sel", _f), ("rows", C.c_int32), ("row_floats", C.c_int32), ("table", _f), ("out_row", _f), ("frames", _f),
+                ("frame_out", _f), ("t_out", _f), ("num_frames", C.c_int32), ("k_min", C.c_int32), ("k_max", C.c_int32),
+                ("k_until", C.c_int32), ("steps", _f), ("k_fine_out", _f), ("status", _f), ("status_log", _f), ("prev_sel", _f)]
+
+
+class EmdTrackedPoseArgs(C.Structure):
+    _fields_ = [("track", EmdTrackArgs), ("q_all", _f), ("t_all", _f), ("valid_all", _f), ("num_frames", C.c_int32), ("frame", C.c_int32),
+                ("frame_dev", _f), ("pose", _f)]
+
+
+class EmdTrackedPoseGrads(C.Structure):
+    _fields_ = [("g_pose", _f), ("d_q_all", _f), ("d_t_all", _f), ("d_weight", _f), ("d_embeddings", _f), ("d_head_w", _f * 4),
+                ("d_head_b", _f * 4), ("head_part", _f), ("counter", _f)]
 
 
 MLP_MAX_BRANCHES = 6
@@ -188,7 +205,8 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_deform_input_backward", "emd_adam_step", "emd_track_heads_forward", "emd_track_heads_backward",
                     "emd_densify_decide", "emd_densify_index", "emd_densify_split_rank", "emd_densify_gather",
                     "emd_mlp_trunk_forward", "emd_mlp_trunk_backward", "emd_mlp_branch_forward", "emd_mlp_branch_backward",
-                    "emd_abs_mean_backward")
+                    "emd_abs_mean_backward", "emd_tracked_pose_forward", "emd_tracked_pose_backward",
+                    "emd_select_step_inputs")
 PROF_STAGES = 8
 
 _lib = None
@@ -203,13 +221,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise EmdError(f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+    path = os.environ.get("EMD_LIB_PATH") or LIB_PATH          # (EMD_LIB_PATH: an alternative BUILD of the same library, for A/B timing)
+    if not os.path.exists(path):
+        raise EmdError(f"HIP extension not built: {path} is missing. Run `python -c 'import __graft_entry__ as g; "
                        f"g.build()'` (or `make -C emd_amd/csrc`). There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name in EXPORTED_SYMBOLS:
         if not hasattr(lib, name):
-            raise EmdError(f"{LIB_PATH} does not export {name}")
+            raise EmdError(f"{path} does not export {name}")
     lib.emd_abi_version.restype = C.c_int
     lib.emd_last_error.restype = C.c_char_p
     v = lib.emd_abi_version()
@@ -257,6 +276,9 @@ def load():
     lib.emd_mlp_branch_backward.argtypes = [C.POINTER(EmdMlpBranch), C.POINTER(EmdMlpBranchGrads), C.c_void_p]
     lib.emd_track_heads_forward.argtypes = [C.POINTER(EmdTrackArgs), C.c_void_p]
     lib.emd_track_heads_backward.argtypes = [C.POINTER(EmdTrackArgs), C.POINTER(EmdTrackGrads), C.c_void_p]
+    lib.emd_select_step_inputs.argtypes = [C.POINTER(EmdStepSelect), C.c_void_p]
+    lib.emd_tracked_pose_forward.argtypes = [C.POINTER(EmdTrackedPoseArgs), C.c_void_p]
+    lib.emd_tracked_pose_backward.argtypes = [C.POINTER(EmdTrackedPoseArgs), C.POINTER(EmdTrackedPoseGrads), C.c_void_p]
     lib.emd_sky_forward.argtypes = [C.POINTER(EmdSkyArgs), C.c_void_p]
     lib.emd_sky_backward.argtypes = [C.POINTER(EmdSkyBwdArgs), C.c_void_p]
     lib.emd_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]

@@ -77,6 +77,37 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_zero_words(uint32_t* __restrict__
 }
 }  // namespace
 
+// Per-step inputs of a replayed training step, selected on the device in one launch (see EmdStepSelect in emd_raster.h): what a
+// host-driven loop does with a handful of tiny copies and index ops per step (camera upload, frame number, frame time, the
+// coarse-to-fine level of the step) when the whole step is one hipGraph whose inputs must live at fixed device addresses.
+__global__ void __launch_bounds__(EMD_WAVE) k_select_step_inputs(EmdStepSelect a) {
+    const long long row = a.sel[0];
+    const int lane = threadIdx.x;
+    if (a.status_log && a.status && a.prev_sel) {            // the status words of the step before (its forward is long done): logged by row
+        const long long prev = a.prev_sel[0];
+        if (prev >= 0 && prev < a.rows && lane < 4) a.status_log[4 * prev + lane] = a.status[lane];
+    }
+    if (row < 0 || row >= a.rows) {                          // flush-only call (sel = -1 after the last step)
+        if (a.prev_sel && lane == 0) a.prev_sel[0] = -1;
+        return;
+    }
+    for (int j = lane; j < a.row_floats; j += EMD_WAVE) a.out_row[j] = a.table[(size_t)row * a.row_floats + j];
+    if (lane == 0) {
+        if (a.prev_sel) a.prev_sel[0] = row;
+        if (a.frames && a.frame_out) {
+            const int f = a.frames[row];
+            a.frame_out[0] = f;
+            if (a.t_out) a.t_out[0] = (float)f / (float)(a.num_frames > 1 ? a.num_frames - 1 : 1);
+        }
+        if (a.k_fine_out) {
+            // int_lininterp(step, k_min, k_max, until) of rigid.py:147-148,194-201, with the reference's float division + truncation
+            long long step = a.steps ? a.steps[row] : row;
+            step = step < 0 ? 0 : (step > a.k_until ? a.k_until : step);
+            a.k_fine_out[0] = (int)((double)a.k_min + (double)(a.k_max - a.k_min) * (double)step / (double)a.k_until);
+        }
+    }
+}
+
 int emd_zero_async(void* p, size_t bytes, hipStream_t st) {
     if (!p || bytes == 0) return EMD_OK;
     if (((uintptr_t)p & 3) || (bytes & 3)) { emd_set_error("emd_zero_async: pointer / size not a multiple of 4 bytes"); return EMD_ERR_INVALID; }
@@ -294,8 +325,13 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
         if (!a->colors_extra[k] || !a->out_extra[k]) { emd_set_error("backward: extra colour set %d: null colours / forward output", k); return EMD_ERR_INVALID; }
         ex.colors[k] = a->colors_extra[k]; ex.out[k] = (float*)a->out_extra[k]; ex.dL_dout[k] = a->dL_dextra[k];
     }
+    if (a->pair_stats && (a->num_extra > 0 || (a->flags & EMD_FLAG_ABSGRAD) || a->dL_dnormal)) {
+        emd_set_error("backward: pair_stats (diagnostic counters) only with the plain call: no extra colour sets, absgrad or normal gradient");
+        return EMD_ERR_INVALID;
+    }
     rc = emd_launch_render_backward(a->s, a->settings_dev, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->dL_dcolor,
-                                    a->dL_ddepth, a->dL_dalpha, a->dL_dnormal, &ex, (float*)a->bwd_ws, pose_grad, pose_grad_n, st);
+                                    a->dL_ddepth, a->dL_dalpha, a->dL_dnormal, &ex, (float*)a->bwd_ws, pose_grad, pose_grad_n,
+                                    (unsigned long long*)a->pair_stats, st);
     if (rc) return rc;
     STAGE_SYNC("render_backward");
     PreBwdArgs pb;
@@ -416,6 +452,16 @@ int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* d
                             float* dL_dq_f, float* dL_dt_f, float* dL_ddt, float* dL_ddq, const int32_t* frame_dev, void* hip_stream) {
     if (num_actors < 0 || (num_actors > 0 && (!q_f || !dL_dpose || !dL_dq_f || !dL_dt_f))) { emd_set_error("actor_pose_backward: bad argument"); return EMD_ERR_INVALID; }
     return emd_launch_actor_pose_backward(num_actors, q_f, dt, dq, dL_dpose, dL_dq_f, dL_dt_f, dL_ddt, dL_ddq, frame_dev, (hipStream_t)hip_stream);
+}
+
+int emd_select_step_inputs(const EmdStepSelect* a, void* hip_stream) {
+    if (!a || !a->sel) { emd_set_error("select_step_inputs: null args"); return EMD_ERR_INVALID; }
+    if (a->rows < 0 || a->row_floats < 0 || (a->row_floats > 0 && (!a->table || !a->out_row)) || (a->k_fine_out && a->k_until < 1)) {
+        emd_set_error("select_step_inputs: bad sizes / null table"); return EMD_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(k_select_step_inputs, dim3(1), dim3(EMD_WAVE), 0, (hipStream_t)hip_stream, *a);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
 }
 
 int emd_l1_loss(int64_t n, const float* a, const float* b, float* loss, float* grad, void* hip_stream) {

@@ -6,7 +6,7 @@
 // the least-significant 32 bits of the LSD sort can be done BEFORE duplicating, on N (depth, id) pairs instead of
 // D (key, id) triples (D ~ 3.8 V on the bench scene):
 //     1. stable LSD radix sort of the VISIBLE Gaussians by depth: the keys are (depth bits - bits(near plane)), non-negative floats
-//        order like their bit patterns, so 3 passes of 9 bits cover depths up to ~2^13 x near (EMD_ERR_DEPTH_RANGE -> the caller
+//        order like their bit patterns, so 3 passes of 9 bits cover depths up to 65 536 x near (EMD_ERR_DEPTH_RANGE -> the caller
 //        retries with EMD_FLAG_WIDE_DEPTH_SORT: 4 passes of 8 bits on the raw bits).  The first pass reads the N keys, drops the
 //        culled ones (0xFFFFFFFF) and publishes V; the other two run over V (key, id) pairs,
 //     2. gather the tile rectangle / tile count of each Gaussian in that order, scan, duplicate: the duplicates appear

@@ -184,7 +184,7 @@ int emd_launch_render_backward(const EmdSettings& s, const float* sdev, int flag
                                const float* out_color, const float* out_depth, const float* out_normal,
                                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                                const float* dL_dnormal, const EmdExtra* x, float* grad_rec, float* zero_buf, int zero_n,
-                               hipStream_t st);  // render.hip (zero_buf: small table cleared by block 0 for K8)
+                               unsigned long long* pair_stats, hipStream_t st);  // render.hip (zero_buf: small table cleared by block 0 for K8)
 struct PreBwdArgs {
     EmdSettings s;
     int N, M, flags;

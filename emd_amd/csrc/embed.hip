@@ -290,7 +290,8 @@ __global__ void __launch_bounds__(EMD_WAVE) k_track_heads(EmdTrackArgs a, EmdTra
     const int act = blockIdx.x, lane = threadIdx.x, dim = a.dim, E = a.embed_dim, width = dim + E;
     const float* w = a.weight + (size_t)act * a.rows * dim;
     const float t = a.t_dev ? a.t_dev[0] : a.t;
-    const TeSample sc = te_rows(t, a.k_coarse, a.rows), sf = te_rows(t, a.k_fine, a.rows);
+    const int k_fine = a.k_fine_dev ? a.k_fine_dev[0] : a.k_fine;
+    const TeSample sc = te_rows(t, a.k_coarse, a.rows), sf = te_rows(t, k_fine, a.rows);
     float hc = 0.f, hf = 0.f;
     if (lane < dim) { hc = te_column(w, dim, sc, lane, 0.f, nullptr); hf = te_column(w, dim, sf, lane, 0.f, nullptr); }
     else if (lane < width) hc = hf = a.emb_sum[(size_t)act * E + (lane - dim)] / a.count[act];
@@ -330,6 +331,224 @@ __global__ void __launch_bounds__(EMD_WAVE) k_track_heads(EmdTrackArgs a, EmdTra
         te_column(w, dim, sc, lane, dhc, G);
         te_column(w, dim, sf, lane, dhf, G);
     } else if (lane < width) g.d_mean[(size_t)act * E + (lane - dim)] = dhc + dhf;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The whole per-actor chain in ONE launch each way (round 3): embedding sums -> track heads -> pose row, and pose row gradient ->
+// heads -> temporal table / embeddings / per-frame pose tables.  Every step of the chain is per actor, so one 1024-thread
+// workgroup per actor runs it front to back: the forward replaces three launch-bound kernels (k_track_embed_sum_seg,
+// k_track_heads, k_actor_pose_forward: ~21 us of a 1.5 ms step), the backward replaces three more plus the two zero fills of
+// their dense outputs -- each workgroup clears what it owns (its actor's temporal table gradient and its column of the
+// [F, A, .] pose gradients) before accumulating.  Only the head parameters are shared between actors: every workgroup
+// writes its contribution to a scratch row and the last one to finish (a self-resetting ticket in `counter`) sums them, so
+// no output needs a zero fill and no float atomic crosses workgroups.  The pose arithmetic is the one of k_actor_pose_*
+// (preprocess.hip), evaluated without contraction so that both produce the same bits.
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tp_quat_mul(const float a[4], const float b[4], float o[4]) {
+#pragma clang fp contract(off)
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+__device__ __forceinline__ float tp_quat_norm(const float q[4]) {
+#pragma clang fp contract(off)
+    return sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+}
+__device__ __forceinline__ void tp_dnormalize4(const float vu[4], float n, const float g[4], float out[4]) {
+#pragma clang fp contract(off)
+    float dot = ((vu[0] * g[0] + vu[1] * g[1]) + vu[2] * g[2]) + vu[3] * g[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = (g[k] - vu[k] * dot) / n;
+}
+__device__ __forceinline__ bool tp_any_nan(const float* v, int n) {
+    bool b = false;
+    for (int k = 0; k < n; k++) b |= !(v[k] == v[k]);
+    return b;
+}
+
+// per-actor sum of the embeddings of its points [lo, hi) by the whole workgroup -> s_sum[0..E) (E <= 8)
+__device__ __forceinline__ void tp_segment_sum(int E, const float* __restrict__ emb, int lo, int hi, float (*s_part)[8], float* s_sum) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = 0.f;
+    if (E == 4 && ((uintptr_t)emb & 15) == 0) {
+        const float4* e4 = (const float4*)emb;
+        for (int i = lo + (int)threadIdx.x; i < hi; i += SEG_THREADS) {
+            const float4 v = e4[i];
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        }
+    } else {
+        for (int i = lo + (int)threadIdx.x; i < hi; i += SEG_THREADS)
+#pragma unroll
+            for (int e = 0; e < 8; e++) if (e < E) acc[e] += emb[(size_t)i * E + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float w = wave_sum_all(acc[e]);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6][e] = w;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < SEG_THREADS / 64; w++) t += s_part[w][threadIdx.x];
+        s_sum[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs p, EmdTrackedPoseGrads g) {
+    __shared__ float s_part[SEG_THREADS / 64][8];
+    __shared__ float s_sum[8];
+    __shared__ float s_dmean[8];
+    __shared__ uint32_t s_last;
+    const EmdTrackArgs& a = p.track;
+    const int act = blockIdx.x, A = a.num_actors, dim = a.dim, E = a.embed_dim, width = dim + E;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo = a.segment_start[act], hi = a.segment_start[act + 1];
+    const int frame = p.frame_dev ? p.frame_dev[0] : p.frame;
+    if (BWD) {
+        // clear what this workgroup owns: its actor's temporal-table gradient and its column of the dense per-frame pose gradients
+        float* G = g.d_weight + (size_t)act * a.rows * dim;
+        for (int i = threadIdx.x; i < a.rows * dim; i += SEG_THREADS) G[i] = 0.f;
+        for (int f = threadIdx.x; f < p.num_frames; f += SEG_THREADS) {
+            if (f == frame) continue;                 // (written below)
+            float* dq = g.d_q_all + ((size_t)f * A + act) * 4;
+            float* dt = g.d_t_all + ((size_t)f * A + act) * 3;
+            dq[0] = dq[1] = dq[2] = dq[3] = 0.f; dt[0] = dt[1] = dt[2] = 0.f;
+        }
+    }
+    if (!BWD) {
+        if (E > 0) tp_segment_sum(E, a.embeddings, lo, hi, s_part, s_sum);
+        if ((int)threadIdx.x < E) a.emb_sum[(size_t)act * E + threadIdx.x] = s_sum[threadIdx.x];      // kept for the backward
+    } else {
+        if ((int)threadIdx.x < E) s_sum[threadIdx.x] = a.emb_sum[(size_t)act * E + threadIdx.x];
+        __syncthreads();                                                                           // (also: the clears above are done)
+    }
+    if (wave == 0) {
+        const float* w = a.weight + (size_t)act * a.rows * dim;
+        const float t = a.t_dev ? a.t_dev[0] : a.t;
+        const int k_fine = a.k_fine_dev ? a.k_fine_dev[0] : a.k_fine;
+        const TeSample sc = te_rows(t, a.k_coarse, a.rows), sf = te_rows(t, k_fine, a.rows);
+        const float cnt = a.count[act];
+        float hc = 0.f, hf = 0.f;
+        if (lane < dim) { hc = te_column(w, dim, sc, lane, 0.f, nullptr); hf = te_column(w, dim, sf, lane, 0.f, nullptr); }
+        else if (lane < width) hc = hf = s_sum[lane - dim] / cnt;
+        float out[8], wrow[8];
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            const int hd = o < 3 ? 0 : o < 6 ? 1 : o - 4, r = o < 3 ? o : o < 6 ? o - 3 : 0;
+            wrow[o] = lane < width ? a.head_w[hd][r * width + lane] : 0.f;
+            out[o] = wave_sum_all(wrow[o] * ((o < 3 || o == 6) ? hc : hf)) + a.head_b[hd][r];
+        }
+        const float cc = cosf(out[6]), scn = sinf(out[6]), cf = cosf(out[7]), sfn = sinf(out[7]);
+        const float ow = cc * cf - scn * sfn, oz = cc * sfn + scn * cf;
+        const float dtv[3] = {out[0] + out[3], out[1] + out[4], out[2] + out[5]};
+        const float dqv[4] = {ow, 0.f, 0.f, oz};
+        // ---- pose row of this actor (k_actor_pose_forward / _backward, every lane computes the same values) ----
+        const float* q_f = p.q_all + ((size_t)frame * A + act) * 4;
+        const float* t_f = p.t_all + ((size_t)frame * A + act) * 3;
+        const float q[4] = {q_f[0], q_f[1], q_f[2], q_f[3]};
+        const float n = fmaxf(tp_quat_norm(q), 1e-12f);
+        const bool ok_t = !tp_any_nan(dtv, 3), ok_r = !tp_any_nan(dqv, 4);
+        float pq[4] = {q[0], q[1], q[2], q[3]};
+        if (ok_r) tp_quat_mul(q, dqv, pq);
+        const float n2 = fmaxf(tp_quat_norm(pq), 1e-12f);
+        if (!BWD) {
+            if (lane == 0) {
+                if (a.trans) { a.trans[3 * act] = dtv[0]; a.trans[3 * act + 1] = dtv[1]; a.trans[3 * act + 2] = dtv[2]; }
+                if (a.rot) { a.rot[4 * act] = ow; a.rot[4 * act + 1] = 0.f; a.rot[4 * act + 2] = 0.f; a.rot[4 * act + 3] = oz; }
+                float* P = p.pose + (size_t)act * EMD_ACTOR_STRIDE;
+#pragma unroll
+                for (int k = 0; k < 4; k++) P[k] = q[k] / n;
+#pragma unroll
+                for (int k = 0; k < 3; k++) P[4 + k] = ok_t ? t_f[k] + dtv[k] : t_f[k];
+                P[7] = p.valid_all ? (p.valid_all[(size_t)frame * A + act] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) P[8 + k] = pq[k] / n2;
+            }
+        } else {
+            const float* Gp = g.g_pose + (size_t)act * EMD_ACTOR_STRIDE;
+            const float qu[4] = {q[0] / n, q[1] / n, q[2] / n, q[3] / n};
+            const float gm[4] = {Gp[0], Gp[1], Gp[2], Gp[3]};
+            float dqf[4];
+            tp_dnormalize4(qu, n, gm, dqf);
+            const float pu[4] = {pq[0] / n2, pq[1] / n2, pq[2] / n2, pq[3] / n2};
+            const float gr[4] = {Gp[8], Gp[9], Gp[10], Gp[11]};
+            float dp[4], dr[4] = {0.f, 0.f, 0.f, 0.f};
+            tp_dnormalize4(pu, n2, gr, dp);
+            if (ok_r) {
+                const float rc[4] = {dqv[0], -dqv[1], -dqv[2], -dqv[3]}, qc[4] = {q[0], -q[1], -q[2], -q[3]};
+                float t1[4];
+                tp_quat_mul(dp, rc, t1);
+                tp_quat_mul(qc, dp, dr);
+#pragma unroll
+                for (int k = 0; k < 4; k++) dqf[k] += t1[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) dqf[k] += dp[k];
+            }
+            if (lane == 0) {
+                float* dq = g.d_q_all + ((size_t)frame * A + act) * 4;
+                float* dt = g.d_t_all + ((size_t)frame * A + act) * 3;
+#pragma unroll
+                for (int k = 0; k < 4; k++) dq[k] = dqf[k];
+#pragma unroll
+                for (int k = 0; k < 3; k++) dt[k] = Gp[4 + k];
+            }
+            // ---- heads ----
+            const float gt0 = ok_t ? Gp[4] : 0.f, gt1 = ok_t ? Gp[5] : 0.f, gt2 = ok_t ? Gp[6] : 0.f;
+            const float dth = dr[0] * (-oz) + dr[3] * ow;
+            const float go[8] = {gt0, gt1, gt2, gt0, gt1, gt2, dth, dth};
+            float dhc = 0.f, dhf = 0.f;
+            float* part = g.head_part + (size_t)act * 8 * (width + 1);
+#pragma unroll
+            for (int o = 0; o < 8; o++) {
+                const bool coarse = o < 3 || o == 6;
+                if (lane < width) part[o * (width + 1) + lane] = go[o] * (coarse ? hc : hf);
+                if (lane == 0) part[o * (width + 1) + width] = go[o];
+                if (coarse) dhc += go[o] * wrow[o]; else dhf += go[o] * wrow[o];
+            }
+            if (lane < dim) {
+                float* G = g.d_weight + (size_t)act * a.rows * dim;
+                te_column(w, dim, sc, lane, dhc, G);
+                te_column(w, dim, sf, lane, dhf, G);
+            } else if (lane < width) s_dmean[lane - dim] = (dhc + dhf) / cnt;
+        }
+    }
+    if (!BWD) return;
+    __syncthreads();
+    if (g.d_embeddings && E > 0) {
+        if (E == 4 && ((uintptr_t)g.d_embeddings & 15) == 0) {
+            const float4 v = make_float4(s_dmean[0], s_dmean[1], s_dmean[2], s_dmean[3]);
+            float4* d4 = (float4*)g.d_embeddings;
+            for (int i = lo + (int)threadIdx.x; i < hi; i += SEG_THREADS) d4[i] = v;
+        } else {
+            for (int i = (lo * E) + (int)threadIdx.x; i < hi * E; i += SEG_THREADS) g.d_embeddings[i] = s_dmean[i % E];
+        }
+    }
+    // ---- head gradients: the last workgroup to arrive sums the per-actor rows (no zero fill, no cross-workgroup float atomics) ----
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t ticket = atomicAdd(g.counter, 1u);
+        s_last = (ticket == (uint32_t)A - 1u) ? 1u : 0u;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int idx = threadIdx.x; idx < 8 * (width + 1); idx += SEG_THREADS) {
+        const int o = idx / (width + 1), c = idx % (width + 1);
+        float sum = 0.f;
+        for (int b = 0; b < A; b++) sum += __builtin_nontemporal_load(g.head_part + ((size_t)b * 8 + o) * (width + 1) + c);
+        const int hd = o < 3 ? 0 : o < 6 ? 1 : o - 4, r = o < 3 ? o : o < 6 ? o - 3 : 0;
+        if (c < width) g.d_head_w[hd][r * width + c] = sum; else g.d_head_b[hd][r] = sum;
+    }
+    if (threadIdx.x == 0) *g.counter = 0u;          // ticket counter ready for the next launch
 }
 
 int check_track(const EmdTrackArgs* a, const char* who) {
@@ -446,5 +665,41 @@ extern "C" int emd_track_heads_backward(const EmdTrackArgs* a, const EmdTrackGra
                            a->point_ids, a->count, g->d_mean, g->d_embeddings);
         EMD_LAUNCH_CHECK();
     }
+    return EMD_OK;
+}
+
+static int check_tracked(const EmdTrackedPoseArgs* p, const char* who) {
+    if (!p) { emd_set_error("%s: null args", who); return EMD_ERR_INVALID; }
+    int rc = check_track(&p->track, who);
+    if (rc) return rc;
+    const EmdTrackArgs& a = p->track;
+    if (a.num_actors == 0) return EMD_OK;
+    if (!a.segment_start || a.embed_dim > 8) { emd_set_error("%s: needs segment_start (points sorted by actor) and embed_dim <= 8", who); return EMD_ERR_INVALID; }
+    if (!p->q_all || !p->t_all || p->num_frames < 1 || (!p->frame_dev && (p->frame < 0 || p->frame >= p->num_frames))) {
+        emd_set_error("%s: bad pose tables / frame", who); return EMD_ERR_INVALID;
+    }
+    return EMD_OK;
+}
+
+extern "C" int emd_tracked_pose_forward(const EmdTrackedPoseArgs* p, void* hip_stream) {
+    int rc = check_tracked(p, "tracked_pose_forward");
+    if (rc || p->track.num_actors == 0) return rc;
+    if (!p->pose) { emd_set_error("tracked_pose_forward: null output"); return EMD_ERR_INVALID; }
+    EmdTrackedPoseGrads none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL(k_tracked_pose<false>, dim3(p->track.num_actors), dim3(SEG_THREADS), 0, (hipStream_t)hip_stream, *p, none);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+extern "C" int emd_tracked_pose_backward(const EmdTrackedPoseArgs* p, const EmdTrackedPoseGrads* g, void* hip_stream) {
+    int rc = check_tracked(p, "tracked_pose_backward");
+    if (rc || p->track.num_actors == 0) return rc;
+    if (!g || !g->g_pose || !g->d_q_all || !g->d_t_all || !g->d_weight || !g->head_part || !g->counter) {
+        emd_set_error("tracked_pose_backward: null gradient pointer"); return EMD_ERR_INVALID;
+    }
+    for (int h = 0; h < 4; h++) if (!g->d_head_w[h] || !g->d_head_b[h]) { emd_set_error("tracked_pose_backward: null head gradient %d", h); return EMD_ERR_INVALID; }
+    hipLaunchKernelGGL(k_tracked_pose<true>, dim3(p->track.num_actors), dim3(SEG_THREADS), 0, (hipStream_t)hip_stream, *p, *g);
+    EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

@@ -24,6 +24,8 @@
 // Bound: fp32 MFMA (157 TFLOP/s); no kernel here waits on HBM.
 #include <string.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -725,10 +727,13 @@ int mlp_launch(int floats, int num_points, hipStream_t st, Args... args) {
     if (bytes > 64 * 1024) {
         // once per kernel (this function template is instantiated per kernel: the kernel is its template argument): not a stream operation, so it is kept
         // out of the per-launch path and out of any stream capture after the first call
-        static bool raised = false;
-        if (!raised) {
+        // (the attribute is per DEVICE: one flag per device ordinal; an unsynchronised double set by two threads is harmless)
+        static std::atomic<bool> raised[64];
+        int dev = 0;
+        EMD_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !raised[dev].load(std::memory_order_acquire)) {
             EMD_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-            raised = true;
+            if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
         }
     }
     hipLaunchKernelGGL(kernel, dim3(mlp_grid(num_points, PER_CU)), dim3(MLP_THREADS), bytes, st, args...);

@@ -82,6 +82,54 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float4& r0, const float4
     return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Exact-conservative culling against a rectangle of pixel centres (round 3).  The box above is loose for the elongated, diagonal
+// footprints street scenes are made of: on the bench scene 16 % of the (quadrant, entry) pairs that pass it reach alpha >= 1/255
+// at no pixel of the quadrant, 42 % of its (4x4 sub-block, entry) pairs at none of the sub-block (tests/analysis/pair_stats.py).
+// A pixel contributes only if q(d) = A dx^2 + 2 B dx dy + C dy^2 <= 2 ln(255 o); q is convex, so its minimum over the
+// rectangle is 0 when the mean lies inside and otherwise sits on one of the four edges.  On the edge dx = const
+//     q = C (dy - dy*)^2 + (det / C) dx^2,   dy* = -B dx / C,
+// a sum of two non-negative terms (no cancellation), minimised by clamping dy* into the edge.  The threshold carries a 1 % + 0.05
+// margin: det = A C - B^2 loses up to ~3e-3 relative on very thin ellipses, everything else is a few ulp.  NaN means are culled
+// (such an entry fails `power <= 0` at every pixel), degenerate conics are kept.
+// ---------------------------------------------------------------------------------------------------
+struct EllipseCull {
+    float mx, my, A, C, kx, ky, nbc, nba, thr;
+    bool none, all;
+};
+__device__ __forceinline__ EllipseCull ellipse_prepare(const float4& r0, const float4& r1) {
+    EllipseCull e;
+    const float o = r0.w;
+    e.mx = r0.x; e.my = r0.y; e.A = r1.x; e.C = r1.z;
+    e.none = !(o >= (1.f / 255.f));              // can never reach alpha >= 1/255 (also catches NaN)
+    const float det = r1.x * r1.z - r1.y * r1.y;
+    e.all = !(det > 0.f) || !(r1.x > 0.f) || !(r1.z > 0.f);
+    e.thr = 2.f * __logf(255.f * o) * 1.01f + 0.05f;
+    const float ia = __builtin_amdgcn_rcpf(r1.x), ic = __builtin_amdgcn_rcpf(r1.z);
+    e.kx = det * ic; e.ky = det * ia; e.nbc = -r1.y * ic; e.nba = -r1.y * ia;
+    return e;
+}
+// true unless no pixel centre of [x0, x1] x [y0, y1] can reach alpha >= 1/255
+__device__ __forceinline__ bool ellipse_hits_rect(const EllipseCull& e, float x0, float x1, float y0, float y1) {
+    const float dxa = e.mx - x0, dxb = e.mx - x1, dya = e.my - y0, dyb = e.my - y1;       // dxb <= dxa, dyb <= dya
+    const bool inside = dxa >= 0.f && dxb <= 0.f && dya >= 0.f && dyb <= 0.f;
+    float ta = e.nbc * dxa, tb = e.nbc * dxb;
+    float ea = __builtin_amdgcn_fmed3f(ta, dyb, dya) - ta, eb = __builtin_amdgcn_fmed3f(tb, dyb, dya) - tb;
+    const float qa = __builtin_fmaf(e.C * ea, ea, (e.kx * dxa) * dxa), qb = __builtin_fmaf(e.C * eb, eb, (e.kx * dxb) * dxb);
+    ta = e.nba * dya; tb = e.nba * dyb;
+    ea = __builtin_amdgcn_fmed3f(ta, dxb, dxa) - ta; eb = __builtin_amdgcn_fmed3f(tb, dxb, dxa) - tb;
+    const float qc = __builtin_fmaf(e.A * ea, ea, (e.ky * dya) * dya), qd = __builtin_fmaf(e.A * eb, eb, (e.ky * dyb) * dyb);
+    const float q = fminf(fminf(qa, qb), fminf(qc, qd));
+    return !e.none && (e.all || inside || q <= e.thr);
+}
+// bit r (r = sby * 2 + sbx) set when 4x4 sub-block r of the quadrant at (qx0, qy0) can receive alpha >= 1/255
+__device__ __forceinline__ uint32_t ellipse_subblock_mask(const float4& r0, const float4& r1, float qx0, float qy0) {
+    const EllipseCull e = ellipse_prepare(r0, r1);
+    return (ellipse_hits_rect(e, qx0, qx0 + 3.f, qy0, qy0 + 3.f) ? 1u : 0u) | (ellipse_hits_rect(e, qx0 + 4.f, qx0 + 7.f, qy0, qy0 + 3.f) ? 2u : 0u) |
+           (ellipse_hits_rect(e, qx0, qx0 + 3.f, qy0 + 4.f, qy0 + 7.f) ? 4u : 0u) |
+           (ellipse_hits_rect(e, qx0 + 4.f, qx0 + 7.f, qy0 + 4.f, qy0 + 7.f) ? 8u : 0u);
+}
+
 // Two-wide forms of gauss_power / pinned_exp (same operations per component, so bit-identical results): CDNA3/4 issue
 // v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 on register pairs at the rate of the scalar forms, which halves the VALU
 // slots of everything that is not a DPP scan, a compare or a transcendental.  K7 evaluates two pixels per iteration.
@@ -201,7 +249,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
     uint32_t scanned = 0;
     while (scanned < n_tile) {
         if (__ballot(!done) == 0ull) break;
-        // ---- scan: queue entries until more than 64 wait or the list ends ----
+        // ---- scan: queue the entries whose footprint reaches this quadrant until more than 64 wait or the list ends ----
         uint32_t head = 0, len0 = 0, len1 = 0, len2 = 0, len3 = 0;
         while (head <= EMD_WAVE && scanned < n_tile) {
             const uint32_t idx = scanned + lane;
@@ -218,24 +266,39 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
 #pragma unroll
                 for (int k = 0; k < NX; k++) { const float* c = d.xcol[k] + 3 * (size_t)gid; px_[k] = make_float4(c[0], c[1], c[2], 0.f); }
             }
-            const uint32_t m4 = idx < n_tile ? quad_subblock_mask(c0r, c1r, qx0, qy0) : 0u;
-            const unsigned long long bal = __ballot(m4 != 0u);
+#ifdef EMD_AB_BOX_CULL          // A/B build (scratch/mkvariant.sh): round 2's bounding-box tests
+            const bool keep = idx < n_tile && quad_subblock_mask(c0r, c1r, qx0, qy0) != 0u;
+#else
+            const bool keep = idx < n_tile && ellipse_hits_rect(ellipse_prepare(c0r, c1r), qx0, qx0 + 7.f, qy0, qy0 + 7.f);
+#endif
+            const unsigned long long bal = __ballot(keep);
             const uint32_t slot = head + (uint32_t)__popcll(bal & lt);
-            if (m4) {
+            if (keep) {
                 c2r.w = __uint_as_float(idx + 1);           // 1-based position in the tile list
                 s0[slot] = c0r; s1[slot] = c1r; s2[slot] = c2r;
                 if (NORMAL) s3[slot] = c3r;
 #pragma unroll
                 for (int k = 0; k < NX; k++) sx[k][slot] = cxr[k];
             }
+            head += (uint32_t)__popcll(bal);
+            scanned += EMD_WAVE;
+        }
+        __syncthreads();
+        // ---- the queued entries (not the whole list) get the exact per-sub-block test; one byte list per sub-block ----
+        for (uint32_t base = 0; base < head; base += EMD_WAVE) {
+            const uint32_t slot = base + lane;
+            uint32_t m4 = 0u;
+#ifdef EMD_AB_BOX_CULL
+            if (slot < head) m4 = quad_subblock_mask(s0[slot], s1[slot], qx0, qy0);
+#else
+            if (slot < head) m4 = ellipse_subblock_mask(s0[slot], s1[slot], qx0, qy0);
+#endif
             const unsigned long long b0 = __ballot(m4 & 1u), b1 = __ballot(m4 & 2u), b2 = __ballot(m4 & 4u), b3 = __ballot(m4 & 8u);
             if (m4 & 1u) s_list[0][len0 + (uint32_t)__popcll(b0 & lt)] = (uint8_t)slot;
             if (m4 & 2u) s_list[1][len1 + (uint32_t)__popcll(b1 & lt)] = (uint8_t)slot;
             if (m4 & 4u) s_list[2][len2 + (uint32_t)__popcll(b2 & lt)] = (uint8_t)slot;
             if (m4 & 8u) s_list[3][len3 + (uint32_t)__popcll(b3 & lt)] = (uint8_t)slot;
             len0 += (uint32_t)__popcll(b0); len1 += (uint32_t)__popcll(b1); len2 += (uint32_t)__popcll(b2); len3 += (uint32_t)__popcll(b3);
-            head += (uint32_t)__popcll(bal);
-            scanned += EMD_WAVE;
         }
         __syncthreads();
         const uint32_t nmax = max(max(len0, len1), max(len2, len3));
@@ -330,7 +393,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
 // ---------------------------------------------------------------------------------------------------
 #define BQ_QUEUE 128
 
-template <bool NORMAL, bool ABS, int NX>
+template <bool NORMAL, bool ABS, int NX, bool STATS = false>
 __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(NX == 0 ? 4 : NX == 1 ? 3 : 2))) k_render_backward_q(RenderDims d, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ point_list,
                                                                 const float4* __restrict__ rec,
@@ -344,7 +407,8 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
                                                                 const float* __restrict__ dL_dalpha,
                                                                 const float* __restrict__ dL_dnormal,
                                                                 float* __restrict__ grad_rec,
-                                                                float* __restrict__ zero_buf, int zero_n) {
+                                                                float* __restrict__ zero_buf, int zero_n,
+                                                                unsigned long long* __restrict__ pair_stats) {
     // the tiny actor-pose gradient table K8 accumulates into is cleared here (K8 starts after this kernel): no memset launch
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < zero_n; i += EMD_WAVE) zero_buf[i] = 0.f;
@@ -411,6 +475,8 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
     }
     __syncthreads();
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // STATS (diagnostic instantiation, EmdBwdArgs.pair_stats): (pixel, entry) pairs this wave evaluates / pairs that contribute
+    unsigned long long st_eval = 0ull, st_hit = 0ull;
 
     // One batch: lane = queue slot.
     auto process_batch = [&](uint32_t nb) {
@@ -438,11 +504,27 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
             const float dy = g0.y - pys;
             const v2f dx = (v2f){g0.x - pxs, g0.x - (pxs + 1.f)};
             const v2f power = gauss_power2(g1.x, g1.y, g1.z, dx, dy);
-            const v2f G = pinned_exp2(power);
-            const v2f aw = splat2(g0.w) * G;
+            // exp: the hardware v_exp_f32 (1 ulp) unless a lane sits within 2e-5 (relative) of the alpha >= 1/255 threshold, where the
+            // wave re-evaluates with the pinned polynomial K6 used -- both are within 1e-6 of each other, so the skip decisions
+            // equal K6's everywhere (2 quarter-rate instructions instead of 14; the fallback runs once per ~10^4 iterations)
+#ifdef EMD_AB_PINNED_EXP
+            v2f G = pinned_exp2(power);
+            v2f aw = splat2(g0.w) * G;
+            if (false) {
+#else
+            const v2f t2 = power * splat2(1.44269504088896341f);
+            v2f G = (v2f){__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)};
+            v2f aw = splat2(g0.w) * G;
+            {
+#endif
+                const float lo = (1.f / 255.f) * (1.f - 2e-5f), hi = (1.f / 255.f) * (1.f + 2e-5f);
+                const bool band = (aw.x > lo && aw.x < hi) || (aw.y > lo && aw.y < hi);
+                if (__ballot(band) != 0ull) { G = pinned_exp2(power); aw = splat2(g0.w) * G; }
+            }
             const v2f alpha = (v2f){fminf(0.99f, aw.x), fminf(0.99f, aw.y)};
             const bool hit_a = valid && pos < n_a && power.x <= 0.f && alpha.x >= (1.f / 255.f);
             const bool hit_b = valid && pos < n_b && power.y <= 0.f && alpha.y >= (1.f / 255.f);
+            if (STATS) { st_eval += 2ull * nb; st_hit += (unsigned long long)(__popcll(__ballot(hit_a)) + __popcll(__ballot(hit_b))); }
             if (__ballot(hit_a || hit_b) == 0ull) continue;
             const v2f a = (v2f){hit_a ? alpha.x : 0.f, hit_b ? alpha.y : 0.f};
             const v2f om = splat2(1.f) - a;
@@ -561,7 +643,11 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
             load_extra(idB, bx_);
         }
         idC = load_id(step_idx(st_ + 3));
+#ifdef EMD_AB_BOX_CULL
         const bool keep = in_list(idx) && ((quadrant_mask(c0r, c1r, tile_x0, tile_y0) >> quad) & 1u);
+#else
+        const bool keep = in_list(idx) && ellipse_hits_rect(ellipse_prepare(c0r, c1r), qx0, qx0 + 7.f, qy0, qy0 + 7.f);
+#endif
         const unsigned long long bal = __ballot(keep);
         if (keep) {
             const uint32_t slot = head + (uint32_t)__popcll(bal & gt);          // deepest first: the queue order is descending list position
@@ -588,6 +674,7 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
         }
     }
     if (head > 0) process_batch(head);
+    if (STATS && lane == 0) { atomicAdd(pair_stats, st_eval); atomicAdd(pair_stats + 1, st_hit); }
 }
 
 RenderDims make_dims(const EmdSettings& s, const float* sdev, const EmdExtra* x) {
@@ -630,7 +717,8 @@ int emd_launch_render_forward(const EmdSettings& s, const float* sdev, int flags
 int emd_launch_render_backward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                                const float* out_color, const float* out_depth, const float* out_normal,
                                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                               const float* dL_dnormal, const EmdExtra* x, float* grad_rec, float* zero_buf, int zero_n, hipStream_t st) {
+                               const float* dL_dnormal, const EmdExtra* x, float* grad_rec, float* zero_buf, int zero_n,
+                               unsigned long long* pair_stats, hipStream_t st) {
     const RenderDims d = make_dims(s, sdev, x);
     const int T = d.gx * d.gy;
     if (T <= 0) return EMD_OK;
@@ -640,13 +728,18 @@ int emd_launch_render_backward(const EmdSettings& s, const float* sdev, int flag
 #define LAUNCH_BWD(N_, A_, X_)                                                                                          \
     hipLaunchKernelGGL((k_render_backward_q<N_, A_, X_>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec,   \
                        im.final_T, im.n_contrib, out_color, out_depth, out_normal, dL_dcolor, dL_ddepth, dL_dalpha,    \
-                       dL_dnormal, grad_rec, zero_buf, zero_n)
+                       dL_dnormal, grad_rec, zero_buf, zero_n, pair_stats)
 #define LAUNCH_BWD_X(X_)                                   \
     if (nrm && ab) LAUNCH_BWD(true, true, X_);             \
     else if (nrm) LAUNCH_BWD(true, false, X_);             \
     else if (ab) LAUNCH_BWD(false, true, X_);              \
     else LAUNCH_BWD(false, false, X_)
-    if (nx == 0) { LAUNCH_BWD_X(0); }
+    if (nx == 0 && pair_stats) {          // diagnostic: the same kernel with the pair counters compiled in
+        hipLaunchKernelGGL((k_render_backward_q<false, false, 0, true>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl,
+                           g.rec, im.final_T, im.n_contrib, out_color, out_depth, out_normal, dL_dcolor, dL_ddepth, dL_dalpha, nullptr, grad_rec,
+                           zero_buf, zero_n, pair_stats);
+    }
+    else if (nx == 0) { LAUNCH_BWD_X(0); }
     else if (nx == 1) { LAUNCH_BWD_X(1); }
     else { LAUNCH_BWD_X(2); }
 #undef LAUNCH_BWD_X

@@ -24,7 +24,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # (EMD_DP_INIT_WORLD1=1: a one-rank process group, so that EMD_DP_FORCE=1 can run the collectives of the exchange on one GPU)
+    if (world > 1 or os.environ.get("EMD_DP_INIT_WORLD1")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -36,6 +37,41 @@ def init_from_env(backend=None):
 
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def force_exchange():
+    """EMD_DP_FORCE=1 with an initialised process group of ONE rank: GradientExchange issues its collectives anyway (all-reduce,
+    all-gathers, the factor rebuild) instead of short-cutting -- the RCCL path can then be executed, and checked against the plain
+    gradient, on a single GPU (tests/test_dp_nccl_gpu.py, bench.py --exchange-only)."""
+    return os.environ.get("EMD_DP_FORCE", "") not in ("", "0") and dist.is_initialized()
+
+
+def _in_backward():
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f is None or f() != -1          # unknown: assume the engine is running
+
+
+def slab_holds_leaf_grads(rec):
+    """After backward(): True when the `.grad` of every leaf among the slab's four tensors IS its view of the slab (autograd kept the
+    views), so that one in-place all-reduce of the slab reduces all of them."""
+    ins, slab = getattr(rec, "slab_inputs", None), rec.grad_slab
+    if slab is None or ins is None:
+        return False
+    lo, hi = slab.data_ptr(), slab.data_ptr() + slab.numel() * 4
+    leaves = [t for t in ins if t is not None and t.is_leaf and t.requires_grad]
+    return len(leaves) > 0 and all(t.grad is not None and lo <= t.grad.data_ptr() < hi for t in leaves)
+
+
+def slab_is_exclusive(rec):
+    """True when the gradient slab of `rec`'s backward may be all-reduced IN PLACE while autograd is still running: each of the four
+    tensors it was carved for (means3D, scales, rotations, opacities) is a leaf that requires grad and holds no `.grad` yet -- then
+    autograd only stores the views as the parameters' `.grad` and nothing reads or accumulates into them before `finish()`.  With a
+    network in front of the rasterizer (means3D = xyz + dx, ...) the views are inputs of further backward nodes, and a leaf that
+    already holds a gradient gets the view ADDED to it: in both cases the reduction has to wait for backward() to end."""
+    ins = getattr(rec, "slab_inputs", None)
+    if rec.grad_slab is None or ins is None:
+        return False
+    return all(t is not None and t.is_leaf and t.requires_grad and t.grad is None for t in ins)
 
 
 def view_for(step, rank, world, num_views):
@@ -137,7 +173,7 @@ class GradientExchange:
         if g_local is None:
             raise RuntimeError("no SH colour-gradient factor: build the rasterizer with factored_sh_grad=True")
         W = world_size()
-        if W == 1:
+        if W == 1 and not force_exchange():
             return
         dev, N = g_local.device, g_local.shape[0]
         self._g_cat = torch.empty(W * N, 3, device=dev, dtype=g_local.dtype)       # ranks concatenated along dim 0
@@ -150,7 +186,10 @@ class GradientExchange:
             self._poses = torch.empty(W * A, self.actor_pose.shape[1], device=dev, dtype=torch.float32)
             self._gathers.append(dist.all_gather_into_tensor(self._poses, self.actor_pose.detach().float().contiguous(), async_op=True))
         self.num_collectives = len(self._gathers)
-        if rec.grad_slab is not None:
+        # called from inside backward() (RasterCall.on_backward): only an exclusive slab may be reduced while autograd runs; called
+        # after backward() (a replayed graph): the slab if the leaves' .grad are its views.  Otherwise the four gradients are
+        # reduced as leaf `.grad`s in finish().
+        if (slab_is_exclusive(rec) if _in_backward() else slab_holds_leaf_grads(rec)):
             gloo = dist.get_backend() == "gloo"
             op = dist.ReduceOp.SUM if (gloo or not self.average) else dist.ReduceOp.AVG
             self._slab_work = dist.all_reduce(rec.grad_slab, op=op, async_op=True)
@@ -164,7 +203,7 @@ class GradientExchange:
         W = world_size()
         g_local = rec.sh_color_grad
         works, others = [], []
-        if W == 1:
+        if W == 1 and not force_exchange():
             g_all, campos, pose = g_local[None], self.campos_local.reshape(1, 3).to(g_local.device), self.actor_pose
         else:
             N = g_local.shape[0]

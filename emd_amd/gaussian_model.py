@@ -292,6 +292,11 @@ class GaussianModel:
         inc = torch.cumsum(cols, dim=1, dtype=torch.int32).contiguous()
         n_keep, n_clone, n_split = (int(v) for v in inc[:, -1].tolist())          # the event's single host read
         if mode == L.DENSIFY_MODE_DENSIFY and n_clone == 0 and n_split == 0:
+            # nothing selected: the reference's densify_and_clone still runs densification_postfix, which clears the three statistics
+            # (gaussian_model.py:526-530) -- stale ones would leak into the next interval and into prune()'s max_radii2D test
+            for t in (getattr(self, "xyz_gradient_accum", None), getattr(self, "denom", None), getattr(self, "max_radii2D", None)):
+                if t is not None:
+                    t.zero_()
             return n_keep, 0, 0
         if mode == L.DENSIFY_MODE_PRUNE and n_keep == N:
             return n_keep, 0, 0

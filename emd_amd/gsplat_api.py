@@ -105,6 +105,10 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     if rasterize_mode != "classic" or packed or sparse_grad or distributed or radius_clip != 0.0:
         raise NotImplementedError("only the options the reference uses are served (omnire.yaml:11-18): classic, "
                                   "packed=False, sparse_grad=False, radius_clip=0")
+    if far_plane is not None and float(far_plane) < 1e10:
+        # gsplat culls Gaussians beyond far_plane; the reference never sets it (base.py:393-408 leaves the 1e10 default) and the
+        # projection kernel has no far cull -- refusing is better than silently rendering what gsplat would have dropped
+        raise NotImplementedError("far_plane < 1e10 is not served: the reference leaves gsplat's default (no far culling)")
     if render_mode not in ("RGB", "D", "ED", "RGB+D", "RGB+ED"):
         raise ValueError(render_mode)
     Cn = viewmats.shape[0]

@@ -58,12 +58,13 @@ class StreetGaussians(torch.nn.Module):
 
     def actor_pose(self, frame, step=0):
         """[A,12] pose rows for one frame, with the learned track offsets (translation and rotation about z) when the model has
-        the heads: rigid.py:519-532,547-566."""
+        the heads: rigid.py:519-532,547-566.  `frame` / `step` may be device tensors (int32 [1] / any integer [1]): the row and the
+        coarse-to-fine level are then selected on the device and the call can be replayed from a hipGraph."""
         from .motion import actor_pose_table
-        tt = trq = None
         if self.track_heads is not None:
-            tt, trq = self.track_heads(frame, self.num_frames, self._embeddings, self.dyn_ids, step)
-        return actor_pose_table(self.instances_quats, self.instances_trans, self.instances_fv, frame, tt, trq)
+            return self.track_heads.pose_table(self.instances_quats, self.instances_trans, self.instances_fv, frame, self._embeddings,
+                                               self.dyn_ids, step)
+        return actor_pose_table(self.instances_quats, self.instances_trans, self.instances_fv, frame, None, None)
 
 
 def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activations=True, deformation=None, embeddings=None,
@@ -107,17 +108,41 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         if feat_sets:
             kw["colors_extra"] = [f for _, f in feat_sets]
     if model.has_actors:
-        kw.update(actor_ids=model.actor_id, actor_pose=model.actor_pose(frame, 0 if iteration is None else int(iteration)))
+        from .motion import DeviceStep
+        it = 0 if iteration is None else (iteration if isinstance(iteration, (torch.Tensor, DeviceStep)) else int(iteration))
+        kw.update(actor_ids=model.actor_id, actor_pose=model.actor_pose(frame, it))
     image, depth, normal, weight, radii, extra = rasterizer(
         means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, raw_params=fuse_activations, record=record, **kw)
-    out = {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+    out = _RenderOutputs({"render": image, "viewspace_points": screenspace_points, "radii": radii,
            "depth": depth, "weight": weight, "normal": normal, "actor_pose": kw.get("actor_pose"), "ddict": ddict,
            "raster_call": rasterizer.last_call, "rasterizer": rasterizer,
-           "boundary": dict(means3D=means3D, opacities=opacity, scales=scales, rotations=rotations, shs=shs, raw_params=fuse_activations)}
+           "boundary": dict(means3D=means3D, opacities=opacity, scales=scales, rotations=rotations, shs=shs, raw_params=fuse_activations)})
     for (lvl, _), img in zip(feat_sets, extra or []):
         out["feat_c" if lvl == "coarse" else "feat_f"] = img
     return out
+
+
+class _RenderOutputs(dict):
+    """The dict render() returns.  `visibility_filter` (= radii > 0, gaussian_renderer/__init__.py:163) is formed when it is first
+    read: the training loop of this package feeds `radii` to the densification statistics directly
+    (dp.add_densification_stats), so a step that never looks at the mask does not launch an N-sized compare for it."""
+
+    def __missing__(self, key):
+        if key == "visibility_filter":
+            v = self["radii"] > 0
+            self[key] = v
+            return v
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == "visibility_filter" or dict.__contains__(self, key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
 
 
 def raster_settings_for(cam, bg, sh_degree, scaling_modifier=1.0, debug=False):

@@ -51,6 +51,17 @@ def interpolate_quats(q1, q2, fraction=0.5):
     return torch.where(similar[..., None], lerp, slerp)
 
 
+class DeviceStep:
+    """Training-step quantities that live on the DEVICE, for a step replayed from a hipGraph: `k_fine` (int32 [1], the
+    coarse-to-fine row count of the step, rigid.py:194-201) and `t` (float32 [1], the normalised frame time), as
+    `emd_select_step_inputs` writes them; or just `step` (an integer tensor [1]), from which k_fine is derived with torch ops.
+    Pass it wherever a python `step` / `iteration` is accepted by the track heads."""
+    __slots__ = ("step", "k_fine", "t")
+
+    def __init__(self, step=None, k_fine=None, t=None):
+        self.step, self.k_fine, self.t = step, k_fine, t
+
+
 class TrackOffsetHeads(torch.nn.Module):
     """Per-actor learned track offsets, batched over actors (rigid.py:108-122,150-246).
 
@@ -75,15 +86,17 @@ class TrackOffsetHeads(torch.nn.Module):
     def int_lininterp(self, t, init_val, final_val, until):
         return int(init_val + (final_val - init_val) * min(max(t, 0), until) / until)
 
-    def forward(self, frame, num_frames, embeddings, point_ids, step):
-        """-> (track_trans [A,3], track_rot [A,4]).  embeddings [n,4] of the actor Gaussians; point_ids [n] their actor (device
-        tensors).  One HIP launch (+ the per-actor embedding sums) forward and one backward for all actors and both levels
-        (`emd_track_heads_forward/backward`); no host synchronisation: the frame time is a by-value scalar."""
-        if self.weight.device.type != "cuda":
-            raise L.EmdError("TrackOffsetHeads needs its parameters on a ROCm device; there is no CPU path "
-                             "(the checker's restatement is oracle/torch_ref.track_offsets)")
+    def invalidate(self):
+        """Forget the cached per-actor point counts / segment starts (call after any change of the point set: densification,
+        pruning, in-place edits of point_ids).  `GaussianModel`-style stores call it from their restructuring code; the cache key
+        below also carries the tensor's version counter, so in-place edits are seen without it."""
+        self._ids_key = None
+
+    def _prepare_ids(self, point_ids):
         A = self.weight.shape[0]
-        key = (point_ids.data_ptr(), point_ids.numel(), point_ids.dtype)
+        # (the allocator may hand a NEW id tensor the address and size of the old one after a densify + prune: the key carries the
+        #  object identity and its in-place version counter as well)
+        key = (id(point_ids), point_ids._version, point_ids.data_ptr(), point_ids.numel(), point_ids.dtype)
         if getattr(self, "_ids_key", None) != key:             # ids as int32 + points per actor: constant between densifications
             ids32 = point_ids.to(torch.int32).contiguous()
             cnt = torch.zeros(A, device=ids32.device).index_add_(0, point_ids.long().clamp_min(0), (point_ids >= 0).float())
@@ -92,16 +105,61 @@ class TrackOffsetHeads(torch.nn.Module):
             seg = None
             if ids32.numel() > 0 and bool((ids32[1:] >= ids32[:-1]).all()) and int(ids32[0]) >= 0:
                 seg = torch.searchsorted(ids32, torch.arange(A + 1, device=ids32.device, dtype=torch.int32)).to(torch.int32).contiguous()
-            self._ids_key, self._ids32, self._cnt, self._seg = key, ids32, cnt, seg
+            self._ids_key, self._ids_ref, self._ids32, self._cnt, self._seg = key, point_ids, ids32, cnt, seg
+        return self._ids32, self._cnt, self._seg
+
+    def _time_and_k(self, frame, num_frames, step):
         # (frame - start_frame) / (end_frame - start_frame), rigid.py:204,241; a device frame index keeps the time on the device
-        if isinstance(frame, torch.Tensor):
+        if isinstance(step, DeviceStep) and step.t is not None:
+            t = step.t
+        elif isinstance(frame, torch.Tensor):
             t = frame.to(torch.float32) / float(max(num_frames - 1, 1))
         else:
             t = float(frame) / float(max(num_frames - 1, 1))
-        k_f = self.int_lininterp(step, self.min_embeddings, self.max_embeddings, self.c2f_temporal_iter)
+        if isinstance(step, DeviceStep):
+            k_f = step.k_fine if step.k_fine is not None else self.k_fine_from_step(step.step)
+        elif isinstance(step, torch.Tensor):        # device step counter (hipGraph replay): k_fine is evaluated on the device
+            k_f = self.k_fine_from_step(step)
+        else:
+            k_f = self.int_lininterp(step, self.min_embeddings, self.max_embeddings, self.c2f_temporal_iter)
+        return t, k_f
+
+    def k_fine_from_step(self, step_dev):
+        """int_lininterp(step, min, max, until) of a DEVICE step counter -> int32 device tensor [1] (same truncation as the host form)."""
+        s = step_dev.to(torch.float64).clamp(0, self.c2f_temporal_iter)
+        return (self.min_embeddings + (self.max_embeddings - self.min_embeddings) * s / self.c2f_temporal_iter).to(torch.int32).reshape(1)
+
+    def forward(self, frame, num_frames, embeddings, point_ids, step):
+        """-> (track_trans [A,3], track_rot [A,4]).  embeddings [n,4] of the actor Gaussians; point_ids [n] their actor (device
+        tensors).  One HIP launch (+ the per-actor embedding sums) forward and one backward for all actors and both levels
+        (`emd_track_heads_forward/backward`); no host synchronisation: the frame time is a by-value scalar."""
+        if self.weight.device.type != "cuda":
+            raise L.EmdError("TrackOffsetHeads needs its parameters on a ROCm device; there is no CPU path "
+                             "(the checker's restatement is oracle/torch_ref.track_offsets)")
+        ids32, cnt, seg = self._prepare_ids(point_ids)
+        t, k_f = self._time_and_k(frame, num_frames, step)
         return _TrackHeads.apply(self.weight, embeddings, self.track_trans_c.weight, self.track_trans_c.bias, self.track_trans_f.weight,
                                  self.track_trans_f.bias, self.track_rot_c.weight, self.track_rot_c.bias, self.track_rot_f.weight,
-                                 self.track_rot_f.bias, self._ids32, self._cnt, self._seg, t, self.min_embeddings, k_f)
+                                 self.track_rot_f.bias, ids32, cnt, seg, t, self.min_embeddings, k_f)
+
+    def pose_table(self, instances_quats, instances_trans, instances_fv, frame, embeddings, point_ids, step):
+        """The frame's [A,12] pose table WITH the learned offsets, the whole per-actor chain (embedding sums -> heads -> pose row) in
+        ONE launch each way (`emd_tracked_pose_forward/backward`) when an actor's points are contiguous (the reference's layout) and
+        the embedding is at most 8 wide; otherwise the three-launch path `actor_pose_table(..., *self(...))`.  Same values either way."""
+        if self.weight.device.type != "cuda":
+            raise L.EmdError("TrackOffsetHeads needs its parameters on a ROCm device; there is no CPU path")
+        ids32, cnt, seg = self._prepare_ids(point_ids)
+        num_frames = instances_quats.shape[0]
+        if seg is None or embeddings.shape[1] > 8 or embeddings.shape[1] == 0:
+            tt, trq = self(frame, num_frames, embeddings, point_ids, step)
+            return actor_pose_table(instances_quats, instances_trans, instances_fv, frame, tt, trq)
+        t, k_f = self._time_and_k(frame, num_frames, step)
+        if getattr(self, "_ticket", None) is None or self._ticket.device != self.weight.device:
+            self._ticket = torch.zeros(1, dtype=torch.int32, device=self.weight.device)      # zero once; every backward launch leaves it zero
+        return _TrackedPose.apply(self.weight, embeddings, self.track_trans_c.weight, self.track_trans_c.bias, self.track_trans_f.weight,
+                                  self.track_trans_f.bias, self.track_rot_c.weight, self.track_rot_c.bias, self.track_rot_f.weight,
+                                  self.track_rot_f.bias, instances_quats, instances_trans, instances_fv, ids32, cnt, seg, t,
+                                  self.min_embeddings, k_f, frame, self._ticket)
 
 
 def _stream():
@@ -114,7 +172,10 @@ class _TrackHeads(torch.autograd.Function):
         a = L.EmdTrackArgs()
         a.num_actors, a.rows, a.dim = weight.shape
         a.embed_dim, a.num_points = (emb.shape[1], emb.shape[0]) if emb is not None else (0, 0)
-        a.k_coarse, a.k_fine = int(k_c), int(k_f)
+        if isinstance(k_f, torch.Tensor):
+            a.k_coarse, a.k_fine, a.k_fine_dev = int(k_c), 1, k_f.data_ptr()
+        else:
+            a.k_coarse, a.k_fine, a.k_fine_dev = int(k_c), int(k_f), None
         if isinstance(t, torch.Tensor):
             a.t, a.t_dev = 0.0, t.data_ptr()
         else:
@@ -164,6 +225,68 @@ class _TrackHeads(torch.autograd.Function):
             g.d_head_w[h], g.d_head_b[h] = d_heads[2 * h].data_ptr(), d_heads[2 * h + 1].data_ptr()
         L.check(L.load().emd_track_heads_backward(C.byref(a), C.byref(g), _stream()), "emd_track_heads_backward")
         return (d_weight, d_emb, *d_heads, None, None, None, None, None, None)
+
+
+class _TrackedPose(torch.autograd.Function):
+    """embedding sums -> track heads -> pose row: one launch forward, one backward (csrc/embed.hip: k_tracked_pose)."""
+
+    @staticmethod
+    def forward(ctx, weight, emb, wtc, btc, wtf, btf, wrc, brc, wrf, brf, q_all, t_all, fv, ids32, cnt, seg, t, k_c, k_f, frame, ticket):
+        dev = weight.device
+        c = lambda x: x.detach().contiguous().float()
+        weight_c, emb_c, q_c, t_c = c(weight), c(emb), c(q_all), c(t_all)
+        heads = [c(x) for x in (wtc, btc, wtf, btf, wrc, brc, wrf, brf)]
+        A, E = weight_c.shape[0], emb_c.shape[1]
+        if weight_c.shape[2] + E > 64 or any(h.shape[-1] != weight_c.shape[2] + E for h in heads[0::2]):
+            raise ValueError("track heads: temporal dim + embedding dim must be <= 64 and match the head widths")
+        if q_c.shape[1] != A or t_c.shape[:2] != q_c.shape[:2]:
+            raise ValueError("pose tables must be [F, A, 4] / [F, A, 3] with A = number of temporal tables")
+        on_dev = isinstance(frame, torch.Tensor)
+        if on_dev and (frame.dtype != torch.int32 or frame.device != dev):
+            raise ValueError("a device frame index must be an int32 tensor on the tables' device")
+        valid = None if fv is None else fv.contiguous().view(torch.uint8)
+        emb_sum = torch.empty(A, max(E, 1), device=dev)
+        pose = torch.empty(A, L.ACTOR_STRIDE, device=dev, dtype=torch.float32)
+        p = _TrackedPose._args(weight_c, emb_c, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, q_c, t_c, valid, frame, pose)
+        L.check(L.load().emd_tracked_pose_forward(C.byref(p), _stream()), "emd_tracked_pose_forward")
+        ctx.save_for_backward(weight_c, emb_c, ids32, cnt, seg, emb_sum, q_c, t_c, *heads)
+        ctx.scal, ctx.valid, ctx.ticket = (t, k_c, k_f, frame), valid, ticket
+        ctx.shapes = (q_all.shape, t_all.shape)
+        return pose
+
+    @staticmethod
+    def _args(weight, emb, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, q_all, t_all, valid, frame, pose):
+        p = L.EmdTrackedPoseArgs()
+        p.track = _TrackHeads._args(weight, emb, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, None, None)
+        p.q_all, p.t_all, p.valid_all = q_all.data_ptr(), t_all.data_ptr(), L.ptr(valid)
+        p.num_frames = q_all.shape[0]
+        if isinstance(frame, torch.Tensor):
+            p.frame, p.frame_dev = 0, frame.data_ptr()
+        else:
+            p.frame, p.frame_dev = int(frame), None
+        p.pose = L.ptr(pose)
+        return p
+
+    @staticmethod
+    def backward(ctx, g_pose):
+        weight, emb, ids32, cnt, seg, emb_sum, q_all, t_all, *heads = ctx.saved_tensors
+        dev = weight.device
+        A, E, width = weight.shape[0], emb.shape[1], weight.shape[2] + emb.shape[1]
+        t, k_c, k_f, frame = ctx.scal
+        e = lambda ref: torch.empty_like(ref)
+        # every output is written in full by the kernel: nothing here is zero-filled
+        d_weight, d_emb, d_q, d_t = e(weight), e(emb), e(q_all), e(t_all)
+        d_heads = [e(h) for h in heads]
+        part = torch.empty(A * 8 * (width + 1), device=dev)
+        p = _TrackedPose._args(weight, emb, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, q_all, t_all, ctx.valid, frame, None)
+        g = L.EmdTrackedPoseGrads()
+        g.g_pose = g_pose.contiguous().float().data_ptr()
+        g.d_q_all, g.d_t_all, g.d_weight, g.d_embeddings = d_q.data_ptr(), d_t.data_ptr(), d_weight.data_ptr(), d_emb.data_ptr()
+        for h in range(4):
+            g.d_head_w[h], g.d_head_b[h] = d_heads[2 * h].data_ptr(), d_heads[2 * h + 1].data_ptr()
+        g.head_part, g.counter = part.data_ptr(), ctx.ticket.data_ptr()
+        L.check(L.load().emd_tracked_pose_backward(C.byref(p), C.byref(g), _stream()), "emd_tracked_pose_backward")
+        return (d_weight, d_emb, *d_heads, d_q.view(ctx.shapes[0]), d_t.view(ctx.shapes[1]), *([None] * 9))
 
 
 def build_actor_pose(instances_quats, instances_trans, instances_fv, cur_frame, track_trans=None, track_rot=None,

@@ -65,6 +65,11 @@ class RasterOptions:
     keep_render_grads: bool = False  # tests: keep the per-Gaussian accumulator rows of the render backward (RasterCall.render_grads, [N, 12+])
     factored_sh_grad: bool = False  # view-parallel DP: the backward leaves dL/dshs out and publishes the [N,3] factor instead
                                     # (RasterCall.sh_color_grad); emd_amd.dp rebuilds the dense, view-averaged gradient
+    wide_depth_sort: bool = False   # always use the four-pass depth sort (depths beyond 65 536 x the near plane).  The three-pass sort
+                                    # falls back to it by itself when the status word can be read (a retry in the synchronous mode,
+                                    # the next call in no_sync mode); a call captured into a hipGraph reads nothing back and keeps the
+                                    # flags it was captured with, so scenes with such depths must set this for captured steps (or
+                                    # check bit 1 of RasterCall.status after replays: an affected frame renders as background)
 
     def replace(self, **kw):
         return dataclasses.replace(self, **{k: v for k, v in kw.items() if v is not None})
@@ -77,9 +82,14 @@ RasterConfig = RasterOptions()
 class RasterCall:
     """Everything one forward (+ backward) call leaves behind besides the reference's outputs.
     `on_backward` (optional callable) is invoked with the record by the backward pass right after its kernels have been
-    enqueued: view-parallel training starts its gradient collectives there (emd_amd.dp.GradientExchange.start)."""
+    enqueued: view-parallel training starts its gradient collectives there (emd_amd.dp.GradientExchange.start).
+    `status_buffer` (optional, set by the caller before the call): an int32[4] device tensor that receives the status words instead
+    of a fresh allocation -- a fixed address for callers that replay the call from a hipGraph and read the words on the device.
+    `pair_stats` (diagnostic; an int64[2] device tensor set by the caller before backward()): the render backward adds the number of
+    (pixel, list entry) pairs it evaluated and the number that contributed (EmdBwdArgs.pair_stats)."""
     __slots__ = ("status", "num_rendered", "num_visible", "geom_ws", "bin_ws", "img_ws", "sizes", "capacity", "N", "H", "W",
-                 "flags", "settings_dev", "absgrad", "sh_color_grad", "grad_slab", "on_backward", "render_grads")
+                 "flags", "settings_dev", "absgrad", "sh_color_grad", "grad_slab", "on_backward", "render_grads", "pair_stats",
+                 "status_buffer", "slab_inputs")
 
     def __init__(self):
         for k in self.__slots__:
@@ -195,6 +205,15 @@ def _settings_values(rs):
             dev = t.device
         parts.append(t)
     tan_dev = isinstance(rs.tanfovx, torch.Tensor) and rs.tanfovx.device.type != "cpu"
+    if dev is not None and not tan_dev and all(p.device == dev and p.is_contiguous() for p in parts):
+        # the four already sit back to back in ONE device buffer in the block's order (a caller that keeps its cameras packed on the
+        # device, e.g. behind emd_select_step_inputs): hand that memory over as it is -- no concat launch
+        base, off, packed = parts[0].data_ptr(), 0, True
+        for p in parts:
+            packed = packed and p.data_ptr() == base + 4 * off
+            off += p.numel()
+        if packed and parts[0].untyped_storage().nbytes() - 4 * parts[0].storage_offset() >= 4 * off:
+            return None, parts[0].as_strided((off,), (1,))
     if dev is None and not tan_dev:
         flat = torch.cat(parts).tolist()
         return (flat[0:3], flat[3:19], flat[19:35], flat[35:38]), None
@@ -264,7 +283,9 @@ class _Rasterize(torch.autograd.Function):
         out_normal = torch.empty(3, H, W, device=dev, dtype=torch.float32) if flags & L.FLAG_NORMAL else \
             torch.zeros(3, H, W, device=dev, dtype=torch.float32)
         radii = torch.empty(N, device=dev, dtype=torch.int32)
-        status = torch.empty(4, device=dev, dtype=torch.int32)
+        status = rec.status_buffer if rec.status_buffer is not None else torch.empty(4, device=dev, dtype=torch.int32)
+        if status.dtype != torch.int32 or status.numel() != 4 or status.device != dev or not status.is_contiguous():
+            raise ValueError("RasterCall.status_buffer must be a contiguous int32[4] tensor on the call's device")
         extras = [e for e in (extra0, extra1) if e is not None]
         out_extra = [torch.empty(3, H, W, device=dev, dtype=torch.float32) for _ in extras]
 
@@ -274,7 +295,7 @@ class _Rasterize(torch.autograd.Function):
             raise L.EmdError("a rasterizer call captured into a hipGraph must be built with no_sync=True (the duplicate count cannot be read back)")
         if not capturing:
             _poll_pending(key, opts)
-        if key in _wide_depth:
+        if key in _wide_depth or opts.wide_depth_sort:
             flags |= L.FLAG_WIDE_DEPTH_SORT
         capacity = max(int(_capacity_hint.get(key, 0)), opts.min_capacity, 4 * N if key not in _capacity_hint else 0)
         a = L.EmdFwdArgs()
@@ -399,6 +420,7 @@ class _Rasterize(torch.autograd.Function):
         b.dL_dscales, b.dL_drotations, b.dL_dcov3D = L.ptr(d_sc), L.ptr(d_rot), L.ptr(d_cov)
         b.dL_dactor_pose, b.dL_dresidual_dx, b.dL_dresidual_dq = L.ptr(d_pose), L.ptr(d_rdx), L.ptr(d_rdq)
         b.dL_dsh_color = L.ptr(d_shc)
+        b.pair_stats = L.ptr(rec.pair_stats)         # diagnostic: an int64[2] device tensor set on the record before backward(), or None
         b.num_extra = nx
         for k in range(nx):
             b.colors_extra[k], b.out_extra[k] = extras[k].data_ptr(), out_extra[k].data_ptr()
@@ -485,6 +507,14 @@ class GaussianRasterizer(nn.Module):
             residual_dx = _f32c(residual_dx, "residual_dx", (3,))
             residual_dq = _f32c(residual_dq, "residual_dq", (4,))
         rec = record if record is not None else RasterCall()
+        if opts.factored_sh_grad and shs is not None and shs.requires_grad and not shs.is_leaf:
+            # the factored backward returns no dL/dshs at all (the dense gradient is rebuilt from the exchanged factors and assigned
+            # to the LEAF parameter by dp.GradientExchange.finish): anything upstream of a non-leaf `shs` would silently get no gradient
+            raise ValueError("factored_sh_grad needs `shs` to be the leaf SH parameter; with a network in front of it (shs = features + dshs) "
+                             "use the dense gradient (factored_sh_grad=False) and dp.allreduce_gradients")
+        # what the gradient slab of the backward will be carved for (dp.GradientExchange decides from these whether it may reduce the
+        # slab in place while autograd is still running)
+        rec.slab_inputs = (means3D, scales, rotations, opacities)
         extras = [] if colors_extra is None else [_f32c(e, "colors_extra", (3,)) for e in colors_extra]
         if len(extras) > L.MAX_EXTRA:
             raise ValueError(f"at most {L.MAX_EXTRA} extra colour sets per call")

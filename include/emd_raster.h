@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 17
+#define EMD_ABI_VERSION 18
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -242,7 +242,38 @@ typedef struct EmdBwdArgs {
     const float* out_extra[EMD_MAX_EXTRA];
     const float* dL_dextra[EMD_MAX_EXTRA];        /* [3,H,W] or NULL */
     float* dL_dcolors_extra[EMD_MAX_EXTRA];       /* [N,3] or NULL */
+    /* diagnostic (ABI 18): device uint64[2], ADDED to by the render backward: [0] (pixel, list entry) pairs its waves evaluated,
+     * [1] pairs that contributed (alpha >= 1/255 in front of the pixel's last contributor).  NULL in production: the counting
+     * instantiation of the kernel is only launched when the pointer is set (plain call only: no extra sets / absgrad / dL_dnormal) */
+    uint64_t* pair_stats;
 } EmdBwdArgs;
+
+/* Per-step inputs of a training step that is replayed from ONE hipGraph (ABI 18).  A captured step reads everything that changes
+ * from step to step at fixed device addresses; this op fills them from device-resident tables in one launch:
+ *   out_row[0..row_floats)  = table[sel[0]]                 e.g. the 38-float settings block of EmdFwdArgs.settings_dev
+ *   frame_out[0]            = frames[sel[0]],  t_out[0] = frame / max(num_frames - 1, 1)          (rigid.py:204,241)
+ *   k_fine_out[0]           = int(k_min + (k_max - k_min) * clamp(step, 0, k_until) / k_until)    (rigid.py:147-148,194-201)
+ *                             with step = steps[sel[0]] (or the row index when steps is NULL)
+ * and, for callers that want the device status words of every step without reading them back per step:
+ *   status_log[prev_sel[0]] = status[0..4)  (the words the step BEFORE left behind), then prev_sel[0] = sel[0].
+ * A call with sel[0] outside [0, rows) only flushes the pending status row. */
+typedef struct EmdStepSelect {
+    const int64_t* sel;              /* device [1] */
+    int32_t rows, row_floats;
+    const float* table;              /* [rows, row_floats] */
+    float* out_row;                  /* [row_floats] */
+    const int32_t* frames;           /* [rows] or NULL */
+    int32_t* frame_out;              /* [1] or NULL */
+    float* t_out;                    /* [1] or NULL */
+    int32_t num_frames;
+    int32_t k_min, k_max, k_until;
+    const int64_t* steps;            /* [rows] or NULL */
+    int32_t* k_fine_out;             /* [1] or NULL */
+    const int32_t* status;           /* [4] or NULL */
+    int32_t* status_log;             /* [rows, 4] or NULL */
+    int64_t* prev_sel;               /* device [1], -1 = nothing pending; or NULL */
+} EmdStepSelect;
+int emd_select_step_inputs(const EmdStepSelect* args, void* hip_stream);
 
 int emd_abi_version(void);
 const char* emd_last_error(void);
@@ -452,6 +483,8 @@ typedef struct EmdTrackArgs {
     int32_t k_coarse, k_fine, num_points, reserved;
     float t;                                     /* normalised frame (frame - start) / (end - start), rigid.py:204,241 */
     const float* t_dev;                          /* optional DEVICE copy of t (overrides it): hipGraph replay with a new frame */
+    const int32_t* k_fine_dev;                   /* optional DEVICE copy of k_fine (overrides it): the coarse-to-fine row count follows the
+                                                    training step (rigid.py:194-201), which a replayed graph reads from the device (ABI 18) */
     const float* weight;                         /* [A, rows, dim] */
     const float* embeddings;                     /* [num_points, embed_dim] of the actor Gaussians */
     const int32_t* point_ids;                    /* [num_points] actor of every point (-1: none) */
@@ -477,6 +510,39 @@ typedef struct EmdTrackGrads {
 
 int emd_track_heads_forward(const EmdTrackArgs* args, void* hip_stream);
 int emd_track_heads_backward(const EmdTrackArgs* args, const EmdTrackGrads* grads, void* hip_stream);
+
+/* The per-actor chain of a training step in ONE launch each way (ABI 18): embedding sums -> track heads -> pose row
+ * (= emd_track_heads_forward + emd_actor_pose_forward: RigidNodes.transform_means / transform_quats with the learned offsets,
+ * OmniRe/models/nodes/rigid.py:150-246,499-566), one 1024-thread workgroup per actor.  Needs track.segment_start (an actor's
+ * points contiguous, as the reference stores them) and embed_dim <= 8.  track.trans / track.rot are optional outputs here.
+ * The backward WRITES every output in full -- d_q_all / d_t_all are the dense [F, A, .] clip gradients (zero outside the
+ * frame), d_weight, d_embeddings, d_head_w / d_head_b -- so the caller zero-fills nothing; `head_part` is scratch of
+ * A x 8 x (dim + embed_dim + 1) floats and `counter` ONE uint32 that must be zero before the first launch and is left zero by
+ * every launch (the last workgroup to finish sums the per-actor head gradients and resets it). */
+typedef struct EmdTrackedPoseArgs {
+    EmdTrackArgs track;
+    const float* q_all;                          /* [F, A, 4] raw per-frame pose quaternions (instances_quats) */
+    const float* t_all;                          /* [F, A, 3] (instances_trans) */
+    const uint8_t* valid_all;                    /* [F, A] bytes or NULL (instances_fv) */
+    int32_t num_frames, frame;                   /* frame: row of the tables, unless frame_dev is given */
+    const int32_t* frame_dev;                    /* optional DEVICE frame index (hipGraph replay) */
+    float* pose;                                 /* out [A, EMD_ACTOR_STRIDE] */
+} EmdTrackedPoseArgs;
+
+typedef struct EmdTrackedPoseGrads {
+    const float* g_pose;                         /* [A, EMD_ACTOR_STRIDE] */
+    float* d_q_all;                              /* [F, A, 4] */
+    float* d_t_all;                              /* [F, A, 3] */
+    float* d_weight;                             /* [A, rows, dim] */
+    float* d_embeddings;                         /* [num_points, embed_dim] or NULL */
+    float* d_head_w[4];
+    float* d_head_b[4];
+    float* head_part;                            /* scratch [A, 8, dim + embed_dim + 1] */
+    uint32_t* counter;                           /* one zero-initialised word, see above */
+} EmdTrackedPoseGrads;
+
+int emd_tracked_pose_forward(const EmdTrackedPoseArgs* args, void* hip_stream);
+int emd_tracked_pose_backward(const EmdTrackedPoseArgs* args, const EmdTrackedPoseGrads* grads, void* hip_stream);
 
 typedef struct EmdDeformInArgs {
     int32_t num_points, num_freqs_x, num_freqs_t, embed_dim;

@@ -1,0 +1,39 @@
+"""-m gpu: the RCCL ("nccl") path of the gradient exchange executed for real on the one GPU of the test box -- a process group of
+world size 1 with EMD_DP_FORCE=1 (tests/dp_nccl_world1_check.py): all_reduce(AVG) of the slab, the three all_gather_into_tensor calls,
+emd_sh_grad_from_factors, a hipGraph replay with the process group alive, and the deferred path for non-leaf rasterizer inputs; plus
+bench.py --exchange-only.  (Two and more ranks over gloo on one GPU: tests/test_bench_multirank_gpu.py.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_gradient_exchange_over_rccl_with_world_size_one():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_nccl_world1_check.py")], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert any(l.startswith("OK nccl world 1") for l in p.stdout.splitlines()), p.stdout[-1500:]
+
+
+def test_bench_exchange_only_runs_the_collectives_on_one_gpu():
+    """bench.py --exchange-only under a one-rank RCCL process group (RANK / WORLD_SIZE from the environment, EMD_DP_FORCE=1)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), EMD_DP_FORCE="1", EMD_DP_INIT_WORLD1="1", RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--exchange-only", "--steps", "3", "--warmup", "1",
+                        "--gaussians", "60000", "--height", "128", "--width", "192"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["unit"] == "ms" and d["value"] > 0 and d["config"]["forced_at_world_1"] is True and d["config"]["collectives_per_step"] >= 4

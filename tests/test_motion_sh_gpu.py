@@ -240,3 +240,55 @@ def test_fused_track_heads_match_the_checker_forward_and_backward(frame, step):
     for n in hp:
         close(getattr(hd, n).weight.grad, hp[n][0].grad, n + ".weight")
         close(getattr(hd, n).bias.grad, hp[n][1].grad, n + ".bias")
+
+
+@pytest.mark.parametrize("frame,step,on_device", [(0, 0, False), (3, 12000, False), (4, 40000, True)])
+def test_one_launch_actor_chain_equals_the_three_launch_path(frame, step, on_device):
+    """emd_tracked_pose_forward/backward (embedding sums -> track heads -> pose row in ONE launch each way, round 3) against the
+    pinned three-launch path (emd_track_heads_* + emd_actor_pose_*): the pose table bit for bit (same arithmetic, no contraction in
+    either), every gradient -- temporal tables, embeddings, the eight head tensors, the dense [F, A, .] pose tables -- to rounding,
+    twice in a row (the head-gradient ticket counter must come back to zero), with host and with device-resident frame / step."""
+    z = ld("or_rigid.npz")
+    F_ = int(z["num_frames"])
+    heads = _heads_from_golden(z)
+    g = torch.Generator().manual_seed(frame + 11)
+    with torch.no_grad():
+        for lin in (heads.track_trans_c, heads.track_trans_f, heads.track_rot_c, heads.track_rot_f):
+            lin.weight.copy_(0.3 * torch.randn(lin.weight.shape, generator=g))
+            lin.bias.copy_(0.1 * torch.randn(lin.bias.shape, generator=g))
+        heads.weight.copy_(0.5 * torch.randn(heads.weight.shape, generator=g))
+    hd = heads.to(DEV)
+    A = hd.weight.shape[0]
+    ids = torch.tensor(z["point_ids"].astype(np.int64)).to(DEV)
+    assert bool((ids[1:] >= ids[:-1]).all()), "the golden stores an actor's points contiguously"
+    emb0 = torch.tensor(z["embeddings"])
+    iq0 = torch.randn(F_, A, 4, generator=g) * 1.3
+    it0 = torch.randn(F_, A, 3, generator=g)
+    fv = (torch.rand(F_, A, generator=g) > 0.2).to(DEV)
+    w = torch.randn(A, 12, generator=g).to(DEV)
+    params = [hd.weight] + [p for n in ("track_trans_c", "track_trans_f", "track_rot_c", "track_rot_f") for p in (getattr(hd, n).weight, getattr(hd, n).bias)]
+
+    def run(fused):
+        for p in params:
+            p.grad = None
+        e = emb0.to(DEV).requires_grad_(True)
+        iq, it = iq0.to(DEV).requires_grad_(True), it0.to(DEV).requires_grad_(True)
+        fr = torch.tensor([frame], dtype=torch.int32, device=DEV) if on_device else frame
+        st = torch.tensor([step], dtype=torch.int64, device=DEV) if on_device else step
+        if fused:
+            pose = hd.pose_table(iq, it, fv, fr, e, ids, st)
+        else:
+            tt, trq = hd(fr, F_, e, ids, st)
+            pose = motion.actor_pose_table(iq, it, fv, fr, tt, trq)
+        (pose * w).sum().backward()
+        return pose.detach().clone(), [e.grad.clone(), iq.grad.clone(), it.grad.clone()] + [p.grad.clone() for p in params]
+
+    ref_pose, ref_g = run(False)
+    for rep in range(2):
+        pose, got = run(True)
+        np.testing.assert_array_equal(pose.cpu().numpy(), ref_pose.cpu().numpy())
+        for a, b in zip(got, ref_g):
+            a, b = a.cpu().numpy(), b.cpu().numpy()
+            assert a.shape == b.shape
+            assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max() + 1e-7, (rep, np.abs(a - b).max(), np.abs(b).max())
+    assert int(hd._ticket.item()) == 0
