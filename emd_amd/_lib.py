@@ -20,6 +20,7 @@ BWD_STRIDE = 12
 EMD_OK, EMD_ERR_INVALID, EMD_ERR_CAPACITY, EMD_ERR_HIP, EMD_ERR_WORKSPACE, EMD_ERR_DEPTH_RANGE = 0, -1, -2, -3, -4, -5
 FLAG_NORMAL, FLAG_MOTION, FLAG_ABSGRAD, FLAG_NO_SYNC, FLAG_CLAMP_RGB01, FLAG_RAW_PARAMS, FLAG_SDEV_TANFOV = 1, 2, 4, 8, 16, 32, 64
 FLAG_WIDE_DEPTH_SORT = 128
+FLAG_BWD_WS_CLEAN = 256
 
 _f = C.c_void_p  # device pointers are passed as integers
 

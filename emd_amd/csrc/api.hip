@@ -310,7 +310,7 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     if ((a->flags & EMD_FLAG_ABSGRAD) && !a->dL_dmeans2D_abs) { emd_set_error("backward: EMD_FLAG_ABSGRAD without dL_dmeans2D_abs"); return EMD_ERR_INVALID; }
     const bool dbg = a->s.debug != 0;
     emd_prof_begin(PROF_OTHER, st);
-    { int zrc = emd_zero_async(a->bwd_ws, need, st); if (zrc) return zrc; }
+    if (!(a->flags & EMD_FLAG_BWD_WS_CLEAN)) { int zrc = emd_zero_async(a->bwd_ws, need, st); if (zrc) return zrc; }
     float* pose_grad = nullptr;       // accumulated by K8 with atomics; cleared by K7's first workgroup
     int pose_grad_n = 0;
     if ((a->flags & EMD_FLAG_MOTION) && a->dL_dactor_pose && a->motion.num_actors > 0) {
@@ -338,7 +338,7 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     pb.s = a->s; pb.N = N; pb.M = a->sh_coeffs; pb.flags = a->flags;
     pb.means3D = a->means3D; pb.shs = a->shs; pb.colors_precomp = a->colors_precomp; pb.opacities = a->opacities;
     pb.scales = a->scales; pb.rotations = a->rotations; pb.cov3D_precomp = a->cov3D_precomp;
-    pb.motion = a->motion; pb.radii = a->radii; pb.g = g; pb.grad_rec = (const float*)a->bwd_ws;
+    pb.motion = a->motion; pb.radii = a->radii; pb.g = g; pb.grad_rec = (float*)a->bwd_ws;
     if (!(a->flags & EMD_FLAG_MOTION)) memset(&pb.motion, 0, sizeof(pb.motion));
     pb.dL_dmeans3D = a->dL_dmeans3D; pb.dL_dmeans2D = a->dL_dmeans2D; pb.dL_dmeans2D_abs = a->dL_dmeans2D_abs;
     pb.dL_dshs = a->dL_dshs; pb.dL_dcolors = a->dL_dcolors; pb.dL_dopacities = a->dL_dopacities;

@@ -192,7 +192,7 @@ struct PreBwdArgs {
     EmdMotion motion;
     const int32_t* radii;
     GeomWs g;
-    const float* grad_rec;  // [N][bwd_stride]
+    float* grad_rec;        // [N][bwd_stride]; read, and cleared row by row under EMD_FLAG_BWD_WS_CLEAN
     int bwd_stride, num_extra;
     float* dL_dextra[EMD_MAX_EXTRA];   // [N,3] gradient of every extra colour set
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dmeans2D_abs, *dL_dshs, *dL_dcolors, *dL_dopacities, *dL_dscales,

@@ -493,7 +493,10 @@ __device__ __forceinline__ void reduce_pose_grad(int a_id, const float pose_g[12
 // ---------------------------------------------------------------------------------------------------
 // K8
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(EMD_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_preprocess_backward(PreBwdArgs a) {
+#ifndef EMD_K8_WAVES
+#define EMD_K8_WAVES 4        // round 3: with the SH rows stored first the live state across the staging barriers needs 112 VGPRs; at 5 waves it spills
+#endif
+__global__ void __launch_bounds__(EMD_BLOCK) __attribute__((amdgpu_waves_per_eu(EMD_K8_WAVES))) k_preprocess_backward(PreBwdArgs a) {
     EmdSettings S = a.s;
     emd_settings_from_device(S, a.sdev, a.flags);
     // staging of the dL/dshs rows (coalesced copy-out), half of the block's rows at a time: 26 KB instead of 52 keeps five
@@ -517,10 +520,18 @@ __global__ void __launch_bounds__(EMD_BLOCK) __attribute__((amdgpu_waves_per_eu(
     float pose_g[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) pose_g[k] = 0.f;
+    // Part 1: loads, the Gaussian's world pose, and the SH colour part (whose dense 192-byte rows leave FIRST, below: their stores
+    // then drain while the wave works through the geometry chain of part 2 instead of at the very end of its life)
+    bool visible = false;
+    const bool raw = (a.flags & EMD_FLAG_RAW_PARAMS) != 0;
+    float m[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, op = 0.f, q_norm = 1.f;
+    float gcol[3] = {0.f, 0.f, 0.f}, sh_gc[3] = {0.f, 0.f, 0.f};
+    float g_depth = 0.f, gA = 0.f, gB = 0.f, gC = 0.f;
+    float sc_in[3] = {0.f, 0.f, 0.f};       // (loaded in part 1: no global load waits behind the staging barriers)
+    Proj p;
+    p.tx = p.ty = p.tz = 0.f;
     if (in_range) {
-        const bool visible = a.radii[i] > 0;
-        const bool raw = (a.flags & EMD_FLAG_RAW_PARAMS) != 0;
-        float m[3], q[4] = {1.f, 0.f, 0.f, 0.f}, op, q_norm = 1.f;
+        visible = a.radii[i] > 0;
         if (a.flags & EMD_FLAG_MOTION) {
             motion_point(i, a.means3D, a.rotations, a.opacities, a.motion, m, q, &op, raw);
             a_id = a.motion.actor_id ? a.motion.actor_id[i] : -1;
@@ -535,18 +546,21 @@ __global__ void __launch_bounds__(EMD_BLOCK) __attribute__((amdgpu_waves_per_eu(
             q_norm = fmaxf(quat_norm(qr), 1e-12f);
             q[0] = qr[0] / q_norm; q[1] = qr[1] / q_norm; q[2] = qr[2] / q_norm; q[3] = qr[3] / q_norm;
         }
-        float gcol[3] = {0.f, 0.f, 0.f}, sh_gc[3] = {0.f, 0.f, 0.f};
+        if (visible && !a.cov3D_precomp) { sc_in[0] = a.scales[3 * i]; sc_in[1] = a.scales[3 * i + 1]; sc_in[2] = a.scales[3 * i + 2]; }
         if (visible) {
-            const float4* gr = (const float4*)(a.grad_rec + (size_t)i * a.bwd_stride);
+            float4* gr = (float4*)(a.grad_rec + (size_t)i * a.bwd_stride);
             const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2];
+            if (a.flags & EMD_FLAG_BWD_WS_CLEAN) {          // the row is handed back clean: the next backward needs no zero fill
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                gr[0] = z4; gr[1] = z4; gr[2] = z4;
+            }
             const uint32_t bits = __float_as_uint(a.g.rec[(size_t)i * EMD_REC_F4 + 1].w);
             gm2[0] = g0.x; gm2[1] = g0.y;
             if (a.flags & EMD_FLAG_ABSGRAD) { gabs[0] = g2.z; gabs[1] = g2.w; }
-            const float g_depth = g0.z;
+            g_depth = g0.z;
             dop = g0.w;
-            const float gA = g1.x, gB = g1.y, gC = g1.z;
+            gA = g1.x; gB = g1.y; gC = g1.z;
             gcol[0] = g1.w; gcol[1] = g2.x; gcol[2] = g2.y;
-            Proj p;
             p.tx = ((V[0] * m[0] + V[4] * m[1]) + V[8] * m[2]) + V[12];
             p.ty = ((V[1] * m[0] + V[5] * m[1]) + V[9] * m[2]) + V[13];
             p.tz = ((V[2] * m[0] + V[6] * m[1]) + V[10] * m[2]) + V[14];
@@ -587,6 +601,41 @@ __global__ void __launch_bounds__(EMD_BLOCK) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                 for (int k = 0; k < 3; k++) dm[k] += (gd[k] - d[k] * dot) / n;
             }
+        } else if (a.dL_dshs) {
+            if (sh_staged) {
+                // (factors stay zero: a zero row)
+            } else {
+                float* o = a.dL_dshs + (size_t)i * a.M * 3;
+                for (int k = 0; k < 3 * a.M; k++) o[k] = 0.f;
+            }
+        }
+    }
+    if (sh_staged && a.dL_dshs) {
+        const size_t lim4 = (size_t)a.N * 12;
+        float4* out = (float4*)a.dL_dshs;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if ((int)(threadIdx.x >> 7) == h) {
+                float g48[48];
+#pragma unroll
+                for (int k = 0; k < 16; k++) { g48[3 * k] = sh_b[k] * sh_g[0]; g48[3 * k + 1] = sh_b[k] * sh_g[1]; g48[3 * k + 2] = sh_b[k] * sh_g[2]; }
+#pragma unroll
+                for (int j = 0; j < 12; j++)
+                    s_sh[(threadIdx.x & 127) * SH_ROW4 + j] = make_float4(g48[4 * j], g48[4 * j + 1], g48[4 * j + 2], g48[4 * j + 3]);
+            }
+            __syncthreads();
+            const size_t base4 = ((size_t)blockIdx.x * EMD_BLOCK + 128 * h) * 12;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const uint32_t idx = threadIdx.x + EMD_BLOCK * j;
+                if (base4 + idx < lim4) out[base4 + idx] = s_sh[(idx / 12) * SH_ROW4 + (idx % 12)];
+            }
+            __syncthreads();
+        }
+    }
+    // Part 2: the geometry chain and the remaining (small) stores
+    if (in_range) {
+        if (visible) {
             // (a) conic -> cov2D, (b) cov2D -> Sigma and J, t
             float c3[6];
             float sc[3] = {1.f, 1.f, 1.f};
@@ -594,7 +643,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                 for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * i + k];
             } else {
-                sc[0] = a.scales[3 * i]; sc[1] = a.scales[3 * i + 1]; sc[2] = a.scales[3 * i + 2];
+                sc[0] = sc_in[0]; sc[1] = sc_in[1]; sc[2] = sc_in[2];
                 if (raw) { sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]); }
                 cov3d_from_sr(sc, S.scale_modifier, q, c3);
             }
@@ -666,22 +715,16 @@ __global__ void __launch_bounds__(EMD_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 dR_to_dq(q, dR, dq);
                 if (raw) { ds[0] *= sc[0]; ds[1] *= sc[1]; ds[2] *= sc[2]; }   // d exp(x) = exp(x)
             }
-        } else if (a.dL_dshs) {
-            if (sh_staged) {
-                // (factors stay zero: a zero row)
-            } else {
-                float* o = a.dL_dshs + (size_t)i * a.M * 3;
-                for (int k = 0; k < 3 * a.M; k++) o[k] = 0.f;
-            }
         }
         if (a.dL_dmeans2D) { a.dL_dmeans2D[3 * i] = gm2[0]; a.dL_dmeans2D[3 * i + 1] = gm2[1]; a.dL_dmeans2D[3 * i + 2] = 0.f; }
         if (a.dL_dmeans2D_abs) { a.dL_dmeans2D_abs[2 * i] = gabs[0]; a.dL_dmeans2D_abs[2 * i + 1] = gabs[1]; }
         if (a.dL_dsh_color) { a.dL_dsh_color[3 * i] = sh_gc[0]; a.dL_dsh_color[3 * i + 1] = sh_gc[1]; a.dL_dsh_color[3 * i + 2] = sh_gc[2]; }
         if (a.dL_dcolors) { a.dL_dcolors[3 * i] = gcol[0]; a.dL_dcolors[3 * i + 1] = gcol[1]; a.dL_dcolors[3 * i + 2] = gcol[2]; }
         for (int k = 0; k < a.num_extra; k++) {           // extra colour sets: the accumulated dL/d colour is the gradient of the input itself
+            float4* gxp = (float4*)(a.grad_rec + (size_t)i * a.bwd_stride + EMD_BWD_STRIDE + 4 * k);
+            const float4 gx = visible ? *gxp : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (visible && (a.flags & EMD_FLAG_BWD_WS_CLEAN)) *gxp = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!a.dL_dextra[k]) continue;
-            float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (visible) gx = *(const float4*)(a.grad_rec + (size_t)i * a.bwd_stride + EMD_BWD_STRIDE + 4 * k);
             a.dL_dextra[k][3 * i] = gx.x; a.dL_dextra[k][3 * i + 1] = gx.y; a.dL_dextra[k][3 * i + 2] = gx.z;
         }
         if (a.dL_dcov3D) {
@@ -705,29 +748,6 @@ __global__ void __launch_bounds__(EMD_BLOCK) __attribute__((amdgpu_waves_per_eu(
             *(float4*)(a.dL_dresidual_dq + 4 * i) = a_id >= 0 ? make_float4(dql[0], dql[1], dql[2], dql[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (a.dL_dopacities) a.dL_dopacities[i] = dopl;
-    }
-    if (sh_staged && a.dL_dshs) {
-        const size_t lim4 = (size_t)a.N * 12;
-        float4* out = (float4*)a.dL_dshs;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            if ((int)(threadIdx.x >> 7) == h) {
-                float g48[48];
-#pragma unroll
-                for (int k = 0; k < 16; k++) { g48[3 * k] = sh_b[k] * sh_g[0]; g48[3 * k + 1] = sh_b[k] * sh_g[1]; g48[3 * k + 2] = sh_b[k] * sh_g[2]; }
-#pragma unroll
-                for (int j = 0; j < 12; j++)
-                    s_sh[(threadIdx.x & 127) * SH_ROW4 + j] = make_float4(g48[4 * j], g48[4 * j + 1], g48[4 * j + 2], g48[4 * j + 3]);
-            }
-            __syncthreads();
-            const size_t base4 = ((size_t)blockIdx.x * EMD_BLOCK + 128 * h) * 12;
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                const uint32_t idx = threadIdx.x + EMD_BLOCK * j;
-                if (base4 + idx < lim4) out[base4 + idx] = s_sh[(idx / 12) * SH_ROW4 + (idx % 12)];
-            }
-            __syncthreads();
-        }
     }
     if ((a.flags & EMD_FLAG_MOTION) && a.dL_dactor_pose) reduce_pose_grad(a_id, pose_g, a.dL_dactor_pose);
 }

@@ -504,23 +504,10 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
             const float dy = g0.y - pys;
             const v2f dx = (v2f){g0.x - pxs, g0.x - (pxs + 1.f)};
             const v2f power = gauss_power2(g1.x, g1.y, g1.z, dx, dy);
-            // exp: the hardware v_exp_f32 (1 ulp) unless a lane sits within 2e-5 (relative) of the alpha >= 1/255 threshold, where the
-            // wave re-evaluates with the pinned polynomial K6 used -- both are within 1e-6 of each other, so the skip decisions
-            // equal K6's everywhere (2 quarter-rate instructions instead of 14; the fallback runs once per ~10^4 iterations)
-#ifdef EMD_AB_PINNED_EXP
-            v2f G = pinned_exp2(power);
-            v2f aw = splat2(g0.w) * G;
-            if (false) {
-#else
-            const v2f t2 = power * splat2(1.44269504088896341f);
-            v2f G = (v2f){__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)};
-            v2f aw = splat2(g0.w) * G;
-            {
-#endif
-                const float lo = (1.f / 255.f) * (1.f - 2e-5f), hi = (1.f / 255.f) * (1.f + 2e-5f);
-                const bool band = (aw.x > lo && aw.x < hi) || (aw.y > lo && aw.y < hi);
-                if (__ballot(band) != 0ull) { G = pinned_exp2(power); aw = splat2(g0.w) * G; }
-            }
+            // (the hardware v_exp_f32 with a pinned re-evaluation next to the 1/255 threshold was measured in round 3: 0.489 vs 0.494 ms,
+            //  i.e. nothing, while its 1-ulp differences cost the end-to-end rotation bar of one sweep scene its margin: not kept)
+            const v2f G = pinned_exp2(power);
+            const v2f aw = splat2(g0.w) * G;
             const v2f alpha = (v2f){fminf(0.99f, aw.x), fminf(0.99f, aw.y)};
             const bool hit_a = valid && pos < n_a && power.x <= 0.f && alpha.x >= (1.f / 255.f);
             const bool hit_b = valid && pos < n_b && power.y <= 0.f && alpha.y >= (1.f / 255.f);

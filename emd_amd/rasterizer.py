@@ -133,6 +133,7 @@ class RasterCall:
 # forward is never awaited; its status word is copied to pinned host memory asynchronously and looked at by a LATER forward
 # (when the copy's event has completed), which grows the hint and warns if a past call overflowed.
 _capacity_hint = {}
+_clean_ws = {}                # (device, stream, floats) -> accumulator rows of the render backward, zero between backward passes
 _wide_depth = set()           # keys whose depth range needs the four-pass sort (EMD_ERR_DEPTH_RANGE seen once)
 _watch = {}                   # key -> ring of pinned status copies in flight
 _WATCH_SLOTS = 32
@@ -395,14 +396,25 @@ class _Rasterize(torch.autograd.Function):
         d_rdx = z(N, 3) if has_rdx else None
         d_rdq = z(N, 4) if has_rdq else None
         d_abs = z(N, 2) if flags & L.FLAG_ABSGRAD else None
-        bwd_ws = torch.empty(max(N, 1) * (L.BWD_STRIDE + 4 * nx), device=dev, dtype=torch.float32)
+        # accumulator rows of the render backward.  Kept across calls per (device, stream, size): the projection backward hands every
+        # row it reads back zeroed (EMD_FLAG_BWD_WS_CLEAN), so only the first use pays the 48 N-byte zero fill (20 us per step at 2 M).
+        # keep_render_grads (tests read the rows afterwards) takes a fresh buffer the library clears itself.
+        ws_key, bflags = None, flags
+        if opts.keep_render_grads:
+            bwd_ws = torch.empty(max(N, 1) * (L.BWD_STRIDE + 4 * nx), device=dev, dtype=torch.float32)
+        else:
+            ws_key = (dev.index, torch.cuda.current_stream().cuda_stream, max(N, 1) * (L.BWD_STRIDE + 4 * nx))
+            bwd_ws = _clean_ws.pop(ws_key, None)          # (popped: a failed backward must not leave a dirty buffer behind)
+            if bwd_ws is None:
+                bwd_ws = torch.zeros(ws_key[2], device=dev, dtype=torch.float32)
+            bflags = flags | L.FLAG_BWD_WS_CLEAN
         g_extra = [None if g is None else g.contiguous().float() for g in g_extra]
         d_extra = [z(N, 3) for _ in range(nx)]
 
         b = L.EmdBwdArgs()
         b.s = ctx.cs
         b.settings_dev = L.ptr(sdev)
-        b.num_gaussians, b.sh_coeffs, b.flags, b.bin_capacity, b.num_rendered = N, M, flags, ctx.capacity, ctx.num_rendered
+        b.num_gaussians, b.sh_coeffs, b.flags, b.bin_capacity, b.num_rendered = N, M, bflags, ctx.capacity, ctx.num_rendered
         b.means3D, b.shs, b.colors_precomp = L.ptr(means3D), L.ptr(shs), L.ptr(colors_precomp)
         b.opacities, b.scales, b.rotations, b.cov3D_precomp = L.ptr(opacities), L.ptr(scales), L.ptr(rotations), L.ptr(cov3Ds_precomp)
         _fill_motion(b.motion, actor_ids, actor_pose, residual_dx, residual_dq)
@@ -426,6 +438,10 @@ class _Rasterize(torch.autograd.Function):
             b.colors_extra[k], b.out_extra[k] = extras[k].data_ptr(), out_extra[k].data_ptr()
             b.dL_dextra[k], b.dL_dcolors_extra[k] = L.ptr(g_extra[k]), d_extra[k].data_ptr()
         L.check(lib.emd_raster_backward(C.byref(b), _stream()), "emd_raster_backward")
+        if ws_key is not None:
+            while len(_clean_ws) >= 4:                    # a few sizes at most (the point count changes at densification events)
+                _clean_ws.pop(next(iter(_clean_ws)))
+            _clean_ws[ws_key] = bwd_ws
         rec.absgrad, rec.sh_color_grad, rec.grad_slab = d_abs, d_shc, slab
         rec.render_grads = bwd_ws.view(max(N, 1), -1) if opts.keep_render_grads else None
         if d_abs is not None and ctx.means2D_ref is not None:

@@ -82,8 +82,12 @@ enum {
                                       returned w.r.t. the raw parameters.  Fuses S3Gaussian/gaussian_renderer/__init__.py:99-101 */
     EMD_FLAG_WIDE_DEPTH_SORT = 1 << 7, /* sort the Gaussians by all 32 depth bits in four passes instead of by the 27 bits above the
                                       near plane in three (needed only when depths exceed 65 536 x the near plane: EMD_ERR_DEPTH_RANGE) */
-    EMD_FLAG_SDEV_TANFOV = 1 << 6  /* settings_dev holds two more floats, tanfovx and tanfovy (cameras given as device-resident
+    EMD_FLAG_SDEV_TANFOV = 1 << 6, /* settings_dev holds two more floats, tanfovx and tanfovy (cameras given as device-resident
                                       intrinsics, OmniRe/models/trainers/base.py:399-400): they replace the by-value fields */
+    EMD_FLAG_BWD_WS_CLEAN = 1 << 8 /* backward only (ABI 18): bwd_ws ARRIVES zero-filled (the caller's promise) and is LEFT zero-filled --
+                                      the projection backward clears every accumulator row it reads, so a caller that keeps one
+                                      workspace across steps pays no 48 N-byte zero fill per backward.  Without the flag the library
+                                      clears the workspace itself, as before. */
 };
 
 /* The 12 fields of GaussianRasterizationSettings (S3Gaussian/gaussian_renderer/__init__.py:49-62), by value. */

@@ -31,6 +31,15 @@ GRAD_REL_L2 = 1e-5
 END2END_ATOL_FRAC = 1e-4     # (observed worst over the 40-scene sweep and the full-size scenes: 9.3e-5 of max|ref| on one rotation entry of sweep
                              #  scene s1021 whose render gradients pass (a) and whose projection backward passes (b): pure amplification)
 END2END_REL_L2 = 1e-4
+# Round 3: that entry belongs to a nearly degenerate footprint (conic 0.1223 / 0.1265 / 0.1331, det 2.8e-4, radius 89 px).  Its
+# three conic gradients from K7 equal the oracle's to ONE ulp (-280.30725 vs -280.30728, ...), K8 on them equals the oracle's K8 on
+# them bit for bit -- and the rotation gradient still differs from the end-to-end oracle value by 6e-4 relative, because the chain
+# divides by det^2: whether that lands at 0.9 or at 1.5 of the floor above depends on the order of K7's float atomics.  No fp32
+# implementation can do better than the response of the chain to a rounding of its inputs, so the END-TO-END comparison (c) -- and
+# only (c); the per-kernel bars (a) and (b) are what they were -- additionally admits END2END_ULP_RESPONSES times the change of the
+# ORACLE's own projection backward when every render gradient it is fed moves by one fp32 ulp (measured per element, per test, on
+# the oracle; it applies to every output of that chain -- the same Gaussian's means3D entry sat at 1.17 of the strict bar).
+END2END_ULP_RESPONSES = 16.0
 # Per-actor pose gradients are sums over the thousands of Gaussians of an actor, with heavy cancellation (an actor's points pull its
 # pose in all directions: the sum can be a thousand times smaller than its terms).  A bound relative to the RESULT is meaningless
 # there; theirs is relative to the sum of the magnitudes of the terms (condition-aware): see pose_bound().
@@ -229,11 +238,17 @@ def grad_err(a, b, atol_frac=None):
     return worst, l2
 
 
-def assert_grad_close(got, ref, name, rtol=None, atol_frac=None, rel_l2=None):
+def assert_grad_close(got, ref, name, rtol=None, atol_frac=None, rel_l2=None, extra_abs=None):
     """The gradient bar of this repository (see GRAD_RTOL / GRAD_ATOL_FRAC / GRAD_REL_L2 above).  `rtol` scales all three
-    bounds together (rtol / GRAD_RTOL) for the few documented cases that need a looser bar."""
+    bounds together (rtol / GRAD_RTOL) for the few documented cases that need a looser bar.  `extra_abs` (array like ref): an
+    element-wise absolute allowance on top of the bound (the conditioned end-to-end comparison, END2END_ULP_RESPONSES)."""
     got = np.asarray(got)
     ref = np.asarray(ref)
+    if extra_abs is not None:
+        # move every element towards the reference by its allowance, then apply the ordinary bar
+        ex = np.asarray(extra_abs, np.float64).reshape(ref.shape)
+        d = np.asarray(got, np.float64).reshape(ref.shape) - np.asarray(ref, np.float64)
+        got = np.asarray(ref, np.float64) + np.sign(d) * np.maximum(np.abs(d) - ex, 0.0)
     if got.size == ref.size:
         got = got.reshape(ref.shape)
     assert got.shape == ref.shape, f"grad {name}: shape {got.shape} vs {ref.shape}"
@@ -294,15 +309,32 @@ def compare_render_grads(hip_g, orc_g, names=("mean2D", "conic", "opacity", "rgb
         assert_grad_close(hip_g[k], orc_g[k], "render:" + k)
 
 
+def moved_by_one_ulp(render_grads, seed=99):
+    """Every fp32 render gradient moved by one ulp up or down (seeded): the input of the oracle chain's rounding response
+    (END2END_ULP_RESPONSES)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for k_, v in render_grads.items():
+        if isinstance(v, np.ndarray) and v.dtype == np.float32:
+            sgn = rng.choice(np.array([-1.0, 1.0], np.float32), size=v.shape)
+            out[k_] = (v * (np.float32(1.0) + np.float32(2.0 ** -23) * sgn)).astype(np.float32)
+        else:
+            out[k_] = v
+    return out
+
+
 def compare_backward(hip, orc, rtol=None, names=None):
     gh, go = hip["grads"], orc["grads"]
     checked = []
     names = names or ("means3D", "means2D", "shs", "colors", "opacities", "scales", "rotations", "cov3D", "actor_pose",
                       "residual_dx", "residual_dq", "means2D_abs")
-    k8 = None
+    k8 = ulp = None
     if hip.get("render_grads") is not None and rtol is None:
         compare_render_grads(hip["render_grads"], go["render_grads"])                                   # (a)
         k8 = co.preprocess_backward(orc["S"], orc["scene"], orc["pre"], hip["render_grads"], hip["flags"])   # (b) reference for K8 alone
+        k8m = co.preprocess_backward(orc["S"], orc["scene"], orc["pre"], moved_by_one_ulp(hip["render_grads"]), hip["flags"])
+        ulp = {k_: np.abs(np.asarray(k8m[k_], np.float64) - np.asarray(k8[k_], np.float64)) for k_ in k8
+               if isinstance(k8.get(k_), np.ndarray) and isinstance(k8m.get(k_), np.ndarray) and k8[k_].shape == k8m[k_].shape}
     for k in names:
         if gh.get(k) is None:
             continue
@@ -311,9 +343,13 @@ def compare_backward(hip, orc, rtol=None, names=None):
         elif k in CONDITIONED and rtol is None:
             if k8 is not None:
                 assert_grad_close(gh[k], k8[k], "projection backward on the kernel's own render gradients: " + k)
-            assert_grad_close(gh[k], go[k], k, atol_frac=END2END_ATOL_FRAC, rel_l2=END2END_REL_L2)         # (c)
+            extra = END2END_ULP_RESPONSES * ulp[k].reshape(np.asarray(go[k]).shape) if (ulp is not None and k in ulp) else None
+            assert_grad_close(gh[k], go[k], k, atol_frac=END2END_ATOL_FRAC, rel_l2=END2END_REL_L2, extra_abs=extra)         # (c)
         else:
-            assert_grad_close(gh[k], go[k], k, rtol)
+            # (means3D runs through the same det^2 division as scales / rotations for a nearly degenerate footprint: the strict bar plus
+            #  the oracle chain's rounding response, see END2END_ULP_RESPONSES; zero for everything the projection backward does not amplify)
+            extra = END2END_ULP_RESPONSES * ulp[k].reshape(np.asarray(go[k]).shape) if (ulp is not None and k in ulp and rtol is None) else None
+            assert_grad_close(gh[k], go[k], k, rtol, extra_abs=extra)
         checked.append(k)
     return checked
 
@@ -410,15 +446,21 @@ def raw_params_parity(case, log_s, raw_q, logit, device="cuda:0", check_images_e
     if rtol is None:
         compare_render_grads(hg, go["render_grads"])
     k8 = through_activations(co.preprocess_backward(orc["S"], orc["scene"], orc["pre"], hg, case["flags"]))
+    k8_raw = co.preprocess_backward(orc["S"], orc["scene"], orc["pre"], hg, case["flags"])
+    k8m_raw = co.preprocess_backward(orc["S"], orc["scene"], orc["pre"], moved_by_one_ulp(hg), case["flags"])
+    k8m = through_activations(k8m_raw)
+    ulp = {k_: END2END_ULP_RESPONSES * np.abs(np.asarray(k8m[k_], np.float64) - np.asarray(k8[k_], np.float64)) for k_ in k8 if k_ in k8m}
+    ulp["means3D"] = END2END_ULP_RESPONSES * np.abs(np.asarray(k8m_raw["means3D"], np.float64) - np.asarray(k8_raw["means3D"], np.float64))
     exp = through_activations(go)
     res = {}
     got = dict(log_scales=log_s.grad.cpu().numpy(), opacity_logits=logit.grad.cpu().numpy().reshape(-1), raw_quats=raw_q.grad.cpu().numpy())
     for name in ("log_scales", "raw_quats"):
         if rtol is None:
             assert_grad_close(got[name], k8[name], "projection backward on the kernel's own render gradients: " + name)
-        res[name] = assert_grad_close(got[name], exp[name], name, rtol, atol_frac=END2END_ATOL_FRAC, rel_l2=END2END_REL_L2)
+        res[name] = assert_grad_close(got[name], exp[name], name, rtol, atol_frac=END2END_ATOL_FRAC, rel_l2=END2END_REL_L2,
+                                      extra_abs=ulp[name].reshape(np.asarray(exp[name]).shape))
     res["opacity_logits"] = assert_grad_close(got["opacity_logits"], exp["opacity_logits"], "opacity_logits", rtol)
-    res["means3D"] = assert_grad_close(means.grad.cpu().numpy(), go["means3D"], "means3D", rtol)
+    res["means3D"] = assert_grad_close(means.grad.cpu().numpy(), go["means3D"], "means3D", rtol, extra_abs=ulp["means3D"] if rtol is None else None)
     res["means2D"] = assert_grad_close(m2.grad.cpu().numpy(), go["means2D"], "means2D", rtol)
     res["shs"] = assert_grad_close(shs.grad.cpu().numpy(), go["shs"], "shs", rtol)
     if motion:
@@ -429,6 +471,6 @@ def raw_params_parity(case, log_s, raw_q, logit, device="cuda:0", check_images_e
         if rtol is None:
             assert_grad_close(rdq.grad.cpu().numpy(), k8["residual_dq"], "projection backward on the kernel's own render gradients: residual_dq")
         res["residual_dq"] = assert_grad_close(rdq.grad.cpu().numpy(), go["residual_dq"], "residual_dq", rtol, atol_frac=END2END_ATOL_FRAC,
-                                               rel_l2=END2END_REL_L2)
+                                               rel_l2=END2END_REL_L2, extra_abs=ulp["residual_dq"].reshape(np.asarray(go["residual_dq"]).shape))
     res["D"], res["V"] = orc["bin"]["D"], st["num_visible"]
     return res
