@@ -220,7 +220,7 @@ def main():
 
     from emd_amd import dp, scenes, _lib
     from emd_amd import RasterCall, RasterOptions
-    from emd_amd.model import StreetGaussians, render, l1_loss
+    from emd_amd.model import StreetGaussians, render, l1_loss, unit_gradient
     from emd_amd.motion import DeviceStep
 
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -243,6 +243,7 @@ def main():
     bg = torch.zeros(3)
     g3 = torch.Generator().manual_seed(3)
     target = torch.rand(3, H, W, generator=g3).to(dev)
+    unit = unit_gradient(dev)                # loss.backward(unit): the root gradient 1.0 as a resident tensor (no ones_like fill per step)
 
     factored = world > 1 or args.factored_sh or args.exchange_only
     # options of THIS run's rasterizer calls (an instance, handed to every call: nothing process-wide is written)
@@ -281,7 +282,7 @@ def main():
         if xchg is not None:
             xchg.actor_pose = None if out["actor_pose"] is None else out["actor_pose"].detach()   # (no reference into the autograd graph)
         loss = l1_loss(out["render"], target)
-        loss.backward()
+        loss.backward(unit)
         if xchg is not None:
             xchg.finish(model._features, model._xyz, model.active_sh_degree, other_params=params)
             rec.on_backward = None
@@ -338,7 +339,7 @@ def main():
             frame_dev = torch.zeros(1, dtype=torch.int32, device=dev)
             t_dev = torch.zeros(1, device=dev)
             kf_dev = torch.ones(1, dtype=torch.int32, device=dev)
-            status_static = torch.zeros(4, dtype=torch.int32, device=dev)          # the captured call's status words are copied here (graph-static address)
+            status_static = torch.zeros(4, dtype=torch.int32, device=dev)          # the captured call's status words (graph-static address)
             cam0 = views[0][2]
             th = model.track_heads
             k_sched = (th.min_embeddings, th.max_embeddings, th.c2f_temporal_iter) if th is not None else None
@@ -353,11 +354,11 @@ def main():
                                               world_view_transform=blk[3:19].view(4, 4), full_proj_transform=blk[19:35].view(4, 4),
                                               camera_center=blk[35:38])
                 rec_g = RasterCall()
+                rec_g.status_buffer = status_static          # the call's status words at a fixed address: the next step's select launch logs them
                 o = render(model, cam_g, blk[0:3], frame=frame_dev, iteration=DeviceStep(k_fine=kf_dev, t=t_dev), options=opts, record=rec_g)
-                l1_loss(o["render"], target).backward()
+                l1_loss(o["render"], target).backward(unit)
                 if stats is not None:
                     dp.add_densification_stats(o["viewspace_points"].grad, o["radii"], *stats)
-                status_static.copy_(o["raster_call"].status)
                 # what the gradient exchange of a multi-GPU step reads after the replay: graph-static tensors
                 gstate["rec"], gstate["campos"] = rec_g, blk[35:38]
                 gstate["pose"] = None if o["actor_pose"] is None else o["actor_pose"].detach()

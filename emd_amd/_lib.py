@@ -154,12 +154,12 @@ class EmdStepSelect(C.Structure):
 
 class EmdTrackedPoseArgs(C.Structure):
     _fields_ = [("track", EmdTrackArgs), ("q_all", _f), ("t_all", _f), ("valid_all", _f), ("num_frames", C.c_int32), ("frame", C.c_int32),
-                ("frame_dev", _f), ("pose", _f)]
+                ("frame_dev", _f), ("pose", _f), ("head_acc", _f), ("head_acc_floats", C.c_int32), ("reserved", C.c_int32)]
 
 
 class EmdTrackedPoseGrads(C.Structure):
     _fields_ = [("g_pose", _f), ("d_q_all", _f), ("d_t_all", _f), ("d_weight", _f), ("d_embeddings", _f), ("d_head_w", _f * 4),
-                ("d_head_b", _f * 4), ("head_part", _f), ("counter", _f)]
+                ("d_head_b", _f * 4)]
 
 
 MLP_MAX_BRANCHES = 6

@@ -461,9 +461,10 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
     if (gx >= 1024 || gy >= 1024) { emd_set_error("image too large: %d x %d tiles (max 1023)", gx, gy); return EMD_ERR_INVALID; }
     const int nb = (N + EMD_BLOCK - 1) / EMD_BLOCK;
     int rc;
-    // 1. visible Gaussians in depth order.  The status word is cleared first: the depth passes may raise its overflow bit 1.
+    // 1. visible Gaussians in depth order.  (The status word was cleared by K1: the depth passes may raise its overflow bit 1.)
     emd_prof_switch(PROF_PREPROCESS, PROF_SORT, st);
-    { int zrc = emd_zero_async(status, sizeof(EmdStatus), st); if (zrc) return zrc; }
+    // (the status block was cleared by K1, the launch in front of this stage; with no Gaussians there is no K1)
+    if (N <= 0) { int zrc = emd_zero_async(status, sizeof(EmdStatus), st); if (zrc) return zrc; }
     uint32_t* const sort_count = &status->reserved;          // V after the first (compacting) depth pass lives in the status block: one memset
     const bool wide = (flags & EMD_FLAG_WIDE_DEPTH_SORT) != 0;
     const int depth_passes = wide ? EMD_DEPTH_PASSES_WIDE : EMD_DEPTH_PASSES_NARROW;

@@ -339,9 +339,10 @@ __global__ void __launch_bounds__(EMD_WAVE) k_track_heads(EmdTrackArgs a, EmdTra
 // workgroup per actor runs it front to back: the forward replaces three launch-bound kernels (k_track_embed_sum_seg,
 // k_track_heads, k_actor_pose_forward: ~21 us of a 1.5 ms step), the backward replaces three more plus the two zero fills of
 // their dense outputs -- each workgroup clears what it owns (its actor's temporal table gradient and its column of the
-// [F, A, .] pose gradients) before accumulating.  Only the head parameters are shared between actors: every workgroup
-// writes its contribution to a scratch row and the last one to finish (a self-resetting ticket in `counter`) sums them, so
-// no output needs a zero fill and no float atomic crosses workgroups.  The pose arithmetic is the one of k_actor_pose_*
+// [F, A, .] pose gradients) before accumulating.  Only the head parameters are shared between actors: their gradients are
+// float atomics into a 296-float accumulator that the FORWARD launch of the same step cleared (EmdTrackedPoseArgs.head_acc; a
+// last-workgroup reduction with release / acquire fences was measured first: 28 us for the backward launch against 9), so no
+// output needs a fill launch.  The pose arithmetic is the one of k_actor_pose_*
 // (preprocess.hip), evaluated without contraction so that both produce the same bits.
 // ---------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void tp_quat_mul(const float a[4], const float b[4], float o[4]) {
@@ -403,7 +404,6 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
     __shared__ float s_part[SEG_THREADS / 64][8];
     __shared__ float s_sum[8];
     __shared__ float s_dmean[8];
-    __shared__ uint32_t s_last;
     const EmdTrackArgs& a = p.track;
     const int act = blockIdx.x, A = a.num_actors, dim = a.dim, E = a.embed_dim, width = dim + E;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -421,6 +421,8 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
         }
     }
     if (!BWD) {
+        // the accumulator the backward launch of this step adds the shared head gradients into (no fill launch, no ticket)
+        if (blockIdx.x == 0 && p.head_acc) for (int i = threadIdx.x; i < p.head_acc_floats; i += SEG_THREADS) p.head_acc[i] = 0.f;
         if (E > 0) tp_segment_sum(E, a.embeddings, lo, hi, s_part, s_sum);
         if ((int)threadIdx.x < E) a.emb_sum[(size_t)act * E + threadIdx.x] = s_sum[threadIdx.x];      // kept for the backward
     } else {
@@ -503,12 +505,16 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
             const float dth = dr[0] * (-oz) + dr[3] * ow;
             const float go[8] = {gt0, gt1, gt2, gt0, gt1, gt2, dth, dth};
             float dhc = 0.f, dhf = 0.f;
-            float* part = g.head_part + (size_t)act * 8 * (width + 1);
+            // head parameters are shared by the actors: float atomics into `head_acc`, which the FORWARD launch of this step cleared
+            // (layout = the eight head tensors back to back: w_tc, b_tc, w_tf, b_tf, w_rc, b_rc, w_rf, b_rf)
 #pragma unroll
             for (int o = 0; o < 8; o++) {
+                const int hd = o < 3 ? 0 : o < 6 ? 1 : o - 4, r = o < 3 ? o : o < 6 ? o - 3 : 0;
                 const bool coarse = o < 3 || o == 6;
-                if (lane < width) part[o * (width + 1) + lane] = go[o] * (coarse ? hc : hf);
-                if (lane == 0) part[o * (width + 1) + width] = go[o];
+                if (go[o] != 0.f) {
+                    if (lane < width) atomicAdd(g.d_head_w[hd] + r * width + lane, go[o] * (coarse ? hc : hf));
+                    if (lane == 0) atomicAdd(g.d_head_b[hd] + r, go[o]);
+                }
                 if (coarse) dhc += go[o] * wrow[o]; else dhf += go[o] * wrow[o];
             }
             if (lane < dim) {
@@ -529,26 +535,6 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
             for (int i = (lo * E) + (int)threadIdx.x; i < hi * E; i += SEG_THREADS) g.d_embeddings[i] = s_dmean[i % E];
         }
     }
-    // ---- head gradients: the last workgroup to arrive sums the per-actor rows (no zero fill, no cross-workgroup float atomics) ----
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t ticket = atomicAdd(g.counter, 1u);
-        s_last = (ticket == (uint32_t)A - 1u) ? 1u : 0u;
-        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (int idx = threadIdx.x; idx < 8 * (width + 1); idx += SEG_THREADS) {
-        const int o = idx / (width + 1), c = idx % (width + 1);
-        float sum = 0.f;
-        for (int b = 0; b < A; b++) sum += __builtin_nontemporal_load(g.head_part + ((size_t)b * 8 + o) * (width + 1) + c);
-        const int hd = o < 3 ? 0 : o < 6 ? 1 : o - 4, r = o < 3 ? o : o < 6 ? o - 3 : 0;
-        if (c < width) g.d_head_w[hd][r * width + c] = sum; else g.d_head_b[hd][r] = sum;
-    }
-    if (threadIdx.x == 0) *g.counter = 0u;          // ticket counter ready for the next launch
 }
 
 int check_track(const EmdTrackArgs* a, const char* who) {
@@ -695,7 +681,7 @@ extern "C" int emd_tracked_pose_forward(const EmdTrackedPoseArgs* p, void* hip_s
 extern "C" int emd_tracked_pose_backward(const EmdTrackedPoseArgs* p, const EmdTrackedPoseGrads* g, void* hip_stream) {
     int rc = check_tracked(p, "tracked_pose_backward");
     if (rc || p->track.num_actors == 0) return rc;
-    if (!g || !g->g_pose || !g->d_q_all || !g->d_t_all || !g->d_weight || !g->head_part || !g->counter) {
+    if (!g || !g->g_pose || !g->d_q_all || !g->d_t_all || !g->d_weight) {
         emd_set_error("tracked_pose_backward: null gradient pointer"); return EMD_ERR_INVALID;
     }
     for (int h = 0; h < 4; h++) if (!g->d_head_w[h] || !g->d_head_b[h]) { emd_set_error("tracked_pose_backward: null head gradient %d", h); return EMD_ERR_INVALID; }

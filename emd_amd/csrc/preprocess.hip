@@ -251,6 +251,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
     emd_settings_from_device(S, a.sdev, a.flags);
     const bool sh_staged = a.shs && a.M == 16;
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    // the call's four status words are cleared here (the binning kernels behind this launch raise bits in them): no launch of its own
+    if (blockIdx.x == 0 && threadIdx.x < 4 && a.status) reinterpret_cast<uint32_t*>(a.status)[threadIdx.x] = 0u;
     uint32_t touched = 0, rect = 0, dkey = 0xFFFFFFFFu;
     int radius_out = 0;
     const float* V = S.viewmatrix;

@@ -154,12 +154,10 @@ class TrackOffsetHeads(torch.nn.Module):
             tt, trq = self(frame, num_frames, embeddings, point_ids, step)
             return actor_pose_table(instances_quats, instances_trans, instances_fv, frame, tt, trq)
         t, k_f = self._time_and_k(frame, num_frames, step)
-        if getattr(self, "_ticket", None) is None or self._ticket.device != self.weight.device:
-            self._ticket = torch.zeros(1, dtype=torch.int32, device=self.weight.device)      # zero once; every backward launch leaves it zero
         return _TrackedPose.apply(self.weight, embeddings, self.track_trans_c.weight, self.track_trans_c.bias, self.track_trans_f.weight,
                                   self.track_trans_f.bias, self.track_rot_c.weight, self.track_rot_c.bias, self.track_rot_f.weight,
                                   self.track_rot_f.bias, instances_quats, instances_trans, instances_fv, ids32, cnt, seg, t,
-                                  self.min_embeddings, k_f, frame, self._ticket)
+                                  self.min_embeddings, k_f, frame)
 
 
 def _stream():
@@ -231,7 +229,7 @@ class _TrackedPose(torch.autograd.Function):
     """embedding sums -> track heads -> pose row: one launch forward, one backward (csrc/embed.hip: k_tracked_pose)."""
 
     @staticmethod
-    def forward(ctx, weight, emb, wtc, btc, wtf, btf, wrc, brc, wrf, brf, q_all, t_all, fv, ids32, cnt, seg, t, k_c, k_f, frame, ticket):
+    def forward(ctx, weight, emb, wtc, btc, wtf, btf, wrc, brc, wrf, brf, q_all, t_all, fv, ids32, cnt, seg, t, k_c, k_f, frame):
         dev = weight.device
         c = lambda x: x.detach().contiguous().float()
         weight_c, emb_c, q_c, t_c = c(weight), c(emb), c(q_all), c(t_all)
@@ -247,15 +245,17 @@ class _TrackedPose(torch.autograd.Function):
         valid = None if fv is None else fv.contiguous().view(torch.uint8)
         emb_sum = torch.empty(A, max(E, 1), device=dev)
         pose = torch.empty(A, L.ACTOR_STRIDE, device=dev, dtype=torch.float32)
-        p = _TrackedPose._args(weight_c, emb_c, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, q_c, t_c, valid, frame, pose)
+        # the shared head gradients of the backward are accumulated into this buffer, which the forward launch clears (no fill launch)
+        head_acc = torch.empty(sum(h.numel() for h in heads), device=dev) if any(ctx.needs_input_grad[:10]) else None
+        p = _TrackedPose._args(weight_c, emb_c, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, q_c, t_c, valid, frame, pose, head_acc)
         L.check(L.load().emd_tracked_pose_forward(C.byref(p), _stream()), "emd_tracked_pose_forward")
         ctx.save_for_backward(weight_c, emb_c, ids32, cnt, seg, emb_sum, q_c, t_c, *heads)
-        ctx.scal, ctx.valid, ctx.ticket = (t, k_c, k_f, frame), valid, ticket
+        ctx.scal, ctx.valid, ctx.head_acc, ctx.acc_used = (t, k_c, k_f, frame), valid, head_acc, False
         ctx.shapes = (q_all.shape, t_all.shape)
         return pose
 
     @staticmethod
-    def _args(weight, emb, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, q_all, t_all, valid, frame, pose):
+    def _args(weight, emb, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, q_all, t_all, valid, frame, pose, head_acc=None):
         p = L.EmdTrackedPoseArgs()
         p.track = _TrackHeads._args(weight, emb, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, None, None)
         p.q_all, p.t_all, p.valid_all = q_all.data_ptr(), t_all.data_ptr(), L.ptr(valid)
@@ -265,6 +265,7 @@ class _TrackedPose(torch.autograd.Function):
         else:
             p.frame, p.frame_dev = int(frame), None
         p.pose = L.ptr(pose)
+        p.head_acc, p.head_acc_floats = L.ptr(head_acc), 0 if head_acc is None else head_acc.numel()
         return p
 
     @staticmethod
@@ -274,19 +275,23 @@ class _TrackedPose(torch.autograd.Function):
         A, E, width = weight.shape[0], emb.shape[1], weight.shape[2] + emb.shape[1]
         t, k_c, k_f, frame = ctx.scal
         e = lambda ref: torch.empty_like(ref)
-        # every output is written in full by the kernel: nothing here is zero-filled
+        # dense outputs are written in full by the kernel; the head gradients are added into the accumulator the forward launch cleared
         d_weight, d_emb, d_q, d_t = e(weight), e(emb), e(q_all), e(t_all)
-        d_heads = [e(h) for h in heads]
-        part = torch.empty(A * 8 * (width + 1), device=dev)
+        acc = ctx.head_acc
+        if acc is None:
+            acc = torch.zeros(sum(h.numel() for h in heads), device=dev)
+        elif ctx.acc_used:           # a second backward through the same forward (retain_graph): the kernel's clearing happened only once
+            acc = torch.zeros_like(acc)
+        ctx.acc_used = True
+        d_heads = [v.view_as(h) for v, h in zip(torch.split(acc, [h.numel() for h in heads]), heads)]
         p = _TrackedPose._args(weight, emb, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, q_all, t_all, ctx.valid, frame, None)
         g = L.EmdTrackedPoseGrads()
         g.g_pose = g_pose.contiguous().float().data_ptr()
         g.d_q_all, g.d_t_all, g.d_weight, g.d_embeddings = d_q.data_ptr(), d_t.data_ptr(), d_weight.data_ptr(), d_emb.data_ptr()
         for h in range(4):
             g.d_head_w[h], g.d_head_b[h] = d_heads[2 * h].data_ptr(), d_heads[2 * h + 1].data_ptr()
-        g.head_part, g.counter = part.data_ptr(), ctx.ticket.data_ptr()
         L.check(L.load().emd_tracked_pose_backward(C.byref(p), C.byref(g), _stream()), "emd_tracked_pose_backward")
-        return (d_weight, d_emb, *d_heads, d_q.view(ctx.shapes[0]), d_t.view(ctx.shapes[1]), *([None] * 9))
+        return (d_weight, d_emb, *d_heads, d_q.view(ctx.shapes[0]), d_t.view(ctx.shapes[1]), *([None] * 8))
 
 
 def build_actor_pose(instances_quats, instances_trans, instances_fv, cur_frame, track_trans=None, track_rot=None,

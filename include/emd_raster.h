@@ -519,10 +519,10 @@ int emd_track_heads_backward(const EmdTrackArgs* args, const EmdTrackGrads* grad
  * (= emd_track_heads_forward + emd_actor_pose_forward: RigidNodes.transform_means / transform_quats with the learned offsets,
  * OmniRe/models/nodes/rigid.py:150-246,499-566), one 1024-thread workgroup per actor.  Needs track.segment_start (an actor's
  * points contiguous, as the reference stores them) and embed_dim <= 8.  track.trans / track.rot are optional outputs here.
- * The backward WRITES every output in full -- d_q_all / d_t_all are the dense [F, A, .] clip gradients (zero outside the
- * frame), d_weight, d_embeddings, d_head_w / d_head_b -- so the caller zero-fills nothing; `head_part` is scratch of
- * A x 8 x (dim + embed_dim + 1) floats and `counter` ONE uint32 that must be zero before the first launch and is left zero by
- * every launch (the last workgroup to finish sums the per-actor head gradients and resets it). */
+ * The backward WRITES d_q_all / d_t_all (the dense [F, A, .] clip gradients, zero outside the frame), d_weight and d_embeddings in
+ * full and ADDS the head gradients into d_head_w / d_head_b, which must be views of the `head_acc` buffer the FORWARD call of the
+ * same step was given (it clears those head_acc_floats floats): the caller zero-fills nothing.  A second backward through one
+ * forward must clear head_acc itself. */
 typedef struct EmdTrackedPoseArgs {
     EmdTrackArgs track;
     const float* q_all;                          /* [F, A, 4] raw per-frame pose quaternions (instances_quats) */
@@ -531,6 +531,8 @@ typedef struct EmdTrackedPoseArgs {
     int32_t num_frames, frame;                   /* frame: row of the tables, unless frame_dev is given */
     const int32_t* frame_dev;                    /* optional DEVICE frame index (hipGraph replay) */
     float* pose;                                 /* out [A, EMD_ACTOR_STRIDE] */
+    float* head_acc;                             /* forward: cleared (may be NULL when no backward will follow) */
+    int32_t head_acc_floats, reserved;
 } EmdTrackedPoseArgs;
 
 typedef struct EmdTrackedPoseGrads {
@@ -539,10 +541,8 @@ typedef struct EmdTrackedPoseGrads {
     float* d_t_all;                              /* [F, A, 3] */
     float* d_weight;                             /* [A, rows, dim] */
     float* d_embeddings;                         /* [num_points, embed_dim] or NULL */
-    float* d_head_w[4];
+    float* d_head_w[4];                          /* accumulated into: views of the forward's head_acc */
     float* d_head_b[4];
-    float* head_part;                            /* scratch [A, 8, dim + embed_dim + 1] */
-    uint32_t* counter;                           /* one zero-initialised word, see above */
 } EmdTrackedPoseGrads;
 
 int emd_tracked_pose_forward(const EmdTrackedPoseArgs* args, void* hip_stream);

@@ -247,7 +247,7 @@ def test_one_launch_actor_chain_equals_the_three_launch_path(frame, step, on_dev
     """emd_tracked_pose_forward/backward (embedding sums -> track heads -> pose row in ONE launch each way, round 3) against the
     pinned three-launch path (emd_track_heads_* + emd_actor_pose_*): the pose table bit for bit (same arithmetic, no contraction in
     either), every gradient -- temporal tables, embeddings, the eight head tensors, the dense [F, A, .] pose tables -- to rounding,
-    twice in a row (the head-gradient ticket counter must come back to zero), with host and with device-resident frame / step."""
+    twice in a row, with host and with device-resident frame / step."""
     z = ld("or_rigid.npz")
     F_ = int(z["num_frames"])
     heads = _heads_from_golden(z)
@@ -291,4 +291,3 @@ def test_one_launch_actor_chain_equals_the_three_launch_path(frame, step, on_dev
             a, b = a.cpu().numpy(), b.cpu().numpy()
             assert a.shape == b.shape
             assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max() + 1e-7, (rep, np.abs(a - b).max(), np.abs(b).max())
-    assert int(hd._ticket.item()) == 0
