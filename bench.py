@@ -174,7 +174,7 @@ CONFIGS = {
 
 
 def select_step_inputs(sel, table, out_row, frames=None, frame_out=None, t_out=None, num_frames=1, k_sched=None, k_fine_out=None,
-                       status=None, status_log=None, prev_sel=None):
+                       status=None, status_log=None, prev_sel=None, next_sel=None):
     """emd_select_step_inputs: everything a replayed step reads at fixed device addresses, written by ONE launch."""
     import ctypes as C
     from emd_amd import _lib as L
@@ -184,7 +184,7 @@ def select_step_inputs(sel, table, out_row, frames=None, frame_out=None, t_out=N
     a.frames, a.frame_out, a.t_out, a.num_frames = L.ptr(frames), L.ptr(frame_out), L.ptr(t_out), int(num_frames)
     a.k_min, a.k_max, a.k_until = k_sched if k_sched is not None else (1, 1, 1)
     a.steps, a.k_fine_out = None, L.ptr(k_fine_out)
-    a.status, a.status_log, a.prev_sel = L.ptr(status), L.ptr(status_log), L.ptr(prev_sel)
+    a.status, a.status_log, a.prev_sel, a.next_sel = L.ptr(status), L.ptr(status_log), L.ptr(prev_sel), L.ptr(next_sel)
     L.check(L.load().emd_select_step_inputs(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_select_step_inputs")
 
 
@@ -335,6 +335,8 @@ def main():
             frame_of = torch.tensor([f_ for f_, _, _ in views], dtype=torch.int32, device=dev)
             sel = torch.zeros(1, dtype=torch.int64, device=dev)
             prev_sel = torch.full((1,), -1, dtype=torch.int64, device=dev)
+            # successor of every row: the launch advances `sel` itself (the repeats replay the timed views: last timed row -> first)
+            next_row = torch.tensor([r_ + 1 if r_ + 1 < period else args.warmup for r_ in range(period)], dtype=torch.int64, device=dev)
             blk = torch.zeros(38, device=dev)
             frame_dev = torch.zeros(1, dtype=torch.int32, device=dev)
             t_dev = torch.zeros(1, device=dev)
@@ -349,7 +351,7 @@ def main():
                     p.grad = None
                 # (the row index doubles as the training step of the coarse-to-fine schedule, as the eager step passes it)
                 select_step_inputs(sel, blocks, blk, frame_of, frame_dev, t_dev, num_frames, k_sched, kf_dev if th is not None else None,
-                                   status_static, status_log, prev_sel)
+                                   status_static, status_log, prev_sel, next_row)
                 cam_g = types.SimpleNamespace(image_height=H, image_width=W, tanfovx=cam0.tanfovx, tanfovy=cam0.tanfovy,
                                               world_view_transform=blk[3:19].view(4, 4), full_proj_transform=blk[19:35].view(4, 4),
                                               camera_center=blk[35:38])
@@ -377,6 +379,7 @@ def main():
             with torch.cuda.graph(graph, stream=side, capture_error_mode="global" if world == 1 else "thread_local"):
                 graph_body()
             torch.cuda.synchronize()
+            sel.fill_(0)                                      # the first replay renders row 0; every replay leaves the next row in `sel`
         except Exception as e:          # capture is an optimisation of the host side only: fall back to issuing the step from Python
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
@@ -386,8 +389,7 @@ def main():
 
     def timed_step(step):
         if graph is not None:
-            sel.fill_(row_of(step))
-            graph.replay()
+            graph.replay()                                    # (`sel` was advanced to row_of(step) by the replay before)
             if opts.factored_sh_grad:
                 # the exchange is issued behind the replay (RCCL collectives are not captured): what follows K8 inside the graph is
                 # one ~8 us launch of the actor chain's backward, so nothing is lost against starting it from inside backward()

@@ -149,7 +149,8 @@ class EmdTrackGrads(C.Structure):
 class EmdStepSelect(C.Structure):
     _fields_ = [("sel", _f), ("rows", C.c_int32), ("row_floats", C.c_int32), ("table", _f), ("out_row", _f), ("frames", _f),
                 ("frame_out", _f), ("t_out", _f), ("num_frames", C.c_int32), ("k_min", C.c_int32), ("k_max", C.c_int32),
-                ("k_until", C.c_int32), ("steps", _f), ("k_fine_out", _f), ("status", _f), ("status_log", _f), ("prev_sel", _f)]
+                ("k_until", C.c_int32), ("steps", _f), ("k_fine_out", _f), ("status", _f), ("status_log", _f), ("prev_sel", _f),
+                ("next_sel", _f)]
 
 
 class EmdTrackedPoseArgs(C.Structure):

@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_select_step_inputs(EmdStepSelect a
     for (int j = lane; j < a.row_floats; j += EMD_WAVE) a.out_row[j] = a.table[(size_t)row * a.row_floats + j];
     if (lane == 0) {
         if (a.prev_sel) a.prev_sel[0] = row;
+        if (a.next_sel) a.sel[0] = a.next_sel[row];           // the row of the NEXT launch: a replay loop then needs no host-side write at all
         if (a.frames && a.frame_out) {
             const int f = a.frames[row];
             a.frame_out[0] = f;

@@ -245,7 +245,10 @@ __device__ __forceinline__ void sh_row_load(const float* __restrict__ shs, int i
 // colour Jacobian and the record stores.  Twelve independent 13 KB workgroups per CU overlap these phases.
 // ---------------------------------------------------------------------------------------------------
 #define PRE_BLOCK 64
-__global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_preprocess(PreArgs a) {
+#ifndef EMD_K1_WAVES
+#define EMD_K1_WAVES 5
+#endif
+__global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(EMD_K1_WAVES))) k_preprocess(PreArgs a) {
     __shared__ float4 s_sh[(PRE_BLOCK / 2) * SH_ROW4];       // half of the wave's rows at a time: 6.5 KB keeps four waves per SIMD
     EmdSettings S = a.s;
     emd_settings_from_device(S, a.sdev, a.flags);

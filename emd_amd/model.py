@@ -43,6 +43,9 @@ class StreetGaussians(torch.nn.Module):
             g = torch.Generator().manual_seed(track_seed)
             heads = TrackOffsetHeads(A)
             with torch.no_grad():
+                # (the temporal tables too: the module's own initialiser draws from the process-wide generator, which made the actor
+                #  poses -- and with them V and D of a benchmark run -- differ by a few counts from process to process)
+                heads.weight.copy_(torch.randn(heads.weight.shape, generator=g) * 0.01 / heads.weight.shape[2] ** 0.5)
                 for lin, sc in ((heads.track_trans_c, 0.05), (heads.track_trans_f, 0.05), (heads.track_rot_c, 0.01), (heads.track_rot_f, 0.01)):
                     lin.weight.copy_(sc * torch.randn(lin.weight.shape, generator=g))
             self.track_heads = heads.to(device)

@@ -260,9 +260,10 @@ typedef struct EmdBwdArgs {
  *                             with step = steps[sel[0]] (or the row index when steps is NULL)
  * and, for callers that want the device status words of every step without reading them back per step:
  *   status_log[prev_sel[0]] = status[0..4)  (the words the step BEFORE left behind), then prev_sel[0] = sel[0].
- * A call with sel[0] outside [0, rows) only flushes the pending status row. */
+ * A call with sel[0] outside [0, rows) only flushes the pending status row.  With next_sel the launch finally sets sel[0] =
+ * next_sel[row]: a loop of graph replays walks a schedule of rows without the host touching device memory between replays. */
 typedef struct EmdStepSelect {
-    const int64_t* sel;              /* device [1] */
+    int64_t* sel;                    /* device [1]: the row to select; with next_sel it is advanced to next_sel[row] by the launch */
     int32_t rows, row_floats;
     const float* table;              /* [rows, row_floats] */
     float* out_row;                  /* [row_floats] */
@@ -276,6 +277,7 @@ typedef struct EmdStepSelect {
     const int32_t* status;           /* [4] or NULL */
     int32_t* status_log;             /* [rows, 4] or NULL */
     int64_t* prev_sel;               /* device [1], -1 = nothing pending; or NULL */
+    const int64_t* next_sel;         /* [rows] or NULL: successor of every row */
 } EmdStepSelect;
 int emd_select_step_inputs(const EmdStepSelect* args, void* hip_stream);
 
