@@ -46,6 +46,9 @@ struct BinWs {
     uint32_t* tile_order;    // [T] tile ids by descending list length: dispatch order of the render kernels
     uint32_t* hist;          // radix histograms [bins][num_sort_blocks]
     uint32_t* slot_start;    // [ceil(capacity / 2048)] first block of Gaussians of every output block of the duplicate kernel
+    uint32_t* surv;          // [4 * capacity] per (tile, quadrant): the Gaussian ids of the list entries whose footprint reaches the quadrant, in
+                             //   list order, written by the render forward for the render backward (at 4 * range start + quadrant * list length)
+    uint32_t* quad_need;     // [4 * T] how many of them lie in front of the quadrant's deepest contributor (what the backward walks)
     int sorted_buf;          // which ping-pong buffer holds the sorted list after forward (fixed by #passes)
     size_t bytes;
 };
@@ -118,6 +121,8 @@ static inline void emd_carve_bin(void* base, int64_t capacity, int num_tiles, Bi
     size_t nsb = (cap + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
     w->hist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_RADIX_BINS * 4, 256);
     w->slot_start = (uint32_t*)(p + off); off = emd_align_up(off + (nsb + 1) * 4, 256);
+    w->surv = (uint32_t*)(p + off); off = emd_align_up(off + cap * 16, 256);
+    w->quad_need = (uint32_t*)(p + off); off = emd_align_up(off + (size_t)num_tiles * 16, 256);
     w->sorted_buf = emd_tile_passes(num_tiles) & 1;
     w->bytes = off + 256;
 }

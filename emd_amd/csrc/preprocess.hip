@@ -498,21 +498,25 @@ __device__ __forceinline__ void reduce_pose_grad(int a_id, const float pose_g[12
 // ---------------------------------------------------------------------------------------------------
 // K8
 // ---------------------------------------------------------------------------------------------------
+#ifndef K8_BLOCK
+#define K8_BLOCK 256          // threads per workgroup of K8 (A/B: 64 = one wave per workgroup, no cross-wave barrier coupling)
+#endif
+#define K8_HALF (K8_BLOCK / 2)
 #ifndef EMD_K8_WAVES
 #define EMD_K8_WAVES 4        // round 3: with the SH rows stored first the live state across the staging barriers needs 112 VGPRs; at 5 waves it spills
 #endif
-__global__ void __launch_bounds__(EMD_BLOCK) __attribute__((amdgpu_waves_per_eu(EMD_K8_WAVES))) k_preprocess_backward(PreBwdArgs a) {
+__global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(EMD_K8_WAVES))) k_preprocess_backward(PreBwdArgs a) {
     EmdSettings S = a.s;
     emd_settings_from_device(S, a.sdev, a.flags);
     // staging of the dL/dshs rows (coalesced copy-out), half of the block's rows at a time: 26 KB instead of 52 keeps five
     // workgroup-waves per SIMD resident instead of three.  A row is the outer product basis[k] x gc[c]: the lane keeps the 19 factors
     // and multiplies them out when its half is staged.
-    __shared__ float4 s_sh[(EMD_BLOCK / 2) * SH_ROW4];
+    __shared__ float4 s_sh[K8_HALF * SH_ROW4];
     float sh_b[16], sh_g[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 16; k++) sh_b[k] = 0.f;
     const bool sh_staged = a.shs && a.M == 16;
-    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    const int i = blockIdx.x * K8_BLOCK + threadIdx.x;
     const bool in_range = i < a.N;
     const float* V = S.viewmatrix;
     const float* P = S.projmatrix;
@@ -620,19 +624,19 @@ __global__ void __launch_bounds__(EMD_BLOCK) __attribute__((amdgpu_waves_per_eu(
         float4* out = (float4*)a.dL_dshs;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            if ((int)(threadIdx.x >> 7) == h) {
+            if ((int)(threadIdx.x / K8_HALF) == h) {
                 float g48[48];
 #pragma unroll
                 for (int k = 0; k < 16; k++) { g48[3 * k] = sh_b[k] * sh_g[0]; g48[3 * k + 1] = sh_b[k] * sh_g[1]; g48[3 * k + 2] = sh_b[k] * sh_g[2]; }
 #pragma unroll
                 for (int j = 0; j < 12; j++)
-                    s_sh[(threadIdx.x & 127) * SH_ROW4 + j] = make_float4(g48[4 * j], g48[4 * j + 1], g48[4 * j + 2], g48[4 * j + 3]);
+                    s_sh[(threadIdx.x % K8_HALF) * SH_ROW4 + j] = make_float4(g48[4 * j], g48[4 * j + 1], g48[4 * j + 2], g48[4 * j + 3]);
             }
             __syncthreads();
-            const size_t base4 = ((size_t)blockIdx.x * EMD_BLOCK + 128 * h) * 12;
+            const size_t base4 = ((size_t)blockIdx.x * K8_BLOCK + K8_HALF * h) * 12;
 #pragma unroll
             for (int j = 0; j < 6; j++) {
-                const uint32_t idx = threadIdx.x + EMD_BLOCK * j;
+                const uint32_t idx = threadIdx.x + K8_BLOCK * j;
                 if (base4 + idx < lim4) out[base4 + idx] = s_sh[(idx / 12) * SH_ROW4 + (idx % 12)];
             }
             __syncthreads();
@@ -1091,8 +1095,8 @@ int emd_launch_preprocess(const PreArgs& a, hipStream_t st) {
 
 int emd_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t st) {
     if (a.N <= 0) return EMD_OK;
-    const int nb = (a.N + EMD_BLOCK - 1) / EMD_BLOCK;
-    hipLaunchKernelGGL(k_preprocess_backward, dim3(nb), dim3(EMD_BLOCK), 0, st, a);
+    const int nb = (a.N + K8_BLOCK - 1) / K8_BLOCK;
+    hipLaunchKernelGGL(k_preprocess_backward, dim3(nb), dim3(K8_BLOCK), 0, st, a);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

@@ -209,7 +209,8 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
                                                                const float4* __restrict__ rec, float* __restrict__ out_color,
                                                                float* __restrict__ out_depth, float* __restrict__ out_normal,
                                                                float* __restrict__ out_alpha, float* __restrict__ final_T,
-                                                               uint32_t* __restrict__ n_contrib) {
+                                                               uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ surv,
+                                                               uint32_t* __restrict__ quad_need) {
 #pragma clang fp contract(off)   // the forward image is a bit-exact contract: only the explicit fma calls below fuse
     __shared__ float4 s0[FQ_RING], s1[FQ_RING], s2[FQ_RING];
     __shared__ float4 s3[NORMAL ? FQ_RING : 1];
@@ -238,14 +239,21 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
     float4 px_[NX ? NX : 1];
 #pragma unroll
     for (int k = 0; k < (NX ? NX : 1); k++) px_[k] = zero4;
+    uint32_t pgid = 0;
     if (lane < n_tile) {
         const uint32_t gid = point_list[start + lane];
+        pgid = gid;
         const float4* r = rec + (size_t)gid * EMD_REC_F4;
         p0 = r[0]; p1 = r[1]; p2 = r[2];
         if (NORMAL) p3 = r[3];
 #pragma unroll
         for (int k = 0; k < NX; k++) { const float* c = d.xcol[k] + 3 * (size_t)gid; px_[k] = make_float4(c[0], c[1], c[2], 0.f); }
     }
+    // The entries that pass the quadrant test ("survivors") are numbered in list order and their Gaussian ids written out: the
+    // backward walks exactly this list (no second scan of the tile list, no second footprint test there), and a pixel's
+    // n_contrib is the NUMBER of the last survivor that contributed to it (1-based), not its position in the tile list.
+    uint32_t* const sv = surv + 4 * (size_t)start + (size_t)quad * n_tile;
+    uint32_t total = 0;
     uint32_t scanned = 0;
     while (scanned < n_tile) {
         if (__ballot(!done) == 0ull) break;
@@ -258,29 +266,29 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
             float4 cxr[NX ? NX : 1];
 #pragma unroll
             for (int k = 0; k < NX; k++) cxr[k] = px_[k];
+            const uint32_t cgid = pgid;
             if (idx + EMD_WAVE < n_tile) {
                 const uint32_t gid = point_list[start + idx + EMD_WAVE];
+                pgid = gid;
                 const float4* r = rec + (size_t)gid * EMD_REC_F4;
                 p0 = r[0]; p1 = r[1]; p2 = r[2];
                 if (NORMAL) p3 = r[3];
 #pragma unroll
                 for (int k = 0; k < NX; k++) { const float* c = d.xcol[k] + 3 * (size_t)gid; px_[k] = make_float4(c[0], c[1], c[2], 0.f); }
             }
-#ifdef EMD_AB_BOX_CULL          // A/B build (scratch/mkvariant.sh): round 2's bounding-box tests
-            const bool keep = idx < n_tile && quad_subblock_mask(c0r, c1r, qx0, qy0) != 0u;
-#else
             const bool keep = idx < n_tile && ellipse_hits_rect(ellipse_prepare(c0r, c1r), qx0, qx0 + 7.f, qy0, qy0 + 7.f);
-#endif
             const unsigned long long bal = __ballot(keep);
-            const uint32_t slot = head + (uint32_t)__popcll(bal & lt);
+            const uint32_t rank = (uint32_t)__popcll(bal & lt), slot = head + rank;
             if (keep) {
-                c2r.w = __uint_as_float(idx + 1);           // 1-based position in the tile list
+                sv[total + rank] = cgid;
+                c2r.w = __uint_as_float(total + rank + 1);          // 1-based number of this survivor in the quadrant's list
                 s0[slot] = c0r; s1[slot] = c1r; s2[slot] = c2r;
                 if (NORMAL) s3[slot] = c3r;
 #pragma unroll
                 for (int k = 0; k < NX; k++) sx[k][slot] = cxr[k];
             }
             head += (uint32_t)__popcll(bal);
+            total += (uint32_t)__popcll(bal);
             scanned += EMD_WAVE;
         }
         __syncthreads();
@@ -288,11 +296,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
         for (uint32_t base = 0; base < head; base += EMD_WAVE) {
             const uint32_t slot = base + lane;
             uint32_t m4 = 0u;
-#ifdef EMD_AB_BOX_CULL
-            if (slot < head) m4 = quad_subblock_mask(s0[slot], s1[slot], qx0, qy0);
-#else
             if (slot < head) m4 = ellipse_subblock_mask(s0[slot], s1[slot], qx0, qy0);
-#endif
             const unsigned long long b0 = __ballot(m4 & 1u), b1 = __ballot(m4 & 2u), b2 = __ballot(m4 & 4u), b3 = __ballot(m4 & 8u);
             if (m4 & 1u) s_list[0][len0 + (uint32_t)__popcll(b0 & lt)] = (uint8_t)slot;
             if (m4 & 2u) s_list[1][len1 + (uint32_t)__popcll(b1 & lt)] = (uint8_t)slot;
@@ -358,6 +362,10 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
         final_T[pix] = T;
         n_contrib[pix] = last;
     }
+    // what the backward needs of the survivor list: everything up to the quadrant's deepest contributor
+    uint32_t need = inside ? last : 0u;
+    for (int off = 32; off; off >>= 1) need = max(need, (uint32_t)__shfl_xor((int)need, off));
+    if (lane == 0) quad_need[4 * tile + quad] = need;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -395,7 +403,8 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
 
 template <bool NORMAL, bool ABS, int NX, bool STATS = false>
 __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(NX == 0 ? 4 : NX == 1 ? 3 : 2))) k_render_backward_q(RenderDims d, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ ranges,
-                                                                const uint32_t* __restrict__ point_list,
+                                                                const uint32_t* __restrict__ surv,
+                                                                const uint32_t* __restrict__ quad_need,
                                                                 const float4* __restrict__ rec,
                                                                 const float* __restrict__ final_T,
                                                                 const uint32_t* __restrict__ n_contrib,
@@ -412,14 +421,14 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
     // the tiny actor-pose gradient table K8 accumulates into is cleared here (K8 starts after this kernel): no memset launch
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < zero_n; i += EMD_WAVE) zero_buf[i] = 0.f;
-    // queue slot s lives in half s>>6: the gradient staging tile (64 rows x 12 floats = 3 KB) overlays the records of
-    // the lower half, which are dead (held in registers) by the time a batch's gradients are staged.
-    constexpr int NRB = NORMAL ? 4 : 3, NR = NRB + NX;           // record planes: r0, r1, r2 (, r3), one per extra colour set
+    // Round 3: the forward pass leaves, per quadrant, the ids of the entries whose footprint reaches it ("survivors", in list
+    // order) and the number of them in front of its deepest contributor.  The backward walks that list back to front, 64 survivors
+    // per batch, every lane keeping ITS entry's record in registers: no scan of the tile list, no footprint test, no queue.
     constexpr int STRIDE = EMD_BWD_STRIDE + 4 * NX;             // accumulator row: 12 floats + (r, g, b, -) per extra set
     constexpr int PB = NORMAL ? 6 : 4;                          // s_pix planes of the main call; two more per extra set
-    __shared__ float4 q_rec[2][NR][EMD_WAVE];
-    __shared__ uint32_t q_id[BQ_QUEUE], q_pos[BQ_QUEUE];
-    float* const s_stage = reinterpret_cast<float*>(&q_rec[0][0][0]);
+    __shared__ float4 s_stage4[EMD_WAVE * STRIDE / 4];          // gradient staging tile: 64 rows x STRIDE floats
+    __shared__ uint32_t q_id[EMD_WAVE];
+    float* const s_stage = reinterpret_cast<float*>(s_stage4);
     // per-pixel constants and running state, read back as wave-uniform (broadcast) LDS loads in the pixel loop: keeps
     // ~15 v_readlane / v_mov / v_cndmask per pixel-iteration off the VALU, which is what bounds this kernel.
     // Pixels are handled in horizontal pairs (a, b) = (2 pp, 2 pp + 1); every quantity is stored as the pair:
@@ -427,7 +436,6 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
     //   [pp][3] = (Q a,b | -)          [pp][4] = (dN0 a,b | dN1 a,b) [pp][5] = (dN2 a,b | -)
     //   [pp][PB + 2k] = (dX_k0 a,b | dX_k1 a,b)  [pp][PB + 2k + 1] = (dX_k2 a,b | -)     gradients of extra colour set k
     __shared__ float4 s_pix[EMD_WAVE / 2][PB + 2 * NX];
-#define QREC(r, s) q_rec[(s) >> 6][r][(s) & 63]
     uint32_t quad;
     const uint32_t tile = ordered_quadrant_block(blockIdx.x, (uint32_t)(d.gx * d.gy), tile_order, &quad);
     if (tile >= (uint32_t)(d.gx * d.gy)) return;
@@ -436,13 +444,12 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
     const float qx0 = tile_x0 + (float)((quad & 1) * 8), qy0 = tile_y0 + (float)((quad >> 1) * 8);
     const int px = (int)qx0 + (int)(lane & 7), py = (int)qy0 + (int)(lane >> 3);
     const bool inside = px < d.W && py < d.H;
-    const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
-    const size_t HW = (size_t)d.H * d.W, pix = (size_t)py * d.W + px;
-    const uint32_t my_n = inside ? n_contrib[pix] : 0u;
-    uint32_t wave_n = my_n;
-    for (int off = 32; off; off >>= 1) wave_n = max(wave_n, (uint32_t)__shfl_xor((int)wave_n, off));
-    wave_n = min(wave_n, end - start);       // deepest contributor of THIS quadrant
+    const uint32_t start = ranges[2 * tile], n_tile = ranges[2 * tile + 1] - start;
+    const uint32_t wave_n = min(quad_need[4 * tile + quad], n_tile);       // survivors in front of this quadrant's deepest contributor
     if (wave_n == 0) return;
+    const uint32_t* const sv = surv + 4 * (size_t)start + (size_t)quad * n_tile;
+    const size_t HW = (size_t)d.H * d.W, pix = (size_t)py * d.W + px;
+    const uint32_t my_n = inside ? n_contrib[pix] : 0u;                    // 1-based number of the last survivor that contributed to this pixel
     float dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dN0 = 0.f, dN1 = 0.f, dN2 = 0.f, Q = 0.f, Tf = 1.f;
     float dX[NX ? NX : 1][3];
 #pragma unroll
@@ -478,21 +485,14 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
     // STATS (diagnostic instantiation, EmdBwdArgs.pair_stats): (pixel, entry) pairs this wave evaluates / pairs that contribute
     unsigned long long st_eval = 0ull, st_hit = 0ull;
 
-    // One batch: lane = queue slot.
-    auto process_batch = [&](uint32_t nb) {
+    // One batch of nb survivors: lane = entry, lane 0 the DEEPEST; `pos` = 0-based number of the lane's survivor, `gid` its Gaussian.
+    auto process_batch = [&](uint32_t nb, const float4& g0, const float4& g1, const float4& g2, const float4& g3, const float4* gxc, uint32_t pos,
+                             uint32_t gid) {
         const bool valid = lane < nb;
-        const uint32_t sl = valid ? lane : 0u;
-        const float4 g0 = QREC(0, sl), g1 = QREC(1, sl), g2 = QREC(2, sl);
-        float4 g3 = zero4;
-        if (NORMAL) g3 = QREC(3, sl);
-        float4 gxc[NX ? NX : 1];
-#pragma unroll
-        for (int k = 0; k < NX; k++) gxc[k] = QREC(NRB + k, sl);
         v2f xr_2[NX ? NX : 1], xg_2[NX ? NX : 1], xb_2[NX ? NX : 1];
 #pragma unroll
         for (int k = 0; k < (NX ? NX : 1); k++) xr_2[k] = xg_2[k] = xb_2[k] = splat2(0.f);
-        const uint32_t pos = q_pos[sl];
-        const uint32_t last_pos = readlane_u32(pos, (int)nb - 1);     // the queue runs back to front: lane nb-1 is the shallowest entry
+        const uint32_t last_pos = readlane_u32(pos, (int)nb - 1);     // the batch runs back to front: lane nb-1 is the shallowest entry
         const v2f z2 = splat2(0.f);
         v2f m0_2 = z2, gx_2 = z2, gy_2 = z2, m2xx_2 = z2, m2xy_2 = z2, m2yy_2 = z2, dz_2 = z2, r_2 = z2, g_2 = z2, b_2 = z2;
         float a_ax = 0.f, a_ay = 0.f;
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
                     m2xy = m2xy_2.x + m2xy_2.y, m2yy = m2yy_2.x + m2yy_2.y, a_dz = dz_2.x + dz_2.y, a_r = r_2.x + r_2.y,
                     a_g = g_2.x + g_2.y, a_b = b_2.x + b_2.y;
         // rows through LDS so that consecutive lanes add consecutive floats of one 48-byte accumulator row
-        __syncthreads();   // every lane holds its record in registers: the lower half may be overwritten
+        q_id[lane] = gid;
         float4* row = reinterpret_cast<float4*>(s_stage + lane * STRIDE);
         row[0] = make_float4(-gx, -gy, a_dz, m0 * __builtin_amdgcn_rcpf(g0.w));
         row[1] = make_float4(-0.5f * m2xx, -m2xy, -0.5f * m2yy, a_r);
@@ -583,15 +583,14 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
         __syncthreads();
     };
 
-    // The list is walked BACK TO FRONT (from the deepest contributor of this quadrant), 64 entries per step.
-    // Software pipeline of the list scan: Gaussian ids three steps ahead, records two steps ahead of the step being
-    // queued, so the dependent id -> record gather (two L2 round trips) is off the critical path of a wave that shares
-    // its SIMD with only ~3 others.
-    uint32_t head = 0;
+    // The survivor list is walked BACK TO FRONT, 64 per step; the deepest step is the partial one, so every later batch is full.
+    // Software pipeline: Gaussian ids three steps ahead, records two steps ahead of the step being processed, so the dependent
+    // id -> record gather (two L2 round trips) is off the critical path of a wave that shares its SIMD with only ~3 others.
     const int steps = (int)((wave_n + EMD_WAVE - 1) / EMD_WAVE);
-    auto step_idx = [&](int st_) -> int { return (steps - 1 - st_) * EMD_WAVE + (int)lane; };      // list position of this lane in step st_
-    auto in_list = [&](int i) -> bool { return i >= 0 && (uint32_t)i < wave_n; };
-    auto load_id = [&](int i) -> uint32_t { return in_list(i) ? point_list[start + (uint32_t)i] : 0u; };
+    auto step_lo = [&](int st_) -> int { return (steps - 1 - st_) * EMD_WAVE; };
+    auto step_idx = [&](int st_) -> int { return st_ < steps ? min((int)wave_n, step_lo(st_) + EMD_WAVE) - 1 - (int)lane : -1; };   // this lane's survivor in step st_
+    auto in_step = [&](int st_, int i) -> bool { return st_ < steps && i >= step_lo(st_); };
+    auto load_id = [&](int st_) -> uint32_t { const int i = step_idx(st_); return in_step(st_, i) ? sv[i] : 0u; };
     float4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4, b0 = zero4, b1 = zero4, b2 = zero4, b3 = zero4;
     float4 ax_[NX ? NX : 1], bx_[NX ? NX : 1];
 #pragma unroll
@@ -600,20 +599,19 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
 #pragma unroll
         for (int k = 0; k < NX; k++) { const float* c = d.xcol[k] + 3 * (size_t)id; o[k] = make_float4(c[0], c[1], c[2], 0.f); }
     };
-    uint32_t idA = load_id(step_idx(0)), idB = load_id(step_idx(1)), idC = load_id(step_idx(2));
-    if (in_list(step_idx(0))) {
+    uint32_t idA = load_id(0), idB = load_id(1), idC = load_id(2);
+    if (in_step(0, step_idx(0))) {
         const float4* r = rec + (size_t)idA * EMD_REC_F4;
         a0 = r[0]; a1 = r[1]; a2 = r[2];
         if (NORMAL) a3 = r[3];
         load_extra(idA, ax_);
     }
-    if (in_list(step_idx(1))) {
+    if (in_step(1, step_idx(1))) {
         const float4* r = rec + (size_t)idB * EMD_REC_F4;
         b0 = r[0]; b1 = r[1]; b2 = r[2];
         if (NORMAL) b3 = r[3];
         load_extra(idB, bx_);
     }
-    const unsigned long long gt = (lane == 63) ? 0ull : (~0ull << (lane + 1));      // lanes above this one = deeper list positions of the step
     for (int st_ = 0; st_ < steps; st_++) {
         const int idx = step_idx(st_);
         const float4 c0r = a0, c1r = a1, c2r = a2, c3r = a3;
@@ -623,44 +621,19 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
         const uint32_t cid = idA;
         a0 = b0; a1 = b1; a2 = b2; a3 = b3; idA = idB;
         idB = idC;
-        if (in_list(step_idx(st_ + 2))) {
+        b0 = b1 = b2 = b3 = zero4;
+#pragma unroll
+        for (int k = 0; k < NX; k++) bx_[k] = zero4;
+        if (in_step(st_ + 2, step_idx(st_ + 2))) {
             const float4* r = rec + (size_t)idB * EMD_REC_F4;
             b0 = r[0]; b1 = r[1]; b2 = r[2];
             if (NORMAL) b3 = r[3];
             load_extra(idB, bx_);
         }
-        idC = load_id(step_idx(st_ + 3));
-#ifdef EMD_AB_BOX_CULL
-        const bool keep = in_list(idx) && ((quadrant_mask(c0r, c1r, tile_x0, tile_y0) >> quad) & 1u);
-#else
-        const bool keep = in_list(idx) && ellipse_hits_rect(ellipse_prepare(c0r, c1r), qx0, qx0 + 7.f, qy0, qy0 + 7.f);
-#endif
-        const unsigned long long bal = __ballot(keep);
-        if (keep) {
-            const uint32_t slot = head + (uint32_t)__popcll(bal & gt);          // deepest first: the queue order is descending list position
-            QREC(0, slot) = c0r; QREC(1, slot) = c1r; QREC(2, slot) = c2r;
-            if (NORMAL) QREC(3, slot) = c3r;
-#pragma unroll
-            for (int k = 0; k < NX; k++) QREC(NRB + k, slot) = cxr[k];
-            q_id[slot] = cid; q_pos[slot] = (uint32_t)idx;
-        }
-        head += (uint32_t)__popcll(bal);
-        __syncthreads();
-        if (head >= EMD_WAVE) {
-            process_batch(EMD_WAVE);
-            const uint32_t rest = head - EMD_WAVE;
-            // the upper half of the queue moves down (half 0 is dead: process_batch ended with a barrier; the halves do not overlap)
-            if (lane < rest) {
-#pragma unroll
-                for (int r = 0; r < NR; r++) { const float4 v = q_rec[1][r][lane]; q_rec[0][r][lane] = v; }
-                const uint32_t ti = q_id[EMD_WAVE + lane], tp = q_pos[EMD_WAVE + lane];
-                q_id[lane] = ti; q_pos[lane] = tp;
-            }
-            head = rest;
-            __syncthreads();
-        }
+        idC = load_id(st_ + 3);
+        const uint32_t nb = (uint32_t)(min((int)wave_n, step_lo(st_) + EMD_WAVE) - step_lo(st_));
+        process_batch(nb, c0r, c1r, c2r, c3r, cxr, (uint32_t)max(idx, 0), cid);
     }
-    if (head > 0) process_batch(head);
     if (STATS && lane == 0) { atomicAdd(pair_stats, st_eval); atomicAdd(pair_stats + 1, st_hit); }
 }
 
@@ -691,7 +664,7 @@ int emd_launch_render_forward(const EmdSettings& s, const float* sdev, int flags
     const int nx = x ? x->num : 0;
 #define LAUNCH_FWD(N_, X_)                                                                                                          \
     hipLaunchKernelGGL((k_render_forward_q<N_, X_>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec, \
-                       out_color, out_depth, out_normal, out_alpha, im.final_T, im.n_contrib)
+                       out_color, out_depth, out_normal, out_alpha, im.final_T, im.n_contrib, b.surv, b.quad_need)
     const bool nrm = (flags & EMD_FLAG_NORMAL) != 0;
     if (nx == 0) { if (nrm) LAUNCH_FWD(true, 0); else LAUNCH_FWD(false, 0); }
     else if (nx == 1) { if (nrm) LAUNCH_FWD(true, 1); else LAUNCH_FWD(false, 1); }
@@ -709,11 +682,10 @@ int emd_launch_render_backward(const EmdSettings& s, const float* sdev, int flag
     const RenderDims d = make_dims(s, sdev, x);
     const int T = d.gx * d.gy;
     if (T <= 0) return EMD_OK;
-    const uint32_t* pl = b.vals[b.sorted_buf];
     const bool nrm = (flags & EMD_FLAG_NORMAL) && dL_dnormal && out_normal, ab = flags & EMD_FLAG_ABSGRAD;
     const int nx = x ? x->num : 0;
 #define LAUNCH_BWD(N_, A_, X_)                                                                                          \
-    hipLaunchKernelGGL((k_render_backward_q<N_, A_, X_>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec,   \
+    hipLaunchKernelGGL((k_render_backward_q<N_, A_, X_>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, b.surv, b.quad_need, g.rec,   \
                        im.final_T, im.n_contrib, out_color, out_depth, out_normal, dL_dcolor, dL_ddepth, dL_dalpha,    \
                        dL_dnormal, grad_rec, zero_buf, zero_n, pair_stats)
 #define LAUNCH_BWD_X(X_)                                   \
@@ -722,8 +694,8 @@ int emd_launch_render_backward(const EmdSettings& s, const float* sdev, int flag
     else if (ab) LAUNCH_BWD(false, true, X_);              \
     else LAUNCH_BWD(false, false, X_)
     if (nx == 0 && pair_stats) {          // diagnostic: the same kernel with the pair counters compiled in
-        hipLaunchKernelGGL((k_render_backward_q<false, false, 0, true>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl,
-                           g.rec, im.final_T, im.n_contrib, out_color, out_depth, out_normal, dL_dcolor, dL_ddepth, dL_dalpha, nullptr, grad_rec,
+        hipLaunchKernelGGL((k_render_backward_q<false, false, 0, true>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, b.surv,
+                           b.quad_need, g.rec, im.final_T, im.n_contrib, out_color, out_depth, out_normal, dL_dcolor, dL_ddepth, dL_dalpha, nullptr, grad_rec,
                            zero_buf, zero_n, pair_stats);
     }
     else if (nx == 0) { LAUNCH_BWD_X(0); }

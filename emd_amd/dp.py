@@ -158,8 +158,9 @@ class GradientExchange:
 
     World size 1: `start` does nothing and `finish` only rebuilds (the local cost of the factored path)."""
 
-    def __init__(self, campos_local, actor_ids=None, actor_pose=None, residual_dx=None, average=True):
+    def __init__(self, campos_local, actor_ids=None, actor_pose=None, residual_dx=None, average=True, bucket_small=True, bucket_bytes=16 << 20):
         self.campos_local, self.actor_ids, self.residual_dx = campos_local, actor_ids, residual_dx
+        self.bucket_small, self.bucket_bytes = bucket_small, bucket_bytes
         self.actor_pose = None if actor_pose is None else actor_pose.detach()       # values only: no reference into an autograd graph
         self.average = average
         self.rec = None
@@ -202,7 +203,7 @@ class GradientExchange:
             raise RuntimeError("GradientExchange.finish before the backward pass ran (RasterCall.on_backward was not wired)")
         W = world_size()
         g_local = rec.sh_color_grad
-        works, others = [], []
+        works, others, small, bucket, bucket_work = [], [], [], None, None
         if W == 1 and not force_exchange():
             g_all, campos, pose = g_local[None], self.campos_local.reshape(1, 3).to(g_local.device), self.actor_pose
         else:
@@ -221,8 +222,17 @@ class GradientExchange:
             others.sort(key=lambda g: -g.numel())
             gloo = dist.get_backend() == "gloo"
             op = dist.ReduceOp.SUM if (gloo or not self.average) else dist.ReduceOp.AVG
+            # the small rest (actor pose tables, temporal tables, head tensors, point embeddings: a dozen tensors, ~3 MB in all) travels
+            # as ONE bucket: a collective costs tens of microseconds of latency whatever its size, twelve of them a third of a step
+            bucket = None
+            if self.bucket_small and len(others) >= 3:
+                small = [g for g in others if g.numel() * 4 <= self.bucket_bytes and g.dtype == torch.float32 and g.is_contiguous()]
+                if len(small) >= 3:
+                    bucket = torch.cat([g.reshape(-1) for g in small])
+                    others = [g for g in others if not any(g is s_ for s_ in small)]
             works = [dist.all_reduce(g, op=op, async_op=True) for g in others]
-            self.num_collectives += len(works)
+            bucket_work = dist.all_reduce(bucket, op=op, async_op=True) if bucket is not None else None
+            self.num_collectives += len(works) + (1 if bucket is not None else 0)
             for w in self._gathers:
                 w.wait()
             g_all, campos = self._g_cat.view(W, N, 3), self._campos
@@ -233,6 +243,12 @@ class GradientExchange:
             self._slab_work.wait()
         for w in works:
             w.wait()
+        if W > 1 or force_exchange():
+            if bucket_work is not None:
+                bucket_work.wait()
+                if self.average and dist.get_backend() == "gloo":
+                    bucket.div_(float(W))
+                torch._foreach_copy_([g.reshape(-1) for g in small], list(torch.split(bucket, [g.numel() for g in small])))
         if W > 1 and self.average and dist.get_backend() == "gloo":
             for g in others:
                 g.div_(float(W))

@@ -5,7 +5,7 @@
 #   3. the summaries profiles/make_pmc_summary.py / make_valu_summary.py condense them into
 # Everything lands in gpurun_out/<round>prof/; the summaries to be judged are then copied into profiles/.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=$PWD/gpurun_out/${R}prof
 mkdir -p "$OUT"
 export TMPDIR=/tmp

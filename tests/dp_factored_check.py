@@ -54,7 +54,7 @@ xchg.finish(model._features, model._xyz, model.active_sh_degree, other_params=pa
 # gathers: factors + camera centres + pose tables (3); the four small per-Gaussian gradients travel as ONE slab (1); the rest
 # (two actor-pose tables, temporal tables, 8 head tensors, point embeddings) one small all-reduce each
 n_rest = sum(1 for n_, p in model.named_parameters() if n_ not in ("_xyz", "_scaling", "_rotation", "_opacity", "_features"))
-assert xchg.num_collectives == 3 + 1 + n_rest, (xchg.num_collectives, n_rest)
+assert xchg.num_collectives == 3 + 1 + 1, (xchg.num_collectives, n_rest)      # gathers, the slab, ONE bucket for the n_rest small tensors
 for name, p in model.named_parameters():
     want, got = ref[name], p.grad
     tol = 2e-5 * want.abs().max().item() + 1e-12
