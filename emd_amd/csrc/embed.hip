@@ -409,6 +409,31 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lo = a.segment_start[act], hi = a.segment_start[act + 1];
     const int frame = p.frame_dev ? p.frame_dev[0] : p.frame;
+    // wave 0's loads and arithmetic that do not depend on the embedding sums (temporal rows, head weights, the frame's pose row) are
+    // issued FIRST: they overlap the segment sum / the clears of the other waves instead of following them (the kernel is pure latency)
+    float hc_t = 0.f, hf_t = 0.f, wrow[8], hbias[8], cnt = 1.f, qf[4] = {1.f, 0.f, 0.f, 0.f}, tf[3] = {0.f, 0.f, 0.f}, vflag = 1.f;
+    TeSample sc, sf;
+#pragma unroll
+    for (int o = 0; o < 8; o++) wrow[o] = hbias[o] = 0.f;
+    if (wave == 0) {
+        const float* w = a.weight + (size_t)act * a.rows * dim;
+        const float t = a.t_dev ? a.t_dev[0] : a.t;
+        const int k_fine = a.k_fine_dev ? a.k_fine_dev[0] : a.k_fine;
+        sc = te_rows(t, a.k_coarse, a.rows); sf = te_rows(t, k_fine, a.rows);
+        cnt = a.count[act];
+        if (lane < dim) { hc_t = te_column(w, dim, sc, lane, 0.f, nullptr); hf_t = te_column(w, dim, sf, lane, 0.f, nullptr); }
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            const int hd = o < 3 ? 0 : o < 6 ? 1 : o - 4, r = o < 3 ? o : o < 6 ? o - 3 : 0;
+            wrow[o] = lane < width ? a.head_w[hd][r * width + lane] : 0.f;
+            hbias[o] = a.head_b[hd][r];
+        }
+        const float* q_f = p.q_all + ((size_t)frame * A + act) * 4;
+        const float* t_f = p.t_all + ((size_t)frame * A + act) * 3;
+        qf[0] = q_f[0]; qf[1] = q_f[1]; qf[2] = q_f[2]; qf[3] = q_f[3];
+        tf[0] = t_f[0]; tf[1] = t_f[1]; tf[2] = t_f[2];
+        if (p.valid_all) vflag = p.valid_all[(size_t)frame * A + act] ? 1.f : 0.f;
+    }
     if (BWD) {
         // clear what this workgroup owns: its actor's temporal-table gradient and its column of the dense per-frame pose gradients
         float* G = g.d_weight + (size_t)act * a.rows * dim;
@@ -431,28 +456,18 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
     }
     if (wave == 0) {
         const float* w = a.weight + (size_t)act * a.rows * dim;
-        const float t = a.t_dev ? a.t_dev[0] : a.t;
-        const int k_fine = a.k_fine_dev ? a.k_fine_dev[0] : a.k_fine;
-        const TeSample sc = te_rows(t, a.k_coarse, a.rows), sf = te_rows(t, k_fine, a.rows);
-        const float cnt = a.count[act];
-        float hc = 0.f, hf = 0.f;
-        if (lane < dim) { hc = te_column(w, dim, sc, lane, 0.f, nullptr); hf = te_column(w, dim, sf, lane, 0.f, nullptr); }
-        else if (lane < width) hc = hf = s_sum[lane - dim] / cnt;
-        float out[8], wrow[8];
+        float hc = hc_t, hf = hf_t;
+        if (lane >= dim && lane < width) hc = hf = s_sum[lane - dim] / cnt;
+        float out[8];
 #pragma unroll
-        for (int o = 0; o < 8; o++) {
-            const int hd = o < 3 ? 0 : o < 6 ? 1 : o - 4, r = o < 3 ? o : o < 6 ? o - 3 : 0;
-            wrow[o] = lane < width ? a.head_w[hd][r * width + lane] : 0.f;
-            out[o] = wave_sum_all(wrow[o] * ((o < 3 || o == 6) ? hc : hf)) + a.head_b[hd][r];
-        }
+        for (int o = 0; o < 8; o++) out[o] = wave_sum_all(wrow[o] * ((o < 3 || o == 6) ? hc : hf)) + hbias[o];
         const float cc = cosf(out[6]), scn = sinf(out[6]), cf = cosf(out[7]), sfn = sinf(out[7]);
         const float ow = cc * cf - scn * sfn, oz = cc * sfn + scn * cf;
         const float dtv[3] = {out[0] + out[3], out[1] + out[4], out[2] + out[5]};
         const float dqv[4] = {ow, 0.f, 0.f, oz};
         // ---- pose row of this actor (k_actor_pose_forward / _backward, every lane computes the same values) ----
-        const float* q_f = p.q_all + ((size_t)frame * A + act) * 4;
-        const float* t_f = p.t_all + ((size_t)frame * A + act) * 3;
-        const float q[4] = {q_f[0], q_f[1], q_f[2], q_f[3]};
+        const float q[4] = {qf[0], qf[1], qf[2], qf[3]};
+        const float* t_f = tf;
         const float n = fmaxf(tp_quat_norm(q), 1e-12f);
         const bool ok_t = !tp_any_nan(dtv, 3), ok_r = !tp_any_nan(dqv, 4);
         float pq[4] = {q[0], q[1], q[2], q[3]};
@@ -467,7 +482,7 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
                 for (int k = 0; k < 4; k++) P[k] = q[k] / n;
 #pragma unroll
                 for (int k = 0; k < 3; k++) P[4 + k] = ok_t ? t_f[k] + dtv[k] : t_f[k];
-                P[7] = p.valid_all ? (p.valid_all[(size_t)frame * A + act] ? 1.f : 0.f) : 1.f;
+                P[7] = vflag;
 #pragma unroll
                 for (int k = 0; k < 4; k++) P[8 + k] = pq[k] / n2;
             }
