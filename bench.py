@@ -379,7 +379,29 @@ def main():
             with torch.cuda.graph(graph, stream=side, capture_error_mode="global" if world == 1 else "thread_local"):
                 graph_body()
             torch.cuda.synchronize()
+            # ---- self-check of the captured graph before it is trusted with the timed region: two replays of row 0 must reproduce the
+            # eager step's device status words (D, V) and leave finite, identical parameter gradients (a memset node captured on ROCm 7.2
+            # replayed with a corrupt fill pattern from the SECOND replay on: that is how the library's zero fills became kernels)
+            eager = one_step(0)
+            torch.cuda.synchronize()
+            want_status = eager["raster_call"].status.clone()
+            want_grad = model._xyz.grad.clone()
+            del eager
+            gc.collect()
+            for rep_ in range(2):
+                sel.fill_(0)
+                prev_sel.fill_(-1)
+                graph.replay()
+                torch.cuda.synchronize()
+                if not torch.equal(status_static[:3], want_status[:3]):
+                    raise RuntimeError(f"replay {rep_}: status words {status_static.tolist()} differ from the eager step's {want_status.tolist()}")
+                g_ = model._xyz.grad
+                if not bool(torch.isfinite(g_).all()):
+                    raise RuntimeError(f"replay {rep_}: non-finite parameter gradients")
+                if world == 1 and float((g_ - want_grad).abs().max()) > 1e-4 * float(want_grad.abs().max()) + 1e-12:      # (N > 1: the eager step averaged over ranks)
+                    raise RuntimeError(f"replay {rep_}: parameter gradients differ from the eager step's")
             sel.fill_(0)                                      # the first replay renders row 0; every replay leaves the next row in `sel`
+            prev_sel.fill_(-1)
         except Exception as e:          # capture is an optimisation of the host side only: fall back to issuing the step from Python
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
