@@ -52,7 +52,7 @@ class EmdFwdArgs(C.Structure):
                 ("geom_ws", _f), ("geom_bytes", C.c_size_t), ("bin_ws", _f), ("bin_bytes", C.c_size_t),
                 ("img_ws", _f), ("img_bytes", C.c_size_t), ("status", _f),
                 ("num_rendered", C.c_int64), ("num_visible", C.c_int64), ("settings_dev", _f),
-                ("num_extra", C.c_int32), ("colors_extra", _f * 2), ("out_extra", _f * 2)]
+                ("num_extra", C.c_int32), ("colors_extra", _f * 2), ("out_extra", _f * 2), ("aux_stream", _f)]
 
 
 class EmdBwdArgs(C.Structure):

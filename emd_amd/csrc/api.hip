@@ -2,6 +2,7 @@
 // No device memory is allocated or freed here; errors are returned as codes + a thread-local message.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -253,11 +254,36 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
     pa.motion = a->motion; pa.radii = a->radii; pa.g = g; pa.status = a->status; pa.sdev = a->settings_dev;
     if (!(a->flags & EMD_FLAG_MOTION)) memset(&pa.motion, 0, sizeof(pa.motion));
     emd_prof_begin(PROF_PREPROCESS, st);
-    rc = emd_launch_preprocess(pa, st);
+    // With an auxiliary stream the colour half of K1 (SH colour, clamp bits, colour Jacobian: needed by K6 only) runs BESIDE the binning
+    // stage: fork after the geometry half, join in front of K6.  (Measured in round 3 and OFF by default in the binding: the halves cost
+    // 0.075 + 0.122 ms apart against 0.159 ms fused, and beside the colour half's 31 250 workgroups the binning kernels wait for slots:
+    // 684 against 700 it/s.  Kept as an option for callers whose binning is longer.)  Both edges are events, so a capturing stream records them as graph
+    // dependencies.  Every return between fork and join joins first: the caller may free or reuse the workspaces on an error.
+    hipStream_t aux = (hipStream_t)a->aux_stream;
+    const bool split = aux != nullptr && aux != st && N > 0 && !dbg;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    auto join = [&]() -> int {
+        if (!ev_join) return EMD_OK;
+        hipError_t e1 = hipStreamWaitEvent(st, ev_join, 0);
+        (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join);
+        ev_fork = ev_join = nullptr;
+        if (e1 != hipSuccess) { emd_set_error("forward: joining the auxiliary stream failed: %s", hipGetErrorString(e1)); return EMD_ERR_HIP; }
+        return EMD_OK;
+    };
+    rc = emd_launch_preprocess(pa, split ? 1 : 0, st);
     if (rc) return rc;
+    if (split) {
+        EMD_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        EMD_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        EMD_HIP_CHECK(hipEventRecord(ev_fork, st));
+        EMD_HIP_CHECK(hipStreamWaitEvent(aux, ev_fork, 0));
+        rc = emd_launch_preprocess(pa, 2, aux);
+        hipError_t e2 = hipEventRecord(ev_join, aux);
+        if (rc || e2 != hipSuccess) { (void)join(); if (!rc) { emd_set_error("forward: hipEventRecord on the auxiliary stream failed"); rc = EMD_ERR_HIP; } return rc; }
+    }
     STAGE_SYNC("preprocess");
     rc = emd_launch_binning(a->s, a->flags, N, g, b, a->bin_capacity, a->status, st);
-    if (rc) return rc;
+    if (rc) { (void)join(); return rc; }
     STAGE_SYNC("binning");
     a->num_rendered = -1;
     a->num_visible = -1;
@@ -268,14 +294,17 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
         a->num_rendered = hs.num_rendered;
         a->num_visible = hs.num_visible;
         if (hs.overflow & 2u) {
+            (void)join();
             emd_set_error("forward: a visible Gaussian lies beyond 65 536 x the near plane; repeat with EMD_FLAG_WIDE_DEPTH_SORT");
             return EMD_ERR_DEPTH_RANGE;
         }
         if (hs.overflow) {
+            (void)join();
             emd_set_error("forward: %u (tile, Gaussian) pairs exceed bin_capacity %lld", hs.num_rendered, (long long)a->bin_capacity);
             return EMD_ERR_CAPACITY;
         }
     }
+    { int jrc = join(); if (jrc) return jrc; }          // K6 reads the colours
     emd_prof_switch(PROF_RANGES, PROF_RENDER_FWD, st);
     EmdExtra ex;
     memset(&ex, 0, sizeof(ex));

@@ -169,7 +169,7 @@ struct PreArgs {
     EmdStatus* status;
     const float* sdev;       // device copy of bg / viewmatrix / projmatrix / campos (EmdFwdArgs.settings_dev) or null
 };
-int emd_launch_preprocess(const PreArgs& a, hipStream_t st);                 // preprocess.hip
+int emd_launch_preprocess(const PreArgs& a, int part, hipStream_t st);       // preprocess.hip; part 0 = whole kernel, 1 = geometry half, 2 = colour half
 int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,
                        hipStream_t st);                                       // binning.hip
 int emd_launch_export_keys(int64_t D, const GeomWs& g, const BinWs& b, uint64_t* keys, hipStream_t st);  // binning.hip

@@ -248,14 +248,20 @@ __device__ __forceinline__ void sh_row_load(const float* __restrict__ shs, int i
 #ifndef EMD_K1_WAVES
 #define EMD_K1_WAVES 5
 #endif
-__global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(EMD_K1_WAVES))) k_preprocess(PreArgs a) {
-    __shared__ float4 s_sh[(PRE_BLOCK / 2) * SH_ROW4];       // half of the wave's rows at a time: 6.5 KB keeps four waves per SIMD
+// PART 0: the whole kernel.  PART 1 / PART 2 (round 3): its geometry half (everything the binning needs, and rows 0, 1, 3 of the record)
+// and its colour half (SH colour, clamp bits, colour Jacobian: row 2 of the record and shjac) as two launches -- the colour half is
+// needed by K6 only, so with an auxiliary stream (EmdFwdArgs.aux_stream) it runs BESIDE the twenty launch-bound kernels of the binning
+// stage instead of in front of them.  PART 2 recomputes the world mean of its Gaussian (one gather for an actor's point) and takes
+// the visibility from the radii PART 1 wrote.
+template <int PART>
+__global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(PART == 1 ? 6 : EMD_K1_WAVES))) k_preprocess(PreArgs a) {
+    __shared__ float4 s_sh[PART == 1 ? 1 : (PRE_BLOCK / 2) * SH_ROW4];       // half of the wave's rows at a time: 6.5 KB keeps four waves per SIMD
     EmdSettings S = a.s;
     emd_settings_from_device(S, a.sdev, a.flags);
     const bool sh_staged = a.shs && a.M == 16;
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
     // the call's four status words are cleared here (the binning kernels behind this launch raise bits in them): no launch of its own
-    if (blockIdx.x == 0 && threadIdx.x < 4 && a.status) reinterpret_cast<uint32_t*>(a.status)[threadIdx.x] = 0u;
+    if (PART != 2 && blockIdx.x == 0 && threadIdx.x < 4 && a.status) reinterpret_cast<uint32_t*>(a.status)[threadIdx.x] = 0u;
     uint32_t touched = 0, rect = 0, dkey = 0xFFFFFFFFu;
     int radius_out = 0;
     const float* V = S.viewmatrix;
@@ -266,8 +272,15 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
     // the scales are requested with the other parameters, not behind the near-plane test they used to wait for (one HBM round trip less
     // on the way to the visibility decision; a culled Gaussian's 12 bytes are read in vain: measured 0.180 -> 0.172 ms)
     float sc_raw[3] = {0.f, 0.f, 0.f};
-    if (i < a.N && !a.cov3D_precomp) { sc_raw[0] = a.scales[3 * i]; sc_raw[1] = a.scales[3 * i + 1]; sc_raw[2] = a.scales[3 * i + 2]; }
-    if (i < a.N) {
+    if (PART != 2 && i < a.N && !a.cov3D_precomp) { sc_raw[0] = a.scales[3 * i]; sc_raw[1] = a.scales[3 * i + 1]; sc_raw[2] = a.scales[3 * i + 2]; }
+    if (PART == 2) {
+        // colour half: visibility from the geometry half's radii; the world mean again (static point: the parameter itself)
+        if (i < a.N && a.radii[i] > 0) {
+            touched = 1u;
+            if (a.flags & EMD_FLAG_MOTION) motion_point(i, a.means3D, a.rotations, a.opacities, a.motion, m, q, &op, (a.flags & EMD_FLAG_RAW_PARAMS) != 0);
+            else { m[0] = a.means3D[3 * i]; m[1] = a.means3D[3 * i + 1]; m[2] = a.means3D[3 * i + 2]; }
+        }
+    } else if (i < a.N) {
         const float* P = S.projmatrix;
         const int W = S.image_width, H = S.image_height;
         const int gx = (W + EMD_TILE_X - 1) / EMD_TILE_X, gy = (H + EMD_TILE_Y - 1) / EMD_TILE_Y;
@@ -330,7 +343,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
     }
     const bool vis = touched != 0u;
     float sh[48];
-    if (sh_staged) {
+    if (PART != 1 && sh_staged) {
         // rows of the VISIBLE Gaussians only, in two halves of 32 rows: coalesced dwordx4 pieces into LDS, then each lane of the half
         // takes its own row into registers
         const unsigned long long vmask = __ballot(vis);
@@ -355,9 +368,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
         }
     }
     if (vis) {
-        float col[3];
+        float col[3] = {0.f, 0.f, 0.f};
         uint32_t bits = 0;
-        if (a.colors_precomp) {
+        if (PART == 1) {
+            // (geometry half: no colour)
+        } else if (a.colors_precomp) {
             col[0] = a.colors_precomp[3 * i]; col[1] = a.colors_precomp[3 * i + 1];
             col[2] = a.colors_precomp[3 * i + 2];
         } else {
@@ -387,10 +402,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
             jr[2] = make_float4(J[6], J[7], J[8], 0.f);
         }
         float4* rec = a.g.rec + (size_t)i * EMD_REC_F4;
-        rec[0] = make_float4(ix, iy, p.tz, op);
-        rec[1] = make_float4(conA, conB, conC, __uint_as_float(bits));
-        rec[2] = make_float4(col[0], col[1], col[2], 0.f);
-        if (a.flags & EMD_FLAG_NORMAL) {
+        // the clamp bits of the colour ride in row 2 (with the colour they belong to), so that the two halves write disjoint rows
+        if (PART != 2) { rec[0] = make_float4(ix, iy, p.tz, op); rec[1] = make_float4(conA, conB, conC, 0.f); }
+        if (PART != 1) rec[2] = make_float4(col[0], col[1], col[2], __uint_as_float(bits));
+        if (PART != 2 && (a.flags & EMD_FLAG_NORMAL)) {
             float nv[3] = {0.f, 0.f, 0.f};
             if (a.scales) {
                 int ax = 0;
@@ -567,7 +582,7 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 gr[0] = z4; gr[1] = z4; gr[2] = z4;
             }
-            const uint32_t bits = __float_as_uint(a.g.rec[(size_t)i * EMD_REC_F4 + 1].w);
+            const uint32_t bits = __float_as_uint(a.g.rec[(size_t)i * EMD_REC_F4 + 2].w);
             gm2[0] = g0.x; gm2[1] = g0.y;
             if (a.flags & EMD_FLAG_ABSGRAD) { gabs[0] = g2.z; gabs[1] = g2.w; }
             g_depth = g0.z;
@@ -1089,10 +1104,12 @@ int emd_launch_abs_mean_backward(size_t n, const float* x, const float* g, float
     return EMD_OK;
 }
 
-int emd_launch_preprocess(const PreArgs& a, hipStream_t st) {
+int emd_launch_preprocess(const PreArgs& a, int part, hipStream_t st) {
     if (a.N <= 0) return EMD_OK;
     const int nb = (a.N + PRE_BLOCK - 1) / PRE_BLOCK;
-    hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(PRE_BLOCK), 0, st, a);
+    if (part == 1) hipLaunchKernelGGL(k_preprocess<1>, dim3(nb), dim3(PRE_BLOCK), 0, st, a);
+    else if (part == 2) hipLaunchKernelGGL(k_preprocess<2>, dim3(nb), dim3(PRE_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL(k_preprocess<0>, dim3(nb), dim3(PRE_BLOCK), 0, st, a);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

@@ -65,6 +65,9 @@ class RasterOptions:
     keep_render_grads: bool = False  # tests: keep the per-Gaussian accumulator rows of the render backward (RasterCall.render_grads, [N, 12+])
     factored_sh_grad: bool = False  # view-parallel DP: the backward leaves dL/dshs out and publishes the [N,3] factor instead
                                     # (RasterCall.sh_color_grad); emd_amd.dp rebuilds the dense, view-averaged gradient
+    aux_stream: bool = False        # run the colour half of the projection kernel on a second stream beside the binning stage (the binding
+                                    # keeps one side stream per device; results are identical, see EmdFwdArgs.aux_stream).  Measured at the
+                                    # headline size: 684 it/s against 700 fused -- off unless a caller's binning is long
     wide_depth_sort: bool = False   # always use the four-pass depth sort (depths beyond 65 536 x the near plane).  The three-pass sort
                                     # falls back to it by itself when the status word can be read (a retry in the synchronous mode,
                                     # the next call in no_sync mode); a call captured into a hipGraph reads nothing back and keeps the
@@ -133,6 +136,7 @@ class RasterCall:
 # forward is never awaited; its status word is copied to pinned host memory asynchronously and looked at by a LATER forward
 # (when the copy's event has completed), which grows the hint and warns if a past call overflowed.
 _capacity_hint = {}
+_aux_streams = {}             # device index -> the side stream the forward forks the colour half of K1 onto
 _clean_ws = {}                # (device, stream, floats) -> accumulator rows of the render backward, zero between backward passes
 _wide_depth = set()           # keys whose depth range needs the four-pass sort (EMD_ERR_DEPTH_RANGE seen once)
 _watch = {}                   # key -> ring of pinned status copies in flight
@@ -322,6 +326,13 @@ class _Rasterize(torch.autograd.Function):
             a.num_extra = len(extras)
             for k, (e, o) in enumerate(zip(extras, out_extra)):
                 a.colors_extra[k], a.out_extra[k] = e.data_ptr(), o.data_ptr()
+            a.aux_stream = None
+            if opts.aux_stream:
+                aux = _aux_streams.get(dev.index)
+                if aux is None:
+                    aux = _aux_streams[dev.index] = torch.cuda.Stream(device=dev)
+                if aux.cuda_stream != torch.cuda.current_stream().cuda_stream:
+                    a.aux_stream = aux.cuda_stream
             rc = lib.emd_raster_forward(C.byref(a), _stream())
             if rc == L.EMD_ERR_DEPTH_RANGE and not (flags & L.FLAG_WIDE_DEPTH_SORT):
                 _wide_depth.add(key)

@@ -185,6 +185,11 @@ typedef struct EmdFwdArgs {
     int32_t num_extra;                       /* 0 .. EMD_MAX_EXTRA */
     const float* colors_extra[EMD_MAX_EXTRA];  /* [N,3] each */
     float* out_extra[EMD_MAX_EXTRA];           /* [3,H,W] each */
+    /* optional second hipStream_t (ABI 18).  With it the forward splits its projection kernel: the geometry half on the call's stream,
+     * the colour half (SH colour, clamp bits, colour Jacobian -- read by the compositing kernel only) on aux_stream, beside the binning
+     * stage; fork and join are events, i.e. graph edges under stream capture.  The stream must belong to the same device and must not be
+     * the call's own; NULL (or debug = 1) keeps everything on one stream.  Same results bit for bit either way. */
+    void* aux_stream;
 } EmdFwdArgs;
 
 typedef struct EmdBwdArgs {

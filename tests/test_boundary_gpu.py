@@ -314,3 +314,55 @@ def test_accumulator_rows_are_handed_back_clean():
                 assert len(rz._clean_ws) >= 1
                 for ws in rz._clean_ws.values():
                     assert int(torch.count_nonzero(ws)) == 0, "a row was left dirty"
+
+
+def test_colour_half_on_an_auxiliary_stream_gives_the_same_call():
+    """RasterOptions.aux_stream (EmdFwdArgs.aux_stream): the projection kernel split into its geometry half on the call's stream and
+    its colour half on a second stream beside the binning stage, forked and joined by events -- the images of the call are bit for bit
+    those of the one-stream call, with and without fused motion, and so are radii and the status words; gradients agree to the order of
+    the backward's float atomics.  Also inside a captured graph (the fork / join become graph edges)."""
+    from emd_amd import GaussianRasterizer
+    for motion in (False, True):
+        case = make_case(n=9000, H=96, W=144, seed=57, motion=motion)
+        G = torch.randn(3, case["H"], case["W"], generator=torch.Generator().manual_seed(3)).to(DEV)
+        kw = {}
+        if motion:
+            kw = dict(actor_ids=case["actor_ids"].to(DEV), actor_pose=case["actor_pose"].to(DEV))
+
+        def run(aux):
+            t = _leaves(case)
+            r = GaussianRasterizer(_settings(case), aux_stream=aux)
+            out = _call(r, t, **kw)
+            (out[0] * G).sum().backward()
+            return [o.detach().clone() for o in out[:5]], {k: v.grad.clone() for k, v in t.items()}, r.last_call.status.clone()
+
+        ref_out, ref_g, ref_st = run(False)
+        got_out, got_g, got_st = run(True)
+        for a, b in zip(got_out, ref_out):
+            assert torch.equal(a, b)
+        assert torch.equal(got_st[:3], ref_st[:3])
+        for k in ref_g:
+            assert float((got_g[k] - ref_g[k]).abs().max()) <= 2e-4 * float(ref_g[k].abs().max()) + 1e-12, k
+    # captured: fork and join inside one hipGraph
+    case = make_case(n=9000, H=96, W=144, seed=57)
+    t = {k: case[k].to(DEV) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    t["means2D"] = torch.zeros(case["N"], 3, device=DEV)
+    r = GaussianRasterizer(_settings(case), aux_stream=True, no_sync=True)
+    with torch.no_grad():
+        want = _call(GaussianRasterizer(_settings(case)), t)[0].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                img = _call(r, t)[0]
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            img = _call(r, t)[0]
+        for _ in range(3):
+            img.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(img, want)
+        graph.reset()
