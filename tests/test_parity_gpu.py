@@ -388,3 +388,25 @@ def test_depth_beyond_the_three_pass_range_falls_back_to_the_wide_sort():
     hip2 = run_hip(case, backward=False)                    # second call: wide from the start
     np.testing.assert_array_equal(hip2["keys"], orc["bin"]["keys"])
     rasterizer._wide_depth.discard(key)
+
+
+def test_baseline_config0_exact_size_10k_static_256():
+    """BASELINE configs[0] at exactly its size: 10 000 static Gaussians of the bench scene generator, 256 x 256, fx = fy = 272 -- the
+    scene `bench.py --config 0` times -- forward + backward against the oracle: keys / ids / ranges / radii / images bit-exact, all
+    gradients at the bars of tests/helpers.py."""
+    from emd_amd import scenes
+    n, H, W = 10_000, 256, 256
+    sc = scenes.make_static_scene(n, seed=0)
+    case = dict(N=n, H=H, W=W, sh_degree=3, bg=torch.tensor([0.0, 0.0, 0.0]), cam=scenes.rig_camera(0, 0, H, W, fx=272.0, fy=272.0),
+                means3D=sc.means, opacities=torch.sigmoid(sc.opacity_logits), scales=torch.exp(sc.log_scales),
+                rotations=torch.nn.functional.normalize(sc.quats, dim=1), shs=sc.shs, colors_precomp=None, cov3D_precomp=None, actor_ids=None,
+                actor_pose=None, residual_dx=None, residual_dq=None, flags=1)
+    g = np.random.default_rng(23)
+    case["dL_dcolor"] = g.standard_normal((3, H, W)).astype(np.float32)
+    case["dL_ddepth"] = (0.01 * g.standard_normal((1, H, W))).astype(np.float32)
+    case["dL_dalpha"] = g.standard_normal((1, H, W)).astype(np.float32)
+    orc = run_oracle(case, backward=True)
+    assert orc["bin"]["D"] > 5_000 and int((orc["pre"]["radii"] > 0).sum()) > 3_000
+    hip = run_hip(case, backward=True)
+    compare_forward(hip, orc, tol=IMAGE_TOL)
+    compare_backward(hip, orc)
