@@ -148,6 +148,42 @@ class _RenderOutputs(dict):
             return default
 
 
+def render_decomposition(out, levels=("coarse", "fine", "coarse_fine"), top_fraction=0.005):
+    """The evaluation-time decomposition passes of the reference's render() (`return_decomposition`, stage "fine", the branch without
+    `combine_dynamic_static`: S3Gaussian/gaussian_renderer/__init__.py:203-294), from the dict `render(..., deformation=...)` returned:
+    per level of the deformation (coarse dx, fine dx, and their difference) (a) the `top_fraction` of the Gaussians that move farthest,
+    rendered alone -- a boolean-mask subset of every boundary tensor through the SAME rasterizer object -- and (b) the whole scene coloured
+    by |dx| / max |dx| (`colors_precomp`).  Returns {"coarse_render": {render, depth, color, weight, normal, dx}, ...} as the reference's
+    `ddict_render`.  No gradients are needed on this path (the reference only visualises it): it runs under no_grad."""
+    dd, bd, rast = out["ddict"], out["boundary"], out["rasterizer"]
+    if dd is None:
+        raise ValueError("render_decomposition needs the deformation residuals: call render(..., deformation=...) first")
+    dx = {"coarse": dd["coarse"]["dx"] if dd.get("coarse") else None, "fine": dd["fine"]["dx"] if dd.get("fine") else None}
+    if dx["coarse"] is not None and dx["fine"] is not None:
+        dx["coarse_fine"] = dx["coarse"] - dx["fine"]
+    res = {}
+    with torch.no_grad():
+        base = dict(opacities=bd["opacities"], scales=bd["scales"], rotations=bd["rotations"], raw_params=bd["raw_params"], cov3Ds_precomp=None,
+                    extra_attrs=None)
+        m2d = torch.zeros_like(bd["means3D"])
+        for lvl in levels:
+            d = dx.get(lvl)
+            if d is None:
+                continue
+            d_abs = d.detach().abs()
+            dist = d_abs.norm(dim=1)
+            k = int(dist.shape[0] * top_fraction)
+            mask = torch.zeros_like(dist, dtype=torch.bool)
+            if k > 0:
+                mask[torch.topk(dist, k)[1]] = True
+            sub = {n_: (v[mask] if isinstance(v, torch.Tensor) else v) for n_, v in base.items()}
+            img_d, depth_d, normal_d, weight_d, _, _ = rast(means3D=bd["means3D"][mask], means2D=m2d[mask], shs=bd["shs"][mask], colors_precomp=None, **sub)
+            col = d_abs / d_abs.max(dim=0, keepdim=True)[0]
+            color_dx = rast(means3D=bd["means3D"], means2D=m2d, shs=None, colors_precomp=col, **base)[0]
+            res[lvl + "_render"] = {"render": img_d, "depth": depth_d, "color": color_dx, "weight": weight_d, "normal": normal_d, "dx": d}
+    return res
+
+
 def raster_settings_for(cam, bg, sh_degree, scaling_modifier=1.0, debug=False):
     """The 12-field record exactly as S3Gaussian/gaussian_renderer/__init__.py:46-62 builds it from a camera."""
     return GaussianRasterizationSettings(

@@ -117,3 +117,51 @@ def test_fine_stage_trains_through_the_rasterizer():
         adam.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.9 * losses[0], (losses[0], losses[-1])
+
+
+def test_decomposition_passes_of_the_reference_render():
+    """render_decomposition: the evaluation passes of gaussian_renderer/__init__.py:203-294 (no combine_dynamic_static) -- per level the
+    0.5 % farthest-moving Gaussians rendered alone through a boolean-mask subset, and the scene coloured by |dx| / max |dx| -- against
+    the same passes issued by hand (a fresh rasterizer per call, activated parameters, the oracle for the colour pass)."""
+    from emd_amd import GaussianRasterizer, scenes
+    from emd_amd.deformation import DeformOptions, deform_network
+    from emd_amd.model import StreetGaussians, raster_settings_for, render, render_decomposition
+    from oracle import cpu_oracle as co
+    dev = torch.device("cuda", 0)
+    N, H, W = 12000, 80, 128
+    model = StreetGaussians(scenes.make_static_scene(N, seed=5), dev)
+    torch.manual_seed(7)
+    deform = deform_network(DeformOptions()).to(dev)
+    deform.deformation_net.set_aabb([120.0, 30.0, 10.0], [0.0, -30.0, -2.0])
+    for n_, p_ in deform.named_parameters():
+        if p_.dim() > 1 and "grid" not in n_:
+            p_.data.mul_(0.05)
+    emb = 0.1 * torch.randn(N, 4, device=dev)
+    cam, bg = scenes.rig_camera(2, 0, H, W), torch.zeros(3)
+    with torch.no_grad():
+        out = render(model, cam, bg, frame=0, deformation=deform, embeddings=emb, iteration=12000, time=0.3)
+        dec = render_decomposition(out)
+    assert set(dec) == {"coarse_render", "fine_render", "coarse_fine_render"}
+    bd = {k_: (v.detach() if isinstance(v, torch.Tensor) else v) for k_, v in out["boundary"].items()}
+    s_act, q_act, o_act = torch.exp(bd["scales"]), torch.nn.functional.normalize(bd["rotations"]), torch.sigmoid(bd["opacities"])
+    rs = raster_settings_for(cam, bg, model.active_sh_degree)
+    for lvl, d in (("coarse", out["ddict"]["coarse"]["dx"]), ("fine", out["ddict"]["fine"]["dx"]),
+                   ("coarse_fine", out["ddict"]["coarse"]["dx"] - out["ddict"]["fine"]["dx"])):
+        got = dec[lvl + "_render"]
+        d_abs = d.abs()
+        mask = torch.zeros(N, dtype=torch.bool, device=dev)
+        mask[torch.topk(d_abs.norm(dim=1), int(N * 0.005))[1]] = True
+        assert int(mask.sum()) == 60
+        with torch.no_grad():
+            ref = GaussianRasterizer(rs)(means3D=bd["means3D"][mask], means2D=torch.zeros(60, 3, device=dev), shs=bd["shs"][mask], colors_precomp=None,
+                                         opacities=o_act[mask], scales=s_act[mask], rotations=q_act[mask], cov3Ds_precomp=None, extra_attrs=None)
+        torch.testing.assert_close(got["render"], ref[0], rtol=0, atol=2e-6)       # (fused activations vs activated inputs: last-bit differences)
+        torch.testing.assert_close(got["weight"], ref[3], rtol=0, atol=2e-6)
+        # the |dx| colour map against the oracle
+        col = (d_abs / d_abs.max(dim=0, keepdim=True)[0]).cpu().numpy()
+        S = co.make_settings(H, W, cam.tanfovx, cam.tanfovy, [0, 0, 0], cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), 0,
+                             cam.camera_center.numpy(), 1.0)
+        sc = co.Scene(bd["means3D"].cpu().numpy(), o_act.cpu().numpy(), colors_precomp=col, scales=s_act.cpu().numpy(), rotations=q_act.cpu().numpy())
+        _, _, img = co.forward(S, sc, 0)
+        assert float(np.abs(got["color"].cpu().numpy() - img["color"]).max()) <= 1e-4
+        assert torch.equal(got["dx"], d)
