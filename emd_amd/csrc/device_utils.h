@@ -89,6 +89,12 @@ __device__ __forceinline__ void lds_add_f32(float* addr, float v) {
     } while (old != assumed);
 }
 
+// fp64 add into LDS: ds_add_f64, native and at rate (8.9 clocks per wave64 instruction against 16.9 for the fp32 compare-and-swap
+// loop and 193 for ds_add_f32: profiles/r03_lds_atomic_microbench.txt), no return value, so nothing waits on it.
+__device__ __forceinline__ void lds_add_f64(double* addr, float v) {
+    __hip_atomic_fetch_add(addr, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 __device__ __forceinline__ float readlane_f32(float v, int lane) {

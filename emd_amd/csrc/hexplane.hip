@@ -214,170 +214,268 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd2(EmdHexArgs a) {
 
 
 // ---- backward with in-LDS aggregation -----------------------------------------------------------------------------------
-// The plain backward issues one row of float atomics per tap (N x 24 planes x 4 taps); the L2 atomic units retire roughly
-// one dword per clock per channel, so at N = 2 M that is ~20 ms no matter how the rows are spread.  When the caller hands the
-// points in a spatially coherent order (`order`: e.g. Morton order of the positions), 256 consecutive points fall into a small
-// box, and their taps into a few cells of every plane -- above all on the coarse scales and on the three time planes (every
-// point of a step carries the same time).  A 512-thread block therefore accumulates its 256 points into LDS windows
-// (12 x 12 cells per spatial plane, 32 x 2 per time plane, anchored at the block's smallest tap) and flushes each touched
-// cell row to HBM once.  Taps outside a window take the direct global atomic, so any order is correct.  The LDS adds are
-// compare-and-swap loops (device_utils.h: the native ds_add_f32 is ~10x slower on gfx950).
-// Measured at N = 2 M on the street scene, 4 scales x 32 channels: 29 ms plain -> 9.1 ms (structure 5.3, LDS adds 2.3, the
-// remaining global atomics 1.5); geometries 1024/256/16, 512/128/12, 256/256/8 threads/points/window were within 20 %.
+// The plain backward issues one row of float atomics per tap (N x 24 planes x 4 taps).  A CU issues a 64-lane global float atomic
+// in ~117 clocks whatever the rows, their locality or the memory scope (profiles/r03_global_atomic_microbench.txt: 10.4 G rows of
+// 128 bytes per second chip-wide, against 57 G rows/s of plain stores), and while it does, the gathers of its other waves queue
+// behind the atomics in the same vector-memory pipe: at N = 2 M that is ~20 ms no matter how the rows are spread.  So the lever is
+// issuing fewer rows.  When the caller hands the points in a spatially coherent order (`order`: e.g. Morton order of the
+// positions), 256 consecutive points fall into a small box, and their taps into a few cells of every plane -- above all on the
+// coarse scales and on the three time planes.  A block therefore accumulates its 256 points into LDS windows (12 x 12 cells per
+// spatial plane, 32 cells per time plane, anchored at the block's smallest tap) and flushes each touched cell row to HBM once.
+// Taps outside a window take the direct global atomic, so any order is correct.
+//
+// Round 3 (the round-2 kernel: 512 threads, fp32 windows added to with compare-and-swap loops, every channel lane repeating the
+// per-point scalar work, 11.1 ms at 2 M uniform points; this one 7.7 ms):
+//  * the windows are fp64 and added to with ds_add_f64 -- the one native LDS float add that runs at rate on gfx950 (8.9 clocks per
+//    wave64 instruction against 16.9 for the fp32 compare-and-swap loop and 193 for ds_add_f32: profiles/r03_lds_atomic_microbench.txt),
+//    returns nothing, so no wave waits on it, and resolves same-cell collisions in hardware.  One 1024-thread block per CU owns 152 KB;
+//  * phase 0 normalises the block's points once into LDS (s_q) and finds the bounding box of the block;
+//  * the scalar part of a tap -- un-normalise, clip, floor, offset, strides, window address -- is done by one LANE per (point,
+//    plane) pair and left in LDS (32 bytes per pair); the lane = channel part reads it back as broadcast loads: per plane 2 LDS
+//    reads, 4 gathers (uniform base + 32-bit byte offset), the sample and its two slopes, 4 adds;
+//  * the waves of a block run on their own between the flushes, as a software pipeline (see the loop);
+//  * when every point of the block carries the same time (one frame per step: always, in training) the three time planes are
+//    accumulated as x-MARGINALS: two adds per point instead of four, into 32 cells per plane, and the flush spreads a cell over the
+//    two time rows with the block's (1 - ft, ft).  Blocks with mixed times use the same memory as 16 x 2 windows;
+//  * dL/dpts and dL/dtimes are summed over the scales in LDS and written once.
+// What bounds it now (2 M uniform points, rocprofv3 counters): 31 M wave-level atomic instructions = 55 M rows, of which 38 M are
+// the direct rows of the two finest scales (a 256-point run spans ~40 x 40 cells of the 512-cell planes and puts 1.4 taps into a
+// cell: nothing to aggregate) and 13 M the flushes; with the atomics compiled out the kernel takes 3.4 ms.
 #ifndef HEX_AGG_THREADS
-#define HEX_AGG_THREADS 512              /* two blocks per CU (78 KB of LDS each at 32 channels): one block's barriers hide behind the other */
+#define HEX_AGG_THREADS 1024             /* one block per CU (152 KB of LDS at 32 channels), four waves per SIMD */
 #define HEX_AGG_POINTS 256
 #define HEX_SW 12                        /* spatial window: HEX_SW x HEX_SW cells */
 #endif
-#define HEX_TW 32                        /* time-plane window: HEX_TW x 2 cells */
+#define HEX_TW 32                        /* time-plane window: HEX_TW marginal cells, or (HEX_TW / 2) x 2 cells */
 #define HEX_SCELLS (HEX_SW * HEX_SW)
-#define HEX_TCELLS (HEX_TW * 2)
-#define HEX_WIN_CELLS (3 * HEX_SCELLS + 3 * HEX_TCELLS)
-__device__ __forceinline__ void win_shape(int p, int& base, int& wx, int& wy) {
-    // planes 0 (xy), 1 (xz), 3 (yz) are spatial; 2 (xt), 4 (yt), 5 (zt) have the time axis as their second (height) axis
-    const int B[6] = {0, HEX_SCELLS, 3 * HEX_SCELLS, 2 * HEX_SCELLS, 3 * HEX_SCELLS + HEX_TCELLS, 3 * HEX_SCELLS + 2 * HEX_TCELLS};
-    base = B[p];
-    const bool time_plane = (p == 2) || (p >= 4);
-    wx = time_plane ? HEX_TW : HEX_SW;
-    wy = time_plane ? 2 : HEX_SW;
-}
+#define HEX_WIN_CELLS (3 * HEX_SCELLS + 3 * HEX_TW)
+
+__device__ __forceinline__ int sel4i(int v0, int v1, int v2, int v3, int k) { return k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3)); }
+__device__ __forceinline__ float sel4f(float v0, float v1, float v2, float v3, int k) { return k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3)); }
+__device__ __forceinline__ int order_key(float v) { const int b = __float_as_int(v); return b >= 0 ? b : b ^ 0x7fffffff; }   // monotone int image
+__device__ __forceinline__ float key_value(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
 
 template <int C>
-__global__ void __launch_bounds__(HEX_AGG_THREADS) k_hexplane_bwd_agg(EmdHexArgs a, EmdHexGrads g, unsigned chunk_stride) {
-    __shared__ float win[HEX_WIN_CELLS * C];
-    constexpr int GROUPS = HEX_AGG_THREADS / C, ROUNDS = HEX_AGG_POINTS / GROUPS;
-    const int tid = threadIdx.x, group = tid / C, c = tid % C, S = a.num_scales;
+__global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexArgs a, EmdHexGrads g, unsigned chunk_stride) {
+    constexpr int WAVES = HEX_AGG_THREADS / 64, GW = 64 / C, PER_WAVE = HEX_AGG_POINTS / WAVES, ITERS = PER_WAVE / GW, GROUPS = HEX_AGG_THREADS / C;
+    static_assert(GW * 6 <= 64 && C <= 32 && PER_WAVE % GW == 0, "staging geometry");
+    __shared__ double win[HEX_WIN_CELLS * C];           // fp64 cells: ds_add_f64 is the one native LDS float add that runs at rate on gfx950
+    __shared__ uint4 s_a[WAVES * 2 * GW * 6];           // per wave, two buffers of (point, plane) rows: offset of tap (x0, y0), row stride to y1,
+    __shared__ float4 s_b[WAVES * 2 * GW * 6];          //   window address, dx | sy << 8;  fx, fy, d(ix)/d(coord), d(iy)/d(coord)
+    __shared__ float4 s_q[HEX_AGG_POINTS];              // box-normalised x, y, z and the time of every point of the block
+    __shared__ float4 s_dq[HEX_AGG_POINTS];             // dL/d(those), summed over the scales
+    __shared__ int s_n[HEX_AGG_POINTS];                 // its index (-1 past the end)
+    __shared__ int qmin[4], qmax[4];
+    const int tid = threadIdx.x, group = tid / C, c = tid % C, S = a.num_scales, lane = tid & 63, wave = tid >> 6, gw = lane / C;
     // blocks that run side by side take chunks far apart along the curve (stride coprime with the grid): neighbouring chunks
     // flush to the same plane rows, and float atomics to one cache line from many CUs queue up in a single L2 channel
     const long first = (long)(((unsigned long long)blockIdx.x * chunk_stride) % gridDim.x) * HEX_AGG_POINTS;
-    __shared__ int qmin[4];
-    for (int i = tid; i < HEX_WIN_CELLS * C; i += HEX_AGG_THREADS) win[i] = 0.f;
-    if (tid < 4) qmin[tid] = INT_MAX;
+    for (int i = tid; i < HEX_WIN_CELLS * C; i += HEX_AGG_THREADS) win[i] = 0.0;
+    if (tid < 4) { qmin[tid] = INT_MAX; qmax[tid] = INT_MIN; }
     __syncthreads();
-    // the block's smallest coordinate per axis (order-preserving integer image of the float): un-normalise, clip and floor are
-    // monotone, so on every scale and plane the smallest tap cell of the block is the tap cell of this corner
-    for (int r = 0; r < ROUNDS; r++) {
-        const long slot = first + r * GROUPS + group;
-        if (slot >= a.num_points || c >= 4) continue;
-        const long n = a.order ? (long)a.order[slot] : slot;
-        const float qv = c < 3 ? (a.pts[3 * n + c] - a.aabb[c]) * (2.f / (a.aabb[3 + c] - a.aabb[c])) - 1.f : a.times[n];
-        const int bits = __float_as_int(qv);
-        atomicMin(&qmin[c], bits >= 0 ? bits : bits ^ 0x7fffffff);
+    // phase 0: item = (point, axis).  Un-normalise, clip and floor are monotone, so on every scale and plane the smallest tap cell
+    // of the block is the tap cell of its smallest coordinates (order-preserving integer image of the floats)
+    for (int item = tid; item < HEX_AGG_POINTS * 4; item += HEX_AGG_THREADS) {
+        const int j = item >> 2, k = item & 3;
+        const long slot = first + j;
+        float qv = 0.f;
+        int n = -1;
+        if (slot < a.num_points) {
+            n = a.order ? a.order[slot] : (int)slot;
+            qv = k < 3 ? (a.pts[3 * (long)n + k] - a.aabb[k]) * (2.f / (a.aabb[3 + k] - a.aabb[k])) - 1.f : a.times[n];
+            const int key = order_key(qv);
+            atomicMin(&qmin[k], key);
+            atomicMax(&qmax[k], key);
+        }
+        ((float*)&s_q[j])[k] = qv;
+        ((float*)&s_dq[j])[k] = 0.f;
+        if (k == 0) s_n[j] = n;
     }
     __syncthreads();
     float qlo[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int bits = qmin[k]; qlo[k] = __int_as_float(bits >= 0 ? bits : bits ^ 0x7fffffff); }
+    for (int k = 0; k < 4; k++) qlo[k] = key_value(qmin[k]);
+    const bool tuni = qmin[3] == qmax[3];               // one time for the whole block: time planes as marginals
     const bool want_dq = g.dL_dpts || g.dL_dtimes;
+    const int twx = tuni ? HEX_TW : HEX_TW / 2, twy = tuni ? 1 : 2;
+    const int sb = wave * 2 * GW * 6;                   // the wave's staging rows
     for (int s = 0; s < S; s++) {
-        int anc[12];
+        int anc[4];
 #pragma unroll
-        for (int p = 0; p < 6; p++) {
-            int ax, ay;
-            pair_axes(p, ax, ay);
-            const Bilin b = bilin(qlo[ax], qlo[ay], a.res[s][ax], a.res[s][ay]);
-            anc[2 * p] = b.x0; anc[2 * p + 1] = b.y0;
-        }
-        // phase 2: per point the six samples, the product rule, and the taps into the windows
-        for (int r = 0; r < ROUNDS; r++) {
-            const long slot = first + r * GROUPS + group;
-            if (slot >= a.num_points) continue;
-            const long n = a.order ? (long)a.order[slot] : slot;
-            float q[4];
-#pragma unroll
-            for (int k = 0; k < 3; k++) q[k] = (a.pts[3 * n + k] - a.aabb[k]) * (2.f / (a.aabb[3 + k] - a.aabb[k])) - 1.f;
-            q[3] = a.times[n];
-            float f[6], dix[6], diy[6], dq[4] = {0.f, 0.f, 0.f, 0.f};
-            Tap1 axis[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) axis[k] = tap1(q[k], a.res[s][k]);
-#pragma unroll
-            for (int p = 0; p < 6; p++) {
-                int ax, ay;
-                pair_axes(p, ax, ay);
-                const Bilin b = make_bilin(axis[ax], axis[ay]);
-                if (want_dq) f[p] = sample_slopes(a.planes[s][p], b, a.res[s][ax], C, c, dix[p], diy[p]);
-                else f[p] = sample(a.planes[s][p], b, a.res[s][ax], C, c);
+        for (int k = 0; k < 4; k++) anc[k] = tap1(qlo[k], a.res[s][k]).i0;
+        const Tap1 tt = tap1(qlo[3], a.res[s][3]);      // the block's time tap (meaningful when tuni)
+        // The waves of the block run on their own from here to the flush, GW points (one per C-lane group) per iteration, as a
+        // software pipeline:  stage(it + 1) | wait for the taps of `it` | sample, slopes, product rule | issue the gathers of it + 1 |
+        // scatter the rows of `it`.  No block barrier in the loop, so the waves drift apart and one wave's gathers overlap another's
+        // arithmetic and a third's adds; and within a wave the next gathers are in flight while the adds and atomics are issued
+        // (with block-wide batches every wave sat in the same phase at the same time: 70 % of a wave's life in s_waitcnt).
+        // ---- staging, item = (point, plane), lanes 0 .. 6 GW - 1 of the wave: un-normalise, clip, floor, offsets, window address
+        auto stage = [&](int it) {
+            if (lane < GW * 6) {
+                const int jj = lane / 6, p = lane - 6 * jj, pt = wave * PER_WAVE + it * GW + jj, n = s_n[pt];
+                if (n >= 0) {
+                    int ax, ay;
+                    pair_axes(p, ax, ay);
+                    const float4 q = s_q[pt];
+                    const int W = a.res[s][ax], H = a.res[s][ay];
+                    const Tap1 tx = tap1(sel4f(q.x, q.y, q.z, q.w, ax), W), ty = tap1(sel4f(q.x, q.y, q.z, q.w, ay), H);
+                    const bool time_plane = ay == 3, marg = time_plane && tuni;
+                    const int wx = time_plane ? twx : HEX_SW, wy = time_plane ? twy : HEX_SW;
+                    const int ancx = sel4i(anc[0], anc[1], anc[2], anc[3], ax), ancy = sel4i(anc[0], anc[1], anc[2], anc[3], ay);
+                    const int cx0 = tx.i0 - ancx, cx1 = tx.i1 - ancx, cy0 = marg ? 0 : ty.i0 - ancy, cy1 = marg ? 0 : ty.i1 - ancy;
+                    // window base of the plane: spatial planes 0 (xy), 1 (xz), 3 (yz), then the time planes 2 (xt), 4 (yt), 5 (zt)
+                    const int wbase = time_plane ? 3 * HEX_SCELLS + (p == 2 ? 0 : (p == 4 ? HEX_TW : 2 * HEX_TW)) : (p == 3 ? 2 : p) * HEX_SCELLS;
+                    // the whole 2 x 2 footprint in the window (the anchor is the block's smallest tap, but a NaN coordinate maps to
+                    // cell 0): one address, two strides (0 where the neighbour was clamped onto the same cell at the border)
+                    const bool inside = cx0 >= 0 && cy0 >= 0 && cx1 < wx && cy1 < wy;
+                    const uint32_t lds = inside ? (uint32_t)((wbase + cy0 * wx + cx0) * C) : 0xffffffffu;
+                    const uint32_t dx = (uint32_t)((tx.i1 - tx.i0) * C), sy = (uint32_t)((cy1 - cy0) * wx * C);
+                    const int row = sb + (it & 1) * GW * 6 + lane;
+                    s_a[row] = make_uint4(tap_at(tx.i0, ty.i0, W, C, 0), (uint32_t)(ty.i1 - ty.i0) * (uint32_t)W * (uint32_t)C, lds, dx | (sy << 8));
+                    s_b[row] = make_float4(tx.f, ty.f, tx.ds, ty.ds);
+                }
             }
-            const float go = g.dL_dout[(size_t)n * (S * C) + s * C + c];
-            float pre[7], suf[7];
-            pre[0] = 1.f; suf[6] = 1.f;
+        };
+        float nw[6], ne[6], sw[6], se[6], go = 0.f;
+        int n = -1;
+        // ---- the gathers of iteration `it`: uniform plane base + 32-bit byte offsets (the saddr form: no 64-bit address arithmetic)
+        auto gather = [&](int it) {
+            n = s_n[wave * PER_WAVE + it * GW + gw];
+            if (n >= 0) {
+                go = g.dL_dout[(size_t)n * (S * C) + s * C + c];
 #pragma unroll
-            for (int p = 0; p < 6; p++) pre[p + 1] = pre[p] * f[p];
+                for (int p = 0; p < 6; p++) {
+                    const uint4 A = s_a[sb + (it & 1) * GW * 6 + gw * 6 + p];
+                    const char* __restrict__ pl = (const char*)a.planes[s][p];
+                    const uint32_t dx = (A.w & 0xffu) << 2, o00 = (A.x + c) << 2, dy = A.y << 2;
+                    nw[p] = *(const float*)(pl + o00); ne[p] = *(const float*)(pl + (o00 + dx));
+                    sw[p] = *(const float*)(pl + (o00 + dy)); se[p] = *(const float*)(pl + (o00 + dy + dx));
+                }
+            }
+        };
+        stage(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // the wave's own LDS writes, read back by its other lanes
+        __builtin_amdgcn_wave_barrier();
+        gather(0);
+#pragma unroll 1
+        for (int it = 0; it < ITERS; it++) {
+            if (it + 1 < ITERS) stage(it + 1);
+            const int rowb = sb + (it & 1) * GW * 6 + gw * 6, pt = wave * PER_WAVE + it * GW + gw, n_cur = n;
+            float gi[6];
+            if (n_cur >= 0) {
+                float f[6], dix[6], diy[6];
 #pragma unroll
-            for (int p = 5; p >= 0; p--) suf[p] = suf[p + 1] * f[p];
+                for (int p = 0; p < 6; p++) {
+                    const float4 B = s_b[rowb + p];
+                    const float fx = B.x, fy = B.y;
+                    // grid_sampler_2d: nw * (1-fx)(1-fy) + ne * fx (1-fy) + sw * (1-fx) fy + se * fx fy; the clamped neighbour
+                    // (x1 == x0 at the border) contributes no slope: its weight is 0 and the clip mask is 0
+                    f[p] = nw[p] * ((1.f - fx) * (1.f - fy)) + ne[p] * (fx * (1.f - fy)) + sw[p] * ((1.f - fx) * fy) + se[p] * (fx * fy);
+                    dix[p] = ((ne[p] - nw[p]) * (1.f - fy) + (se[p] - sw[p]) * fy) * B.z;
+                    diy[p] = ((sw[p] - nw[p]) * (1.f - fx) + (se[p] - ne[p]) * fx) * B.w;
+                }
+                float pre[7], suf[7], dq[4] = {0.f, 0.f, 0.f, 0.f};
+                pre[0] = 1.f; suf[6] = 1.f;
 #pragma unroll
-            for (int p = 0; p < 6; p++) {
-                int ax, ay, wbase, wx, wy;
-                pair_axes(p, ax, ay);
-                win_shape(p, wbase, wx, wy);
-                const int W = a.res[s][ax];
-                const float gi = go * (pre[p] * suf[p + 1]);
-                const Bilin b = make_bilin(axis[ax], axis[ay]);
-                float* gp = g.dL_dplanes[s][p];
-                if (gp && gi != 0.f) {
-                    const int cx0 = b.x0 - anc[2 * p], cy0 = b.y0 - anc[2 * p + 1], cx1 = b.x1 - anc[2 * p], cy1 = b.y1 - anc[2 * p + 1];
-                    const float w00 = gi * ((1.f - b.fx) * (1.f - b.fy)), w10 = gi * (b.fx * (1.f - b.fy));
-                    const float w01 = gi * ((1.f - b.fx) * b.fy), w11 = gi * (b.fx * b.fy);
-                    if ((unsigned)cx1 < (unsigned)wx && (unsigned)cy1 < (unsigned)wy && cx0 >= 0 && cy0 >= 0) {
-                        // the whole 2 x 2 footprint lies in the window (the anchor is the block's smallest tap, so c*0 >= 0): one
-                        // address, three strides (0 where the neighbour was clamped onto the same cell at the border; its weight is 0)
-                        float* w0 = &win[(wbase + cy0 * wx + cx0) * C + c];
-                        const int sx = (cx1 - cx0) * C, sy = (cy1 - cy0) * wx * C;
-                        lds_add_f32(w0, w00);
-                        lds_add_f32(w0 + sx, w10);
-                        lds_add_f32(w0 + sy, w01);
-                        lds_add_f32(w0 + sy + sx, w11);
-                    } else {
-                        const int xs[2] = {b.x0, b.x1}, ys[2] = {b.y0, b.y1}, cxs[2] = {cx0, cx1}, cys[2] = {cy0, cy1};
-                        const float ws[4] = {w00, w10, w01, w11};
+                for (int p = 0; p < 6; p++) pre[p + 1] = pre[p] * f[p];
 #pragma unroll
-                        for (int j = 0; j < 2; j++)
+                for (int p = 5; p >= 0; p--) suf[p] = suf[p + 1] * f[p];
 #pragma unroll
-                            for (int i = 0; i < 2; i++) {
-                                if ((unsigned)cxs[i] < (unsigned)wx && (unsigned)cys[j] < (unsigned)wy) lds_add_f32(&win[(wbase + cys[j] * wx + cxs[i]) * C + c], ws[2 * j + i]);
-                                else atomicAdd(gp + tap_at(xs[i], ys[j], W, C, c), ws[2 * j + i]);
-                            }
-                    }
+                for (int p = 0; p < 6; p++) {
+                    int ax, ay;
+                    pair_axes(p, ax, ay);
+                    gi[p] = go * (pre[p] * suf[p + 1]);                      // dL / d interp of plane p, channel c
+                    dq[ax] += gi[p] * dix[p];
+                    dq[ay] += gi[p] * diy[p];
                 }
                 if (want_dq) {
-                    dq[ax] += gi * dix[p];
-                    dq[ay] += gi * diy[p];
-                }
-            }
-            if (want_dq) {
-                // a point belongs to one thread group of one block: plain read-modify-write across the scales
+                    // summed over the C channel lanes; a point belongs to one lane group of one wave: plain adds across the scales
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    float v = dq[k];
-                    for (int off = C >> 1; off; off >>= 1) v += __shfl_xor(v, off, C);
+                    for (int k = 0; k < 4; k++)
+                        for (int off = C >> 1; off; off >>= 1) dq[k] += __shfl_xor(dq[k], off, C);
                     if (c == 0) {
-                        if (k < 3) {
-                            if (g.dL_dpts) {
-                                const float add = v * (2.f / (a.aabb[3 + k] - a.aabb[k]));
-                                g.dL_dpts[3 * n + k] = s ? g.dL_dpts[3 * n + k] + add : add;
-                            }
-                        } else if (g.dL_dtimes) g.dL_dtimes[n] = s ? g.dL_dtimes[n] + v : v;
+                        float4 acc = s_dq[pt];
+                        acc.x += dq[0]; acc.y += dq[1]; acc.z += dq[2]; acc.w += dq[3];
+                        s_dq[pt] = acc;
                     }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // stage(it + 1) is visible to the wave
+            __builtin_amdgcn_wave_barrier();
+            if (it + 1 < ITERS) gather(it + 1);                          // in flight while the rows of `it` are scattered
+            // ---- the 24 tap rows of the point: rows inside the windows are native fp64 LDS adds, rows outside leave as global float
+            // atomics; both are fire and forget
+            if (n_cur >= 0) {
+#pragma unroll
+                for (int p = 0; p < 6; p++) {
+                    const bool marg = (p == 2 || p >= 4) && tuni;         // marginal over the block's time: two rows
+                    float* gp = g.dL_dplanes[s][p];
+                    if (!gp || gi[p] == 0.f) continue;
+                    const uint4 A = s_a[rowb + p];                       // (read again: cheaper than live registers)
+                    const float4 Bq = s_b[rowb + p];
+                    const float fx = Bq.x, fy = Bq.y;
+                    const uint32_t dx = A.w & 0xffu, sy = A.w >> 8;
+                    if (A.z != 0xffffffffu) {
+                        double* w0 = &win[A.z + c];
+                        if (marg) {
+                            lds_add_f64(w0, gi[p] * (1.f - fx));
+                            lds_add_f64(w0 + dx, gi[p] * fx);
+                        } else {
+                            lds_add_f64(w0, gi[p] * ((1.f - fx) * (1.f - fy)));
+                            lds_add_f64(w0 + dx, gi[p] * (fx * (1.f - fy)));
+                            lds_add_f64(w0 + sy, gi[p] * ((1.f - fx) * fy));
+                            lds_add_f64(w0 + sy + dx, gi[p] * (fx * fy));
+                        }
+                    } else {
+                        char* g0 = (char*)gp;
+                        const uint32_t b00 = (A.x + c) << 2, bdx = dx << 2, bdy = A.y << 2;
+                        atomicAdd((float*)(g0 + b00), gi[p] * ((1.f - fx) * (1.f - fy)));
+                        atomicAdd((float*)(g0 + (b00 + bdx)), gi[p] * (fx * (1.f - fy)));
+                        atomicAdd((float*)(g0 + (b00 + bdy)), gi[p] * ((1.f - fx) * fy));
+                        atomicAdd((float*)(g0 + (b00 + bdy + bdx)), gi[p] * (fx * fy));
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (stage(it + 2) overwrites the rows read here)
+            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
-        // phase 3: every touched cell row goes to HBM once; the windows are left clean for the next scale
+        // ---- flush: every touched cell row goes to HBM once; the windows are left clean for the next scale
         for (int cell = group; cell < HEX_WIN_CELLS; cell += GROUPS) {
-            const float v = win[cell * C + c];
-            if (v == 0.f) continue;
-            win[cell * C + c] = 0.f;
-            const int p = cell < 3 * HEX_SCELLS ? (cell < HEX_SCELLS ? 0 : (cell < 2 * HEX_SCELLS ? 1 : 3))
-                                                : (cell < 3 * HEX_SCELLS + HEX_TCELLS ? 2 : (cell < 3 * HEX_SCELLS + 2 * HEX_TCELLS ? 4 : 5));
-            int ax, ay, wbase, wx, wy;
-            pair_axes(p, ax, ay);
-            win_shape(p, wbase, wx, wy);
-            const int local = cell - wbase, x = anc[2 * p] + local % wx, y = anc[2 * p + 1] + local / wx;
-            atomicAdd(g.dL_dplanes[s][p] + tap_at(x, y, a.res[s][ax], C, c), v);   // (only cells a tap reached are non-zero)
+            const float v = (float)win[cell * C + c];
+            if (v == 0.f) continue;                       // (only cells a tap reached are non-zero)
+            win[cell * C + c] = 0.0;
+            if (cell < 3 * HEX_SCELLS) {
+                const int idx = cell / HEX_SCELLS, local = cell - idx * HEX_SCELLS, p = idx == 2 ? 3 : idx;
+                int ax, ay;
+                pair_axes(p, ax, ay);
+                const int x = sel4i(anc[0], anc[1], anc[2], anc[3], ax) + local % HEX_SW, y = sel4i(anc[0], anc[1], anc[2], anc[3], ay) + local / HEX_SW;
+                atomicAdd(g.dL_dplanes[s][p] + tap_at(x, y, a.res[s][ax], C, c), v);
+            } else {
+                const int idx = (cell - 3 * HEX_SCELLS) / HEX_TW, local = cell - 3 * HEX_SCELLS - idx * HEX_TW, p = idx == 0 ? 2 : (idx == 1 ? 4 : 5);
+                const int ax = idx, W = a.res[s][ax];       // planes 2, 4, 5 pair x, y, z with the time
+                float* gp = g.dL_dplanes[s][p];
+                if (tuni) {
+                    const int x = sel4i(anc[0], anc[1], anc[2], anc[3], ax) + local;
+                    atomicAdd(gp + tap_at(x, tt.i0, W, C, c), v * (1.f - tt.f));
+                    if (tt.f != 0.f) atomicAdd(gp + tap_at(x, tt.i1, W, C, c), v * tt.f);
+                } else {
+                    const int x = sel4i(anc[0], anc[1], anc[2], anc[3], ax) + local % (HEX_TW / 2), y = anc[3] + local / (HEX_TW / 2);
+                    atomicAdd(gp + tap_at(x, y, W, C, c), v);
+                }
+            }
         }
         __syncthreads();
     }
+    // dL/dpts through normalize_aabb (the time coordinate is used as given)
+    if (want_dq)
+        for (int item = tid; item < HEX_AGG_POINTS * 4; item += HEX_AGG_THREADS) {
+            const int j = item >> 2, k = item & 3, n = s_n[j];
+            if (n < 0) continue;
+            const float v = ((const float*)&s_dq[j])[k];
+            if (k < 3) { if (g.dL_dpts) g.dL_dpts[3 * (long)n + k] = v * (2.f / (a.aabb[3 + k] - a.aabb[k])); }
+            else if (g.dL_dtimes) g.dL_dtimes[n] = v;
+        }
 }
 
 template <int C>
@@ -425,9 +523,16 @@ extern "C" int emd_hexplane_backward(const EmdHexArgs* a, const EmdHexGrads* g, 
     if (rc) return rc;
     if (!g || !g->dL_dout) { emd_set_error("hexplane_backward: null gradient"); return EMD_ERR_INVALID; }
     if (a->num_points == 0) return EMD_OK;
-    // a visiting order promises spatial coherence: aggregate in LDS (windows are sized for C <= 32)
-    if (a->order && a->channels == 32) launch_bwd_agg<32>(a, g, (hipStream_t)hip_stream);
-    else if (a->order && a->channels == 16) launch_bwd_agg<16>(a, g, (hipStream_t)hip_stream);
+    // a visiting order promises spatial coherence: aggregate in LDS (windows are sized for C <= 32; the kernel addresses a plane
+    // with 32-bit BYTE offsets, so planes of 2^30 floats or more take the direct kernel)
+    bool small_planes = true;
+    for (int s = 0; s < a->num_scales; s++)
+        for (int p = 0; p < 6; p++) {
+            const int A_[6] = {0, 0, 0, 1, 1, 2}, B_[6] = {1, 2, 3, 2, 3, 3};
+            if ((int64_t)a->res[s][A_[p]] * a->res[s][B_[p]] * a->channels >= ((int64_t)1 << 30)) small_planes = false;
+        }
+    if (a->order && small_planes && a->channels == 32) launch_bwd_agg<32>(a, g, (hipStream_t)hip_stream);
+    else if (a->order && small_planes && a->channels == 16) launch_bwd_agg<16>(a, g, (hipStream_t)hip_stream);
     else {
         const int per_block = EMD_BLOCK / a->channels;
         hipLaunchKernelGGL(k_hexplane_bwd, dim3((unsigned)((a->num_points + per_block - 1) / per_block)), dim3(EMD_BLOCK), 0,
