@@ -205,6 +205,8 @@ def main():
     ap.add_argument("--factored-sh", action="store_true", help="use the multi-GPU SH-gradient factor exchange at any world size (1 GPU: measures its local cost)")
     ap.add_argument("--no-track-heads", action="store_true", help="leave the learned per-actor track offsets out of the step")
     ap.add_argument("--densify-stats", action="store_true", help="also accumulate the per-view densification statistics every step (one launch)")
+    ap.add_argument("--settle-ms", type=float, default=150.0, help="untimed replays of the step before the warm-up steps until this much wall time has passed: "
+                    "the clocks of an idle GPU take tens of milliseconds of load to settle, more than 5 warm-up steps of 1.4 ms provide (0 = off)")
     ap.add_argument("--eager", action="store_true", help="issue every step from Python instead of replaying it from a hipGraph (1 GPU)")
     ap.add_argument("--exchange-only", action="store_true",
                     help="time ONLY the gradient exchange of a view-parallel step (GradientExchange.start + finish on a fixed backward's outputs): "
@@ -321,6 +323,7 @@ def main():
     # (--eager, or a failed capture, issues the same step from Python.)
     period = args.warmup + args.steps             # the repeats replay the timed views: row = warmup + (step - warmup) mod steps
     graph = None
+    settle_replays = 0
     out = o = None          # no autograd graph of an eager step may be alive at capture time (its AccumulateGrad nodes are bound to the eager stream)
     import gc
     gc.collect()            # ... including graphs held only by reference cycles (RasterCall <-> GradientExchange)
@@ -400,14 +403,31 @@ def main():
                     raise RuntimeError(f"replay {rep_}: non-finite parameter gradients")
                 if world == 1 and float((g_ - want_grad).abs().max()) > 1e-4 * float(want_grad.abs().max()) + 1e-12:      # (N > 1: the eager step averaged over ranks)
                     raise RuntimeError(f"replay {rep_}: parameter gradients differ from the eager step's")
+            # ---- settle: the GPU has idled through set-up, capture and the host-side checks above; replay the step (untimed, rows walk
+            # on from row 1) until the clocks have settled, so that the warm-up steps and the timed region run at the rate a training
+            # run sees (measured: with --steps 20 --warmup 5 the first timed block was 2.4 % slower than its back-to-back repeats)
+            t_settle = time.perf_counter()
+            while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+                for _ in range(8):
+                    graph.replay()
+                    settle_replays += 1
+                torch.cuda.synchronize()
             sel.fill_(0)                                      # the first replay renders row 0; every replay leaves the next row in `sel`
             prev_sel.fill_(-1)
+            torch.cuda.synchronize()
         except Exception as e:          # capture is an optimisation of the host side only: fall back to issuing the step from Python
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
 
     def row_of(step):
         return step if step < period else args.warmup + (step - args.warmup) % args.steps
+
+    if graph is None and args.settle_ms > 0:                  # the eager step settles the same way
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            one_step(0)
+            settle_replays += 1
+            torch.cuda.synchronize()
 
     def timed_step(step):
         if graph is not None:
@@ -554,6 +574,7 @@ def main():
             "repeats_ms_per_step": None if not rep else {"n": len(rep), "min": round(rep_sorted[0], 4), "median": round(rep_sorted[len(rep) // 2], 4),
                                                         "max": round(rep_sorted[-1], 4),
                                                         "note": "the timed block replayed again back to back after it; `value` is the first block only"},
+            "settle": {"ms": args.settle_ms, "untimed_steps": settle_replays, "note": "untimed steps before the warm-up steps: an idle GPU's clocks settle under load"},
             "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"] + (f" ({num_actors} actors x 5000" + (", learned per-actor track offsets" if heads_on else "") + ")" if num_actors else "")
