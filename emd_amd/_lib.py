@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16
@@ -104,7 +104,8 @@ class EmdHexArgs(C.Structure):
 
 
 class EmdHexGrads(C.Structure):
-    _fields_ = [("dL_dout", _f), ("dL_dplanes", (_f * 6) * HEX_MAX_SCALES), ("dL_dpts", _f), ("dL_dtimes", _f)]
+    _fields_ = [("dL_dout", _f), ("dL_dplanes", (_f * 6) * HEX_MAX_SCALES), ("dL_dpts", _f), ("dL_dtimes", _f),
+                ("order2d", C.c_void_p * 3), ("pos2d", C.c_void_p * 3), ("defer_rows", _f), ("defer_mask", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class EmdDeformInArgs(C.Structure):

@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd2(EmdHexArgs a) {
 #ifndef HEX_AGG_THREADS
 #define HEX_AGG_THREADS 1024             /* one block per CU (152 KB of LDS at 32 channels), four waves per SIMD */
 #define HEX_AGG_POINTS 256
-#define HEX_SW 12                        /* spatial window: HEX_SW x HEX_SW cells */
+#define HEX_SW 10                        /* spatial window: HEX_SW x HEX_SW cells (finer scales go through the per-plane pass) */
 #endif
 #define HEX_TW 32                        /* time-plane window: HEX_TW marginal cells, or (HEX_TW / 2) x 2 cells */
 #define HEX_SCELLS (HEX_SW * HEX_SW)
@@ -258,13 +258,16 @@ __device__ __forceinline__ float key_value(int k) { return __int_as_float(k >= 0
 template <int C>
 __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexArgs a, EmdHexGrads g, unsigned chunk_stride) {
     constexpr int WAVES = HEX_AGG_THREADS / 64, GW = 64 / C, PER_WAVE = HEX_AGG_POINTS / WAVES, ITERS = PER_WAVE / GW, GROUPS = HEX_AGG_THREADS / C;
-    static_assert(GW * 6 <= 64 && C <= 32 && PER_WAVE % GW == 0, "staging geometry");
+    constexpr int SROWS = 2 * GW * 6;                   // staging rows of TWO iterations (one stage() call)
+    static_assert(SROWS <= 64 && C <= 32 && PER_WAVE % GW == 0 && ITERS % 2 == 0, "staging geometry");
     __shared__ double win[HEX_WIN_CELLS * C];           // fp64 cells: ds_add_f64 is the one native LDS float add that runs at rate on gfx950
-    __shared__ uint4 s_a[WAVES * 2 * GW * 6];           // per wave, two buffers of (point, plane) rows: offset of tap (x0, y0), row stride to y1,
-    __shared__ float4 s_b[WAVES * 2 * GW * 6];          //   window address, dx | sy << 8;  fx, fy, d(ix)/d(coord), d(iy)/d(coord)
+    __shared__ uint4 s_a[WAVES * 2 * SROWS];            // per wave, two buffers of (point, plane) rows: offset of tap (x0, y0), row stride to y1, window address, dx | sy << 8
+    __shared__ float4 s_w[WAVES * 2 * SROWS];           //   the four bilinear weights (nw, ne, sw, se)
+    __shared__ float4 s_c[WAVES * 2 * SROWS];           //   slope coefficients: d(ix)/d(coord) (1 - fy), d(ix)/d(coord) fy, d(iy)/d(coord) (1 - fx), d(iy)/d(coord) fx
     __shared__ float4 s_q[HEX_AGG_POINTS];              // box-normalised x, y, z and the time of every point of the block
     __shared__ float4 s_dq[HEX_AGG_POINTS];             // dL/d(those), summed over the scales
     __shared__ int s_n[HEX_AGG_POINTS];                 // its index (-1 past the end)
+    __shared__ int s_pos[HEX_AGG_POINTS * 3];           // its position in the visiting orders of the planes xy, xz, yz (deferred scales)
     __shared__ int qmin[4], qmax[4];
     const int tid = threadIdx.x, group = tid / C, c = tid % C, S = a.num_scales, lane = tid & 63, wave = tid >> 6, gw = lane / C;
     // blocks that run side by side take chunks far apart along the curve (stride coprime with the grid): neighbouring chunks
@@ -290,29 +293,43 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         ((float*)&s_q[j])[k] = qv;
         ((float*)&s_dq[j])[k] = 0.f;
         if (k == 0) s_n[j] = n;
+        else if (g.defer_mask && n >= 0) s_pos[3 * j + k - 1] = g.pos2d[k - 1][n];
     }
     __syncthreads();
+    if (g.defer_mask && tid < HEX_AGG_POINTS * 3) {
+        // the per-plane pass reads the two normalised coordinates of a point at its position in the plane's order (behind the rows)
+        const int j = tid / 3, pidx = tid - 3 * j;
+        if (s_n[j] >= 0) {
+            const float4 q = s_q[j];
+            float2* defer_q = (float2*)(g.defer_rows + (size_t)__builtin_popcount(g.defer_mask) * 3 * (size_t)a.num_points * C) + (size_t)pidx * a.num_points;
+            defer_q[s_pos[3 * j + pidx]] = pidx == 0 ? make_float2(q.x, q.y) : (pidx == 1 ? make_float2(q.x, q.z) : make_float2(q.y, q.z));
+        }
+    }
     float qlo[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) qlo[k] = key_value(qmin[k]);
     const bool tuni = qmin[3] == qmax[3];               // one time for the whole block: time planes as marginals
     const bool want_dq = g.dL_dpts || g.dL_dtimes;
     const int twx = tuni ? HEX_TW : HEX_TW / 2, twy = tuni ? 1 : 2;
-    const int sb = wave * 2 * GW * 6;                   // the wave's staging rows
+    const int sb = wave * 2 * SROWS;                    // the wave's staging rows
     for (int s = 0; s < S; s++) {
         int anc[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) anc[k] = tap1(qlo[k], a.res[s][k]).i0;
         const Tap1 tt = tap1(qlo[3], a.res[s][3]);      // the block's time tap (meaningful when tuni)
+        // deferred scale: the rows of the spatial planes go to the per-plane pass (k_hexplane_bwd_plane) instead of the windows
+        const bool deferred = (g.defer_mask >> s) & 1u;
+        const size_t defer_base = (size_t)__builtin_popcount(g.defer_mask & ((1u << s) - 1u)) * 3u;
         // The waves of the block run on their own from here to the flush, GW points (one per C-lane group) per iteration, as a
         // software pipeline:  stage(it + 1) | wait for the taps of `it` | sample, slopes, product rule | issue the gathers of it + 1 |
         // scatter the rows of `it`.  No block barrier in the loop, so the waves drift apart and one wave's gathers overlap another's
         // arithmetic and a third's adds; and within a wave the next gathers are in flight while the adds and atomics are issued
         // (with block-wide batches every wave sat in the same phase at the same time: 70 % of a wave's life in s_waitcnt).
         // ---- staging, item = (point, plane), lanes 0 .. 6 GW - 1 of the wave: un-normalise, clip, floor, offsets, window address
-        auto stage = [&](int it) {
-            if (lane < GW * 6) {
-                const int jj = lane / 6, p = lane - 6 * jj, pt = wave * PER_WAVE + it * GW + jj, n = s_n[pt];
+        auto stage = [&](int it) {                      // `it` even: rows of iterations it and it + 1 into buffer (it >> 1) & 1
+            if (lane < SROWS) {
+                const int k2 = lane / (GW * 6), rem = lane - k2 * GW * 6, jj = rem / 6, p = rem - 6 * jj;
+                const int pt = wave * PER_WAVE + (it + k2) * GW + jj, n = s_n[pt];
                 if (n >= 0) {
                     int ax, ay;
                     pair_axes(p, ax, ay);
@@ -330,9 +347,12 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     const bool inside = cx0 >= 0 && cy0 >= 0 && cx1 < wx && cy1 < wy;
                     const uint32_t lds = inside ? (uint32_t)((wbase + cy0 * wx + cx0) * C) : 0xffffffffu;
                     const uint32_t dx = (uint32_t)((tx.i1 - tx.i0) * C), sy = (uint32_t)((cy1 - cy0) * wx * C);
-                    const int row = sb + (it & 1) * GW * 6 + lane;
+                    const int row = sb + ((it >> 1) & 1) * SROWS + lane;
                     s_a[row] = make_uint4(tap_at(tx.i0, ty.i0, W, C, 0), (uint32_t)(ty.i1 - ty.i0) * (uint32_t)W * (uint32_t)C, lds, dx | (sy << 8));
-                    s_b[row] = make_float4(tx.f, ty.f, tx.ds, ty.ds);
+                    // grid_sampler_2d: nw * (1-fx)(1-fy) + ne * fx (1-fy) + sw * (1-fx) fy + se * fx fy; the clamped neighbour
+                    // (x1 == x0 at the border) contributes no slope: its weight is 0 and the clip mask is 0
+                    s_w[row] = make_float4((1.f - tx.f) * (1.f - ty.f), tx.f * (1.f - ty.f), (1.f - tx.f) * ty.f, tx.f * ty.f);
+                    s_c[row] = make_float4(tx.ds * (1.f - ty.f), tx.ds * ty.f, ty.ds * (1.f - tx.f), ty.ds * tx.f);
                 }
             }
         };
@@ -345,7 +365,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                 go = g.dL_dout[(size_t)n * (S * C) + s * C + c];
 #pragma unroll
                 for (int p = 0; p < 6; p++) {
-                    const uint4 A = s_a[sb + (it & 1) * GW * 6 + gw * 6 + p];
+                    const uint4 A = s_a[sb + ((it >> 1) & 1) * SROWS + (it & 1) * GW * 6 + gw * 6 + p];
                     const char* __restrict__ pl = (const char*)a.planes[s][p];
                     const uint32_t dx = (A.w & 0xffu) << 2, o00 = (A.x + c) << 2, dy = A.y << 2;
                     nw[p] = *(const float*)(pl + o00); ne[p] = *(const float*)(pl + (o00 + dx));
@@ -359,20 +379,17 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         gather(0);
 #pragma unroll 1
         for (int it = 0; it < ITERS; it++) {
-            if (it + 1 < ITERS) stage(it + 1);
-            const int rowb = sb + (it & 1) * GW * 6 + gw * 6, pt = wave * PER_WAVE + it * GW + gw, n_cur = n;
+            if ((it & 1) && it + 1 < ITERS) stage(it + 1);               // (the rows of the next two iterations)
+            const int rowb = sb + ((it >> 1) & 1) * SROWS + (it & 1) * GW * 6 + gw * 6, pt = wave * PER_WAVE + it * GW + gw, n_cur = n;
             float gi[6];
             if (n_cur >= 0) {
                 float f[6], dix[6], diy[6];
 #pragma unroll
                 for (int p = 0; p < 6; p++) {
-                    const float4 B = s_b[rowb + p];
-                    const float fx = B.x, fy = B.y;
-                    // grid_sampler_2d: nw * (1-fx)(1-fy) + ne * fx (1-fy) + sw * (1-fx) fy + se * fx fy; the clamped neighbour
-                    // (x1 == x0 at the border) contributes no slope: its weight is 0 and the clip mask is 0
-                    f[p] = nw[p] * ((1.f - fx) * (1.f - fy)) + ne[p] * (fx * (1.f - fy)) + sw[p] * ((1.f - fx) * fy) + se[p] * (fx * fy);
-                    dix[p] = ((ne[p] - nw[p]) * (1.f - fy) + (se[p] - sw[p]) * fy) * B.z;
-                    diy[p] = ((sw[p] - nw[p]) * (1.f - fx) + (se[p] - ne[p]) * fx) * B.w;
+                    const float4 w = s_w[rowb + p], sc = s_c[rowb + p];
+                    f[p] = nw[p] * w.x + ne[p] * w.y + sw[p] * w.z + se[p] * w.w;
+                    dix[p] = (ne[p] - nw[p]) * sc.x + (se[p] - sw[p]) * sc.y;
+                    diy[p] = (sw[p] - nw[p]) * sc.z + (se[p] - ne[p]) * sc.w;
                 }
                 float pre[7], suf[7], dq[4] = {0.f, 0.f, 0.f, 0.f};
                 pre[0] = 1.f; suf[6] = 1.f;
@@ -391,9 +408,16 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                 if (want_dq) {
                     // summed over the C channel lanes; a point belongs to one lane group of one wave: plain adds across the scales
 #pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        for (int off = C >> 1; off; off >>= 1) dq[k] += __shfl_xor(dq[k], off, C);
-                    if (c == 0) {
+                    for (int k = 0; k < 4; k++) {                          // DPP row sums; the last lane of the group holds the total
+                        float v = dq[k];
+                        v = dpp_add_f32<DPP_ROW_SHR(1), 0xf>(v);
+                        v = dpp_add_f32<DPP_ROW_SHR(2), 0xf>(v);
+                        v = dpp_add_f32<DPP_ROW_SHR(4), 0xf>(v);
+                        v = dpp_add_f32<DPP_ROW_SHR(8), 0xf>(v);
+                        if (C == 32) v = dpp_add_f32<DPP_ROW_BCAST15, 0xa>(v);
+                        dq[k] = v;
+                    }
+                    if (c == C - 1) {
                         float4 acc = s_dq[pt];
                         acc.x += dq[0]; acc.y += dq[1]; acc.z += dq[2]; acc.w += dq[3];
                         s_dq[pt] = acc;
@@ -410,29 +434,35 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                 for (int p = 0; p < 6; p++) {
                     const bool marg = (p == 2 || p >= 4) && tuni;         // marginal over the block's time: two rows
                     float* gp = g.dL_dplanes[s][p];
-                    if (!gp || gi[p] == 0.f) continue;
+                    if (!gp) continue;
+                    if (deferred && p != 2 && p < 4) {                    // spatial plane of a deferred scale: the row itself, at the point's
+                        const int pidx = p == 3 ? 2 : p;                  // position in that plane's order (plain store)
+                        char* rows = (char*)(g.defer_rows + (defer_base + pidx) * (size_t)a.num_points * C);
+                        *(float*)(rows + (((uint32_t)s_pos[3 * pt + pidx] * C + c) << 2)) = gi[p];
+                        continue;
+                    }
+                    if (gi[p] == 0.f) continue;
                     const uint4 A = s_a[rowb + p];                       // (read again: cheaper than live registers)
-                    const float4 Bq = s_b[rowb + p];
-                    const float fx = Bq.x, fy = Bq.y;
+                    const float4 w = s_w[rowb + p];
                     const uint32_t dx = A.w & 0xffu, sy = A.w >> 8;
                     if (A.z != 0xffffffffu) {
                         double* w0 = &win[A.z + c];
-                        if (marg) {
-                            lds_add_f64(w0, gi[p] * (1.f - fx));
-                            lds_add_f64(w0 + dx, gi[p] * fx);
+                        if (marg) {                                       // the x-marginals: the two time rows summed
+                            lds_add_f64(w0, gi[p] * (w.x + w.z));
+                            lds_add_f64(w0 + dx, gi[p] * (w.y + w.w));
                         } else {
-                            lds_add_f64(w0, gi[p] * ((1.f - fx) * (1.f - fy)));
-                            lds_add_f64(w0 + dx, gi[p] * (fx * (1.f - fy)));
-                            lds_add_f64(w0 + sy, gi[p] * ((1.f - fx) * fy));
-                            lds_add_f64(w0 + sy + dx, gi[p] * (fx * fy));
+                            lds_add_f64(w0, gi[p] * w.x);
+                            lds_add_f64(w0 + dx, gi[p] * w.y);
+                            lds_add_f64(w0 + sy, gi[p] * w.z);
+                            lds_add_f64(w0 + sy + dx, gi[p] * w.w);
                         }
                     } else {
                         char* g0 = (char*)gp;
                         const uint32_t b00 = (A.x + c) << 2, bdx = dx << 2, bdy = A.y << 2;
-                        atomicAdd((float*)(g0 + b00), gi[p] * ((1.f - fx) * (1.f - fy)));
-                        atomicAdd((float*)(g0 + (b00 + bdx)), gi[p] * (fx * (1.f - fy)));
-                        atomicAdd((float*)(g0 + (b00 + bdy)), gi[p] * ((1.f - fx) * fy));
-                        atomicAdd((float*)(g0 + (b00 + bdy + bdx)), gi[p] * (fx * fy));
+                        atomicAdd((float*)(g0 + b00), gi[p] * w.x);
+                        atomicAdd((float*)(g0 + (b00 + bdx)), gi[p] * w.y);
+                        atomicAdd((float*)(g0 + (b00 + bdy)), gi[p] * w.z);
+                        atomicAdd((float*)(g0 + (b00 + bdy + bdx)), gi[p] * w.w);
                     }
                 }
             }
@@ -478,6 +508,92 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         }
 }
 
+// ---- per-plane pass of the deferred scales -----------------------------------------------------------------------------------
+// grid (runs of 256 positions, 3 planes).  The block walks 256 consecutive points of ITS plane's order: on a fine scale they cover a
+// few cells of that plane (2 M points over 512 x 512 cells: 7.6 points per cell; a run touches ~60 cells), so a 16 x 16 window of
+// fp64 cells catches 93 % of its taps (98 % at resolution 256: tests/analysis/hex_order_sim.py) and a cell row reaches HBM once per
+// block instead of once per tap.  Per scale: one thread per point computes the tap (from the plane's two normalised coordinates,
+// which the main kernel left beside the rows -- no dependent gather) and the block's anchor, then lane = channel: the point's row
+// (sequential in defer_rows, all loads of a lane group in flight at once), four LDS adds, then the flush.
+#define HEX_PL_THREADS 512
+#define HEX_PL_POINTS 256
+#define HEX_PW 16
+template <int C>
+__global__ void __launch_bounds__(HEX_PL_THREADS) k_hexplane_bwd_plane(EmdHexArgs a, EmdHexGrads g) {
+    constexpr int GROUPS = HEX_PL_THREADS / C, PER = HEX_PL_POINTS / GROUPS, WCELLS = HEX_PW * HEX_PW;
+    __shared__ double win[WCELLS * C];
+    __shared__ int s_x0[HEX_PL_POINTS], s_y0[HEX_PL_POINTS];           // tap cell
+    __shared__ uint32_t s_d[HEX_PL_POINTS];                              // (x1 - x0) | (y1 - y0) << 1
+    __shared__ float2 s_f[HEX_PL_POINTS];
+    __shared__ int cmin[2];
+    const int tid = threadIdx.x, group = tid / C, c = tid % C, pidx = blockIdx.y, p = pidx == 2 ? 3 : pidx;
+    int ax, ay;
+    pair_axes(p, ax, ay);
+    const long first = (long)blockIdx.x * HEX_PL_POINTS;
+    const int count = (int)min((long)HEX_PL_POINTS, (long)a.num_points - first);
+    const size_t NC = (size_t)a.num_points * C;
+    const float2* defer_q = (const float2*)(g.defer_rows + (size_t)__builtin_popcount(g.defer_mask) * 3 * NC) + (size_t)pidx * a.num_points;
+    for (int i = tid; i < WCELLS * C; i += HEX_PL_THREADS) win[i] = 0.0;
+    const float2 q = tid < count ? defer_q[first + tid] : make_float2(0.f, 0.f);
+    int sidx = 0;
+    for (uint32_t rest = g.defer_mask; rest; rest &= rest - 1, sidx++) {
+        const int s = __builtin_ctz(rest);
+        float* gp = g.dL_dplanes[s][p];
+        if (!gp) continue;                                                 // (uniform)
+        const float* rows = g.defer_rows + ((size_t)sidx * 3 + pidx) * NC;
+        const int W = a.res[s][ax], H = a.res[s][ay];
+        // the group's rows, all in flight at once (while the taps are staged)
+        float gis[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int j = group + GROUPS * k;
+            gis[k] = j < count ? rows[(size_t)(first + j) * C + c] : 0.f;
+        }
+        if (tid < 2) cmin[tid] = INT_MAX;
+        __syncthreads();
+        if (tid < count) {
+            const Tap1 tx = tap1(q.x, W), ty = tap1(q.y, H);
+            s_x0[tid] = tx.i0; s_y0[tid] = ty.i0;
+            s_d[tid] = (uint32_t)(tx.i1 - tx.i0) | ((uint32_t)(ty.i1 - ty.i0) << 1);
+            s_f[tid] = make_float2(tx.f, ty.f);
+            atomicMin(&cmin[0], tx.i0);
+            atomicMin(&cmin[1], ty.i0);
+        }
+        __syncthreads();
+        const int ancx = cmin[0], ancy = cmin[1];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int j = group + GROUPS * k;
+            const float gi = gis[k];
+            if (j >= count || gi == 0.f) continue;
+            const int x0 = s_x0[j], y0 = s_y0[j], dx = s_d[j] & 1u, dy = s_d[j] >> 1;
+            const float fx = s_f[j].x, fy = s_f[j].y;
+            const int cx0 = x0 - ancx, cy0 = y0 - ancy;
+            const float w00 = gi * ((1.f - fx) * (1.f - fy)), w10 = gi * (fx * (1.f - fy)), w01 = gi * ((1.f - fx) * fy), w11 = gi * (fx * fy);
+            if (cx0 + dx < HEX_PW && cy0 + dy < HEX_PW) {                  // (cx0, cy0 >= 0: the anchor is the block's smallest tap)
+                double* w0 = &win[(cy0 * HEX_PW + cx0) * C + c];
+                lds_add_f64(w0, w00);
+                lds_add_f64(w0 + dx * C, w10);
+                lds_add_f64(w0 + dy * HEX_PW * C, w01);
+                lds_add_f64(w0 + (dy * HEX_PW + dx) * C, w11);
+            } else {
+                atomicAdd(gp + tap_at(x0, y0, W, C, c), w00);
+                atomicAdd(gp + tap_at(x0 + dx, y0, W, C, c), w10);
+                atomicAdd(gp + tap_at(x0, y0 + dy, W, C, c), w01);
+                atomicAdd(gp + tap_at(x0 + dx, y0 + dy, W, C, c), w11);
+            }
+        }
+        __syncthreads();
+        for (int cell = group; cell < WCELLS; cell += GROUPS) {
+            const float v = (float)win[cell * C + c];
+            if (v == 0.f) continue;
+            win[cell * C + c] = 0.0;
+            atomicAdd(gp + tap_at(ancx + cell % HEX_PW, ancy + cell / HEX_PW, W, C, c), v);
+        }
+        __syncthreads();
+    }
+}
+
 template <int C>
 void launch_bwd_agg(const EmdHexArgs* a, const EmdHexGrads* g, hipStream_t st) {
     const unsigned blocks = (unsigned)((a->num_points + HEX_AGG_POINTS - 1) / HEX_AGG_POINTS);
@@ -485,6 +601,8 @@ void launch_bwd_agg(const EmdHexArgs* a, const EmdHexGrads* g, hipStream_t st) {
     auto gcd = [](unsigned x, unsigned y) { while (y) { unsigned t = x % y; x = y; y = t; } return x; };
     while (stride == 0 || gcd(stride, blocks) != 1) stride++;          // a bijection on [0, blocks)
     hipLaunchKernelGGL(k_hexplane_bwd_agg<C>, dim3(blocks), dim3(HEX_AGG_THREADS), 0, st, *a, *g, stride);
+    if (g->defer_mask)
+        hipLaunchKernelGGL(k_hexplane_bwd_plane<C>, dim3((unsigned)((a->num_points + HEX_PL_POINTS - 1) / HEX_PL_POINTS), 3), dim3(HEX_PL_THREADS), 0, st, *a, *g);
 }
 
 int check_hex(const EmdHexArgs* a, const char* who) {
@@ -523,6 +641,14 @@ extern "C" int emd_hexplane_backward(const EmdHexArgs* a, const EmdHexGrads* g, 
     if (rc) return rc;
     if (!g || !g->dL_dout) { emd_set_error("hexplane_backward: null gradient"); return EMD_ERR_INVALID; }
     if (a->num_points == 0) return EMD_OK;
+    if (g->defer_mask) {
+        const bool agg = a->order && (a->channels == 32 || a->channels == 16);
+        if (!agg || !g->defer_rows || !g->order2d[0] || !g->order2d[1] || !g->order2d[2] || !g->pos2d[0] || !g->pos2d[1] || !g->pos2d[2] ||
+            (g->defer_mask >> a->num_scales) || (int64_t)a->num_points * a->channels * 4 >= ((int64_t)1 << 32)) {
+            emd_set_error("hexplane_backward: defer_mask needs a visiting order, 16 or 32 channels, order2d / pos2d / defer_rows, bits below num_scales and N * C < 2^30");
+            return EMD_ERR_INVALID;
+        }
+    }
     // a visiting order promises spatial coherence: aggregate in LDS (windows are sized for C <= 32; the kernel addresses a plane
     // with 32-bit BYTE offsets, so planes of 2^30 floats or more take the direct kernel)
     bool small_planes = true;

@@ -19,6 +19,10 @@ PAIRS = list(itertools.combinations(range(4), 2))
 class _HexLookup(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, times, aabb, res, order, *planes):
+        # `order`: None, an int32 permutation, or a VisitingOrders record (the permutation + the per-plane orders of the fine scales)
+        plane_orders = order if isinstance(order, VisitingOrders) else None
+        if plane_orders is not None:
+            order = plane_orders.order
         if pts.device.type != "cuda":
             raise L.EmdError("HexPlane lookup needs tensors on a ROCm device; there is no CPU path")
         lib = L.load()
@@ -42,7 +46,7 @@ class _HexLookup(torch.autograd.Function):
         out = torch.empty(N, S * Cc, device=pts.device, dtype=torch.float32)
         a.out = out.data_ptr()
         L.check(lib.emd_hexplane_forward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_hexplane_forward")
-        ctx.args, ctx.keep = a, (pts_c, times_c, cl, order)
+        ctx.args, ctx.keep = a, (pts_c, times_c, cl, order, plane_orders)
         ctx.shapes = [tuple(p.shape) for p in planes]
         ctx.times_shape = tuple(times.shape)
         return out
@@ -69,6 +73,13 @@ class _HexLookup(torch.autograd.Function):
         g.dL_dpts = L.ptr(d_pts)
         d_times = torch.empty(ctx.times_shape, device=g_out.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
         g.dL_dtimes = L.ptr(d_times)
+        po = ctx.keep[4]
+        rows = None
+        if po is not None and po.defer_mask and need_planes and a.num_points * Cc * 4 < 2 ** 32:
+            for k in range(3):
+                g.order2d[k], g.pos2d[k] = po.order2d[k].data_ptr(), po.pos2d[k].data_ptr()
+            rows = torch.empty(bin(po.defer_mask).count("1") * 3 * a.num_points * Cc + 6 * a.num_points, device=g_out.device, dtype=torch.float32)
+            g.defer_rows, g.defer_mask = rows.data_ptr(), po.defer_mask
         L.check(lib.emd_hexplane_backward(C.byref(a), C.byref(g), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                 "emd_hexplane_backward")
         grads = [t.permute(2, 0, 1)[None] for t in gcl] if need_planes else [None] * len(ctx.shapes)   # channel-last, like the planes
@@ -102,6 +113,52 @@ def morton_order(pts, aabb, bits=10):
             return (v | (v << 2)) & 0x09249249
         key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
         return key.argsort().to(torch.int32)
+
+
+def plane_order(pts, aabb, ax, ay, bits=12):
+    """int32 permutation that visits the points along a Z-order curve of TWO of their box-normalised coordinates (12 bits each): runs
+    of consecutive points are compact in the plane (ax, ay) whatever their third coordinate."""
+    with torch.no_grad():
+        q = ((pts.detach() - aabb[0]) / (aabb[1] - aabb[0])).clamp_(0.0, 1.0).mul_(float(2 ** bits - 1)).to(torch.int64)
+
+        def spread(v):                                  # 12 bits -> every second bit
+            v = (v | (v << 8)) & 0x00FF00FF
+            v = (v | (v << 4)) & 0x0F0F0F0F
+            v = (v | (v << 2)) & 0x33333333
+            return (v | (v << 1)) & 0x55555555
+        return (spread(q[:, ax]) | (spread(q[:, ay]) << 1)).argsort().to(torch.int32)
+
+
+class VisitingOrders:
+    """What the aggregating backward is handed: the 3-D visiting order, and for the scales in `defer_mask` the visiting orders of the
+    three spatial planes with their inverses (EmdHexGrads.order2d / pos2d)."""
+
+    def __init__(self, order, order2d=None, pos2d=None, defer_mask=0):
+        self.order, self.order2d, self.pos2d, self.defer_mask = order, order2d, pos2d, defer_mask
+
+    @staticmethod
+    def build(pts, aabb, res, run=256, window=10):
+        """Scales on whose spatial planes a run of `run` points (compact in 3-D) spreads over more than 1.5 x the 10 x 10 window are
+        deferred to the per-plane pass: a run fills run / N of the box, i.e. ~1.7 (run / N)^(1/3) of its side along the curve, times
+        the scale's resolution (2 M points: 11 cells at resolution 128 -- the window still catches three taps in four --, 22 at 256)."""
+        n = pts.shape[0]
+        order = morton_order(pts, aabb)
+        side = 1.7 * (run / max(n, 1)) ** (1.0 / 3.0)
+        mask = 0
+        for s, r in enumerate(res):
+            if side * max(r[:3]) > 1.5 * window:
+                mask |= 1 << s
+        if not mask:
+            return VisitingOrders(order)
+        o2, p2 = [], []
+        ar = torch.arange(n, device=pts.device, dtype=torch.int32)
+        for ax, ay in ((0, 1), (0, 2), (1, 2)):
+            o = plane_order(pts, aabb, ax, ay)
+            inv = torch.empty_like(o)
+            inv[o.long()] = ar
+            o2.append(o)
+            p2.append(inv)
+        return VisitingOrders(order, o2, p2, mask)
 
 
 class HexPlaneField(nn.Module):
@@ -165,8 +222,8 @@ class HexPlaneField(nn.Module):
         if n < self.reorder_min_points or pts.device.type != "cuda" or self.grids[0][0].shape[1] not in (16, 32):
             return None
         cache = getattr(self, "_order_cache", None)
-        if cache is None or cache[0] != n or cache[1] >= self.reorder_every or cache[2].device != pts.device:
-            cache = self._order_cache = [n, 0, morton_order(pts, self.aabb)]
+        if cache is None or cache[0] != n or cache[1] >= self.reorder_every or cache[2].order.device != pts.device:
+            cache = self._order_cache = [n, 0, VisitingOrders.build(pts, self.aabb, self._res)]
         cache[1] += 1
         return cache[2]
 

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 18
+#define EMD_ABI_VERSION 19
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -463,6 +463,18 @@ typedef struct EmdHexGrads {
     float* dL_dplanes[EMD_HEX_MAX_SCALES][6];    /* channel-last like planes; ZEROED BY THE CALLER, accumulated with float atomics; may be NULL */
     float* dL_dpts;                              /* [N,3] or NULL */
     float* dL_dtimes;                            /* [N] or NULL (reaches the reference's time_offset parameter, deformation.py:325-328) */
+    /* Optional per-plane pass for the fine scales (ABI 19; needs args->order and 16 or 32 channels).  On the scales named by
+     * defer_mask a run of 256 points that is compact in 3-D still spans tens of cells of a SPATIAL plane and puts ~1 tap into a cell,
+     * so nothing aggregates and every tap row is a global atomic.  With the three extra orders below the backward instead writes, per
+     * point and spatial plane, the 128-byte row dL/d(interpolated plane value) into defer_rows at the point's position in THAT
+     * plane's order, and a second launch walks each plane in its own order -- runs that are compact in the plane's two coordinates
+     * share cells -- and adds the taps through LDS windows.  Any permutations give the same sums (up to float rounding); all of
+     * order2d / pos2d / defer_rows must be non-NULL when defer_mask != 0. */
+    const int32_t* order2d[3];                   /* [N] each: visiting order of the planes xy, xz, yz */
+    const int32_t* pos2d[3];                     /* [N] each: the inverse permutations, pos2d[p][order2d[p][i]] = i */
+    float* defer_rows;                           /* scratch of popcount(defer_mask) * 3 * N * C + 6 * N floats (the rows, then the planes' coordinates); written and read by the call */
+    uint32_t defer_mask;                         /* bit s set: the spatial planes of scale s go through the per-plane pass */
+    uint32_t reserved;
 } EmdHexGrads;
 
 int emd_hexplane_forward(const EmdHexArgs* args, void* hip_stream);

@@ -80,6 +80,15 @@ void pair_stats(int W, int H, const uint32_t* ranges, const uint32_t* ids, const
                     if (n > nt) nt = n;
                 }
             a[1] += 256.0 * nt;
+            for (uint32_t k = s; k < e; k++) {       /* [24] entries whose alpha >= 1/255 ellipse reaches a pixel centre of the 16 x 16 tile at all */
+                const uint32_t g = ids[k];
+                const float* m = means2D + 2 * g;
+                const float* co = conic_opacity + 4 * g;
+                if (!(co[3] >= 1.f / 255.f)) continue;
+                const float tau2 = 2.f * logf(255.f * co[3]) * 1.01f + 0.05f;
+                const float x1 = (float)(tx0 + 15 < W - 1 ? tx0 + 15 : W - 1), y1 = (float)(ty0 + 15 < H - 1 ? ty0 + 15 : H - 1);
+                if (min_form_rect(m[0], m[1], co[0], co[1], co[2], (float)tx0, x1, (float)ty0, y1) <= tau2) { a[24] += 1; if (k - s < nt) a[25] += 1; }
+            }
             for (uint32_t k = s; k < e; k++) {
                 const uint32_t pos = k - s;          /* 0-based list position; contributes to a pixel if pos < n_contrib */
                 if (pos >= nt) break;

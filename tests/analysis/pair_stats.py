@@ -36,6 +36,7 @@ def main(frame=10, n=2_000_000):
         print(f"{k:24s} {v:14.0f}")
     for k, v in zip(["8x8", "8x4", "4x4", "8x2", "4x2", "8x1", "2x2"], out[16:23]):
         print(f"exact {k:19s} {v:14.0f}  ({v / out[3]:.3f} of quad_pairs)")
+    print(f"tile entries whose exact footprint reaches the tile: {out[24]:.0f} of D = {out[0]:.0f} ({out[24] / out[0]:.3f}); in front of the tile's deepest contributor: {out[25]:.0f}")
     print("hit fraction of quadrant pairs", out[6] / out[3], " of sub-block pairs", out[6] / out[5], " of row spans", out[6] / out[8])
 
 

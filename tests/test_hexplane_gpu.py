@@ -71,11 +71,15 @@ def test_hexplane_vs_oracle(N, C, res, multires):
             _close(prm.grad, planes0[s][p].grad.numpy(), f"plane {s} {p}")
 
 
-@pytest.mark.parametrize("C,layout", [(32, "morton"), (32, "random_order"), (16, "morton"), (32, "clustered"), (32, "same_time")])
+@pytest.mark.parametrize("C,layout", [(32, "morton"), (32, "random_order"), (16, "morton"), (32, "clustered"), (32, "same_time"),
+                                      (32, "plane_pass"), (16, "plane_pass"), (32, "plane_pass_some_scales"), (32, "plane_pass_random_orders"),
+                                      (32, "plane_pass_clustered")])
 def test_hexplane_aggregating_backward(C, layout):
     """The LDS-aggregating backward (taken when a visiting order is given) against the oracle: Morton order (windows hit), an
-    arbitrary permutation (almost every tap falls back to the direct atomic), points piled into a few cells, one shared time."""
-    from emd_amd.hexplane import HexPlaneField, _HexLookup, morton_order
+    arbitrary permutation (almost every tap falls back to the direct atomic), points piled into a few cells, one shared time; and
+    with the spatial planes of all / some scales deferred to the per-plane pass (EmdHexGrads.defer_mask), under plane-coherent
+    orders, arbitrary permutations (every tap of the pass falls back to the direct atomic) and piled-up points."""
+    from emd_amd.hexplane import HexPlaneField, VisitingOrders, _HexLookup, morton_order
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(C + len(layout))
     N, res, multires = 30011, [16, 12, 10, 6], [1, 2, 4]
@@ -85,9 +89,9 @@ def test_hexplane_aggregating_backward(C, layout):
         for prm in gp:
             prm.data = torch.rand_like(prm) + 0.3
     pts = torch.rand(N, 3, generator=g) * 3.6 - 1.8
-    if layout == "clustered":
+    if layout.endswith("clustered"):
         pts = torch.randn(N, 3, generator=g) * 0.02 + torch.tensor([0.3, -0.7, 1.1])
-    t = torch.full((N, 1), 0.21) if layout == "same_time" else torch.rand(N, 1, generator=g) * 2.2 - 1.1
+    t = torch.full((N, 1), 0.21) if layout in ("same_time", "plane_pass") else torch.rand(N, 1, generator=g) * 2.2 - 1.1
     gout = torch.randn(N, C * len(multires), generator=g)
     p0, t0 = pts.clone().requires_grad_(True), t.clone().requires_grad_(True)
     planes0 = [[prm.detach().cpu().clone().requires_grad_(True) for prm in gp] for gp in field.grids]
@@ -96,6 +100,16 @@ def test_hexplane_aggregating_backward(C, layout):
     p1, t1 = pts.to(dev).requires_grad_(True), t.to(dev).requires_grad_(True)
     order = torch.randperm(N, generator=g).to(torch.int32).to(dev) if layout == "random_order" else morton_order(p1, field.aabb)
     assert sorted(order.cpu().tolist()) == list(range(N))
+    if layout.startswith("plane_pass"):
+        vo = VisitingOrders.build(p1, field.aabb, field._res, window=0)          # window 0: every scale is deferred
+        assert vo.defer_mask == 0b111 and all(sorted(o.cpu().tolist()) == list(range(N)) for o in vo.order2d)
+        assert all(torch.equal(inv[o.long()].cpu(), torch.arange(N, dtype=torch.int32)) for o, inv in zip(vo.order2d, vo.pos2d))
+        if layout == "plane_pass_some_scales":
+            vo.defer_mask = 0b101
+        if layout == "plane_pass_random_orders":
+            vo.order2d = [torch.randperm(N, generator=g).to(torch.int32).to(dev) for _ in range(3)]
+            vo.pos2d = [torch.empty_like(o).scatter_(0, o.long(), torch.arange(N, dtype=torch.int32, device=dev)) for o in vo.order2d]
+        order = vo
     planes = [p for gp in field.grids for p in gp]
     f1 = _HexLookup.apply(p1, t1, field._aabb_host(), field._res, order, *planes)
     (f1 * gout.to(dev)).sum().backward()
