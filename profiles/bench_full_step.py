@@ -10,6 +10,10 @@ front of the rasterizer on all 2 M Gaussians and is trained through it, plus the
 --feat (with --fine): the reference's default feature head (feat_head=True, arguments/gaussian_options.py:163): the two feature
 images rendered as extra colour sets of the main rasterizer call (one binning, three colour sets) and an L2 loss on each;
 --feat-separate: the same step issued the way the reference issues it, as three rasterizer calls.
+--graph: the step of every frame captured once into a hipGraph (one graph per frame of the clip, all in one memory pool: camera, frame time
+and sky rays are host constants of a frame and are baked into its graph) and replayed -- the host then spends ~0.05 ms per step
+instead of 15-19 ms issuing ~170 launches from Python, so the rate is the GPU's whatever the host is doing; one replay is checked
+against the eager step of the same frame before the timed region.
 --adam / --torch-adam: also take the optimiser step (train.py:428) with emd_amd.optim.Adam / torch.optim.Adam over the groups of
 gaussian_model.py:188-199 (per-group learning rates, eps 1e-15)."""
 import json
@@ -114,11 +118,52 @@ OPTS[0] = RasterOptions(no_sync=True)
 for s in range(10):
     step(s)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
 K_STEPS = 50
+graphs = None
+if "--graph" in sys.argv:
+    import gc
+    from emd_amd.sky import _camera_rays_params
+    for f in range(F):                      # host-side per-camera constants (a device-to-host copy each) are formed before capture
+        _camera_rays_params(skycams[f])
+    if FINE:                                # the cached visiting orders must not be refreshed (re-allocated) inside a capture: their memory
+        deform.deformation_net.grid.reorder_every = 1 << 60      # would belong to that graph's pool and be recycled by the next one
+    step(0)
+    torch.cuda.synchronize()
+    want = {"xyz": model._xyz.grad.clone()}
+    if FINE:
+        want["grid"] = deform.deformation_net.grid.grids[-1][0].grad.clone()
+    gc.collect()                            # no autograd graph of an eager step may be alive at capture time (bench.py)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graphs, pool = [], None
+    with torch.cuda.stream(side):
+        for f in range(F):
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_, pool=pool, stream=side):
+                step(f)
+            pool = g_.pool()
+            graphs.append(g_)
+            if f == 0:                      # graph 0's gradient tensors stay referenced for the self-check below (the later graphs
+                keep0 = {"xyz": model._xyz.grad, "grid": deform.deformation_net.grid.grids[-1][0].grad if FINE else None}   # recycle everything else)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    # self-check: the replay of frame 0 against the eager step of frame 0 (densification statistics accumulate: compare the increment)
+    graphs[0].replay()
+    torch.cuda.synchronize()
+    tol = lambda a, b: float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-12
+    assert tol(keep0["xyz"], want["xyz"]), "graph replay: dL/dxyz differs from the eager step"
+    if FINE:
+        assert tol(keep0["grid"], want["grid"]), "graph replay: plane gradients differ from the eager step"
+    for s in range(10):
+        graphs[s % F].replay()
+    torch.cuda.synchronize()
+t0 = time.perf_counter()
 for s in range(K_STEPS):
-    step(10 + s)
-t_host = time.perf_counter() - t0          # the step is issued eagerly from Python: on a slow host THIS, not the GPU, sets the rate
+    if graphs is not None:
+        graphs[(10 + s) % F].replay()
+    else:
+        step(10 + s)
+t_host = time.perf_counter() - t0          # an eagerly issued step: on a slow host THIS, not the GPU, sets the rate
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 op = "S3G-style step: raster (fused motion) + sky cube map + blend + L1/depth/D-SSIM/sky-BCE + backward + densification stats"
@@ -133,4 +178,5 @@ if optimizer is not None:
 print(json.dumps({"op": op,
                   "gaussians": N, "height": H, "width": W, "steps": K_STEPS, "ms_per_step": round(dt / K_STEPS * 1e3, 4),
                   "iters_per_s": round(K_STEPS / dt, 1), "host_enqueue_ms_per_step": round(t_host / K_STEPS * 1e3, 4),
-                  "host_bound": bool(t_host > 0.9 * dt)}))
+                  "host_bound": bool(t_host > 0.9 * dt),
+                  "step_issue": "hipGraph replay (one graph per frame of the clip, one memory pool)" if graphs is not None else "eager (Python)"}))
