@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16
@@ -52,7 +52,7 @@ class EmdFwdArgs(C.Structure):
                 ("geom_ws", _f), ("geom_bytes", C.c_size_t), ("bin_ws", _f), ("bin_bytes", C.c_size_t),
                 ("img_ws", _f), ("img_bytes", C.c_size_t), ("status", _f),
                 ("num_rendered", C.c_int64), ("num_visible", C.c_int64), ("settings_dev", _f),
-                ("num_extra", C.c_int32), ("colors_extra", _f * 2), ("out_extra", _f * 2), ("aux_stream", _f)]
+                ("num_extra", C.c_int32), ("colors_extra", _f * 2), ("out_extra", _f * 2), ("aux_stream", _f), ("shs_residual", _f * 2)]
 
 
 class EmdBwdArgs(C.Structure):
@@ -208,7 +208,7 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_deform_input_backward", "emd_adam_step", "emd_track_heads_forward", "emd_track_heads_backward",
                     "emd_densify_decide", "emd_densify_index", "emd_densify_split_rank", "emd_densify_gather",
                     "emd_mlp_trunk_forward", "emd_mlp_trunk_backward", "emd_mlp_branch_forward", "emd_mlp_branch_backward",
-                    "emd_abs_mean_backward", "emd_tracked_pose_forward", "emd_tracked_pose_backward",
+                    "emd_abs_mean_backward", "emd_residual_l1_backward", "emd_tracked_pose_forward", "emd_tracked_pose_backward",
                     "emd_select_step_inputs")
 PROF_STAGES = 8
 
@@ -273,6 +273,7 @@ def load():
     lib.emd_densify_split_rank.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.emd_densify_gather.argtypes = [C.POINTER(EmdDensifyGather), C.c_void_p]
     lib.emd_abs_mean_backward.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_residual_l1_backward.argtypes = [C.c_int64] + [C.c_void_p] * 9
     lib.emd_mlp_trunk_forward.argtypes = [C.POINTER(EmdMlpTrunk), C.c_void_p]
     lib.emd_mlp_trunk_backward.argtypes = [C.POINTER(EmdMlpTrunk), C.POINTER(EmdMlpTrunkGrads), C.c_void_p]
     lib.emd_mlp_branch_forward.argtypes = [C.POINTER(EmdMlpBranch), C.c_void_p]

@@ -126,6 +126,8 @@ int emd_zero_async(void* p, size_t bytes, hipStream_t st) {
 }
 
 int emd_launch_abs_mean_backward(size_t n, const float* x, const float* g, float* out, hipStream_t st);
+int emd_launch_residual_l1_backward(size_t n, const float* up_a, const float* up_b, const float* x_a, const float* x_b, const float* g_a,
+                                    const float* g_b, float* out_a, float* out_b, hipStream_t st);
 int emd_launch_motion_forward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
                               float* wm, float* wq, float* wo, hipStream_t st);
 int emd_launch_motion_backward(int n, const float* means, const float* quats, const float* opac, const EmdMotion& mo,
@@ -252,6 +254,9 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
     pa.means3D = a->means3D; pa.shs = a->shs; pa.colors_precomp = a->colors_precomp; pa.opacities = a->opacities;
     pa.scales = a->scales; pa.rotations = a->rotations; pa.cov3D_precomp = a->cov3D_precomp;
     pa.motion = a->motion; pa.radii = a->radii; pa.g = g; pa.status = a->status; pa.sdev = a->settings_dev;
+    pa.shs_res0 = a->shs_residual[0]; pa.shs_res1 = a->shs_residual[1];
+    if ((pa.shs_res0 || pa.shs_res1) && !a->shs) { emd_set_error("raster_forward: shs_residual needs shs"); return EMD_ERR_INVALID; }
+    if (pa.shs_res1 && !pa.shs_res0) { pa.shs_res0 = pa.shs_res1; pa.shs_res1 = nullptr; }
     if (!(a->flags & EMD_FLAG_MOTION)) memset(&pa.motion, 0, sizeof(pa.motion));
     emd_prof_begin(PROF_PREPROCESS, st);
     // With an auxiliary stream the colour half of K1 (SH colour, clamp bits, colour Jacobian: needed by K6 only) runs BESIDE the binning
@@ -504,6 +509,15 @@ int emd_abs_mean_backward(int64_t n, const float* x, const float* g, float* grad
     if (n < 0 || (n > 0 && (!x || !g || !grad))) { emd_set_error("abs_mean_backward: bad argument"); return EMD_ERR_INVALID; }
     if (((uintptr_t)x & 15) || ((uintptr_t)grad & 15)) { emd_set_error("abs_mean_backward: x, grad must be 16-byte aligned"); return EMD_ERR_INVALID; }
     return emd_launch_abs_mean_backward((size_t)n, x, g, grad, (hipStream_t)hip_stream);
+}
+
+int emd_residual_l1_backward(int64_t n, const float* up_a, const float* up_b, const float* x_a, const float* x_b, const float* g_a,
+                             const float* g_b, float* grad_a, float* grad_b, void* hip_stream) {
+    if (n < 0 || (n > 0 && (!x_a || !x_b || !grad_a || !grad_b))) { emd_set_error("residual_l1_backward: bad argument"); return EMD_ERR_INVALID; }
+    if ((((uintptr_t)up_a) | ((uintptr_t)up_b) | ((uintptr_t)x_a) | ((uintptr_t)x_b) | ((uintptr_t)grad_a) | ((uintptr_t)grad_b)) & 15) {
+        emd_set_error("residual_l1_backward: the tensors must be 16-byte aligned"); return EMD_ERR_INVALID;
+    }
+    return emd_launch_residual_l1_backward((size_t)n, up_a, up_b, x_a, x_b, g_a, g_b, grad_a, grad_b, (hipStream_t)hip_stream);
 }
 
 int emd_activations_forward(int32_t n, const float* log_scales, float* scales, const float* raw_quats, float* quats,

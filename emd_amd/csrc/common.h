@@ -168,6 +168,7 @@ struct PreArgs {
     GeomWs g;
     EmdStatus* status;
     const float* sdev;       // device copy of bg / viewmatrix / projmatrix / campos (EmdFwdArgs.settings_dev) or null
+    const float *shs_res0, *shs_res1;   // optional residuals of the SH coefficients (EmdFwdArgs.shs_residual) or null
 };
 int emd_launch_preprocess(const PreArgs& a, int part, hipStream_t st);       // preprocess.hip; part 0 = whole kernel, 1 = geometry half, 2 = colour half
 int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,

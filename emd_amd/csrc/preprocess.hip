@@ -232,10 +232,16 @@ __device__ __forceinline__ void sh_dir_jacobian(int deg, const float d[3], const
 // ---------------------------------------------------------------------------------------------------
 #define SH_ROW4 13
 // this lane's 48 coefficients [k][c] into registers straight from HBM (the M != 16 path; M == 16 goes through the staging tile)
-__device__ __forceinline__ void sh_row_load(const float* __restrict__ shs, int i, int M, int K, float v[48]) {
-    const float* sh = shs + (size_t)i * M * 3;
+__device__ __forceinline__ void sh_row_load(const float* __restrict__ shs, const float* __restrict__ r0, const float* __restrict__ r1, int i, int M,
+                                            int K, float v[48]) {
+    const size_t o = (size_t)i * M * 3;
 #pragma unroll
-    for (int k = 0; k < 48; k++) v[k] = (k < 3 * K) ? sh[k] : 0.f;
+    for (int k = 0; k < 48; k++) {
+        float x = (k < 3 * K) ? shs[o + k] : 0.f;
+        if (r0 && k < 3 * K) x = x + r0[o + k];          // (shs + r0) + r1, the order of the reference's two adds
+        if (r1 && k < 3 * K) x = x + r1[o + k];
+        v[k] = x;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -253,7 +259,9 @@ __device__ __forceinline__ void sh_row_load(const float* __restrict__ shs, int i
 // needed by K6 only, so with an auxiliary stream (EmdFwdArgs.aux_stream) it runs BESIDE the twenty launch-bound kernels of the binning
 // stage instead of in front of them.  PART 2 recomputes the world mean of its Gaussian (one gather for an actor's point) and takes
 // the visibility from the radii PART 1 wrote.
-template <int PART>
+// RES: residuals of the SH coefficients are added while the rows are staged (EmdFwdArgs.shs_residual); a separate instantiation, so
+// that the usual kernel keeps its registers (with the residual loads in the same code it spilled 24)
+template <int PART, bool RES = false>
 __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(PART == 1 ? 6 : EMD_K1_WAVES))) k_preprocess(PreArgs a) {
     __shared__ float4 s_sh[PART == 1 ? 1 : (PRE_BLOCK / 2) * SH_ROW4];       // half of the wave's rows at a time: 6.5 KB keeps four waves per SIMD
     EmdSettings S = a.s;
@@ -354,7 +362,18 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int j = 0; j < 6; j++) {
                 const uint32_t idx = threadIdx.x + PRE_BLOCK * (6 * h + j), row = idx / 12;
-                if ((vmask >> row) & 1ull) s_sh[(row - 32 * h) * SH_ROW4 + (idx % 12)] = src[base4 + idx];
+                if ((vmask >> row) & 1ull) {
+                    float4 v = src[base4 + idx];
+                    if (RES && a.shs_res0) {                          // (shs + r0) + r1, the order of the reference's two adds
+                        const float4 r = ((const float4*)a.shs_res0)[base4 + idx];
+                        v.x = v.x + r.x; v.y = v.y + r.y; v.z = v.z + r.z; v.w = v.w + r.w;
+                    }
+                    if (RES && a.shs_res1) {
+                        const float4 r = ((const float4*)a.shs_res1)[base4 + idx];
+                        v.x = v.x + r.x; v.y = v.y + r.y; v.z = v.z + r.z; v.w = v.w + r.w;
+                    }
+                    s_sh[(row - 32 * h) * SH_ROW4 + (idx % 12)] = v;
+                }
             }
             __syncthreads();
             if ((int)(threadIdx.x >> 5) == h) {
@@ -382,7 +401,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
             float bs[16];
             sh_basis(S.sh_degree, d, bs);
             const int K = (S.sh_degree + 1) * (S.sh_degree + 1);
-            if (!sh_staged) sh_row_load(a.shs, i, a.M, K, sh);
+            if (!sh_staged) sh_row_load(a.shs, RES ? a.shs_res0 : nullptr, RES ? a.shs_res1 : nullptr, i, a.M, K, sh);
             col[0] = col[1] = col[2] = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -1092,7 +1111,44 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_abs_mean_backward(size_t n, const
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; i < n; i += stride) out[i] = sg(x[i]);
 }
 
+// The same for a PAIR of residuals that also carry an upstream gradient (the fine stage's dshs_coarse / dshs_fine: both receive the
+// rasterizer's dL/dshs -- usually the very same tensor -- plus the gradient of their L1 regulariser):
+//   out_a[i] = up_a[i] + sign(x_a[i]) g_a[0] / n,   out_b[i] = up_b[i] + sign(x_b[i]) g_b[0] / n
+// in one pass that reads the shared upstream gradient once (instead of two sign passes and two adds over [N,16,3]).
+__global__ void __launch_bounds__(EMD_BLOCK) k_residual_l1_backward(size_t n, const float* __restrict__ up_a, const float* __restrict__ up_b,
+                                                                    const float* __restrict__ x_a, const float* __restrict__ x_b,
+                                                                    const float* __restrict__ g_a, const float* __restrict__ g_b, float inv_n,
+                                                                    float* __restrict__ out_a, float* __restrict__ out_b) {
+    const float sa = g_a ? g_a[0] * inv_n : 0.f, sb = g_b ? g_b[0] * inv_n : 0.f;
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * EMD_BLOCK;
+    auto sg = [](float d, float s) { return d > 0.f ? s : (d < 0.f ? -s : 0.f); };
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; i < n4; i += stride) {
+        const float4 ua = up_a ? ((const float4*)up_a)[i] : z;
+        const float4 ub = (up_b == up_a) ? ua : (up_b ? ((const float4*)up_b)[i] : z);
+        const float4 a = ((const float4*)x_a)[i], b = ((const float4*)x_b)[i];
+        ((float4*)out_a)[i] = make_float4(ua.x + sg(a.x, sa), ua.y + sg(a.y, sa), ua.z + sg(a.z, sa), ua.w + sg(a.w, sa));
+        ((float4*)out_b)[i] = make_float4(ub.x + sg(b.x, sb), ub.y + sg(b.y, sb), ub.z + sg(b.z, sb), ub.w + sg(b.w, sb));
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; i < n; i += stride) {
+        out_a[i] = (up_a ? up_a[i] : 0.f) + sg(x_a[i], sa);
+        out_b[i] = (up_b ? up_b[i] : 0.f) + sg(x_b[i], sb);
+    }
+}
+
 }  // namespace
+
+int emd_launch_residual_l1_backward(size_t n, const float* up_a, const float* up_b, const float* x_a, const float* x_b, const float* g_a,
+                                    const float* g_b, float* out_a, float* out_b, hipStream_t st) {
+    if (n == 0) return EMD_OK;
+    size_t blocks = (n / 4 + EMD_BLOCK - 1) / EMD_BLOCK;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_residual_l1_backward, dim3((unsigned)blocks), dim3(EMD_BLOCK), 0, st, n, up_a, up_b, x_a, x_b, g_a, g_b, 1.f / (float)n,
+                       out_a, out_b);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
 
 int emd_launch_abs_mean_backward(size_t n, const float* x, const float* g, float* out, hipStream_t st) {
     if (n == 0) return EMD_OK;
@@ -1107,8 +1163,11 @@ int emd_launch_abs_mean_backward(size_t n, const float* x, const float* g, float
 int emd_launch_preprocess(const PreArgs& a, int part, hipStream_t st) {
     if (a.N <= 0) return EMD_OK;
     const int nb = (a.N + PRE_BLOCK - 1) / PRE_BLOCK;
+    const bool res = a.shs_res0 != nullptr;
     if (part == 1) hipLaunchKernelGGL(k_preprocess<1>, dim3(nb), dim3(PRE_BLOCK), 0, st, a);
+    else if (part == 2 && res) hipLaunchKernelGGL((k_preprocess<2, true>), dim3(nb), dim3(PRE_BLOCK), 0, st, a);
     else if (part == 2) hipLaunchKernelGGL(k_preprocess<2>, dim3(nb), dim3(PRE_BLOCK), 0, st, a);
+    else if (res) hipLaunchKernelGGL((k_preprocess<0, true>), dim3(nb), dim3(PRE_BLOCK), 0, st, a);
     else hipLaunchKernelGGL(k_preprocess<0>, dim3(nb), dim3(PRE_BLOCK), 0, st, a);
     EMD_LAUNCH_CHECK();
     return EMD_OK;

@@ -406,8 +406,9 @@ class deform_network(nn.Module):
     def get_aabb(self):
         return self.deformation_net.get_aabb
 
-    def apply_deform(self, point, scales=None, rotations=None, opacity=None, shs=None, ddict_c=None, ddict_f=None):
-        """deformation.py:439-481; the `.clone()`s of the reference are dropped where an add follows (same values, same graph)."""
+    def apply_deform(self, point, scales=None, rotations=None, opacity=None, shs=None, ddict_c=None, ddict_f=None, defer_shs=False):
+        """deformation.py:439-481; the `.clone()`s of the reference are dropped where an add follows (same values, same graph).
+        `defer_shs`: `shs` is returned as it came and the dshs residuals are left to the caller (the rasterizer's `shs_residuals`)."""
         a = self.args
         levels = [d for off, d in ((a.no_coarse_deform, ddict_c), (a.no_fine_deform, ddict_f)) if not off]
 
@@ -424,12 +425,17 @@ class deform_network(nn.Module):
                 rot_f = batch_quaternion_multiply(rot_f, d["dr"])
             if not a.no_do:
                 opac_f = opac_f + d["do"]
-            if not a.no_dshs:
+            if not a.no_dshs and not defer_shs:
                 shs_f = shs_f + d["dshs"]
         return point_f, scales_f, rot_f, opac_f, shs_f
 
     def forward(self, point, scales=None, rotations=None, opacity=None, shs=None, times_sel=None, embeddings=None, iter=None, cam_no=None,
-                time_diff=None, is_train=None, need_feat=True):
+                time_diff=None, is_train=None, need_feat=True, fused_shs_residuals=False):
+        """`fused_shs_residuals` (not in the reference): the SH residuals are NOT added to `shs`; they are returned as
+        ddict["shs_residuals"] for `GaussianRasterizer(..., shs_residuals=...)`, which forms shs + dshs_c + dshs_f for the visible Gaussians
+        inside its projection kernel, and each level's dict carries "dshs_abs_mean" -- mean |dshs|, the regulariser of train.py:238-310,
+        whose gradient is folded into the residual's in one pass (emd_amd.model.residual_pair_l1).  Needs both levels and the default
+        direct_add_dshs; otherwise the call behaves as without the flag."""
         net = self.deformation_net
         times_sel = net.forward_time_offset(times_sel, cam_no)
         ddict_c = net(point, times_sel, embeddings, is_coarse=True, iter=iter, num_down_emb_c=self.min_embeddings,
@@ -439,8 +445,18 @@ class deform_network(nn.Module):
             pts = point + ddict_c["dx"]
         ddict_f = net(pts, times_sel, embeddings, is_coarse=False, iter=iter, num_down_emb_f=self.min_embeddings,
                       apply_deform=not self.no_fine_deform, time_diff=time_diff, is_train=is_train, need_feat=need_feat)
-        out = self.apply_deform(point, scales, rotations, opacity, shs, ddict_c, ddict_f)
-        return (*out, {"coarse": ddict_c, "fine": ddict_f})
+        a = self.args
+        fuse = (fused_shs_residuals and shs is not None and not a.no_dshs and a.direct_add_dshs and not self.no_coarse_deform
+                and not self.no_fine_deform and ddict_c.get("dshs") is not None and ddict_f.get("dshs") is not None)
+        dd = {"coarse": ddict_c, "fine": ddict_f}
+        if fuse:
+            from .model import residual_pair_l1
+            rc, rf, l1c, l1f = residual_pair_l1(ddict_c["dshs"].reshape(shs.shape), ddict_f["dshs"].reshape(shs.shape))
+            ddict_c["dshs"], ddict_f["dshs"] = rc, rf
+            ddict_c["dshs_abs_mean"], ddict_f["dshs_abs_mean"] = l1c, l1f
+            dd["shs_residuals"] = [rc, rf]
+        out = self.apply_deform(point, scales, rotations, opacity, shs, ddict_c, ddict_f, defer_shs=fuse)
+        return (*out, dd)
 
     def get_mlp_parameters(self):
         return self.deformation_net.get_mlp_parameters()

@@ -95,7 +95,8 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         t = float(getattr(cam, "time", 0.0) if time is None else time)
         times_sel = torch.full((means3D.shape[0], 1), t, device=dev, dtype=torch.float32)
         from .deformation import deform_network as _dn
-        extra_kw = {"need_feat": bool(need_feat or render_feat)} if isinstance(deformation, _dn) else {}
+        # (an emd_amd network hands the SH residuals over unsummed: `shs + dshs_c + dshs_f` is formed inside the projection kernel)
+        extra_kw = {"need_feat": bool(need_feat or render_feat), "fused_shs_residuals": True} if isinstance(deformation, _dn) else {}
         means3D, scales, rotations, opacity, shs, ddict = deformation(
             means3D, scales, rotations, opacity, shs, times_sel, embeddings, iteration, int(getattr(cam, "cam_no", 0)),
             getattr(cam, "time_diff", 0.0), True, **extra_kw)
@@ -110,6 +111,9 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         feat_sets = [(lvl, ddict[lvl]["feat"]) for lvl in ("coarse", "fine") if ddict.get(lvl) is not None and ddict[lvl].get("feat") is not None]
         if feat_sets:
             kw["colors_extra"] = [f for _, f in feat_sets]
+    shs_res = ddict.get("shs_residuals") if ddict is not None else None
+    if shs_res:
+        kw["shs_residuals"] = shs_res
     if model.has_actors:
         from .motion import DeviceStep
         it = 0 if iteration is None else (iteration if isinstance(iteration, (torch.Tensor, DeviceStep)) else int(iteration))
@@ -120,7 +124,8 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
     out = _RenderOutputs({"render": image, "viewspace_points": screenspace_points, "radii": radii,
            "depth": depth, "weight": weight, "normal": normal, "actor_pose": kw.get("actor_pose"), "ddict": ddict,
            "raster_call": rasterizer.last_call, "rasterizer": rasterizer,
-           "boundary": dict(means3D=means3D, opacities=opacity, scales=scales, rotations=rotations, shs=shs, raw_params=fuse_activations)})
+           "boundary": dict(means3D=means3D, opacities=opacity, scales=scales, rotations=rotations, shs=shs, raw_params=fuse_activations,
+                            shs_residuals=shs_res)})
     for (lvl, _), img in zip(feat_sets, extra or []):
         out["feat_c" if lvl == "coarse" else "feat_f"] = img
     return out
@@ -163,6 +168,9 @@ def render_decomposition(out, levels=("coarse", "fine", "coarse_fine"), top_frac
         dx["coarse_fine"] = dx["coarse"] - dx["fine"]
     res = {}
     with torch.no_grad():
+        shs_all = bd["shs"]
+        for r_ in (bd.get("shs_residuals") or []):           # (handed to the main pass unsummed)
+            shs_all = shs_all + r_
         base = dict(opacities=bd["opacities"], scales=bd["scales"], rotations=bd["rotations"], raw_params=bd["raw_params"], cov3Ds_precomp=None,
                     extra_attrs=None)
         m2d = torch.zeros_like(bd["means3D"])
@@ -177,7 +185,7 @@ def render_decomposition(out, levels=("coarse", "fine", "coarse_fine"), top_frac
             if k > 0:
                 mask[torch.topk(dist, k)[1]] = True
             sub = {n_: (v[mask] if isinstance(v, torch.Tensor) else v) for n_, v in base.items()}
-            img_d, depth_d, normal_d, weight_d, _, _ = rast(means3D=bd["means3D"][mask], means2D=m2d[mask], shs=bd["shs"][mask], colors_precomp=None, **sub)
+            img_d, depth_d, normal_d, weight_d, _, _ = rast(means3D=bd["means3D"][mask], means2D=m2d[mask], shs=shs_all[mask], colors_precomp=None, **sub)
             col = d_abs / d_abs.max(dim=0, keepdim=True)[0]
             color_dx = rast(means3D=bd["means3D"], means2D=m2d, shs=None, colors_precomp=col, **base)[0]
             res[lvl + "_render"] = {"render": img_d, "depth": depth_d, "color": color_dx, "weight": weight_d, "normal": normal_d, "dx": d}
@@ -286,6 +294,56 @@ def abs_mean(x):
     242-310 -- in one launch forward (no |x| tensor) and one backward (sign(x) g / n with the upstream gradient read on the device)
     instead of abs / mean / sign / mul / expand launches over tensors of up to 48 floats per Gaussian."""
     return _AbsMean.apply(x)
+
+
+class _ResidualPairL1(torch.autograd.Function):
+    """(x_a, x_b) -> (x_a, x_b, mean |x_a|, mean |x_b|): the identity on two residual tensors with their L1 means as extra outputs.  The
+    backward forms  up_a + sign(x_a) g_a / n  and  up_b + sign(x_b) g_b / n  in ONE pass (`emd_residual_l1_backward`); when both residuals
+    received the same upstream tensor -- the rasterizer's dL/dshs for `shs_residuals=[x_a, x_b]` -- it is read once."""
+
+    @staticmethod
+    def forward(ctx, xa, xb):
+        import ctypes as C
+        from . import _lib as L
+        if xa.device.type != "cuda":
+            raise L.EmdError("residual_pair_l1 needs tensors on a ROCm device; there is no CPU path")
+        if xa.shape != xb.shape:
+            raise ValueError("residual_pair_l1: the two residuals must have one shape")
+        a, b = xa.detach().contiguous().float(), xb.detach().contiguous().float()
+        out = torch.empty(2, device=xa.device, dtype=torch.float32)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(L.load().emd_l1_loss(a.numel(), a.data_ptr(), None, out.data_ptr(), None, st), "emd_l1_loss")
+        L.check(L.load().emd_l1_loss(b.numel(), b.data_ptr(), None, out[1:].data_ptr(), None, st), "emd_l1_loss")
+        ctx.save_for_backward(a, b)
+        return a.view(xa.shape), b.view(xb.shape), out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, up_a, up_b, g_a, g_b):
+        import ctypes as C
+        from . import _lib as L
+        a, b = ctx.saved_tensors
+        same = up_a is not None and up_b is not None and (up_a is up_b or (up_a.data_ptr() == up_b.data_ptr() and up_a.stride() == up_b.stride()))
+        ua = None if up_a is None else up_a.contiguous().float()
+        ub = ua if same else (None if up_b is None else up_b.contiguous().float())
+        ga = None if g_a is None else g_a.detach().reshape(1).float().contiguous()
+        gb = None if g_b is None else g_b.detach().reshape(1).float().contiguous()
+        grad_a, grad_b = torch.empty_like(a), torch.empty_like(b)
+        L.check(L.load().emd_residual_l1_backward(a.numel(), L.ptr(ua), L.ptr(ub), a.data_ptr(), b.data_ptr(), L.ptr(ga), L.ptr(gb),
+                                                  grad_a.data_ptr(), grad_b.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                "emd_residual_l1_backward")
+        return grad_a, grad_b
+
+
+def residual_pair_l1(xa, xb):
+    """The two residuals unchanged, and mean |xa|, mean |xb| (the regularisers of S3Gaussian/train.py:238-310) -- see _ResidualPairL1."""
+    return _ResidualPairL1.apply(xa, xb)
+
+
+def residual_abs_mean(level_dict, key):
+    """mean |level_dict[key]|: the value the deformation network formed beside the residual when it ran with fused SH residuals
+    (`<key>_abs_mean`), else `abs_mean(level_dict[key])`."""
+    v = level_dict.get(key + "_abs_mean")
+    return v if v is not None else abs_mean(level_dict[key])
 
 
 def l1_loss(network_output, gt):

@@ -270,7 +270,7 @@ def _fill_motion(m: L.EmdMotion, actor_ids, actor_pose, residual_dx, residual_dq
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose,
-                residual_dx, residual_dq, actor_ids, raster_settings, flags, opts, rec, extra0=None, extra1=None):
+                residual_dx, residual_dq, actor_ids, raster_settings, flags, opts, rec, extra0=None, extra1=None, shs_res0=None, shs_res1=None):
         lib = L.load()
         dev = means3D.device
         if dev.type != "cuda":
@@ -313,6 +313,7 @@ class _Rasterize(torch.autograd.Function):
             a.settings_dev = L.ptr(sdev)
             a.num_gaussians, a.sh_coeffs, a.flags, a.bin_capacity = N, M, flags, capacity
             a.means3D, a.shs, a.colors_precomp = L.ptr(means3D), L.ptr(shs), L.ptr(colors_precomp)
+            a.shs_residual[0], a.shs_residual[1] = L.ptr(shs_res0), L.ptr(shs_res1)
             a.opacities, a.scales, a.rotations = L.ptr(opacities), L.ptr(scales), L.ptr(rotations)
             a.cov3D_precomp = L.ptr(cov3Ds_precomp)
             _fill_motion(a.motion, actor_ids, actor_pose, residual_dx, residual_dq)
@@ -355,6 +356,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.sizes = (gb, bb, ib)
         ctx.opts, ctx.rec = opts, rec
         ctx.means2D_ref = means2D if (flags & L.FLAG_ABSGRAD) else None      # gsplat convention: `.absgrad` is set on this tensor
+        ctx.has_shs_res = (shs_res0 is not None, shs_res1 is not None)
         ctx.has = (shs is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None,
                    actor_pose is not None, residual_dx is not None, residual_dq is not None)
         ctx.num_extra = len(extras)
@@ -460,7 +462,10 @@ class _Rasterize(torch.autograd.Function):
         if rec.on_backward is not None:
             rec.on_backward(rec)
         d_x = d_extra + [None] * (2 - nx)
-        return (d_means3D, d_means2D, d_shs, d_col, d_op, d_sc, d_rot, d_cov, d_pose, d_rdx, d_rdq, None, None, None, None, None, d_x[0], d_x[1])
+        # (the residuals of the SH coefficients enter as a sum: each receives dL/dshs itself -- the same tensor, no copy)
+        d_r0, d_r1 = (d_shs if ctx.has_shs_res[0] else None), (d_shs if ctx.has_shs_res[1] else None)
+        return (d_means3D, d_means2D, d_shs, d_col, d_op, d_sc, d_rot, d_cov, d_pose, d_rdx, d_rdq, None, None, None, None, None, d_x[0], d_x[1],
+                d_r0, d_r1)
 
 
 class GaussianRasterizer(nn.Module):
@@ -483,11 +488,14 @@ class GaussianRasterizer(nn.Module):
                 cov3Ds_precomp=None, extra_attrs=None, actor_ids: Optional[torch.Tensor] = None,
                 actor_pose: Optional[torch.Tensor] = None, residual_dx: Optional[torch.Tensor] = None,
                 residual_dq: Optional[torch.Tensor] = None, raw_params: bool = False, record: Optional[RasterCall] = None,
-                colors_extra=None):
+                colors_extra=None, shs_residuals=None):
         """`colors_extra`: up to two more colour sets [N,3] composited by the SAME call -- the reference's feature passes
         (`colors_precomp = ddict["coarse"/"fine"]["feat"]`, gaussian_renderer/__init__.py:170-201) without their second and third
         projection, sort and list walk.  Their images [3,H,W] are returned as a list in the sixth slot of the result (the
-        reference's `extra`); each equals the colour image of a separate call with that colour set, bit for bit."""
+        reference's `extra`); each equals the colour image of a separate call with that colour set, bit for bit.
+        `shs_residuals`: up to two tensors shaped like `shs`; the colours are evaluated on (shs + r0) + r1, formed inside the projection
+        kernel for the visible Gaussians only -- the fine stage's `shs + dshs_coarse + dshs_fine` (S3Gaussian/scene/deformation.py:468-481)
+        without its two passes over [N,16,3]; same image bit for bit, and each term receives dL/dshs."""
         rs, opts = self.raster_settings, self.options
         if (shs is None) == (colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
@@ -548,9 +556,17 @@ class GaussianRasterizer(nn.Module):
         if any(e.shape[0] != N for e in extras):
             raise ValueError("colors_extra must hold one colour per Gaussian")
         extras += [None] * (2 - len(extras))
+        res = [] if shs_residuals is None else [_f32c(r, "shs_residuals") for r in shs_residuals if r is not None]
+        if res and shs is None:
+            raise ValueError("shs_residuals needs shs")
+        if len(res) > 2 or any(r.shape != shs.shape for r in res):
+            raise ValueError("shs_residuals: at most two tensors of the shape of shs")
+        if res and opts.factored_sh_grad:
+            raise ValueError("shs_residuals need the dense dL/dshs (factored_sh_grad=False)")
+        res += [None] * (2 - len(res))
         color, depth, normal, alpha, radii, *x_imgs = _Rasterize.apply(
             means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, actor_pose, residual_dx,
-            residual_dq, actor_ids, rs, flags, opts, rec, extras[0], extras[1])
+            residual_dq, actor_ids, rs, flags, opts, rec, extras[0], extras[1], res[0], res[1])
         self.last_call = rec
         return color, depth, normal, alpha, radii, (list(x_imgs) if x_imgs else None)
 

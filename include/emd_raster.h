@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 19
+#define EMD_ABI_VERSION 20
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -190,6 +190,12 @@ typedef struct EmdFwdArgs {
      * stage; fork and join are events, i.e. graph edges under stream capture.  The stream must belong to the same device and must not be
      * the call's own; NULL (or debug = 1) keeps everything on one stream.  Same results bit for bit either way. */
     void* aux_stream;
+    /* Optional residuals of the SH coefficients (ABI 20), [N,sh_coeffs,3] each or NULL: the colour is evaluated on
+     * (shs + shs_residual[0]) + shs_residual[1], added in that order while the rows are staged.  The reference's fine stage forms
+     * `shs_final = shs + dshs_coarse + dshs_fine` as two element-wise passes over [N,16,3] before every render
+     * (S3Gaussian/scene/deformation.py:468-481); here the sum exists only for the Gaussians that are visible, inside the projection
+     * kernel.  dL/dshs of the backward is the gradient of each of the three terms (the sum's Jacobian is the identity). */
+    const float* shs_residual[2];
 } EmdFwdArgs;
 
 typedef struct EmdBwdArgs {
@@ -362,6 +368,11 @@ int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* d
  * emd_abs_mean_backward writes their gradient sign(x[i]) * g[0] / n with the upstream gradient g read on the device. */
 int emd_l1_loss(int64_t n, const float* a, const float* b, float* loss /*[1]*/, float* grad /*[n] or NULL*/, void* hip_stream);
 int emd_abs_mean_backward(int64_t n, const float* x, const float* g /*[1], device*/, float* grad /*[n]*/, void* hip_stream);
+/* ABI 20.  The backward of a PAIR of regularised residuals that also feed the renderer (dshs_coarse / dshs_fine of the fine stage,
+ * S3Gaussian/train.py:238-310 with scene/deformation.py:468-481): grad_a[i] = up_a[i] + sign(x_a[i]) g_a[0] / n, likewise b, in one
+ * pass; up_a / up_b (the renderer's dL/dshs, usually one tensor: read once when the pointers are equal) and g_a / g_b may be NULL (= 0). */
+int emd_residual_l1_backward(int64_t n, const float* up_a, const float* up_b, const float* x_a, const float* x_b, const float* g_a /*[1], device*/,
+                             const float* g_b /*[1], device*/, float* grad_a /*[n]*/, float* grad_b /*[n]*/, void* hip_stream);
 
 /* The activations exactly as EMD_FLAG_RAW_PARAMS applies them (exp, F.normalize, sigmoid); any pair may be NULL. */
 int emd_activations_forward(int32_t n, const float* log_scales, float* scales, const float* raw_quats, float* quats,

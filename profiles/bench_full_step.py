@@ -27,7 +27,7 @@ sys.path.insert(0, ".")
 from emd_amd import dp, scenes, RasterOptions  # noqa: E402
 from emd_amd import rasterizer as _rz  # noqa: E402
 from emd_amd.loss import image_loss  # noqa: E402
-from emd_amd.model import StreetGaussians, abs_mean, render  # noqa: E402
+from emd_amd.model import StreetGaussians, abs_mean, render, residual_abs_mean  # noqa: E402
 from emd_amd.sky import SkyCubeMap, composite_s3g  # noqa: E402
 
 dev = torch.device("cuda", 0)
@@ -99,7 +99,7 @@ def step(s):
     if FINE:                                           # residual regularisers (train.py: lambda_dx / do / dshs on both levels)
         for lvl in ("coarse", "fine"):
             d = out["ddict"][lvl]
-            loss = loss + 0.001 * (abs_mean(d["dx"]) + abs_mean(d["do"]) + abs_mean(d["dshs"]))
+            loss = loss + 0.001 * (abs_mean(d["dx"]) + abs_mean(d["do"]) + residual_abs_mean(d, "dshs"))
     if FEAT:
         loss = loss + 0.001 * (((out["feat_c"] - gt_feat) ** 2).mean() + ((out["feat_f"] - gt_feat) ** 2).mean())
     loss.backward()

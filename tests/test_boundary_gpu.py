@@ -366,3 +366,47 @@ def test_colour_half_on_an_auxiliary_stream_gives_the_same_call():
             torch.cuda.synchronize()
             assert torch.equal(img, want)
         graph.reset()
+
+
+@pytest.mark.parametrize("sh_degree", [3, 2])
+def test_shs_residuals_equal_the_summed_coefficients(sh_degree):
+    """EmdFwdArgs.shs_residual (ABI 20): the call with shs_residuals=(a, b) gives, bit for bit, the image of the call with
+    shs = (shs + a) + b -- the fine stage's `shs + dshs_coarse + dshs_fine` (S3Gaussian/scene/deformation.py:468-481) -- and each of the
+    three terms receives the same dL/dshs; one residual alone and the row path without the LDS staging (9 coefficients) included."""
+    from emd_amd import GaussianRasterizer
+    case = make_case(n=6000, H=80, W=112, seed=11 + sh_degree, sh_degree=sh_degree)
+    K = (sh_degree + 1) ** 2
+    case["shs"] = case["shs"][:, :K].contiguous()
+    rs = _settings(case)
+    gen = torch.Generator().manual_seed(sh_degree)
+    ra, rb = torch.randn(case["shs"].shape, generator=gen) * 0.1, torch.randn(case["shs"].shape, generator=gen) * 0.05
+    gout = torch.rand(3, case["H"], case["W"], generator=gen).to(DEV)
+
+    def run(mode):
+        t = _leaves(case)
+        res = [r_.to(DEV).clone().requires_grad_(True) for r_ in (ra, rb)]
+        base = t["shs"]
+        if mode == "summed":
+            t = dict(t, shs=(base + res[0]) + res[1])
+            img = _call(GaussianRasterizer(rs), t)[0]
+        elif mode == "one":
+            img = _call(GaussianRasterizer(rs), t, shs_residuals=[res[0]])[0]
+        elif mode == "one_summed":
+            t = dict(t, shs=base + res[0])
+            img = _call(GaussianRasterizer(rs), t)[0]
+        else:
+            img = _call(GaussianRasterizer(rs), t, shs_residuals=res)[0]
+        (img * gout).sum().backward()
+        return img.detach(), [base.grad] + [r_.grad for r_ in res]
+    img_sum, g_sum = run("summed")
+    img_res, g_res = run("residuals")
+    assert float(img_sum.abs().max()) > 0 and torch.equal(img_res, img_sum)
+    close = lambda a_, b_: float((a_ - b_).abs().max()) <= 1e-5 * float(b_.abs().max())     # (the render backward's float atomics reorder sums between runs)
+    for a_, b_ in zip(g_res, g_sum):
+        assert a_ is not None and close(a_, b_)
+    assert torch.equal(g_res[0], g_res[1]) and torch.equal(g_res[0], g_res[2])              # one dL/dshs for the three terms
+    img_one, g_one = run("one")
+    img_one_sum, g_one_sum = run("one_summed")
+    assert torch.equal(img_one, img_one_sum) and close(g_one[0], g_one_sum[0]) and close(g_one[1], g_one_sum[1]) and g_one[2] is None
+    with pytest.raises(ValueError):
+        _call(GaussianRasterizer(rs), _leaves(case), shs_residuals=[ra[:10].to(DEV)])

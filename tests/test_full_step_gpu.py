@@ -144,6 +144,8 @@ def test_decomposition_passes_of_the_reference_render():
     assert set(dec) == {"coarse_render", "fine_render", "coarse_fine_render"}
     bd = {k_: (v.detach() if isinstance(v, torch.Tensor) else v) for k_, v in out["boundary"].items()}
     s_act, q_act, o_act = torch.exp(bd["scales"]), torch.nn.functional.normalize(bd["rotations"]), torch.sigmoid(bd["opacities"])
+    assert bd["shs_residuals"] is not None and len(bd["shs_residuals"]) == 2        # render() hands the dshs residuals to K1 unsummed
+    shs_all = (bd["shs"] + bd["shs_residuals"][0].detach()) + bd["shs_residuals"][1].detach()
     rs = raster_settings_for(cam, bg, model.active_sh_degree)
     for lvl, d in (("coarse", out["ddict"]["coarse"]["dx"]), ("fine", out["ddict"]["fine"]["dx"]),
                    ("coarse_fine", out["ddict"]["coarse"]["dx"] - out["ddict"]["fine"]["dx"])):
@@ -153,7 +155,7 @@ def test_decomposition_passes_of_the_reference_render():
         mask[torch.topk(d_abs.norm(dim=1), int(N * 0.005))[1]] = True
         assert int(mask.sum()) == 60
         with torch.no_grad():
-            ref = GaussianRasterizer(rs)(means3D=bd["means3D"][mask], means2D=torch.zeros(60, 3, device=dev), shs=bd["shs"][mask], colors_precomp=None,
+            ref = GaussianRasterizer(rs)(means3D=bd["means3D"][mask], means2D=torch.zeros(60, 3, device=dev), shs=shs_all[mask], colors_precomp=None,
                                          opacities=o_act[mask], scales=s_act[mask], rotations=q_act[mask], cov3Ds_precomp=None, extra_attrs=None)
         torch.testing.assert_close(got["render"], ref[0], rtol=0, atol=2e-6)       # (fused activations vs activated inputs: last-bit differences)
         torch.testing.assert_close(got["weight"], ref[3], rtol=0, atol=2e-6)
@@ -165,3 +167,56 @@ def test_decomposition_passes_of_the_reference_render():
         _, _, img = co.forward(S, sc, 0)
         assert float(np.abs(got["color"].cpu().numpy() - img["color"]).max()) <= 1e-4
         assert torch.equal(got["dx"], d)
+
+
+def test_fused_sh_residuals_and_regulariser_equal_the_reference_formulation():
+    """The fine-stage step with the SH residuals handed to the projection kernel unsummed and their L1 regulariser folded into the residuals'
+    gradient (deform_network(..., fused_shs_residuals=True), GaussianRasterizer(shs_residuals=...), model.residual_pair_l1) against the
+    formulation of the reference: shs + dshs_c + dshs_f as tensors (scene/deformation.py:468-481) and torch.abs(dshs).mean() per level
+    (train.py:238-310).  Same image bit for bit, same loss, same gradients of every parameter."""
+    from emd_amd import GaussianRasterizer, scenes
+    from emd_amd.deformation import DeformOptions, deform_network
+    from emd_amd.model import StreetGaussians, l1_loss, raster_settings_for, render, residual_abs_mean
+    dev = torch.device("cuda", 0)
+    N, H, W = 15000, 80, 128
+    model = StreetGaussians(scenes.make_static_scene(N, seed=8), dev)
+    torch.manual_seed(9)
+    deform = deform_network(DeformOptions()).to(dev)
+    deform.deformation_net.set_aabb([120.0, 30.0, 10.0], [0.0, -30.0, -2.0])
+    for n_, p_ in deform.named_parameters():
+        if p_.dim() > 1 and "grid" not in n_:
+            p_.data.mul_(0.05)
+    emb = torch.nn.Parameter(0.1 * torch.randn(N, 4, device=dev))
+    cam, bg = scenes.rig_camera(3, 0, H, W), torch.zeros(3)
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    params = list(model.parameters()) + list(deform.parameters()) + [emb]
+
+    def grads():
+        return [None if p.grad is None else p.grad.clone() for p in params]
+
+    # (a) the fused path (what render() does with an emd_amd network)
+    for p in params:
+        p.grad = None
+    out = render(model, cam, bg, frame=0, deformation=deform, embeddings=emb, iteration=12000, time=0.4)
+    assert out["ddict"].get("shs_residuals") is not None and "dshs_abs_mean" in out["ddict"]["fine"]
+    loss_a = l1_loss(out["render"], target) + 0.01 * (residual_abs_mean(out["ddict"]["coarse"], "dshs") + residual_abs_mean(out["ddict"]["fine"], "dshs"))
+    loss_a.backward()
+    img_a, g_a = out["render"].detach().clone(), grads()
+    # (b) the reference's formulation, from the same network: explicit sums and torch means
+    for p in params:
+        p.grad = None
+    z = torch.zeros_like(model._xyz).requires_grad_(True)
+    m3, sc_, rot_, op_, shs_sum, dd = deform(model._xyz, model._scaling, model._rotation, model._opacity, model._features,
+                                            torch.full((N, 1), 0.4, device=dev), emb, 12000, 0, 0.0, True)
+    assert "shs_residuals" not in dd and torch.equal(shs_sum, (model._features + dd["coarse"]["dshs"]) + dd["fine"]["dshs"])
+    img_b = GaussianRasterizer(raster_settings_for(cam, bg, model.active_sh_degree))(
+        means3D=m3, means2D=z, shs=shs_sum, colors_precomp=None, opacities=op_, scales=sc_, rotations=rot_, cov3Ds_precomp=None, raw_params=True)[0]
+    loss_b = l1_loss(img_b, target) + 0.01 * (dd["coarse"]["dshs"].abs().mean() + dd["fine"]["dshs"].abs().mean())
+    loss_b.backward()
+    g_b = grads()
+    assert torch.equal(img_a, img_b.detach())
+    assert abs(float(loss_a.detach()) - float(loss_b.detach())) <= 1e-6 * abs(float(loss_b.detach()))
+    for p, a_, b_ in zip(params, g_a, g_b):
+        assert (a_ is None) == (b_ is None)
+        if a_ is not None:
+            assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(b_.abs().max()), 1e-20), tuple(p.shape)
