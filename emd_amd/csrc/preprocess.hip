@@ -262,7 +262,7 @@ __device__ __forceinline__ void sh_row_load(const float* __restrict__ shs, const
 // RES: residuals of the SH coefficients are added while the rows are staged (EmdFwdArgs.shs_residual); a separate instantiation, so
 // that the usual kernel keeps its registers (with the residual loads in the same code it spilled 24)
 template <int PART, bool RES = false>
-__global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(PART == 1 ? 6 : EMD_K1_WAVES))) k_preprocess(PreArgs a) {
+__global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(PART == 1 ? 6 : (RES ? 4 : EMD_K1_WAVES)))) k_preprocess(PreArgs a) {
     __shared__ float4 s_sh[PART == 1 ? 1 : (PRE_BLOCK / 2) * SH_ROW4];       // half of the wave's rows at a time: 6.5 KB keeps four waves per SIMD
     EmdSettings S = a.s;
     emd_settings_from_device(S, a.sdev, a.flags);
