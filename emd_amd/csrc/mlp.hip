@@ -46,6 +46,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MLP_BWD_WAVES 1
 #endif
 #define MLP_OCC(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+// Kernels whose tiles fit 256 registers run two waves per SIMD (measured round 3: k_mlp_branch_fwd<1,1> 228 -> 219 us, k_mlp_trunk_bwd<0>
+// 504 -> 457 us at 2 M rows; the others spill at half the register file and lose).
+#define MLP_W_F11 2
+#define MLP_W_T0 2
+#define MLP_W_TB0 2
 
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -311,7 +316,7 @@ __device__ __forceinline__ void branch_stage(float* lds, const EmdMlpBranch& a) 
 }
 
 template <int DEPTH, int NTO>
-__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_FWD_WAVES) k_mlp_branch_fwd(EmdMlpBranch a) {
+__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1) ? MLP_W_F11 : MLP_FWD_WAVES) k_mlp_branch_fwd(EmdMlpBranch a) {
     typedef BranchLds<DEPTH, NTO> L;
     extern __shared__ float lds[];
     branch_stage<DEPTH, NTO, false>(lds, a);
@@ -559,7 +564,7 @@ __device__ __forceinline__ void trunk_load_x(const EmdMlpTrunk& a, size_t row, b
 }
 
 template <int KTA>
-__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_FWD_WAVES) k_mlp_trunk_fwd(EmdMlpTrunk a) {
+__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(KTA == 0 ? MLP_W_T0 : MLP_FWD_WAVES) k_mlp_trunk_fwd(EmdMlpTrunk a) {
     extern __shared__ float lds[];
     trunk_stage<KTA>(lds, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
@@ -589,7 +594,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_FWD_WAVES) k_mlp_trun
 }
 
 template <int KTA>
-__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_trunk_bwd(EmdMlpTrunk a, EmdMlpTrunkGrads g) {
+__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(KTA == 0 ? MLP_W_TB0 : MLP_BWD_WAVES) k_mlp_trunk_bwd(EmdMlpTrunk a, EmdMlpTrunkGrads g) {
     typedef TrunkLds<KTA> L;
     extern __shared__ float lds[];
     if (KTA) stage_matrix_t(lds + L::wat, WS, 64, 32 * KTA, a.w, a.ld_w, a.col_a, 64, a.ka);
@@ -749,7 +754,7 @@ extern "C" int emd_mlp_branch_forward(const EmdMlpBranch* a, void* hip_stream) {
     if (!a->out) { emd_set_error("mlp_branch_forward: null output"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     const int nto = a->out_dim > 32 ? 2 : 1;
-    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1>, MLP_FWD_WAVES>(BranchLds<1, 1>::fwd_floats, a->num_points, st, *a);
+    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1>, MLP_W_F11>(BranchLds<1, 1>::fwd_floats, a->num_points, st, *a);
     if (a->depth == 1) return mlp_launch<k_mlp_branch_fwd<1, 2>, MLP_FWD_WAVES>(BranchLds<1, 2>::fwd_floats, a->num_points, st, *a);
     if (nto == 1) return mlp_launch<k_mlp_branch_fwd<2, 1>, MLP_FWD_WAVES>(BranchLds<2, 1>::fwd_floats, a->num_points, st, *a);
     return mlp_launch<k_mlp_branch_fwd<2, 2>, MLP_FWD_WAVES>(BranchLds<2, 2>::fwd_floats, a->num_points, st, *a);
@@ -773,7 +778,7 @@ extern "C" int emd_mlp_trunk_forward(const EmdMlpTrunk* a, void* hip_stream) {
     if (rc || a->num_points == 0) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
     switch ((a->ka + 31) / 32) {            // input tiles of 32 columns (the last one zero-padded)
-        case 0: return mlp_launch<k_mlp_trunk_fwd<0>, MLP_FWD_WAVES>(TrunkLds<0>::fwd_floats, a->num_points, st, *a);
+        case 0: return mlp_launch<k_mlp_trunk_fwd<0>, MLP_W_T0>(TrunkLds<0>::fwd_floats, a->num_points, st, *a);
         case 1: return mlp_launch<k_mlp_trunk_fwd<1>, MLP_FWD_WAVES>(TrunkLds<1>::fwd_floats, a->num_points, st, *a);
         case 2: return mlp_launch<k_mlp_trunk_fwd<2>, MLP_FWD_WAVES>(TrunkLds<2>::fwd_floats, a->num_points, st, *a);
         case 3: return mlp_launch<k_mlp_trunk_fwd<3>, MLP_FWD_WAVES>(TrunkLds<3>::fwd_floats, a->num_points, st, *a);
@@ -790,7 +795,7 @@ extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGra
     if (g->d_xa && ((uintptr_t)g->d_xa & 15)) { emd_set_error("mlp_trunk_backward: d_xa must be 16-byte aligned"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     switch ((a->ka + 31) / 32) {
-        case 0: return mlp_launch<k_mlp_trunk_bwd<0>, MLP_BWD_WAVES>(TrunkLds<0>::bwd_floats, a->num_points, st, *a, *g);
+        case 0: return mlp_launch<k_mlp_trunk_bwd<0>, MLP_W_TB0>(TrunkLds<0>::bwd_floats, a->num_points, st, *a, *g);
         case 1: return mlp_launch<k_mlp_trunk_bwd<1>, MLP_BWD_WAVES>(TrunkLds<1>::bwd_floats, a->num_points, st, *a, *g);
         case 2: return mlp_launch<k_mlp_trunk_bwd<2>, MLP_BWD_WAVES>(TrunkLds<2>::bwd_floats, a->num_points, st, *a, *g);
         case 3: return mlp_launch<k_mlp_trunk_bwd<3>, MLP_BWD_WAVES>(TrunkLds<3>::bwd_floats, a->num_points, st, *a, *g);
