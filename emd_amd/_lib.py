@@ -191,7 +191,7 @@ ADAM_MAX_TENSORS = 32
 class EmdAdamTensor(C.Structure):
     _fields_ = [("param", _f), ("grad", _f), ("exp_avg", _f), ("exp_avg_sq", _f), ("numel", C.c_int64), ("step_size", C.c_float),
                 ("bias_correction2_sqrt", C.c_float), ("one_minus_beta1", C.c_float), ("beta2", C.c_float), ("one_minus_beta2", C.c_float),
-                ("eps", C.c_float)]
+                ("eps", C.c_float), ("step_dev", _f), ("lr_dev", _f)]
 
 
 class EmdAdamArgs(C.Structure):

@@ -37,7 +37,12 @@ __global__ void __launch_bounds__(ADAM_THREADS) k_adam(AdamLaunch L) {
     int ti = 0;
 #pragma unroll 1
     while (ti + 1 < L.a.num_tensors && blockIdx.x >= L.first_block[ti + 1]) ti++;
-    const EmdAdamTensor t = L.a.tensors[ti];
+    EmdAdamTensor t = L.a.tensors[ti];
+    if (t.step_dev) {                      // capturable: the step-dependent scalars from the device-resident step count and learning rate
+        const float st = t.step_dev[0], b1 = 1.f - t.one_minus_beta1;
+        t.bias_correction2_sqrt = sqrtf(1.f - powf(t.beta2, st));
+        t.step_size = t.lr_dev[0] / (1.f - powf(b1, st));
+    }
     const int64_t base = (int64_t)(blockIdx.x - L.first_block[ti]) * ADAM_CHUNK;
     const bool vec = ((((uintptr_t)t.param) | ((uintptr_t)t.grad) | ((uintptr_t)t.exp_avg) | ((uintptr_t)t.exp_avg_sq)) & 15) == 0;
 #pragma unroll
@@ -81,7 +86,8 @@ extern "C" int emd_adam_step(const EmdAdamArgs* a, void* hip_stream) {
         if (t.numel < 0 || (t.numel > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq))) {
             emd_set_error("adam_step: tensor %d has a null pointer or a negative size", i); return EMD_ERR_INVALID;
         }
-        if (!(t.bias_correction2_sqrt > 0.f)) { emd_set_error("adam_step: tensor %d: bias_correction2_sqrt must be > 0", i); return EMD_ERR_INVALID; }
+        if (t.step_dev && !t.lr_dev) { emd_set_error("adam_step: tensor %d: step_dev needs lr_dev", i); return EMD_ERR_INVALID; }
+        if (!t.step_dev && !(t.bias_correction2_sqrt > 0.f)) { emd_set_error("adam_step: tensor %d: bias_correction2_sqrt must be > 0", i); return EMD_ERR_INVALID; }
         L.first_block[i] = (uint32_t)blocks;
         blocks += (uint64_t)((t.numel + ADAM_CHUNK - 1) / ADAM_CHUNK);
     }

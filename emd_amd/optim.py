@@ -6,6 +6,8 @@ groups (S3Gaussian/scene/gaussian_model.py:188-201; OmniRe/models/trainers/base.
 (`update_learning_rate`, gaussian_model.py:224-243), its densification surgery on the optimiser state (`_prune_optimizer`,
 `cat_tensors_to_optimizer`, `replace_tensor_to_optimizer`, :470-556) and its checkpoints (`optimizer.state_dict()`, :74-118)
 work unchanged.  `step()` is one HIP launch for every 32 tensors (`emd_adam_step`) instead of ~10 passes per group.
+`capturable=True` (torch.optim.Adam's flag of the same name): the step counts and the groups' learning rates live on the device and the
+kernel forms the bias corrections itself, so a `step()` recorded into a hipGraph replays correctly (`push_lrs()` uploads changed rates).
 `expon_lr` restates the schedule helper (S3Gaussian/utils/general_utils.py:196-229).  No CPU path."""
 import ctypes as C
 import math
@@ -30,10 +32,38 @@ def expon_lr(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, capturable=False):
         if weight_decay != 0 or amsgrad:
             raise NotImplementedError("the reference uses plain Adam (no weight decay, no amsgrad)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+        self.capturable = bool(capturable)
+        self._step_buf = None          # capturable: one device float per parameter, incremented by ONE launch per step
+        self._lr_dev = {}              # capturable: one device float per group
+
+    def _capturable_state(self):
+        """Device-resident step counts (views of one buffer: a single add advances them all) and learning rates."""
+        plist = [p for g in self.param_groups for p in g["params"]]
+        dev = plist[0].device
+        if self._step_buf is None or self._step_buf.numel() != len(plist) or self._step_buf.device != dev:
+            old = [float(self.state[p]["step"]) if p in self.state and "step" in self.state[p] else 0.0 for p in plist]
+            self._step_buf = torch.tensor(old, dtype=torch.float32, device=dev)
+        for i, p in enumerate(plist):
+            st = self.state[p]
+            if len(st) == 0:
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] = self._step_buf[i]
+        for gi, g in enumerate(self.param_groups):
+            if gi not in self._lr_dev or self._lr_dev[gi].device != dev:
+                self._lr_dev[gi] = torch.full((1,), float(g["lr"]), dtype=torch.float32, device=dev)
+
+    def push_lrs(self):
+        """capturable: upload the groups' current learning rates (call after changing `param_groups[i]["lr"]`, outside a capture)."""
+        if not self.capturable:
+            return
+        self._capturable_state()
+        for gi, g in enumerate(self.param_groups):
+            self._lr_dev[gi].fill_(float(g["lr"]))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -43,6 +73,13 @@ class Adam(torch.optim.Optimizer):
                 loss = closure()
         lib = L.load()
         batch, keep = [], []
+        cap = self.capturable
+        if cap:
+            self._capturable_state()
+            if not torch.cuda.is_current_stream_capturing():
+                self.push_lrs()            # (a capture must not bake the rate of the step it was recorded at: replays read the device copy)
+            self._step_buf.add_(1.0)       # every parameter's step, one launch (parameters without a gradient this step included, like
+                                           # a fused optimiser step; the reference gives every parameter a gradient every step)
 
         def flush():
             if not batch:
@@ -52,11 +89,11 @@ class Adam(torch.optim.Optimizer):
             for i, d in enumerate(batch):
                 t = a.tensors[i]
                 (t.param, t.grad, t.exp_avg, t.exp_avg_sq, t.numel, t.step_size, t.bias_correction2_sqrt, t.one_minus_beta1, t.beta2,
-                 t.one_minus_beta2, t.eps) = d
+                 t.one_minus_beta2, t.eps, t.step_dev, t.lr_dev) = d
             L.check(lib.emd_adam_step(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_adam_step")
             batch.clear()
 
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             beta1, beta2 = group["betas"]
             for p in group["params"]:
                 if p.grad is None:
@@ -70,8 +107,11 @@ class Adam(torch.optim.Optimizer):
                     state["step"] = torch.tensor(0.0, dtype=torch.float32)
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state["step"] += 1
-                step = float(state["step"])
+                if not cap:
+                    state["step"] += 1
+                    step = float(state["step"])
+                else:
+                    step = 1.0             # (unused: the kernel reads the device copy)
                 m, v, g = state["exp_avg"], state["exp_avg_sq"], p.grad
                 # the kernel walks the four tensors as flat arrays: one memory layout for all of them
                 for name, t in (("exp_avg", m), ("exp_avg_sq", v)):
@@ -88,7 +128,8 @@ class Adam(torch.optim.Optimizer):
                 bias_correction1 = 1 - beta1 ** step
                 bias_correction2 = 1 - beta2 ** step
                 batch.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), group["lr"] / bias_correction1,
-                              math.sqrt(bias_correction2), 1 - beta1, beta2, 1 - beta2, group["eps"]))
+                              math.sqrt(bias_correction2), 1 - beta1, beta2, 1 - beta2, group["eps"],
+                              state["step"].data_ptr() if cap else None, self._lr_dev[gi].data_ptr() if cap else None))
                 if len(batch) == L.ADAM_MAX_TENSORS:
                     flush()
         flush()

@@ -721,6 +721,12 @@ typedef struct EmdAdamTensor {
     float* exp_avg_sq;
     int64_t numel;
     float step_size, bias_correction2_sqrt, one_minus_beta1, beta2, one_minus_beta2, eps;
+    /* ABI 20, optional ("capturable" steps: an optimiser step recorded into a hipGraph must not bake the step count or the learning rate
+     * into its launch): with step_dev != NULL the kernel forms step_size = lr_dev[0] / (1 - beta1^t) and bias_correction2_sqrt =
+     * sqrt(1 - beta2^t) itself from t = step_dev[0] (the step count AFTER this step's increment, a device float as torch's capturable
+     * Adam keeps it) and ignores the two by-value fields; lr_dev must then be non-NULL too. */
+    const float* step_dev;
+    const float* lr_dev;
 } EmdAdamTensor;
 
 typedef struct EmdAdamArgs {

@@ -139,3 +139,63 @@ def test_adam_full_size_against_torch():
     d = (a.detach() - b.detach()).abs().max()
     assert float(d) <= 2e-6 * float(b.detach().abs().max()), float(d)
     assert float((o1.state[a]["exp_avg_sq"] - o2.state[b]["exp_avg_sq"]).abs().max()) <= 2e-6 * float(o2.state[b]["exp_avg_sq"].max())
+
+
+def test_capturable_adam_matches_the_host_stepped_one_and_replays_from_a_graph():
+    """capturable=True (step counts and learning rates on the device, bias corrections formed in the kernel, EmdAdamTensor.step_dev / lr_dev):
+    (a) stepped eagerly it follows torch.optim.Adam like the host-stepped optimiser does, through a learning-rate change; (b) ONE captured
+    step() replayed n times equals n eager steps of torch.optim.Adam with the same gradients -- the step count advances inside the graph and
+    a rate uploaded between replays (push_lrs) takes effect."""
+    from emd_amd.optim import Adam
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(4)
+    shapes = [(4000, 3), (4000, 16, 3), (77,), (4000, 1)]
+    base = [torch.randn(*s, generator=gen) for s in shapes]
+    mk_params = lambda: [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+    mk = lambda cls, ps, **kw: cls([{"params": ps[:2], "lr": 1e-2}, {"params": ps[2:], "lr": 3e-3, "betas": (0.8, 0.99)}], lr=0.0, eps=1e-15, **kw)
+    grads = [[(torch.randn(s, generator=gen) * 10.0 ** (k % 3 - 1)).to(dev) for s in shapes] for k in range(6)]
+    # (a) eager
+    mine, ref = mk_params(), mk_params()
+    o1, o2 = mk(Adam, mine, capturable=True), mk(torch.optim.Adam, ref)
+    for k in range(6):
+        if k == 3:
+            for o in (o1, o2):
+                o.param_groups[0]["lr"] = 2e-3
+        for a, b, g in zip(mine, ref, grads[k]):
+            a.grad, b.grad = g.clone(), g.clone()
+        o1.step(); o2.step()
+    for i, (a, b) in enumerate(zip(mine, ref)):
+        _close(a, b.detach().cpu().numpy(), f"eager param {i}")
+    assert float(o1.state[mine[0]]["step"]) == 6.0 and o1.state[mine[0]]["step"].device.type == "cuda"
+    # (b) one captured step, replayed
+    mine, ref = mk_params(), mk_params()
+    o1, o2 = mk(Adam, mine, capturable=True), mk(torch.optim.Adam, ref)
+    static_g = [torch.zeros_like(p) for p in mine]
+    for a, g in zip(mine, static_g):
+        a.grad = g
+    for b in ref:
+        b.grad = torch.zeros_like(b)
+    o1._capturable_state()                 # state tensors are allocated outside the capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            o1.step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    # (the capture itself executed nothing: the parameters and the step counts are untouched)
+    assert float(o1.state[mine[0]]["step"]) == 0.0 and torch.equal(mine[0].detach().cpu(), base[0])
+    for k in range(6):
+        if k == 3:
+            o1.param_groups[1]["lr"] = o2.param_groups[1]["lr"] = 1e-3
+            o1.push_lrs()
+        for sg, b, g in zip(static_g, ref, grads[k]):
+            sg.copy_(g)
+            b.grad.copy_(g)
+        graph.replay()
+        o2.step()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(mine, ref)):
+        _close(a, b.detach().cpu().numpy(), f"replayed param {i}")
+    assert float(o1.state[mine[0]]["step"]) == 6.0
