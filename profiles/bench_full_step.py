@@ -122,34 +122,23 @@ torch.cuda.synchronize()
 K_STEPS = 50
 graphs = None
 if "--graph" in sys.argv:
-    import gc
+    from emd_amd.graphs import StepGraphs
     from emd_amd.sky import _camera_rays_params
-    for f in range(F):                      # host-side per-camera constants (a device-to-host copy each) are formed before capture
-        _camera_rays_params(skycams[f])
-    if FINE:                                # the cached visiting orders must not be refreshed (re-allocated) inside a capture: their memory
-        deform.deformation_net.grid.reorder_every = 1 << 60      # would belong to that graph's pool and be recycled by the next one
-    if optimizer is not None and hasattr(optimizer, "_capturable_state"):
-        optimizer._capturable_state()      # the optimiser's state tensors exist before the first capture
     step(0)
     torch.cuda.synchronize()
     want = {"xyz": model._xyz.grad.clone()}
     if FINE:
         want["grid"] = deform.deformation_net.grid.grids[-1][0].grad.clone()
-    gc.collect()                            # no autograd graph of an eager step may be alive at capture time (bench.py)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    graphs, pool = [], None
-    with torch.cuda.stream(side):
-        for f in range(F):
-            g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_, pool=pool, stream=side):
-                step(f)
-            pool = g_.pool()
-            graphs.append(g_)
-            if f == 0:                      # graph 0's gradient tensors stay referenced for the self-check below (the later graphs
-                keep0 = {"xyz": model._xyz.grad, "grid": deform.deformation_net.grid.grids[-1][0].grad if FINE else None}   # recycle everything else)
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
+    keep0 = {}
+
+    def recorded(f):
+        step(f)
+        if f == 0:                          # graph 0's gradient tensors stay referenced for the self-check below (the later graphs
+            keep0["xyz"] = model._xyz.grad  # recycle everything else)
+            keep0["grid"] = deform.deformation_net.grid.grids[-1][0].grad if FINE else None
+    sg = StepGraphs(recorded, range(F), prime=lambda f: _camera_rays_params(skycams[f]), freeze=[deform.deformation_net.grid] if FINE else [],
+                    optimizers=[optimizer] if optimizer is not None else [], warmup=0)
+    graphs = [sg.graphs[f] for f in range(F)]
     # self-check: the replay of frame 0 against the eager step of frame 0 (densification statistics accumulate: compare the increment)
     graphs[0].replay()
     torch.cuda.synchronize()

@@ -220,3 +220,103 @@ def test_fused_sh_residuals_and_regulariser_equal_the_reference_formulation():
         assert (a_ is None) == (b_ is None)
         if a_ is not None:
             assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(b_.abs().max()), 1e-20), tuple(p.shape)
+
+
+def test_step_graphs_replay_the_fine_stage_step_per_frame():
+    """emd_amd.graphs.StepGraphs: one hipGraph per frame of a fine-stage step (deformation network -> rasterizer -> sky blend -> loss -> backward
+    -> densification statistics -> capturable Adam), all in one pool.  (a) Without the optimiser every replay leaves the gradients of the eager
+    step of ITS frame; (b) with it, a sequence of replays follows the same sequence of eager steps."""
+    import copy
+    import types
+    from emd_amd import RasterOptions, dp, scenes
+    from emd_amd.deformation import DeformOptions, deform_network
+    from emd_amd.graphs import StepGraphs
+    from emd_amd.loss import image_loss
+    from emd_amd.model import StreetGaussians, abs_mean, render, residual_abs_mean
+    from emd_amd.optim import Adam
+    from emd_amd.sky import SkyCubeMap, _camera_rays_params, composite_s3g
+    from emd_amd import rasterizer as _rz
+    dev = torch.device("cuda", 0)
+    N, H, W, F = 12000, 64, 96, 3
+    g = torch.Generator().manual_seed(5)
+    gt, gt_depth = torch.rand(3, H, W, generator=g).to(dev), (torch.rand(1, H, W, generator=g) * 90).to(dev)
+    sky_mask = (torch.rand(1, H, W, generator=g) < 0.2).to(dev)
+    cams, skycams = {}, {}
+    for f in range(F):
+        cam = scenes.rig_camera(f, 0, H, W)
+        K = torch.tensor([[W / (2 * cam.tanfovx), 0, W / 2], [0, H / (2 * cam.tanfovy), H / 2], [0, 0, 1]], dtype=torch.float32)
+        cams[f] = cam
+        skycams[f] = types.SimpleNamespace(image_height=H, image_width=W, intrinsic=K.to(dev), world_view_transform=cam.world_view_transform.to(dev))
+
+    def build(with_adam):
+        torch.manual_seed(11)
+        model = StreetGaussians(scenes.make_static_scene(N, seed=4), dev)
+        deform = deform_network(DeformOptions()).to(dev)
+        deform.deformation_net.set_aabb([120.0, 30.0, 10.0], [0.0, -30.0, -2.0])
+        for n_, p_ in deform.named_parameters():
+            if p_.dim() > 1 and "grid" not in n_:
+                p_.data.mul_(0.05)
+        deform.deformation_net.grid.reorder_min_points = 1000          # (the aggregating HexPlane backward and its cached orders at this size)
+        emb = torch.nn.Parameter(0.1 * torch.randn(N, 4, device=dev))
+        sky = SkyCubeMap(types.SimpleNamespace(sky_resolution=64, sky_white_background=False, white_background=False), device=dev)
+        params = list(model.parameters()) + list(deform.parameters()) + [emb, sky.sky_cube_map]
+        opt = Adam([{"params": [p for p in params if p.requires_grad], "lr": 1e-3}], lr=0.0, eps=1e-15, capturable=True) if with_adam else None
+        stats = [torch.zeros(N, device=dev) for _ in range(3)]
+        opts = RasterOptions(no_sync=True)
+
+        def step(f):
+            for p in params:
+                p.grad = None
+            out = render(model, cams[f], torch.zeros(3), frame=f, deformation=deform, embeddings=emb, iteration=12000, time=f / 2.0, options=opts,
+                         need_feat=False)
+            image, _ = composite_s3g(sky, skycams[f], out["render"], out["weight"])
+            loss, _ = image_loss(image, gt, out["depth"], gt_depth, ~sky_mask, out["weight"], sky_mask)
+            for lvl in ("coarse", "fine"):
+                d = out["ddict"][lvl]
+                loss = loss + 0.001 * (abs_mean(d["dx"]) + abs_mean(d["do"]) + residual_abs_mean(d, "dshs"))
+            loss.backward()
+            dp.add_densification_stats(out["viewspace_points"].grad, out["radii"], *stats)
+            if opt is not None:
+                opt.step()
+        return model, deform, emb, sky, params, opt, stats, step
+
+    _rz._capacity_hint[(dev.index, H, W)] = 400000
+    # ---- (a) gradients of every frame's replay against the eager step of that frame
+    model, deform, emb, sky, params, opt, stats, step = build(False)
+    want = {}
+    for f in range(F):
+        step(f)
+        want[f] = [None if p.grad is None else p.grad.clone() for p in params]
+    held = {}
+
+    def recorded(f):
+        step(f)
+        held[f] = [p.grad for p in params]            # (keeps every graph's gradient tensors alive: they are compared below)
+    sg = StepGraphs(recorded, range(F), prime=lambda f: _camera_rays_params(skycams[f]), freeze=[deform.deformation_net.grid], warmup=1)
+    assert deform.deformation_net.grid.reorder_every >= 1 << 60
+    for f in (2, 0, 1, 2):
+        sg.replay(f)
+        torch.cuda.synchronize()
+        for p, got, ref in zip(params, held[f], want[f]):
+            assert (got is None) == (ref is None)
+            if got is not None:
+                assert float((got - ref).abs().max()) <= 2e-4 * max(float(ref.abs().max()), 1e-20) + 1e-12, (f, tuple(p.shape))
+    sg.release()
+    assert deform.deformation_net.grid.reorder_every < 1 << 60
+    # ---- (b) with the optimiser inside: replays follow eager steps
+    seq = [0, 1, 2, 1, 0, 2]
+    m1 = build(True)
+    for f in [0] + seq:                                   # (the recorder's one eager warm-up step of frame 0, then the sequence)
+        m1[-1](f)
+    m2 = build(True)
+    with pytest.raises(RuntimeError):                     # no eager step yet: the visiting orders would be built inside a capture
+        StepGraphs(m2[-1], range(F), prime=lambda f: _camera_rays_params(skycams[f]), freeze=[m2[1].deformation_net.grid], optimizers=[m2[5]], warmup=0)
+    sg2 = StepGraphs(m2[-1], range(F), prime=lambda f: _camera_rays_params(skycams[f]), freeze=[m2[1].deformation_net.grid], optimizers=[m2[5]], warmup=1)
+    for f in seq:
+        sg2.replay(f)
+    torch.cuda.synchronize()
+    assert float(m2[5].state[m2[0]._xyz]["step"]) == len(seq) + 1
+    for a_, b_ in zip(m1[4], m2[4]):
+        assert float((a_.detach() - b_.detach()).abs().max()) <= 1e-4 * max(float(a_.detach().abs().max()), 1e-20) + 1e-7, tuple(a_.shape)
+    with pytest.raises(ValueError):
+        StepGraphs(lambda f: None, [0], optimizers=[Adam([{"params": [m2[2]], "lr": 1e-3}], lr=0.0, eps=1e-15)], warmup=0)
