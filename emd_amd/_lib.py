@@ -178,11 +178,12 @@ class EmdMlpTrunkGrads(C.Structure):
 
 class EmdMlpBranch(C.Structure):
     _fields_ = [("num_points", C.c_int32), ("depth", C.c_int32), ("relu_input", C.c_int32), ("out_dim", C.c_int32), ("h", _f),
-                ("w_hidden", _f * 2), ("b_hidden", _f * 2), ("w_out", _f), ("b_out", _f), ("out", _f)]
+                ("w_hidden", _f * 2), ("b_hidden", _f * 2), ("w_out", _f), ("b_out", _f), ("out", _f), ("l1_sum", _f)]
 
 
 class EmdMlpBranchGrads(C.Structure):
-    _fields_ = [("g_out", _f), ("g_h", _f), ("d_w_hidden", _f * 2), ("d_b_hidden", _f * 2), ("d_w_out", _f), ("d_b_out", _f)]
+    _fields_ = [("g_out", _f), ("g_h", _f), ("d_w_hidden", _f * 2), ("d_b_hidden", _f * 2), ("d_w_out", _f), ("d_b_out", _f),
+                ("l1_grad", _f), ("out", _f)]
 
 
 ADAM_MAX_TENSORS = 32

@@ -27,6 +27,7 @@
 #include <atomic>
 
 #include "common.h"
+#include "device_utils.h"
 
 namespace {
 
@@ -315,14 +316,17 @@ __device__ __forceinline__ void branch_stage(float* lds, const EmdMlpBranch& a) 
     __syncthreads();
 }
 
-template <int DEPTH, int NTO>
-__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1) ? MLP_W_F11 : MLP_FWD_WAVES) k_mlp_branch_fwd(EmdMlpBranch a) {
+// L1: the head's regulariser mean |out| is formed beside the outputs (EmdMlpBranch.l1_sum); a separate instantiation keeps the registers of
+// the usual kernels as they were
+template <int DEPTH, int NTO, bool L1 = false>
+__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 && !L1) ? MLP_W_F11 : MLP_FWD_WAVES) k_mlp_branch_fwd(EmdMlpBranch a) {
     typedef BranchLds<DEPTH, NTO> L;
     extern __shared__ float lds[];
     branch_stage<DEPTH, NTO, false>(lds, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
     const bool wide_out = (a.out_dim & 3) == 0;
+    float l1_acc = 0.f;
     const size_t tile0 = (size_t)blockIdx.x * MLP_WAVES + wave, tstep = (size_t)gridDim.x * MLP_WAVES;
     // the next tile's rows are loaded while this tile computes: one wave per SIMD has nothing else to hide the HBM latency behind
     f32x16 nx[2] = {load_tile<true>(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 0, hh), load_tile<true>(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 32, hh)};
@@ -347,6 +351,13 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1) 
 #pragma unroll
         for (int t = 0; t < NTO; t++) o[t] = bias_tile(lds + L::bo, 32 * t, hh);
         layer_fwd<2, NTO>(o, m, lds + L::wo, WS, 0, r, hh);
+        if (L1 && a.l1_sum && ok) {                   // the head's L1 regulariser, formed while the outputs are in registers
+#pragma unroll
+            for (int t = 0; t < NTO; t++)
+#pragma unroll
+                for (int v = 0; v < 16; v++)
+                    if (32 * t + 8 * (v >> 2) + 4 * hh + (v & 3) < a.out_dim) l1_acc += fabsf(o[t][v]);
+        }
 #pragma unroll
         for (int t = 0; t < NTO; t++) {
             // (a wide tile may still hang over the row's end: out_dim = 48 -> the second tile holds features 32..47)
@@ -354,9 +365,13 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1) 
             else store_tile_narrow(a.out, a.out_dim, row, ok, 32 * t, hh, o[t]);
         }
     }
+    if (L1 && a.l1_sum) {                             // one atomic per wave: mean |out| over the N x out_dim outputs
+        const float s = wave_reduce_to_lane63(l1_acc);
+        if (lane == 63) atomicAdd(a.l1_sum, s / ((float)a.num_points * (float)a.out_dim));
+    }
 }
 
-template <int DEPTH, int NTO>
+template <int DEPTH, int NTO, bool L1 = false>
 __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_branch_bwd(EmdMlpBranch a, EmdMlpBranchGrads g) {
     typedef BranchLds<DEPTH, NTO> L;
     extern __shared__ float lds[];
@@ -375,9 +390,18 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
     for (int t = 0; t < NTO; t++) { dWo[t][0] = zero16(); dWo[t][1] = zero16(); dbo[t] = 0.f; }
 
     const size_t tile0 = (size_t)blockIdx.x * MLP_WAVES + wave, tstep = (size_t)gridDim.x * MLP_WAVES;
+    // g.l1_grad: the gradient of the head's L1 regulariser (mean |out|, EmdMlpBranch.l1_sum) joins dL/dout while it is loaded:
+    // + sign(out) l1_grad / (N out_dim); g_out itself may then be absent
+    const float l1_s = (L1 && g.l1_grad) ? g.l1_grad[0] / ((float)a.num_points * (float)a.out_dim) : 0.f;
     auto load_go = [&](size_t row_, bool ok_, int t) -> f32x16 {
-        return (wide_out && 32 * t + 32 <= a.out_dim) ? load_tile(g.g_out, a.out_dim, row_, ok_, 32 * t, hh)
-                                                      : load_tile_narrow(g.g_out, a.out_dim, row_, ok_, 32 * t, hh);
+        const bool wide = wide_out && 32 * t + 32 <= a.out_dim;
+        f32x16 v = (L1 && !g.g_out) ? zero16() : (wide ? load_tile(g.g_out, a.out_dim, row_, ok_, 32 * t, hh) : load_tile_narrow(g.g_out, a.out_dim, row_, ok_, 32 * t, hh));
+        if (L1 && g.l1_grad) {
+            const f32x16 o = wide ? load_tile(g.out, a.out_dim, row_, ok_, 32 * t, hh) : load_tile_narrow(g.out, a.out_dim, row_, ok_, 32 * t, hh);
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] += o[k] > 0.f ? l1_s : (o[k] < 0.f ? -l1_s : 0.f);      // (rows / features past the end read 0: no term)
+        }
+        return v;
     };
     // the next tile's h and g_out are loaded while this tile computes (one wave per SIMD: nothing else hides the HBM latency)
     f32x16 nh[2] = {load_tile(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 0, hh), load_tile(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 32, hh)};
@@ -754,6 +778,12 @@ extern "C" int emd_mlp_branch_forward(const EmdMlpBranch* a, void* hip_stream) {
     if (!a->out) { emd_set_error("mlp_branch_forward: null output"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     const int nto = a->out_dim > 32 ? 2 : 1;
+    if (a->l1_sum) {
+        if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1, true>, MLP_FWD_WAVES>(BranchLds<1, 1>::fwd_floats, a->num_points, st, *a);
+        if (a->depth == 1) return mlp_launch<k_mlp_branch_fwd<1, 2, true>, MLP_FWD_WAVES>(BranchLds<1, 2>::fwd_floats, a->num_points, st, *a);
+        if (nto == 1) return mlp_launch<k_mlp_branch_fwd<2, 1, true>, MLP_FWD_WAVES>(BranchLds<2, 1>::fwd_floats, a->num_points, st, *a);
+        return mlp_launch<k_mlp_branch_fwd<2, 2, true>, MLP_FWD_WAVES>(BranchLds<2, 2>::fwd_floats, a->num_points, st, *a);
+    }
     if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1>, MLP_W_F11>(BranchLds<1, 1>::fwd_floats, a->num_points, st, *a);
     if (a->depth == 1) return mlp_launch<k_mlp_branch_fwd<1, 2>, MLP_FWD_WAVES>(BranchLds<1, 2>::fwd_floats, a->num_points, st, *a);
     if (nto == 1) return mlp_launch<k_mlp_branch_fwd<2, 1>, MLP_FWD_WAVES>(BranchLds<2, 1>::fwd_floats, a->num_points, st, *a);
@@ -763,10 +793,17 @@ extern "C" int emd_mlp_branch_forward(const EmdMlpBranch* a, void* hip_stream) {
 extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranchGrads* g, void* hip_stream) {
     int rc = check_branch(a, "mlp_branch_backward");
     if (rc || a->num_points == 0) return rc;
-    if (!g || !g->g_out || !g->g_h) { emd_set_error("mlp_branch_backward: null gradient pointer"); return EMD_ERR_INVALID; }
+    if (!g || (!g->g_out && !g->l1_grad) || !g->g_h) { emd_set_error("mlp_branch_backward: null gradient pointer"); return EMD_ERR_INVALID; }
+    if (g->l1_grad && !g->out) { emd_set_error("mlp_branch_backward: l1_grad needs the forward's output tensor"); return EMD_ERR_INVALID; }
     if (((uintptr_t)g->g_h & 15)) { emd_set_error("mlp_branch_backward: g_h must be 16-byte aligned"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     const int nto = a->out_dim > 32 ? 2 : 1;
+    if (g->l1_grad) {
+        if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1, true>, MLP_BWD_WAVES>(BranchLds<1, 1>::bwd_floats, a->num_points, st, *a, *g);
+        if (a->depth == 1) return mlp_launch<k_mlp_branch_bwd<1, 2, true>, MLP_BWD_WAVES>(BranchLds<1, 2>::bwd_floats, a->num_points, st, *a, *g);
+        if (nto == 1) return mlp_launch<k_mlp_branch_bwd<2, 1, true>, MLP_BWD_WAVES>(BranchLds<2, 1>::bwd_floats, a->num_points, st, *a, *g);
+        return mlp_launch<k_mlp_branch_bwd<2, 2, true>, MLP_BWD_WAVES>(BranchLds<2, 2>::bwd_floats, a->num_points, st, *a, *g);
+    }
     if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1>, MLP_BWD_WAVES>(BranchLds<1, 1>::bwd_floats, a->num_points, st, *a, *g);
     if (a->depth == 1) return mlp_launch<k_mlp_branch_bwd<1, 2>, MLP_BWD_WAVES>(BranchLds<1, 2>::bwd_floats, a->num_points, st, *a, *g);
     if (nto == 1) return mlp_launch<k_mlp_branch_bwd<2, 1>, MLP_BWD_WAVES>(BranchLds<2, 1>::bwd_floats, a->num_points, st, *a, *g);

@@ -321,7 +321,7 @@ class Deformation(nn.Module):
     _HEADS = (("pos_deform", "no_dx", "dx"), ("scales_deform", "no_ds", "ds"), ("rotations_deform", "no_dr", "dr"),
               ("opacity_deform", "no_do", "do"), ("shs_deform", "no_dshs", "dshs"))
 
-    def _level_fused(self, pts, time_emb, embeddings, coarse, it, num_down_emb, need_feat=True):
+    def _level_fused(self, pts, time_emb, embeddings, coarse, it, num_down_emb, need_feat=True, l1_dshs=False):
         """The same level as `_feature` + `_heads`, or None when the configuration is outside what the fused kernels serve (width 64,
         defor_depth 1, at most 128 HexPlane features, an embedding of at most 8 values, at most six heads): the GEMM path then runs."""
         from . import mlp
@@ -349,24 +349,29 @@ class Deformation(nn.Module):
             bias = torch.addmv(bias, Wm[:, col:col + T], te)           # the same row for every Gaussian: a bias, not N copies
             col += T
         xa = self.grid(pts[:, :3], time_emb[:, :1]) if use_hex else None
-        outs = mlp.level_mlp(xa, embeddings if use_emb else None, Wm, bias, 0, col, branches)
+        keys = [key for _, key in heads]
+        l1_heads = [keys.index("dshs")] if (l1_dshs and "dshs" in keys) else []
+        outs = mlp.level_mlp(xa, embeddings if use_emb else None, Wm, bias, 0, col, branches, l1_heads=l1_heads)
         out = dict(dx=None, ds=None, dr=None, do=None, dshs=None, feat=None)
         for (_, key), o in zip(heads, outs):
             out[key] = o.reshape(o.shape[0], 16, 3) if key == "dshs" else o
         if feat:
-            out["feat"] = outs[-1]
+            out["feat"] = outs[len(branches) - 1]
+        if l1_heads:
+            out["dshs_abs_mean"] = outs[len(branches)]          # mean |dshs| from the head's own kernels (regulariser of train.py:238-310)
         return out
 
     def forward(self, rays_pts_emb, time_emb=None, embeddings=None, is_coarse=True, iter=None, num_down_emb_c=30, num_down_emb_f=30,
-                apply_deform=True, time_diff=1.0, is_train=False, need_feat=True):
-        """`need_feat=False` (not a reference argument): the caller will not read ddict["feat"], so the feature head is not evaluated
+                apply_deform=True, time_diff=1.0, is_train=False, need_feat=True, l1_dshs=False):
+        """`l1_dshs` (not a reference argument): on the fused kernels the level's dict also carries "dshs_abs_mean" = mean |dshs|.
+        `need_feat=False` (not a reference argument): the caller will not read ddict["feat"], so the feature head is not evaluated
         (its entry is None); the default evaluates it whenever `feat_head` is set, as the reference does."""
         if time_emb is None:
             raise NotImplementedError("forward_static (static_mlp) is outside the hot-path scope")
         if not apply_deform:
             return None
         n_rows = num_down_emb_c if is_coarse else num_down_emb_f
-        fused = self._level_fused(rays_pts_emb, time_emb, embeddings, is_coarse, iter, n_rows, need_feat)
+        fused = self._level_fused(rays_pts_emb, time_emb, embeddings, is_coarse, iter, n_rows, need_feat, l1_dshs)
         if fused is not None:
             return fused
         hidden = self._feature(rays_pts_emb, time_emb, embeddings, is_coarse, iter, n_rows)
@@ -438,18 +443,22 @@ class deform_network(nn.Module):
         direct_add_dshs; otherwise the call behaves as without the flag."""
         net = self.deformation_net
         times_sel = net.forward_time_offset(times_sel, cam_no)
+        lk = {"l1_dshs": True} if fused_shs_residuals else {}
         ddict_c = net(point, times_sel, embeddings, is_coarse=True, iter=iter, num_down_emb_c=self.min_embeddings,
-                      apply_deform=not self.no_coarse_deform, time_diff=time_diff, is_train=is_train, need_feat=need_feat)
+                      apply_deform=not self.no_coarse_deform, time_diff=time_diff, is_train=is_train, need_feat=need_feat, **lk)
         pts = point
         if not self.no_coarse_deform and self.args.apply_coarse_dx:
             pts = point + ddict_c["dx"]
         ddict_f = net(pts, times_sel, embeddings, is_coarse=False, iter=iter, num_down_emb_f=self.min_embeddings,
-                      apply_deform=not self.no_fine_deform, time_diff=time_diff, is_train=is_train, need_feat=need_feat)
+                      apply_deform=not self.no_fine_deform, time_diff=time_diff, is_train=is_train, need_feat=need_feat, **lk)
         a = self.args
         fuse = (fused_shs_residuals and shs is not None and not a.no_dshs and a.direct_add_dshs and not self.no_coarse_deform
                 and not self.no_fine_deform and ddict_c.get("dshs") is not None and ddict_f.get("dshs") is not None)
         dd = {"coarse": ddict_c, "fine": ddict_f}
-        if fuse:
+        if fuse and ddict_c.get("dshs_abs_mean") is not None and ddict_f.get("dshs_abs_mean") is not None:
+            # (the fused MLP kernels formed mean |dshs| themselves and differentiate it inside the heads' backward: nothing to add here)
+            dd["shs_residuals"] = [ddict_c["dshs"].reshape(shs.shape), ddict_f["dshs"].reshape(shs.shape)]
+        elif fuse:
             from .model import residual_pair_l1
             rc, rf, l1c, l1f = residual_pair_l1(ddict_c["dshs"].reshape(shs.shape), ddict_f["dshs"].reshape(shs.shape))
             ddict_c["dshs"], ddict_f["dshs"] = rc, rf

@@ -29,9 +29,10 @@ def eligible(ka, kb, hidden_shapes, out_dims):
 class _LevelMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, xa, xb, w0, b_eff, *params):
-        """spec = (col_a, col_b, ((relu_input, depth, out_dim), ...)); params = per branch: (w_h, b_h) x depth, w_out, b_out."""
+        """spec = (col_a, col_b, ((relu_input, depth, out_dim), ...), l1_heads); params = per branch: (w_h, b_h) x depth, w_out, b_out.
+        l1_heads: indices of the heads whose regulariser mean |out| is returned behind the outputs (formed by the head's own kernels)."""
         lib = L.load()
-        col_a, col_b, branches = spec
+        col_a, col_b, branches, l1_heads = spec
         dev = w0.device
         if dev.type != "cuda":
             raise L.EmdError("level_mlp needs tensors on a ROCm device; there is no CPU path")
@@ -46,7 +47,8 @@ class _LevelMLP(torch.autograd.Function):
         t.xa, t.xb, t.w, t.b, t.h = L.ptr(xa_c), L.ptr(xb_c), w0_c.data_ptr(), b_c.data_ptr(), h.data_ptr()
         L.check(lib.emd_mlp_trunk_forward(C.byref(t), _stream()), "emd_mlp_trunk_forward")
         outs, structs, i = [], [], 0
-        for relu_input, depth, out_dim in branches:
+        l1 = torch.zeros(max(len(l1_heads), 1), device=dev, dtype=torch.float32)
+        for k, (relu_input, depth, out_dim) in enumerate(branches):
             b = L.EmdMlpBranch()
             b.num_points, b.depth, b.relu_input, b.out_dim, b.h = N, depth, 1 if relu_input else 0, out_dim, h.data_ptr()
             for d in range(depth):
@@ -56,20 +58,26 @@ class _LevelMLP(torch.autograd.Function):
             i += 2
             out = torch.empty(N, out_dim, device=dev, dtype=torch.float32)
             b.out = out.data_ptr()
+            if k in l1_heads:
+                b.l1_sum = l1[l1_heads.index(k):].data_ptr()
             L.check(lib.emd_mlp_branch_forward(C.byref(b), _stream()), "emd_mlp_branch_forward")
             outs.append(out)
             structs.append(b)
         ctx.spec, ctx.trunk, ctx.structs, ctx.N = spec, t, structs, N
         ctx.set_materialize_grads(False)        # a head nobody uses costs no backward launch and leaves its parameters' .grad at None
         ctx.has = (xa is not None, xb is not None)
-        ctx.save_for_backward(xa_c, xb_c, w0_c, b_c, h, *params_c)
-        return tuple(outs)
+        ctx.num_params = len(params_c)
+        ctx.save_for_backward(xa_c, xb_c, w0_c, b_c, h, *params_c, *[outs[k] for k in l1_heads])
+        return tuple(outs) + tuple(l1[j] for j in range(len(l1_heads)))
 
     @staticmethod
     def backward(ctx, *g_outs):
         lib = L.load()
-        xa_c, xb_c, w0_c, b_c, h, *params_c = ctx.saved_tensors
-        col_a, col_b, branches = ctx.spec
+        xa_c, xb_c, w0_c, b_c, h, *rest = ctx.saved_tensors
+        params_c, l1_outs = rest[:ctx.num_params], rest[ctx.num_params:]
+        col_a, col_b, branches, l1_heads = ctx.spec
+        g_l1 = g_outs[len(branches):]
+        g_outs = g_outs[:len(branches)]
         N, dev = ctx.N, w0_c.device
         # every accumulated gradient is carved from ONE zero-filled allocation
         sizes = [w0_c.numel(), b_c.numel()] + [p.numel() for p in params_c]
@@ -79,15 +87,23 @@ class _LevelMLP(torch.autograd.Function):
         d_params = [p.view_as(q) for p, q in zip(parts[2:], params_c)]
         g_hs, i = [], 0
         unused = set()               # parameters of heads whose output received no gradient: their gradient is None, as autograd would leave it
-        for (relu_input, depth, out_dim), b, g_out in zip(branches, ctx.structs, g_outs):
+        keep = []
+        for k, ((relu_input, depth, out_dim), b, g_out) in enumerate(zip(branches, ctx.structs, g_outs)):
             n_par = 2 * depth + 2
-            if g_out is None:
+            gl = g_l1[l1_heads.index(k)] if k in l1_heads else None        # gradient of the head's mean |out|: folded into g_out by the kernel
+            if g_out is None and gl is None:
                 unused.update(range(i, i + n_par))
-            if g_out is not None:
-                g_out = g_out.contiguous().float()
+            else:
                 g = L.EmdMlpBranchGrads()
                 g_h = torch.empty(N, WIDTH, device=dev, dtype=torch.float32)
-                g.g_out, g.g_h = g_out.data_ptr(), g_h.data_ptr()
+                if g_out is not None:
+                    g_out = g_out.contiguous().float()
+                    g.g_out = g_out.data_ptr()
+                if gl is not None:
+                    gl = gl.detach().reshape(1).float().contiguous()
+                    keep.append(gl)
+                    g.l1_grad, g.out = gl.data_ptr(), l1_outs[l1_heads.index(k)].data_ptr()
+                g.g_h = g_h.data_ptr()
                 for d in range(depth):
                     g.d_w_hidden[d], g.d_b_hidden[d] = d_params[i + 2 * d].data_ptr(), d_params[i + 2 * d + 1].data_ptr()
                 g.d_w_out, g.d_b_out = d_params[i + 2 * depth].data_ptr(), d_params[i + 2 * depth + 1].data_ptr()
@@ -111,8 +127,10 @@ class _LevelMLP(torch.autograd.Function):
         return (None, d_xa, d_xb, d_w0, d_b, *[None if k in unused else p for k, p in enumerate(d_params)])
 
 
-def level_mlp(xa, xb, w0, b_eff, col_a, col_b, branches):
-    """`branches`: list of (relu_input, [(w_hidden, b_hidden), ...], (w_out, b_out)); returns the list of head outputs [N, out_dim].
+def level_mlp(xa, xb, w0, b_eff, col_a, col_b, branches, l1_heads=()):
+    """`branches`: list of (relu_input, [(w_hidden, b_hidden), ...], (w_out, b_out)); returns the list of head outputs [N, out_dim]
+    followed, for every index in `l1_heads`, by that head's mean |out| (a 0-d tensor: the L1 regulariser of a residual head,
+    S3Gaussian/train.py:238-310, formed by the head's forward kernel and differentiated inside its backward kernel).
     `xa` [N,128] or None, `xb` [N,kb <= 8] or None; `w0` is the first layer's full weight [64, ld] whose column blocks starting at
     `col_a` / `col_b` multiply xa / xb; `b_eff` [64] is its bias plus whatever is constant over the Gaussians."""
     spec, params = [], []
@@ -121,4 +139,4 @@ def level_mlp(xa, xb, w0, b_eff, col_a, col_b, branches):
         for w, b in hidden:
             params += [w, b]
         params += [w_out, b_out]
-    return list(_LevelMLP.apply((int(col_a), int(col_b), tuple(spec)), xa, xb, w0, b_eff, *params))
+    return list(_LevelMLP.apply((int(col_a), int(col_b), tuple(spec), tuple(int(k) for k in l1_heads)), xa, xb, w0, b_eff, *params))

@@ -634,6 +634,8 @@ typedef struct EmdMlpBranch {
     const float* w_out;                          /* [out_dim,64] */
     const float* b_out;                          /* [out_dim] */
     float* out;                                  /* [N,out_dim] (forward) */
+    float* l1_sum;                               /* optional (ABI 20), [1], ZEROED BY THE CALLER: the forward adds mean |out| to it -- the L1 regulariser
+                                                    of a residual head (S3Gaussian/train.py:238-310) formed while the outputs are stored */
 } EmdMlpBranch;
 
 typedef struct EmdMlpBranchGrads {
@@ -643,6 +645,10 @@ typedef struct EmdMlpBranchGrads {
     float* d_b_hidden[2];
     float* d_w_out;
     float* d_b_out;
+    /* optional (ABI 20): the gradient of l1_sum's mean |out|, folded into g_out while it is loaded: g_out[i] + sign(out[i]) l1_grad[0] / (N out_dim).
+     * `out` is the forward's output tensor; g_out may then be NULL (no other gradient reaches the head). */
+    const float* l1_grad;                        /* [1], device */
+    const float* out;                            /* [N,out_dim] */
 } EmdMlpBranchGrads;
 
 int emd_mlp_trunk_forward(const EmdMlpTrunk* args, void* hip_stream);

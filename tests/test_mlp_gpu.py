@@ -111,3 +111,44 @@ def test_unused_head_gets_no_gradient_and_costs_no_launch():
     outs[0].sum().backward()
     assert br[1][2][0].grad is None and br[1][1][0][0].grad is None          # the unused head's parameters: no gradient at all, as autograd leaves them
     assert float(br[0][2][0].grad.abs().max()) > 0.0 and xa.grad is not None
+
+
+@pytest.mark.parametrize("with_gout", [True, False])
+def test_level_mlp_head_regulariser_is_folded_into_the_head_kernels(with_gout):
+    """level_mlp(..., l1_heads=[k]): mean |out_k| comes back behind the outputs (formed by the head's forward kernel) and its gradient
+    is added to dL/dout_k inside the head's backward kernel (EmdMlpBranch.l1_sum, EmdMlpBranchGrads.l1_grad / out) -- against the same
+    level with the regulariser written as torch ops on the outputs, for a 48-wide (dshs) and a 3-wide head, with and without another
+    gradient reaching the regularised head."""
+    from emd_amd.mlp import level_mlp
+    g = torch.Generator().manual_seed(21)
+    N, ka, kb, heads = 3001, 128, 4, [(True, 1, 3), (True, 1, 48), (True, 1, 1)]
+    net = _net(g, ka, kb, heads)
+    xa, xb = torch.randn(N, ka, generator=g), torch.randn(N, kb, generator=g)
+    gouts = [torch.randn(N, o, generator=g).to(DEV) for _, _, o in heads]
+    lam = [0.7, 0.0, 1.3]
+
+    def run(folded):
+        c = lambda t: t.detach().to(DEV, torch.float32).requires_grad_(True)
+        hx, hb = c(xa), c(xb)
+        hnet = dict(w0=c(net["w0"]), b=c(net["b"]), branches=[(ri, [(c(w), c(b)) for w, b in hid], (c(wo), c(bo))) for ri, hid, (wo, bo) in net["branches"]])
+        if folded:
+            outs = level_mlp(hx, hb, hnet["w0"], hnet["b"], net["col_a"], net["col_b"], hnet["branches"], l1_heads=[1, 0])
+            assert len(outs) == 5 and outs[3].dim() == 0
+            l1_dshs, l1_dx = outs[3], outs[4]
+            outs = outs[:3]
+        else:
+            outs = level_mlp(hx, hb, hnet["w0"], hnet["b"], net["col_a"], net["col_b"], hnet["branches"])
+            l1_dshs, l1_dx = outs[1].abs().mean(), outs[0].abs().mean()
+        loss = lam[0] * l1_dshs + lam[2] * l1_dx + (outs[2] * gouts[2]).sum() + (outs[0] * gouts[0]).sum()
+        if with_gout:
+            loss = loss + (outs[1] * gouts[1]).sum()
+        loss.backward()
+        leaves = [hx, hb, hnet["w0"], hnet["b"]] + [t for _, hid, (wo, bo) in hnet["branches"] for t in [x for wb in hid for x in wb] + [wo, bo]]
+        return float(l1_dshs.detach()), float(l1_dx.detach()), [t.grad for t in leaves]
+    a1, a2, ga = run(True)
+    b1, b2, gb = run(False)
+    assert abs(a1 - b1) <= 2e-6 * abs(b1) and abs(a2 - b2) <= 2e-6 * abs(b2)
+    for k, (x, y) in enumerate(zip(ga, gb)):
+        assert (x is None) == (y is None), k
+        if x is not None:
+            assert float((x - y).abs().max()) <= 2e-5 * max(float(y.abs().max()), 1e-20), (k, float((x - y).abs().max()), float(y.abs().max()))
