@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd2(EmdHexArgs a) {
 #define HEX_AGG_POINTS 256
 #define HEX_SW 10                        /* spatial window: HEX_SW x HEX_SW cells (finer scales go through the per-plane pass) */
 #endif
-#define HEX_TW 32                        /* time-plane window: HEX_TW marginal cells, or (HEX_TW / 2) x 2 cells */
+#define HEX_TW 48                        /* time-plane window: HEX_TW marginal cells, or (HEX_TW / 2) x 2 cells (a run spans ~46 cells of a 512-cell axis) */
 #define HEX_SCELLS (HEX_SW * HEX_SW)
 #define HEX_WIN_CELLS (3 * HEX_SCELLS + 3 * HEX_TW)
 
