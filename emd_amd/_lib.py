@@ -183,7 +183,7 @@ class EmdMlpBranch(C.Structure):
 
 class EmdMlpBranchGrads(C.Structure):
     _fields_ = [("g_out", _f), ("g_h", _f), ("d_w_hidden", _f * 2), ("d_b_hidden", _f * 2), ("d_w_out", _f), ("d_b_out", _f),
-                ("l1_grad", _f), ("out", _f)]
+                ("l1_grad", _f), ("out", _f), ("g_h_in", _f)]
 
 
 ADAM_MAX_TENSORS = 32

@@ -422,6 +422,9 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
 #pragma unroll
             for (int t = 0; t < NTO; t++) ngo[t] = load_go(nrow, nrow < N, t);
         }
+        // the sum of the earlier heads' dL/dh for these rows (EmdMlpBranchGrads.g_h_in), requested now and added before the store
+        f32x16 gin[2] = {zero16(), zero16()};
+        if (DEPTH == 1 && g.g_h_in) { gin[0] = load_tile(g.g_h_in, 64, row, ok, 0, hh); gin[1] = load_tile(g.g_h_in, 64, row, ok, 32, hh); }
         f32x16 x[2] = {hin[0], hin[1]};
         if (a.relu_input) { x[0] = relu16(x[0]); x[1] = relu16(x[1]); }
         f32x16 m1[2] = {bias_tile(lds + L::b1, 0, hh), bias_tile(lds + L::b1, 32, hh)};
@@ -470,6 +473,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
         f32x16 gx[2] = {zero16(), zero16()};
         layer_fwd<2, 2>(gx, g1, lds + L::w1t, WS, 0, r, hh);
         if (a.relu_input) { gx[0] = mask16(gx[0], hin[0]); gx[1] = mask16(gx[1], hin[1]); }
+        if (DEPTH == 1 && g.g_h_in) { gx[0] += gin[0]; gx[1] += gin[1]; }     // (one-hidden-layer heads only: the other kernel has no registers left)
         store_tile(g.g_h, 64, row, ok, 0, hh, gx[0]);
         store_tile(g.g_h, 64, row, ok, 32, hh, gx[1]);
         {
@@ -794,6 +798,8 @@ extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranch
     int rc = check_branch(a, "mlp_branch_backward");
     if (rc || a->num_points == 0) return rc;
     if (!g || (!g->g_out && !g->l1_grad) || !g->g_h) { emd_set_error("mlp_branch_backward: null gradient pointer"); return EMD_ERR_INVALID; }
+    if (g->g_h_in && a->depth != 1) { emd_set_error("mlp_branch_backward: g_h_in is served for depth 1 only"); return EMD_ERR_INVALID; }
+    if (g->g_h_in && ((uintptr_t)g->g_h_in & 15)) { emd_set_error("mlp_branch_backward: g_h_in must be 16-byte aligned"); return EMD_ERR_INVALID; }
     if (g->l1_grad && !g->out) { emd_set_error("mlp_branch_backward: l1_grad needs the forward's output tensor"); return EMD_ERR_INVALID; }
     if (((uintptr_t)g->g_h & 15)) { emd_set_error("mlp_branch_backward: g_h must be 16-byte aligned"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;

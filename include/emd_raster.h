@@ -649,6 +649,10 @@ typedef struct EmdMlpBranchGrads {
      * `out` is the forward's output tensor; g_out may then be NULL (no other gradient reaches the head). */
     const float* l1_grad;                        /* [1], device */
     const float* out;                            /* [N,out_dim] */
+    /* optional (ABI 20): g_h = g_h_in + this head's contribution (g_h_in may be g_h itself: every element is read and written by the same
+     * lane).  Chaining the heads of a level through ONE buffer leaves the trunk's backward a single [N,64] tensor to read instead of one
+     * per head.  Depth 1 only (the two-hidden-layer kernel has no registers for the extra tile: EMD_ERR_INVALID). */
+    const float* g_h_in;                         /* [N,64] or NULL */
 } EmdMlpBranchGrads;
 
 int emd_mlp_trunk_forward(const EmdMlpTrunk* args, void* hip_stream);
