@@ -440,7 +440,11 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
         // ---- output layer
         f32x16 gl[2] = {zero16(), zero16()};
         if (NTO == 1 && a.out_dim <= 8) layer_fwd<NTO, 2, 1>(gl, go, lds + L::wot, L::WOT, 0, r, hh);  // dx / do / feat: one 8-feature chunk carries everything
-        else layer_fwd<NTO, 2>(gl, go, lds + L::wot, L::WOT, 0, r, hh);
+        else if (NTO == 2 && a.out_dim <= 48) {       // dshs (48 outputs): the second tile's upper two 8-feature chunks are padding
+            const f32x16 g0[1] = {go[0]}, g1[1] = {go[NTO - 1]};
+            layer_fwd<1, 2>(gl, g0, lds + L::wot, L::WOT, 0, r, hh);
+            layer_fwd<1, 2, 2>(gl, g1, lds + L::wot, L::WOT, 32, r, hh);
+        } else layer_fwd<NTO, 2>(gl, go, lds + L::wot, L::WOT, 0, r, hh);
         gl[0] = mask16(gl[0], last[0]); gl[1] = mask16(gl[1], last[1]);
         {   // dWo += go (x) last, dbo += rowsum(go)
             f32x16 af[2] = {transpose_tile(last[0], T, r, hh), transpose_tile(last[1], T, r, hh)};
