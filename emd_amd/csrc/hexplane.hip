@@ -515,9 +515,15 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
 // block instead of once per tap.  Per scale: one thread per point computes the tap (from the plane's two normalised coordinates,
 // which the main kernel left beside the rows -- no dependent gather) and the block's anchor, then lane = channel: the point's row
 // (sequential in defer_rows, all loads of a lane group in flight at once), four LDS adds, then the flush.
+#ifndef HEX_PL_THREADS
 #define HEX_PL_THREADS 512
+#endif
+#ifndef HEX_PL_POINTS
 #define HEX_PL_POINTS 256
+#endif
+#ifndef HEX_PW
 #define HEX_PW 16
+#endif
 template <int C>
 __global__ void __launch_bounds__(HEX_PL_THREADS) k_hexplane_bwd_plane(EmdHexArgs a, EmdHexGrads g) {
     constexpr int GROUPS = HEX_PL_THREADS / C, PER = HEX_PL_POINTS / GROUPS, WCELLS = HEX_PW * HEX_PW;
