@@ -182,7 +182,9 @@ class GaussianModel:
                    {"params": [self._embedding], "lr": a.feature_lr, "name": "embedding"}]
         if self._sky_model is not None:
             groups.append({"params": [self._sky_model.sky_cube_map], "lr": a.sky_cube_map_lr_init, "name": "sky_cube_map"})
-        self.optimizer = Adam(groups, lr=0.0, eps=1e-15)
+        # (`capturable_optimizer`, not a reference option: step counts and learning rates on the device, so that optimizer.step() can be part of
+        #  an iteration replayed from a hipGraph -- emd_amd.StepGraphs; update_learning_rate then also uploads the new rates)
+        self.optimizer = Adam(groups, lr=0.0, eps=1e-15, capturable=bool(getattr(a, "capturable_optimizer", False)))
         self.xyz_scheduler_args = expon_lr(a.position_lr_init * s, a.position_lr_final * s, lr_delay_mult=a.position_lr_delay_mult,
                                            max_steps=a.position_lr_max_steps)
         self.deformation_scheduler_args = expon_lr(a.deformation_lr_init * s, a.deformation_lr_final * s,
@@ -192,6 +194,13 @@ class GaussianModel:
         self.sky_cube_map_scheduler_args = expon_lr(a.sky_cube_map_lr_init, a.sky_cube_map_lr_final, max_steps=a.sky_cube_map_max_steps)
 
     def update_learning_rate(self, iteration):
+        try:
+            return self._update_learning_rate(iteration)
+        finally:
+            if getattr(self.optimizer, "capturable", False):
+                self.optimizer.push_lrs()
+
+    def _update_learning_rate(self, iteration):
         lr_pos = None
         for g in self.optimizer.param_groups:
             if g["name"] == "xyz":

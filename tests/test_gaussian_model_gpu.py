@@ -200,3 +200,77 @@ def test_ply_and_checkpoint_round_trip(tmp_path):
         assert torch.equal(p.detach(), q.detach())
         assert torch.equal(m3.optimizer.state[p]["exp_avg"], m.optimizer.state[q]["exp_avg"])
     assert torch.equal(m3.xyz_gradient_accum, m.xyz_gradient_accum)
+
+
+def test_graph_replayed_training_loop_with_density_control():
+    """The same unattended loop with every iteration REPLAYED from a hipGraph (emd_amd.StepGraphs: render -> L1 -> backward -> statistics ->
+    capturable Adam recorded once), learning rates uploaded by update_learning_rate, and the graphs released and recorded again around
+    every densification / prune / opacity reset (the point count and the parameter tensors change there).  The optimiser's step counts
+    and moments survive the surgery, the point count moves, the loss falls."""
+    from emd_amd import GaussianRasterizationSettings, GaussianRasterizer, RasterOptions, StepGraphs, scenes
+    from emd_amd import rasterizer as _rz
+    from emd_amd.gaussian_model import GaussianModel
+    from emd_amd.model import l1_loss
+    torch.manual_seed(0)
+    H, W, N = 96, 128, 6000
+    sc = scenes.make_static_scene(N, seed=3)
+    cam = scenes.small_camera(H, W)
+    means = sc.means.clone()
+    means[:, 0] = means[:, 0] * 0.25 + 1.0
+    means[:, 1] *= 0.3
+    means[:, 2] = means[:, 2] * 0.3 + 1.0
+    m = GaussianModel(device=DEV, densify_seed=1)
+    m.create_from_tensors(means, torch.rand(N, 3), sc.log_scales + 1.0, spatial_lr_scale=1.0)
+    m.active_sh_degree = 3
+    m.training_setup(_train_args(position_lr_init=1.6e-3, capturable_optimizer=True))
+    assert m.optimizer.capturable
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(9)).to(DEV) * 0.5 + 0.25
+    rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, torch.zeros(3, device=DEV), 1.0, cam.world_view_transform.to(DEV),
+                                       cam.full_proj_transform.to(DEV), 3, cam.camera_center.to(DEV), False, False)
+    opts = RasterOptions(compute_normal=False, no_sync=True)
+    _rz._capacity_hint[(DEV.index, H, W)] = 3_000_000
+    loss_buf = torch.zeros((), device=DEV)
+    state = {}
+
+    def iteration(_key):
+        m.optimizer.zero_grad(set_to_none=True)
+        sp = state["sp"]
+        sp.grad = None
+        img, _, _, _, radii, _ = GaussianRasterizer(rs, options=opts)(means3D=m._xyz, means2D=sp, shs=m.get_features, opacities=m._opacity,
+                                                                      scales=m._scaling, rotations=m._rotation, raw_params=True)
+        loss = l1_loss(img, target)
+        loss.backward()
+        with torch.no_grad():
+            m.add_densification_stats(sp.grad, radii)
+            m.optimizer.step()
+            loss_buf.copy_(loss.detach())
+
+    def record():
+        state["sp"] = torch.zeros_like(m._xyz, requires_grad=True)
+        return StepGraphs(iteration, [0], optimizers=[m.optimizer], warmup=1)       # (one eager iteration, then the recording)
+    graphs = record()
+    counts, losses, it = [m._xyz.shape[0]], [], 1
+    while it <= 200:
+        m.update_learning_rate(it)                 # host-side schedule -> the groups' device-resident rates
+        graphs.replay(0)
+        losses.append(loss_buf.clone())
+        it += 1
+        if it % 50 == 0 or it == 150:
+            graphs.release()
+            with torch.no_grad():
+                if it % 50 == 0:
+                    m.densify(2e-4, 0.005, 4.0, None)
+                if it % 100 == 0:
+                    m.prune(2e-4, 0.005, 4.0, 20)
+                if it == 150:
+                    m.reset_opacity()
+            graphs = record()
+            it += 1                                # (the recorder's eager iteration)
+        counts.append(m._xyz.shape[0])
+    losses = [float(x) for x in losses]
+    assert len(set(counts)) >= 3, counts[::25]
+    assert all(np.isfinite(losses)) and np.mean(losses[-10:]) < np.mean(losses[:10])
+    st = m.optimizer.state[m._xyz]
+    assert st["exp_avg"].shape == m._xyz.shape and st["step"].device.type == "cuda" and float(st["step"]) >= 195.0
+    lr_dev = float(m.optimizer._lr_dev[0])
+    assert abs(lr_dev - m.optimizer.param_groups[0]["lr"]) <= 1e-9 + 1e-6 * lr_dev      # the schedule reached the device copy
