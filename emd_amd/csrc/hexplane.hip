@@ -70,7 +70,7 @@ __device__ __forceinline__ void pair_axes(int p, int& a, int& b) {
     a = A[p]; b = B[p];
 }
 
-// element offset of tap (x, y), channel c, in a channel-last plane (32-bit: a plane holds < 2^31 floats, checked on the host)
+// element offset of tap (x, y), channel c, in a channel-last plane (32-bit: a plane holds < 2^30 floats, checked on the host)
 __device__ __forceinline__ uint32_t tap_at(int x, int y, int W, int C, int c) { return ((uint32_t)y * (uint32_t)W + (uint32_t)x) * (uint32_t)C + (uint32_t)c; }
 
 __device__ __forceinline__ float sample(const float* __restrict__ pl, const Bilin& t, int W, int C, int c) {
@@ -203,8 +203,12 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd2(EmdHexArgs a) {
             for (int p = 0; p < 6; p++) {
                 const uint4 o = s_off[j * 6 + p];
                 const float4 w = s_w[j * 6 + p];
-                const float* __restrict__ pl = a.planes[s][p] + c;
-                prod = prod * (pl[o.x] * w.x + pl[o.y] * w.y + pl[o.z] * w.z + pl[o.w] * w.w);
+                // uniform plane base + 32-bit byte offsets (the saddr form: no 64-bit address arithmetic per tap; planes of 2^30 floats or more
+                // are refused by check_hex)
+                const char* __restrict__ pl = (const char*)a.planes[s][p];
+                const uint32_t cb = (uint32_t)c << 2;
+                prod = prod * (*(const float*)(pl + ((o.x << 2) + cb)) * w.x + *(const float*)(pl + ((o.y << 2) + cb)) * w.y +
+                               *(const float*)(pl + ((o.z << 2) + cb)) * w.z + *(const float*)(pl + ((o.w << 2) + cb)) * w.w);
             }
             a.out[(size_t)s_n[j] * (S * C) + s * C + c] = prod;
         }
@@ -622,8 +626,8 @@ int check_hex(const EmdHexArgs* a, const char* who) {
             if (!a->planes[s][p]) { emd_set_error("%s: plane %d of scale %d is null", who, p, s); return EMD_ERR_INVALID; }
             if (a->res[s][0] < 1 || a->res[s][1] < 1 || a->res[s][2] < 1 || a->res[s][3] < 1) { emd_set_error("%s: bad resolution", who); return EMD_ERR_INVALID; }
             const int A_[6] = {0, 0, 0, 1, 1, 2}, B_[6] = {1, 2, 3, 2, 3, 3};
-            if ((int64_t)a->res[s][A_[p]] * a->res[s][B_[p]] * C >= ((int64_t)1 << 31)) {       // the kernels index a plane with 32 bits
-                emd_set_error("%s: plane %d of scale %d holds 2^31 floats or more", who, p, s); return EMD_ERR_INVALID;
+            if ((int64_t)a->res[s][A_[p]] * a->res[s][B_[p]] * C >= ((int64_t)1 << 30)) {       // the kernels address a plane with 32-bit BYTE offsets
+                emd_set_error("%s: plane %d of scale %d holds 2^30 floats or more", who, p, s); return EMD_ERR_INVALID;
             }
         }
     return EMD_OK;
