@@ -462,8 +462,15 @@ class _Rasterize(torch.autograd.Function):
         if rec.on_backward is not None:
             rec.on_backward(rec)
         d_x = d_extra + [None] * (2 - nx)
-        # (the residuals of the SH coefficients enter as a sum: each receives dL/dshs itself -- the same tensor, no copy)
-        d_r0, d_r1 = (d_shs if ctx.has_shs_res[0] else None), (d_shs if ctx.has_shs_res[1] else None)
+        # (the residuals of the SH coefficients enter as a sum: each receives dL/dshs itself -- the same memory, no copy; as VIEWS, because
+        #  autograd's AccumulateGrad clones a gradient whose tensor object is referenced more than once instead of adopting it: handing the
+        #  one object to three inputs cost the leaf `shs` a 384 MB copy per step)
+        d_r0 = d_r1 = None
+        if d_shs is not None and any(ctx.has_shs_res):
+            # a second tensor object over the same storage WITHOUT a base relation (a .view() keeps its base referenced): the leaf's
+            # gradient object then has a single owner and is adopted, not cloned
+            alias = torch.empty(0, device=d_shs.device, dtype=d_shs.dtype).set_(d_shs.untyped_storage(), d_shs.storage_offset(), d_shs.shape, d_shs.stride())
+            d_r0, d_r1 = (alias if ctx.has_shs_res[0] else None), (alias if ctx.has_shs_res[1] else None)
         return (d_means3D, d_means2D, d_shs, d_col, d_op, d_sc, d_rot, d_cov, d_pose, d_rdx, d_rdq, None, None, None, None, None, d_x[0], d_x[1],
                 d_r0, d_r1)
 
