@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16
@@ -21,6 +21,7 @@ EMD_OK, EMD_ERR_INVALID, EMD_ERR_CAPACITY, EMD_ERR_HIP, EMD_ERR_WORKSPACE, EMD_E
 FLAG_NORMAL, FLAG_MOTION, FLAG_ABSGRAD, FLAG_NO_SYNC, FLAG_CLAMP_RGB01, FLAG_RAW_PARAMS, FLAG_SDEV_TANFOV = 1, 2, 4, 8, 16, 32, 64
 FLAG_WIDE_DEPTH_SORT = 128
 FLAG_BWD_WS_CLEAN = 256
+FLAG_KEEP_ALL_PAIRS = 512
 
 _f = C.c_void_p  # device pointers are passed as integers
 
@@ -242,7 +243,7 @@ def load():
     lib.emd_raster_forward.argtypes = [C.POINTER(EmdFwdArgs), C.c_void_p]
     lib.emd_raster_backward.argtypes = [C.POINTER(EmdBwdArgs), C.c_void_p]
     lib.emd_raster_export_binning.argtypes = [C.POINTER(EmdDims), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
-                                              C.c_void_p, C.c_void_p, C.c_void_p]
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_raster_export_geometry.argtypes = [C.POINTER(EmdDims), C.c_void_p, C.c_size_t] + [C.c_void_p] * 7
     lib.emd_motion_forward.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(EmdMotion),
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -229,6 +229,7 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
     }
     if ((a->flags & EMD_FLAG_NORMAL) && !a->out_normal) { emd_set_error("forward: EMD_FLAG_NORMAL without out_normal"); return EMD_ERR_INVALID; }
     if (a->bin_capacity < 0) { emd_set_error("forward: negative bin_capacity"); return EMD_ERR_INVALID; }
+    if ((int64_t)N >= (int64_t)1 << 28) { emd_set_error("forward: %d Gaussians; a list word holds a 28-bit Gaussian id beside the pair's quadrant mask", N); return EMD_ERR_INVALID; }
     if (a->num_extra < 0 || a->num_extra > EMD_MAX_EXTRA) { emd_set_error("forward: num_extra %d not in 0..%d", a->num_extra, EMD_MAX_EXTRA); return EMD_ERR_INVALID; }
     for (int k = 0; k < a->num_extra; k++)
         if (!a->colors_extra[k] || !a->out_extra[k]) { emd_set_error("forward: extra colour set %d: null colours / output", k); return EMD_ERR_INVALID; }
@@ -392,7 +393,8 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
 }
 
 int emd_raster_export_binning(const EmdDims* dims, const void* geom_ws, size_t geom_bytes, const void* bin_ws, size_t bin_bytes,
-                              int64_t num_rendered, uint64_t* keys, uint32_t* ids, uint32_t* ranges, void* hip_stream) {
+                              int64_t num_rendered, uint64_t* keys, uint32_t* ids, uint32_t* ranges, uint32_t* quad_masks,
+                              void* hip_stream) {
     if (!dims || !bin_ws || !geom_ws) { emd_set_error("export_binning: null argument"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     const int gx = (dims->image_width + EMD_TILE_X - 1) / EMD_TILE_X, gy = (dims->image_height + EMD_TILE_Y - 1) / EMD_TILE_Y;
@@ -401,8 +403,7 @@ int emd_raster_export_binning(const EmdDims* dims, const void* geom_ws, size_t g
     emd_carve_bin((void*)bin_ws, dims->bin_capacity, gx * gy, &b);
     if (g.bytes > geom_bytes || b.bytes > bin_bytes || num_rendered > dims->bin_capacity || num_rendered < 0) { emd_set_error("export_binning: bad sizes"); return EMD_ERR_WORKSPACE; }
     // the sort moves (tile id, Gaussian id) pairs; upstream's 64-bit key is tile id << 32 | depth bits of the Gaussian
-    if (keys && num_rendered) { int rc = emd_launch_export_keys(num_rendered, g, b, keys, st); if (rc) return rc; }
-    if (ids && num_rendered) EMD_HIP_CHECK(hipMemcpyAsync(ids, b.vals[b.sorted_buf], (size_t)num_rendered * 4, hipMemcpyDeviceToDevice, st));
+    if ((keys || ids || quad_masks) && num_rendered) { int rc = emd_launch_export_keys(num_rendered, g, b, keys, ids, quad_masks, st); if (rc) return rc; }
     if (ranges) EMD_HIP_CHECK(hipMemcpyAsync(ranges, b.ranges, (size_t)gx * gy * 8, hipMemcpyDeviceToDevice, st));
     return EMD_OK;
 }

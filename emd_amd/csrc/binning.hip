@@ -31,6 +31,7 @@
 
 #include "common.h"
 #include "device_utils.h"
+#include "footprint.h"       // (EMD_ID_BITS: the quadrant mask rides above the 28-bit Gaussian id of a list word)
 
 namespace {
 
@@ -52,21 +53,20 @@ __device__ __forceinline__ uint32_t sort_n(const SortN& c) {
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32_t* __restrict__ num_sorted,
                                                              const uint32_t* __restrict__ perm,
-                                                             const uint2* __restrict__ binrec,
-                                                             uint32_t* __restrict__ rect_s, uint32_t* __restrict__ cnt_s,
-                                                             uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_vis,
+                                                             const uint4* __restrict__ binrec,
+                                                             uint4* __restrict__ bin_s,
+                                                             uint32_t* __restrict__ block_sums,
                                                              uint32_t* __restrict__ ranges, uint32_t n_ranges) {
     __shared__ uint32_t s_scan[4];
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
-    uint2 br = make_uint2(0u, 0u);
+    uint4 br = make_uint4(0u, 0u, 0u, 0u);
     if (i < N && (uint32_t)i < *num_sorted) br = binrec[perm[i]];         // the depth sort kept the V visible Gaussians only
-    if (i < N) { rect_s[i] = br.x; cnt_s[i] = br.y; }
+    if (i < N) bin_s[i] = br;
     // empty tiles keep the range (0, 0): cleared here instead of by a separate memset launch
     for (uint32_t r = (uint32_t)i; r < n_ranges; r += gridDim.x * EMD_BLOCK) ranges[r] = 0u;
-    uint32_t total, vis;
-    block_scan_add_u32(br.y, s_scan, &total);
-    block_scan_add_u32(br.y ? 1u : 0u, s_scan, &vis);
-    if (threadIdx.x == 0) { block_sums[blockIdx.x] = total; block_vis[blockIdx.x] = vis; }
+    uint32_t total;
+    block_scan_add_u32(br.y & 0xFFFFFu, s_scan, &total);                  // pairs this Gaussian emits
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
 // Single workgroup: inclusive scan of the per-block tile counts in place, D / overflow / V into the status word, and for
@@ -74,20 +74,19 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32
 #define DUP_SLOTS EMD_SORT_TILE
 #define PUB_THREADS 1024
 #define PUB_ITEMS 8
-__global__ void __launch_bounds__(PUB_THREADS) k_scan_publish(uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ block_vis,
+__global__ void __launch_bounds__(PUB_THREADS) k_scan_publish(uint32_t* __restrict__ block_sums,
                                                               uint32_t nb, uint64_t capacity, EmdStatus* __restrict__ status,
                                                               uint32_t* __restrict__ slot_start, uint32_t n_slot_blocks) {
     // 1024 threads x 8 values: the 7812 block totals of a 2 M scene are ONE trip (the 256-thread version walked them in 8
     // dependent trips of load -> scan -> store, 15 us on the critical path of every forward)
     __shared__ uint32_t s_w[PUB_THREADS / 64];
-    uint32_t carry = 0, vis = 0;
+    uint32_t carry = 0;
     for (uint32_t base = 0; base < nb; base += PUB_THREADS * PUB_ITEMS) {
         const uint32_t i0 = base + threadIdx.x * PUB_ITEMS;
         uint32_t v[PUB_ITEMS], sum = 0;
 #pragma unroll
         for (int k = 0; k < PUB_ITEMS; k++) {
             v[k] = (i0 + k < nb) ? block_sums[i0 + k] : 0u;
-            vis += (i0 + k < nb) ? block_vis[i0 + k] : 0u;
             sum += v[k];
         }
         const uint32_t inc = wave_scan_add_u32(sum);
@@ -110,17 +109,10 @@ __global__ void __launch_bounds__(PUB_THREADS) k_scan_publish(uint32_t* __restri
         }
         carry += total;
     }
-    // visible count: wave sums, then the 16 partials
-    const uint32_t vinc = wave_scan_add_u32(vis);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = vinc;
-    __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t vtot = 0;
-        for (uint32_t w = 0; w < PUB_THREADS / 64; w++) vtot += s_w[w];
         status->num_rendered = carry;
         status->overflow = (status->overflow & 2u) | (((uint64_t)carry > capacity) ? 1u : 0u);     // bit 1: depth range (set by the depth sort)
-        status->num_visible = vtot;
+        status->num_visible = status->reserved;          // V: the Gaussians the compacting first depth pass kept (radii > 0)
     }
 }
 
@@ -134,8 +126,19 @@ __global__ void __launch_bounds__(PUB_THREADS) k_scan_publish(uint32_t* __restri
 // An output block of 2048 slots IS a block of the first tile-sort pass, so the digit histogram of that pass is built here, from
 // the tile ids while they are in registers (hist0: [bin][block], bin-major over the capacity block count): the pass's own
 // histogram launch (a second read of all D tile ids) is gone.
-__global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const uint32_t* __restrict__ rect_s,
-                                                         const uint32_t* __restrict__ cnt_s,
+//
+// Round 4: the rectangle a Gaussian enumerates is no longer upstream's 3-sigma square of the LARGEST eigenvalue but that square cut down
+// to the tiles its alpha >= 1/255 bounding box reaches (K1, preprocess.hip): on street scenes -- elongated, often faint footprints -- 25 %
+// of upstream's (tile, Gaussian) pairs lie outside that box (31 % reach no pixel of their tile at all: tests/analysis/pair_stats.py), and
+// everything from here on -- this kernel, both tile passes, the range kernel, the list scans of the render forward -- shrinks with them.
+// Images, radii and gradients are unchanged bit for bit: a pair that is left out is one upstream's render loop skips at every pixel of
+// the tile (its alpha < 1/255 `continue`).  EMD_FLAG_KEEP_ALL_PAIRS restores upstream's list entry for entry.
+// The same box gives every emitted pair the mask of the tile's four 8x8 quadrants that hold a pixel centre inside it (four integer
+// compares here, where the vector units idle); it rides in the top four bits of the list word, and the quadrant waves of the render
+// forward read 4 bytes per list entry and fetch the 64-byte records of their own entries only.  (Measured and dropped on the way: the
+// exact ellipse-rectangle test of footprint.h per pair in this kernel -- its inputs are a 32-byte gather per Gaussian through 128-byte
+// lines, 26 -> 67 us, whatever the arithmetic behind it costs.)
+__global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const uint4* __restrict__ bin_s,
                                                          const uint32_t* __restrict__ perm,
                                                          const uint32_t* __restrict__ block_sums_inc,
                                                          const uint32_t* __restrict__ slot_start,
@@ -146,6 +149,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
     __shared__ uint32_t s_excl[EMD_BLOCK];     // exclusive offsets inside the block
     __shared__ uint32_t s_rect[EMD_BLOCK];     // x0 | y0 << 10 | width << 20   (grid dims < 1024 tiles = 16K px)
     __shared__ uint32_t s_id[EMD_BLOCK];
+    __shared__ uint32_t s_qx[EMD_BLOCK], s_qy[EMD_BLOCK];   // first | last << 11 quadrant column / row of the alpha >= 1/255 box
     __shared__ uint32_t s_h0[EMD_BLOCK];       // digit histogram of tile pass 0 (at most 8 bits per pass)
     s_h0[threadIdx.x] = 0;
     const uint32_t D = status->overflow ? 0u : status->num_rendered;
@@ -162,12 +166,15 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
         const uint32_t end = block_sums_inc[gb];
         if (end <= S0) continue;
         const uint32_t i = gb * EMD_BLOCK + threadIdx.x;
-        const uint32_t cnt = (i < (uint32_t)N) ? cnt_s[i] : 0u;
+        const uint4 br = (i < (uint32_t)N) ? bin_s[i] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t cnt = br.y & 0xFFFFFu;
         uint32_t total;
         const uint32_t inc = block_scan_add_u32(cnt, s_scan, &total);
         s_excl[threadIdx.x] = inc - cnt;
-        s_rect[threadIdx.x] = cnt ? rect_s[i] : 0u;
+        s_rect[threadIdx.x] = br.x;
         s_id[threadIdx.x] = cnt ? perm[i] : 0u;
+        s_qx[threadIdx.x] = (br.y >> 20) | ((br.z >> 20) << 11);
+        s_qy[threadIdx.x] = br.w;
         __syncthreads();
         const uint32_t lo_slot = max(S0, base), hi_slot = min(S1, end);
         for (uint32_t eg = lo_slot + threadIdx.x; eg < hi_slot; eg += EMD_BLOCK) {
@@ -185,8 +192,13 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
             const uint32_t w = r >> 20, x0 = r & 1023u, y0 = (r >> 10) & 1023u;
             const uint32_t ty = y0 + local / w, tx = x0 + local % w;
             const uint32_t tile = ty * (uint32_t)gx + tx;
+            const uint32_t qx = s_qx[lo], qy = s_qy[lo];
+            const uint32_t lqx = qx & 2047u, hqx = qx >> 11, lqy = qy & 2047u, hqy = qy >> 11;
+            const bool xl = lqx <= 2u * tx && hqx >= 2u * tx, xr = lqx <= 2u * tx + 1u && hqx >= 2u * tx + 1u;
+            const bool yt = lqy <= 2u * ty && hqy >= 2u * ty, yb = lqy <= 2u * ty + 1u && hqy >= 2u * ty + 1u;
+            const uint32_t qm = (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
             tkeys[eg] = tile;
-            vals[eg] = s_id[lo];
+            vals[eg] = s_id[lo] | (qm << EMD_ID_BITS);
             atomicAdd(&s_h0[tile & mask0], 1u);
         }
         __syncthreads();   // LDS reused by the next block of Gaussians
@@ -427,9 +439,14 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_tile_order_identity(uint32_t T, u
 __global__ void __launch_bounds__(EMD_BLOCK) k_export_keys(size_t D, const uint32_t* __restrict__ tkeys,
                                                            const uint32_t* __restrict__ vals,
                                                            const uint32_t* __restrict__ depth_key,
-                                                           uint64_t* __restrict__ keys) {
+                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ ids,
+                                                           uint32_t* __restrict__ quad_masks) {
     const size_t i = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x;
-    if (i < D) keys[i] = ((uint64_t)tkeys[i] << 32) | depth_key[vals[i]];
+    if (i >= D) return;
+    const uint32_t w = vals[i], id = w & EMD_ID_MASK;          // (the top four bits of a list word are the pair's quadrant mask)
+    if (keys) keys[i] = ((uint64_t)tkeys[i] << 32) | depth_key[id];
+    if (ids) ids[i] = id;
+    if (quad_masks) quad_masks[i] = w >> EMD_ID_BITS;
 }
 
 // one stable LSD pass over `n_cap` (launch bound) / sort_n(cnt) (actual) pairs; `skip_hist`: the histogram was built by the producer
@@ -494,10 +511,10 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
     if (N == 0 || capacity <= 0) {
         { int zrc = emd_zero_async(b.ranges, (size_t)T * 8, st); if (zrc) return zrc; }
         if (N > 0) {   // D and V are still reported (capacity 0 is how callers size the workspace)
-            hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.rect_s, g.cnt_s,
-                               g.block_sums, g.block_vis, b.ranges, 0u);
+            hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.bin_s,
+                               g.block_sums, b.ranges, 0u);
             EMD_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(PUB_THREADS), 0, st, g.block_sums, g.block_vis, (uint32_t)nb,
+            hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(PUB_THREADS), 0, st, g.block_sums, (uint32_t)nb,
                                (uint64_t)(capacity > 0 ? capacity : 0), status, b.slot_start, 0u);
             EMD_LAUNCH_CHECK();
         }
@@ -507,15 +524,15 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
         return EMD_OK;
     }
     const uint32_t nslot = (uint32_t)(((size_t)capacity + DUP_SLOTS - 1) / DUP_SLOTS);
-    hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.rect_s, g.cnt_s,
-                       g.block_sums, g.block_vis, b.ranges, (uint32_t)(2 * T));
+    hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.bin_s,
+                       g.block_sums, b.ranges, (uint32_t)(2 * T));
     EMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(PUB_THREADS), 0, st, g.block_sums, g.block_vis, (uint32_t)nb, (uint64_t)capacity,
+    hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(PUB_THREADS), 0, st, g.block_sums, (uint32_t)nb, (uint64_t)capacity,
                        status, b.slot_start, nslot);
     EMD_LAUNCH_CHECK();
     const int passes = emd_tile_passes(T), bits = emd_tile_pass_bits(T);
     // (the duplicate kernel also builds the digit histogram of the first tile pass: its 2048-slot output blocks are that pass's blocks)
-    hipLaunchKernelGGL(k_duplicate, dim3(nslot), dim3(EMD_BLOCK), 0, st, N, gx, g.rect_s, g.cnt_s, perm, g.block_sums, b.slot_start,
+    hipLaunchKernelGGL(k_duplicate, dim3(nslot), dim3(EMD_BLOCK), 0, st, N, gx, g.bin_s, perm, g.block_sums, b.slot_start,
                        status, b.tkeys[0], b.vals[0], passes > 0 ? b.hist : nullptr, passes > 0 ? (1u << bits) - 1u : 0u, nslot);
     EMD_LAUNCH_CHECK();
     // 3. stable partition by tile id
@@ -538,10 +555,10 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
     return EMD_OK;   // PROF_RANGES is closed by the render-forward switch
 }
 
-int emd_launch_export_keys(int64_t D, const GeomWs& g, const BinWs& b, uint64_t* keys, hipStream_t st) {
+int emd_launch_export_keys(int64_t D, const GeomWs& g, const BinWs& b, uint64_t* keys, uint32_t* ids, uint32_t* quad_masks, hipStream_t st) {
     if (D <= 0) return EMD_OK;
     hipLaunchKernelGGL(k_export_keys, dim3((unsigned)((D + EMD_BLOCK - 1) / EMD_BLOCK)), dim3(EMD_BLOCK), 0, st, (size_t)D,
-                       b.tkeys[b.sorted_buf], b.vals[b.sorted_buf], g.depth_key, keys);
+                       b.tkeys[b.sorted_buf], b.vals[b.sorted_buf], g.depth_key, keys, ids, quad_masks);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

@@ -26,22 +26,22 @@ struct GeomWs {
     float4* rec;             // [N][4]
     float4* shjac;           // [N][3] d rgb_c / d (unit view direction): row c = (d/dx, d/dy, d/dz, -); written by K1 for
                              // visible Gaussians so that K8 need not re-read the 192 B of SH coefficients
-    uint2* binrec;           // [N] by Gaussian id: x = tile rectangle x0 | y0 << 10 | width << 20, y = tiles touched (K1)
+    uint4* binrec;           // [N] by Gaussian id (K1): x = ENUMERATED tile rectangle x0 | y0 << 10 | width << 20 (upstream's rectangle cut down to the
+                             //   alpha >= 1/255 box), y = pairs emitted | first quadrant column << 20, z = upstream's tiles touched | last quadrant
+                             //   column << 20, w = first | last << 11 quadrant row of that box (8-pixel units)
     uint32_t* depth_key;     // [N] by Gaussian id: float bits of the view depth, 0xFFFFFFFF when not visible (K1)
     uint32_t* gkeys[2];      // [N] ping-pong of the Gaussian depth sort
     uint32_t* gvals[2];      // [N] Gaussian ids in depth order after the sort (gvals[1])
-    uint32_t* rect_s;        // [N] tile rectangle of the Gaussians in depth order
-    uint32_t* cnt_s;         // [N] tiles touched of the Gaussians in depth order
+    uint4* bin_s;            // [N] the same records in depth order
     uint32_t* ghist;         // radix histograms of the depth sort [bins][ceil(N / sort tile)]
     uint32_t* sort_count;    // [1] visible Gaussians V: published by the first depth pass (which compacts), read by the later ones
     uint32_t* block_sums;    // [ceil(N/256)] tile counts per block of depth-ordered Gaussians, inclusive-scanned in place
-    uint32_t* block_vis;     // [ceil(N/256)] visible Gaussians per block
     size_t bytes;
 };
 
 struct BinWs {
     uint32_t* tkeys[2];      // [capacity] ping-pong: tile id of every (tile, Gaussian) pair
-    uint32_t* vals[2];       // [capacity] Gaussian id
+    uint32_t* vals[2];       // [capacity] list word: Gaussian id | quadrant mask of the pair << 28 (footprint.h)
     uint32_t* ranges;        // [T][2]
     uint32_t* tile_order;    // [T] tile ids by descending list length: dispatch order of the render kernels
     uint32_t* hist;          // radix histograms [bins][num_sort_blocks]
@@ -95,18 +95,16 @@ static inline void emd_carve_geom(void* base, int N, GeomWs* w) {
     const size_t n = (size_t)(N > 0 ? N : 1);
     w->rec = (float4*)(p + off); off = emd_align_up(off + n * EMD_REC_F4 * sizeof(float4), 256);
     w->shjac = (float4*)(p + off); off = emd_align_up(off + n * 3 * sizeof(float4), 256);
-    w->binrec = (uint2*)(p + off); off = emd_align_up(off + n * 8, 256);
+    w->binrec = (uint4*)(p + off); off = emd_align_up(off + n * 16, 256);
     w->depth_key = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256);
     for (int i = 0; i < 2; i++) { w->gkeys[i] = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256); }
     for (int i = 0; i < 2; i++) { w->gvals[i] = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256); }
-    w->rect_s = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256);
-    w->cnt_s = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256);
+    w->bin_s = (uint4*)(p + off); off = emd_align_up(off + n * 16, 256);
     size_t nsb = (n + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
     w->ghist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_DEPTH_BINS_MAX * 4, 256);
     w->sort_count = (uint32_t*)(p + off); off = emd_align_up(off + 16, 256);
     size_t nb = (n + EMD_BLOCK - 1) / EMD_BLOCK;
     w->block_sums = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 1) * 4, 256);
-    w->block_vis = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 1) * 4, 256);
     w->bytes = off + 256;
 }
 
@@ -173,7 +171,7 @@ struct PreArgs {
 int emd_launch_preprocess(const PreArgs& a, int part, hipStream_t st);       // preprocess.hip; part 0 = whole kernel, 1 = geometry half, 2 = colour half
 int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, const BinWs& b, int64_t capacity, EmdStatus* status,
                        hipStream_t st);                                       // binning.hip
-int emd_launch_export_keys(int64_t D, const GeomWs& g, const BinWs& b, uint64_t* keys, hipStream_t st);  // binning.hip
+int emd_launch_export_keys(int64_t D, const GeomWs& g, const BinWs& b, uint64_t* keys, uint32_t* ids, uint32_t* quad_masks, hipStream_t st);  // binning.hip
 // extra colour sets composited by the same list walk as the main colours (EmdFwdArgs.colors_extra ...)
 struct EmdExtra {
     int num;

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
     // the call's four status words are cleared here (the binning kernels behind this launch raise bits in them): no launch of its own
     if (PART != 2 && blockIdx.x == 0 && threadIdx.x < 4 && a.status) reinterpret_cast<uint32_t*>(a.status)[threadIdx.x] = 0u;
-    uint32_t touched = 0, rect = 0, dkey = 0xFFFFFFFFu;
+    uint32_t touched = 0, rect = 0, dkey = 0xFFFFFFFFu, emit = 0, qrange = 0, qrange_y = 0;
     int radius_out = 0;
     const float* V = S.viewmatrix;
     float m[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, op = 0.f, sc[3] = {1.f, 1.f, 1.f};
@@ -339,14 +339,42 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 int area = (x1 - x0) * (y1 - y0);
                 if (area > 0) {
                     touched = (uint32_t)area;
-                    rect = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
                     dkey = __float_as_uint(p.tz);
                     radius_out = (int)rad;
+                    // Round 4: the rectangle the binning ENUMERATES is upstream's 3-sigma square cut down to the tiles the alpha >= 1/255
+                    // ellipse of this Gaussian can reach: a pixel contributes only where d^T Conic d <= 2 ln(255 o), whose bounding box
+                    // has the half extents sqrt(2 ln(255 o) cov_xx), sqrt(. cov_yy) -- straight from the 2-D covariance, no division.
+                    // Pixel centres are integers, so the box is kept as the range of 8-pixel quadrant columns / rows that hold a centre
+                    // inside it (11 bits each, clamped to the image): the duplicate kernel derives every pair's quadrant mask from it.
+                    const float thr = 2.f * __logf(255.f * op) * 1.01f + 0.05f;           // (same margin as footprint.h)
+                    float bx = __builtin_sqrtf(thr * p.a) * 1.0001f + 0.01f, by = __builtin_sqrtf(thr * p.c) * 1.0001f + 0.01f;
+                    const bool never = !(op >= (1.f / 255.f));                            // cannot reach 1/255 anywhere (also NaN)
+                    if (!(bx == bx) || !(by == by)) bx = by = 3.0e38f;                    // (NaN covariance entries: keep everything)
+                    const float QMAX = 2047.f;
+                    const float lqxf = floorf(ceilf(ix - bx) * 0.125f), hqxf = floorf(floorf(ix + bx) * 0.125f);
+                    const float lqyf = floorf(ceilf(iy - by) * 0.125f), hqyf = floorf(floorf(iy + by) * 0.125f);
+                    const bool off = never || hqxf < 0.f || hqyf < 0.f || lqxf > QMAX || lqyf > QMAX || !(lqxf == lqxf) || !(lqyf == lqyf);
+                    const int lqx = (int)fminf(fmaxf(lqxf, 0.f), QMAX), hqx = (int)fminf(fmaxf(hqxf, 0.f), QMAX);
+                    const int lqy = (int)fminf(fmaxf(lqyf, 0.f), QMAX), hqy = (int)fminf(fmaxf(hqyf, 0.f), QMAX);
+                    qrange = (uint32_t)lqx | ((uint32_t)hqx << 11);
+                    qrange_y = (uint32_t)lqy | ((uint32_t)hqy << 11);
+                    int cx0 = x0, cy0 = y0, cx1 = x1, cy1 = y1;
+                    if (!(a.flags & EMD_FLAG_KEEP_ALL_PAIRS)) {
+                        cx0 = max(x0, lqx >> 1); cx1 = min(x1, (hqx >> 1) + 1);
+                        cy0 = max(y0, lqy >> 1); cy1 = min(y1, (hqy >> 1) + 1);
+                        if (off || cx1 <= cx0 || cy1 <= cy0) { cx1 = cx0; cy1 = cy0; }
+                    } else if (off) {
+                        qrange = 2047u; qrange_y = 2047u;              // (lq = 2047 > hq = 0: no quadrant bit for any pair)
+                    }
+                    emit = (uint32_t)((cx1 - cx0) * (cy1 - cy0));
+                    rect = (uint32_t)cx0 | ((uint32_t)cy0 << 10) | ((uint32_t)(cx1 - cx0) << 20);
                 }
             }
         }
         a.radii[i] = radius_out;
-        a.g.binrec[i] = make_uint2(rect, touched);     // binning input: tile rectangle, tiles touched
+        // binning input (by Gaussian id): x = enumerated tile rectangle x0 | y0 << 10 | width << 20, y = pairs it emits | first quadrant column << 20,
+        // z = upstream's tiles touched | last quadrant column << 20, w = first | last << 11 quadrant row
+        a.g.binrec[i] = make_uint4(rect, emit | ((qrange & 2047u) << 20), touched | ((qrange >> 11) << 20), qrange_y);
         a.g.depth_key[i] = dkey;                         // key of the depth sort (invisible: sorts last)
     }
     const bool vis = touched != 0u;
@@ -962,12 +990,12 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_densification_stats(int n, const 
     if (max_radii) max_radii[i] = fmaxf(max_radii[i], (float)r);
 }
 
-__global__ void __launch_bounds__(EMD_BLOCK) k_export_geometry(int N, const float4* rec, const uint2* binrec,
+__global__ void __launch_bounds__(EMD_BLOCK) k_export_geometry(int N, const float4* rec, const uint4* binrec,
                                                                float* means2D, float* depths, float* conic_opacity,
                                                                float* rgb, float* normal, uint32_t* tiles_touched) {
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
     if (i >= N) return;
-    const uint32_t tt = binrec[i].y;
+    const uint32_t tt = binrec[i].z & 0xFFFFFu;          // upstream's tiles touched (the enumerated rectangle may be smaller)
     const bool vis = tt != 0;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 r0 = vis ? rec[(size_t)i * EMD_REC_F4] : z, r1 = vis ? rec[(size_t)i * EMD_REC_F4 + 1] : z,

@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "device_utils.h"
+#include "footprint.h"
 
 namespace {
 
@@ -53,81 +54,6 @@ __device__ __forceinline__ float gauss_power(float A, float B, float C, float dx
 #pragma clang fp contract(off)
     const float q = __builtin_fmaf(A * dx, dx, (C * dy) * dy);
     return __builtin_fmaf(-0.5f, q, -((B * dx) * dy));
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Exact-conservative footprint culling.  A pixel receives alpha >= 1/255 from a Gaussian only if
-// power >= -tau with tau = ln(255 * opacity), i.e. inside the ellipse d^T Conic d <= 2 tau, whose axis-aligned
-// bounding box has half-extents sqrt(2 tau * cov_xx), sqrt(2 tau * cov_yy) (cov = Conic^-1).  That box is much
-// tighter than the 3-sigma square of the largest eigenvalue that defines the tile list (anisotropic or faint
-// Gaussians), so: the lane that stages entry t computes the box once and a 4-bit mask of the 8x8 quadrants it
-// overlaps; ballots compact the 256 staged entries into one index list per quadrant (order preserved), and each
-// wave walks only its own list.  Pixels outside the box would have been rejected by the alpha test anyway, so the
-// result is unchanged; the box carries a small margin so float rounding can never cull a contributing pixel.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t quadrant_mask(const float4& r0, const float4& r1, float tile_x0, float tile_y0) {
-    const float o = r0.w;
-    if (!(o >= (1.f / 255.f))) return 0u;            // can never reach alpha >= 1/255 (also catches NaN)
-    const float det = r1.x * r1.z - r1.y * r1.y;
-    if (!(det > 0.f)) return 0xFu;                   // degenerate conic: no culling
-    const float tau2 = 2.f * __logf(255.f * o);
-    const float inv = 1.f / det;
-    const float bx = sqrtf(tau2 * r1.z * inv) * 1.0001f + 0.01f;
-    const float by = sqrtf(tau2 * r1.x * inv) * 1.0001f + 0.01f;
-    if (!(bx == bx) || !(by == by)) return 0xFu;
-    const float lx = r0.x - bx, hx = r0.x + bx, ly = r0.y - by, hy = r0.y + by;
-    // quadrant q covers pixel centres [x0 + 8(q&1), +7] x [y0 + 8(q>>1), +7]
-    const bool xl = lx <= tile_x0 + 7.f && hx >= tile_x0, xr = lx <= tile_x0 + 15.f && hx >= tile_x0 + 8.f;
-    const bool yt = ly <= tile_y0 + 7.f && hy >= tile_y0, yb = ly <= tile_y0 + 15.f && hy >= tile_y0 + 8.f;
-    return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Exact-conservative culling against a rectangle of pixel centres (round 3).  The box above is loose for the elongated, diagonal
-// footprints street scenes are made of: on the bench scene 16 % of the (quadrant, entry) pairs that pass it reach alpha >= 1/255
-// at no pixel of the quadrant, 42 % of its (4x4 sub-block, entry) pairs at none of the sub-block (tests/analysis/pair_stats.py).
-// A pixel contributes only if q(d) = A dx^2 + 2 B dx dy + C dy^2 <= 2 ln(255 o); q is convex, so its minimum over the
-// rectangle is 0 when the mean lies inside and otherwise sits on one of the four edges.  On the edge dx = const
-//     q = C (dy - dy*)^2 + (det / C) dx^2,   dy* = -B dx / C,
-// a sum of two non-negative terms (no cancellation), minimised by clamping dy* into the edge.  The threshold carries a 1 % + 0.05
-// margin: det = A C - B^2 loses up to ~3e-3 relative on very thin ellipses, everything else is a few ulp.  NaN means are culled
-// (such an entry fails `power <= 0` at every pixel), degenerate conics are kept.
-// ---------------------------------------------------------------------------------------------------
-struct EllipseCull {
-    float mx, my, A, C, kx, ky, nbc, nba, thr;
-    bool none, all;
-};
-__device__ __forceinline__ EllipseCull ellipse_prepare(const float4& r0, const float4& r1) {
-    EllipseCull e;
-    const float o = r0.w;
-    e.mx = r0.x; e.my = r0.y; e.A = r1.x; e.C = r1.z;
-    e.none = !(o >= (1.f / 255.f));              // can never reach alpha >= 1/255 (also catches NaN)
-    const float det = r1.x * r1.z - r1.y * r1.y;
-    e.all = !(det > 0.f) || !(r1.x > 0.f) || !(r1.z > 0.f);
-    e.thr = 2.f * __logf(255.f * o) * 1.01f + 0.05f;
-    const float ia = __builtin_amdgcn_rcpf(r1.x), ic = __builtin_amdgcn_rcpf(r1.z);
-    e.kx = det * ic; e.ky = det * ia; e.nbc = -r1.y * ic; e.nba = -r1.y * ia;
-    return e;
-}
-// true unless no pixel centre of [x0, x1] x [y0, y1] can reach alpha >= 1/255
-__device__ __forceinline__ bool ellipse_hits_rect(const EllipseCull& e, float x0, float x1, float y0, float y1) {
-    const float dxa = e.mx - x0, dxb = e.mx - x1, dya = e.my - y0, dyb = e.my - y1;       // dxb <= dxa, dyb <= dya
-    const bool inside = dxa >= 0.f && dxb <= 0.f && dya >= 0.f && dyb <= 0.f;
-    float ta = e.nbc * dxa, tb = e.nbc * dxb;
-    float ea = __builtin_amdgcn_fmed3f(ta, dyb, dya) - ta, eb = __builtin_amdgcn_fmed3f(tb, dyb, dya) - tb;
-    const float qa = __builtin_fmaf(e.C * ea, ea, (e.kx * dxa) * dxa), qb = __builtin_fmaf(e.C * eb, eb, (e.kx * dxb) * dxb);
-    ta = e.nba * dya; tb = e.nba * dyb;
-    ea = __builtin_amdgcn_fmed3f(ta, dxb, dxa) - ta; eb = __builtin_amdgcn_fmed3f(tb, dxb, dxa) - tb;
-    const float qc = __builtin_fmaf(e.A * ea, ea, (e.ky * dya) * dya), qd = __builtin_fmaf(e.A * eb, eb, (e.ky * dyb) * dyb);
-    const float q = fminf(fminf(qa, qb), fminf(qc, qd));
-    return !e.none && (e.all || inside || q <= e.thr);
-}
-// bit r (r = sby * 2 + sbx) set when 4x4 sub-block r of the quadrant at (qx0, qy0) can receive alpha >= 1/255
-__device__ __forceinline__ uint32_t ellipse_subblock_mask(const float4& r0, const float4& r1, float qx0, float qy0) {
-    const EllipseCull e = ellipse_prepare(r0, r1);
-    return (ellipse_hits_rect(e, qx0, qx0 + 3.f, qy0, qy0 + 3.f) ? 1u : 0u) | (ellipse_hits_rect(e, qx0 + 4.f, qx0 + 7.f, qy0, qy0 + 3.f) ? 2u : 0u) |
-           (ellipse_hits_rect(e, qx0, qx0 + 3.f, qy0 + 4.f, qy0 + 7.f) ? 4u : 0u) |
-           (ellipse_hits_rect(e, qx0 + 4.f, qx0 + 7.f, qy0 + 4.f, qy0 + 7.f) ? 8u : 0u);
 }
 
 // Two-wide forms of gauss_power / pinned_exp (same operations per component, so bit-identical results): CDNA3/4 issue
@@ -186,23 +112,6 @@ __device__ __forceinline__ v2f pinned_exp2(v2f x) {
 // ---------------------------------------------------------------------------------------------------
 #define FQ_RING 128
 
-// bit r (r = sby * 2 + sbx) set when the tight alpha >= 1/255 box overlaps 4x4 sub-block r of the quadrant at (qx0, qy0)
-__device__ __forceinline__ uint32_t quad_subblock_mask(const float4& r0, const float4& r1, float qx0, float qy0) {
-    const float o = r0.w;
-    if (!(o >= (1.f / 255.f))) return 0u;
-    const float det = r1.x * r1.z - r1.y * r1.y;
-    if (!(det > 0.f)) return 0xFu;
-    const float tau2 = 2.f * __logf(255.f * o);
-    const float inv = 1.f / det;
-    const float bx = sqrtf(tau2 * r1.z * inv) * 1.0001f + 0.01f;
-    const float by = sqrtf(tau2 * r1.x * inv) * 1.0001f + 0.01f;
-    if (!(bx == bx) || !(by == by)) return 0xFu;
-    const float lx = r0.x - bx, hx = r0.x + bx, ly = r0.y - by, hy = r0.y + by;
-    const bool c0 = lx <= qx0 + 3.f && hx >= qx0, c1 = lx <= qx0 + 7.f && hx >= qx0 + 4.f;
-    const bool w0 = ly <= qy0 + 3.f && hy >= qy0, w1 = ly <= qy0 + 7.f && hy >= qy0 + 4.f;
-    return (c0 && w0 ? 1u : 0u) | (c1 && w0 ? 2u : 0u) | (c0 && w1 ? 4u : 0u) | (c1 && w1 ? 8u : 0u);
-}
-
 template <bool NORMAL, int NX>
 __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ ranges,
                                                                const uint32_t* __restrict__ point_list,
@@ -239,19 +148,29 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
     float4 px_[NX ? NX : 1];
 #pragma unroll
     for (int k = 0; k < (NX ? NX : 1); k++) px_[k] = zero4;
-    uint32_t pgid = 0;
-    if (lane < n_tile) {
-        const uint32_t gid = point_list[start + lane];
-        pgid = gid;
-        const float4* r = rec + (size_t)gid * EMD_REC_F4;
-        p0 = r[0]; p1 = r[1]; p2 = r[2];
-        if (NORMAL) p3 = r[3];
+    // Which entries of the tile list reach THIS quadrant was decided when the list was built: the duplicate kernel (binning.hip) runs the
+    // exact ellipse-rectangle test of footprint.h once per (tile, Gaussian) pair and leaves the four quadrant bits in the top bits of the
+    // list word.  The scan here reads 4 bytes per entry and fetches the 64-byte record of the survivors only (one step ahead; the list
+    // words two steps ahead).
+    const uint32_t qbit = 1u << (EMD_ID_BITS + quad);
+    uint32_t w_nxt = 0, pgid = 0;
+    bool pkeep = false;
+    {
+        const uint32_t w = lane < n_tile ? point_list[start + lane] : 0u;
+        if (lane + EMD_WAVE < n_tile) w_nxt = point_list[start + lane + EMD_WAVE];
+        pkeep = (w & qbit) != 0u;
+        pgid = w & EMD_ID_MASK;
+        if (pkeep) {
+            const float4* r = rec + (size_t)pgid * EMD_REC_F4;
+            p0 = r[0]; p1 = r[1]; p2 = r[2];
+            if (NORMAL) p3 = r[3];
 #pragma unroll
-        for (int k = 0; k < NX; k++) { const float* c = d.xcol[k] + 3 * (size_t)gid; px_[k] = make_float4(c[0], c[1], c[2], 0.f); }
+            for (int k = 0; k < NX; k++) { const float* c = d.xcol[k] + 3 * (size_t)pgid; px_[k] = make_float4(c[0], c[1], c[2], 0.f); }
+        }
     }
-    // The entries that pass the quadrant test ("survivors") are numbered in list order and their Gaussian ids written out: the
-    // backward walks exactly this list (no second scan of the tile list, no second footprint test there), and a pixel's
-    // n_contrib is the NUMBER of the last survivor that contributed to it (1-based), not its position in the tile list.
+    // The survivors are numbered in list order and their Gaussian ids written out: the backward walks exactly this list (no scan of
+    // the tile list there), and a pixel's n_contrib is the NUMBER of the last survivor that contributed to it (1-based), not its
+    // position in the tile list.
     uint32_t* const sv = surv + 4 * (size_t)start + (size_t)quad * n_tile;
     uint32_t total = 0;
     uint32_t scanned = 0;
@@ -267,37 +186,47 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
 #pragma unroll
             for (int k = 0; k < NX; k++) cxr[k] = px_[k];
             const uint32_t cgid = pgid;
-            if (idx + EMD_WAVE < n_tile) {
-                const uint32_t gid = point_list[start + idx + EMD_WAVE];
-                pgid = gid;
-                const float4* r = rec + (size_t)gid * EMD_REC_F4;
-                p0 = r[0]; p1 = r[1]; p2 = r[2];
-                if (NORMAL) p3 = r[3];
+            const bool keep = pkeep;
+            {
+                const uint32_t w = w_nxt;                 // (0 beyond the end of the list)
+                w_nxt = (idx + 2 * EMD_WAVE < n_tile) ? point_list[start + idx + 2 * EMD_WAVE] : 0u;
+                pkeep = (w & qbit) != 0u;
+                pgid = w & EMD_ID_MASK;
+                if (pkeep) {
+                    const float4* r = rec + (size_t)pgid * EMD_REC_F4;
+                    p0 = r[0]; p1 = r[1]; p2 = r[2];
+                    if (NORMAL) p3 = r[3];
 #pragma unroll
-                for (int k = 0; k < NX; k++) { const float* c = d.xcol[k] + 3 * (size_t)gid; px_[k] = make_float4(c[0], c[1], c[2], 0.f); }
+                    for (int k = 0; k < NX; k++) { const float* c = d.xcol[k] + 3 * (size_t)pgid; px_[k] = make_float4(c[0], c[1], c[2], 0.f); }
+                }
             }
-            const bool keep = idx < n_tile && ellipse_hits_rect(ellipse_prepare(c0r, c1r), qx0, qx0 + 7.f, qy0, qy0 + 7.f);
             const unsigned long long bal = __ballot(keep);
-            const uint32_t rank = (uint32_t)__popcll(bal & lt), slot = head + rank;
+            const uint32_t slot = head + (uint32_t)__popcll(bal & lt);
             if (keep) {
-                sv[total + rank] = cgid;
-                c2r.w = __uint_as_float(total + rank + 1);          // 1-based number of this survivor in the quadrant's list
+                c2r.w = __uint_as_float(cgid);                      // (replaced by the survivor number below)
                 s0[slot] = c0r; s1[slot] = c1r; s2[slot] = c2r;
                 if (NORMAL) s3[slot] = c3r;
 #pragma unroll
                 for (int k = 0; k < NX; k++) sx[k][slot] = cxr[k];
             }
             head += (uint32_t)__popcll(bal);
-            total += (uint32_t)__popcll(bal);
             scanned += EMD_WAVE;
         }
         __syncthreads();
-        // ---- the queued entries (not the whole list) get the exact per-sub-block test; one byte list per sub-block ----
+        // ---- the queued entries (not the whole list) get the exact per-sub-block test; one byte list per sub-block.  The entries that
+        //      reach at least one sub-block are the quadrant's SURVIVORS: numbered here, in list order, ids written out for the backward
         for (uint32_t base = 0; base < head; base += EMD_WAVE) {
             const uint32_t slot = base + lane;
-            uint32_t m4 = 0u;
-            if (slot < head) m4 = ellipse_subblock_mask(s0[slot], s1[slot], qx0, qy0);
+            uint32_t m4 = 0u, gid = 0u;
+            if (slot < head) { gid = __float_as_uint(reinterpret_cast<const float*>(&s2[slot])[3]); m4 = ellipse_subblock_mask(s0[slot], s1[slot], qx0, qy0); }
             const unsigned long long b0 = __ballot(m4 & 1u), b1 = __ballot(m4 & 2u), b2 = __ballot(m4 & 4u), b3 = __ballot(m4 & 8u);
+            const unsigned long long ba = b0 | b1 | b2 | b3;
+            if (m4) {
+                const uint32_t num = total + (uint32_t)__popcll(ba & lt);
+                sv[num] = gid;
+                reinterpret_cast<float*>(&s2[slot])[3] = __uint_as_float(num + 1);      // 1-based number of this survivor in the quadrant's list
+            }
+            total += (uint32_t)__popcll(ba);
             if (m4 & 1u) s_list[0][len0 + (uint32_t)__popcll(b0 & lt)] = (uint8_t)slot;
             if (m4 & 2u) s_list[1][len1 + (uint32_t)__popcll(b1 & lt)] = (uint8_t)slot;
             if (m4 & 4u) s_list[2][len2 + (uint32_t)__popcll(b2 & lt)] = (uint8_t)slot;

@@ -68,6 +68,9 @@ class RasterOptions:
     aux_stream: bool = False        # run the colour half of the projection kernel on a second stream beside the binning stage (the binding
                                     # keeps one side stream per device; results are identical, see EmdFwdArgs.aux_stream).  Measured at the
                                     # headline size: 684 it/s against 700 fused -- off unless a caller's binning is long
+    keep_all_pairs: bool = False    # enumerate every tile of upstream's tile rectangles (EMD_FLAG_KEEP_ALL_PAIRS): the sorted keys are then
+                                    # upstream's, entry for entry.  Default: only the tiles a Gaussian's alpha >= 1/255 bounding box reaches
+                                    # -- same images and gradients bit for bit, 25 % fewer list entries on street scenes
     wide_depth_sort: bool = False   # always use the four-pass depth sort (depths beyond 65 536 x the near plane).  The three-pass sort
                                     # falls back to it by itself when the status word can be read (a retry in the synchronous mode,
                                     # the next call in no_sync mode); a call captured into a hipGraph reads nothing back and keeps the
@@ -99,23 +102,28 @@ class RasterCall:
             setattr(self, k, None)
 
     def last_status(self):
-        """(num_rendered D, overflow, num_visible V) of this call's forward; synchronises."""
+        """(num_rendered D, overflow, num_visible V) of this call's forward; synchronises.  D is the length of the sorted (tile, Gaussian)
+        list: upstream's duplicate count with keep_all_pairs, otherwise without the pairs outside the Gaussians' alpha >= 1/255 boxes."""
         st = self.status.cpu().tolist()
         return dict(num_rendered=st[0] & 0xFFFFFFFF, overflow=st[1], num_visible=st[2] & 0xFFFFFFFF)
 
-    def export_binning(self):
-        """Sorted keys (uint64 as int64 bit pattern), Gaussian ids and tile ranges of this call's forward."""
+    def export_binning(self, with_masks=False):
+        """Sorted keys (uint64 as int64 bit pattern), Gaussian ids and tile ranges of this call's forward (+ the quadrant mask of every
+        list entry with `with_masks`)."""
         lib = L.load()
-        D = self.last_status()["num_rendered"]
+        st = self.last_status()
+        D = 0 if st["overflow"] else st["num_rendered"]
         dev = self.status.device
         T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
         keys = torch.empty(max(D, 1), device=dev, dtype=torch.int64)
         ids = torch.empty(max(D, 1), device=dev, dtype=torch.int32)
+        masks = torch.empty(max(D, 1), device=dev, dtype=torch.int32) if with_masks else None
         ranges = torch.empty(T, 2, device=dev, dtype=torch.int32)
         d = L.EmdDims(self.N, self.H, self.W, self.capacity, self.flags)
         L.check(lib.emd_raster_export_binning(C.byref(d), self.geom_ws.data_ptr(), self.sizes[0], self.bin_ws.data_ptr(), self.sizes[1], D,
-                                              keys.data_ptr(), ids.data_ptr(), ranges.data_ptr(), _stream()), "emd_raster_export_binning")
-        return keys[:D], ids[:D], ranges
+                                              keys.data_ptr(), ids.data_ptr(), ranges.data_ptr(), L.ptr(masks), _stream()),
+                "emd_raster_export_binning")
+        return (keys[:D], ids[:D], ranges, masks[:D]) if with_masks else (keys[:D], ids[:D], ranges)
 
     def export_geometry(self):
         lib = L.load()
@@ -533,6 +541,8 @@ class GaussianRasterizer(nn.Module):
             flags |= L.FLAG_ABSGRAD
         if opts.clamp_rgb01:
             flags |= L.FLAG_CLAMP_RGB01
+        if opts.keep_all_pairs:
+            flags |= L.FLAG_KEEP_ALL_PAIRS
         if raw_params:
             # scales / rotations / opacities are the raw parameters; exp / normalize / sigmoid
             # (S3Gaussian/gaussian_renderer/__init__.py:99-101) run inside the projection kernel, forward and backward
@@ -581,8 +591,8 @@ class GaussianRasterizer(nn.Module):
     def last_status(self):
         return self.last_call.last_status()
 
-    def export_binning(self):
-        return self.last_call.export_binning()
+    def export_binning(self, with_masks=False):
+        return self.last_call.export_binning(with_masks=with_masks)
 
     def export_geometry(self):
         return self.last_call.export_geometry()

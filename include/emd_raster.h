@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 20
+#define EMD_ABI_VERSION 21
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -84,10 +84,18 @@ enum {
                                       near plane in three (needed only when depths exceed 65 536 x the near plane: EMD_ERR_DEPTH_RANGE) */
     EMD_FLAG_SDEV_TANFOV = 1 << 6, /* settings_dev holds two more floats, tanfovx and tanfovy (cameras given as device-resident
                                       intrinsics, OmniRe/models/trainers/base.py:399-400): they replace the by-value fields */
-    EMD_FLAG_BWD_WS_CLEAN = 1 << 8 /* backward only (ABI 18): bwd_ws ARRIVES zero-filled (the caller's promise) and is LEFT zero-filled --
+    EMD_FLAG_BWD_WS_CLEAN = 1 << 8, /* backward only (ABI 18): bwd_ws ARRIVES zero-filled (the caller's promise) and is LEFT zero-filled --
                                       the projection backward clears every accumulator row it reads, so a caller that keeps one
                                       workspace across steps pays no 48 N-byte zero fill per backward.  Without the flag the library
                                       clears the workspace itself, as before. */
+    EMD_FLAG_KEEP_ALL_PAIRS = 1 << 9 /* (ABI 21) enumerate every tile of upstream's tile rectangle (the 3-sigma square of the largest
+                                      eigenvalue): the sorted keys then ARE upstream's (tile << 32 | depth bits) list, entry for entry.
+                                      By default a Gaussian enumerates only the tiles of that rectangle which its alpha >= 1/255 bounding
+                                      box (half extents sqrt(2 ln(255 o) cov_xx), sqrt(2 ln(255 o) cov_yy)) reaches: the pairs left out are
+                                      pairs upstream's render loop skips at every pixel of the tile (its alpha < 1/255 `continue`), so
+                                      images, radii and gradients are the same bit for bit and the sorted list is upstream's list with
+                                      those entries left out -- same keys, same order, 25 % fewer entries on the street scenes of
+                                      BASELINE.json. */
 };
 
 /* The 12 fields of GaussianRasterizationSettings (S3Gaussian/gaussian_renderer/__init__.py:49-62), by value. */
@@ -127,7 +135,9 @@ typedef struct EmdMotion {
 
 /* Small device-side status block written by the forward pass. */
 typedef struct EmdStatus {
-    uint32_t num_rendered;  /* D = sum of tiles touched */
+    uint32_t num_rendered;  /* D = (tile, Gaussian) pairs of the sorted list: the sum over the Gaussians of the tiles their alpha >= 1/255
+                               bounding box reaches inside upstream's tile rectangle (ABI 21; with EMD_FLAG_KEEP_ALL_PAIRS: upstream's
+                               sum of tiles touched) */
     uint32_t overflow;      /* bit 0: D > bin_capacity; bit 1: depth range beyond the three-pass sort (either: results invalid,
                                the image is the background) */
     uint32_t num_visible;   /* V = Gaussians with radii > 0 */
@@ -301,13 +311,14 @@ int emd_raster_workspace_size(const EmdDims* dims, size_t out[4]);
 int emd_raster_forward(EmdFwdArgs* args, void* hip_stream);
 int emd_raster_backward(const EmdBwdArgs* args, void* hip_stream);
 
-/* Copy binning state out for parity tests: sorted keys (tile<<32 | depth bits), sorted Gaussian ids,
- * per-tile [start,end) ranges.  Any output may be NULL.  keys/ids hold num_rendered entries.
+/* Copy binning state out for parity tests: sorted keys (tile<<32 | depth bits), sorted Gaussian ids, the quadrant mask of every
+ * entry (bit q = qy * 2 + qx: the Gaussian's alpha >= 1/255 footprint reaches the 8x8 quadrant q of the tile; ABI 21),
+ * per-tile [start,end) ranges.  Any output may be NULL.  keys / ids / quad_masks hold num_entries = EmdStatus.num_rendered entries.
  * The sort itself moves (tile id, Gaussian id) pairs of Gaussians pre-ordered by depth; the 64-bit keys of the
  * reference are rebuilt here from the tile id and the depth bits kept per Gaussian in geom_ws. */
 int emd_raster_export_binning(const EmdDims* dims, const void* geom_ws, size_t geom_bytes, const void* bin_ws, size_t bin_bytes,
-                              int64_t num_rendered, uint64_t* keys, uint32_t* ids, uint32_t* ranges /*[T,2]*/,
-                              void* hip_stream);
+                              int64_t num_entries, uint64_t* keys, uint32_t* ids, uint32_t* ranges /*[T,2]*/,
+                              uint32_t* quad_masks, void* hip_stream);
 
 /* Copy per-Gaussian projection state out for parity tests.  Any output may be NULL. */
 int emd_raster_export_geometry(const EmdDims* dims, const void* geom_ws, size_t geom_bytes,

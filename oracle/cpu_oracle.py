@@ -154,6 +154,17 @@ def bin_tiles(S, pre):
     return dict(D=D, keys=keys[:D], ids=ids[:D], ranges=ranges)
 
 
+def pair_quadrant_hits(S, pre, binning):
+    """Checker of the product's footprint culling: per entry of the sorted list the 4-bit mask of the tile's 8x8 quadrants in which at
+    least one pixel passes the render loop's skip tests (brute force over the pixels; orc_pair_quadrant_hits)."""
+    D = binning["D"]
+    out = np.zeros(max(D, 1), np.uint8)
+    if D:
+        lib().orc_pair_quadrant_hits(C.byref(S), C.c_int64(D), _p(binning["keys"]), _p(binning["ids"]), _p(pre["means2D"]),
+                                     _p(pre["conic_opacity"]), _p(out))
+    return out[:D]
+
+
 def render_forward(S, pre, binning, flags=0):
     H, W = S.H, S.W
     out = dict(color=np.zeros((3, H, W), np.float32), depth=np.zeros((1, H, W), np.float32),

@@ -442,6 +442,37 @@ int orc_render_forward(const OrcSettings* S, int flags, const uint32_t* ranges, 
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Checker of the product's footprint culling (round 4; upstream has no such step): for every entry of the sorted list, by brute force
+ * over the pixels of its tile that lie inside the image, the 4-bit mask of the 8x8 quadrants (bit qy * 2 + qx) in which AT LEAST ONE
+ * pixel passes the render loop's own skip tests (power <= 0 and alpha >= 1/255, evaluated exactly as orc_render_forward does).
+ * The product may drop an entry from its list only when this mask is 0, and must set every bit that is set here.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_pair_quadrant_hits(const OrcSettings* S, int64_t D, const uint64_t* keys, const uint32_t* ids, const float* means2D,
+                           const float* conic_opacity, uint8_t* out_mask) {
+    const int W = S->W, H = S->H, gx = (W + TILE - 1) / TILE;
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int64_t k = 0; k < D; k++) {
+        const uint32_t t = (uint32_t)(keys[k] >> 32), g = ids[k];
+        const int x0 = (int)(t % (uint32_t)gx) * TILE, y0 = (int)(t / (uint32_t)gx) * TILE;
+        const float* co = conic_opacity + 4 * g;
+        uint8_t m = 0;
+        for (int py = y0; py < y0 + TILE && py < H; py++)
+            for (int px = x0; px < x0 + TILE && px < W; px++) {
+                const uint8_t bit = (uint8_t)(1u << (((py - y0) >> 3) * 2 + ((px - x0) >> 3)));
+                if (m & bit) continue;
+                float dx = means2D[2 * g] - (float)px, dy = means2D[2 * g + 1] - (float)py;
+                float power = gauss_power(co[0], co[1], co[2], dx, dy);
+                if (power > 0.f) continue;
+                float alpha = fminf(0.99f, co[3] * pinned_exp(power));
+                if (alpha < 1.f / 255.f) continue;
+                m |= bit;
+            }
+        out_mask[k] = m;
+    }
+    return 0;
+}
+
 static int g_accumulate_fp32 = 0;
 void orc_set_accumulate_fp32(int on) { g_accumulate_fp32 = on; }
 

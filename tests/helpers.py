@@ -39,7 +39,15 @@ END2END_REL_L2 = 1e-4
 # only (c); the per-kernel bars (a) and (b) are what they were -- additionally admits END2END_ULP_RESPONSES times the change of the
 # ORACLE's own projection backward when every render gradient it is fed moves by one fp32 ulp (measured per element, per test, on
 # the oracle; it applies to every output of that chain -- the same Gaussian's means3D entry sat at 1.17 of the strict bar).
-END2END_ULP_RESPONSES = 16.0
+END2END_ULP_RESPONSES = 8.0
+# Round 4: the allowance is OBSERVABLE and BOUNDED.  Every comparison that is given one records how many elements exceeded the plain
+# bound (i.e. leaned on the allowance) and the largest multiple of the one-ulp response any of them used (ALLOWANCE_LOG, printed by the
+# full-size tests); at most ALLOWANCE_MAX_FRACTION of a tensor's elements (but never fewer than ALLOWANCE_MIN_COUNT) may lean on it, and
+# none by more than END2END_ULP_RESPONSES responses (16 in round 3, 8 now).  A systematic error of the projection backward confined to
+# ill-conditioned footprints would show up as a count, not hide behind the allowance.
+ALLOWANCE_MAX_FRACTION = 1e-5
+ALLOWANCE_MIN_COUNT = 2
+ALLOWANCE_LOG = []
 # Per-actor pose gradients are sums over the thousands of Gaussians of an actor, with heavy cancellation (an actor's points pull its
 # pose in all directions: the sum can be a thousand times smaller than its terms).  A bound relative to the RESULT is meaningless
 # there; theirs is relative to the sum of the magnitudes of the terms (condition-aware): see pose_bound().
@@ -144,7 +152,7 @@ def run_oracle(case, backward=False):
     return out
 
 
-def run_hip(case, backward=False, device="cuda:0", absgrad=False, factored_sh_grad=False):
+def run_hip(case, backward=False, device="cuda:0", absgrad=False, factored_sh_grad=False, keep_all_pairs=False):
     """The product path: emd_amd.GaussianRasterizer -> C ABI -> HIP kernels."""
     from emd_amd import GaussianRasterizationSettings, GaussianRasterizer
     cam = case["cam"]
@@ -160,7 +168,8 @@ def run_hip(case, backward=False, device="cuda:0", absgrad=False, factored_sh_gr
              cov3Ds_precomp=d(case["cov3D_precomp"]), actor_pose=d(case["actor_pose"]),
              residual_dx=d(case["residual_dx"]), residual_dq=d(case["residual_dq"]))
     means2D = torch.zeros(case["N"], 3, device=dev, requires_grad=backward)
-    rast = GaussianRasterizer(rs, compute_normal=True, absgrad=absgrad, factored_sh_grad=factored_sh_grad, keep_render_grads=backward)   # options belong to this instance
+    rast = GaussianRasterizer(rs, compute_normal=True, absgrad=absgrad, factored_sh_grad=factored_sh_grad, keep_render_grads=backward,
+                              keep_all_pairs=keep_all_pairs)   # options belong to this instance
     kw = {}
     if case["flags"] & co.F_MOTION:
         kw = dict(actor_ids=None if case["actor_ids"] is None else case["actor_ids"].to(dev), actor_pose=T["actor_pose"],
@@ -171,10 +180,12 @@ def run_hip(case, backward=False, device="cuda:0", absgrad=False, factored_sh_gr
                                                  cov3Ds_precomp=T["cov3Ds_precomp"], extra_attrs=None, **kw)
     out = dict(color=color.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(),
                normal=normal.detach().cpu().numpy(), alpha=alpha.detach().cpu().numpy(), radii=radii.cpu().numpy())
-    keys, ids, ranges = rast.export_binning()
+    keys, ids, ranges, masks = rast.export_binning(with_masks=True)
     out["keys"] = keys.cpu().numpy().view(np.uint64)
     out["ids"] = ids.cpu().numpy().view(np.uint32)
     out["ranges"] = ranges.cpu().numpy().view(np.uint32)
+    out["quad_masks"] = masks.cpu().numpy().astype(np.uint8)
+    out["keep_all_pairs"] = keep_all_pairs
     out["status"] = rast.last_status()
     geo = rast.export_geometry()
     out["geo"] = {k: (None if v is None else v.cpu().numpy()) for k, v in geo.items()}
@@ -197,16 +208,70 @@ def run_hip(case, backward=False, device="cuda:0", absgrad=False, factored_sh_gr
     return out
 
 
+def locate_in_list(keys, ids, ref_keys, ref_ids):
+    """Position of every (key, id) entry in the reference list (sorted by key, then id); -1 where it is absent."""
+    pos = np.searchsorted(ref_keys, keys, side="left").astype(np.int64)
+    D = ref_keys.shape[0]
+    ok = np.zeros(keys.shape[0], bool)
+    for _ in range(64):                                  # equal keys = equal tile AND equal depth bits: runs are short
+        inb = pos < D
+        hit = np.zeros_like(ok)
+        hit[inb] = (ref_keys[pos[inb]] == keys[inb]) & (ref_ids[pos[inb]] == ids[inb])
+        ok |= hit
+        more = ~ok & inb
+        more[more] = ref_keys[pos[more]] == keys[more]
+        if not more.any():
+            break
+        pos[more] += 1
+    pos[~ok] = -1
+    return pos
+
+
+def compare_binning(hip, orc):
+    """The sort-key contract.  With keep_all_pairs the sorted list IS upstream's: keys (tile << 32 | depth bits), ids and tile ranges
+    bit for bit.  By default the list is upstream's list WITHOUT the entries whose footprint reaches no pixel of their tile:
+      * every entry the product keeps is an entry of the oracle's list, bit for bit, and the entries keep their order;
+      * every entry it drops is one the oracle's brute-force check (orc_pair_quadrant_hits) finds no contributing pixel for;
+      * the tile ranges are those of the kept list.
+    Either way an entry's quadrant mask must contain every quadrant the brute-force check finds a contributing pixel in."""
+    pre, b = orc["pre"], orc["bin"]
+    true = co.pair_quadrant_hits(orc["S"], pre, b)
+    if hip["keep_all_pairs"]:
+        assert hip["status"]["num_rendered"] == b["D"]
+        np.testing.assert_array_equal(hip["keys"], b["keys"], err_msg="sorted keys (tile<<32 | depth bits)")
+        np.testing.assert_array_equal(hip["ids"], b["ids"], err_msg="sorted Gaussian ids")
+        np.testing.assert_array_equal(hip["ranges"], b["ranges"], err_msg="tile ranges")
+        pos = np.arange(b["D"])
+    else:
+        assert hip["status"]["num_rendered"] == hip["keys"].shape[0] <= b["D"]
+        pos = locate_in_list(hip["keys"], hip["ids"], b["keys"], b["ids"])
+        assert (pos >= 0).all(), f"{int((pos < 0).sum())} entries of the sorted list are not entries of the oracle's list"
+        assert (np.diff(pos) > 0).all(), "the kept entries are not in the oracle's order"
+        kept = np.zeros(b["D"], bool)
+        kept[pos] = True
+        wrong = int((true[~kept] != 0).sum())
+        assert wrong == 0, f"{wrong} dropped (tile, Gaussian) pairs have a contributing pixel in their tile"
+        # ranges of the kept list: [first, last + 1) per tile, (0, 0) for tiles without entries
+        T = hip["ranges"].shape[0]
+        tiles = (hip["keys"] >> np.uint64(32)).astype(np.int64)
+        first = np.searchsorted(tiles, np.arange(T), side="left")
+        last = np.searchsorted(tiles, np.arange(T), side="right")
+        want = np.stack([first, last], 1).astype(np.uint32)
+        want[first == last] = 0
+        np.testing.assert_array_equal(hip["ranges"], want, err_msg="tile ranges of the kept list")
+    missing = int((true[pos] & ~hip["quad_masks"]).astype(bool).sum())
+    assert missing == 0, f"{missing} list entries lack the mask bit of a quadrant they contribute to"
+    hip["cull_stats"] = dict(D=int(b["D"]), kept=int(hip["keys"].shape[0]), contributing=int((true != 0).sum()),
+                             quadrant_bits=int(np.unpackbits(hip["quad_masks"] & 15).sum()), true_quadrant_bits=int(np.unpackbits(true).sum()))
+
+
 def compare_forward(hip, orc, tol=IMAGE_TOL, exact_images=True):
     pre, b, img = orc["pre"], orc["bin"], orc["img"]
     # integer / key contract: bit-exact
     np.testing.assert_array_equal(hip["radii"], pre["radii"], err_msg="radii")
     np.testing.assert_array_equal(hip["geo"]["tiles_touched"].view(np.uint32), pre["tiles_touched"], err_msg="tiles_touched")
-    assert hip["status"]["num_rendered"] == b["D"], (hip["status"], b["D"])
     assert hip["status"]["num_visible"] == int((pre["radii"] > 0).sum())
-    np.testing.assert_array_equal(hip["keys"], b["keys"], err_msg="sorted keys (tile<<32 | depth bits)")
-    np.testing.assert_array_equal(hip["ids"], b["ids"], err_msg="sorted Gaussian ids")
-    np.testing.assert_array_equal(hip["ranges"], b["ranges"], err_msg="tile ranges")
+    compare_binning(hip, orc)
     vis = pre["radii"] > 0
     # pixel means and depths feed the keys / rects: bit-exact; conic, colour: tolerance
     np.testing.assert_array_equal(hip["geo"]["means2D"][vis].view(np.uint32), pre["means2D"][vis].view(np.uint32))
@@ -245,9 +310,23 @@ def assert_grad_close(got, ref, name, rtol=None, atol_frac=None, rel_l2=None, ex
     got = np.asarray(got)
     ref = np.asarray(ref)
     if extra_abs is not None:
-        # move every element towards the reference by its allowance, then apply the ordinary bar
         ex = np.asarray(extra_abs, np.float64).reshape(ref.shape)
         d = np.asarray(got, np.float64).reshape(ref.shape) - np.asarray(ref, np.float64)
+        # how much of the allowance is actually used: elements over the PLAIN bound, and by how many one-ulp responses
+        kk = 1.0 if rtol is None else rtol / GRAD_RTOL
+        plain = kk * (GRAD_RTOL * np.abs(np.asarray(ref, np.float64)) + (GRAD_ATOL_FRAC if atol_frac is None else atol_frac) * max(float(np.abs(ref).max()), 1e-30))
+        over = np.abs(d) - plain
+        leaning = over > 0
+        n_lean = int(leaning.sum())
+        unit = ex / END2END_ULP_RESPONSES
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mult = np.where(leaning, over / np.where(unit > 0, unit, np.nan), 0.0)
+        max_mult = float(np.nanmax(mult)) if n_lean else 0.0
+        ALLOWANCE_LOG.append(dict(name=name, elements=int(ref.size), leaning=n_lean, max_responses=round(max_mult, 3)))
+        allowed = max(int(np.ceil(ALLOWANCE_MAX_FRACTION * ref.size)), ALLOWANCE_MIN_COUNT)
+        assert n_lean <= allowed, (f"grad {name}: {n_lean} of {ref.size} elements exceed the plain bound and lean on the conditioning allowance "
+                                   f"(at most {allowed} may)")
+        # move every element towards the reference by its allowance, then apply the ordinary bar
         got = np.asarray(ref, np.float64) + np.sign(d) * np.maximum(np.abs(d) - ex, 0.0)
     if got.size == ref.size:
         got = got.reshape(ref.shape)
@@ -403,13 +482,27 @@ def raw_params_parity(case, log_s, raw_q, logit, device="cuda:0", check_images_e
     rast = GaussianRasterizer(rs, compute_normal=True, keep_render_grads=True)
     color, depth, normal, alpha, radii, _ = rast(means3D=means, means2D=m2, shs=shs, opacities=logit, scales=log_s,
                                                  rotations=raw_q, raw_params=True, **kw)
-    keys, ids, ranges = rast.export_binning()
+    keys, ids, ranges, masks = rast.export_binning(with_masks=True)
     st = rast.last_status()
-    assert st["num_rendered"] == orc["bin"]["D"] and st["num_visible"] == int((orc["pre"]["radii"] > 0).sum())
+    assert st["num_visible"] == int((orc["pre"]["radii"] > 0).sum())
     np.testing.assert_array_equal(radii.cpu().numpy(), orc["pre"]["radii"], err_msg="radii")
-    np.testing.assert_array_equal(keys.cpu().numpy().view(np.uint64), orc["bin"]["keys"], err_msg="sorted keys")
-    np.testing.assert_array_equal(ids.cpu().numpy().view(np.uint32), orc["bin"]["ids"], err_msg="sorted ids")
-    np.testing.assert_array_equal(ranges.cpu().numpy().view(np.uint32), orc["bin"]["ranges"], err_msg="tile ranges")
+    hb = dict(keys=keys.cpu().numpy().view(np.uint64), ids=ids.cpu().numpy().view(np.uint32), ranges=ranges.cpu().numpy().view(np.uint32),
+              quad_masks=masks.cpu().numpy().astype(np.uint8), keep_all_pairs=False, status=st)
+    compare_binning(hb, orc)                      # the default list: upstream's without the entries that reach no pixel of their tile
+    cull = hb["cull_stats"]
+    # ... and upstream's list itself, entry for entry, with keep_all_pairs (forward only; same images bit for bit)
+    with torch.no_grad():
+        rast_all = GaussianRasterizer(rs, compute_normal=True, keep_all_pairs=True)
+        c_all, d_all, n_all, a_all, r_all, _ = rast_all(means3D=means.detach(), means2D=m2.detach(), shs=shs.detach(), opacities=logit.detach(),
+                                                        scales=log_s.detach(), rotations=raw_q.detach(), raw_params=True,
+                                                        **{k_: (v.detach() if v.is_floating_point() else v) for k_, v in kw.items()})
+        k_all, i_all, rg_all, m_all = rast_all.export_binning(with_masks=True)
+        ha = dict(keys=k_all.cpu().numpy().view(np.uint64), ids=i_all.cpu().numpy().view(np.uint32), ranges=rg_all.cpu().numpy().view(np.uint32),
+                  quad_masks=m_all.cpu().numpy().astype(np.uint8), keep_all_pairs=True, status=rast_all.last_status())
+        compare_binning(ha, orc)
+        assert torch.equal(c_all, color.detach()) and torch.equal(d_all, depth.detach()) and torch.equal(a_all, alpha.detach()) \
+            and torch.equal(n_all, normal.detach()) and torch.equal(r_all, radii), "keep_all_pairs changes the images"
+        del c_all, d_all, n_all, a_all, k_all, i_all, rg_all, m_all, rast_all
     for name, t in (("color", color), ("depth", depth), ("alpha", alpha), ("normal", normal)):
         got = t.detach().cpu().numpy()
         scale = max(1.0, float(np.abs(orc["img"][name]).max())) if name == "depth" else 1.0
@@ -472,5 +565,6 @@ def raw_params_parity(case, log_s, raw_q, logit, device="cuda:0", check_images_e
             assert_grad_close(rdq.grad.cpu().numpy(), k8["residual_dq"], "projection backward on the kernel's own render gradients: residual_dq")
         res["residual_dq"] = assert_grad_close(rdq.grad.cpu().numpy(), go["residual_dq"], "residual_dq", rtol, atol_frac=END2END_ATOL_FRAC,
                                                rel_l2=END2END_REL_L2, extra_abs=ulp["residual_dq"].reshape(np.asarray(go["residual_dq"]).shape))
-    res["D"], res["V"] = orc["bin"]["D"], st["num_visible"]
+    res["D"], res["V"], res["D_sorted"], res["D_contributing"] = orc["bin"]["D"], st["num_visible"], cull["kept"], cull["contributing"]
+    res["allowance"] = [a for a in ALLOWANCE_LOG[-8:] if a["leaning"]]
     return res

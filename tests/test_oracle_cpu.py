@@ -77,3 +77,32 @@ def test_oracle_alpha_and_background():
     img0 = run_oracle(case0)["img"]
     np.testing.assert_allclose(img["color"] - img0["color"], img["final_T"][None] * case["bg"].numpy()[:, None, None], atol=1e-6)
 
+
+
+def test_oracle_pair_quadrant_hits_is_the_render_loops_own_skip_test():
+    """orc_pair_quadrant_hits (the checker of the product's footprint culling) against the render forward: rendering only the entries
+    it marks as contributing gives the same image bit for bit, the entry that contributed last to a pixel always carries the bit of
+    that pixel's quadrant, and on a street-like scene a sizeable part of upstream's (tile, Gaussian) pairs contributes nowhere."""
+    case = make_case(n=3000, H=70, W=90, seed=6)
+    orc = run_oracle(case)
+    pre, b, img = orc["pre"], orc["bin"], orc["img"]
+    m = co.pair_quadrant_hits(orc["S"], pre, b)
+    assert m.shape[0] == b["D"] and m.max() <= 15
+    keep = m != 0
+    assert 0.05 < 1.0 - keep.mean() < 0.95
+    tiles = (b["keys"][keep] >> np.uint64(32)).astype(np.int64)
+    T = b["ranges"].shape[0]
+    first, last = np.searchsorted(tiles, np.arange(T), "left"), np.searchsorted(tiles, np.arange(T), "right")
+    rg = np.stack([first, last], 1).astype(np.uint32)
+    rg[first == last] = 0
+    img2 = co.render_forward(orc["S"], pre, dict(D=int(keep.sum()), keys=b["keys"][keep], ids=b["ids"][keep], ranges=rg), case["flags"])
+    for k in ("color", "depth", "alpha", "normal", "final_T"):
+        np.testing.assert_array_equal(img2[k].view(np.uint32), img[k].view(np.uint32), err_msg=k)
+    gx = (case["W"] + 15) // 16
+    for py in range(0, case["H"], 5):
+        for px in range(0, case["W"], 7):
+            n = int(img["n_contrib"][py, px])
+            if n:
+                t = (py // 16) * gx + px // 16
+                e = int(b["ranges"][t, 0]) + n - 1
+                assert m[e] & (1 << (((py % 16) >> 3) * 2 + ((px % 16) >> 3)))
