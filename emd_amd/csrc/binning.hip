@@ -19,6 +19,11 @@
 // (tile id, depth bits of the Gaussian) for the parity tests.  Bytes through the radix passes on the bench scene
 // (N = 2 M, V = 1.06 M, D = 4.6 M): 6 x 24 B x 4.6 M = 670 MB upstream, 4 N + 8 V + 2 x 16 V + 2 x 16 D = 200 MB here.
 //
+// Launches of the stage (19): per depth pass histogram -> digit scan -> scatter (9); the binning records gathered into depth order with
+// the pairs every 256 of them emit (1); the duplicate kernel, which scans those block sums itself (every workgroup, 31 KB from L2) and
+// publishes D / overflow / V -- the single-workgroup scan kernel of rounds 1-3 is gone (1); two tile passes, the first one's histogram
+// built by the duplicate kernel (5); tile ranges; the dispatch order of the render kernels.
+//
 // Design for gfx950:
 //   - the duplicate count D stays on the device (EmdStatus.num_rendered); every kernel here is launched on the
 //     caller-provided capacity and bounds itself by D, so the forward pass needs no host read-back to proceed.
@@ -48,9 +53,14 @@ __device__ __forceinline__ uint32_t sort_n(const SortN& c) {
 #define SCAN_ITEMS 4
 #define SCAN_TILE (EMD_BLOCK * SCAN_ITEMS)
 
+#define DUP_SLOTS EMD_SORT_TILE
+
 // ---------------------------------------------------------------------------------------------------
-// K2': tile rectangle and tile count of the Gaussians in depth order (one 8-byte gather each) + block totals
+// K2': binning records of the Gaussians in depth order (one 16-byte gather each) + the pairs every block of 256 of them emits
 // ---------------------------------------------------------------------------------------------------
+// (Round 4, measured and dropped: this gather inside the last depth pass's scatter kernel, with the block sums as one float... integer
+//  atomic per (wave, output block) -- 117 k single-lane atomic instructions at ~117 clocks each on the CU's memory path made that pass
+//  78 us instead of 18; as its own launch with 4900 independent workgroups the gather takes 20.)
 __global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32_t* __restrict__ num_sorted,
                                                              const uint32_t* __restrict__ perm,
                                                              const uint4* __restrict__ binrec,
@@ -66,53 +76,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32
     for (uint32_t r = (uint32_t)i; r < n_ranges; r += gridDim.x * EMD_BLOCK) ranges[r] = 0u;
     uint32_t total;
     block_scan_add_u32(br.y & 0xFFFFFu, s_scan, &total);                  // pairs this Gaussian emits
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-// Single workgroup: inclusive scan of the per-block tile counts in place, D / overflow / V into the status word, and for
-// every 2048-slot output block of the duplicate kernel the block of Gaussians that holds its first slot.
-#define DUP_SLOTS EMD_SORT_TILE
-#define PUB_THREADS 1024
-#define PUB_ITEMS 8
-__global__ void __launch_bounds__(PUB_THREADS) k_scan_publish(uint32_t* __restrict__ block_sums,
-                                                              uint32_t nb, uint64_t capacity, EmdStatus* __restrict__ status,
-                                                              uint32_t* __restrict__ slot_start, uint32_t n_slot_blocks) {
-    // 1024 threads x 8 values: the 7812 block totals of a 2 M scene are ONE trip (the 256-thread version walked them in 8
-    // dependent trips of load -> scan -> store, 15 us on the critical path of every forward)
-    __shared__ uint32_t s_w[PUB_THREADS / 64];
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < nb; base += PUB_THREADS * PUB_ITEMS) {
-        const uint32_t i0 = base + threadIdx.x * PUB_ITEMS;
-        uint32_t v[PUB_ITEMS], sum = 0;
-#pragma unroll
-        for (int k = 0; k < PUB_ITEMS; k++) {
-            v[k] = (i0 + k < nb) ? block_sums[i0 + k] : 0u;
-            sum += v[k];
-        }
-        const uint32_t inc = wave_scan_add_u32(sum);
-        __syncthreads();                                   // s_w free again (previous trip)
-        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        uint32_t wbase = 0, total = 0;
-        for (uint32_t w = 0; w < PUB_THREADS / 64; w++) { const uint32_t t = s_w[w]; if (w < (threadIdx.x >> 6)) wbase += t; total += t; }
-        uint32_t run = carry + wbase + inc - sum;
-#pragma unroll
-        for (int k = 0; k < PUB_ITEMS; k++) {
-            const uint32_t excl = run;
-            run += v[k];
-            if (i0 + k < nb) {
-                block_sums[i0 + k] = run;
-                // output blocks whose first slot falls into [excl, run)
-                for (uint32_t sb = (excl + DUP_SLOTS - 1) / DUP_SLOTS; sb < n_slot_blocks && (uint64_t)sb * DUP_SLOTS < run; sb++)
-                    slot_start[sb] = i0 + k;
-            }
-        }
-        carry += total;
-    }
     if (threadIdx.x == 0) {
-        status->num_rendered = carry;
-        status->overflow = (status->overflow & 2u) | (((uint64_t)carry > capacity) ? 1u : 0u);     // bit 1: depth range (set by the depth sort)
-        status->num_visible = status->reserved;          // V: the Gaussians the compacting first depth pass kept (radii > 0)
+        block_sums[blockIdx.x] = total;
+        if (blockIdx.x == gridDim.x - 1) { block_sums[gridDim.x] = 0u; block_sums[gridDim.x + 1] = 0u; block_sums[gridDim.x + 2] = 0u; }   // (read as uint4)
     }
 }
 
@@ -140,36 +106,75 @@ __global__ void __launch_bounds__(PUB_THREADS) k_scan_publish(uint32_t* __restri
 // lines, 26 -> 67 us, whatever the arithmetic behind it costs.)
 __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const uint4* __restrict__ bin_s,
                                                          const uint32_t* __restrict__ perm,
-                                                         const uint32_t* __restrict__ block_sums_inc,
-                                                         const uint32_t* __restrict__ slot_start,
-                                                         const EmdStatus* __restrict__ status,
+                                                         const uint32_t* __restrict__ block_sums,
+                                                         uint64_t capacity, EmdStatus* __restrict__ status,
                                                          uint32_t* __restrict__ tkeys, uint32_t* __restrict__ vals,
                                                          uint32_t* __restrict__ hist0, uint32_t mask0, uint32_t nblocks_cap) {
     __shared__ uint32_t s_scan[4];
+    __shared__ uint32_t s_first[2];            // block of Gaussians that holds this workgroup's first slot, pairs in front of that block
     __shared__ uint32_t s_excl[EMD_BLOCK];     // exclusive offsets inside the block
     __shared__ uint32_t s_rect[EMD_BLOCK];     // x0 | y0 << 10 | width << 20   (grid dims < 1024 tiles = 16K px)
     __shared__ uint32_t s_id[EMD_BLOCK];
     __shared__ uint32_t s_qx[EMD_BLOCK], s_qy[EMD_BLOCK];   // first | last << 11 quadrant column / row of the alpha >= 1/255 box
     __shared__ uint32_t s_h0[EMD_BLOCK];       // digit histogram of tile pass 0 (at most 8 bits per pass)
     s_h0[threadIdx.x] = 0;
-    const uint32_t D = status->overflow ? 0u : status->num_rendered;
+    // ---- every workgroup scans the pair counts of the 256-Gaussian blocks itself (the last depth pass left them in block_sums; 7812
+    //      words at 2 M Gaussians, from L2): D, and where its own 2048 slots start.  This replaces a single-workgroup scan kernel whose
+    //      14 us sat on the critical path of every forward.
+    const uint32_t V = status->reserved;                                      // Gaussians the depth sort kept
+    // chunks of 1024 block sums: a thread takes four consecutive ones (one dwordx4), eight chunks in flight together
+    const uint32_t nbv = (V + EMD_BLOCK - 1) / EMD_BLOCK;
     const uint64_t S0l = (uint64_t)blockIdx.x * DUP_SLOTS;
-    if (S0l >= D) {                            // (uniform per block) nothing to write: the pass still reads this block's histogram column
+    const uint4* bs4 = reinterpret_cast<const uint4*>(block_sums);            // (256-byte aligned, padded with zeros to a multiple of 4)
+    uint32_t D = 0;
+    bool found = false;
+    for (uint32_t c0 = 0; c0 < nbv; c0 += 8u * 4u * EMD_BLOCK) {
+        uint4 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const uint32_t e0 = c0 + (uint32_t)c * 4u * EMD_BLOCK + 4u * threadIdx.x;
+            v[c] = e0 < nbv ? bs4[e0 / 4u] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const uint32_t e0 = c0 + (uint32_t)c * 4u * EMD_BLOCK + 4u * threadIdx.x;
+            if (c0 + (uint32_t)c * 4u * EMD_BLOCK >= nbv) break;                // (uniform)
+            const uint32_t sum = v[c].x + v[c].y + v[c].z + v[c].w;
+            uint32_t total;
+            const uint32_t incl = block_scan_add_u32(sum, s_scan, &total);
+            uint32_t run = D + incl - sum;
+            if (!found && S0l >= run && S0l < (uint64_t)run + sum) {           // exactly one thread over all chunks: its four sums hold slot S0
+                const uint32_t w4[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (S0l < (uint64_t)run + w4[q]) { s_first[0] = e0 + (uint32_t)q; s_first[1] = run; break; }
+                    run += w4[q];
+                }
+            }
+            D += total;
+            found = found || S0l < D;
+        }
+    }
+    const bool bad = (uint64_t)D > capacity || (status->overflow & 2u) != 0u;   // (bit 1: depth range, set by the depth sort)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        status->num_rendered = D;
+        status->overflow = (status->overflow & 2u) | (((uint64_t)D > capacity) ? 1u : 0u);
+        status->num_visible = V;
+    }
+    if (bad || S0l >= D) {                     // (uniform per block) nothing to write: the pass still reads this block's histogram column
         if (hist0) hist0[(size_t)threadIdx.x * nblocks_cap + blockIdx.x] = 0u;
         return;
     }
     const uint32_t S0 = (uint32_t)S0l, S1 = (uint32_t)min((uint64_t)D, S0l + DUP_SLOTS);
-    const uint32_t nb = ((uint32_t)N + EMD_BLOCK - 1) / EMD_BLOCK;
-    for (uint32_t gb = slot_start[blockIdx.x]; gb < nb; gb++) {
-        const uint32_t base = gb ? block_sums_inc[gb - 1] : 0u;
-        if (base >= S1) break;
-        const uint32_t end = block_sums_inc[gb];
-        if (end <= S0) continue;
+    __syncthreads();
+    uint32_t base = s_first[1];
+    for (uint32_t gb = s_first[0]; gb < nbv && base < S1; gb++) {
         const uint32_t i = gb * EMD_BLOCK + threadIdx.x;
-        const uint4 br = (i < (uint32_t)N) ? bin_s[i] : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 br = (i < V) ? bin_s[i] : make_uint4(0u, 0u, 0u, 0u);
         const uint32_t cnt = br.y & 0xFFFFFu;
         uint32_t total;
         const uint32_t inc = block_scan_add_u32(cnt, s_scan, &total);
+        const uint32_t end = base + total;
         s_excl[threadIdx.x] = inc - cnt;
         s_rect[threadIdx.x] = br.x;
         s_id[threadIdx.x] = cnt ? perm[i] : 0u;
@@ -187,10 +192,10 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
                 int mid = (lo + hi + 1) >> 1;
                 if (s_excl[mid] <= e) lo = mid; else hi = mid - 1;
             }
-            const uint32_t local = e - s_excl[lo];
+            const uint32_t local_e = e - s_excl[lo];
             const uint32_t r = s_rect[lo];
             const uint32_t w = r >> 20, x0 = r & 1023u, y0 = (r >> 10) & 1023u;
-            const uint32_t ty = y0 + local / w, tx = x0 + local % w;
+            const uint32_t ty = y0 + local_e / w, tx = x0 + local_e % w;
             const uint32_t tile = ty * (uint32_t)gx + tx;
             const uint32_t qx = s_qx[lo], qy = s_qy[lo];
             const uint32_t lqx = qx & 2047u, hqx = qx >> 11, lqy = qy & 2047u, hqy = qy >> 11;
@@ -201,6 +206,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
             vals[eg] = s_id[lo] | (qm << EMD_ID_BITS);
             atomicAdd(&s_h0[tile & mask0], 1u);
         }
+        base = end;
         __syncthreads();   // LDS reused by the next block of Gaussians
     }
     if (hist0) hist0[(size_t)threadIdx.x * nblocks_cap + blockIdx.x] = s_h0[threadIdx.x];
@@ -294,13 +300,27 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __r
     __syncthreads();
     const size_t wbase = (size_t)blockIdx.x * EMD_SORT_TILE + (size_t)wave * (EMD_SORT_TILE / 4);
     uint32_t key[EMD_SORT_ITEMS];
+    uint32_t val[EMD_SORT_ITEMS];
     uint32_t rank[EMD_SORT_ITEMS];
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // all loads of the block first (keys, values, the digit rows of the scanned histogram further down): one round trip, not three
+#pragma unroll
+    for (int k = 0; k < EMD_SORT_ITEMS; k++) {
+        const size_t idx = wbase + (size_t)k * 64 + lane;
+        key[k] = idx < D ? keys_in[idx] : 0xFFFFFFFFu;
+        val[k] = FIRST ? (uint32_t)idx : (idx < D ? vals_in[idx] : 0u);
+    }
+    uint32_t h_before[PER], h_tot[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint32_t* row = hist_inc + (size_t)(threadIdx.x * PER + j) * nblocks_cap;       // a thread owns PER consecutive digits
+        h_before[j] = blockIdx.x ? row[blockIdx.x - 1] : 0u;
+        h_tot[j] = row[nblocks_cap - 1];
+    }
 #pragma unroll
     for (int k = 0; k < EMD_SORT_ITEMS; k++) {
         const size_t idx = wbase + (size_t)k * 64 + lane;
         bool valid = idx < D;
-        key[k] = valid ? keys_in[idx] : 0xFFFFFFFFu;
         if (FIRST) valid = valid && key[k] != 0xFFFFFFFFu;          // culled Gaussian: dropped here
         const uint32_t digit = ((key[k] - offset) >> shift) & mask;
         // lanes with the same digit (invalid lanes form their own class and are ignored)
@@ -331,9 +351,8 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __r
             for (int w = 0; w < 4; w++) c[j][w] = s_cnt[w][d];
             csum[j] = c[j][0] + c[j][1] + c[j][2] + c[j][3];
             // keys of digit d in earlier blocks (row-wise inclusive scan) + all keys of smaller digits (row totals)
-            const uint32_t* row = hist_inc + (size_t)d * nblocks_cap;
-            before[j] = blockIdx.x ? row[blockIdx.x - 1] : 0u;
-            dtot[j] = row[nblocks_cap - 1];
+            before[j] = h_before[j];
+            dtot[j] = h_tot[j];
             csum_t += csum[j]; dtot_t += dtot[j];
         }
         uint32_t total;
@@ -364,7 +383,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __r
             const uint32_t digit = ((key[k] - offset) >> shift) & mask;
             const uint32_t pos = s_cnt[wave][digit] + rank[k];
             s_keys[pos] = key[k];
-            s_vals[pos] = FIRST ? (uint32_t)idx : vals_in[idx];
+            s_vals[pos] = val[k];
             nvalid_w++;
         }
     }
@@ -404,6 +423,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_tile_ranges(const uint32_t* __res
 // start first and the kernel's tail is made of short ones (longest-processing-time-first).  Order inside a bucket is
 // arbitrary: it only decides when a tile is rendered, never what is rendered.  One workgroup; above 64 K tiles the
 // identity order is kept (plenty of tiles to fill the tail anyway).
+// (Round 4, measured and dropped: formed by the last workgroup of the range kernel to finish -- a ticket behind a device-scope release
+//  fence.  On gfx950 that fence writes the XCD's L2 back: 4096 workgroups x one fence made the range kernel 0.33 ms instead of 6 us.
+//  The same cost sits under every decoupled look-back scheme, which is why the single-pass scans of round 1 lost as well.)
 #define ORDER_BUCKETS 1024
 __global__ void __launch_bounds__(ORDER_BUCKETS) k_tile_order(const uint32_t* __restrict__ ranges, uint32_t T, uint32_t* __restrict__ order) {
     __shared__ uint32_t s_h[ORDER_BUCKETS];
@@ -478,14 +500,20 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
     if (gx >= 1024 || gy >= 1024) { emd_set_error("image too large: %d x %d tiles (max 1023)", gx, gy); return EMD_ERR_INVALID; }
     const int nb = (N + EMD_BLOCK - 1) / EMD_BLOCK;
     int rc;
-    // 1. visible Gaussians in depth order.  (The status word was cleared by K1: the depth passes may raise its overflow bit 1.)
     emd_prof_switch(PROF_PREPROCESS, PROF_SORT, st);
-    // (the status block was cleared by K1, the launch in front of this stage; with no Gaussians there is no K1)
-    if (N <= 0) { int zrc = emd_zero_async(status, sizeof(EmdStatus), st); if (zrc) return zrc; }
-    uint32_t* const sort_count = &status->reserved;          // V after the first (compacting) depth pass lives in the status block: one memset
+    if (N <= 0) {           // nothing to sort: empty ranges, identity order (the status block was not cleared by a projection kernel)
+        { int zrc = emd_zero_async(status, sizeof(EmdStatus), st); if (zrc) return zrc; }
+        { int zrc = emd_zero_async(b.ranges, (size_t)T * 8, st); if (zrc) return zrc; }
+        hipLaunchKernelGGL(k_tile_order_identity, dim3((T + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, (uint32_t)T, b.tile_order);
+        EMD_LAUNCH_CHECK();
+        emd_prof_switch(PROF_SORT, PROF_RANGES, st);
+        return EMD_OK;
+    }
+    // 1. visible Gaussians in depth order.  (The status word was cleared by K1: the depth passes may raise its overflow bit 1.)
+    uint32_t* const sort_count = &status->reserved;          // V after the first (compacting) depth pass lives in the status block
     const bool wide = (flags & EMD_FLAG_WIDE_DEPTH_SORT) != 0;
     const int depth_passes = wide ? EMD_DEPTH_PASSES_WIDE : EMD_DEPTH_PASSES_NARROW;
-    if (N > 0) {
+    {
         const SortN c0 = {nullptr, nullptr, (uint32_t)N}, cv = {sort_count, nullptr, 0u};
         uint32_t near_bits = 0;
         if (!wide) { const float np = s.near_plane > 0.f ? s.near_plane : 0.f; memcpy(&near_bits, &np, 4); }
@@ -506,34 +534,26 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
         if (rc) return rc;
     }
     const uint32_t* perm = g.gvals[(depth_passes - 1) & 1];
-    // 2. tile counts in that order, offsets, duplicate
+    // 2. the binning records in depth order + block sums; duplicate: every workgroup scans the block sums, finds its 2048 output slots and
+    //    writes their (tile, Gaussian | quadrant mask) pairs; workgroup 0 publishes D / overflow / V
     emd_prof_switch(PROF_SORT, PROF_DUPLICATE, st);
-    if (N == 0 || capacity <= 0) {
-        { int zrc = emd_zero_async(b.ranges, (size_t)T * 8, st); if (zrc) return zrc; }
-        if (N > 0) {   // D and V are still reported (capacity 0 is how callers size the workspace)
-            hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.bin_s,
-                               g.block_sums, b.ranges, 0u);
-            EMD_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(PUB_THREADS), 0, st, g.block_sums, (uint32_t)nb,
-                               (uint64_t)(capacity > 0 ? capacity : 0), status, b.slot_start, 0u);
-            EMD_LAUNCH_CHECK();
-        }
+    const int passes = emd_tile_passes(T), bits = emd_tile_pass_bits(T);
+    hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.bin_s, g.block_sums, b.ranges,
+                       (uint32_t)(2 * T));
+    EMD_LAUNCH_CHECK();
+    if (capacity <= 0) {    // D and V are still reported (capacity 0 is how callers size the workspace)
+        hipLaunchKernelGGL(k_duplicate, dim3(1), dim3(EMD_BLOCK), 0, st, N, gx, g.bin_s, perm, g.block_sums, (uint64_t)0, status, b.tkeys[0], b.vals[0],
+                           (uint32_t*)nullptr, 0u, 1u);
+        EMD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_tile_order_identity, dim3((T + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, (uint32_t)T, b.tile_order);
         EMD_LAUNCH_CHECK();
         emd_prof_switch(PROF_DUPLICATE, PROF_RANGES, st);
         return EMD_OK;
     }
     const uint32_t nslot = (uint32_t)(((size_t)capacity + DUP_SLOTS - 1) / DUP_SLOTS);
-    hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.bin_s,
-                       g.block_sums, b.ranges, (uint32_t)(2 * T));
-    EMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(PUB_THREADS), 0, st, g.block_sums, (uint32_t)nb, (uint64_t)capacity,
-                       status, b.slot_start, nslot);
-    EMD_LAUNCH_CHECK();
-    const int passes = emd_tile_passes(T), bits = emd_tile_pass_bits(T);
     // (the duplicate kernel also builds the digit histogram of the first tile pass: its 2048-slot output blocks are that pass's blocks)
-    hipLaunchKernelGGL(k_duplicate, dim3(nslot), dim3(EMD_BLOCK), 0, st, N, gx, g.bin_s, perm, g.block_sums, b.slot_start,
-                       status, b.tkeys[0], b.vals[0], passes > 0 ? b.hist : nullptr, passes > 0 ? (1u << bits) - 1u : 0u, nslot);
+    hipLaunchKernelGGL(k_duplicate, dim3(nslot), dim3(EMD_BLOCK), 0, st, N, gx, g.bin_s, perm, g.block_sums, (uint64_t)capacity, status,
+                       b.tkeys[0], b.vals[0], passes > 0 ? b.hist : nullptr, passes > 0 ? (1u << bits) - 1u : 0u, nslot);
     EMD_LAUNCH_CHECK();
     // 3. stable partition by tile id
     emd_prof_switch(PROF_DUPLICATE, PROF_SORT, st);

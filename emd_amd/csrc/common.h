@@ -35,7 +35,7 @@ struct GeomWs {
     uint4* bin_s;            // [N] the same records in depth order
     uint32_t* ghist;         // radix histograms of the depth sort [bins][ceil(N / sort tile)]
     uint32_t* sort_count;    // [1] visible Gaussians V: published by the first depth pass (which compacts), read by the later ones
-    uint32_t* block_sums;    // [ceil(N/256)] tile counts per block of depth-ordered Gaussians, inclusive-scanned in place
+    uint32_t* block_sums;    // [ceil(N/256)] pairs emitted per block of 256 depth-ordered Gaussians (added up by the last depth pass)
     size_t bytes;
 };
 
@@ -45,7 +45,6 @@ struct BinWs {
     uint32_t* ranges;        // [T][2]
     uint32_t* tile_order;    // [T] tile ids by descending list length: dispatch order of the render kernels
     uint32_t* hist;          // radix histograms [bins][num_sort_blocks]
-    uint32_t* slot_start;    // [ceil(capacity / 2048)] first block of Gaussians of every output block of the duplicate kernel
     uint32_t* surv;          // [4 * capacity] per (tile, quadrant): the Gaussian ids of the list entries whose footprint reaches the quadrant, in
                              //   list order, written by the render forward for the render backward (at 4 * range start + quadrant * list length)
     uint32_t* quad_need;     // [4 * T] how many of them lie in front of the quadrant's deepest contributor (what the backward walks)
@@ -104,7 +103,7 @@ static inline void emd_carve_geom(void* base, int N, GeomWs* w) {
     w->ghist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_DEPTH_BINS_MAX * 4, 256);
     w->sort_count = (uint32_t*)(p + off); off = emd_align_up(off + 16, 256);
     size_t nb = (n + EMD_BLOCK - 1) / EMD_BLOCK;
-    w->block_sums = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 1) * 4, 256);
+    w->block_sums = (uint32_t*)(p + off); off = emd_align_up(off + (nb + 8) * 4, 256);
     w->bytes = off + 256;
 }
 
@@ -118,7 +117,6 @@ static inline void emd_carve_bin(void* base, int64_t capacity, int num_tiles, Bi
     w->tile_order = (uint32_t*)(p + off); off = emd_align_up(off + (size_t)num_tiles * 4, 256);
     size_t nsb = (cap + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
     w->hist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_RADIX_BINS * 4, 256);
-    w->slot_start = (uint32_t*)(p + off); off = emd_align_up(off + (nsb + 1) * 4, 256);
     w->surv = (uint32_t*)(p + off); off = emd_align_up(off + cap * 16, 256);
     w->quad_need = (uint32_t*)(p + off); off = emd_align_up(off + (size_t)num_tiles * 16, 256);
     w->sorted_buf = emd_tile_passes(num_tiles) & 1;

@@ -437,7 +437,8 @@ def test_elongated_and_faint_footprints_are_not_overculled():
     o = case["opacities"]
     o[: n // 4] = 0.0040 + 0.002 * torch.rand(n // 4, 1, generator=g).reshape(o[: n // 4].shape)      # around 1/255 = 0.0039
     o[n // 4: n // 2] = 0.99
-    orc = run_oracle(case, backward=False)
+    from tests.helpers import compare_render_grads
+    orc = run_oracle(case, backward=True)
     hip = run_hip(case, backward=True)
     compare_forward(hip, orc, tol=IMAGE_TOL)
     st = hip["cull_stats"]
@@ -447,9 +448,8 @@ def test_elongated_and_faint_footprints_are_not_overculled():
     compare_forward(full, orc, tol=IMAGE_TOL)
     for k in ("color", "depth", "alpha", "normal"):
         np.testing.assert_array_equal(full[k], hip[k], err_msg=k)
-    # (needles make the projection backward as ill-conditioned as it gets: the gradients of the two lists are compared with each other --
-    #  the same survivors reach the backward either way -- not with the oracle at the bars of well-conditioned scenes)
-    for k, v in hip["grads"].items():
-        if v is not None and full["grads"].get(k) is not None:
-            ref = full["grads"][k]
-            assert float(np.abs(v - ref).max()) <= 1e-4 * max(float(np.abs(ref).max()), 1e-12), k
+    # The render backward's per-Gaussian sums at the strict bar, for both lists (the same survivors reach the backward either way).
+    # The projection backward behind them is as ill-conditioned as it gets on needles (aspect 2000 : 1 -- a one-ulp move of a conic
+    # gradient moves dL/dmean by percents), so its end-to-end comparison belongs to the well-conditioned scenes of this file.
+    compare_render_grads(hip["render_grads"], orc["grads"]["render_grads"])
+    compare_render_grads(full["render_grads"], orc["grads"]["render_grads"])
