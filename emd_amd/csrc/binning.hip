@@ -56,26 +56,26 @@ __device__ __forceinline__ uint32_t sort_n(const SortN& c) {
 #define DUP_SLOTS EMD_SORT_TILE
 
 // ---------------------------------------------------------------------------------------------------
-// K2': binning records of the Gaussians in depth order (one 16-byte gather each) + the pairs every block of 256 of them emits
+// K2': binning records of the Gaussians in depth order (one 8-byte gather each) + the pairs every block of 256 of them emits
 // ---------------------------------------------------------------------------------------------------
 // (Round 4, measured and dropped: this gather inside the last depth pass's scatter kernel, with the block sums as one float... integer
 //  atomic per (wave, output block) -- 117 k single-lane atomic instructions at ~117 clocks each on the CU's memory path made that pass
 //  78 us instead of 18; as its own launch with 4900 independent workgroups the gather takes 20.)
 __global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32_t* __restrict__ num_sorted,
                                                              const uint32_t* __restrict__ perm,
-                                                             const uint4* __restrict__ binrec,
-                                                             uint4* __restrict__ bin_s,
+                                                             const uint2* __restrict__ binrec,
+                                                             uint2* __restrict__ bin_s,
                                                              uint32_t* __restrict__ block_sums,
                                                              uint32_t* __restrict__ ranges, uint32_t n_ranges) {
     __shared__ uint32_t s_scan[4];
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
-    uint4 br = make_uint4(0u, 0u, 0u, 0u);
+    uint2 br = make_uint2(0u, 0u);
     if (i < N && (uint32_t)i < *num_sorted) br = binrec[perm[i]];         // the depth sort kept the V visible Gaussians only
     if (i < N) bin_s[i] = br;
     // empty tiles keep the range (0, 0): cleared here instead of by a separate memset launch
     for (uint32_t r = (uint32_t)i; r < n_ranges; r += gridDim.x * EMD_BLOCK) ranges[r] = 0u;
     uint32_t total;
-    block_scan_add_u32(br.y & 0xFFFFFu, s_scan, &total);                  // pairs this Gaussian emits
+    block_scan_add_u32(((br.x >> 20) & 1023u) * (br.y & 1023u), s_scan, &total);   // pairs this Gaussian emits: width x height
     if (threadIdx.x == 0) {
         block_sums[blockIdx.x] = total;
         if (blockIdx.x == gridDim.x - 1) { block_sums[gridDim.x] = 0u; block_sums[gridDim.x + 1] = 0u; block_sums[gridDim.x + 2] = 0u; }   // (read as uint4)
@@ -99,12 +99,13 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32
 // everything from here on -- this kernel, both tile passes, the range kernel, the list scans of the render forward -- shrinks with them.
 // Images, radii and gradients are unchanged bit for bit: a pair that is left out is one upstream's render loop skips at every pixel of
 // the tile (its alpha < 1/255 `continue`).  EMD_FLAG_KEEP_ALL_PAIRS restores upstream's list entry for entry.
-// The same box gives every emitted pair the mask of the tile's four 8x8 quadrants that hold a pixel centre inside it (four integer
-// compares here, where the vector units idle); it rides in the top four bits of the list word, and the quadrant waves of the render
+// The same box gives every emitted pair the mask of the tile's four 8x8 quadrants that hold a pixel centre inside it (K1 leaves four
+// bits per Gaussian: is the outer quadrant column / row of the rectangle's first / last tile outside the box); it rides in the top four
+// bits of the list word, and the quadrant waves of the render
 // forward read 4 bytes per list entry and fetch the 64-byte records of their own entries only.  (Measured and dropped on the way: the
 // exact ellipse-rectangle test of footprint.h per pair in this kernel -- its inputs are a 32-byte gather per Gaussian through 128-byte
 // lines, 26 -> 67 us, whatever the arithmetic behind it costs.)
-__global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const uint4* __restrict__ bin_s,
+__global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const uint2* __restrict__ bin_s,
                                                          const uint32_t* __restrict__ perm,
                                                          const uint32_t* __restrict__ block_sums,
                                                          uint64_t capacity, EmdStatus* __restrict__ status,
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
     __shared__ uint32_t s_excl[EMD_BLOCK];     // exclusive offsets inside the block
     __shared__ uint32_t s_rect[EMD_BLOCK];     // x0 | y0 << 10 | width << 20   (grid dims < 1024 tiles = 16K px)
     __shared__ uint32_t s_id[EMD_BLOCK];
-    __shared__ uint32_t s_qx[EMD_BLOCK], s_qy[EMD_BLOCK];   // first | last << 11 quadrant column / row of the alpha >= 1/255 box
+    __shared__ uint32_t s_hs[EMD_BLOCK];       // height | skip-top << 10 | skip-bottom << 11
     __shared__ uint32_t s_h0[EMD_BLOCK];       // digit histogram of tile pass 0 (at most 8 bits per pass)
     s_h0[threadIdx.x] = 0;
     // ---- every workgroup scans the pair counts of the 256-Gaussian blocks itself (the last depth pass left them in block_sums; 7812
@@ -170,16 +171,15 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
     uint32_t base = s_first[1];
     for (uint32_t gb = s_first[0]; gb < nbv && base < S1; gb++) {
         const uint32_t i = gb * EMD_BLOCK + threadIdx.x;
-        const uint4 br = (i < V) ? bin_s[i] : make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t cnt = br.y & 0xFFFFFu;
+        const uint2 br = (i < V) ? bin_s[i] : make_uint2(0u, 0u);
+        const uint32_t cnt = ((br.x >> 20) & 1023u) * (br.y & 1023u);
         uint32_t total;
         const uint32_t inc = block_scan_add_u32(cnt, s_scan, &total);
         const uint32_t end = base + total;
         s_excl[threadIdx.x] = inc - cnt;
         s_rect[threadIdx.x] = br.x;
         s_id[threadIdx.x] = cnt ? perm[i] : 0u;
-        s_qx[threadIdx.x] = (br.y >> 20) | ((br.z >> 20) << 11);
-        s_qy[threadIdx.x] = br.w;
+        s_hs[threadIdx.x] = br.y & 4095u;
         __syncthreads();
         const uint32_t lo_slot = max(S0, base), hi_slot = min(S1, end);
         for (uint32_t eg = lo_slot + threadIdx.x; eg < hi_slot; eg += EMD_BLOCK) {
@@ -194,13 +194,13 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
             }
             const uint32_t local_e = e - s_excl[lo];
             const uint32_t r = s_rect[lo];
-            const uint32_t w = r >> 20, x0 = r & 1023u, y0 = (r >> 10) & 1023u;
-            const uint32_t ty = y0 + local_e / w, tx = x0 + local_e % w;
+            const uint32_t w = (r >> 20) & 1023u, x0 = r & 1023u, y0 = (r >> 10) & 1023u, hs = s_hs[lo];
+            const uint32_t ly = local_e / w, lx = local_e - ly * w;
+            const uint32_t ty = y0 + ly, tx = x0 + lx;
             const uint32_t tile = ty * (uint32_t)gx + tx;
-            const uint32_t qx = s_qx[lo], qy = s_qy[lo];
-            const uint32_t lqx = qx & 2047u, hqx = qx >> 11, lqy = qy & 2047u, hqy = qy >> 11;
-            const bool xl = lqx <= 2u * tx && hqx >= 2u * tx, xr = lqx <= 2u * tx + 1u && hqx >= 2u * tx + 1u;
-            const bool yt = lqy <= 2u * ty && hqy >= 2u * ty, yb = lqy <= 2u * ty + 1u && hqy >= 2u * ty + 1u;
+            // quadrant mask of the pair: everything but the outer quadrant column / row of the rectangle's first / last tile where K1 says so
+            const bool xl = !((r >> 30 & 1u) && lx == 0u), xr = !((r >> 31) && lx == w - 1u);
+            const bool yt = !((hs >> 10 & 1u) && ly == 0u), yb = !((hs >> 11) && ly == (hs & 1023u) - 1u);
             const uint32_t qm = (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
             tkeys[eg] = tile;
             vals[eg] = s_id[lo] | (qm << EMD_ID_BITS);

@@ -26,13 +26,13 @@ struct GeomWs {
     float4* rec;             // [N][4]
     float4* shjac;           // [N][3] d rgb_c / d (unit view direction): row c = (d/dx, d/dy, d/dz, -); written by K1 for
                              // visible Gaussians so that K8 need not re-read the 192 B of SH coefficients
-    uint4* binrec;           // [N] by Gaussian id (K1): x = ENUMERATED tile rectangle x0 | y0 << 10 | width << 20 (upstream's rectangle cut down to the
-                             //   alpha >= 1/255 box), y = pairs emitted | first quadrant column << 20, z = upstream's tiles touched | last quadrant
-                             //   column << 20, w = first | last << 11 quadrant row of that box (8-pixel units)
+    uint2* binrec;           // [N] by Gaussian id (K1): x = ENUMERATED tile rectangle x0 | y0 << 10 | width << 20 (upstream's rectangle cut down to the
+                             //   alpha >= 1/255 box) | skip-left / skip-right << 30, y = its height | skip-top / skip-bottom << 10 | upstream's tiles
+                             //   touched << 12.  A skip bit: the outer quadrant column / row of the rectangle's first / last tile lies outside the box
     uint32_t* depth_key;     // [N] by Gaussian id: float bits of the view depth, 0xFFFFFFFF when not visible (K1)
     uint32_t* gkeys[2];      // [N] ping-pong of the Gaussian depth sort
     uint32_t* gvals[2];      // [N] Gaussian ids in depth order after the sort (gvals[1])
-    uint4* bin_s;            // [N] the same records in depth order
+    uint2* bin_s;            // [N] the same records in depth order
     uint32_t* ghist;         // radix histograms of the depth sort [bins][ceil(N / sort tile)]
     uint32_t* sort_count;    // [1] visible Gaussians V: published by the first depth pass (which compacts), read by the later ones
     uint32_t* block_sums;    // [ceil(N/256)] pairs emitted per block of 256 depth-ordered Gaussians (added up by the last depth pass)
@@ -94,11 +94,11 @@ static inline void emd_carve_geom(void* base, int N, GeomWs* w) {
     const size_t n = (size_t)(N > 0 ? N : 1);
     w->rec = (float4*)(p + off); off = emd_align_up(off + n * EMD_REC_F4 * sizeof(float4), 256);
     w->shjac = (float4*)(p + off); off = emd_align_up(off + n * 3 * sizeof(float4), 256);
-    w->binrec = (uint4*)(p + off); off = emd_align_up(off + n * 16, 256);
+    w->binrec = (uint2*)(p + off); off = emd_align_up(off + n * 8, 256);
     w->depth_key = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256);
     for (int i = 0; i < 2; i++) { w->gkeys[i] = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256); }
     for (int i = 0; i < 2; i++) { w->gvals[i] = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256); }
-    w->bin_s = (uint4*)(p + off); off = emd_align_up(off + n * 16, 256);
+    w->bin_s = (uint2*)(p + off); off = emd_align_up(off + n * 8, 256);
     size_t nsb = (n + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
     w->ghist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_DEPTH_BINS_MAX * 4, 256);
     w->sort_count = (uint32_t*)(p + off); off = emd_align_up(off + 16, 256);

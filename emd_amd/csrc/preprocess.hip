@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
     // the call's four status words are cleared here (the binning kernels behind this launch raise bits in them): no launch of its own
     if (PART != 2 && blockIdx.x == 0 && threadIdx.x < 4 && a.status) reinterpret_cast<uint32_t*>(a.status)[threadIdx.x] = 0u;
-    uint32_t touched = 0, rect = 0, dkey = 0xFFFFFFFFu, emit = 0, qrange = 0, qrange_y = 0;
+    uint32_t touched = 0, rect = 0, rect_h = 0, dkey = 0xFFFFFFFFu, skip = 0;
     int radius_out = 0;
     const float* V = S.viewmatrix;
     float m[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, op = 0.f, sc[3] = {1.f, 1.f, 1.f};
@@ -356,25 +356,26 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
                     const bool off = never || hqxf < 0.f || hqyf < 0.f || lqxf > QMAX || lqyf > QMAX || !(lqxf == lqxf) || !(lqyf == lqyf);
                     const int lqx = (int)fminf(fmaxf(lqxf, 0.f), QMAX), hqx = (int)fminf(fmaxf(hqxf, 0.f), QMAX);
                     const int lqy = (int)fminf(fmaxf(lqyf, 0.f), QMAX), hqy = (int)fminf(fmaxf(hqyf, 0.f), QMAX);
-                    qrange = (uint32_t)lqx | ((uint32_t)hqx << 11);
-                    qrange_y = (uint32_t)lqy | ((uint32_t)hqy << 11);
                     int cx0 = x0, cy0 = y0, cx1 = x1, cy1 = y1;
                     if (!(a.flags & EMD_FLAG_KEEP_ALL_PAIRS)) {
                         cx0 = max(x0, lqx >> 1); cx1 = min(x1, (hqx >> 1) + 1);
                         cy0 = max(y0, lqy >> 1); cy1 = min(y1, (hqy >> 1) + 1);
                         if (off || cx1 <= cx0 || cy1 <= cy0) { cx1 = cx0; cy1 = cy0; }
-                    } else if (off) {
-                        qrange = 2047u; qrange_y = 2047u;              // (lq = 2047 > hq = 0: no quadrant bit for any pair)
-                    }
-                    emit = (uint32_t)((cx1 - cx0) * (cy1 - cy0));
-                    rect = (uint32_t)cx0 | ((uint32_t)cy0 << 10) | ((uint32_t)(cx1 - cx0) << 20);
+                        // Inside the cut rectangle every quadrant lies in the box except, possibly, the outer quadrant column / row of its
+                        // first and last tile: where the rectangle ends at the box (not at upstream's square) and the box starts in the
+                        // right (odd) / ends in the left (even) quadrant column -- rows likewise.  Four bits give every pair its mask.
+                        skip = ((cx0 == (lqx >> 1) && (lqx & 1)) ? 1u : 0u) | ((cx1 - 1 == (hqx >> 1) && !(hqx & 1)) ? 2u : 0u) |
+                               ((cy0 == (lqy >> 1) && (lqy & 1)) ? 4u : 0u) | ((cy1 - 1 == (hqy >> 1) && !(hqy & 1)) ? 8u : 0u);
+                    }       // (with every pair kept the masks are all ones: the render forward's own sub-block test decides)
+                    rect = (uint32_t)cx0 | ((uint32_t)cy0 << 10) | ((uint32_t)(cx1 - cx0) << 20) | ((skip & 3u) << 30);
+                    rect_h = (uint32_t)(cy1 - cy0) | ((skip >> 2) << 10);
                 }
             }
         }
         a.radii[i] = radius_out;
-        // binning input (by Gaussian id): x = enumerated tile rectangle x0 | y0 << 10 | width << 20, y = pairs it emits | first quadrant column << 20,
-        // z = upstream's tiles touched | last quadrant column << 20, w = first | last << 11 quadrant row
-        a.g.binrec[i] = make_uint4(rect, emit | ((qrange & 2047u) << 20), touched | ((qrange >> 11) << 20), qrange_y);
+        // binning input (by Gaussian id), 8 bytes: x = ENUMERATED tile rectangle x0 | y0 << 10 | width << 20 | skip-left/right bits << 30,
+        // y = its height | skip-top/bottom bits << 10 | upstream's tiles touched << 12
+        a.g.binrec[i] = make_uint2(rect, rect_h | (touched << 12));
         a.g.depth_key[i] = dkey;                         // key of the depth sort (invisible: sorts last)
     }
     const bool vis = touched != 0u;
@@ -990,12 +991,12 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_densification_stats(int n, const 
     if (max_radii) max_radii[i] = fmaxf(max_radii[i], (float)r);
 }
 
-__global__ void __launch_bounds__(EMD_BLOCK) k_export_geometry(int N, const float4* rec, const uint4* binrec,
+__global__ void __launch_bounds__(EMD_BLOCK) k_export_geometry(int N, const float4* rec, const uint2* binrec,
                                                                float* means2D, float* depths, float* conic_opacity,
                                                                float* rgb, float* normal, uint32_t* tiles_touched) {
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
     if (i >= N) return;
-    const uint32_t tt = binrec[i].z & 0xFFFFFu;          // upstream's tiles touched (the enumerated rectangle may be smaller)
+    const uint32_t tt = binrec[i].y >> 12;               // upstream's tiles touched (the enumerated rectangle may be smaller)
     const bool vis = tt != 0;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 r0 = vis ? rec[(size_t)i * EMD_REC_F4] : z, r1 = vis ? rec[(size_t)i * EMD_REC_F4 + 1] : z,
