@@ -1119,12 +1119,13 @@ __global__ void k_actor_pose_backward(int A, const float* __restrict__ q_f, cons
 // L1 photometric loss (S3Gaussian/utils/loss_utils.py:21-22, train.py:226): mean |a - b| and its gradient
 // sign(a - b) / n in one pass (the reference spends ~9 element-wise launches on it per step).
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(EMD_BLOCK) k_l1_loss(size_t n, const float* __restrict__ a, const float* __restrict__ b,
-                                                       float inv_n, float* __restrict__ loss, float* __restrict__ grad) {
-    __shared__ float s_part[4];
+#define L1_THREADS 1024      // (the block count is capped by the same-address atomics below: wide blocks keep enough bytes in flight)
+__global__ void __launch_bounds__(L1_THREADS) k_l1_loss(size_t n, const float* __restrict__ a, const float* __restrict__ b,
+                                                        float inv_n, float* __restrict__ loss, float* __restrict__ grad) {
+    __shared__ float s_part[L1_THREADS / 64];
     float acc = 0.f;
-    const size_t n4 = n / 4, stride = (size_t)gridDim.x * EMD_BLOCK;
-    for (size_t i = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; i < n4; i += stride) {
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * L1_THREADS;
+    for (size_t i = (size_t)blockIdx.x * L1_THREADS + threadIdx.x; i < n4; i += stride) {
         const float4 x = ((const float4*)a)[i], y = b ? ((const float4*)b)[i] : make_float4(0.f, 0.f, 0.f, 0.f);   // b == NULL: mean |a|
         const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
         acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
@@ -1133,7 +1134,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_l1_loss(size_t n, const float* __
             ((float4*)grad)[i] = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
         }
     }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; i < n; i += stride) {
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * L1_THREADS + threadIdx.x; i < n; i += stride) {
         const float d = a[i] - (b ? b[i] : 0.f);
         acc += fabsf(d);
         if (grad) grad[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
@@ -1141,7 +1142,12 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_l1_loss(size_t n, const float* __
     acc = wave_reduce_to_lane63(acc);
     if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) * inv_n);
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < L1_THREADS / 64; w++) t += s_part[w];
+        atomicAdd(loss, t * inv_n);
+    }
 }
 
 // gradient of w * mean |x| with the upstream gradient g on the DEVICE: out[i] = sign(x[i]) * g[0] / n -- one pass, no host read of g
@@ -1317,10 +1323,10 @@ int emd_launch_actor_pose_backward(int A, const float* q, const float* dt, const
 int emd_launch_l1_loss(size_t n, const float* a, const float* b, float* loss, float* grad, hipStream_t st) {
     { int zrc = emd_zero_async(loss, sizeof(float), st); if (zrc) return zrc; }
     if (n == 0) return EMD_OK;
-    size_t blocks = (n / 4 + EMD_BLOCK - 1) / EMD_BLOCK;
+    size_t blocks = (n / 4 + L1_THREADS - 1) / L1_THREADS;
     if (blocks > 512) blocks = 512;     // one same-address float atomic per block: 2048 of them serialised for ~20 us
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(k_l1_loss, dim3((unsigned)blocks), dim3(EMD_BLOCK), 0, st, n, a, b, 1.0f / (float)n, loss, grad);
+    hipLaunchKernelGGL(k_l1_loss, dim3((unsigned)blocks), dim3(L1_THREADS), 0, st, n, a, b, 1.0f / (float)n, loss, grad);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }
