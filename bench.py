@@ -173,19 +173,7 @@ CONFIGS = {
 }
 
 
-def select_step_inputs(sel, table, out_row, frames=None, frame_out=None, t_out=None, num_frames=1, k_sched=None, k_fine_out=None,
-                       status=None, status_log=None, prev_sel=None, next_sel=None):
-    """emd_select_step_inputs: everything a replayed step reads at fixed device addresses, written by ONE launch."""
-    import ctypes as C
-    from emd_amd import _lib as L
-    a = L.EmdStepSelect()
-    a.sel, a.rows, a.row_floats = sel.data_ptr(), table.shape[0], table.shape[1]
-    a.table, a.out_row = table.data_ptr(), out_row.data_ptr()
-    a.frames, a.frame_out, a.t_out, a.num_frames = L.ptr(frames), L.ptr(frame_out), L.ptr(t_out), int(num_frames)
-    a.k_min, a.k_max, a.k_until = k_sched if k_sched is not None else (1, 1, 1)
-    a.steps, a.k_fine_out = None, L.ptr(k_fine_out)
-    a.status, a.status_log, a.prev_sel, a.next_sel = L.ptr(status), L.ptr(status_log), L.ptr(prev_sel), L.ptr(next_sel)
-    L.check(L.load().emd_select_step_inputs(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_select_step_inputs")
+from emd_amd.graphs import select_step_inputs          # noqa: E402  (emd_select_step_inputs: the per-step inputs of a replayed step, one launch)
 
 
 def main():
@@ -300,7 +288,6 @@ def main():
     total_steps = args.warmup + args.steps * (1 + max(args.repeats, 0))
     for s_ in range(args.warmup + args.steps):          # the cameras are dataset state: built (and their centres uploaded) before timing
         cam_for(s_)
-    from emd_amd import rasterizer as _rz
     sync_opts = opts.replace(no_sync=False)
     out = one_step(0, sync_opts, backward=not cfg["forward_only"])
     dmax = out["raster_call"].last_status()["num_rendered"]
@@ -309,7 +296,7 @@ def main():
             f, c, cam = cam_for(s_)
             o = render(model, cam, bg, frame=f, options=sync_opts)
             dmax = max(dmax, o["raster_call"].last_status()["num_rendered"])
-    _rz._capacity_hint[(dev.index, H, W)] = int(dmax * 1.3) + 1024
+    opts.capacity_hint = int(dmax * 1.3) + 1024          # (an option of this run's calls: nothing process-wide is written)
 
     if cfg["forward_only"]:
         return bench_forward_only(args, cfg, scene, model, render, cam_for, bg, opts, _lib, N, H, W, rank)
@@ -526,10 +513,13 @@ def main():
         # V and D of EVERY timed step (device status words of rank 0's views), not of one frame
         Ds, Vs = st_all[:, 0], st_all[:, 2]
         D, V = float(Ds.mean()), float(Vs.mean())
+        # the roofline's algorithmic bytes use D and V of the SAME steps the stage durations were measured over (the eager repetitions of the
+        # first `prof_steps` timed steps behind a graph run; every timed step otherwise), so achieved / frac are self-consistent for any --steps
+        Dp, Vp = float(Ds[:prof_steps].mean()), float(Vs[:prof_steps].mean())
         T = ((W + 15) // 16) * ((H + 15) // 16)
         C = 7 if opts.compute_normal else 4
         passes = (max(T - 1, 1).bit_length() + 7) // 8            # radix passes over the D duplicates (tile bits)
-        ab = algorithmic_bytes(N, V, D, H * W, T, C, passes, C_bwd=4)   # the L1 loss sends no gradient into the normal image
+        ab = algorithmic_bytes(N, Vp, Dp, H * W, T, C, passes, C_bwd=4)   # the L1 loss sends no gradient into the normal image
         stages = {}
         for name, (ms, cnt) in prof.items():
             if cnt and name in ab:
@@ -553,7 +543,9 @@ def main():
                     "stage_durations_measured_over": stage_region,
                     "per_step": {"steps": int(len(Ds)), "D_min": int(Ds.min()), "D_mean": round(D, 1), "D_max": int(Ds.max()),
                                  "V_min": int(Vs.min()), "V_mean": round(V, 1), "V_max": int(Vs.max()),
-                                 "note": "duplicates D and visible Gaussians V of every timed step, read from the device status words after the timed region; algorithmic bytes use the means"},
+                                 "D_mean_profiled_steps": round(Dp, 1), "V_mean_profiled_steps": round(Vp, 1),
+                                 "note": "list entries D (the (tile, Gaussian) pairs inside the Gaussians' alpha >= 1/255 boxes) and visible Gaussians V of every timed step, read from "
+                                         "the device status words after the timed region; the algorithmic bytes use the means over the steps the stage durations were measured on"},
                     "whole_iter": {"algorithmic_GB": round(total_alg / 1e9, 3), "kernel_ms": round(kernel_ms, 3),
                                    "GBps": round(total_alg / 1e9 / (kernel_ms * 1e-3), 1),
                                    "frac": round(total_alg / 1e9 / (kernel_ms * 1e-3) / HBM_PEAK_GBS, 4)},

@@ -6,6 +6,6 @@ hand-written HIP for gfx950 behind the C ABI of include/emd_raster.h.
 """
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, RasterCall, RasterConfig, RasterOptions  # noqa: F401
 
-from .graphs import StepGraphs  # noqa: F401
+from .graphs import StepGraphs, StepInputs  # noqa: F401
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "RasterCall", "RasterConfig", "RasterOptions", "StepGraphs"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "RasterCall", "RasterConfig", "RasterOptions", "StepGraphs", "StepInputs"]

@@ -81,7 +81,7 @@ class EmdSkyArgs(C.Structure):
     _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("resolution", C.c_int32), ("flags", C.c_int32),
                 ("cube", _f), ("dirs", _f), ("Kinv", C.c_float * 9), ("R", C.c_float * 9), ("T", C.c_float * 3),
                 ("jitter", _f), ("acc", _f), ("mask_threshold", C.c_float), ("fill", C.c_float), ("fg", _f),
-                ("sky", _f), ("out", _f)]
+                ("sky", _f), ("out", _f), ("camera_dev", _f)]
 
 
 class EmdSkyBwdArgs(C.Structure):

@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_track_heads(EmdTrackArgs a, EmdTra
     const int act = blockIdx.x, lane = threadIdx.x, dim = a.dim, E = a.embed_dim, width = dim + E;
     const float* w = a.weight + (size_t)act * a.rows * dim;
     const float t = a.t_dev ? a.t_dev[0] : a.t;
-    const int k_fine = a.k_fine_dev ? a.k_fine_dev[0] : a.k_fine;
+    const int k_fine = a.k_fine_dev ? min(max(a.k_fine_dev[0], 1), a.rows) : a.k_fine;      // (a device-side level is clamped into the table)
     const TeSample sc = te_rows(t, a.k_coarse, a.rows), sf = te_rows(t, k_fine, a.rows);
     float hc = 0.f, hf = 0.f;
     if (lane < dim) { hc = te_column(w, dim, sc, lane, 0.f, nullptr); hf = te_column(w, dim, sf, lane, 0.f, nullptr); }
@@ -408,7 +408,9 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
     const int act = blockIdx.x, A = a.num_actors, dim = a.dim, E = a.embed_dim, width = dim + E;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lo = a.segment_start[act], hi = a.segment_start[act + 1];
-    const int frame = p.frame_dev ? p.frame_dev[0] : p.frame;
+    // a frame / level that arrives from the DEVICE (a step replayed from a hipGraph) is clamped into the tables it indexes: the host can
+    // only validate the values it passes itself (a select table built for another clip length would otherwise read and write out of bounds)
+    const int frame = p.frame_dev ? min(max(p.frame_dev[0], 0), p.num_frames - 1) : p.frame;
     // wave 0's loads and arithmetic that do not depend on the embedding sums (temporal rows, head weights, the frame's pose row) are
     // issued FIRST: they overlap the segment sum / the clears of the other waves instead of following them (the kernel is pure latency)
     float hc_t = 0.f, hf_t = 0.f, wrow[8], hbias[8], cnt = 1.f, qf[4] = {1.f, 0.f, 0.f, 0.f}, tf[3] = {0.f, 0.f, 0.f}, vflag = 1.f;
@@ -418,7 +420,7 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
     if (wave == 0) {
         const float* w = a.weight + (size_t)act * a.rows * dim;
         const float t = a.t_dev ? a.t_dev[0] : a.t;
-        const int k_fine = a.k_fine_dev ? a.k_fine_dev[0] : a.k_fine;
+        const int k_fine = a.k_fine_dev ? min(max(a.k_fine_dev[0], 1), a.rows) : a.k_fine;
         sc = te_rows(t, a.k_coarse, a.rows); sf = te_rows(t, k_fine, a.rows);
         cnt = a.count[act];
         if (lane < dim) { hc_t = te_column(w, dim, sc, lane, 0.f, nullptr); hf_t = te_column(w, dim, sf, lane, 0.f, nullptr); }

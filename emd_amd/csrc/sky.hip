@@ -84,7 +84,8 @@ __device__ __forceinline__ void pixel_ray(const EmdSkyArgs& a, int px, int py, s
     if (a.dirs) { dx = a.dirs[3 * p]; dy = a.dirs[3 * p + 1]; dz = a.dirs[3 * p + 2]; return; }
     const float ox = a.jitter ? a.jitter[2 * p] : 0.5f, oy = a.jitter ? a.jitter[2 * p + 1] : 0.5f;
     const float X = (float)px + ox, Y = (float)py + oy;
-    const float* Ki = a.Kinv; const float* R = a.R; const float* T = a.T;
+    const float* Ki = a.camera_dev ? a.camera_dev : a.Kinv;           // (device copy of the 21 floats: a recorded pass serves every camera)
+    const float* R = a.camera_dev ? a.camera_dev + 9 : a.R; const float* T = a.camera_dev ? a.camera_dev + 18 : a.T;
     // pixel_camera = (X, Y, 1) Kinv^T ; pixel_world = (pixel_camera - T) R ; rays_o = -(R^T T)
     float pc[3], ro[3], pw[3];
 #pragma unroll

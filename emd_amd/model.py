@@ -70,8 +70,32 @@ class StreetGaussians(torch.nn.Module):
         return actor_pose_table(self.instances_quats, self.instances_trans, self.instances_fv, frame, None, None)
 
 
+def mix_dynamic_static(opacity_dynamic, opacity_static, shs_dynamic=None, shs_static=None, colors_dynamic=None, colors_static=None):
+    """The `combine_dynamic_static` mixing of the reference's render() (S3Gaussian/gaussian_renderer/__init__.py:118-138; flag default off,
+    arguments/gaussian_options.py:195): the deformed ("dynamic") and the undeformed ("static") copy of every Gaussian are drawn as ONE
+    Gaussian whose ACTIVATED opacities add up (the sum may exceed 1; the rasterizer clamps alpha at 0.99) and whose colour is their
+    opacity-weighted mean -- of the SH coefficients, or of the precomputed colours when those are given.  Plain tensor arithmetic in the
+    reference's order of operations -> (opacity, shs or None, colors or None)."""
+    total = opacity_dynamic + opacity_static
+    dynamic_ratio, static_ratio = opacity_dynamic / total, opacity_static / total
+    if colors_dynamic is not None:
+        return total, None, colors_dynamic * dynamic_ratio + colors_static * static_ratio
+    n, tail = shs_dynamic.shape[0], shs_dynamic.shape[1:]
+    shs = shs_dynamic.view(n, -1) * dynamic_ratio + shs_static.view(n, -1) * static_ratio
+    return total, shs.view(-1, *tail), None
+
+
+def pre_compute_colors(shs, xyz, camera_center, degree):
+    """SH -> RGB on the host side of the boundary (`convert_SHs_python`, gaussian_renderer/__init__.py:19-25): directions from the
+    UNDEFORMED means, emd_sh_forward (HIP), + 0.5, clamp at 0."""
+    from .gsplat_api import spherical_harmonics
+    dirs = xyz - camera_center.to(xyz.device).reshape(1, 3)
+    return torch.clamp_min(spherical_harmonics(degree, dirs, shs) + 0.5, 0.0)
+
+
 def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activations=True, deformation=None, embeddings=None,
-           iteration=None, time=None, options=None, record=None, render_feat=False, need_feat=True):
+           iteration=None, time=None, options=None, record=None, render_feat=False, need_feat=True, combine_dynamic_static=False,
+           convert_SHs_python=False):
     """The reference render() restricted to the hot path; returns the dict the training loop consumes.
     `deformation` (an emd_amd.deformation.deform_network) switches on the "fine" stage of gaussian_renderer/__init__.py:86-96:
     the residuals of the self-supervised EMD network are added to the raw parameters before the activations.
@@ -80,7 +104,10 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
     `render_feat` (with a deformation network that has the feature head): the reference's two feature passes
     (`colors_precomp = ddict["coarse"]["feat"]` / `["fine"]["feat"]`, gaussian_renderer/__init__.py:170-201) as extra colour
     sets of the SAME rasterizer call -> out["feat_c"], out["feat_f"]: one projection, one sort, one list walk instead of three.
-    `need_feat=False` (with an emd_amd deform_network): nobody will read ddict[...]["feat"], so the feature head is not evaluated."""
+    `need_feat=False` (with an emd_amd deform_network): nobody will read ddict[...]["feat"], so the feature head is not evaluated.
+    `combine_dynamic_static` (fine stage; the reference's args.combine_dynamic_static, :118-138): the deformed and the undeformed copy of
+    every Gaussian drawn as one (mix_dynamic_static); `convert_SHs_python` evaluates the colours in front of the boundary (:106-110),
+    which is also the only configuration in which the reference's own decomposition passes run with that flag (render_decomposition)."""
     dev = model._xyz.device
     # the reference's zero "screen-space points" leaf that only collects dL/dmean2D: the zeros are never written, so one
     # cached buffer per model serves every step (a fresh leaf view each time, no 24 MB fill launch)
@@ -100,11 +127,40 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         means3D, scales, rotations, opacity, shs, ddict = deformation(
             means3D, scales, rotations, opacity, shs, times_sel, embeddings, iteration, int(getattr(cam, "cam_no", 0)),
             getattr(cam, "time_diff", 0.0), True, **extra_kw)
-    if not fuse_activations:
-        # (fused: the three activations of the reference run inside K1 / K8 (raw_params), not as ~25 separate torch launches)
-        scales = torch.exp(scales)
-        rotations = F.normalize(rotations)
-        opacity = torch.sigmoid(opacity)
+    colors_precomp, combined = None, None
+
+    def summed_shs():
+        """shs + the residuals an emd_amd network hands over unsummed (formed inside the projection kernel on the usual path)"""
+        t = shs
+        for r_ in ((ddict.get("shs_residuals") if ddict is not None else None) or []):
+            t = t + r_
+        if ddict is not None and ddict.get("shs_residuals"):
+            ddict["shs_residuals"] = None
+        return t
+    if combine_dynamic_static and deformation is not None:
+        # the mixing works on ACTIVATED opacities (they are added): the three activations run here, as in the reference (:99-101,114-116)
+        fuse_activations = False
+        shs_dyn = summed_shs()
+        o_dyn, o_sta = torch.sigmoid(opacity), torch.sigmoid(model._opacity)
+        sc_sta, rot_sta = torch.exp(model._scaling), F.normalize(model._rotation)
+        scales, rotations = torch.exp(scales), F.normalize(rotations)
+        col_dyn = col_sta = None
+        if convert_SHs_python:
+            col_dyn = pre_compute_colors(shs_dyn, model._xyz, cam.camera_center, model.active_sh_degree)
+            col_sta = pre_compute_colors(model._features, model._xyz, cam.camera_center, model.active_sh_degree)
+        opacity, shs, colors_precomp = mix_dynamic_static(o_dyn, o_sta, shs_dyn, model._features, col_dyn, col_sta)
+        combined = dict(dynamic=dict(means3D=means3D, shs=None if convert_SHs_python else shs_dyn, colors_precomp=col_dyn, opacities=o_dyn,
+                                     scales=scales, rotations=rotations),
+                        static=dict(means3D=model._xyz, shs=None if convert_SHs_python else model._features, colors_precomp=col_sta,
+                                    opacities=o_sta, scales=sc_sta, rotations=rot_sta))
+    else:
+        if convert_SHs_python:
+            colors_precomp, shs = pre_compute_colors(summed_shs(), model._xyz, cam.camera_center, model.active_sh_degree), None
+        if not fuse_activations:
+            # (fused: the three activations of the reference run inside K1 / K8 (raw_params), not as ~25 separate torch launches)
+            scales = torch.exp(scales)
+            rotations = F.normalize(rotations)
+            opacity = torch.sigmoid(opacity)
     kw = {}
     feat_sets = []
     if render_feat and ddict is not None:
@@ -119,13 +175,14 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         it = 0 if iteration is None else (iteration if isinstance(iteration, (torch.Tensor, DeviceStep)) else int(iteration))
         kw.update(actor_ids=model.actor_id, actor_pose=model.actor_pose(frame, it))
     image, depth, normal, weight, radii, extra = rasterizer(
-        means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opacity,
-        scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, raw_params=fuse_activations, record=record, **kw)
+        means3D=means3D, means2D=screenspace_points, shs=None if colors_precomp is not None else shs, colors_precomp=colors_precomp,
+        opacities=opacity, scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, raw_params=fuse_activations,
+        record=record, **kw)
     out = _RenderOutputs({"render": image, "viewspace_points": screenspace_points, "radii": radii,
            "depth": depth, "weight": weight, "normal": normal, "actor_pose": kw.get("actor_pose"), "ddict": ddict,
            "raster_call": rasterizer.last_call, "rasterizer": rasterizer,
-           "boundary": dict(means3D=means3D, opacities=opacity, scales=scales, rotations=rotations, shs=shs, raw_params=fuse_activations,
-                            shs_residuals=shs_res)})
+           "boundary": dict(means3D=means3D, opacities=opacity, scales=scales, rotations=rotations, shs=None if colors_precomp is not None else shs,
+                            colors_precomp=colors_precomp, raw_params=fuse_activations, shs_residuals=shs_res, combined=combined)})
     for (lvl, _), img in zip(feat_sets, extra or []):
         out["feat_c" if lvl == "coarse" else "feat_f"] = img
     return out
@@ -154,8 +211,8 @@ class _RenderOutputs(dict):
 
 
 def render_decomposition(out, levels=("coarse", "fine", "coarse_fine"), top_fraction=0.005):
-    """The evaluation-time decomposition passes of the reference's render() (`return_decomposition`, stage "fine", the branch without
-    `combine_dynamic_static`: S3Gaussian/gaussian_renderer/__init__.py:203-294), from the dict `render(..., deformation=...)` returned:
+    """The evaluation-time decomposition passes of the reference's render() (`return_decomposition`, stage "fine":
+    S3Gaussian/gaussian_renderer/__init__.py:203-294; both branches of `combine_dynamic_static`), from the dict `render(..., deformation=...)` returned:
     per level of the deformation (coarse dx, fine dx, and their difference) (a) the `top_fraction` of the Gaussians that move farthest,
     rendered alone -- a boolean-mask subset of every boundary tensor through the SAME rasterizer object -- and (b) the whole scene coloured
     by |dx| / max |dx| (`colors_precomp`).  Returns {"coarse_render": {render, depth, color, weight, normal, dx}, ...} as the reference's
@@ -167,6 +224,7 @@ def render_decomposition(out, levels=("coarse", "fine", "coarse_fine"), top_frac
     if dx["coarse"] is not None and dx["fine"] is not None:
         dx["coarse_fine"] = dx["coarse"] - dx["fine"]
     res = {}
+    comb = bd.get("combined")
     with torch.no_grad():
         shs_all = bd["shs"]
         for r_ in (bd.get("shs_residuals") or []):           # (handed to the main pass unsummed)
@@ -179,13 +237,24 @@ def render_decomposition(out, levels=("coarse", "fine", "coarse_fine"), top_frac
             if d is None:
                 continue
             d_abs = d.detach().abs()
-            dist = d_abs.norm(dim=1)
-            k = int(dist.shape[0] * top_fraction)
-            mask = torch.zeros_like(dist, dtype=torch.bool)
-            if k > 0:
-                mask[torch.topk(dist, k)[1]] = True
-            sub = {n_: (v[mask] if isinstance(v, torch.Tensor) else v) for n_, v in base.items()}
-            img_d, depth_d, normal_d, weight_d, _, _ = rast(means3D=bd["means3D"][mask], means2D=m2d[mask], shs=shs_all[mask], colors_precomp=None, **sub)
+            if comb is not None:
+                # combine_dynamic_static (:206-231): no top-0.5 % subset -- the coarse level shows the DYNAMIC copies (deformed means, their own
+                # opacity and colour), the fine and coarse - fine levels the STATIC ones.  (The reference reaches these passes only with
+                # precomputed colours: with SH colours its `colors_precomp_static` is unassigned, :214; here both colour forms work.)
+                part = comb["dynamic" if lvl == "coarse" else "static"]
+                img_d, depth_d, normal_d, weight_d, _, _ = rast(means3D=part["means3D"], means2D=m2d, shs=part["shs"], colors_precomp=part["colors_precomp"],
+                                                               opacities=part["opacities"], scales=part["scales"], rotations=part["rotations"],
+                                                               cov3Ds_precomp=None, extra_attrs=None)
+            else:
+                dist = d_abs.norm(dim=1)
+                k = int(dist.shape[0] * top_fraction)
+                mask = torch.zeros_like(dist, dtype=torch.bool)
+                if k > 0:
+                    mask[torch.topk(dist, k)[1]] = True
+                sub = {n_: (v[mask] if isinstance(v, torch.Tensor) else v) for n_, v in base.items()}
+                cp = bd.get("colors_precomp")
+                img_d, depth_d, normal_d, weight_d, _, _ = rast(means3D=bd["means3D"][mask], means2D=m2d[mask], shs=None if cp is not None else shs_all[mask],
+                                                               colors_precomp=None if cp is None else cp[mask], **sub)
             col = d_abs / d_abs.max(dim=0, keepdim=True)[0]
             color_dx = rast(means3D=bd["means3D"], means2D=m2d, shs=None, colors_precomp=col, **base)[0]
             res[lvl + "_render"] = {"render": img_d, "depth": depth_d, "color": color_dx, "weight": weight_d, "normal": normal_d, "dx": d}

@@ -286,7 +286,8 @@ class _TrackedPose(torch.autograd.Function):
         d_heads = [v.view_as(h) for v, h in zip(torch.split(acc, [h.numel() for h in heads]), heads)]
         p = _TrackedPose._args(weight, emb, heads, ids32, cnt, seg, t, k_c, k_f, emb_sum, q_all, t_all, ctx.valid, frame, None)
         g = L.EmdTrackedPoseGrads()
-        g.g_pose = g_pose.contiguous().float().data_ptr()
+        g_pose_c = g_pose.contiguous().float()           # (kept in a local until the launch has been issued: a temporary could be freed)
+        g.g_pose = g_pose_c.data_ptr()
         g.d_q_all, g.d_t_all, g.d_weight, g.d_embeddings = d_q.data_ptr(), d_t.data_ptr(), d_weight.data_ptr(), d_emb.data_ptr()
         for h in range(4):
             g.d_head_w[h], g.d_head_b[h] = d_heads[2 * h].data_ptr(), d_heads[2 * h + 1].data_ptr()

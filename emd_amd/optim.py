@@ -44,18 +44,31 @@ class Adam(torch.optim.Optimizer):
         """Device-resident step counts (views of one buffer: a single add advances them all) and learning rates."""
         plist = [p for g in self.param_groups for p in g["params"]]
         dev = plist[0].device
-        if self._step_buf is None or self._step_buf.numel() != len(plist) or self._step_buf.device != dev:
+        # The step counts live in ONE buffer (state[p]["step"] are views of it).  It is rebuilt from the per-parameter state whenever that
+        # state no longer IS the buffer: load_state_dict or the densification surgery replaced `state[p]` (then its step is a plain number,
+        # a fresh tensor, or missing: a parameter whose state was dropped starts again at 0), or the parameter list changed.
+        def is_view(i, p):
+            st = self.state.get(p)
+            t = None if not st else st.get("step")
+            return (self._step_buf is not None and isinstance(t, torch.Tensor) and t.device == self._step_buf.device and t.numel() == 1
+                    and t.data_ptr() == self._step_buf.data_ptr() + 4 * i)
+        if self._step_buf is None or self._step_buf.numel() != len(plist) or self._step_buf.device != dev or \
+                not all(is_view(i, p) for i, p in enumerate(plist)):
             old = [float(self.state[p]["step"]) if p in self.state and "step" in self.state[p] else 0.0 for p in plist]
             self._step_buf = torch.tensor(old, dtype=torch.float32, device=dev)
         for i, p in enumerate(plist):
             st = self.state[p]
-            if len(st) == 0:
+            if len(st) == 0 or "exp_avg" not in st:
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["step"] = self._step_buf[i]
         for gi, g in enumerate(self.param_groups):
             if gi not in self._lr_dev or self._lr_dev[gi].device != dev:
                 self._lr_dev[gi] = torch.full((1,), float(g["lr"]), dtype=torch.float32, device=dev)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._step_buf = None          # the loaded step counts are the truth: the device buffer is rebuilt from them at the next step
 
     def push_lrs(self):
         """capturable: upload the groups' current learning rates (call after changing `param_groups[i]["lr"]`, outside a capture)."""

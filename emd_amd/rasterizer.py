@@ -60,6 +60,9 @@ class RasterOptions:
     no_sync: bool = False           # True: never read the duplicate count back (overflow surfaces lazily, see RasterCall)
     capacity_margin: float = 1.25   # head-room applied to the last observed duplicate count
     min_capacity: int = 1 << 16
+    capacity_hint: int = 0          # a binning capacity the caller knows to be large enough ((tile, Gaussian) pairs; e.g. measured over the clip with
+                                    # synchronising forwards): calls made with these options never start below it.  0: the binding's own
+                                    # per-(device, H, W) cache of the last observed count decides alone
     absgrad: bool = False           # also accumulate sum |d/d mean2D| (RasterCall.absgrad and `means2D.absgrad`, as gsplat does)
     clamp_rgb01: bool = False       # OmniRe colour clamp
     keep_render_grads: bool = False  # tests: keep the per-Gaussian accumulator rows of the render backward (RasterCall.render_grads, [N, 12+])
@@ -137,6 +140,19 @@ class RasterCall:
                                                L.ptr(out["normal"]), out["tiles_touched"].data_ptr(), _stream()),
                 "emd_raster_export_geometry")
         return out
+
+
+def prepare_backward_workspace(device, num_gaussians, num_extra=0, stream=None):
+    """Seed the kept-clean accumulator rows of the render backward for `stream` (default: the current one) with an eagerly zero-filled
+    buffer.  Steps recorded into hipGraphs on that stream then share it (every backward hands it back clean) instead of clearing a
+    buffer of their own inside each graph.  emd_amd.StepGraphs calls this for its capture stream."""
+    dev = torch.device(device)
+    st = torch.cuda.current_stream(dev) if stream is None else stream
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), st.cuda_stream, max(int(num_gaussians), 1) * (L.BWD_STRIDE + 4 * int(num_extra)))
+    if key not in _clean_ws:
+        with torch.cuda.stream(st):
+            _clean_ws[key] = torch.zeros(key[2], device=dev, dtype=torch.float32)
+    return key
 
 
 # ---- binning-capacity hints ------------------------------------------------------------------------------------------------
@@ -218,13 +234,17 @@ def _settings_values(rs):
             dev = t.device
         parts.append(t)
     tan_dev = isinstance(rs.tanfovx, torch.Tensor) and rs.tanfovx.device.type != "cpu"
-    if dev is not None and not tan_dev and all(p.device == dev and p.is_contiguous() for p in parts):
-        # the four already sit back to back in ONE device buffer in the block's order (a caller that keeps its cameras packed on the
-        # device, e.g. behind emd_select_step_inputs): hand that memory over as it is -- no concat launch
-        base, off, packed = parts[0].data_ptr(), 0, True
-        for p in parts:
-            packed = packed and p.data_ptr() == base + 4 * off
-            off += p.numel()
+    if dev is not None and all(p.device == dev and p.is_contiguous() for p in parts):
+        # the four (and, when they are device tensors too, tanfovx / tanfovy right behind them) already sit back to back in ONE device buffer
+        # in the block's order (a caller that keeps its cameras packed on the device: emd_amd.StepInputs, bench.py): hand that memory over
+        # as it is -- no concat launch
+        seq = list(parts)
+        if tan_dev:
+            seq += [rs.tanfovx.detach().reshape(-1), rs.tanfovy.detach().reshape(-1)]
+        base, off, packed = parts[0].data_ptr(), 0, all(q.dtype == torch.float32 and q.device == dev and q.is_contiguous() for q in seq)
+        for q in seq:
+            packed = packed and q.data_ptr() == base + 4 * off
+            off += q.numel()
         if packed and parts[0].untyped_storage().nbytes() - 4 * parts[0].storage_offset() >= 4 * off:
             return None, parts[0].as_strided((off,), (1,))
     if dev is None and not tan_dev:
@@ -310,7 +330,8 @@ class _Rasterize(torch.autograd.Function):
             _poll_pending(key, opts)
         if key in _wide_depth or opts.wide_depth_sort:
             flags |= L.FLAG_WIDE_DEPTH_SORT
-        capacity = max(int(_capacity_hint.get(key, 0)), opts.min_capacity, 4 * N if key not in _capacity_hint else 0)
+        capacity = max(int(_capacity_hint.get(key, 0)), opts.min_capacity, int(opts.capacity_hint),
+                       4 * N if (key not in _capacity_hint and not opts.capacity_hint) else 0)
         a = L.EmdFwdArgs()
         while True:
             gb, bb, ib, _ = L.workspace_sizes(N, H, W, capacity, flags, len(extras))
@@ -421,14 +442,24 @@ class _Rasterize(torch.autograd.Function):
         # row it reads back zeroed (EMD_FLAG_BWD_WS_CLEAN), so only the first use pays the 48 N-byte zero fill (20 us per step at 2 M).
         # keep_render_grads (tests read the rows afterwards) takes a fresh buffer the library clears itself.
         ws_key, bflags = None, flags
+        capturing = torch.cuda.is_current_stream_capturing()
         if opts.keep_render_grads:
             bwd_ws = torch.empty(max(N, 1) * (L.BWD_STRIDE + 4 * nx), device=dev, dtype=torch.float32)
         else:
             ws_key = (dev.index, torch.cuda.current_stream().cuda_stream, max(N, 1) * (L.BWD_STRIDE + 4 * nx))
             bwd_ws = _clean_ws.pop(ws_key, None)          # (popped: a failed backward must not leave a dirty buffer behind)
-            if bwd_ws is None:
+            if bwd_ws is not None:
+                bflags = flags | L.FLAG_BWD_WS_CLEAN
+            elif capturing:
+                # No kept buffer for this stream and a hipGraph is being recorded: a zero fill issued now would become a node of THIS graph
+                # only (it does not run at capture time), and a buffer from the graph's pool handed to later captures as "clean" would be
+                # memory nobody ever cleared.  So: a fresh buffer the library clears itself inside every graph, and nothing is kept.
+                # (`prepare_backward_workspace`, or any eager step on the capture stream, seeds a kept buffer before recording.)
+                bwd_ws = torch.empty(ws_key[2], device=dev, dtype=torch.float32)
+                ws_key = None
+            else:
                 bwd_ws = torch.zeros(ws_key[2], device=dev, dtype=torch.float32)
-            bflags = flags | L.FLAG_BWD_WS_CLEAN
+                bflags = flags | L.FLAG_BWD_WS_CLEAN
         g_extra = [None if g is None else g.contiguous().float() for g in g_extra]
         d_extra = [z(N, 3) for _ in range(nx)]
 

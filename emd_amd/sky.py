@@ -54,6 +54,12 @@ class _SkyOp(torch.autograd.Function):
             dirs = dirs.contiguous().float()
             keep.append(dirs)
             a.dirs = dirs.data_ptr()
+        elif isinstance(cam, torch.Tensor):
+            # the 21 floats (Kinv, R, T) on the device, e.g. a row emd_amd.StepInputs selected: nothing of the camera is baked into a capture
+            if cam.device != dev or cam.dtype != torch.float32 or cam.numel() != 21 or not cam.is_contiguous():
+                raise L.EmdError("sky: a device-side camera is 21 contiguous float32 values (Kinv[9], R[9], T[3]) on the cube map's device")
+            keep.append(cam)
+            a.camera_dev = cam.data_ptr()
         else:
             _fill_camera(a, cam)
         if jitter is not None:
@@ -104,19 +110,27 @@ def _camera_rays_params(camera):
     """Host copy of (Kinv, R, T) exactly as SkyCubeMap.forward derives them (sky_cubemap.py:52-54): 21 floats that go
     into the kernel arguments.  A camera's matrices are fixed, so the inverse + device-to-host copy happens once per camera
     (cached on the object, keyed by the tensors' storage and version) instead of stalling the stream every step."""
+    dev_rays = getattr(camera, "sky_rays", None)
+    if dev_rays is not None:                 # a camera whose ray constants live on the device (emd_amd.StepInputs.camera)
+        return dev_rays
     K, wvt = camera.intrinsic, camera.world_view_transform
     key = (K.data_ptr(), K._version, wvt.data_ptr(), wvt._version)
     hit = getattr(camera, "_emd_sky_params", None)
     if hit is not None and hit[0] == key:
         return hit[1]
     w2c = wvt.transpose(0, 1)
-    vals = torch.cat([torch.inverse(K.float()).reshape(-1), w2c[:3, :3].reshape(-1), w2c[:3, 3].reshape(-1)]
-                     ).detach().to("cpu", torch.float32).tolist()
+    vals = sky_ray_constants(K, wvt).tolist()
     try:
         camera._emd_sky_params = (key, vals)
     except AttributeError:
         pass
     return vals
+
+
+def sky_ray_constants(K, world_view_transform):
+    """The 21 floats (Kinv, R, T) of a camera as SkyCubeMap.forward derives them (sky_cubemap.py:52-54), on the CPU."""
+    w2c = world_view_transform.transpose(0, 1)
+    return torch.cat([torch.inverse(K.float()).reshape(-1), w2c[:3, :3].reshape(-1), w2c[:3, 3].reshape(-1)]).detach().to("cpu", torch.float32)
 
 
 class SkyCubeMap(torch.nn.Module):

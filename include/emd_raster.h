@@ -424,6 +424,8 @@ typedef struct EmdSkyArgs {
     const float* fg;            /* foreground image for the blend, or NULL */
     float* sky;                 /* out: sky colour, or NULL */
     float* out;                 /* out: blended image, or NULL */
+    const float* camera_dev;    /* optional (ABI 21): Kinv[9], R[9], T[3] on the DEVICE (21 floats) -- they replace the by-value fields, so a pass
+                                   recorded into a hipGraph can serve every camera of a rig (emd_amd.StepInputs) */
 } EmdSkyArgs;
 
 typedef struct EmdSkyBwdArgs {

@@ -82,9 +82,8 @@ check(grads(), ref, "eager")
 say("(a) exchange from inside backward: ok")
 # ---- (b) captured step, replayed with the process group alive; exchange behind the replay
 opts = RasterOptions(factored_sh_grad=True, no_sync=True)
-from emd_amd import rasterizer as _rz
 o = step(False, RasterOptions(no_sync=False))[0]
-_rz._capacity_hint[(dev.index, H, W)] = int(o["raster_call"].last_status()["num_rendered"] * 1.3) + 1024
+opts.capacity_hint = int(o["raster_call"].last_status()["num_rendered"] * 1.3) + 1024
 n_coll = xchg.num_collectives
 del o, out, xchg, rec      # no autograd graph of an eager step may be alive at capture time (its AccumulateGrad nodes are bound to the eager stream)
 import gc

@@ -17,6 +17,8 @@ Fixtures (all fp32):
   s3g_render.npz    render() executed with a recording stand-in for diff_gauss: the 12 settings fields and the tensors at
                     the rasterizer boundary (coarse and fine stage, run-script flags no_ds / no_dr), plus the deformation
                     network's residuals that produced them                S3Gaussian/gaussian_renderer/__init__.py:27-168
+  s3g_render_combined.npz   the same render() with combine_dynamic_static and return_decomposition: the boundary tensors of its seven rasterizer
+                    calls (opacity-mixed main pass; dynamic / static sets and |dx| colour passes)   S3Gaussian/gaussian_renderer/__init__.py:118-138,203-294
   s3g_sky.npz       SkyCubeMap.forward (rays, mask, clamp, layout) and the sky blend of render(), executed by the reference
                     with oracle/sky_oracle.cube_lookup standing in for the absent nvdiffrast dr.texture (its arguments are
                     recorded too)           S3Gaussian/scene/sky_cubemap.py:41-87, gaussian_renderer/__init__.py:299-301
@@ -168,8 +170,9 @@ def gen_s3g():
     unload(["utils", "scene", "arguments", "gaussian_renderer"])
 
 
-def gen_s3g_render():
-    """Run the reference render() on CPU with a recording fake rasterizer (SURVEY appendix B, step 4)."""
+def _s3g_render_setup():
+    """The reference's render() importable on CPU with a recording stand-in for diff_gauss, a 64-point GaussianModel with a visible
+    deformation and one camera -> (args, pc, cam, bg, render, rec, base dict).  Caller: sys.path.pop(0) + unload(...) afterwards."""
     from typing import NamedTuple
     sys.path.insert(0, os.path.join(REF, "S3Gaussian"))
     sys.modules["utils.tcnn_modules"] = _Stub("utils.tcnn_modules")   # raises at import without CUDA (tcnn_modules.py:36-39)
@@ -242,6 +245,13 @@ def gen_s3g_render():
         bg = torch.tensor([0.1, 0.2, 0.3])
         out = dict(R=c2w_R, T=T, fovx=cam.FoVx, fovy=cam.FoVy, H=64, W=96, bg=bg, xyz=pc._xyz.data, scaling=pc._scaling.data,
                    rotation=pc._rotation.data, opacity=pc._opacity.data, features=pc.get_features.data, active_sh_degree=2)
+    return args, pc, cam, bg, render, rec, out
+
+
+def gen_s3g_render():
+    """Run the reference render() on CPU with a recording fake rasterizer (SURVEY appendix B, step 4)."""
+    args, pc, cam, bg, render, rec, out = _s3g_render_setup()
+    with _CpuMode():
         for stage in ("coarse", "fine"):
             rec.clear()
             res = render(args, cam, pc, bg, stage=stage, return_dx=True, iter=3000, is_train=True)
@@ -261,6 +271,42 @@ def gen_s3g_render():
                         out[f"ddict_{lvl}_{k}"] = dd[lvl][k]
                     assert dd[lvl]["ds"] is None and dd[lvl]["dr"] is None
         save("s3g_render.npz", **out)
+    sys.path.pop(0)
+    unload(["utils", "scene", "arguments", "gaussian_renderer"])
+
+
+def gen_s3g_render_combined():
+    """The same render() with `combine_dynamic_static` on (gaussian_renderer/__init__.py:118-138): (A) the SH path -- the boundary tensors
+    of the one rasterizer call on the opacity-mixed set; (B) with `convert_SHs_python` and `return_decomposition` (:203-294) the seven
+    calls: the main pass, then per decomposition level (coarse: the dynamic set, fine and coarse - fine: the static set) the set itself
+    and the |dx| colour pass.  [With SH colours the reference's decomposition branch raises NameError: `colors_precomp_static` is only
+    assigned on the precomputed-colour path (:129-133 vs :214).]"""
+    args, pc, cam, bg, render, rec, out = _s3g_render_setup()
+    with _CpuMode():
+        args.combine_dynamic_static = True
+        rec.clear()
+        res = render(args, cam, pc, bg, stage="fine", return_dx=True, iter=3000, is_train=False)
+        assert len(rec) == 1
+        kw = rec[0][1]
+        assert kw["colors_precomp"] is None and kw["cov3Ds_precomp"] is None and kw["extra_attrs"] is None
+        for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+            out[f"sh_main_{k}"] = kw[k]
+        dd = res["ddict"]
+        for lvl in ("coarse", "fine"):
+            for k in ("dx", "do", "dshs"):
+                out[f"ddict_{lvl}_{k}"] = dd[lvl][k]
+        args.convert_SHs_python = True
+        rec.clear()
+        res = render(args, cam, pc, bg, stage="fine", return_dx=True, return_decomposition=True, iter=3000, is_train=False)
+        assert len(rec) == 7, len(rec)
+        names = ("main", "coarse_set", "coarse_dx", "fine_set", "fine_dx", "coarse_fine_set", "coarse_fine_dx")
+        for nm, (rs, kw) in zip(names, rec):
+            assert kw["cov3Ds_precomp"] is None and kw["extra_attrs"] is None and kw["shs"] is None
+            for k in ("means3D", "colors_precomp", "opacities", "scales", "rotations"):
+                out[f"{nm}_{k}"] = kw[k]
+        assert set(res["ddict_render"].keys()) == {"coarse_render", "fine_render", "coarse_fine_render"}
+        out["camera_center"] = cam.camera_center
+        save("s3g_render_combined.npz", **out)
     sys.path.pop(0)
     unload(["utils", "scene", "arguments", "gaussian_renderer"])
 
@@ -929,6 +975,7 @@ if __name__ == "__main__":
     print("S3Gaussian:")
     gen_s3g()
     gen_s3g_render()
+    gen_s3g_render_combined()
     gen_s3g_sky()
     gen_s3g_loss()
     gen_s3g_hexplane()

@@ -230,13 +230,12 @@ def test_step_replayed_from_a_hip_graph_equals_the_eager_step():
         l1_loss(o["render"], target).backward()
         return o["render"].detach().clone(), [None if p.grad is None else p.grad.detach().clone() for p in params]
     # a synchronising call sizes the binning workspace for all views
-    from emd_amd import rasterizer as rz
     dmax = 0
     for f, c, cam in views:
         with torch.no_grad():
             o = render(model, cam, bg, frame=f, iteration=0, options=opts.replace(no_sync=False))
         dmax = max(dmax, o["raster_call"].last_status()["num_rendered"])
-    rz._capacity_hint[(DEV.index, H, W)] = int(dmax * 1.3) + 1024
+    opts.capacity_hint = int(dmax * 1.3) + 1024
     ref = [eager(i) for i in range(len(views))]
     blocks = torch.stack([torch.cat([bg, c_.world_view_transform.reshape(-1), c_.full_proj_transform.reshape(-1), c_.camera_center.reshape(-1)])
                           for _, _, c_ in views]).to(DEV)

@@ -169,6 +169,69 @@ def test_decomposition_passes_of_the_reference_render():
         assert torch.equal(got["dx"], d)
 
 
+def test_combine_dynamic_static_render_and_decomposition_reproduce_the_reference_calls():
+    """render(..., combine_dynamic_static=True, convert_SHs_python=True) + render_decomposition against the seven rasterizer calls the
+    reference's render() makes with that flag (tests/golden/s3g_render_combined.npz: gaussian_renderer/__init__.py:118-138,203-294; the
+    fixture's residuals are replayed by a stand-in deformation): every boundary tensor of every call, in the reference's order -- and the
+    SH path's single call (shs mixed by the activated opacities)."""
+    import os
+    from emd_amd import camera, model as M, scenes
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "s3g_render_combined.npz"))
+    dev = torch.device("cuda", 0)
+    t = lambda k: torch.tensor(z[k]).to(dev)
+    N = z["xyz"].shape[0]
+    sc = scenes.make_static_scene(N, seed=0)
+    mdl = M.StreetGaussians(sc, dev)
+    with torch.no_grad():
+        mdl._xyz.copy_(t("xyz")); mdl._scaling.copy_(t("scaling")); mdl._rotation.copy_(t("rotation")); mdl._opacity.copy_(t("opacity"))
+        mdl._features.copy_(t("features"))
+    mdl.active_sh_degree = int(z["active_sh_degree"])
+    dd = {lvl: {k: t(f"ddict_{lvl}_{k}") for k in ("dx", "do", "dshs")} for lvl in ("coarse", "fine")}
+
+    def deformation(means3D, scales, rotations, opacity, shs, *a, **k):
+        p, s_, r_, o_, h_ = M.apply_deform(means3D, scales, rotations, opacity, shs, dd["coarse"], dd["fine"])
+        return p, s_, r_, o_, h_, {"coarse": dict(dd["coarse"]), "fine": dict(dd["fine"])}
+    cam = camera.make_camera(z["R"].astype(np.float64), z["T"].astype(np.float64), float(z["fovx"]), float(z["fovy"]), int(z["H"]), int(z["W"]))
+    calls = []
+    real = M.GaussianRasterizer
+
+    class Recording(real):
+        def forward(self, **kw):
+            calls.append({k: (None if v is None else v.detach().clone()) for k, v in kw.items() if k in
+                          ("means3D", "shs", "colors_precomp", "opacities", "scales", "rotations")})
+            return super().forward(**kw)
+    M.GaussianRasterizer = Recording
+    try:
+        with torch.no_grad():
+            out = M.render(mdl, cam, torch.tensor(z["bg"]), deformation=deformation, embeddings=None, iteration=3000, time=0.3,
+                           combine_dynamic_static=True, convert_SHs_python=True)
+            dec = M.render_decomposition(out)
+            assert len(calls) == 7 and set(dec) == {"coarse_render", "fine_render", "coarse_fine_render"}
+            names = ("main", "coarse_set", "coarse_dx", "fine_set", "fine_dx", "coarse_fine_set", "coarse_fine_dx")
+            for nm, kw in zip(names, calls):
+                assert kw["shs"] is None, nm
+                for k in ("means3D", "colors_precomp", "opacities", "scales", "rotations"):
+                    got, want = kw[k].cpu().numpy().reshape(z[f"{nm}_{k}"].shape), z[f"{nm}_{k}"]
+                    np.testing.assert_allclose(got, want, rtol=2e-5, atol=5e-6, err_msg=f"{nm}.{k}")
+            assert float(calls[0]["opacities"].max()) > 1.0 and bool(torch.isfinite(out["render"]).all())
+            # the SH path: ONE call on the mixed coefficients
+            calls.clear()
+            out = M.render(mdl, cam, torch.tensor(z["bg"]), deformation=deformation, embeddings=None, iteration=3000, time=0.3,
+                           combine_dynamic_static=True)
+            assert len(calls) == 1 and calls[0]["colors_precomp"] is None
+            for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+                np.testing.assert_allclose(calls[0][k].cpu().numpy().reshape(z[f"sh_main_{k}"].shape), z[f"sh_main_{k}"], rtol=2e-5, atol=5e-6,
+                                           err_msg="sh_main." + k)
+            # ... and its decomposition passes run too (the reference raises NameError there): coarse = the dynamic copies, fine = the static ones
+            calls.clear()
+            dec = M.render_decomposition(out)
+            assert len(calls) == 6 and calls[0]["shs"] is not None
+            np.testing.assert_allclose(calls[0]["means3D"].cpu().numpy(), z["sh_main_means3D"], rtol=2e-5, atol=5e-6)
+            np.testing.assert_allclose(calls[2]["means3D"].cpu().numpy(), z["xyz"], atol=0)
+    finally:
+        M.GaussianRasterizer = real
+
+
 def test_fused_sh_residuals_and_regulariser_equal_the_reference_formulation():
     """The fine-stage step with the SH residuals handed to the projection kernel unsummed and their L1 regulariser folded into the residuals'
     gradient (deform_network(..., fused_shs_residuals=True), GaussianRasterizer(shs_residuals=...), model.residual_pair_l1) against the
@@ -235,7 +298,6 @@ def test_step_graphs_replay_the_fine_stage_step_per_frame():
     from emd_amd.model import StreetGaussians, abs_mean, render, residual_abs_mean
     from emd_amd.optim import Adam
     from emd_amd.sky import SkyCubeMap, _camera_rays_params, composite_s3g
-    from emd_amd import rasterizer as _rz
     dev = torch.device("cuda", 0)
     N, H, W, F = 12000, 64, 96, 3
     g = torch.Generator().manual_seed(5)
@@ -262,7 +324,7 @@ def test_step_graphs_replay_the_fine_stage_step_per_frame():
         params = list(model.parameters()) + list(deform.parameters()) + [emb, sky.sky_cube_map]
         opt = Adam([{"params": [p for p in params if p.requires_grad], "lr": 1e-3}], lr=0.0, eps=1e-15, capturable=True) if with_adam else None
         stats = [torch.zeros(N, device=dev) for _ in range(3)]
-        opts = RasterOptions(no_sync=True)
+        opts = RasterOptions(no_sync=True, capacity_hint=400000)
 
         def step(f):
             for p in params:
@@ -280,7 +342,6 @@ def test_step_graphs_replay_the_fine_stage_step_per_frame():
                 opt.step()
         return model, deform, emb, sky, params, opt, stats, step
 
-    _rz._capacity_hint[(dev.index, H, W)] = 400000
     # ---- (a) gradients of every frame's replay against the eager step of that frame
     model, deform, emb, sky, params, opt, stats, step = build(False)
     want = {}

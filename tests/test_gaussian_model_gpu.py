@@ -208,7 +208,6 @@ def test_graph_replayed_training_loop_with_density_control():
     every densification / prune / opacity reset (the point count and the parameter tensors change there).  The optimiser's step counts
     and moments survive the surgery, the point count moves, the loss falls."""
     from emd_amd import GaussianRasterizationSettings, GaussianRasterizer, RasterOptions, StepGraphs, scenes
-    from emd_amd import rasterizer as _rz
     from emd_amd.gaussian_model import GaussianModel
     from emd_amd.model import l1_loss
     torch.manual_seed(0)
@@ -227,8 +226,7 @@ def test_graph_replayed_training_loop_with_density_control():
     target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(9)).to(DEV) * 0.5 + 0.25
     rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, torch.zeros(3, device=DEV), 1.0, cam.world_view_transform.to(DEV),
                                        cam.full_proj_transform.to(DEV), 3, cam.camera_center.to(DEV), False, False)
-    opts = RasterOptions(compute_normal=False, no_sync=True)
-    _rz._capacity_hint[(DEV.index, H, W)] = 3_000_000
+    opts = RasterOptions(compute_normal=False, no_sync=True, capacity_hint=3_000_000)
     loss_buf = torch.zeros((), device=DEV)
     state = {}
 
@@ -274,3 +272,107 @@ def test_graph_replayed_training_loop_with_density_control():
     assert st["exp_avg"].shape == m._xyz.shape and st["step"].device.type == "cuda" and float(st["step"]) >= 195.0
     lr_dev = float(m.optimizer._lr_dev[0])
     assert abs(lr_dev - m.optimizer.param_groups[0]["lr"]) <= 1e-9 + 1e-6 * lr_dev      # the schedule reached the device copy
+
+
+def test_one_graph_for_all_views_equals_the_graphs_per_view():
+    """StepGraphs(..., inputs=StepInputs(...)): ONE recorded step serves every view of a rig / clip -- camera block, field-of-view tangents,
+    background and frame index come from device tables through the graph's first node (emd_select_step_inputs) -- where round 3 recorded
+    one graph per view.  Ten views: every view's replay of the one graph leaves the gradients, the image and the densification statistics
+    the per-view graphs leave (image bit for bit), in any order of replays; then an unattended loop over the views with density control
+    every 40 iterations re-records ONE graph per event (S3Gaussian/train.py:203-229,404-423)."""
+    from emd_amd import GaussianRasterizer, RasterOptions, StepGraphs, StepInputs, scenes
+    from emd_amd.gaussian_model import GaussianModel
+    from emd_amd.model import l1_loss, raster_settings_for
+    torch.manual_seed(0)
+    H, W, N, NV = 96, 128, 6000, 10
+    sc = scenes.make_static_scene(N, seed=3)
+    means = sc.means.clone()
+    means[:, 0] = means[:, 0] * 0.25 + 1.0
+    means[:, 1] *= 0.3
+    means[:, 2] = means[:, 2] * 0.3 + 1.0
+    # (two focal lengths in the rig: the field-of-view tangents must come from the selected row too)
+    cams = [scenes.small_camera(H, W, yaw=-30.0 + 7.0 * v, focal=(1.0625 if v % 2 else 0.9) * W) for v in range(NV)]
+    bg = torch.tensor([0.05, 0.1, 0.15])
+    targets = (torch.rand(NV, 3, H, W, generator=torch.Generator().manual_seed(9)) * 0.5 + 0.25).to(DEV)
+
+    def build():
+        m = GaussianModel(device=DEV, densify_seed=1)
+        m.create_from_tensors(means, torch.rand(N, 3, generator=torch.Generator().manual_seed(4)), sc.log_scales + 1.0, spatial_lr_scale=1.0)
+        m.active_sh_degree = 3
+        m.training_setup(_train_args(position_lr_init=1.6e-3, capturable_optimizer=True))
+        return m
+    opts = RasterOptions(compute_normal=False, no_sync=True, capacity_hint=3_000_000)
+    out = {}
+    rs_of = []                                       # the per-view graphs' settings: uploaded before any capture
+    for c in cams:
+        rs = raster_settings_for(c, bg.to(DEV), 3)
+        rs_of.append(rs._replace(viewmatrix=rs.viewmatrix.to(DEV), projmatrix=rs.projmatrix.to(DEV), campos=rs.campos.to(DEV)))
+
+    def make_iteration(m, state, optimise):
+        def iteration(view):
+            """view: a row index (per-view graphs: the camera is a host constant of the capture) or the StepInputs (one graph)"""
+            m.optimizer.zero_grad(set_to_none=True)
+            sp = state["sp"]
+            sp.grad = None
+            if isinstance(view, StepInputs):
+                rs = raster_settings_for(view.camera, view.bg, 3)
+                target = targets.index_select(0, view.frame.long())[0]      # (the frame table names the view's target image)
+            else:
+                rs, target = rs_of[view], targets[view]
+            img, _, _, _, radii, _ = GaussianRasterizer(rs, options=opts)(means3D=m._xyz, means2D=sp, shs=m.get_features, opacities=m._opacity,
+                                                                          scales=m._scaling, rotations=m._rotation, raw_params=True)
+            loss = l1_loss(img, target)
+            loss.backward()
+            with torch.no_grad():
+                m.add_densification_stats(sp.grad, radii)
+                if optimise:
+                    m.optimizer.step()
+                out["img"], out["loss"] = img.detach(), loss.detach()
+                # (every recorded graph has its OWN output and gradient tensors in the shared pool: `p.grad` names those of the last capture)
+                out[view if not isinstance(view, StepInputs) else "one"] = (img.detach(), m._xyz.grad, m._features_dc.grad, m._opacity.grad, sp.grad)
+        return iteration
+    # ---- (a) one graph against ten: same image (bit for bit), same gradients, for every view, replayed out of order
+    m = build()
+    state = {"sp": torch.zeros_like(m._xyz, requires_grad=True)}
+    it = make_iteration(m, state, optimise=False)
+    per_view = StepGraphs(it, list(range(NV)), warmup=1)
+    want = {}
+    for v in (3, 0, 9, 5, 1, 2, 4, 6, 7, 8):
+        per_view.replay(v)
+        want[v] = tuple(t.clone() for t in out[v])
+    per_view.release()
+    inputs = StepInputs(cams, bg, frames=list(range(NV)), device=DEV)
+    one = StepGraphs(it, list(range(NV)), warmup=1, inputs=inputs)
+    assert len(one.graphs) == 1
+    for v in (7, 7, 2, 9, 0, 4, 1, 3, 5, 6, 8, 2):
+        one.replay(v)
+        got = out["one"]
+        assert torch.equal(got[0], want[v][0]), v
+        for a_, b_ in zip(got[1:], want[v][1:]):
+            assert float((a_ - b_).abs().max()) <= 1e-5 * max(float(b_.abs().max()), 1e-12), v
+    assert int(inputs.frame) == 2
+    one.release()
+    # ---- (b) the unattended loop on ONE graph: re-recorded once per density-control event
+    m = build()
+    state = {}
+
+    def record():
+        state["sp"] = torch.zeros_like(m._xyz, requires_grad=True)
+        return StepGraphs(make_iteration(m, state, optimise=True), list(range(NV)), optimizers=[m.optimizer], warmup=1, inputs=inputs)
+    graphs, captures = record(), 1
+    counts, losses = [m._xyz.shape[0]], []
+    for i in range(1, 161):
+        m.update_learning_rate(i)
+        graphs.replay((i * 7) % NV)
+        losses.append(out["loss"].clone())
+        if i % 40 == 0:
+            graphs.release()
+            with torch.no_grad():
+                m.densify(2e-4, 0.005, 4.0, None)
+                if i % 80 == 0:
+                    m.prune(2e-4, 0.005, 4.0, 20)
+            graphs, captures = record(), captures + 1
+        counts.append(m._xyz.shape[0])
+    losses = [float(x) for x in losses]
+    assert captures == 5 and len(set(counts)) >= 3, (captures, counts[::20])
+    assert all(np.isfinite(losses)) and np.mean(losses[-20:]) < np.mean(losses[:20])

@@ -175,3 +175,46 @@ def test_densification_stats_formula_matches_reference():
     np.testing.assert_allclose(accum.numpy(), g["accum"], rtol=1e-6)
     np.testing.assert_array_equal(denom.numpy(), g["denom"])
     np.testing.assert_array_equal(maxr.numpy(), g["maxr"])
+
+
+def test_combine_dynamic_static_mixing_matches_reference_render():
+    """model.mix_dynamic_static against the reference render() run with `combine_dynamic_static` (tests/golden/s3g_render_combined.npz:
+    S3Gaussian/gaussian_renderer/__init__.py:118-138): the SH path (one call) and the precomputed-colour path with the dynamic / static
+    sets of the decomposition passes; colours through the oracle's SH evaluation (pre_compute_colors, :19-25)."""
+    from emd_amd import model
+    from oracle import cpu_oracle as co
+    z = ld("s3g_render_combined.npz")
+    t = lambda k: torch.tensor(z[k])
+    dd = {lvl: {k: t(f"ddict_{lvl}_{k}") for k in ("dx", "do", "dshs")} for lvl in ("coarse", "fine")}
+    xyz, scaling, rotation, opacity, feats = t("xyz"), t("scaling"), t("rotation"), t("opacity"), t("features")
+    fin = model.apply_deform(xyz, scaling, rotation, opacity, feats, dd["coarse"], dd["fine"])
+    o_dyn, o_sta = torch.sigmoid(fin[3]), torch.sigmoid(opacity)
+    # (A) SH path
+    op, shs, col = model.mix_dynamic_static(o_dyn, o_sta, fin[4], feats)
+    assert col is None
+    np.testing.assert_allclose(op.numpy(), z["sh_main_opacities"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(shs.numpy(), z["sh_main_shs"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(fin[0].numpy(), z["sh_main_means3D"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(torch.exp(fin[1]).numpy(), z["sh_main_scales"], rtol=1e-6)
+    assert float(op.max()) > 1.0                                   # the summed opacities do leave [0, 1]: the rasterizer's alpha clamp handles it
+    # (B) precomputed colours: directions from the undeformed means
+    deg = int(z["active_sh_degree"])
+    dirs = (xyz - t("camera_center").reshape(1, 3)).numpy()
+    c = lambda s_: np.maximum(co.sh_forward(deg, dirs, s_.numpy()) + 0.5, 0.0)
+    col_dyn, col_sta = torch.tensor(c(fin[4])), torch.tensor(c(feats))
+    np.testing.assert_allclose(col_dyn.numpy(), z["coarse_set_colors_precomp"], rtol=1e-5, atol=2e-6)       # the dynamic set (coarse level)
+    np.testing.assert_allclose(col_sta.numpy(), z["fine_set_colors_precomp"], rtol=1e-5, atol=2e-6)         # the static set (fine level)
+    op2, shs2, col2 = model.mix_dynamic_static(o_dyn, o_sta, None, None, col_dyn, col_sta)
+    assert shs2 is None
+    np.testing.assert_allclose(col2.numpy(), z["main_colors_precomp"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(op2.numpy(), z["main_opacities"], rtol=1e-6, atol=1e-7)
+    # the sets of the decomposition passes: dynamic = deformed means with their own opacity, static = the undeformed copy
+    np.testing.assert_allclose(z["coarse_set_means3D"], fin[0].numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(z["coarse_set_opacities"], o_dyn.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(z["fine_set_means3D"], xyz.numpy(), atol=0)
+    np.testing.assert_allclose(z["fine_set_opacities"], o_sta.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(z["coarse_fine_set_means3D"], xyz.numpy(), atol=0)
+    for lvl, d in (("coarse", dd["coarse"]["dx"]), ("fine", dd["fine"]["dx"]), ("coarse_fine", dd["coarse"]["dx"] - dd["fine"]["dx"])):
+        a = d.abs()
+        np.testing.assert_allclose((a / a.max(dim=0, keepdim=True)[0]).numpy(), z[f"{lvl}_dx_colors_precomp"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(z[f"{lvl}_dx_opacities"], z["main_opacities"], atol=0)
