@@ -266,6 +266,7 @@ def main():
             # 192 B per Gaussian; the collectives are issued from inside backward(), right behind K8 (emd_amd/dp.py)
             xchg = dp.GradientExchange(campos_dev[(f, c)], actor_ids=model.actor_id if model.has_actors else None)
             rec.on_backward = xchg.start
+            rec.on_sh_factor = xchg.start_factors        # (the factor gathers run under K8; needs the actor poses of this step: set below)
         out = render(model, cam, bg, frame=f, iteration=step, options=options, record=rec)
         if not backward:
             return out

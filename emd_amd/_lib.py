@@ -22,6 +22,8 @@ FLAG_NORMAL, FLAG_MOTION, FLAG_ABSGRAD, FLAG_NO_SYNC, FLAG_CLAMP_RGB01, FLAG_RAW
 FLAG_WIDE_DEPTH_SORT = 128
 FLAG_BWD_WS_CLEAN = 256
 FLAG_KEEP_ALL_PAIRS = 512
+FLAG_BWD_RENDER_ONLY = 1024
+FLAG_BWD_PROJECT_ONLY = 2048
 
 _f = C.c_void_p  # device pointers are passed as integers
 

@@ -345,31 +345,41 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     }
     if ((a->flags & EMD_FLAG_ABSGRAD) && !a->dL_dmeans2D_abs) { emd_set_error("backward: EMD_FLAG_ABSGRAD without dL_dmeans2D_abs"); return EMD_ERR_INVALID; }
     const bool dbg = a->s.debug != 0;
-    emd_prof_begin(PROF_OTHER, st);
-    if (!(a->flags & EMD_FLAG_BWD_WS_CLEAN)) { int zrc = emd_zero_async(a->bwd_ws, need, st); if (zrc) return zrc; }
-    float* pose_grad = nullptr;       // accumulated by K8 with atomics; cleared by K7's first workgroup
-    int pose_grad_n = 0;
-    if ((a->flags & EMD_FLAG_MOTION) && a->dL_dactor_pose && a->motion.num_actors > 0) {
-        pose_grad = a->dL_dactor_pose;
-        pose_grad_n = a->motion.num_actors * EMD_ACTOR_STRIDE;
+    // the two halves of the pass may arrive as two calls (EMD_FLAG_BWD_RENDER_ONLY, then EMD_FLAG_BWD_PROJECT_ONLY on the same workspaces)
+    const bool do_render = !(a->flags & EMD_FLAG_BWD_PROJECT_ONLY), do_project = !(a->flags & EMD_FLAG_BWD_RENDER_ONLY);
+    if (!do_render && !do_project) { emd_set_error("backward: EMD_FLAG_BWD_RENDER_ONLY and EMD_FLAG_BWD_PROJECT_ONLY exclude each other"); return EMD_ERR_INVALID; }
+    if (do_render) {
+        emd_prof_begin(PROF_OTHER, st);
+        if (!(a->flags & EMD_FLAG_BWD_WS_CLEAN)) { int zrc = emd_zero_async(a->bwd_ws, need, st); if (zrc) return zrc; }
+        float* pose_grad = nullptr;       // accumulated by K8 with atomics; cleared by K7's first workgroup
+        int pose_grad_n = 0;
+        if ((a->flags & EMD_FLAG_MOTION) && a->dL_dactor_pose && a->motion.num_actors > 0) {
+            pose_grad = a->dL_dactor_pose;
+            pose_grad_n = a->motion.num_actors * EMD_ACTOR_STRIDE;
+        }
+        emd_prof_switch(PROF_OTHER, PROF_RENDER_BWD, st);
+        EmdExtra ex;
+        memset(&ex, 0, sizeof(ex));
+        ex.num = a->num_extra;
+        for (int k = 0; k < a->num_extra; k++) {
+            if (!a->colors_extra[k] || !a->out_extra[k]) { emd_set_error("backward: extra colour set %d: null colours / forward output", k); return EMD_ERR_INVALID; }
+            ex.colors[k] = a->colors_extra[k]; ex.out[k] = (float*)a->out_extra[k]; ex.dL_dout[k] = a->dL_dextra[k];
+        }
+        if (a->pair_stats && (a->num_extra > 0 || (a->flags & EMD_FLAG_ABSGRAD) || a->dL_dnormal)) {
+            emd_set_error("backward: pair_stats (diagnostic counters) only with the plain call: no extra colour sets, absgrad or normal gradient");
+            return EMD_ERR_INVALID;
+        }
+        rc = emd_launch_render_backward(a->s, a->settings_dev, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->dL_dcolor,
+                                        a->dL_ddepth, a->dL_dalpha, a->dL_dnormal, &ex, (float*)a->bwd_ws, pose_grad, pose_grad_n,
+                                        (unsigned long long*)a->pair_stats, st);
+        if (rc) return rc;
+        if (!do_project && a->dL_dsh_color) {      // the SH factor right behind K7: a view-parallel step starts gathering it under K8
+            rc = emd_launch_sh_factor(N, a->radii, g, (const float*)a->bwd_ws, emd_bwd_stride(a->num_extra), a->dL_dsh_color, st);
+            if (rc) return rc;
+        }
+        STAGE_SYNC("render_backward");
+        if (!do_project) { emd_prof_end(PROF_RENDER_BWD, st); return EMD_OK; }
     }
-    emd_prof_switch(PROF_OTHER, PROF_RENDER_BWD, st);
-    EmdExtra ex;
-    memset(&ex, 0, sizeof(ex));
-    ex.num = a->num_extra;
-    for (int k = 0; k < a->num_extra; k++) {
-        if (!a->colors_extra[k] || !a->out_extra[k]) { emd_set_error("backward: extra colour set %d: null colours / forward output", k); return EMD_ERR_INVALID; }
-        ex.colors[k] = a->colors_extra[k]; ex.out[k] = (float*)a->out_extra[k]; ex.dL_dout[k] = a->dL_dextra[k];
-    }
-    if (a->pair_stats && (a->num_extra > 0 || (a->flags & EMD_FLAG_ABSGRAD) || a->dL_dnormal)) {
-        emd_set_error("backward: pair_stats (diagnostic counters) only with the plain call: no extra colour sets, absgrad or normal gradient");
-        return EMD_ERR_INVALID;
-    }
-    rc = emd_launch_render_backward(a->s, a->settings_dev, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->dL_dcolor,
-                                    a->dL_ddepth, a->dL_dalpha, a->dL_dnormal, &ex, (float*)a->bwd_ws, pose_grad, pose_grad_n,
-                                    (unsigned long long*)a->pair_stats, st);
-    if (rc) return rc;
-    STAGE_SYNC("render_backward");
     PreBwdArgs pb;
     pb.s = a->s; pb.N = N; pb.M = a->sh_coeffs; pb.flags = a->flags;
     pb.means3D = a->means3D; pb.shs = a->shs; pb.colors_precomp = a->colors_precomp; pb.opacities = a->opacities;
@@ -384,7 +394,7 @@ int emd_raster_backward(const EmdBwdArgs* a, void* hip_stream) {
     pb.sdev = a->settings_dev;
     pb.bwd_stride = emd_bwd_stride(a->num_extra); pb.num_extra = a->num_extra;
     for (int k = 0; k < EMD_MAX_EXTRA; k++) pb.dL_dextra[k] = k < a->num_extra ? a->dL_dcolors_extra[k] : nullptr;
-    emd_prof_switch(PROF_RENDER_BWD, PROF_PREPROCESS_BWD, st);
+    if (do_render) emd_prof_switch(PROF_RENDER_BWD, PROF_PREPROCESS_BWD, st); else emd_prof_begin(PROF_PREPROCESS_BWD, st);
     rc = emd_launch_preprocess_backward(pb, st);
     emd_prof_end(PROF_PREPROCESS_BWD, st);
     if (rc) return rc;

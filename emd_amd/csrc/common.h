@@ -214,3 +214,5 @@ __device__ __forceinline__ void emd_settings_from_device(EmdSettings& S, const f
     for (int k = 0; k < 3; k++) S.campos[k] = sdev[35 + k];
 }
 int emd_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t st);     // preprocess.hip
+// the clamp-masked colour gradient of every Gaussian (the factor of its rank-one dL/dshs) from the render backward's accumulator rows
+int emd_launch_sh_factor(int N, const int32_t* radii, const GeomWs& g, const float* grad_rec, int bwd_stride, float* dL_dsh_color, hipStream_t st);

@@ -1288,6 +1288,28 @@ int emd_launch_densification_stats(int n, const int32_t* radii, const float* g2d
     return EMD_OK;
 }
 
+// dL/d(SH colour) of every Gaussian, clamp-masked (0 when not visible): what K8 writes as dL_dsh_color, available as soon as the render
+// backward has run -- accumulator row columns 7..9 and the clamp bits K1 left in row 2 of the record
+__global__ void __launch_bounds__(EMD_BLOCK) k_sh_factor(int N, const int32_t* __restrict__ radii, const float4* __restrict__ rec,
+                                                         const float* __restrict__ grad_rec, int stride, float* __restrict__ out) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    float g[3] = {0.f, 0.f, 0.f};
+    if (radii[i] > 0) {
+        const float* r = grad_rec + (size_t)i * stride;
+        const uint32_t bits = __float_as_uint(rec[(size_t)i * EMD_REC_F4 + 2].w);
+        g[0] = (bits & 1u) ? 0.f : r[7]; g[1] = (bits & 2u) ? 0.f : r[8]; g[2] = (bits & 4u) ? 0.f : r[9];
+    }
+    out[3 * i] = g[0]; out[3 * i + 1] = g[1]; out[3 * i + 2] = g[2];
+}
+
+int emd_launch_sh_factor(int N, const int32_t* radii, const GeomWs& g, const float* grad_rec, int bwd_stride, float* dL_dsh_color, hipStream_t st) {
+    if (N <= 0) return EMD_OK;
+    hipLaunchKernelGGL(k_sh_factor, dim3((N + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, N, radii, g.rec, grad_rec, bwd_stride, dL_dsh_color);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
 int emd_launch_export_geometry(int N, const GeomWs& g, float* means2D, float* depths, float* conic_opacity, float* rgb,
                                float* normal, uint32_t* tiles_touched, hipStream_t st) {
     if (N <= 0) return EMD_OK;

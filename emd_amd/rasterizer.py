@@ -92,13 +92,16 @@ class RasterCall:
     """Everything one forward (+ backward) call leaves behind besides the reference's outputs.
     `on_backward` (optional callable) is invoked with the record by the backward pass right after its kernels have been
     enqueued: view-parallel training starts its gradient collectives there (emd_amd.dp.GradientExchange.start).
+    `on_sh_factor` (optional callable; factored_sh_grad only) is invoked BETWEEN the two halves of the backward: the render backward and the
+    extraction of the SH colour factor (`sh_color_grad`) are enqueued, the projection backward is not yet -- collectives started there
+    (GradientExchange.start_factors) run under the projection backward instead of behind it.
     `status_buffer` (optional, set by the caller before the call): an int32[4] device tensor that receives the status words instead
     of a fresh allocation -- a fixed address for callers that replay the call from a hipGraph and read the words on the device.
     `pair_stats` (diagnostic; an int64[2] device tensor set by the caller before backward()): the render backward adds the number of
     (pixel, list entry) pairs it evaluated and the number that contributed (EmdBwdArgs.pair_stats)."""
     __slots__ = ("status", "num_rendered", "num_visible", "geom_ws", "bin_ws", "img_ws", "sizes", "capacity", "N", "H", "W",
                  "flags", "settings_dev", "absgrad", "sh_color_grad", "grad_slab", "on_backward", "render_grads", "pair_stats",
-                 "status_buffer", "slab_inputs")
+                 "status_buffer", "slab_inputs", "on_sh_factor")
 
     def __init__(self):
         for k in self.__slots__:
@@ -489,7 +492,17 @@ class _Rasterize(torch.autograd.Function):
         for k in range(nx):
             b.colors_extra[k], b.out_extra[k] = extras[k].data_ptr(), out_extra[k].data_ptr()
             b.dL_dextra[k], b.dL_dcolors_extra[k] = L.ptr(g_extra[k]), d_extra[k].data_ptr()
-        L.check(lib.emd_raster_backward(C.byref(b), _stream()), "emd_raster_backward")
+        if factored and rec.on_sh_factor is not None:
+            # two calls: render backward + the SH factor, the caller's hook (collectives of the factors on the communication stream), then the
+            # projection backward, under which they run
+            b.flags = bflags | L.FLAG_BWD_RENDER_ONLY
+            L.check(lib.emd_raster_backward(C.byref(b), _stream()), "emd_raster_backward (render half)")
+            rec.sh_color_grad = d_shc
+            rec.on_sh_factor(rec)
+            b.flags, b.dL_dsh_color = bflags | L.FLAG_BWD_PROJECT_ONLY, None
+            L.check(lib.emd_raster_backward(C.byref(b), _stream()), "emd_raster_backward (projection half)")
+        else:
+            L.check(lib.emd_raster_backward(C.byref(b), _stream()), "emd_raster_backward")
         if ws_key is not None:
             while len(_clean_ws) >= 4:                    # a few sizes at most (the point count changes at densification events)
                 _clean_ws.pop(next(iter(_clean_ws)))

@@ -88,6 +88,13 @@ enum {
                                       the projection backward clears every accumulator row it reads, so a caller that keeps one
                                       workspace across steps pays no 48 N-byte zero fill per backward.  Without the flag the library
                                       clears the workspace itself, as before. */
+    EMD_FLAG_BWD_RENDER_ONLY = 1 << 10, /* emd_raster_backward (ABI 21): only the render backward (K7).  With dL_dsh_color set, the clamp-masked
+                                      colour gradient of every Gaussian -- the factor of its rank-one dL/dshs -- is extracted from the
+                                      accumulator rows right behind it (one small launch), so that a view-parallel step can start the
+                                      all-gather of the factors while the projection backward is still to run */
+    EMD_FLAG_BWD_PROJECT_ONLY = 1 << 11, /* ... and only the projection backward (K8) on the accumulator rows of such a call: the two halves
+                                      of one backward as two calls, with whatever the caller enqueues in between (emd_amd.dp: collectives
+                                      on the communication stream).  dL_dsh_color is then left alone (pass NULL). */
     EMD_FLAG_KEEP_ALL_PAIRS = 1 << 9 /* (ABI 21) enumerate every tile of upstream's tile rectangle (the 3-sigma square of the largest
                                       eigenvalue): the sorted keys then ARE upstream's (tile << 32 | depth bits) list, entry for entry.
                                       By default a Gaussian enumerates only the tiles of that rectangle which its alpha >= 1/255 bounding

@@ -4,7 +4,8 @@ factors.  At world size 1 every collective is the identity, so the result must e
  (a) the exchange started from inside backward() (eager step),
  (b) a hipGraph-captured step replayed with the process group (and its watchdog thread) alive, the exchange issued behind the replay,
  (c) a NON-leaf means3D / opacity in front of the rasterizer (a network's residual): the slab must not be reduced in place while
-     autograd is running -- the leaf gradients are reduced once, in finish().
+ (d) the factor gathers started BETWEEN the halves of the backward (RasterCall.on_sh_factor -> GradientExchange.start_factors): by HIP
+     events they have completed before the projection backward has, i.e. they ran under it; gradients as in (a).
 Prints OK from rank 0.  Run by tests/test_dp_nccl_gpu.py."""
 import faulthandler
 import os
@@ -146,6 +147,61 @@ try:        # a non-leaf shs with the factored gradient would train nothing upst
     raise SystemExit("factored_sh_grad accepted a non-leaf shs")
 except ValueError:
     pass
-print("OK nccl world 1:", len(ref), "gradients, collectives per step", n_coll)
+say("(c) non-leaf inputs: ok")
+# ---- (d) the factor gathers run UNDER the projection backward (a scene large enough for K8 to take ~0.1 ms)
+del img, rec, xc, rast, delta, g
+gc.collect()
+N2 = 800000
+scene2 = scenes.add_actors(scenes.make_static_scene(N2, seed=2), num_actors=4, pts_per_actor=2000, num_frames=6, seed=1)
+model2 = StreetGaussians(scene2, dev, track_heads=True)
+params2 = list(model2.parameters())
+H2, W2 = 320, 480
+cam2 = scenes.rig_camera(frame, 0, H2, W2)
+target2 = torch.rand(3, H2, W2, generator=torch.Generator().manual_seed(4)).to(dev)
+ev = {}
+s2 = torch.cuda.Stream()
+
+
+def step2(mode):
+    for p in params2:
+        p.grad = None
+    r_ = RasterCall()
+    x_ = None
+    if mode != "plain":
+        x_ = dp.GradientExchange(cam2.camera_center, actor_ids=model2.actor_id)
+
+        def on_factor(rec_):
+            ev["mid"] = torch.cuda.Event(enable_timing=True); ev["mid"].record()             # K7 + factor extraction enqueued, K8 not yet
+            x_.start_factors(rec_)
+            with torch.cuda.stream(s2):
+                for w_ in x_._gathers:
+                    w_.wait()                                                                 # s2 waits for the collectives
+                ev["gathered"] = torch.cuda.Event(enable_timing=True); ev["gathered"].record()
+
+        def on_bwd(rec_):
+            ev["k8"] = torch.cuda.Event(enable_timing=True); ev["k8"].record()               # K8 enqueued: this event follows it
+            x_.start(rec_)
+        r_.on_backward = on_bwd
+        if mode == "overlap":
+            r_.on_sh_factor = on_factor
+    o_ = render(model2, cam2, bg, frame=frame, iteration=100, options=RasterOptions(factored_sh_grad=(mode != "plain")), record=r_)
+    if x_ is not None:
+        x_.actor_pose = o_["actor_pose"].detach()
+    l1_loss(o_["render"], target2).backward()
+    if x_ is not None:
+        x_.finish(model2._features, model2._xyz, model2.active_sh_degree, other_params=params2)
+    torch.cuda.synchronize()
+    return {n: p.grad.detach().clone() for n, p in model2.named_parameters() if p.grad is not None}, x_
+
+
+ref2, _ = step2("plain")
+for _ in range(2):
+    got2, x2 = step2("overlap")
+check(got2, ref2, "gathers between the halves of the backward")
+assert x2.num_collectives == 3 + 1 + 1
+t_g, t_k8 = ev["mid"].elapsed_time(ev["gathered"]), ev["mid"].elapsed_time(ev["k8"])
+say(f"(d) factor gathers done {t_g * 1e3:.0f} us after K7, projection backward done after {t_k8 * 1e3:.0f} us")
+assert t_g < t_k8, ("the factor gathers did not run under the projection backward", t_g, t_k8)
+print("OK nccl world 1:", len(ref), "gradients, collectives per step", n_coll, f"| factor gathers under K8: {t_g * 1e3:.0f} us vs {t_k8 * 1e3:.0f} us")
 dist.barrier()
 dist.destroy_process_group()
