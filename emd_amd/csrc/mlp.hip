@@ -164,6 +164,121 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&acc)[NT], const f32x16 (&in)[
         }
 }
 
+// ---- split-bf16 MFMA (round 4) ---------------------------------------------------------------------------------------------------------
+// fp32 MFMA runs at 1/16 of the bf16 rate on gfx950.  A product of fp32 values is reproduced to fp32 accuracy from bf16 pieces:
+//     x = x1 + x2 + x3 (three bf16 terms = 24 mantissa bits: exact), W x ~ W1 x1 + (W1 x2 + W2 x1) + (W1 x3 + W2 x2 + W3 x1)
+// -- the six products above 2^-24 of the result; a bf16 x bf16 product is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32.
+// profiles/microbench_mfma_split_bf16.hip: the same error against float64 as the fp32 MFMA path (4.1e-7 of O(1) outputs after three
+// layers) at 1.8x its rate, conversions included.  The data flow does not change: a tile's 16 registers of a lane are, in pairs of eight,
+// exactly the eight consecutive k-positions the bf16 shape wants from that lane (k-block 0 = registers 0..7 of both lane halves = features
+// {0-3, 8-11 | 4-7, 12-15} of the tile, k-block 1 = registers 8..15), so the accumulator of a layer is still the B operand of the next
+// one after its registers have been split (5.5 vector instructions per value), and the weights are staged in LDS as ready-made A fragments:
+//     image[term 0..2][out tile][k-block][lane] = uint4 of eight bf16 = term(M[32 tile + lane % 32][feature(k-block, lane / 32, 0..7)])
+// Per kernel (bit 0: the layers' products W x on split bf16, bit 1: the weight gradients' outer products): chosen from measurements at 2 M
+// rows (profiles/r04_mlp_split_variants.txt) -- the split costs 176 vector instructions per 32 x 32 tile, which a kernel with few MFMAs per
+// tile (the forward of the narrow heads) does not earn back.
+#ifndef MLP_SP_F11
+#define MLP_SP_F11 0          /* forward, one output tile (dx / do / feat heads) */
+#endif
+#ifndef MLP_SP_F12
+#define MLP_SP_F12 1          /* forward, two output tiles (the dshs head) */
+#endif
+#ifndef MLP_SP_B11
+#define MLP_SP_B11 3          /* backward, one output tile */
+#endif
+#ifndef MLP_SP_B12
+#define MLP_SP_B12 1          /* backward, two output tiles */
+#endif
+#ifndef MLP_SP_TF
+#define MLP_SP_TF 1           /* trunk forward (xa block) */
+#endif
+#ifndef MLP_SP_TB
+#define MLP_SP_TB 3           /* trunk backward (xa block) */
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Split { uint4 t[3][2]; };          // [term][k-block of the tile]
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 r = __builtin_convertvector((f32x2){a, b}, bf16x2);        // v_cvt_pk_bf16_f32: round to nearest even
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    p1 = pack_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);         // exact residuals
+    p2 = pack_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xffff0000u);
+    p3 = pack_bf16(s0, s1);
+}
+__device__ __forceinline__ Split split_tile(const f32x16& x) {
+    Split s;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+        uint32_t p[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) split2(x[8 * kb + 2 * q], x[8 * kb + 2 * q + 1], p[0][q], p[1][q], p[2][q]);
+#pragma unroll
+        for (int m = 0; m < 3; m++) s.t[m][kb] = make_uint4(p[m][0], p[m][1], p[m][2], p[m][3]);
+    }
+    return s;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the six products of one k-block, smallest first
+__device__ __forceinline__ f32x16 mfma_split(f32x16 c, uint4 a1, uint4 a2, uint4 a3, uint4 b1, uint4 b2, uint4 b3) {
+    c = mfma_bf16(a3, b1, c); c = mfma_bf16(a2, b2, c); c = mfma_bf16(a1, b3, c);
+    c = mfma_bf16(a2, b1, c); c = mfma_bf16(a1, b2, c);
+    return mfma_bf16(a1, b1, c);
+}
+// floats (4-byte units) of the image of a [32 NT][16 KB] matrix
+constexpr int split_floats(int nt, int kb) { return 3 * nt * kb * 64 * 4; }
+// layer_fwd on an image: acc[to] += M[32 to + .][k] in[k], k-blocks kb0 .. of the image (NB = k-blocks of an input tile that are non-zero)
+template <int KT, int NT, int NB = 2>
+__device__ __forceinline__ void layer_fwd_s(f32x16 (&acc)[NT], const f32x16 (&in)[KT], const uint4* __restrict__ img, int nt_img, int kb_img, int kb0, int lane) {
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+        const Split x = split_tile(in[kt]);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int kb = kb0 + 2 * kt + b;
+#pragma unroll
+            for (int to = 0; to < NT; to++) {
+                const uint4 w1 = img[((0 * nt_img + to) * kb_img + kb) * 64 + lane], w2 = img[((1 * nt_img + to) * kb_img + kb) * 64 + lane],
+                            w3 = img[((2 * nt_img + to) * kb_img + kb) * 64 + lane];
+                acc[to] = mfma_split(acc[to], w1, w2, w3, x.t[0][b], x.t[1][b], x.t[2][b]);
+            }
+        }
+    }
+}
+// M[o][f] = src[o ld + col0 + f] (o < rows, f < cols), or transposed: M[o][f] = src[f ld + col0 + o] (f < rows, o < cols); zero elsewhere
+__device__ __forceinline__ void stage_split(float* __restrict__ dst_f, int nt_img, int kb_img, const float* __restrict__ src, int ld, int col0, int rows, int cols,
+                                            bool transposed) {
+    uint4* dst = reinterpret_cast<uint4*>(dst_f);
+    const int total = nt_img * kb_img * 64;
+    for (int idx = threadIdx.x; idx < total; idx += MLP_THREADS) {
+        const int ln = idx & 63, kb = (idx >> 6) % kb_img, to = (idx >> 6) / kb_img, hh = ln >> 5, o = 32 * to + (ln & 31);
+        float w[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int v = 8 * (kb & 1) + t, f = 32 * (kb >> 1) + 8 * (v >> 2) + 4 * hh + (v & 3);
+            const bool in = src && (transposed ? (f < rows && o < cols) : (o < rows && f < cols));
+            w[t] = in ? (transposed ? src[(size_t)f * ld + col0 + o] : src[(size_t)o * ld + col0 + f]) : 0.f;
+        }
+        uint32_t p[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) split2(w[2 * q], w[2 * q + 1], p[0][q], p[1][q], p[2][q]);
+#pragma unroll
+        for (int m = 0; m < 3; m++) dst[((m * nt_img + to) * kb_img + kb) * 64 + ln] = make_uint4(p[m][0], p[m][1], p[m][2], p[m][3]);
+    }
+}
+// dW += gf (x) af over the 32 rows of the fragments (registers 0..7 / 8..15 of both lane halves = the two k-blocks), split the same way
+__device__ __forceinline__ f32x16 outer_acc_s(f32x16 acc, const Split& g, const Split& a) {
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc = mfma_split(acc, g.t[0][b], g.t[1][b], g.t[2][b], a.t[0][b], a.t[1][b], a.t[2][b]);
+    return acc;
+}
+
 // ---- transposed fragments for the weight gradients -------------------------------------------------------------------------------
 // tile (lane = row, registers = features) -> fragment (lane r = feature, registers = the 16 rows 16 hh .. 16 hh + 15) through the wave's
 // private LDS scratch.  LDS serves the DS instructions of one wave in order, so the reads see the writes; the fences only pin the
@@ -281,35 +396,78 @@ __device__ __forceinline__ void stage_vector(float* __restrict__ dst, int n_pad,
 // branch: [relu] -> Linear(64, 64) -> relu [-> Linear(64, 64) -> relu] -> Linear(64, out_dim)
 // ---------------------------------------------------------------------------------------------------------------------------------
 // LDS (floats): W1 [64][WS] | W2 [64][WS] (DEPTH 2) | Wo [32 NTO][WS] | b1 [64] | b2 [64] | bo [64] | scratch [waves][32][TS] (backward)
-template <int DEPTH, int NTO>
+constexpr int branch_mode(int depth, int nto, bool bwd) {
+    // (the two-hidden-layer feature head keeps fp32 MFMA: its six images + transposes would need 167 KB of LDS)
+    return depth != 1 ? 0 : (bwd ? (nto == 1 ? MLP_SP_B11 : MLP_SP_B12) : (nto == 1 ? MLP_SP_F11 : MLP_SP_F12));
+}
+template <int DEPTH, int NTO, int MODE = 0>
 struct BranchLds {
+    static constexpr bool SP = (MODE & 1) != 0;            // weights as split-bf16 images
+    static constexpr bool SPO = (MODE & 2) != 0;           // outer products on split bf16
+    static constexpr int W64 = SP ? split_floats(2, 4) : 64 * WS;                    // a 64 x 64 matrix
     static constexpr int w1 = 0;
-    static constexpr int w2 = w1 + 64 * WS;
-    static constexpr int wo = w2 + (DEPTH == 2 ? 64 * WS : 0);
-    static constexpr int b1 = wo + 32 * NTO * WS;
+    static constexpr int w2 = w1 + W64;
+    static constexpr int wo = w2 + (DEPTH == 2 ? W64 : 0);
+    static constexpr int b1 = wo + (SP ? split_floats(NTO, 4) : 32 * NTO * WS);
     static constexpr int b2 = b1 + 64;
     static constexpr int bo = b2 + 64;
     static constexpr int fwd_floats = bo + 64;
     // backward only: the transposed images W1^T [64][WS], W2^T, Wo^T [64][WOT] and one transpose tile per wave
     static constexpr int WOT = 32 * NTO + 4;
     static constexpr int w1t = fwd_floats;
-    static constexpr int w2t = w1t + 64 * WS;
-    static constexpr int wot = w2t + (DEPTH == 2 ? 64 * WS : 0);
-    static constexpr int scratch = wot + 64 * WOT;
+    static constexpr int w2t = w1t + W64;
+    static constexpr int wot = w2t + (DEPTH == 2 ? W64 : 0);
+    static constexpr int scratch = wot + (SP ? split_floats(2, 2 * NTO) : 64 * WOT);
     static constexpr int bwd_floats = scratch + MLP_WAVES * 32 * TS;
 };
 
+// one call for both weight forms: the fp32 path reads rows of a padded LDS matrix, the split path ready-made bf16 fragments
+template <bool SP, int KT, int NT, int NA = 4>
+__device__ __forceinline__ void mm(f32x16 (&acc)[NT], const f32x16 (&in)[KT], const float* __restrict__ W, int stride, int k0, int nt_img, int kb_img, int r, int hh,
+                                   int lane) {
+    if constexpr (SP) layer_fwd_s<KT, NT, (NA + 1) / 2>(acc, in, reinterpret_cast<const uint4*>(W), nt_img, kb_img, k0 / 16, lane);
+    else layer_fwd<KT, NT, NA>(acc, in, W, stride, k0, r, hh);
+}
+// dW[t][i] += gf (x) af[i], i = 0 .. NI - 1 (the fragments are split once per call on the bf16 path)
+template <bool SP, int NI>
+__device__ __forceinline__ void outer_all(f32x16 (&dW)[NI], const f32x16& gf, const f32x16 (&af)[NI], const Split (&afs)[NI]) {
+    if constexpr (SP) {
+        const Split gs = split_tile(gf);
+#pragma unroll
+        for (int i = 0; i < NI; i++) dW[i] = outer_acc_s(dW[i], gs, afs[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; i++) dW[i] = outer_acc(dW[i], gf, af[i]);
+    }
+}
+template <bool SP, int NI>
+__device__ __forceinline__ void split_all(Split (&afs)[NI], const f32x16 (&af)[NI]) {
+    if constexpr (SP) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) afs[i] = split_tile(af[i]);
+    }
+}
+
 template <int DEPTH, int NTO, bool BWD>
 __device__ __forceinline__ void branch_stage(float* lds, const EmdMlpBranch& a) {
-    typedef BranchLds<DEPTH, NTO> L;
-    if (BWD) {
-        stage_matrix_t(lds + L::w1t, WS, 64, 64, a.w_hidden[0], 64, 0, 64, 64);
-        if (DEPTH == 2) stage_matrix_t(lds + L::w2t, WS, 64, 64, a.w_hidden[1], 64, 0, 64, 64);
-        stage_matrix_t(lds + L::wot, L::WOT, 32 * NTO, 64, a.w_out, 64, 0, a.out_dim, 64);
+    typedef BranchLds<DEPTH, NTO, branch_mode(DEPTH, NTO, BWD)> L;
+    if constexpr (L::SP) {
+        if (BWD) {
+            stage_split(lds + L::w1t, 2, 4, a.w_hidden[0], 64, 0, 64, 64, true);
+            stage_split(lds + L::wot, 2, 2 * NTO, a.w_out, 64, 0, a.out_dim, 64, true);
+        }
+        stage_split(lds + L::w1, 2, 4, a.w_hidden[0], 64, 0, 64, 64, false);
+        stage_split(lds + L::wo, NTO, 4, a.w_out, 64, 0, a.out_dim, 64, false);
+    } else {
+        if (BWD) {
+            stage_matrix_t(lds + L::w1t, WS, 64, 64, a.w_hidden[0], 64, 0, 64, 64);
+            if (DEPTH == 2) stage_matrix_t(lds + L::w2t, WS, 64, 64, a.w_hidden[1], 64, 0, 64, 64);
+            stage_matrix_t(lds + L::wot, L::WOT, 32 * NTO, 64, a.w_out, 64, 0, a.out_dim, 64);
+        }
+        stage_matrix(lds + L::w1, WS, 64, 64, a.w_hidden[0], 64, 0, 64, 64);
+        if (DEPTH == 2) stage_matrix(lds + L::w2, WS, 64, 64, a.w_hidden[1], 64, 0, 64, 64);
+        stage_matrix(lds + L::wo, WS, 32 * NTO, 64, a.w_out, 64, 0, a.out_dim, 64);
     }
-    stage_matrix(lds + L::w1, WS, 64, 64, a.w_hidden[0], 64, 0, 64, 64);
-    if (DEPTH == 2) stage_matrix(lds + L::w2, WS, 64, 64, a.w_hidden[1], 64, 0, 64, 64);
-    stage_matrix(lds + L::wo, WS, 32 * NTO, 64, a.w_out, 64, 0, a.out_dim, 64);
     stage_vector(lds + L::b1, 64, a.b_hidden[0], 64);
     stage_vector(lds + L::b2, 64, DEPTH == 2 ? a.b_hidden[1] : nullptr, 64);
     stage_vector(lds + L::bo, 64, a.b_out, a.out_dim);
@@ -320,7 +478,7 @@ __device__ __forceinline__ void branch_stage(float* lds, const EmdMlpBranch& a) 
 // the usual kernels as they were
 template <int DEPTH, int NTO, bool L1 = false>
 __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 && !L1) ? MLP_W_F11 : MLP_FWD_WAVES) k_mlp_branch_fwd(EmdMlpBranch a) {
-    typedef BranchLds<DEPTH, NTO> L;
+    typedef BranchLds<DEPTH, NTO, branch_mode(DEPTH, NTO, false)> L;
     extern __shared__ float lds[];
     branch_stage<DEPTH, NTO, false>(lds, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
@@ -340,7 +498,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
         }
         if (a.relu_input) { x[0] = relu16(x[0]); x[1] = relu16(x[1]); }
         f32x16 m[2] = {bias_tile(lds + L::b1, 0, hh), bias_tile(lds + L::b1, 32, hh)};
-        layer_fwd<2, 2>(m, x, lds + L::w1, WS, 0, r, hh);
+        mm<L::SP, 2, 2>(m, x, lds + L::w1, WS, 0, 2, 4, r, hh, lane);
         m[0] = relu16(m[0]); m[1] = relu16(m[1]);
         if (DEPTH == 2) {
             f32x16 m2[2] = {bias_tile(lds + L::b2, 0, hh), bias_tile(lds + L::b2, 32, hh)};
@@ -350,7 +508,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
         f32x16 o[NTO];
 #pragma unroll
         for (int t = 0; t < NTO; t++) o[t] = bias_tile(lds + L::bo, 32 * t, hh);
-        layer_fwd<2, NTO>(o, m, lds + L::wo, WS, 0, r, hh);
+        mm<L::SP, 2, NTO>(o, m, lds + L::wo, WS, 0, NTO, 4, r, hh, lane);
         if (L1 && a.l1_sum && ok) {                   // the head's L1 regulariser, formed while the outputs are in registers
 #pragma unroll
             for (int t = 0; t < NTO; t++)
@@ -373,7 +531,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
 
 template <int DEPTH, int NTO, bool L1 = false>
 __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_branch_bwd(EmdMlpBranch a, EmdMlpBranchGrads g) {
-    typedef BranchLds<DEPTH, NTO> L;
+    typedef BranchLds<DEPTH, NTO, branch_mode(DEPTH, NTO, true)> L;
     extern __shared__ float lds[];
     branch_stage<DEPTH, NTO, true>(lds, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
@@ -428,7 +586,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
         f32x16 x[2] = {hin[0], hin[1]};
         if (a.relu_input) { x[0] = relu16(x[0]); x[1] = relu16(x[1]); }
         f32x16 m1[2] = {bias_tile(lds + L::b1, 0, hh), bias_tile(lds + L::b1, 32, hh)};
-        layer_fwd<2, 2>(m1, x, lds + L::w1, WS, 0, r, hh);
+        mm<L::SP, 2, 2>(m1, x, lds + L::w1, WS, 0, 2, 4, r, hh, lane);
         m1[0] = relu16(m1[0]); m1[1] = relu16(m1[1]);
         f32x16 m2[2];
         if (DEPTH == 2) {
@@ -439,21 +597,22 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
         f32x16 (&last)[2] = DEPTH == 2 ? m2 : m1;          // the activation that feeds the output layer
         // ---- output layer
         f32x16 gl[2] = {zero16(), zero16()};
-        if (NTO == 1 && a.out_dim <= 8) layer_fwd<NTO, 2, 1>(gl, go, lds + L::wot, L::WOT, 0, r, hh);  // dx / do / feat: one 8-feature chunk carries everything
+        if (NTO == 1 && a.out_dim <= 8) mm<L::SP, NTO, 2, 1>(gl, go, lds + L::wot, L::WOT, 0, 2, 2 * NTO, r, hh, lane);  // dx / do / feat: one 8-feature chunk carries everything
         else if (NTO == 2 && a.out_dim <= 48) {       // dshs (48 outputs): the second tile's upper two 8-feature chunks are padding
             const f32x16 g0[1] = {go[0]}, g1[1] = {go[NTO - 1]};
-            layer_fwd<1, 2>(gl, g0, lds + L::wot, L::WOT, 0, r, hh);
-            layer_fwd<1, 2, 2>(gl, g1, lds + L::wot, L::WOT, 32, r, hh);
-        } else layer_fwd<NTO, 2>(gl, go, lds + L::wot, L::WOT, 0, r, hh);
+            mm<L::SP, 1, 2>(gl, g0, lds + L::wot, L::WOT, 0, 2, 2 * NTO, r, hh, lane);
+            mm<L::SP, 1, 2, 2>(gl, g1, lds + L::wot, L::WOT, 32, 2, 2 * NTO, r, hh, lane);
+        } else mm<L::SP, NTO, 2>(gl, go, lds + L::wot, L::WOT, 0, 2, 2 * NTO, r, hh, lane);
         gl[0] = mask16(gl[0], last[0]); gl[1] = mask16(gl[1], last[1]);
         {   // dWo += go (x) last, dbo += rowsum(go)
-            f32x16 af[2] = {transpose_tile(last[0], T, r, hh), transpose_tile(last[1], T, r, hh)};
+            const f32x16 af[2] = {transpose_tile(last[0], T, r, hh), transpose_tile(last[1], T, r, hh)};
+            Split afs[2];
+            split_all<L::SPO, 2>(afs, af);
 #pragma unroll
             for (int t = 0; t < NTO; t++) {
                 const f32x16 gf = transpose_tile(go[t], T, r, hh);
                 dbo[t] += frag_sum(gf);
-                dWo[t][0] = outer_acc(dWo[t][0], gf, af[0]);
-                dWo[t][1] = outer_acc(dWo[t][1], gf, af[1]);
+                outer_all<L::SPO, 2>(dWo[t], gf, af, afs);
             }
         }
         // ---- second hidden layer (feature head)
@@ -475,19 +634,20 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
         }
         // ---- first hidden layer
         f32x16 gx[2] = {zero16(), zero16()};
-        layer_fwd<2, 2>(gx, g1, lds + L::w1t, WS, 0, r, hh);
+        mm<L::SP, 2, 2>(gx, g1, lds + L::w1t, WS, 0, 2, 4, r, hh, lane);
         if (a.relu_input) { gx[0] = mask16(gx[0], hin[0]); gx[1] = mask16(gx[1], hin[1]); }
         if (DEPTH == 1 && g.g_h_in) { gx[0] += gin[0]; gx[1] += gin[1]; }     // (one-hidden-layer heads only: the other kernel has no registers left)
         store_tile(g.g_h, 64, row, ok, 0, hh, gx[0]);
         store_tile(g.g_h, 64, row, ok, 32, hh, gx[1]);
         {
-            f32x16 af[2] = {transpose_tile(x[0], T, r, hh), transpose_tile(x[1], T, r, hh)};
+            const f32x16 af[2] = {transpose_tile(x[0], T, r, hh), transpose_tile(x[1], T, r, hh)};
+            Split afs[2];
+            split_all<L::SPO, 2>(afs, af);
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 const f32x16 gf = transpose_tile(g1[t], T, r, hh);
                 db1[t] += frag_sum(gf);
-                dW1[t][0] = outer_acc(dW1[t][0], gf, af[0]);
-                dW1[t][1] = outer_acc(dW1[t][1], gf, af[1]);
+                outer_all<L::SPO, 2>(dW1[t], gf, af, afs);
             }
         }
     }
@@ -527,24 +687,28 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
 // trunk: h = b + W[:, col_a : col_a + ka] xa + W[:, col_b : col_b + kb] xb           (ka = 32 KTA, kb <= 8)
 // ---------------------------------------------------------------------------------------------------------------------------------
 // LDS: Wa [64][SA] | Wb [64][12] | b [64] | scratch (backward)
-template <int KTA>
+template <int KTA, int MODE = 0>
 struct TrunkLds {
+    static constexpr bool SP = (MODE & 1) != 0 && KTA > 0, SPO = (MODE & 2) != 0 && KTA > 0;
     static constexpr int SA = 32 * KTA + 4;                 // 4 x odd
     static constexpr int wa = 0;
-    static constexpr int wb = wa + (KTA ? 64 * SA : 0);
+    static constexpr int wb = wa + (KTA ? (SP ? split_floats(2, 2 * KTA) : 64 * SA) : 0);
     static constexpr int b = wb + 64 * 12;
     static constexpr int fwd_floats = b + 64;
     // backward: only the transposed images Wa^T [32 KTA][WS], Wb^T [32][WS] (rows >= kb zero) and one transpose tile per wave
     static constexpr int wat = 0;
-    static constexpr int wbt = wat + 32 * KTA * WS;
+    static constexpr int wbt = wat + (SP ? split_floats(KTA, 4) : 32 * KTA * WS);
     static constexpr int scratch = wbt + 32 * WS;
     static constexpr int bwd_floats = scratch + MLP_WAVES * 32 * TS;
 };
 
 template <int KTA>
 __device__ __forceinline__ void trunk_stage(float* lds, const EmdMlpTrunk& a) {
-    typedef TrunkLds<KTA> L;
-    if (KTA) stage_matrix(lds + L::wa, L::SA, 64, 32 * KTA, a.w, a.ld_w, a.col_a, 64, a.ka);
+    typedef TrunkLds<KTA, MLP_SP_TF> L;
+    if (KTA) {
+        if constexpr (L::SP) stage_split(lds + L::wa, 2, 2 * KTA, a.w, a.ld_w, a.col_a, 64, a.ka, false);
+        else stage_matrix(lds + L::wa, L::SA, 64, 32 * KTA, a.w, a.ld_w, a.col_a, 64, a.ka);
+    }
     stage_matrix(lds + L::wb, 12, 64, 8, a.kb > 0 ? a.w : nullptr, a.ld_w, a.col_b, 64, a.kb);
     stage_vector(lds + L::b, 64, a.b, 64);
     __syncthreads();
@@ -573,9 +737,9 @@ __device__ __forceinline__ void load_xb(const float* __restrict__ xb, int kb, si
 // this tile's xa / xb rows (already in registers) -> h
 template <int KTA>
 __device__ __forceinline__ void trunk_forward_tile(const float* lds, int r, int hh, const f32x16 (&xa)[KTA ? KTA : 1], const float (&xb)[4], f32x16 (&h)[2]) {
-    typedef TrunkLds<KTA> L;
+    typedef TrunkLds<KTA, MLP_SP_TF> L;
     h[0] = bias_tile(lds + L::b, 0, hh); h[1] = bias_tile(lds + L::b, 32, hh);
-    if (KTA) layer_fwd<(KTA ? KTA : 1), 2>(h, xa, lds + L::wa, L::SA, 0, r, hh);
+    if (KTA) mm<L::SP, (KTA ? KTA : 1), 2>(h, xa, lds + L::wa, L::SA, 0, 2, 2 * KTA, r, hh, r + 32 * hh);
 #pragma unroll
     for (int to = 0; to < 2; to++) {
         const float4 w = *(const float4*)(lds + L::wb + (32 * to + r) * 12 + 4 * hh);
@@ -627,9 +791,12 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(KTA == 0 ? MLP_W_T0 : MLP
 
 template <int KTA>
 __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(KTA == 0 ? MLP_W_TB0 : MLP_BWD_WAVES) k_mlp_trunk_bwd(EmdMlpTrunk a, EmdMlpTrunkGrads g) {
-    typedef TrunkLds<KTA> L;
+    typedef TrunkLds<KTA, MLP_SP_TB> L;
     extern __shared__ float lds[];
-    if (KTA) stage_matrix_t(lds + L::wat, WS, 64, 32 * KTA, a.w, a.ld_w, a.col_a, 64, a.ka);
+    if (KTA) {
+        if constexpr (L::SP) stage_split(lds + L::wat, KTA, 4, a.w, a.ld_w, a.col_a, 64, a.ka, true);
+        else stage_matrix_t(lds + L::wat, WS, 64, 32 * KTA, a.w, a.ld_w, a.col_a, 64, a.ka);
+    }
     stage_matrix_t(lds + L::wbt, WS, 64, 32, a.kb > 0 ? a.w : nullptr, a.ld_w, a.col_b, 64, a.kb);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
@@ -675,15 +842,25 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(KTA == 0 ? MLP_W_TB0 : ML
                 f32x16 gx[KTA ? KTA : 1];
 #pragma unroll
                 for (int t = 0; t < KTA; t++) gx[t] = zero16();
-                layer_fwd<2, (KTA ? KTA : 1)>(gx, gh, lds + L::wat, WS, 0, r, hh);
+                mm<L::SP, 2, (KTA ? KTA : 1)>(gx, gh, lds + L::wat, WS, 0, KTA, 4, r, hh, lane);
 #pragma unroll
                 for (int t = 0; t < KTA; t++) store_tile(g.d_xa, a.ka, row, ok, 32 * t, hh, gx[t], a.ka);
             }
+            if constexpr (L::SPO) {
+                const Split gs[2] = {split_tile(gf[0]), split_tile(gf[1])};
 #pragma unroll
-            for (int t = 0; t < KTA; t++) {
-                const f32x16 af = transpose_tile(xa[t], T, r, hh);
-                dWa[0][t] = outer_acc(dWa[0][t], gf[0], af);
-                dWa[1][t] = outer_acc(dWa[1][t], gf[1], af);
+                for (int t = 0; t < KTA; t++) {
+                    const Split as = split_tile(transpose_tile(xa[t], T, r, hh));
+                    dWa[0][t] = outer_acc_s(dWa[0][t], gs[0], as);
+                    dWa[1][t] = outer_acc_s(dWa[1][t], gs[1], as);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < KTA; t++) {
+                    const f32x16 af = transpose_tile(xa[t], T, r, hh);
+                    dWa[0][t] = outer_acc(dWa[0][t], gf[0], af);
+                    dWa[1][t] = outer_acc(dWa[1][t], gf[1], af);
+                }
             }
         }
         if (a.kb > 0) {
@@ -787,15 +964,15 @@ extern "C" int emd_mlp_branch_forward(const EmdMlpBranch* a, void* hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
     const int nto = a->out_dim > 32 ? 2 : 1;
     if (a->l1_sum) {
-        if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1, true>, MLP_FWD_WAVES>(BranchLds<1, 1>::fwd_floats, a->num_points, st, *a);
-        if (a->depth == 1) return mlp_launch<k_mlp_branch_fwd<1, 2, true>, MLP_FWD_WAVES>(BranchLds<1, 2>::fwd_floats, a->num_points, st, *a);
-        if (nto == 1) return mlp_launch<k_mlp_branch_fwd<2, 1, true>, MLP_FWD_WAVES>(BranchLds<2, 1>::fwd_floats, a->num_points, st, *a);
-        return mlp_launch<k_mlp_branch_fwd<2, 2, true>, MLP_FWD_WAVES>(BranchLds<2, 2>::fwd_floats, a->num_points, st, *a);
+        if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1, true>, MLP_FWD_WAVES>(BranchLds<1, 1, branch_mode(1, 1, false)>::fwd_floats, a->num_points, st, *a);
+        if (a->depth == 1) return mlp_launch<k_mlp_branch_fwd<1, 2, true>, MLP_FWD_WAVES>(BranchLds<1, 2, branch_mode(1, 2, false)>::fwd_floats, a->num_points, st, *a);
+        if (nto == 1) return mlp_launch<k_mlp_branch_fwd<2, 1, true>, MLP_FWD_WAVES>(BranchLds<2, 1, branch_mode(2, 1, false)>::fwd_floats, a->num_points, st, *a);
+        return mlp_launch<k_mlp_branch_fwd<2, 2, true>, MLP_FWD_WAVES>(BranchLds<2, 2, branch_mode(2, 2, false)>::fwd_floats, a->num_points, st, *a);
     }
-    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1>, MLP_W_F11>(BranchLds<1, 1>::fwd_floats, a->num_points, st, *a);
-    if (a->depth == 1) return mlp_launch<k_mlp_branch_fwd<1, 2>, MLP_FWD_WAVES>(BranchLds<1, 2>::fwd_floats, a->num_points, st, *a);
-    if (nto == 1) return mlp_launch<k_mlp_branch_fwd<2, 1>, MLP_FWD_WAVES>(BranchLds<2, 1>::fwd_floats, a->num_points, st, *a);
-    return mlp_launch<k_mlp_branch_fwd<2, 2>, MLP_FWD_WAVES>(BranchLds<2, 2>::fwd_floats, a->num_points, st, *a);
+    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1>, MLP_W_F11>(BranchLds<1, 1, branch_mode(1, 1, false)>::fwd_floats, a->num_points, st, *a);
+    if (a->depth == 1) return mlp_launch<k_mlp_branch_fwd<1, 2>, MLP_FWD_WAVES>(BranchLds<1, 2, branch_mode(1, 2, false)>::fwd_floats, a->num_points, st, *a);
+    if (nto == 1) return mlp_launch<k_mlp_branch_fwd<2, 1>, MLP_FWD_WAVES>(BranchLds<2, 1, branch_mode(2, 1, false)>::fwd_floats, a->num_points, st, *a);
+    return mlp_launch<k_mlp_branch_fwd<2, 2>, MLP_FWD_WAVES>(BranchLds<2, 2, branch_mode(2, 2, false)>::fwd_floats, a->num_points, st, *a);
 }
 
 extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranchGrads* g, void* hip_stream) {
@@ -809,15 +986,15 @@ extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranch
     hipStream_t st = (hipStream_t)hip_stream;
     const int nto = a->out_dim > 32 ? 2 : 1;
     if (g->l1_grad) {
-        if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1, true>, MLP_BWD_WAVES>(BranchLds<1, 1>::bwd_floats, a->num_points, st, *a, *g);
-        if (a->depth == 1) return mlp_launch<k_mlp_branch_bwd<1, 2, true>, MLP_BWD_WAVES>(BranchLds<1, 2>::bwd_floats, a->num_points, st, *a, *g);
-        if (nto == 1) return mlp_launch<k_mlp_branch_bwd<2, 1, true>, MLP_BWD_WAVES>(BranchLds<2, 1>::bwd_floats, a->num_points, st, *a, *g);
-        return mlp_launch<k_mlp_branch_bwd<2, 2, true>, MLP_BWD_WAVES>(BranchLds<2, 2>::bwd_floats, a->num_points, st, *a, *g);
+        if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1, true>, MLP_BWD_WAVES>(BranchLds<1, 1, branch_mode(1, 1, true)>::bwd_floats, a->num_points, st, *a, *g);
+        if (a->depth == 1) return mlp_launch<k_mlp_branch_bwd<1, 2, true>, MLP_BWD_WAVES>(BranchLds<1, 2, branch_mode(1, 2, true)>::bwd_floats, a->num_points, st, *a, *g);
+        if (nto == 1) return mlp_launch<k_mlp_branch_bwd<2, 1, true>, MLP_BWD_WAVES>(BranchLds<2, 1, branch_mode(2, 1, true)>::bwd_floats, a->num_points, st, *a, *g);
+        return mlp_launch<k_mlp_branch_bwd<2, 2, true>, MLP_BWD_WAVES>(BranchLds<2, 2, branch_mode(2, 2, true)>::bwd_floats, a->num_points, st, *a, *g);
     }
-    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1>, MLP_BWD_WAVES>(BranchLds<1, 1>::bwd_floats, a->num_points, st, *a, *g);
-    if (a->depth == 1) return mlp_launch<k_mlp_branch_bwd<1, 2>, MLP_BWD_WAVES>(BranchLds<1, 2>::bwd_floats, a->num_points, st, *a, *g);
-    if (nto == 1) return mlp_launch<k_mlp_branch_bwd<2, 1>, MLP_BWD_WAVES>(BranchLds<2, 1>::bwd_floats, a->num_points, st, *a, *g);
-    return mlp_launch<k_mlp_branch_bwd<2, 2>, MLP_BWD_WAVES>(BranchLds<2, 2>::bwd_floats, a->num_points, st, *a, *g);
+    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1>, MLP_BWD_WAVES>(BranchLds<1, 1, branch_mode(1, 1, true)>::bwd_floats, a->num_points, st, *a, *g);
+    if (a->depth == 1) return mlp_launch<k_mlp_branch_bwd<1, 2>, MLP_BWD_WAVES>(BranchLds<1, 2, branch_mode(1, 2, true)>::bwd_floats, a->num_points, st, *a, *g);
+    if (nto == 1) return mlp_launch<k_mlp_branch_bwd<2, 1>, MLP_BWD_WAVES>(BranchLds<2, 1, branch_mode(2, 1, true)>::bwd_floats, a->num_points, st, *a, *g);
+    return mlp_launch<k_mlp_branch_bwd<2, 2>, MLP_BWD_WAVES>(BranchLds<2, 2, branch_mode(2, 2, true)>::bwd_floats, a->num_points, st, *a, *g);
 }
 
 extern "C" int emd_mlp_trunk_forward(const EmdMlpTrunk* a, void* hip_stream) {
@@ -825,11 +1002,11 @@ extern "C" int emd_mlp_trunk_forward(const EmdMlpTrunk* a, void* hip_stream) {
     if (rc || a->num_points == 0) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
     switch ((a->ka + 31) / 32) {            // input tiles of 32 columns (the last one zero-padded)
-        case 0: return mlp_launch<k_mlp_trunk_fwd<0>, MLP_W_T0>(TrunkLds<0>::fwd_floats, a->num_points, st, *a);
-        case 1: return mlp_launch<k_mlp_trunk_fwd<1>, MLP_FWD_WAVES>(TrunkLds<1>::fwd_floats, a->num_points, st, *a);
-        case 2: return mlp_launch<k_mlp_trunk_fwd<2>, MLP_FWD_WAVES>(TrunkLds<2>::fwd_floats, a->num_points, st, *a);
-        case 3: return mlp_launch<k_mlp_trunk_fwd<3>, MLP_FWD_WAVES>(TrunkLds<3>::fwd_floats, a->num_points, st, *a);
-        default: return mlp_launch<k_mlp_trunk_fwd<4>, MLP_FWD_WAVES>(TrunkLds<4>::fwd_floats, a->num_points, st, *a);
+        case 0: return mlp_launch<k_mlp_trunk_fwd<0>, MLP_W_T0>(TrunkLds<0, MLP_SP_TF>::fwd_floats, a->num_points, st, *a);
+        case 1: return mlp_launch<k_mlp_trunk_fwd<1>, MLP_FWD_WAVES>(TrunkLds<1, MLP_SP_TF>::fwd_floats, a->num_points, st, *a);
+        case 2: return mlp_launch<k_mlp_trunk_fwd<2>, MLP_FWD_WAVES>(TrunkLds<2, MLP_SP_TF>::fwd_floats, a->num_points, st, *a);
+        case 3: return mlp_launch<k_mlp_trunk_fwd<3>, MLP_FWD_WAVES>(TrunkLds<3, MLP_SP_TF>::fwd_floats, a->num_points, st, *a);
+        default: return mlp_launch<k_mlp_trunk_fwd<4>, MLP_FWD_WAVES>(TrunkLds<4, MLP_SP_TF>::fwd_floats, a->num_points, st, *a);
     }
 }
 
@@ -842,10 +1019,10 @@ extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGra
     if (g->d_xa && ((uintptr_t)g->d_xa & 15)) { emd_set_error("mlp_trunk_backward: d_xa must be 16-byte aligned"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     switch ((a->ka + 31) / 32) {
-        case 0: return mlp_launch<k_mlp_trunk_bwd<0>, MLP_W_TB0>(TrunkLds<0>::bwd_floats, a->num_points, st, *a, *g);
-        case 1: return mlp_launch<k_mlp_trunk_bwd<1>, MLP_BWD_WAVES>(TrunkLds<1>::bwd_floats, a->num_points, st, *a, *g);
-        case 2: return mlp_launch<k_mlp_trunk_bwd<2>, MLP_BWD_WAVES>(TrunkLds<2>::bwd_floats, a->num_points, st, *a, *g);
-        case 3: return mlp_launch<k_mlp_trunk_bwd<3>, MLP_BWD_WAVES>(TrunkLds<3>::bwd_floats, a->num_points, st, *a, *g);
-        default: return mlp_launch<k_mlp_trunk_bwd<4>, MLP_BWD_WAVES>(TrunkLds<4>::bwd_floats, a->num_points, st, *a, *g);
+        case 0: return mlp_launch<k_mlp_trunk_bwd<0>, MLP_W_TB0>(TrunkLds<0, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
+        case 1: return mlp_launch<k_mlp_trunk_bwd<1>, MLP_BWD_WAVES>(TrunkLds<1, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
+        case 2: return mlp_launch<k_mlp_trunk_bwd<2>, MLP_BWD_WAVES>(TrunkLds<2, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
+        case 3: return mlp_launch<k_mlp_trunk_bwd<3>, MLP_BWD_WAVES>(TrunkLds<3, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
+        default: return mlp_launch<k_mlp_trunk_bwd<4>, MLP_BWD_WAVES>(TrunkLds<4, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
     }
 }
