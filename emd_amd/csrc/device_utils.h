@@ -58,6 +58,24 @@ __device__ __forceinline__ void wave_scan_add2_f32_asm(float& a, float& b) {
     EMD_DPP_STEP2("v_add_f32_dpp", a, b, "row_bcast:31 row_mask:0xc bank_mask:0xf");
 }
 
+// The same scans inside each 32-lane HALF of the wave (the first five steps: lanes 31 and 63 end up with their half's totals)
+__device__ __forceinline__ void half_scan_mul2_f32_asm(float& a, float& b) {
+    asm volatile("s_nop 0");
+    EMD_DPP_STEP2("v_mul_f32_dpp", a, b, "row_shr:1 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP2("v_mul_f32_dpp", a, b, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP2("v_mul_f32_dpp", a, b, "row_shr:4 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP2("v_mul_f32_dpp", a, b, "row_shr:8 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP2("v_mul_f32_dpp", a, b, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+}
+__device__ __forceinline__ void half_scan_add2_f32_asm(float& a, float& b) {
+    asm volatile("s_nop 0");
+    EMD_DPP_STEP2("v_add_f32_dpp", a, b, "row_shr:1 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP2("v_add_f32_dpp", a, b, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP2("v_add_f32_dpp", a, b, "row_shr:4 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP2("v_add_f32_dpp", a, b, "row_shr:8 row_mask:0xf bank_mask:0xf");
+    EMD_DPP_STEP2("v_add_f32_dpp", a, b, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+}
+
 // Sum over the wave, valid in lane 63 only.
 __device__ __forceinline__ float wave_reduce_to_lane63(float v) { return wave_scan_add_f32(v); }
 

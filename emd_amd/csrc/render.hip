@@ -19,6 +19,8 @@
 //     lane adds ONE 48-byte row (+16 B per extra colour set) to its Gaussian with global float atomics.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "device_utils.h"
 #include "footprint.h"
@@ -365,6 +367,7 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
     //   [pp][3] = (Q a,b | -)          [pp][4] = (dN0 a,b | dN1 a,b) [pp][5] = (dN2 a,b | -)
     //   [pp][PB + 2k] = (dX_k0 a,b | dX_k1 a,b)  [pp][PB + 2k + 1] = (dX_k2 a,b | -)     gradients of extra colour set k
     __shared__ float4 s_pix[EMD_WAVE / 2][PB + 2 * NX];
+    __shared__ uint32_t s_myn[EMD_WAVE];                        // n_contrib of the quadrant's pixels (half-wave batches read it per lane)
     uint32_t quad;
     const uint32_t tile = ordered_quadrant_block(blockIdx.x, (uint32_t)(d.gx * d.gy), tile_order, &quad);
     if (tile >= (uint32_t)(d.gx * d.gy)) return;
@@ -379,6 +382,7 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
     const uint32_t* const sv = surv + 4 * (size_t)start + (size_t)quad * n_tile;
     const size_t HW = (size_t)d.H * d.W, pix = (size_t)py * d.W + px;
     const uint32_t my_n = inside ? n_contrib[pix] : 0u;                    // 1-based number of the last survivor that contributed to this pixel
+    s_myn[lane] = my_n;
     float dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dN0 = 0.f, dN1 = 0.f, dN2 = 0.f, Q = 0.f, Tf = 1.f;
     float dX[NX ? NX : 1][3];
 #pragma unroll
@@ -415,9 +419,16 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
     unsigned long long st_eval = 0ull, st_hit = 0ull;
 
     // One batch of nb survivors: lane = entry, lane 0 the DEEPEST; `pos` = 0-based number of the lane's survivor, `gid` its Gaussian.
-    auto process_batch = [&](uint32_t nb, const float4& g0, const float4& g1, const float4& g2, const float4& g3, const float4* gxc, uint32_t pos,
+    // HALF (round 4): a batch of at most 32 survivors -- only the deepest step of a walk can be that short -- runs on both halves of the
+    // wave at once: lanes 0..31 take the entries against pixel pairs 0..15, lanes 32..63 the SAME entries against pixel pairs 16..31, so the
+    // pixel loop has 16 iterations instead of 32 (the scans run inside the 32-lane halves: five DPP steps; the per-pixel constants become
+    // two-address LDS loads; the two halves' moment sums of an entry are added at the end).  A quadrant's walk is ~2.4 batches long and its
+    // deepest one is half empty on average: the 64-lane form spent a third of its lane-iterations on lanes without an entry.
+    auto process_batch = [&](auto half_c, uint32_t nb, const float4& g0, const float4& g1, const float4& g2, const float4& g3, const float4* gxc, uint32_t pos,
                              uint32_t gid) {
-        const bool valid = lane < nb;
+        constexpr bool HALF = decltype(half_c)::value;
+        const uint32_t el = HALF ? (lane & 31u) : lane, hp = HALF ? (lane >> 5) : 0u;      // entry slot of the lane, its half of the pixels
+        const bool valid = el < nb;
         v2f xr_2[NX ? NX : 1], xg_2[NX ? NX : 1], xb_2[NX ? NX : 1];
 #pragma unroll
         for (int k = 0; k < (NX ? NX : 1); k++) xr_2[k] = xg_2[k] = xb_2[k] = splat2(0.f);
@@ -425,9 +436,16 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
         const v2f z2 = splat2(0.f);
         v2f m0_2 = z2, gx_2 = z2, gy_2 = z2, m2xx_2 = z2, m2xy_2 = z2, m2yy_2 = z2, dz_2 = z2, r_2 = z2, g_2 = z2, b_2 = z2;
         float a_ax = 0.f, a_ay = 0.f;
-        for (int pp = 0; pp < EMD_WAVE / 2; pp++) {
-            const uint32_t n_a = readlane_u32(my_n, 2 * pp), n_b = readlane_u32(my_n, 2 * pp + 1);
-            if (max(n_a, n_b) <= last_pos) continue;             // both pixels terminated before the shallowest entry of this batch
+        for (int pp0 = 0; pp0 < (HALF ? EMD_WAVE / 4 : EMD_WAVE / 2); pp0++) {
+            const int pp = HALF ? pp0 + (int)(hp * (EMD_WAVE / 4)) : pp0;                    // (per lane half in the HALF form)
+            uint32_t n_a, n_b;
+            if (HALF) {
+                n_a = s_myn[2 * pp]; n_b = s_myn[2 * pp + 1];
+                if (__ballot(max(n_a, n_b) > last_pos) == 0ull) continue;
+            } else {
+                n_a = readlane_u32(my_n, 2 * pp); n_b = readlane_u32(my_n, 2 * pp + 1);
+                if (max(n_a, n_b) <= last_pos) continue;         // both pixels terminated before the shallowest entry of this batch
+            }
             const float4 c01 = s_pix[pp][0], c2d = s_pix[pp][1], ts = s_pix[pp][2], qq = s_pix[pp][3];
             const float pxs = qx0 + (float)((2 * pp) & 7), pys = qy0 + (float)(pp >> 2);
             const float dy = g0.y - pys;
@@ -440,7 +458,7 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
             const v2f alpha = (v2f){fminf(0.99f, aw.x), fminf(0.99f, aw.y)};
             const bool hit_a = valid && pos < n_a && power.x <= 0.f && alpha.x >= (1.f / 255.f);
             const bool hit_b = valid && pos < n_b && power.y <= 0.f && alpha.y >= (1.f / 255.f);
-            if (STATS) { st_eval += 2ull * nb; st_hit += (unsigned long long)(__popcll(__ballot(hit_a)) + __popcll(__ballot(hit_b))); }
+            if (STATS) { st_eval += (HALF ? 4ull : 2ull) * nb; st_hit += (unsigned long long)(__popcll(__ballot(hit_a)) + __popcll(__ballot(hit_b))); }
             if (__ballot(hit_a || hit_b) == 0ull) continue;
             const v2f a = (v2f){hit_a ? alpha.x : 0.f, hit_b ? alpha.y : 0.f};
             const v2f om = splat2(1.f) - a;
@@ -448,7 +466,7 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
             // lane 0 is the DEEPEST entry of the batch.  T_k (in front of entry k) = T_behind / prod_{entries from k to the back} (1 - alpha):
             // an inclusive prefix product of the reciprocals over the lanes, times the value carried from the batches behind
             float t_a = inv.x, t_b = inv.y;
-            wave_scan_mul2_f32_asm(t_a, t_b);
+            if (HALF) half_scan_mul2_f32_asm(t_a, t_b); else wave_scan_mul2_f32_asm(t_a, t_b);
             const v2f cT = (v2f){ts.x, ts.y}, cR = (v2f){ts.z, ts.w};
             const v2f Tk = cT * (v2f){t_a, t_b};
             const v2f w = a * Tk;
@@ -467,8 +485,10 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
             // R_k = sum over the entries BEHIND k of g_i alpha_i T_i: exclusive prefix sum over the lanes + the carried value
             const v2f gw = g * w;
             float s_a = gw.x, s_b = gw.y;
-            wave_scan_add2_f32_asm(s_a, s_b);
-            const v2f Rk = cR + (v2f){wave_shift_up1_f32(s_a, 0.f), wave_shift_up1_f32(s_b, 0.f)};
+            if (HALF) half_scan_add2_f32_asm(s_a, s_b); else wave_scan_add2_f32_asm(s_a, s_b);
+            float ex_a = wave_shift_up1_f32(s_a, 0.f), ex_b = wave_shift_up1_f32(s_b, 0.f);
+            if (HALF && lane == 32u) { ex_a = 0.f; ex_b = 0.f; }                             // (lane 32 is the deepest entry of its half)
+            const v2f Rk = cR + (v2f){ex_a, ex_b};
             // dL/dalpha_k = g_k T_k - R_k / (1 - alpha_k) + T_final (dL/dalpha_img - bg . dL/dC) / (1 - alpha_k)
             v2f dL_da = g * Tk + inv * ((v2f){qq.x, qq.y} - Rk);
             dL_da = (v2f){hit_a ? dL_da.x : 0.f, hit_b ? dL_da.y : 0.f};
@@ -490,7 +510,15 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
                 xr_2[k] += w * (v2f){x01[k].x, x01[k].y}; xg_2[k] += w * (v2f){x01[k].z, x01[k].w}; xb_2[k] += w * (v2f){x2_[k].x, x2_[k].y};
             }
             // lane 63 holds the batch totals: carry the transmittance and the weighted colour in front of this batch to the next one
-            if (lane == 63) s_pix[pp][2] = make_float4(cT.x * t_a, cT.y * t_b, cR.x + s_a, cR.y + s_b);
+            if ((lane & (HALF ? 31u : 63u)) == (HALF ? 31u : 63u)) s_pix[pp][2] = make_float4(cT.x * t_a, cT.y * t_b, cR.x + s_a, cR.y + s_b);
+        }
+        if (HALF) {
+            // the two pixel halves of every entry: lane e += lane e + 32 (both halves end up with the sums)
+            auto fold = [](v2f& x) { x.x += __shfl_xor(x.x, 32); x.y += __shfl_xor(x.y, 32); };
+            fold(m0_2); fold(gx_2); fold(gy_2); fold(m2xx_2); fold(m2xy_2); fold(m2yy_2); fold(dz_2); fold(r_2); fold(g_2); fold(b_2);
+            if (ABS) { a_ax += __shfl_xor(a_ax, 32); a_ay += __shfl_xor(a_ay, 32); }
+#pragma unroll
+            for (int k = 0; k < NX; k++) { fold(xr_2[k]); fold(xg_2[k]); fold(xb_2[k]); }
         }
         const float m0 = m0_2.x + m0_2.y, gx = gx_2.x + gx_2.y, gy = gy_2.x + gy_2.y, m2xx = m2xx_2.x + m2xx_2.y,
                     m2xy = m2xy_2.x + m2xy_2.y, m2yy = m2yy_2.x + m2yy_2.y, a_dz = dz_2.x + dz_2.y, a_r = r_2.x + r_2.y,
@@ -561,7 +589,18 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
         }
         idC = load_id(st_ + 3);
         const uint32_t nb = (uint32_t)(min((int)wave_n, step_lo(st_) + EMD_WAVE) - step_lo(st_));
-        process_batch(nb, c0r, c1r, c2r, c3r, cxr, (uint32_t)max(idx, 0), cid);
+        if (nb <= EMD_WAVE / 2) {
+            // (only the deepest step can be this short) the upper half of the wave takes copies of the lower half's entries
+            const int src = (int)(lane & 31u);
+            auto dup4 = [&](float4 v) { return make_float4(__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src), __shfl(v.w, src)); };
+            const float4 h0 = dup4(c0r), h1 = dup4(c1r), h2 = dup4(c2r), h3 = NORMAL ? dup4(c3r) : c3r;
+            float4 hx[NX ? NX : 1];
+#pragma unroll
+            for (int k = 0; k < NX; k++) hx[k] = dup4(cxr[k]);
+            process_batch(std::true_type{}, nb, h0, h1, h2, h3, hx, (uint32_t)__shfl(max(idx, 0), src), (uint32_t)__shfl((int)cid, src));
+        } else {
+            process_batch(std::false_type{}, nb, c0r, c1r, c2r, c3r, cxr, (uint32_t)max(idx, 0), cid);
+        }
     }
     if (STATS && lane == 0) { atomicAdd(pair_stats, st_eval); atomicAdd(pair_stats + 1, st_hit); }
 }
