@@ -55,7 +55,9 @@ class StepInputs:
     the per-frame actor pose tables).
 
     `camera` is the camera object of the CURRENT row for emd_amd.model.render / raster_settings_for / the sky model: every per-view field
-    is a view of the selected row.  Image size is common to all views (it shapes the launch grids)."""
+    is a view of the selected row.  Image size is common to all views (it shapes the launch grids).  What stays a host constant of the
+    capture: the image size, `cam_no` (the index of S3Gaussian's per-camera time offset: views that differ in it need a graph each) and the
+    iteration-dependent coarse-to-fine level of the deformation network (re-record when it changes, as at a density-control event)."""
     SETTINGS, SKY, TIME = 40, 21, 1
 
     def __init__(self, cameras, bg, frames=None, times=None, extra=None, device="cuda"):

@@ -119,8 +119,12 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
     rasterizer = GaussianRasterizer(raster_settings=rs, options=options)
     means3D, scales, rotations, opacity, shs, ddict = model._xyz, model._scaling, model._rotation, model._opacity, model._features, None
     if deformation is not None:
-        t = float(getattr(cam, "time", 0.0) if time is None else time)
-        times_sel = torch.full((means3D.shape[0], 1), t, device=dev, dtype=torch.float32)
+        t = getattr(cam, "time", 0.0) if time is None else time
+        if isinstance(t, torch.Tensor) and t.device.type != "cpu":
+            # a view's time that lives on the device (emd_amd.StepInputs.camera.time): nothing of it is baked into a recorded step
+            times_sel = t.reshape(1, 1).to(torch.float32).expand(means3D.shape[0], 1).contiguous()
+        else:
+            times_sel = torch.full((means3D.shape[0], 1), float(t), device=dev, dtype=torch.float32)
         from .deformation import deform_network as _dn
         # (an emd_amd network hands the SH residuals over unsummed: `shs + dshs_c + dshs_f` is formed inside the projection kernel)
         extra_kw = {"need_feat": bool(need_feat or render_feat), "fused_shs_residuals": True} if isinstance(deformation, _dn) else {}
