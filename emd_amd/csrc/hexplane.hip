@@ -7,7 +7,7 @@
 // consecutive lanes (lane = channel): every tap is one coalesced C x 4-byte read, the product over the six planes and
 // the concat over scales happen in registers, and the backward scatters C consecutive floats per tap (the row shape
 // float atomics like).  One launch forward, one backward, for all scales.
-// Three kernels: k_hexplane_fwd2 (two-phase forward, at the L2 -> CU gather rate), k_hexplane_bwd_agg (backward that aggregates
+// Kernels: k_hexplane_fwd4 / fwd2 (two-phase forward, lane = four channels / one channel, at the L2 -> CU gather rate), k_hexplane_bwd_agg (backward that aggregates
 // plane gradients in LDS over a spatially coherent visiting order; VALU-issue-bound) and k_hexplane_bwd (direct float atomics,
 // bound by the L2 atomic units; used when no order is given).
 #include <limits.h>
@@ -161,6 +161,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_bwd(EmdHexArgs a, EmdHex
     }
 }
 
+__device__ __forceinline__ int sel4i(int v0, int v1, int v2, int v3, int k) { return k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3)); }
+__device__ __forceinline__ float sel4f(float v0, float v1, float v2, float v3, int k) { return k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3)); }
+
 // ---- forward, two-phase ---------------------------------------------------------------------------------------------------
 // With lane = channel every lane of a point repeats the point's scalar work (un-normalise, clip, floor, tap offsets, bilinear
 // weights: ~125 of the ~220 VALU instructions per two points and scale), and the one-phase kernel above is VALU-issue-bound.
@@ -217,6 +220,81 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd2(EmdHexArgs a) {
 }
 
 
+// ---- forward, lane = FOUR channels ---------------------------------------------------------------------------------------------
+// The same two phases with C / 4 lanes per point: a tap row is read as 16 bytes per lane (a quarter of the vector-memory instructions and of
+// the broadcast LDS reads per point), the output row written the same way.  A workgroup takes 128 points (768 (point, plane) items = three
+// full rounds of phase A); the normalised coordinates are formed once per point, not once per scale and plane.
+// Chunk -> XCD: workgroups are dealt round-robin over the 8 XCDs, so workgroup b takes chunk (b % 8) * ceil(chunks / 8) + b / 8: every XCD
+// walks ONE contiguous eighth of the visiting order, and with a spatially coherent order its L2 holds an eighth of the box's taps instead
+// of every XCD streaming every plane.
+#define HEX_F4_POINTS 128
+__device__ __forceinline__ long xcd_chunk(unsigned b, unsigned chunks) {
+    const unsigned per = (chunks + 7u) / 8u, chunk = (b % 8u) * per + b / 8u;
+    return (b / 8u < per && chunk < chunks) ? (long)chunk : -1;
+}
+template <int C>
+__global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsigned chunks) {
+    constexpr int LPP = C / 4, GROUPS = EMD_BLOCK / LPP;
+    __shared__ uint4 s_off[HEX_F4_POINTS * 6];          // BYTE offsets of the 2 x 2 taps (without the channel)
+    __shared__ float4 s_w[HEX_F4_POINTS * 6];           // their bilinear weights
+    __shared__ float4 s_q[HEX_F4_POINTS];               // normalised x, y, z and the time
+    __shared__ int s_n[HEX_F4_POINTS];
+    const int S = a.num_scales, tid = threadIdx.x;
+    const int group = tid / LPP, c4 = (tid % LPP) * 4;
+    const long chunk = xcd_chunk(blockIdx.x, chunks);
+    if (chunk < 0) return;
+    const long first = chunk * HEX_F4_POINTS;
+    const int count = (int)min((long)HEX_F4_POINTS, (long)a.num_points - first);
+    if (tid < HEX_F4_POINTS) {
+        const long n = tid < count ? (a.order ? (long)a.order[first + tid] : first + tid) : 0;
+        s_n[tid] = (int)n;
+        float4 q;
+        q.x = (a.pts[3 * n] - a.aabb[0]) * (2.f / (a.aabb[3] - a.aabb[0])) - 1.f;
+        q.y = (a.pts[3 * n + 1] - a.aabb[1]) * (2.f / (a.aabb[4] - a.aabb[1])) - 1.f;
+        q.z = (a.pts[3 * n + 2] - a.aabb[2]) * (2.f / (a.aabb[5] - a.aabb[2])) - 1.f;
+        q.w = a.times[n];
+        s_q[tid] = q;
+    }
+    __syncthreads();
+    for (int s = 0; s < S; s++) {
+        // phase A: item = (point, plane)
+        for (int item = tid; item < HEX_F4_POINTS * 6; item += EMD_BLOCK) {
+            const int j = item / 6, p = item - 6 * j;
+            if (j >= count) continue;
+            int ax, ay;
+            pair_axes(p, ax, ay);
+            const float4 q = s_q[j];
+            const int W = a.res[s][ax];
+            const Tap1 tx = tap1(sel4f(q.x, q.y, q.z, q.w, ax), W), ty = tap1(sel4f(q.x, q.y, q.z, q.w, ay), a.res[s][ay]);
+            s_off[item] = make_uint4(tap_at(tx.i0, ty.i0, W, C, 0) << 2, tap_at(tx.i1, ty.i0, W, C, 0) << 2, tap_at(tx.i0, ty.i1, W, C, 0) << 2,
+                                     tap_at(tx.i1, ty.i1, W, C, 0) << 2);
+            // grid_sampler_2d: nw * (1-fx)(1-fy) + ne * fx (1-fy) + sw * (1-fx) fy + se * fx fy
+            s_w[item] = make_float4((1.f - tx.f) * (1.f - ty.f), tx.f * (1.f - ty.f), (1.f - tx.f) * ty.f, tx.f * ty.f);
+        }
+        __syncthreads();
+        // phase B: lane = four channels
+        for (int j = group; j < count; j += GROUPS) {
+            float4 prod = make_float4(1.f, 1.f, 1.f, 1.f);
+            const uint32_t cb = (uint32_t)c4 << 2;
+#pragma unroll
+            for (int p = 0; p < 6; p++) {
+                const uint4 o = s_off[j * 6 + p];
+                const float4 w = s_w[j * 6 + p];
+                const char* __restrict__ pl = (const char*)a.planes[s][p];
+                const float4 nw = *(const float4*)(pl + (o.x + cb)), ne = *(const float4*)(pl + (o.y + cb)), sw = *(const float4*)(pl + (o.z + cb)),
+                             se = *(const float4*)(pl + (o.w + cb));
+                // (the evaluation order of k_hexplane_fwd2, per channel)
+                prod.x = prod.x * (nw.x * w.x + ne.x * w.y + sw.x * w.z + se.x * w.w);
+                prod.y = prod.y * (nw.y * w.x + ne.y * w.y + sw.y * w.z + se.y * w.w);
+                prod.z = prod.z * (nw.z * w.x + ne.z * w.y + sw.z * w.z + se.z * w.w);
+                prod.w = prod.w * (nw.w * w.x + ne.w * w.y + sw.w * w.z + se.w * w.w);
+            }
+            *(float4*)(a.out + ((size_t)s_n[j] * (S * C) + s * C + c4)) = prod;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- backward with in-LDS aggregation -----------------------------------------------------------------------------------
 // The plain backward issues one row of float atomics per tap (N x 24 planes x 4 taps).  A CU issues a 64-lane global float atomic
 // in ~117 clocks whatever the rows, their locality or the memory scope (profiles/r03_global_atomic_microbench.txt: 10.4 G rows of
@@ -254,8 +332,6 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd2(EmdHexArgs a) {
 #define HEX_SCELLS (HEX_SW * HEX_SW)
 #define HEX_WIN_CELLS (3 * HEX_SCELLS + 3 * HEX_TW)
 
-__device__ __forceinline__ int sel4i(int v0, int v1, int v2, int v3, int k) { return k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3)); }
-__device__ __forceinline__ float sel4f(float v0, float v1, float v2, float v3, int k) { return k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3)); }
 __device__ __forceinline__ int order_key(float v) { const int b = __float_as_int(v); return b >= 0 ? b : b ^ 0x7fffffff; }   // monotone int image
 __device__ __forceinline__ float key_value(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
 
@@ -640,8 +716,12 @@ extern "C" int emd_hexplane_forward(const EmdHexArgs* a, void* hip_stream) {
     if (rc) return rc;
     if (!a->out) { emd_set_error("hexplane_forward: null output"); return EMD_ERR_INVALID; }
     if (a->num_points == 0) return EMD_OK;
-    hipLaunchKernelGGL(k_hexplane_fwd2, dim3((unsigned)((a->num_points + HEX_F2_POINTS - 1) / HEX_F2_POINTS)), dim3(EMD_BLOCK), 0,
-                       (hipStream_t)hip_stream, *a);
+    const unsigned chunks = (unsigned)((a->num_points + HEX_F4_POINTS - 1) / HEX_F4_POINTS), grid4 = (chunks + 7u) / 8u * 8u;
+    if (a->channels == 32) hipLaunchKernelGGL(k_hexplane_fwd4<32>, dim3(grid4), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, *a, chunks);
+    else if (a->channels == 16) hipLaunchKernelGGL(k_hexplane_fwd4<16>, dim3(grid4), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, *a, chunks);
+    else          // other channel counts: lane = channel
+        hipLaunchKernelGGL(k_hexplane_fwd2, dim3((unsigned)((a->num_points + HEX_F2_POINTS - 1) / HEX_F2_POINTS)), dim3(EMD_BLOCK), 0,
+                           (hipStream_t)hip_stream, *a);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }
