@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
     for (int k = 0; k < 4; k++) qlo[k] = key_value(qmin[k]);
     const bool tuni = qmin[3] == qmax[3];               // one time for the whole block: time planes as marginals
     const bool want_dq = g.dL_dpts || g.dL_dtimes;
-    const int twx = tuni ? HEX_TW : HEX_TW / 2, twy = tuni ? 1 : 2;
+    const int twy = tuni ? 1 : 2;
     const int sb = wave * 2 * SROWS;                    // the wave's staging rows
     for (int s = 0; s < S; s++) {
         int anc[4];
@@ -400,6 +400,10 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         // deferred scale: the rows of the spatial planes go to the per-plane pass (k_hexplane_bwd_plane) instead of the windows
         const bool deferred = (g.defer_mask >> s) & 1u;
         const size_t defer_base = (size_t)__builtin_popcount(g.defer_mask & ((1u << s) - 1u)) * 3u;
+        // a deferred scale does not use the spatial windows: its three time windows take the whole memory (148 cells each instead of 48 -- on
+        // the fine scales, the deferred ones, a run spans 35 - 50 cells of an axis and 18 % of its x taps left the 48-cell window, each such
+        // tap four partly filled atomic instructions)
+        const int tw = deferred ? HEX_WIN_CELLS / 3 : HEX_TW, tbase = deferred ? 0 : 3 * HEX_SCELLS, twx = tuni ? tw : tw / 2;
         // The waves of the block run on their own from here to the flush, GW points (one per C-lane group) per iteration, as a
         // software pipeline:  stage(it + 1) | wait for the taps of `it` | sample, slopes, product rule | issue the gathers of it + 1 |
         // scatter the rows of `it`.  No block barrier in the loop, so the waves drift apart and one wave's gathers overlap another's
@@ -421,7 +425,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     const int ancx = sel4i(anc[0], anc[1], anc[2], anc[3], ax), ancy = sel4i(anc[0], anc[1], anc[2], anc[3], ay);
                     const int cx0 = tx.i0 - ancx, cx1 = tx.i1 - ancx, cy0 = marg ? 0 : ty.i0 - ancy, cy1 = marg ? 0 : ty.i1 - ancy;
                     // window base of the plane: spatial planes 0 (xy), 1 (xz), 3 (yz), then the time planes 2 (xt), 4 (yt), 5 (zt)
-                    const int wbase = time_plane ? 3 * HEX_SCELLS + (p == 2 ? 0 : (p == 4 ? HEX_TW : 2 * HEX_TW)) : (p == 3 ? 2 : p) * HEX_SCELLS;
+                    const int wbase = time_plane ? tbase + (p == 2 ? 0 : (p == 4 ? tw : 2 * tw)) : (p == 3 ? 2 : p) * HEX_SCELLS;
                     // the whole 2 x 2 footprint in the window (the anchor is the block's smallest tap, but a NaN coordinate maps to
                     // cell 0): one address, two strides (0 where the neighbour was clamped onto the same cell at the border)
                     const bool inside = cx0 >= 0 && cy0 >= 0 && cx1 < wx && cy1 < wy;
@@ -555,14 +559,14 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
             const float v = (float)win[cell * C + c];
             if (v == 0.f) continue;                       // (only cells a tap reached are non-zero)
             win[cell * C + c] = 0.0;
-            if (cell < 3 * HEX_SCELLS) {
+            if (cell < tbase) {
                 const int idx = cell / HEX_SCELLS, local = cell - idx * HEX_SCELLS, p = idx == 2 ? 3 : idx;
                 int ax, ay;
                 pair_axes(p, ax, ay);
                 const int x = sel4i(anc[0], anc[1], anc[2], anc[3], ax) + local % HEX_SW, y = sel4i(anc[0], anc[1], anc[2], anc[3], ay) + local / HEX_SW;
                 atomicAdd(g.dL_dplanes[s][p] + tap_at(x, y, a.res[s][ax], C, c), v);
             } else {
-                const int idx = (cell - 3 * HEX_SCELLS) / HEX_TW, local = cell - 3 * HEX_SCELLS - idx * HEX_TW, p = idx == 0 ? 2 : (idx == 1 ? 4 : 5);
+                const int idx = (cell - tbase) / tw, local = cell - tbase - idx * tw, p = idx == 0 ? 2 : (idx == 1 ? 4 : 5);
                 const int ax = idx, W = a.res[s][ax];       // planes 2, 4, 5 pair x, y, z with the time
                 float* gp = g.dL_dplanes[s][p];
                 if (tuni) {
@@ -570,7 +574,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     atomicAdd(gp + tap_at(x, tt.i0, W, C, c), v * (1.f - tt.f));
                     if (tt.f != 0.f) atomicAdd(gp + tap_at(x, tt.i1, W, C, c), v * tt.f);
                 } else {
-                    const int x = sel4i(anc[0], anc[1], anc[2], anc[3], ax) + local % (HEX_TW / 2), y = anc[3] + local / (HEX_TW / 2);
+                    const int x = sel4i(anc[0], anc[1], anc[2], anc[3], ax) + local % (tw / 2), y = anc[3] + local / (tw / 2);
                     atomicAdd(gp + tap_at(x, y, W, C, c), v);
                 }
             }

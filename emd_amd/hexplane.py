@@ -116,17 +116,24 @@ def morton_order(pts, aabb, bits=10):
 
 
 def plane_order(pts, aabb, ax, ay, bits=12):
-    """int32 permutation that visits the points along a Z-order curve of TWO of their box-normalised coordinates (12 bits each): runs
-    of consecutive points are compact in the plane (ax, ay) whatever their third coordinate."""
+    """int32 permutation that visits the points along a HILBERT curve of TWO of their box-normalised coordinates (12 bits each): runs
+    of consecutive points are compact in the plane (ax, ay) whatever their third coordinate.  (A Z-order curve jumps: 256 consecutive
+    of 2 M uniform points then leave the per-plane pass's 16 x 16 window with 6.9 % of their taps at resolution 512, 2.4 % at 256, each
+    such tap four partly filled atomic instructions; along the Hilbert curve none do -- tests/analysis/plane_order_sim.py.)"""
     with torch.no_grad():
         q = ((pts.detach() - aabb[0]) / (aabb[1] - aabb[0])).clamp_(0.0, 1.0).mul_(float(2 ** bits - 1)).to(torch.int64)
-
-        def spread(v):                                  # 12 bits -> every second bit
-            v = (v | (v << 8)) & 0x00FF00FF
-            v = (v | (v << 4)) & 0x0F0F0F0F
-            v = (v | (v << 2)) & 0x33333333
-            return (v | (v << 1)) & 0x55555555
-        return (spread(q[:, ax]) | (spread(q[:, ay]) << 1)).argsort().to(torch.int32)
+        x, y = q[:, ax].clone(), q[:, ay].clone()
+        d = torch.zeros_like(x)
+        s = 1 << (bits - 1)
+        while s:                                        # the classic xy -> d walk, one level per pass, all points at once
+            rx, ry = (x & s) > 0, (y & s) > 0
+            d += (s * s) * ((3 * rx.to(torch.int64)) ^ ry.to(torch.int64))
+            flip = ~ry & rx
+            x = torch.where(flip, s - 1 - x, x)
+            y = torch.where(flip, s - 1 - y, y)
+            x, y = torch.where(~ry, y, x), torch.where(~ry, x, y)
+            s >>= 1
+        return d.argsort().to(torch.int32)
 
 
 class VisitingOrders:
@@ -146,7 +153,7 @@ class VisitingOrders:
         side = 1.7 * (run / max(n, 1)) ** (1.0 / 3.0)
         mask = 0
         for s, r in enumerate(res):
-            if side * max(r[:3]) > 1.5 * window:
+            if side * max(r[:3]) > float(__import__('os').environ.get('EMD_HEX_DEFER_FACTOR', '1.5')) * window:
                 mask |= 1 << s
         if not mask:
             return VisitingOrders(order)
