@@ -593,12 +593,15 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
 }
 
 // ---- per-plane pass of the deferred scales -----------------------------------------------------------------------------------
-// grid (runs of 256 positions, 3 planes).  The block walks 256 consecutive points of ITS plane's order: on a fine scale they cover a
-// few cells of that plane (2 M points over 512 x 512 cells: 7.6 points per cell; a run touches ~60 cells), so a 16 x 16 window of
-// fp64 cells catches 93 % of its taps (98 % at resolution 256: tests/analysis/hex_order_sim.py) and a cell row reaches HBM once per
-// block instead of once per tap.  Per scale: one thread per point computes the tap (from the plane's two normalised coordinates,
-// which the main kernel left beside the rows -- no dependent gather) and the block's anchor, then lane = channel: the point's row
-// (sequential in defer_rows, all loads of a lane group in flight at once), four LDS adds, then the flush.
+// grid (runs of 256 positions, 3 planes, deferred scales).  The block walks 256 consecutive points of ITS plane's order -- a Hilbert curve of
+// the plane's two coordinates (emd_amd/hexplane.py plane_order) -- : on a fine scale they cover a few cells of that plane (2 M points over
+// 512 x 512 cells: 7.6 points per cell; a run touches ~60 cells inside a 12 x 12 box: tests/analysis/plane_order_sim.py: 1 % of the taps
+// of uniform points leave a 12 x 12 window at resolution 512, none at 256; along a Z-order curve 7 % left even a 16 x 16 one), so a cell
+// row reaches HBM once per block instead of once per tap.  One thread per point computes the tap (from the plane's two normalised
+// coordinates, which the main kernel left beside the rows -- no dependent gather) and the block's anchor, then lane = channel: the point's
+// row (sequential in defer_rows, all loads of a lane group in flight at once), four LDS adds, then the flush.  Round 4: 1.30 -> 0.74 ms
+// at 2 M points (Hilbert orders 1.08; a workgroup per scale instead of a loop over the scales 1.05; 12 x 12 windows, i.e. 3 -> 4 resident
+// workgroups per CU: the chain load -> taps -> adds -> flush is latency, and what hides it is the number of chains in flight).
 #ifndef HEX_PL_THREADS
 #define HEX_PL_THREADS 512
 #endif
@@ -606,14 +609,13 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
 #define HEX_PL_POINTS 256
 #endif
 #ifndef HEX_PW
-#define HEX_PW 16
+#define HEX_PW 12                        /* 12 x 12 fp64 cells + staging = 39.9 KB: four workgroups (32 waves) per CU */
 #endif
 template <int C>
 __global__ void __launch_bounds__(HEX_PL_THREADS) k_hexplane_bwd_plane(EmdHexArgs a, EmdHexGrads g) {
     constexpr int GROUPS = HEX_PL_THREADS / C, PER = HEX_PL_POINTS / GROUPS, WCELLS = HEX_PW * HEX_PW;
     __shared__ double win[WCELLS * C];
-    __shared__ int s_x0[HEX_PL_POINTS], s_y0[HEX_PL_POINTS];           // tap cell
-    __shared__ uint32_t s_d[HEX_PL_POINTS];                              // (x1 - x0) | (y1 - y0) << 1
+    __shared__ uint32_t s_tap[HEX_PL_POINTS];                            // tap cell x0 | y0 << 14 | (x1 - x0) << 28 | (y1 - y0) << 29 (resolutions < 2^14, checked on the host)
     __shared__ float2 s_f[HEX_PL_POINTS];
     __shared__ int cmin[2];
     const int tid = threadIdx.x, group = tid / C, c = tid % C, pidx = blockIdx.y, p = pidx == 2 ? 3 : pidx;
@@ -625,11 +627,15 @@ __global__ void __launch_bounds__(HEX_PL_THREADS) k_hexplane_bwd_plane(EmdHexArg
     const float2* defer_q = (const float2*)(g.defer_rows + (size_t)__builtin_popcount(g.defer_mask) * 3 * NC) + (size_t)pidx * a.num_points;
     for (int i = tid; i < WCELLS * C; i += HEX_PL_THREADS) win[i] = 0.0;
     const float2 q = tid < count ? defer_q[first + tid] : make_float2(0.f, 0.f);
-    int sidx = 0;
-    for (uint32_t rest = g.defer_mask; rest; rest &= rest - 1, sidx++) {
+    // one workgroup per (run, plane, deferred scale): nothing is carried from scale to scale, and the chain load -> taps -> adds -> flush of one
+    // scale no longer waits for the flush of the one before
+    const int sidx = blockIdx.z;
+    {
+        uint32_t rest = g.defer_mask;
+        for (int k = 0; k < sidx; k++) rest &= rest - 1;
         const int s = __builtin_ctz(rest);
         float* gp = g.dL_dplanes[s][p];
-        if (!gp) continue;                                                 // (uniform)
+        if (!gp) return;                                                   // (uniform)
         const float* rows = g.defer_rows + ((size_t)sidx * 3 + pidx) * NC;
         const int W = a.res[s][ax], H = a.res[s][ay];
         // the group's rows, all in flight at once (while the taps are staged)
@@ -643,8 +649,7 @@ __global__ void __launch_bounds__(HEX_PL_THREADS) k_hexplane_bwd_plane(EmdHexArg
         __syncthreads();
         if (tid < count) {
             const Tap1 tx = tap1(q.x, W), ty = tap1(q.y, H);
-            s_x0[tid] = tx.i0; s_y0[tid] = ty.i0;
-            s_d[tid] = (uint32_t)(tx.i1 - tx.i0) | ((uint32_t)(ty.i1 - ty.i0) << 1);
+            s_tap[tid] = (uint32_t)tx.i0 | ((uint32_t)ty.i0 << 14) | ((uint32_t)(tx.i1 - tx.i0) << 28) | ((uint32_t)(ty.i1 - ty.i0) << 29);
             s_f[tid] = make_float2(tx.f, ty.f);
             atomicMin(&cmin[0], tx.i0);
             atomicMin(&cmin[1], ty.i0);
@@ -656,7 +661,8 @@ __global__ void __launch_bounds__(HEX_PL_THREADS) k_hexplane_bwd_plane(EmdHexArg
             const int j = group + GROUPS * k;
             const float gi = gis[k];
             if (j >= count || gi == 0.f) continue;
-            const int x0 = s_x0[j], y0 = s_y0[j], dx = s_d[j] & 1u, dy = s_d[j] >> 1;
+            const uint32_t tap = s_tap[j];
+            const int x0 = tap & 0x3fffu, y0 = (tap >> 14) & 0x3fffu, dx = (tap >> 28) & 1u, dy = (tap >> 29) & 1u;
             const float fx = s_f[j].x, fy = s_f[j].y;
             const int cx0 = x0 - ancx, cy0 = y0 - ancy;
             const float w00 = gi * ((1.f - fx) * (1.f - fy)), w10 = gi * (fx * (1.f - fy)), w01 = gi * ((1.f - fx) * fy), w11 = gi * (fx * fy);
@@ -692,7 +698,16 @@ void launch_bwd_agg(const EmdHexArgs* a, const EmdHexGrads* g, hipStream_t st) {
     while (stride == 0 || gcd(stride, blocks) != 1) stride++;          // a bijection on [0, blocks)
     hipLaunchKernelGGL(k_hexplane_bwd_agg<C>, dim3(blocks), dim3(HEX_AGG_THREADS), 0, st, *a, *g, stride);
     if (g->defer_mask)
-        hipLaunchKernelGGL(k_hexplane_bwd_plane<C>, dim3((unsigned)((a->num_points + HEX_PL_POINTS - 1) / HEX_PL_POINTS), 3), dim3(HEX_PL_THREADS), 0, st, *a, *g);
+        hipLaunchKernelGGL(k_hexplane_bwd_plane<C>, dim3((unsigned)((a->num_points + HEX_PL_POINTS - 1) / HEX_PL_POINTS), 3, (unsigned)__builtin_popcount(g->defer_mask)),
+                           dim3(HEX_PL_THREADS), 0, st, *a, *g);
+}
+
+// the per-plane pass packs a tap cell into 14 + 14 bits
+bool defer_res_ok(const EmdHexArgs* a, unsigned mask) {
+    for (int s = 0; s < a->num_scales; s++)
+        if ((mask >> s) & 1u)
+            for (int k = 0; k < 3; k++) if (a->res[s][k] >= (1 << 14)) return false;
+    return true;
 }
 
 int check_hex(const EmdHexArgs* a, const char* who) {
@@ -738,8 +753,8 @@ extern "C" int emd_hexplane_backward(const EmdHexArgs* a, const EmdHexGrads* g, 
     if (g->defer_mask) {
         const bool agg = a->order && (a->channels == 32 || a->channels == 16);
         if (!agg || !g->defer_rows || !g->order2d[0] || !g->order2d[1] || !g->order2d[2] || !g->pos2d[0] || !g->pos2d[1] || !g->pos2d[2] ||
-            (g->defer_mask >> a->num_scales) || (int64_t)a->num_points * a->channels * 4 >= ((int64_t)1 << 32)) {
-            emd_set_error("hexplane_backward: defer_mask needs a visiting order, 16 or 32 channels, order2d / pos2d / defer_rows, bits below num_scales and N * C < 2^30");
+            (g->defer_mask >> a->num_scales) || (int64_t)a->num_points * a->channels * 4 >= ((int64_t)1 << 32) || !defer_res_ok(a, g->defer_mask)) {
+            emd_set_error("hexplane_backward: defer_mask needs a visiting order, 16 or 32 channels, order2d / pos2d / defer_rows, bits below num_scales, deferred resolutions < 2^14 and N * C < 2^30");
             return EMD_ERR_INVALID;
         }
     }
