@@ -335,7 +335,8 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
 __device__ __forceinline__ int order_key(float v) { const int b = __float_as_int(v); return b >= 0 ? b : b ^ 0x7fffffff; }   // monotone int image
 __device__ __forceinline__ float key_value(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
 
-template <int C>
+// DT: dL/dtimes is wanted (the training steps do not ask for it: the time planes' slope along t, a fourth lane sum and its adds drop out)
+template <int C, bool DT>
 __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexArgs a, EmdHexGrads g, unsigned chunk_stride) {
     constexpr int WAVES = HEX_AGG_THREADS / 64, GW = 64 / C, PER_WAVE = HEX_AGG_POINTS / WAVES, ITERS = PER_WAVE / GW, GROUPS = HEX_AGG_THREADS / C;
     constexpr int SROWS = 2 * GW * 6;                   // staging rows of TWO iterations (one stage() call)
@@ -487,12 +488,12 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     pair_axes(p, ax, ay);
                     gi[p] = go * (pre[p] * suf[p + 1]);                      // dL / d interp of plane p, channel c
                     dq[ax] += gi[p] * dix[p];
-                    dq[ay] += gi[p] * diy[p];
+                    if (DT || ay < 3) dq[ay] += gi[p] * diy[p];
                 }
                 if (want_dq) {
                     // summed over the C channel lanes; a point belongs to one lane group of one wave: plain adds across the scales
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {                          // DPP row sums; the last lane of the group holds the total
+                    for (int k = 0; k < (DT ? 4 : 3); k++) {               // DPP row sums; the last lane of the group holds the total
                         float v = dq[k];
                         v = dpp_add_f32<DPP_ROW_SHR(1), 0xf>(v);
                         v = dpp_add_f32<DPP_ROW_SHR(2), 0xf>(v);
@@ -696,7 +697,8 @@ void launch_bwd_agg(const EmdHexArgs* a, const EmdHexGrads* g, hipStream_t st) {
     unsigned stride = 7919u % blocks;
     auto gcd = [](unsigned x, unsigned y) { while (y) { unsigned t = x % y; x = y; y = t; } return x; };
     while (stride == 0 || gcd(stride, blocks) != 1) stride++;          // a bijection on [0, blocks)
-    hipLaunchKernelGGL(k_hexplane_bwd_agg<C>, dim3(blocks), dim3(HEX_AGG_THREADS), 0, st, *a, *g, stride);
+    if (g->dL_dtimes) hipLaunchKernelGGL((k_hexplane_bwd_agg<C, true>), dim3(blocks), dim3(HEX_AGG_THREADS), 0, st, *a, *g, stride);
+    else hipLaunchKernelGGL((k_hexplane_bwd_agg<C, false>), dim3(blocks), dim3(HEX_AGG_THREADS), 0, st, *a, *g, stride);
     if (g->defer_mask)
         hipLaunchKernelGGL(k_hexplane_bwd_plane<C>, dim3((unsigned)((a->num_points + HEX_PL_POINTS - 1) / HEX_PL_POINTS), 3, (unsigned)__builtin_popcount(g->defer_mask)),
                            dim3(HEX_PL_THREADS), 0, st, *a, *g);
