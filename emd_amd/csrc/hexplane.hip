@@ -320,9 +320,12 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
 //    accumulated as x-MARGINALS: two adds per point instead of four, into 32 cells per plane, and the flush spreads a cell over the
 //    two time rows with the block's (1 - ft, ft).  Blocks with mixed times use the same memory as 16 x 2 windows;
 //  * dL/dpts and dL/dtimes are summed over the scales in LDS and written once.
-// What bounds it now (2 M uniform points, rocprofv3 counters): 31 M wave-level atomic instructions = 55 M rows, of which 38 M are
-// the direct rows of the two finest scales (a 256-point run spans ~40 x 40 cells of the 512-cell planes and puts 1.4 taps into a
-// cell: nothing to aggregate) and 13 M the flushes; with the atomics compiled out the kernel takes 3.4 ms.
+// What bounds it (round 4, 2 M uniform points, builds with one part compiled out): without the tap gathers 4.04 -> 3.80 ms, without the
+// deferred-row stores 3.84, without the LDS adds and the flush atomics 3.11: the gathers are hidden, the atomics cost 0.9 ms, the rest is
+// instruction issue (520 vector + 336 scalar + 81 LDS instructions per iteration of two points).  Two channels per lane (packed fp32, 45 %
+// fewer vector instructions per point) was built and measured SLOWER, 5.2 ms: 48 tap registers in flight per iteration, spills at the
+// 128-VGPR cap or three waves per SIMD without them -- four un-spilled waves per SIMD are worth more than the instruction count (DESIGN.md
+// section 8, round 4).  Built without SLP vectorisation (Makefile): the packer cost 129 v_mov per iteration and 8 spilled registers.
 #ifndef HEX_AGG_THREADS
 #define HEX_AGG_THREADS 1024             /* one block per CU (152 KB of LDS at 32 channels), four waves per SIMD */
 #define HEX_AGG_POINTS 256

@@ -1,3 +1,6 @@
+"""How many taps of a run of consecutive points leave the per-plane pass's window (csrc/hexplane.hip k_hexplane_bwd_plane), and how many cell
+rows a run flushes, for plane orders along a Z-order curve and along a Hilbert curve: 2 M uniform points, runs of 256 / 512, a 16 x 16
+window anchored at the run's smallest tap.     python3 tests/analysis/plane_order_sim.py"""
 import numpy as np
 N=2_000_000
 rng=np.random.default_rng(0)
