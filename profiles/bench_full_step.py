@@ -25,7 +25,6 @@ import torch
 
 sys.path.insert(0, ".")
 from emd_amd import dp, scenes, RasterOptions  # noqa: E402
-from emd_amd import rasterizer as _rz  # noqa: E402
 from emd_amd.loss import image_loss  # noqa: E402
 from emd_amd.model import StreetGaussians, abs_mean, render, residual_abs_mean  # noqa: E402
 from emd_amd.sky import SkyCubeMap, composite_s3g  # noqa: E402
@@ -114,8 +113,7 @@ for f in range(0, F, 7):
     with torch.no_grad():
         o = render(model, cams[f], bg, frame=f, deformation=deform, embeddings=embeddings, iteration=12000, time=f / (F - 1), options=OPTS[0])
     dmax = max(dmax, o["raster_call"].last_status()["num_rendered"])
-_rz._capacity_hint[(dev.index, H, W)] = int(dmax * 1.3) + 1024
-OPTS[0] = RasterOptions(no_sync=True)
+OPTS[0] = RasterOptions(no_sync=True, capacity_hint=int(dmax * 1.3) + 1024)
 for s in range(10):
     step(s)
 torch.cuda.synchronize()
