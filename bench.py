@@ -196,6 +196,8 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=150.0, help="untimed replays of the step before the warm-up steps until this much wall time has passed: "
                     "the clocks of an idle GPU take tens of milliseconds of load to settle, more than 5 warm-up steps of 1.4 ms provide (0 = off)")
     ap.add_argument("--eager", action="store_true", help="issue every step from Python instead of replaying it from a hipGraph (1 GPU)")
+    ap.add_argument("--one-graph", action="store_true", help="multi-GPU / --factored-sh: record the step as ONE graph and issue the whole exchange behind its replay "
+                    "(default: two graphs cut between the render backward and the projection backward, the factor gathers issued between their replays)")
     ap.add_argument("--exchange-only", action="store_true",
                     help="time ONLY the gradient exchange of a view-parallel step (GradientExchange.start + finish on a fixed backward's outputs): "
                          "separates communication from compute in the 2/4/8-GPU runs")
@@ -310,7 +312,8 @@ def main():
     # ~20 us per step instead of ~1-2 ms of Python + launch calls, i.e. the run is GPU-bound whatever the host is doing.
     # (--eager, or a failed capture, issues the same step from Python.)
     period = args.warmup + args.steps             # the repeats replay the timed views: row = warmup + (step - warmup) mod steps
-    graph = None
+    graph = graph_b = None
+    two_graphs = False
     settle_replays = 0
     out = o = None          # no autograd graph of an eager step may be alive at capture time (its AccumulateGrad nodes are bound to the eager stream)
     import gc
@@ -337,7 +340,7 @@ def main():
             th = model.track_heads
             k_sched = (th.min_embeddings, th.max_embeddings, th.c2f_temporal_iter) if th is not None else None
 
-            def graph_body():
+            def graph_body(cut=None):
                 for p in params:
                     p.grad = None
                 # (the row index doubles as the training step of the coarse-to-fine schedule, as the eager step passes it)
@@ -348,6 +351,7 @@ def main():
                                               camera_center=blk[35:38])
                 rec_g = RasterCall()
                 rec_g.status_buffer = status_static          # the call's status words at a fixed address: the next step's select launch logs them
+                rec_g.on_sh_factor = cut                     # (two-graph capture: called between the halves of the rasterizer's backward)
                 o = render(model, cam_g, blk[0:3], frame=frame_dev, iteration=DeviceStep(k_fine=kf_dev, t=t_dev), options=opts, record=rec_g)
                 l1_loss(o["render"], target).backward(unit)
                 if stats is not None:
@@ -365,11 +369,42 @@ def main():
             torch.cuda.synchronize()
             prev_sel.fill_(-1)
             graph = torch.cuda.CUDAGraph()
-            # (multi-rank: the process group's watchdog thread polls events while we capture; "thread_local" keeps its calls from
-            #  invalidating the capture -- nothing of the exchange is captured)
-            with torch.cuda.graph(graph, stream=side, capture_error_mode="global" if world == 1 else "thread_local"):
-                graph_body()
+            if opts.factored_sh_grad and not args.one_graph:
+                # ---- TWO graphs, cut between the halves of the rasterizer's backward: [forward, loss, render backward K7, SH factor] |
+                # [projection backward K8, actor chain backward].  RCCL collectives cannot be captured, so a one-graph step can only start its
+                # exchange behind the replay; with the cut the factor gathers are issued between the two replays and travel under K8.
+                # The cut is made from RasterCall.on_sh_factor, i.e. from autograd's device thread: capture A is ended and capture B begun
+                # there, capture B ended by this thread -- stream capture in "relaxed" mode (the only mode that allows begin / end on
+                # different threads; it also keeps the process group's watchdog thread from invalidating the capture).
+                graph_b = torch.cuda.CUDAGraph()
+                cut_state = {"n": 0}
+
+                def cut_capture(_rec):
+                    graph.capture_end()
+                    graph_b.capture_begin(pool=graph.pool(), capture_error_mode="relaxed")
+                    cut_state["n"] += 1
+                gc.collect()
+                torch.cuda.synchronize()
+                with torch.cuda.stream(side):
+                    graph.capture_begin(capture_error_mode="relaxed")
+                    try:
+                        graph_body(cut=cut_capture)
+                    finally:
+                        (graph_b if cut_state["n"] else graph).capture_end()
+                if cut_state["n"] != 1:
+                    raise RuntimeError(f"two-graph capture: the backward was cut {cut_state['n']} times")
+                gstate["rec"].on_sh_factor = None
+            else:
+                # (multi-rank: the process group's watchdog thread polls events while we capture; "thread_local" keeps its calls from
+                #  invalidating the capture -- nothing of the exchange is captured)
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="global" if world == 1 else "thread_local"):
+                    graph_body()
             torch.cuda.synchronize()
+
+            def replay_compute():
+                graph.replay()
+                if graph_b is not None:
+                    graph_b.replay()
             # ---- self-check of the captured graph before it is trusted with the timed region: two replays of row 0 must reproduce the
             # eager step's device status words (D, V) and leave finite, identical parameter gradients (a memset node captured on ROCm 7.2
             # replayed with a corrupt fill pattern from the SECOND replay on: that is how the library's zero fills became kernels)
@@ -382,7 +417,7 @@ def main():
             for rep_ in range(2):
                 sel.fill_(0)
                 prev_sel.fill_(-1)
-                graph.replay()
+                replay_compute()
                 torch.cuda.synchronize()
                 if not torch.equal(status_static[:3], want_status[:3]):
                     raise RuntimeError(f"replay {rep_}: status words {status_static.tolist()} differ from the eager step's {want_status.tolist()}")
@@ -397,7 +432,7 @@ def main():
             t_settle = time.perf_counter()
             while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
                 for _ in range(8):
-                    graph.replay()
+                    replay_compute()
                     settle_replays += 1
                 torch.cuda.synchronize()
             sel.fill_(0)                                      # the first replay renders row 0; every replay leaves the next row in `sel`
@@ -405,7 +440,7 @@ def main():
             torch.cuda.synchronize()
         except Exception as e:          # capture is an optimisation of the host side only: fall back to issuing the step from Python
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
+            graph = graph_b = None
 
     def row_of(step):
         return step if step < period else args.warmup + (step - args.warmup) % args.steps
@@ -421,9 +456,12 @@ def main():
         if graph is not None:
             graph.replay()                                    # (`sel` was advanced to row_of(step) by the replay before)
             if opts.factored_sh_grad:
-                # the exchange is issued behind the replay (RCCL collectives are not captured): what follows K8 inside the graph is
-                # one ~8 us launch of the actor chain's backward, so nothing is lost against starting it from inside backward()
+                # RCCL collectives are not captured.  Two graphs: the factor gathers are issued between the replays and run under K8, the
+                # slab all-reduce behind the second; one graph (--one-graph): the whole exchange behind the replay
                 xchg = dp.GradientExchange(gstate["campos"], actor_ids=model.actor_id if model.has_actors else None, actor_pose=gstate["pose"])
+                if graph_b is not None:
+                    xchg.start_factors(gstate["rec"])
+                    graph_b.replay()
                 xchg.start(gstate["rec"])
                 xchg.finish(model._features, model._xyz, model.active_sh_degree, other_params=params)
             elif world > 1:
@@ -497,6 +535,9 @@ def main():
                                            "of the pixel's last contributor; counting instantiation of the kernel (EmdBwdArgs.pair_stats), outside the timed region"}
     if graph is not None:          # release the captured graph and its memory pool explicitly, in a quiet state
         torch.cuda.synchronize()
+        two_graphs = graph_b is not None
+        if two_graphs:
+            graph_b.reset()
         graph.reset()
         graph = "released"
     if world > 1:
@@ -580,7 +621,9 @@ def main():
                        "rig_cameras": num_cams, "rank_view_mapping": mapping, "track_heads": heads_on,
                        "densification_stats_in_step": bool(args.densify_stats),
                        "step_issue": ("hipGraph replay (one capture; camera block, frame, frame time and coarse-to-fine level selected on the device by one launch"
-                                      + ("; the gradient exchange is issued behind each replay)" if world > 1 else ")"))
+                                      + (("; TWO graphs cut between the render backward and the projection backward: the SH-factor gathers are issued "
+                                          "between their replays and travel under K8, the slab all-reduce behind the second)") if two_graphs else
+                                         ("; the gradient exchange is issued behind each replay)" if (world > 1 or opts.factored_sh_grad) else ")")))
                                      if graph is not None else "eager (Python issues every launch)",
                        "parallelism": f"view-parallel dp{world}", "count_readback": bool(args.sync_count),
                        "gradient_exchange": ("none (1 GPU)" if world == 1 else
