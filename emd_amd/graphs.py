@@ -103,13 +103,21 @@ class StepInputs:
 
 
 class StepGraphs:
-    def __init__(self, step_fn, keys, prime=None, freeze=(), optimizers=(), warmup=1, inputs=None):
+    def __init__(self, step_fn, keys, prime=None, freeze=(), optimizers=(), warmup=1, inputs=None, segmented=False):
         """step_fn(key) -> None records one training step.  `warmup` eager calls of the FIRST key run before recording, on the capture
         stream (lazy allocations: workspaces, caches); `prime(key)` runs for every key, without gradients (per-key host constants).
         `inputs` (a StepInputs whose rows are the keys, in order): ONE graph for all keys -- step_fn(inputs) reads the view from
         `inputs.camera / .bg / .frame / .time` (device memory the graph's first node fills from the selected row) and must not bake anything
-        else of a view into its launches; `replay(key)` selects the row and replays the one graph."""
+        else of a view into its launches; `replay(key)` selects the row and replays the one graph.
+        `segmented`: the recorded step may call `self.cut` -- from any thread, typically as `RasterCall.on_sh_factor`, which the rasterizer's
+        backward calls between its halves from autograd's device thread -- to end the current graph and begin the next: a step then is a
+        LIST of graphs, and `replay(key, between=fn)` calls `fn(i)` on the host between segment i and i + 1.  That is where a view-parallel
+        loop issues the collectives that cannot be captured (RCCL): `between=lambda i: exchange.start_factors(rec)` puts the SH-factor
+        gathers under the projection backward of a REPLAYED step.  Stream capture then runs in relaxed mode (the only
+        mode in which begin and end may come from different threads)."""
         self.keys = list(keys)
+        self.segmented = bool(segmented)
+        self._recording = None
         self.inputs = inputs
         if inputs is not None:
             if len(self.keys) != inputs.rows:
@@ -161,10 +169,23 @@ class StepGraphs:
             with torch.cuda.stream(side):
                 for k in (self.keys if inputs is None else self._record_keys):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=self.pool, stream=side):
+                    if not self.segmented:
+                        with torch.cuda.graph(g, pool=self.pool, stream=side):
+                            step_fn(k)
+                        self.pool = g.pool()
+                        self.graphs[k] = g
+                        continue
+                    torch.cuda.synchronize()
+                    self._recording = [g]
+                    if self.pool is None:
+                        self.pool = torch.cuda.graph_pool_handle()        # (a graph's own pool() is only known once its capture has ended)
+                    g.capture_begin(pool=self.pool, capture_error_mode="relaxed")
+                    try:
                         step_fn(k)
-                    self.pool = g.pool()
-                    self.graphs[k] = g
+                    finally:
+                        segs, self._recording = self._recording, None
+                        segs[-1].capture_end()
+                    self.graphs[k] = segs
         except BaseException:
             # a failed recording must not leave the fields frozen: the caller gets no object to release() them with
             for f, every in saved:
@@ -178,12 +199,35 @@ class StepGraphs:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
-    def replay(self, key):
+    def cut(self, *_):
+        """Inside a recording of a `segmented` StepGraphs: ends the current graph and begins the next, on the capture stream and in the same
+        memory pool (callable from any thread; the arguments a hook is called with are ignored).  Outside a recording: nothing."""
+        segs = self._recording
+        if segs is None:
+            return
+        segs[-1].capture_end()
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self.pool, capture_error_mode="relaxed")
+        segs.append(g)
+
+    def segments(self, key=None):
+        """Number of graphs the step of `key` was recorded as (1 unless `segmented` and the step called `cut`)."""
+        g = self.graphs[self._record_keys[0] if self.inputs is not None else (self.keys[0] if key is None else key)]
+        return len(g) if isinstance(g, list) else 1
+
+    def replay(self, key, between=None):
         if self.inputs is not None:
             self.inputs.select(self._row_of[key])
-            self.graphs[self._record_keys[0]].replay()
+            g = self.graphs[self._record_keys[0]]
         else:
-            self.graphs[key].replay()
+            g = self.graphs[key]
+        if not isinstance(g, list):
+            g.replay()
+            return
+        for i, seg in enumerate(g):
+            seg.replay()
+            if between is not None and i + 1 < len(g):
+                between(i)
 
     def release(self):
         """Drop the graphs (and their pool) and give the frozen fields their refresh interval back."""

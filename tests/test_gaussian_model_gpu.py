@@ -376,3 +376,75 @@ def test_one_graph_for_all_views_equals_the_graphs_per_view():
     losses = [float(x) for x in losses]
     assert captures == 5 and len(set(counts)) >= 3, (captures, counts[::20])
     assert all(np.isfinite(losses)) and np.mean(losses[-20:]) < np.mean(losses[:20])
+
+
+def test_segmented_step_graphs_are_cut_inside_backward():
+    """StepGraphs(..., segmented=True): the recorded step calls `graphs.cut` from RasterCall.on_sh_factor -- i.e. from autograd's device thread,
+    between the render backward and the projection backward -- and is recorded as TWO graphs; `replay(key, between=fn)` runs fn on the host
+    between them (where a view-parallel loop issues the SH-factor gathers, which then travel under the projection backward of a REPLAYED
+    step: DESIGN section 7).  What the pair leaves -- image, factor, every gradient of the slab -- equals the one-graph step, for three views
+    of one StepInputs, and the colour factor is complete when `between` runs."""
+    from emd_amd import GaussianRasterizer, RasterCall, RasterOptions, StepGraphs, StepInputs, scenes
+    from emd_amd.model import l1_loss, raster_settings_for
+    torch.manual_seed(0)
+    H, W, N, NV = 96, 128, 5000, 3
+    sc = scenes.make_static_scene(N, seed=5)
+    means = sc.means.clone()
+    means[:, 0] = means[:, 0] * 0.25 + 1.0
+    means[:, 1] *= 0.3
+    means[:, 2] = means[:, 2] * 0.3 + 1.0
+    cams = [scenes.small_camera(H, W, yaw=-20.0 + 15.0 * v, focal=W) for v in range(NV)]
+    bg = torch.tensor([0.05, 0.1, 0.15])
+    targets = (torch.rand(NV, 3, H, W, generator=torch.Generator().manual_seed(2)) * 0.5 + 0.25).to(DEV)
+    P = {"xyz": means.to(DEV).requires_grad_(True), "shs": (torch.randn(N, 16, 3, generator=torch.Generator().manual_seed(3)) * 0.2).to(DEV).requires_grad_(True),
+         "opacity": torch.full((N, 1), 0.5, device=DEV).requires_grad_(True), "scaling": (sc.log_scales + 1.0).exp().to(DEV).requires_grad_(True),
+         "rotation": torch.nn.functional.normalize(torch.randn(N, 4, generator=torch.Generator().manual_seed(6)), dim=1).to(DEV).requires_grad_(True)}
+    opts = RasterOptions(compute_normal=False, no_sync=True, capacity_hint=2_000_000, factored_sh_grad=True)
+    inputs = StepInputs(cams, bg, frames=list(range(NV)), device=DEV)
+    out, holder = {}, {}
+
+    def step(view):
+        for p in P.values():
+            p.grad = None
+        rs = raster_settings_for(view.camera, view.bg, 3)
+        rec = RasterCall()
+        rec.on_sh_factor = holder["graphs"].cut if holder.get("graphs") is not None else None
+        img = GaussianRasterizer(rs, options=opts)(means3D=P["xyz"], means2D=torch.zeros_like(P["xyz"], requires_grad=True), shs=P["shs"],
+                                                   opacities=P["opacity"], scales=P["scaling"], rotations=P["rotation"], record=rec)[0]
+        l1_loss(img, targets.index_select(0, view.frame.long())[0]).backward()
+        out["img"], out["rec"] = img.detach(), rec
+        out["grads"] = (P["xyz"].grad, P["opacity"].grad, P["scaling"].grad, P["rotation"].grad)
+
+    # a proxy the step can name before the StepGraphs object exists (its constructor already runs the step)
+    class _Cut:
+        target = None
+        def cut(self, *a):
+            if self.target is not None:
+                self.target.cut(*a)
+    proxy = _Cut()
+    holder["graphs"] = None
+    one = StepGraphs(step, list(range(NV)), warmup=1, inputs=inputs)
+    want = {}
+    for v in (2, 0, 1):
+        one.replay(v)
+        want[v] = (out["img"].clone(), out["rec"].sh_color_grad.clone()) + tuple(g.clone() for g in out["grads"])
+    one.release()
+    holder["graphs"] = proxy
+    two = StepGraphs.__new__(StepGraphs)
+    proxy.target = two
+    two.__init__(step, list(range(NV)), warmup=1, inputs=inputs, segmented=True)
+    assert two.segments() == 2
+    seen = []
+    for v in (1, 2, 0, 2):
+        def between(i, v=v):
+            # host code between the graphs: the colour factor of THIS view is complete on the stream (a collective issued here reads it)
+            seen.append((v, i, float((out["rec"].sh_color_grad - want[v][1]).abs().max())))
+        two.replay(v, between=between)
+        torch.cuda.synchronize()
+        got = (out["img"], out["rec"].sh_color_grad) + tuple(out["grads"])
+        assert torch.equal(got[0], want[v][0])                     # the image bit for bit
+        for a, b in zip(got[1:], want[v][1:]):                     # (gradients are sums of float atomics: equal up to their order)
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
+    assert [s_[:2] for s_ in seen] == [(1, 0), (2, 0), (0, 0), (2, 0)]
+    assert all(s_[2] <= 1e-5 * float(want[s_[0]][1].abs().max()) + 1e-12 for s_ in seen)
+    two.release()
