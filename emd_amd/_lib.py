@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16
@@ -207,7 +207,7 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_raster_backward", "emd_raster_export_binning", "emd_raster_export_geometry",
                     "emd_motion_forward", "emd_motion_backward", "emd_sh_forward", "emd_sh_backward",
                     "emd_profile_enable", "emd_profile_read", "emd_profile_stage_name", "emd_activations_forward", "emd_actor_pose_forward", "emd_actor_pose_backward", "emd_l1_loss",
-                    "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss", "emd_hexplane_forward", "emd_hexplane_backward", "emd_sh_grad_from_factors", "emd_densification_stats",
+                    "emd_sky_forward", "emd_sky_backward", "emd_image_loss_workspace", "emd_image_loss", "emd_hexplane_forward", "emd_hexplane_backward", "emd_hexplane_order_keys", "emd_sh_grad_from_factors", "emd_densification_stats",
                     "emd_temporal_embed_forward", "emd_temporal_embed_backward", "emd_deform_input_width", "emd_deform_input_forward",
                     "emd_deform_input_backward", "emd_adam_step", "emd_track_heads_forward", "emd_track_heads_backward",
                     "emd_densify_decide", "emd_densify_index", "emd_densify_split_rank", "emd_densify_gather",
@@ -266,6 +266,7 @@ def load():
     lib.emd_densification_stats.argtypes = [C.c_int32] + [C.c_void_p] * 6
     lib.emd_hexplane_forward.argtypes = [C.POINTER(EmdHexArgs), C.c_void_p]
     lib.emd_hexplane_backward.argtypes = [C.POINTER(EmdHexArgs), C.POINTER(EmdHexGrads), C.c_void_p]
+    lib.emd_hexplane_order_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.emd_temporal_embed_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_temporal_embed_backward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
     lib.emd_deform_input_width.argtypes = [C.c_int, C.c_int, C.c_int]

@@ -378,7 +378,6 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __r
     uint32_t nvalid_w = 0;
 #pragma unroll
     for (int k = 0; k < EMD_SORT_ITEMS; k++) {
-        const size_t idx = wbase + (size_t)k * 64 + lane;
         if (rank[k] != 0xFFFFFFFFu) {
             const uint32_t digit = ((key[k] - offset) >> shift) & mask;
             const uint32_t pos = s_cnt[wave][digit] + rank[k];

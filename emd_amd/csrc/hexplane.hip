@@ -733,7 +733,53 @@ int check_hex(const EmdHexArgs* a, const char* who) {
     return EMD_OK;
 }
 
+// ---- sort keys of the visiting orders ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {     // abcdefghij -> a00b00c00d00e00f00g00h00i00j
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    return (v | (v << 2)) & 0x09249249u;
+}
+__device__ __forceinline__ uint32_t hilbert2(uint32_t x, uint32_t y, int bits) {       // the classic xy -> d walk
+    uint32_t d = 0;
+    for (uint32_t s = 1u << (bits - 1); s; s >>= 1) {
+        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (!ry) {
+            if (rx) { x = s - 1u - x; y = s - 1u - y; }
+            const uint32_t t = x; x = y; y = t;
+        }
+    }
+    return d;
+}
+__global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_order_keys(const float* __restrict__ pts, const float* __restrict__ aabb, int64_t N, int32_t* __restrict__ keys) {
+    const int64_t n = (int64_t)blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    uint32_t q10[3], q12[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float u = (pts[3 * n + k] - aabb[k]) / (aabb[3 + k] - aabb[k]);
+        u = fminf(fmaxf(u, 0.f), 1.f);                    // (NaN -> 0: fmaxf returns the other operand)
+        q10[k] = (uint32_t)(u * 1023.f);
+        q12[k] = (uint32_t)(u * 4095.f);
+    }
+    keys[n] = (int32_t)(spread3(q10[0]) | (spread3(q10[1]) << 1) | (spread3(q10[2]) << 2));
+    keys[N + n] = (int32_t)hilbert2(q12[0], q12[1], 12);
+    keys[2 * N + n] = (int32_t)hilbert2(q12[0], q12[2], 12);
+    keys[3 * N + n] = (int32_t)hilbert2(q12[1], q12[2], 12);
+}
+
 }  // namespace
+
+extern "C" int emd_hexplane_order_keys(const float* pts, const float* aabb, int64_t num_points, int32_t* keys, void* hip_stream) {
+    if (num_points < 0 || (num_points > 0 && (!pts || !aabb || !keys))) { emd_set_error("hexplane_order_keys: null pointer"); return EMD_ERR_INVALID; }
+    if (num_points == 0) return EMD_OK;
+    hipLaunchKernelGGL(k_hexplane_order_keys, dim3((unsigned)((num_points + EMD_BLOCK - 1) / EMD_BLOCK)), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream,
+                       pts, aabb, num_points, keys);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
 
 extern "C" int emd_hexplane_forward(const EmdHexArgs* a, void* hip_stream) {
     int rc = check_hex(a, "hexplane_forward");

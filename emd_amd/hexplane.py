@@ -151,18 +151,26 @@ class VisitingOrders:
         filled atomic instructions --, 22 at 256).  Round 4: with the per-plane pass at 0.32 ms per scale the threshold came down from
         1.5 x to 1 x the window: main kernel 4.08 -> 3.69 ms, per-plane pass 0.63 -> 0.95 ms at 2 M points."""
         n = pts.shape[0]
-        order = morton_order(pts, aabb)
         side = 1.7 * (run / max(n, 1)) ** (1.0 / 3.0)
         mask = 0
         for s, r in enumerate(res):
             if side * max(r[:3]) > window:
                 mask |= 1 << s
+        keys = None
+        if pts.is_cuda and n > 0:
+            # all four sort keys in one launch (emd_hexplane_order_keys); `morton_order` / `plane_order` are the same curves in torch ops
+            # (~600 element-wise launches for the three Hilbert walks: 6 ms per refresh at 2 M points) and serve CPU tensors
+            keys = torch.empty(4 * n, device=pts.device, dtype=torch.int32)
+            L.check(L.load().emd_hexplane_order_keys(pts.detach().contiguous().float().data_ptr(), aabb.detach().contiguous().float().data_ptr(), n,
+                                                     keys.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_hexplane_order_keys")
+            keys = keys.view(4, n)
+        order = keys[0].argsort().to(torch.int32) if keys is not None else morton_order(pts, aabb)
         if not mask:
             return VisitingOrders(order)
         o2, p2 = [], []
         ar = torch.arange(n, device=pts.device, dtype=torch.int32)
-        for ax, ay in ((0, 1), (0, 2), (1, 2)):
-            o = plane_order(pts, aabb, ax, ay)
+        for k, (ax, ay) in enumerate(((0, 1), (0, 2), (1, 2))):
+            o = keys[1 + k].argsort().to(torch.int32) if keys is not None else plane_order(pts, aabb, ax, ay)
             inv = torch.empty_like(o)
             inv[o.long()] = ar
             o2.append(o)

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 21
+#define EMD_ABI_VERSION 22
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -510,6 +510,15 @@ typedef struct EmdHexGrads {
 
 int emd_hexplane_forward(const EmdHexArgs* args, void* hip_stream);
 int emd_hexplane_backward(const EmdHexArgs* args, const EmdHexGrads* grads, void* hip_stream);
+
+/* Sort keys of the visiting orders the aggregating backward is handed (EmdHexArgs.order, EmdHexGrads.order2d): in ONE launch, per point, the
+ * 30-bit Z-order key of its box-normalised position (10 bits per axis) -> keys[0 .. N) and the 24-bit HILBERT keys of its (x, y), (x, z),
+ * (y, z) coordinates (12 bits per axis) -> keys[N .. 4 N).  Runs of consecutive points of the sorted keys are compact in 3-D / in that
+ * plane; a Hilbert curve has no jumps, so a run of the per-plane pass stays inside its LDS window (a Z-order run leaves it with 7 % of its
+ * taps at resolution 512).  aabb: six floats, the two corners of the box in either order (HexPlaneField.aabb); coordinates are clamped
+ * into the box, NaN goes to cell 0.  [host side: emd_amd/hexplane.py VisitingOrders.build; no reference counterpart -- the reference's
+ * grid_sample backward scatters in the order the points come] */
+int emd_hexplane_order_keys(const float* pts, const float* aabb, int64_t num_points, int32_t* keys, void* hip_stream);
 
 /* ---- embedding ops in front of the deformation MLPs (rows a3, a12, a15) ---------------------
  * emd_temporal_embed_*: one row of the coarse-to-fine temporal embedding -- each of the num_tables [rows, dim] tables resized

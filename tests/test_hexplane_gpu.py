@@ -220,3 +220,31 @@ def test_hexplane_tolerates_nonfinite_points():
     assert torch.equal(out.detach()[rows], clean[rows])
     out.sum().backward()
     assert all(torch.isfinite(p.grad).all() for gp in field.grids for p in gp)
+
+
+def test_order_keys_kernel_matches_the_host_curves():
+    """emd_hexplane_order_keys (one launch: the Z-order key of the position and the Hilbert keys of the three spatial planes) against the same
+    curves written in torch ops (emd_amd.hexplane.morton_order / plane_order, which serve CPU tensors): the orders VisitingOrders.build forms from
+    the kernel's keys visit the same cells in the same sequence -- points of one cell may swap (argsort ties) --, including points outside the
+    box and NaN coordinates."""
+    from emd_amd.hexplane import VisitingOrders, morton_order, plane_order
+    DEV = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(1)
+    N = 40_000
+    aabb = torch.tensor([[1.6, 1.6, 1.6], [-1.6, -1.6, -1.6]], device=DEV)
+    pts = (torch.rand(N, 3, generator=g) * 3.6 - 1.8).to(DEV)          # some outside the box
+    pts[7, 1] = float("nan")
+    res = [[64, 64, 64, 25], [512, 512, 512, 25]]
+    vo = VisitingOrders.build(pts, aabb, res)
+    assert vo.defer_mask == 0b11 and sorted(vo.order.tolist()) == list(range(N))
+    clean = torch.where(torch.isnan(pts), aabb[0].expand_as(pts), pts)      # (the kernel sends NaN to cell 0 = the aabb[0] corner)
+    q = ((clean - aabb[0]) / (aabb[1] - aabb[0])).clamp(0.0, 1.0)
+
+    def cells(order, bits, axes):
+        return (q[order.long()][:, axes] * float(2 ** bits - 1)).to(torch.int64)
+    # the sequence of visited cells is the host curve's (ties inside a cell aside)
+    assert torch.equal(cells(vo.order, 10, [0, 1, 2]), cells(morton_order(clean, aabb), 10, [0, 1, 2]))
+    for k, (ax, ay) in enumerate(((0, 1), (0, 2), (1, 2))):
+        o = vo.order2d[k]
+        assert sorted(o.tolist()) == list(range(N)) and torch.equal(vo.pos2d[k].long()[o.long()], torch.arange(N, device=DEV))
+        assert torch.equal(cells(o, 12, [ax, ay]), cells(plane_order(clean, aabb, ax, ay), 12, [ax, ay]))
