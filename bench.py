@@ -389,8 +389,13 @@ def main():
                     graph.capture_begin(capture_error_mode="relaxed")
                     try:
                         graph_body(cut=cut_capture)
-                    finally:
-                        (graph_b if cut_state["n"] else graph).capture_end()
+                    except BaseException:
+                        try:
+                            (graph_b if cut_state["n"] else graph).capture_end()      # (leave capture mode; the body's error is the one to report)
+                        except Exception:
+                            pass
+                        raise
+                    (graph_b if cut_state["n"] else graph).capture_end()
                 if cut_state["n"] != 1:
                     raise RuntimeError(f"two-graph capture: the backward was cut {cut_state['n']} times")
                 gstate["rec"].on_sh_factor = None

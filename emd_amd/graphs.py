@@ -182,9 +182,15 @@ class StepGraphs:
                     g.capture_begin(pool=self.pool, capture_error_mode="relaxed")
                     try:
                         step_fn(k)
-                    finally:
+                    except BaseException:
                         segs, self._recording = self._recording, None
-                        segs[-1].capture_end()
+                        try:
+                            segs[-1].capture_end()             # leave the stream out of capture mode; the step's own error is the one to report
+                        except Exception:
+                            pass
+                        raise
+                    segs, self._recording = self._recording, None
+                    segs[-1].capture_end()
                     self.graphs[k] = segs
         except BaseException:
             # a failed recording must not leave the fields frozen: the caller gets no object to release() them with
