@@ -248,3 +248,45 @@ def test_order_keys_kernel_matches_the_host_curves():
         o = vo.order2d[k]
         assert sorted(o.tolist()) == list(range(N)) and torch.equal(vo.pos2d[k].long()[o.long()], torch.arange(N, device=DEV))
         assert torch.equal(cells(o, 12, [ax, ay]), cells(plane_order(clean, aabb, ax, ay), 12, [ax, ay]))
+
+
+def test_backward_without_the_time_gradient_equals_the_one_with_it():
+    """k_hexplane_bwd_agg<C, DT>: the instantiation without dL/dtimes (the caller's timestamps do not require a gradient) leaves the same plane and
+    point gradients as the one with it, and the time gradient of the latter matches a central difference of the lookup; mixed timestamps, three
+    deferred scales (the reference's plane configuration at a size where resolutions 128 .. 512 go through the per-plane pass)."""
+    from emd_amd.hexplane import HexPlaneField
+    dev = torch.device("cuda", 0)
+    cfg = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32, "resolution": [64, 64, 64, 25]}
+    torch.manual_seed(5)
+    field = HexPlaneField(1.6, cfg, [1, 2, 4, 8]).to(dev)
+    with torch.no_grad():
+        for gp in field.grids:
+            for p in gp:
+                p.copy_(torch.rand_like(p) * 0.8 + 0.6)
+    N = 400_000
+    pts = (torch.rand(N, 3, device=dev) * 3.2 - 1.6).requires_grad_(True)
+    gout = torch.randn(N, 128, device=dev)
+    res = {}
+    for with_t in (False, True):
+        t = torch.full((N, 1), 0.37, device=dev)
+        t[::7] = 0.52                                                   # (blocks with mixed times take the two-row windows)
+        t.requires_grad_(with_t)
+        pts.grad = None
+        for p in field.parameters():
+            p.grad = None
+        field(pts, t).backward(gout)
+        res[with_t] = (pts.grad.clone(), [p.grad.clone() for gp in field.grids for p in gp], t.grad.clone() if with_t else None)
+    assert field._order_cache is not None and field._order_cache[2].defer_mask == 0b1110
+    scale = float(res[True][0].abs().max())
+    assert float((res[False][0] - res[True][0]).abs().max()) <= 1e-5 * scale
+    for a, b in zip(res[False][1], res[True][1]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12          # (sums of float atomics: equal up to their order)
+    # dL/dtimes against a central difference of sum(out * gout) in t (the lookup is piecewise bilinear in t: exact inside a cell)
+    with torch.no_grad():
+        t0 = torch.full((N, 1), 0.37, device=dev)
+        t0[::7] = 0.52
+        h = 1e-3
+        fd = ((field(pts.detach(), t0 + h) - field(pts.detach(), t0 - h)) * gout).sum(dim=1, keepdim=True) / (2 * h)
+    gt = res[True][2]
+    err = (gt - fd).abs()
+    assert float(err.max()) <= 2e-2 * float(fd.abs().max()), float(err.max())
