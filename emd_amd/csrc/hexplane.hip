@@ -232,6 +232,33 @@ __device__ __forceinline__ long xcd_chunk(unsigned b, unsigned chunks) {
     const unsigned per = (chunks + 7u) / 8u, chunk = (b % 8u) * per + b / 8u;
     return (b / 8u < per && chunk < chunks) ? (long)chunk : -1;
 }
+// 1-D tables of the three time planes for a call whose points share one time (EmdHexArgs.time_tables): row ix of (scale, axis) =
+// (1 - ft) plane[it0][ix] + ft plane[it1][ix].  Element offset of that table: C * (sum of res_x + res_y + res_z over the scales before + the axes before).
+__device__ __forceinline__ uint32_t time_table_offset(const EmdHexArgs& a, int s, int axis) {
+    uint32_t off = 0;
+    for (int s2 = 0; s2 < s; s2++) off += (uint32_t)(a.res[s2][0] + a.res[s2][1] + a.res[s2][2]);
+    for (int k = 0; k < axis; k++) off += (uint32_t)a.res[s][k];
+    return off * (uint32_t)a.channels;
+}
+__global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_time_tables(EmdHexArgs a) {
+    const int C = a.channels, S = a.num_scales;
+    long item = (long)blockIdx.x * EMD_BLOCK + threadIdx.x;            // (row of all tables, channel)
+    const int c = (int)(item % C);
+    long row = item / C;
+    for (int s = 0; s < S; s++)
+        for (int axis = 0; axis < 3; axis++) {
+            const int W = a.res[s][axis];
+            if (row < W) {
+                const Tap1 tt = tap1(a.times[0], a.res[s][3]);
+                const float* pl = a.planes[s][axis == 0 ? 2 : (axis == 1 ? 4 : 5)];     // the planes that pair x, y, z with the time
+                const float v0 = pl[tap_at((int)row, tt.i0, W, C, c)], v1 = pl[tap_at((int)row, tt.i1, W, C, c)];
+                a.time_tables[time_table_offset(a, s, axis) + (uint32_t)row * C + c] = v0 * (1.f - tt.f) + v1 * tt.f;
+                return;
+            }
+            row -= W;
+        }
+}
+
 template <int C>
 __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsigned chunks) {
     constexpr int LPP = C / 4, GROUPS = EMD_BLOCK / LPP;
@@ -245,6 +272,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
     if (chunk < 0) return;
     const long first = chunk * HEX_F4_POINTS;
     const int count = (int)min((long)HEX_F4_POINTS, (long)a.num_points - first);
+    const bool uni = a.time_tables != nullptr;          // one time for all points: the time planes are read from their 1-D tables, two taps
     if (tid < HEX_F4_POINTS) {
         const long n = tid < count ? (a.order ? (long)a.order[first + tid] : first + tid) : 0;
         s_n[tid] = (int)n;
@@ -265,7 +293,14 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
             pair_axes(p, ax, ay);
             const float4 q = s_q[j];
             const int W = a.res[s][ax];
-            const Tap1 tx = tap1(sel4f(q.x, q.y, q.z, q.w, ax), W), ty = tap1(sel4f(q.x, q.y, q.z, q.w, ay), a.res[s][ay]);
+            const Tap1 tx = tap1(sel4f(q.x, q.y, q.z, q.w, ax), W);
+            if (uni && ay == 3) {                       // two taps of the (scale, axis) table
+                const uint32_t tb = time_table_offset(a, s, ax);
+                s_off[item] = make_uint4((tb + (uint32_t)tx.i0 * C) << 2, (tb + (uint32_t)tx.i1 * C) << 2, 0u, 0u);
+                s_w[item] = make_float4(1.f - tx.f, tx.f, 0.f, 0.f);
+                continue;
+            }
+            const Tap1 ty = tap1(sel4f(q.x, q.y, q.z, q.w, ay), a.res[s][ay]);
             s_off[item] = make_uint4(tap_at(tx.i0, ty.i0, W, C, 0) << 2, tap_at(tx.i1, ty.i0, W, C, 0) << 2, tap_at(tx.i0, ty.i1, W, C, 0) << 2,
                                      tap_at(tx.i1, ty.i1, W, C, 0) << 2);
             // grid_sampler_2d: nw * (1-fx)(1-fy) + ne * fx (1-fy) + sw * (1-fx) fy + se * fx fy
@@ -280,6 +315,15 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
             for (int p = 0; p < 6; p++) {
                 const uint4 o = s_off[j * 6 + p];
                 const float4 w = s_w[j * 6 + p];
+                if (uni && (p == 2 || p >= 4)) {            // (uniform branch; p is a constant of the unrolled loop)
+                    const char* __restrict__ tb = (const char*)a.time_tables;
+                    const float4 t0 = *(const float4*)(tb + (o.x + cb)), t1 = *(const float4*)(tb + (o.y + cb));
+                    prod.x = prod.x * (t0.x * w.x + t1.x * w.y);
+                    prod.y = prod.y * (t0.y * w.x + t1.y * w.y);
+                    prod.z = prod.z * (t0.z * w.x + t1.z * w.y);
+                    prod.w = prod.w * (t0.w * w.x + t1.w * w.y);
+                    continue;
+                }
                 const char* __restrict__ pl = (const char*)a.planes[s][p];
                 const float4 nw = *(const float4*)(pl + (o.x + cb)), ne = *(const float4*)(pl + (o.y + cb)), sw = *(const float4*)(pl + (o.z + cb)),
                              se = *(const float4*)(pl + (o.w + cb));
@@ -787,6 +831,13 @@ extern "C" int emd_hexplane_forward(const EmdHexArgs* a, void* hip_stream) {
     if (!a->out) { emd_set_error("hexplane_forward: null output"); return EMD_ERR_INVALID; }
     if (a->num_points == 0) return EMD_OK;
     const unsigned chunks = (unsigned)((a->num_points + HEX_F4_POINTS - 1) / HEX_F4_POINTS), grid4 = (chunks + 7u) / 8u * 8u;
+    if (a->time_tables) {
+        if (a->channels != 32 && a->channels != 16) { emd_set_error("hexplane_forward: time_tables are served for 16 or 32 channels"); return EMD_ERR_INVALID; }
+        long rows = 0;
+        for (int s = 0; s < a->num_scales; s++) rows += (long)a->res[s][0] + a->res[s][1] + a->res[s][2];
+        if (rows * a->channels >= ((long)1 << 28)) { emd_set_error("hexplane_forward: time_tables too large"); return EMD_ERR_INVALID; }
+        hipLaunchKernelGGL(k_hexplane_time_tables, dim3((unsigned)((rows * a->channels + EMD_BLOCK - 1) / EMD_BLOCK)), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, *a);
+    }
     if (a->channels == 32) hipLaunchKernelGGL(k_hexplane_fwd4<32>, dim3(grid4), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, *a, chunks);
     else if (a->channels == 16) hipLaunchKernelGGL(k_hexplane_fwd4<16>, dim3(grid4), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, *a, chunks);
     else          // other channel counts: lane = channel

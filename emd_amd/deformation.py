@@ -261,6 +261,9 @@ class Deformation(nn.Module):
     def forward_time_offset(self, time_emb, cam_no):
         if self.args.no_time_offset:
             return time_emb
+        if time_emb.dim() == 2 and time_emb.shape[0] > 1 and time_emb.stride(0) == 0:
+            # one time broadcast over the points stays a broadcast (the HexPlane lookup recognises it: 1-D time tables); same values
+            return (time_emb[:1] + self.time_offset[cam_no]).expand(time_emb.shape[0], -1)
         return time_emb + self.time_offset[cam_no]
 
     # ---- one level (deformation.py:187-296)

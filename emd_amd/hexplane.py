@@ -41,6 +41,13 @@ class _HexLookup(torch.autograd.Function):
                 a.planes[s][p] = cl[s * 6 + p].data_ptr()
         a.pts, a.times = pts_c.data_ptr(), times_c.data_ptr()
         a.order = L.ptr(order)                    # visiting order (int32 permutation) or None
+        # One timestamp BROADCAST over the points (an expanded tensor: stride 0 along the points -- what emd_amd.model.render and
+        # Deformation.forward_time_offset hand over, one frame per step) is uniform by construction, no device read needed: the forward blends
+        # the time planes' two time rows into 1-D tables once and reads two taps instead of four there (EmdHexArgs.time_tables)
+        tables = None
+        if N > 1 and Cc in (16, 32) and times.dim() == 2 and times.shape[0] == N and times.stride(0) == 0:
+            tables = torch.empty(Cc * sum(int(r[0]) + int(r[1]) + int(r[2]) for r in res[:S]), device=pts.device, dtype=torch.float32)
+            a.time_tables = tables.data_ptr()
         for k in range(6):
             a.aabb[k] = aabb[k]
         out = torch.empty(N, S * Cc, device=pts.device, dtype=torch.float32)

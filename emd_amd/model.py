@@ -122,9 +122,9 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         t = getattr(cam, "time", 0.0) if time is None else time
         if isinstance(t, torch.Tensor) and t.device.type != "cpu":
             # a view's time that lives on the device (emd_amd.StepInputs.camera.time): nothing of it is baked into a recorded step
-            times_sel = t.reshape(1, 1).to(torch.float32).expand(means3D.shape[0], 1).contiguous()
+            times_sel = t.reshape(1, 1).to(torch.float32).expand(means3D.shape[0], 1)       # (a broadcast: one frame per step)
         else:
-            times_sel = torch.full((means3D.shape[0], 1), float(t), device=dev, dtype=torch.float32)
+            times_sel = torch.full((1, 1), float(t), device=dev, dtype=torch.float32).expand(means3D.shape[0], 1)
         from .deformation import deform_network as _dn
         # (an emd_amd network hands the SH residuals over unsummed: `shs + dshs_c + dshs_f` is formed inside the projection kernel)
         extra_kw = {"need_feat": bool(need_feat or render_feat), "fused_shs_residuals": True} if isinstance(deformation, _dn) else {}

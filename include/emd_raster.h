@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 22
+#define EMD_ABI_VERSION 23
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -487,6 +487,12 @@ typedef struct EmdHexArgs {
                                                     A spatially coherent one (e.g. Morton order of pts) lets the backward
                                                     aggregate the plane gradients in LDS before they reach HBM; results are
                                                     the same up to the order of the float sums. */
+    float* time_tables;                          /* (ABI 23) NULL, or scratch of C * sum over scales of (res_x + res_y + res_z) floats.  Non-NULL is
+                                                    the caller's PROMISE that every timestamp equals times[0] (one frame per step: always, in
+                                                    training): emd_hexplane_forward then blends the two time rows of the planes (x,t), (y,t),
+                                                    (z,t) into 1-D tables once per call and reads two taps instead of four on those planes --
+                                                    18 instead of 24 tap rows per point and scale.  Same values up to rounding ((1-fx) [(1-ft) nw
+                                                    + ft sw] + fx [...] instead of the four-term sum).  The backward does not use it. */
 } EmdHexArgs;
 
 typedef struct EmdHexGrads {
