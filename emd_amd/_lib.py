@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16
@@ -101,14 +101,14 @@ HEX_MAX_SCALES = 8
 
 
 class EmdHexArgs(C.Structure):
-    _fields_ = [("num_points", C.c_int32), ("channels", C.c_int32), ("num_scales", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("num_points", C.c_int32), ("channels", C.c_int32), ("num_scales", C.c_int32), ("times_broadcast", C.c_int32),
                 ("res", (C.c_int32 * 4) * HEX_MAX_SCALES), ("planes", (_f * 6) * HEX_MAX_SCALES), ("pts", _f), ("times", _f),
                 ("aabb", C.c_float * 6), ("out", _f), ("order", _f), ("time_tables", _f)]
 
 
 class EmdHexGrads(C.Structure):
     _fields_ = [("dL_dout", _f), ("dL_dplanes", (_f * 6) * HEX_MAX_SCALES), ("dL_dpts", _f), ("dL_dtimes", _f),
-                ("order2d", C.c_void_p * 3), ("pos2d", C.c_void_p * 3), ("defer_rows", _f), ("defer_mask", C.c_uint32), ("reserved", C.c_uint32)]
+                ("order2d", C.c_void_p * 3), ("pos2d", C.c_void_p * 3), ("defer_rows", _f), ("defer_mask", C.c_uint32), ("reserved", C.c_uint32), ("dL_dtime_sum", _f)]
 
 
 class EmdDeformInArgs(C.Structure):

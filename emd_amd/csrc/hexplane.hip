@@ -100,9 +100,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_bwd(EmdHexArgs a, EmdHex
     float q[4];
 #pragma unroll
     for (int k = 0; k < 3; k++) q[k] = (a.pts[3 * n + k] - a.aabb[k]) * (2.f / (a.aabb[3 + k] - a.aabb[k])) - 1.f;
-    q[3] = a.times[n];
+    q[3] = a.times[a.times_broadcast ? 0 : n];
     float dq[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool want_dq = g.dL_dpts || g.dL_dtimes;
+    const bool want_dq = g.dL_dpts || g.dL_dtimes || g.dL_dtime_sum;
     for (int s = 0; s < S; s++) {
         float f[6], dix[6], diy[6];
         Bilin t[6];
@@ -156,6 +156,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_bwd(EmdHexArgs a, EmdHex
             if (c == 0) {
                 if (k < 3) { if (g.dL_dpts) g.dL_dpts[3 * n + k] = v * (2.f / (a.aabb[3 + k] - a.aabb[k])); }
                 else if (g.dL_dtimes) g.dL_dtimes[n] = v;
+                else if (g.dL_dtime_sum) atomicAdd(g.dL_dtime_sum, v);
             }
         }
     }
@@ -190,7 +191,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd2(EmdHexArgs a) {
             int ax, ay;
             pair_axes(p, ax, ay);
             const float qx = (a.pts[3 * n + ax] - a.aabb[ax]) * (2.f / (a.aabb[3 + ax] - a.aabb[ax])) - 1.f;     // ax < 3 always
-            const float qy = ay < 3 ? (a.pts[3 * n + ay] - a.aabb[ay]) * (2.f / (a.aabb[3 + ay] - a.aabb[ay])) - 1.f : a.times[n];
+            const float qy = ay < 3 ? (a.pts[3 * n + ay] - a.aabb[ay]) * (2.f / (a.aabb[3 + ay] - a.aabb[ay])) - 1.f : a.times[a.times_broadcast ? 0 : n];
             const int W = a.res[s][ax];
             const Tap1 tx = tap1(qx, W), ty = tap1(qy, a.res[s][ay]);
             s_off[item] = make_uint4(tap_at(tx.i0, ty.i0, W, C, 0), tap_at(tx.i1, ty.i0, W, C, 0), tap_at(tx.i0, ty.i1, W, C, 0),
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
         q.x = (a.pts[3 * n] - a.aabb[0]) * (2.f / (a.aabb[3] - a.aabb[0])) - 1.f;
         q.y = (a.pts[3 * n + 1] - a.aabb[1]) * (2.f / (a.aabb[4] - a.aabb[1])) - 1.f;
         q.z = (a.pts[3 * n + 2] - a.aabb[2]) * (2.f / (a.aabb[5] - a.aabb[2])) - 1.f;
-        q.w = a.times[n];
+        q.w = a.times[a.times_broadcast ? 0 : n];
         s_q[tid] = q;
     }
     __syncthreads();
@@ -382,8 +383,11 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
 __device__ __forceinline__ int order_key(float v) { const int b = __float_as_int(v); return b >= 0 ? b : b ^ 0x7fffffff; }   // monotone int image
 __device__ __forceinline__ float key_value(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
 
-// DT: dL/dtimes is wanted (the training steps do not ask for it: the time planes' slope along t, a fourth lane sum and its adds drop out)
-template <int C, bool DT>
+// DT: 0 = no time gradient (the time planes' slope along t, a fourth lane sum and its adds drop out); 1 = dL/dtimes per point;
+// 2 = only its SUM over the points (EmdHexGrads.dL_dtime_sum: one broadcast timestamp, S3Gaussian's time_offset parameter) -- every lane keeps
+// its channel's partial sum over all its points and scales in a register, one add per iteration instead of a lane sum, and a workgroup adds
+// one float atomically at the end
+template <int C, int DT>
 __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexArgs a, EmdHexGrads g, unsigned chunk_stride) {
     constexpr int WAVES = HEX_AGG_THREADS / 64, GW = 64 / C, PER_WAVE = HEX_AGG_POINTS / WAVES, ITERS = PER_WAVE / GW, GROUPS = HEX_AGG_THREADS / C;
     constexpr int SROWS = 2 * GW * 6;                   // staging rows of TWO iterations (one stage() call)
@@ -413,7 +417,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         int n = -1;
         if (slot < a.num_points) {
             n = a.order ? a.order[slot] : (int)slot;
-            qv = k < 3 ? (a.pts[3 * (long)n + k] - a.aabb[k]) * (2.f / (a.aabb[3 + k] - a.aabb[k])) - 1.f : a.times[n];
+            qv = k < 3 ? (a.pts[3 * (long)n + k] - a.aabb[k]) * (2.f / (a.aabb[3 + k] - a.aabb[k])) - 1.f : a.times[a.times_broadcast ? 0 : n];
             const int key = order_key(qv);
             atomicMin(&qmin[k], key);
             atomicMax(&qmax[k], key);
@@ -437,7 +441,8 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
 #pragma unroll
     for (int k = 0; k < 4; k++) qlo[k] = key_value(qmin[k]);
     const bool tuni = qmin[3] == qmax[3];               // one time for the whole block: time planes as marginals
-    const bool want_dq = g.dL_dpts || g.dL_dtimes;
+    const bool want_dq = g.dL_dpts || g.dL_dtimes || g.dL_dtime_sum;
+    float t_acc = 0.f;                                  // (DT == 2)
     const int twy = tuni ? 1 : 2;
     const int sb = wave * 2 * SROWS;                    // the wave's staging rows
     for (int s = 0; s < S; s++) {
@@ -539,8 +544,9 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                 }
                 if (want_dq) {
                     // summed over the C channel lanes; a point belongs to one lane group of one wave: plain adds across the scales
+                    if (DT == 2) t_acc += dq[3];
 #pragma unroll
-                    for (int k = 0; k < (DT ? 4 : 3); k++) {               // DPP row sums; the last lane of the group holds the total
+                    for (int k = 0; k < (DT == 1 ? 4 : 3); k++) {          // DPP row sums; the last lane of the group holds the total
                         float v = dq[k];
                         v = dpp_add_f32<DPP_ROW_SHR(1), 0xf>(v);
                         v = dpp_add_f32<DPP_ROW_SHR(2), 0xf>(v);
@@ -551,7 +557,8 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     }
                     if (c == C - 1) {
                         float4 acc = s_dq[pt];
-                        acc.x += dq[0]; acc.y += dq[1]; acc.z += dq[2]; acc.w += dq[3];
+                        acc.x += dq[0]; acc.y += dq[1]; acc.z += dq[2];
+                        if (DT == 1) acc.w += dq[3];
                         s_dq[pt] = acc;
                     }
                 }
@@ -636,8 +643,17 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
             if (n < 0) continue;
             const float v = ((const float*)&s_dq[j])[k];
             if (k < 3) { if (g.dL_dpts) g.dL_dpts[3 * (long)n + k] = v * (2.f / (a.aabb[3 + k] - a.aabb[k])); }
-            else if (g.dL_dtimes) g.dL_dtimes[n] = v;
+            else if (DT == 1 && g.dL_dtimes) g.dL_dtimes[n] = v;
         }
+    if (DT == 2) {                                      // the workgroup's share of sum_n dL/dtimes[n]: wave sums, then one atomic
+        const float wsum = wave_reduce_to_lane63(t_acc);
+        __syncthreads();                                // (qmin / qmax are no longer read)
+        if (lane == 63) ((float*)qmax)[0] = 0.f;
+        __syncthreads();
+        if (lane == 63) lds_add_f32((float*)qmax, wsum);
+        __syncthreads();
+        if (tid == 0) atomicAdd(g.dL_dtime_sum, ((float*)qmax)[0]);
+    }
 }
 
 // ---- per-plane pass of the deferred scales -----------------------------------------------------------------------------------
@@ -744,8 +760,9 @@ void launch_bwd_agg(const EmdHexArgs* a, const EmdHexGrads* g, hipStream_t st) {
     unsigned stride = 7919u % blocks;
     auto gcd = [](unsigned x, unsigned y) { while (y) { unsigned t = x % y; x = y; y = t; } return x; };
     while (stride == 0 || gcd(stride, blocks) != 1) stride++;          // a bijection on [0, blocks)
-    if (g->dL_dtimes) hipLaunchKernelGGL((k_hexplane_bwd_agg<C, true>), dim3(blocks), dim3(HEX_AGG_THREADS), 0, st, *a, *g, stride);
-    else hipLaunchKernelGGL((k_hexplane_bwd_agg<C, false>), dim3(blocks), dim3(HEX_AGG_THREADS), 0, st, *a, *g, stride);
+    if (g->dL_dtimes) hipLaunchKernelGGL((k_hexplane_bwd_agg<C, 1>), dim3(blocks), dim3(HEX_AGG_THREADS), 0, st, *a, *g, stride);
+    else if (g->dL_dtime_sum) hipLaunchKernelGGL((k_hexplane_bwd_agg<C, 2>), dim3(blocks), dim3(HEX_AGG_THREADS), 0, st, *a, *g, stride);
+    else hipLaunchKernelGGL((k_hexplane_bwd_agg<C, 0>), dim3(blocks), dim3(HEX_AGG_THREADS), 0, st, *a, *g, stride);
     if (g->defer_mask)
         hipLaunchKernelGGL(k_hexplane_bwd_plane<C>, dim3((unsigned)((a->num_points + HEX_PL_POINTS - 1) / HEX_PL_POINTS), 3, (unsigned)__builtin_popcount(g->defer_mask)),
                            dim3(HEX_PL_THREADS), 0, st, *a, *g);

@@ -29,11 +29,15 @@ class _HexLookup(torch.autograd.Function):
         S = len(planes) // 6
         Cc = planes[0].shape[1]
         N = pts.shape[0]
+        # `times`: [N, 1], or ONE timestamp [1, 1] shared by all points (HexPlaneField.get_density passes the base of a broadcast): the
+        # kernels then read times[0] (EmdHexArgs.times_broadcast), the forward takes its 1-D time tables, and the backward returns the
+        # gradient of that one timestamp as a sum formed inside the kernel (EmdHexGrads.dL_dtime_sum) -- no [N] column either way
+        bcast = times.numel() == 1 and N > 1
         pts_c, times_c = pts.detach().contiguous().float(), times.detach().reshape(-1).contiguous().float()
         # channel-last copies: a tap becomes one contiguous C x 4-byte row
         cl = [p.detach()[0].permute(1, 2, 0).contiguous().float() for p in planes]
         a = L.EmdHexArgs()
-        a.num_points, a.channels, a.num_scales = N, Cc, S
+        a.num_points, a.channels, a.num_scales, a.times_broadcast = N, Cc, S, int(bcast)
         for s in range(S):
             for k in range(4):
                 a.res[s][k] = res[s][k]
@@ -41,11 +45,10 @@ class _HexLookup(torch.autograd.Function):
                 a.planes[s][p] = cl[s * 6 + p].data_ptr()
         a.pts, a.times = pts_c.data_ptr(), times_c.data_ptr()
         a.order = L.ptr(order)                    # visiting order (int32 permutation) or None
-        # One timestamp BROADCAST over the points (an expanded tensor: stride 0 along the points -- what emd_amd.model.render and
-        # Deformation.forward_time_offset hand over, one frame per step) is uniform by construction, no device read needed: the forward blends
-        # the time planes' two time rows into 1-D tables once and reads two taps instead of four there (EmdHexArgs.time_tables)
+        # One timestamp for all points is uniform by construction, no device read needed: the forward blends the time planes' two time
+        # rows into 1-D tables once and reads two taps instead of four there (EmdHexArgs.time_tables)
         tables = None
-        if N > 1 and Cc in (16, 32) and times.dim() == 2 and times.shape[0] == N and times.stride(0) == 0:
+        if bcast and Cc in (16, 32):
             tables = torch.empty(Cc * sum(int(r[0]) + int(r[1]) + int(r[2]) for r in res[:S]), device=pts.device, dtype=torch.float32)
             a.time_tables = tables.data_ptr()
         for k in range(6):
@@ -78,8 +81,14 @@ class _HexLookup(torch.autograd.Function):
                 off += n
         d_pts = torch.empty(a.num_points, 3, device=g_out.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         g.dL_dpts = L.ptr(d_pts)
-        d_times = torch.empty(ctx.times_shape, device=g_out.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
-        g.dL_dtimes = L.ptr(d_times)
+        d_times = None
+        if ctx.needs_input_grad[1]:
+            if a.times_broadcast:
+                d_times = torch.zeros(ctx.times_shape, device=g_out.device, dtype=torch.float32)      # one float: the kernel adds the sum
+                g.dL_dtime_sum = d_times.data_ptr()
+            else:
+                d_times = torch.empty(ctx.times_shape, device=g_out.device, dtype=torch.float32)
+                g.dL_dtimes = d_times.data_ptr()
         po = ctx.keep[4]
         rows = None
         if po is not None and po.defer_mask and need_planes and a.num_points * Cc * 4 < 2 ** 32:
@@ -234,7 +243,10 @@ class HexPlaneField(nn.Module):
     def get_density(self, pts, timestamps=None):
         pts = pts.reshape(-1, pts.shape[-1])
         planes = [p for gp in self.grids for p in gp]
-        return _HexLookup.apply(pts, timestamps.reshape(-1, 1), self._aabb_host(), self._res, self._visiting_order(pts), *planes)
+        t = timestamps.reshape(-1, 1)
+        if t.shape[0] == pts.shape[0] and t.shape[0] > 1 and t.stride(0) == 0:
+            t = t[:1]         # one timestamp broadcast over the points (emd_amd.model.render, Deformation.forward_time_offset): its base, [1, 1]
+        return _HexLookup.apply(pts, t, self._aabb_host(), self._res, self._visiting_order(pts), *planes)
 
     def _visiting_order(self, pts):
         """Morton order of the points, cached across steps: with it 256 consecutive points share plane cells, and the backward

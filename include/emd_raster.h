@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 23
+#define EMD_ABI_VERSION 24
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -476,11 +476,12 @@ int emd_image_loss(const EmdLossArgs* args, void* workspace, size_t workspace_by
  * grid_sample, concatenated over scales.  Planes are passed CHANNEL-LAST: [res_h][res_w][C]. */
 #define EMD_HEX_MAX_SCALES 8
 typedef struct EmdHexArgs {
-    int32_t num_points, channels, num_scales, reserved;
+    int32_t num_points, channels, num_scales;
+    int32_t times_broadcast;                     /* (ABI 24) non-zero: `times` holds ONE timestamp, shared by all points */
     int32_t res[EMD_HEX_MAX_SCALES][4];          /* per scale: resolution along x, y, z, t */
     const float* planes[EMD_HEX_MAX_SCALES][6];  /* per scale: planes of the pairs (0,1),(0,2),(0,3),(1,2),(1,3),(2,3), [res[b]][res[a]][C] */
     const float* pts;                            /* [N,3] */
-    const float* times;                          /* [N] */
+    const float* times;                          /* [N], or one float with times_broadcast */
     float aabb[6];                               /* aabb[0] (3 floats) then aabb[1] (3 floats), as HexPlaneField stores them */
     float* out;                                  /* [N, num_scales * C] (forward) */
     const int32_t* order;                        /* [N] a permutation of the points, or NULL: the order the kernels visit them in.
@@ -512,6 +513,9 @@ typedef struct EmdHexGrads {
     float* defer_rows;                           /* scratch of popcount(defer_mask) * 3 * N * C + 6 * N floats (the rows, then the planes' coordinates); written and read by the call */
     uint32_t defer_mask;                         /* bit s set: the spatial planes of scale s go through the per-plane pass */
     uint32_t reserved;
+    float* dL_dtime_sum;                         /* (ABI 24) NULL, or one float ZEROED BY THE CALLER that receives sum_n dL/dtimes[n] (float atomics, one per
+                                                    workgroup): the gradient of a broadcast timestamp -- S3Gaussian's time_offset parameter,
+                                                    deformation.py:325-328 -- without the [N] gradient and its reduction; used when dL_dtimes is NULL */
 } EmdHexGrads;
 
 int emd_hexplane_forward(const EmdHexArgs* args, void* hip_stream);
