@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
     // pixel loop has 16 iterations instead of 32 (the scans run inside the 32-lane halves: five DPP steps; the per-pixel constants become
     // two-address LDS loads; the two halves' moment sums of an entry are added at the end).  A quadrant's walk is ~2.4 batches long and its
     // deepest one is half empty on average: the 64-lane form spent a third of its lane-iterations on lanes without an entry.
-    auto process_batch = [&](auto half_c, uint32_t nb, const float4& g0, const float4& g1, const float4& g2, const float4& g3, const float4* gxc, uint32_t pos,
+    auto process_batch = [&](auto half_c, uint32_t nb, const float4 g0, const float4 g1, const float4 g2, const float4 g3, const float4* gxc, uint32_t pos,
                              uint32_t gid) {
         constexpr bool HALF = decltype(half_c)::value;
         const uint32_t el = HALF ? (lane & 31u) : lane, hp = HALF ? (lane >> 5) : 0u;      // entry slot of the lane, its half of the pixels
