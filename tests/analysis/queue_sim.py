@@ -17,7 +17,8 @@ def main(frame=10, n=2_000_000):
     from tests.test_parity_gpu import _bench_scene_case
     from tests.helpers import oracle_settings, oracle_scene
     here = os.path.dirname(os.path.abspath(__file__))
-    so = os.path.join(here, "libqueue_sim.so")
+    os.makedirs(os.path.join(here, "_build"), exist_ok=True)
+    so = os.path.join(here, "_build", "libqueue_sim.so")
     subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", so, os.path.join(here, "queue_sim.c"), "-lm"])
     lib = C.CDLL(so)
     case, sc = _bench_scene_case(n, frame=frame, actors=True)
