@@ -170,7 +170,52 @@ CONFIGS = {
             focal=1700.0, actors=0, forward_only=False),
     2: dict(name="BASELINE configs[2]: 50-frame dynamic clip, per-actor rigid motion on 2M Gaussians", gaussians=2_000_000, height=1066,
             width=1600, focal=1700.0, actors=32, forward_only=False),
+    3: dict(name="BASELINE configs[3]: 4-camera rig, 2M Gaussians + deformation residual (dx for all, dq for actor points) as inputs of the fused "
+                 "transform, view-parallel", gaussians=2_000_000, height=1066, width=1600, focal=1700.0, actors=32, forward_only=False, rig=4,
+            residual=True),
+    4: dict(name="BASELINE configs[4]: 6-camera rig, 3M Gaussians, 48 actors, densification statistics every step + one density-control event",
+            gaussians=3_000_000, height=1066, width=1600, focal=1700.0, actors=48, forward_only=False, rig=6, densify=True),
 }
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun around it: start the N ranks ourselves, as a FRESH child process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), relay rank 0's JSON line and exit with
+    the children's code.  Decided before anything has touched the GPU (no torch.cuda call has run in this process and none will: a process that
+    has initialised HIP must never replace or fork itself into GPU work).  Returns None when this process is itself a rank (or N = 1)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    import socket
+    import subprocess
+    share = bool(os.environ.get("EMD_BENCH_SHARE_GPU"))
+    have = torch.cuda.device_count()          # (counts devices without initialising the runtime)
+    if have < args.gpus and not share:
+        print(f"[bench] --gpus {args.gpus} but this node shows {have} GPU(s) (EMD_BENCH_SHARE_GPU=1 EMD_DP_BACKEND=gloo puts all ranks on GPU 0 "
+              "for a functional run)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd[1:])}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for line in child.stdout:
+        if line.startswith("{"):
+            lines += 1
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        print(f"[bench] the ranks printed {lines} JSON lines (expected one, from rank 0)", file=sys.stderr)
+        rc = 3
+    return rc
 
 
 from emd_amd.graphs import select_step_inputs          # noqa: E402  (emd_select_step_inputs: the per-step inputs of a replayed step, one launch)
@@ -181,8 +226,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=2, choices=(0, 1, 2),
-                    help="BASELINE.json configs[k]: 0 = 10k static 256x256 (K1 forward next to the CPU leg), 1 = 1M static fwd+bwd, 2 = the headline (default)")
+    ap.add_argument("--config", type=int, default=2, choices=(0, 1, 2, 3, 4),
+                    help="BASELINE.json configs[k]: 0 = 10k static 256x256 (K1 forward next to the CPU leg), 1 = 1M static fwd+bwd, 2 = the headline (default), "
+                         "3 = 4-camera rig, 2M + deformation residual (per-rank workload at --gpus 1), 4 = 6-camera rig, 3M, 48 actors, densification "
+                         "statistics in every step and one density-control event after the timed steps (reported separately)")
     ap.add_argument("--gaussians", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
@@ -201,8 +248,18 @@ def main():
     ap.add_argument("--exchange-only", action="store_true",
                     help="time ONLY the gradient exchange of a view-parallel step (GradientExchange.start + finish on a fixed backward's outputs): "
                          "separates communication from compute in the 2/4/8-GPU runs")
+    ap.add_argument("--densify-grad-threshold", type=float, default=None,
+                    help="config 4's density-control event: view-space gradient threshold (default: the value that selects ~5 %% of the seen Gaussians of the synthetic scene)")
     args = ap.parse_args()
+    rc = self_launch(args, sys.argv[1:])            # N > 1 without torchrun: the ranks run as a fresh child process; nothing here has touched the GPU
+    if rc is not None:
+        sys.exit(rc)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:                      # (checked before the first GPU call)
+        sys.exit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with --nproc-per-node {args.gpus}, or without torchrun")
     cfg = CONFIGS[args.config]
+    if cfg.get("densify"):
+        args.densify_stats = True
     if args.gaussians is None:
         args.gaussians = cfg["gaussians"]
     if args.height is None:
@@ -221,17 +278,28 @@ def main():
     torch.cuda.set_device(local)              # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local)
     rank, world, local = dp.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    ranks_seen = dp.world_size()              # what the process group reports (RCCL / gloo saw this many ranks)
 
     N, H, W = args.gaussians, args.height, args.width
     num_frames, num_actors = 50, cfg["actors"]
     focal = cfg["focal"] * (W / cfg["width"])
-    num_cams = dp.rig_size(world)             # 1 / 2 / 4 cameras on 1 / 2 / 4 GPUs (rank <-> camera of one timestamp), 6 on 8 GPUs
+    # cameras of the rig: configs 3 / 4 name theirs (4 / 6: at --gpus 1 the one rank walks the rig's cameras, the per-rank workload of that
+    # configuration); configs 0-2: 1 / 2 / 4 cameras on 1 / 2 / 4 GPUs (rank <-> camera of one timestamp), 6 on 8 GPUs
+    num_cams = cfg.get("rig") or dp.rig_size(world)
     scene = scenes.make_static_scene(N, seed=0)
     if num_actors:
         scene = scenes.add_actors(scene, num_actors=num_actors, pts_per_actor=5000, num_frames=num_frames, seed=1)
     model = StreetGaussians(scene, dev, track_heads=bool(num_actors) and not args.no_track_heads)
     params = [p for p in model.parameters()]
+    residual = None
+    if cfg.get("residual"):
+        # the learned per-Gaussian deformation residual as the fused transform consumes it (deformable.py:49-68): activations of a network, not
+        # parameters -- a leaf each that collects its gradient (what the network's backward would start from), not part of the exchange
+        tg = torch.Generator().manual_seed(11)
+        rdx = (0.02 * torch.randn(N, 3, generator=tg)).to(dev).requires_grad_(True)
+        rdq = (0.02 * torch.randn(N, 4, generator=tg)).to(dev).requires_grad_(True) if num_actors else None
+        residual = (rdx, rdq)
+    res_leaves = [t for t in (residual or ()) if t is not None]
     bg = torch.zeros(3)
     g3 = torch.Generator().manual_seed(3)
     target = torch.rand(3, H, W, generator=g3).to(dev)
@@ -244,6 +312,7 @@ def main():
     stats = None
     if args.densify_stats:
         stats = [torch.zeros(N, 1, device=dev), torch.zeros(N, 1, device=dev), torch.zeros(N, device=dev)]
+    S = {"params": params, "stats": stats, "N": N}          # what a density-control event replaces (config 4)
 
     def cam_for(step):
         # views are ordered timestamp-major and dealt out by dp.view_for: every rank renders a DISTINCT (frame, camera);
@@ -259,17 +328,19 @@ def main():
 
     def one_step(step, options=opts, record=None, backward=True):
         f, c, cam = cam_for(step)
-        for p in params:
+        params, stats = S["params"], S["stats"]
+        for p in params + res_leaves:
             p.grad = None
         rec = record if record is not None else RasterCall()
         xchg = None
         if options.factored_sh_grad and backward:
             # SH gradient (81 % of the gradient bytes): rank-one factors, 12 B per Gaussian and rank instead of all-reducing
             # 192 B per Gaussian; the collectives are issued from inside backward(), right behind K8 (emd_amd/dp.py)
-            xchg = dp.GradientExchange(campos_dev[(f, c)], actor_ids=model.actor_id if model.has_actors else None)
+            xchg = dp.GradientExchange(campos_dev[(f, c)], actor_ids=model.actor_id if model.has_actors else None,
+                                       residual_dx=None if residual is None else residual[0].detach())
             rec.on_backward = xchg.start
             rec.on_sh_factor = xchg.start_factors        # (the factor gathers run under K8; needs the actor poses of this step: set below)
-        out = render(model, cam, bg, frame=f, iteration=step, options=options, record=rec)
+        out = render(model, cam, bg, frame=f, iteration=step, options=options, record=rec, residual=residual)
         if not backward:
             return out
         if xchg is not None:
@@ -297,7 +368,7 @@ def main():
     with torch.no_grad():
         for s_ in sorted(set(list(range(0, args.warmup + args.steps, 7)) + [args.warmup + args.steps - 1])):
             f, c, cam = cam_for(s_)
-            o = render(model, cam, bg, frame=f, options=sync_opts)
+            o = render(model, cam, bg, frame=f, options=sync_opts, residual=residual)
             dmax = max(dmax, o["raster_call"].last_status()["num_rendered"])
     opts.capacity_hint = int(dmax * 1.3) + 1024          # (an option of this run's calls: nothing process-wide is written)
 
@@ -312,53 +383,58 @@ def main():
     # ~20 us per step instead of ~1-2 ms of Python + launch calls, i.e. the run is GPU-bound whatever the host is doing.
     # (--eager, or a failed capture, issues the same step from Python.)
     period = args.warmup + args.steps             # the repeats replay the timed views: row = warmup + (step - warmup) mod steps
-    graph = graph_b = None
-    two_graphs = False
-    settle_replays = 0
+    settle = {"replays": 0}
     out = o = None          # no autograd graph of an eager step may be alive at capture time (its AccumulateGrad nodes are bound to the eager stream)
     import gc
+    import types
     gc.collect()            # ... including graphs held only by reference cycles (RasterCall <-> GradientExchange)
     status_log = torch.zeros(max(period, 1), 4, dtype=torch.int32, device=dev)
-    gstate = {}
-    if not args.eager and opts.no_sync:
-        try:
-            import types
-            views = [cam_for(s_) for s_ in range(period)]
-            blocks = torch.stack([torch.cat([bg.reshape(-1).float(), c_.world_view_transform.reshape(-1), c_.full_proj_transform.reshape(-1),
-                                             c_.camera_center.reshape(-1)]) for _, _, c_ in views]).to(dev).contiguous()            # [rows, 38]
-            frame_of = torch.tensor([f_ for f_, _, _ in views], dtype=torch.int32, device=dev)
-            sel = torch.zeros(1, dtype=torch.int64, device=dev)
-            prev_sel = torch.full((1,), -1, dtype=torch.int64, device=dev)
-            # successor of every row: the launch advances `sel` itself (the repeats replay the timed views: last timed row -> first)
-            next_row = torch.tensor([r_ + 1 if r_ + 1 < period else args.warmup for r_ in range(period)], dtype=torch.int64, device=dev)
-            blk = torch.zeros(38, device=dev)
-            frame_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-            t_dev = torch.zeros(1, device=dev)
-            kf_dev = torch.ones(1, dtype=torch.int32, device=dev)
-            status_static = torch.zeros(4, dtype=torch.int32, device=dev)          # the captured call's status words (graph-static address)
-            cam0 = views[0][2]
-            th = model.track_heads
-            k_sched = (th.min_embeddings, th.max_embeddings, th.c2f_temporal_iter) if th is not None else None
+    views = [cam_for(s_) for s_ in range(period)]
+    blocks = torch.stack([torch.cat([bg.reshape(-1).float(), c_.world_view_transform.reshape(-1), c_.full_proj_transform.reshape(-1),
+                                     c_.camera_center.reshape(-1)]) for _, _, c_ in views]).to(dev).contiguous()            # [rows, 38]
+    frame_of = torch.tensor([f_ for f_, _, _ in views], dtype=torch.int32, device=dev)
+    # successor of every row: the launch advances `sel` itself (the repeats replay the timed views: last timed row -> first)
+    next_row = torch.tensor([r_ + 1 if r_ + 1 < period else args.warmup for r_ in range(period)], dtype=torch.int64, device=dev)
+    cam0 = views[0][2]
+    th = model.track_heads
+    k_sched = (th.min_embeddings, th.max_embeddings, th.c2f_temporal_iter) if th is not None else None
 
-            def graph_body(cut=None):
-                for p in params:
-                    p.grad = None
-                # (the row index doubles as the training step of the coarse-to-fine schedule, as the eager step passes it)
-                select_step_inputs(sel, blocks, blk, frame_of, frame_dev, t_dev, num_frames, k_sched, kf_dev if th is not None else None,
-                                   status_static, status_log, prev_sel, next_row)
-                cam_g = types.SimpleNamespace(image_height=H, image_width=W, tanfovx=cam0.tanfovx, tanfovy=cam0.tanfovy,
-                                              world_view_transform=blk[3:19].view(4, 4), full_proj_transform=blk[19:35].view(4, 4),
-                                              camera_center=blk[35:38])
-                rec_g = RasterCall()
-                rec_g.status_buffer = status_static          # the call's status words at a fixed address: the next step's select launch logs them
-                rec_g.on_sh_factor = cut                     # (two-graph capture: called between the halves of the rasterizer's backward)
-                o = render(model, cam_g, blk[0:3], frame=frame_dev, iteration=DeviceStep(k_fine=kf_dev, t=t_dev), options=opts, record=rec_g)
-                l1_loss(o["render"], target).backward(unit)
-                if stats is not None:
-                    dp.add_densification_stats(o["viewspace_points"].grad, o["radii"], *stats)
-                # what the gradient exchange of a multi-GPU step reads after the replay: graph-static tensors
-                gstate["rec"], gstate["campos"] = rec_g, blk[35:38]
-                gstate["pose"] = None if o["actor_pose"] is None else o["actor_pose"].detach()
+    def record_step():
+        """Capture the step for the CURRENT parameter tensors (S) as one hipGraph (or two, cut inside backward()); returns the state a replay
+        needs, or None when the capture failed (the step is then issued from Python).  Called again after a density-control event: the point
+        count, every parameter tensor and the workspaces behind them have changed."""
+        G = types.SimpleNamespace(graph=None, graph_b=None, gstate={}, two_graphs=False)
+        params = S["params"]
+        G.sel = sel = torch.zeros(1, dtype=torch.int64, device=dev)
+        G.prev_sel = prev_sel = torch.full((1,), -1, dtype=torch.int64, device=dev)
+        blk = torch.zeros(38, device=dev)
+        frame_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        t_dev = torch.zeros(1, device=dev)
+        kf_dev = torch.ones(1, dtype=torch.int32, device=dev)
+        G.status_static = status_static = torch.zeros(4, dtype=torch.int32, device=dev)          # the captured call's status words (graph-static address)
+        gstate = G.gstate
+
+        def graph_body(cut=None):
+            for p in params + res_leaves:
+                p.grad = None
+            # (the row index doubles as the training step of the coarse-to-fine schedule, as the eager step passes it)
+            select_step_inputs(sel, blocks, blk, frame_of, frame_dev, t_dev, num_frames, k_sched, kf_dev if th is not None else None,
+                               status_static, status_log, prev_sel, next_row)
+            cam_g = types.SimpleNamespace(image_height=H, image_width=W, tanfovx=cam0.tanfovx, tanfovy=cam0.tanfovy,
+                                          world_view_transform=blk[3:19].view(4, 4), full_proj_transform=blk[19:35].view(4, 4),
+                                          camera_center=blk[35:38])
+            rec_g = RasterCall()
+            rec_g.status_buffer = status_static          # the call's status words at a fixed address: the next step's select launch logs them
+            rec_g.on_sh_factor = cut                     # (two-graph capture: called between the halves of the rasterizer's backward)
+            o = render(model, cam_g, blk[0:3], frame=frame_dev, iteration=DeviceStep(k_fine=kf_dev, t=t_dev), options=opts, record=rec_g,
+                       residual=residual)
+            l1_loss(o["render"], target).backward(unit)
+            if S["stats"] is not None:
+                dp.add_densification_stats(o["viewspace_points"].grad, o["radii"], *S["stats"])
+            # what the gradient exchange of a multi-GPU step reads after the replay: graph-static tensors
+            gstate["rec"], gstate["campos"] = rec_g, blk[35:38]
+            gstate["pose"] = None if o["actor_pose"] is None else o["actor_pose"].detach()
+        try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -369,6 +445,7 @@ def main():
             torch.cuda.synchronize()
             prev_sel.fill_(-1)
             graph = torch.cuda.CUDAGraph()
+            graph_b = None
             if opts.factored_sh_grad and not args.one_graph:
                 # ---- TWO graphs, cut between the halves of the rasterizer's backward: [forward, loss, render backward K7, SH factor] |
                 # [projection backward K8, actor chain backward].  RCCL collectives cannot be captured, so a one-graph step can only start its
@@ -405,6 +482,7 @@ def main():
                 with torch.cuda.graph(graph, stream=side, capture_error_mode="global" if world == 1 else "thread_local"):
                     graph_body()
             torch.cuda.synchronize()
+            G.graph, G.graph_b, G.two_graphs = graph, graph_b, graph_b is not None
 
             def replay_compute():
                 graph.replay()
@@ -413,6 +491,7 @@ def main():
             # ---- self-check of the captured graph before it is trusted with the timed region: two replays of row 0 must reproduce the
             # eager step's device status words (D, V) and leave finite, identical parameter gradients (a memset node captured on ROCm 7.2
             # replayed with a corrupt fill pattern from the SECOND replay on: that is how the library's zero fills became kernels)
+            keep_stats = None if S["stats"] is None else [t.clone() for t in S["stats"]]
             eager = one_step(0)
             torch.cuda.synchronize()
             want_status = eager["raster_call"].status.clone()
@@ -438,39 +517,51 @@ def main():
             while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
                 for _ in range(8):
                     replay_compute()
-                    settle_replays += 1
+                    settle["replays"] += 1
                 torch.cuda.synchronize()
+            if keep_stats is not None:                        # the checks and the settle phase are not training steps: their statistics do not count
+                for t_, k_ in zip(S["stats"], keep_stats):
+                    t_.copy_(k_)
             sel.fill_(0)                                      # the first replay renders row 0; every replay leaves the next row in `sel`
             prev_sel.fill_(-1)
             torch.cuda.synchronize()
+            return G
         except Exception as e:          # capture is an optimisation of the host side only: fall back to issuing the step from Python
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = graph_b = None
+            return None
+
+    G = record_step() if (not args.eager and opts.no_sync) else None
 
     def row_of(step):
         return step if step < period else args.warmup + (step - args.warmup) % args.steps
 
-    if graph is None and args.settle_ms > 0:                  # the eager step settles the same way
+    if G is None and args.settle_ms > 0:                  # the eager step settles the same way
+        keep_stats = None if S["stats"] is None else [t.clone() for t in S["stats"]]
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
             one_step(0)
-            settle_replays += 1
+            settle["replays"] += 1
             torch.cuda.synchronize()
+        if keep_stats is not None:
+            for t_, k_ in zip(S["stats"], keep_stats):
+                t_.copy_(k_)
 
     def timed_step(step):
-        if graph is not None:
-            graph.replay()                                    # (`sel` was advanced to row_of(step) by the replay before)
+        if G is not None:
+            G.graph.replay()                                    # (`sel` was advanced to row_of(step) by the replay before)
             if opts.factored_sh_grad:
                 # RCCL collectives are not captured.  Two graphs: the factor gathers are issued between the replays and run under K8, the
                 # slab all-reduce behind the second; one graph (--one-graph): the whole exchange behind the replay
-                xchg = dp.GradientExchange(gstate["campos"], actor_ids=model.actor_id if model.has_actors else None, actor_pose=gstate["pose"])
-                if graph_b is not None:
-                    xchg.start_factors(gstate["rec"])
-                    graph_b.replay()
-                xchg.start(gstate["rec"])
-                xchg.finish(model._features, model._xyz, model.active_sh_degree, other_params=params)
+                gs = G.gstate
+                xchg = dp.GradientExchange(gs["campos"], actor_ids=model.actor_id if model.has_actors else None, actor_pose=gs["pose"],
+                                           residual_dx=None if residual is None else residual[0].detach())
+                if G.graph_b is not None:
+                    xchg.start_factors(gs["rec"])
+                    G.graph_b.replay()
+                xchg.start(gs["rec"])
+                xchg.finish(model._features, model._xyz, model.active_sh_degree, other_params=S["params"])
             elif world > 1:
-                dp.allreduce_gradients(params)
+                dp.allreduce_gradients(S["params"])
         else:
             o = one_step(row_of(step))
             status_log[row_of(step)].copy_(o["raster_call"].status)
@@ -485,32 +576,38 @@ def main():
             timed_step(first + s)
         t_enq = time.perf_counter() - t0      # host time to enqueue the steps (the GPU runs behind it)
         torch.cuda.synchronize()
+        t_own = time.perf_counter() - t0      # this rank's own time (before the closing barrier): min / max over ranks are reported
         if world > 1:
             torch.distributed.barrier()
-        return time.perf_counter() - t0, t_enq
+        return time.perf_counter() - t0, t_enq, t_own
+
+    def flush_status_log():
+        if G is not None:       # the status row of the last replay
+            G.sel.fill_(-1)
+            select_step_inputs(G.sel, blocks, torch.zeros(38, device=dev), status=G.status_static, status_log=status_log, prev_sel=G.prev_sel)
+            torch.cuda.synchronize()
 
     for s in range(args.warmup):
         timed_step(s)
-    if graph is None:
+    if G is None:
         torch.cuda.synchronize()
         _lib.profile_enable(True)
         _lib.profile_read()
-    dt, t_enqueue = timed_block(args.warmup, args.steps)
+    dt, t_enqueue, dt_own = timed_block(args.warmup, args.steps)
     prof_timed = None
-    if graph is None:
+    if G is None:
         prof_timed = _lib.profile_read()
         _lib.profile_enable(False)
     # ---- the same block again, `repeats` times back to back: spread of the measurement (`value` stays the first block)
     rep = []
     for r in range(max(args.repeats, 0)):
-        d_r, _ = timed_block(args.warmup + args.steps * (1 + r), args.steps)
+        d_r, _, _ = timed_block(args.warmup + args.steps * (1 + r), args.steps)
         rep.append(d_r / args.steps * 1e3)
-    if graph is not None:       # flush the status row of the last replay
-        sel.fill_(-1)
-        select_step_inputs(sel, blocks, blk, status=status_static, status_log=status_log, prev_sel=prev_sel)
-        torch.cuda.synchronize()
+    flush_status_log()
+    st_all = status_log[args.warmup:args.warmup + args.steps].cpu().numpy().astype("int64") & 0xFFFFFFFF          # (D, flags, V, .) of every timed step
     stage_region = "the timed region"
-    if graph is not None:
+    keep_stats = None if S["stats"] is None else [t.clone() for t in S["stats"]]       # (the diagnostic steps below are not training steps)
+    if G is not None:
         # Per-stage HIP events are recorded by host code, which does not run when a graph is replayed: the stage durations of the
         # roofline block come from the SAME steps issued eagerly right after the timed region (same kernels, same inputs).
         n_prof = min(args.steps, 20)
@@ -528,29 +625,90 @@ def main():
     # ---- pair statistics of the render backward (diagnostic instantiation of K7, a few of the timed views): evaluated vs contributing
     pairs = None
     if world == 1:
-        ps = torch.zeros(2, dtype=torch.int64, device=dev)
+        ps = torch.zeros(4, dtype=torch.int64, device=dev)
         n_ps = min(args.steps, 5)
         for s in range(n_ps):
             rec_p = RasterCall()
             rec_p.pair_stats = ps
             one_step(args.warmup + s * max(args.steps // n_ps, 1), record=rec_p)
-        ev, hit = [int(x) for x in ps.cpu().tolist()]
+        ev, hit, rows_k7, atoms_k7 = [int(x) for x in ps.cpu().tolist()]
         pairs = {"evaluated_per_launch": ev / n_ps, "contributing_per_launch": hit / n_ps, "useful_fraction": round(hit / max(ev, 1), 4),
                  "launches": n_ps, "note": "(pixel, list entry) pairs the lanes of k_render_backward_q evaluate / pairs with alpha >= 1/255 in front "
                                            "of the pixel's last contributor; counting instantiation of the kernel (EmdBwdArgs.pair_stats), outside the timed region"}
-    if graph is not None:          # release the captured graph and its memory pool explicitly, in a quiet state
+    if keep_stats is not None:
+        for t_, k_ in zip(S["stats"], keep_stats):
+            t_.copy_(k_)
+    step_issue_graph, two_graphs = G is not None, (G is not None and G.two_graphs)
+
+    def release_graphs(G_):
+        if G_ is not None:          # release the captured graph and its memory pool explicitly, in a quiet state
+            torch.cuda.synchronize()
+            if G_.graph_b is not None:
+                G_.graph_b.reset()
+            G_.graph.reset()
+            G_.gstate.clear()
+    release_graphs(G)
+
+    # ---- config 4: ONE density-control event behind the timed steps, timed on its own, then the loop goes on with the new point count
+    density_event = None
+    if cfg.get("densify"):
+        from emd_amd.model import density_control
         torch.cuda.synchronize()
-        two_graphs = graph_b is not None
-        if two_graphs:
-            graph_b.reset()
-        graph.reset()
-        graph = "released"
+        t0 = time.perf_counter()
+        dp.reduce_densification_stats(*S["stats"])          # every rank then holds the statistics of all views of all ranks (SUM, SUM, MAX)
+        thr = args.densify_grad_threshold
+        if thr is None:
+            # (the synthetic scene's gradients have nothing of a real scene's scale: the reference's 2e-4 would select nothing or everything.
+            #  The threshold is the 95 % quantile of the mean view-space gradient over the Gaussians seen at least once -- computed from the REDUCED
+            #  statistics, hence identical on every rank)
+            seen = S["stats"][1].reshape(-1) > 0
+            avg = (S["stats"][0].reshape(-1) / S["stats"][1].reshape(-1).clamp_min(1.0))[seen]
+            thr = float(torch.quantile(avg[:: max(avg.numel() // 1_000_000, 1)], 0.95)) if avg.numel() else 2e-4
+        ev = density_control(model, *S["stats"], max_grad=thr, min_opacity=0.005, extent=27.5, percent_dense=0.01, seed=0, event=0)
+        N2 = ev["n_after"]
+        S["params"] = [p for p in model.parameters()]
+        S["stats"] = [torch.zeros(N2, 1, device=dev), torch.zeros(N2, 1, device=dev), torch.zeros(N2, device=dev)]
+        S["N"] = N2
+        torch.cuda.synchronize()
+        t_event = time.perf_counter() - t0
+        if world > 1:          # replicas must agree on the new point count before the next collective
+            n_all = torch.tensor([N2], device=dev, dtype=torch.int64)
+            n_max, n_min = n_all.clone(), n_all.clone()
+            torch.distributed.all_reduce(n_max, op=torch.distributed.ReduceOp.MAX)
+            torch.distributed.all_reduce(n_min, op=torch.distributed.ReduceOp.MIN)
+            assert int(n_max) == int(n_min) == N2, f"ranks disagree on the point count after density control: {int(n_min)}..{int(n_max)}"
+        opts.capacity_hint = int(opts.capacity_hint * (1.0 + 1.5 * max(N2 - N, 0) / N)) + 1024
+        gc.collect()
+        t0 = time.perf_counter()
+        G = record_step() if (not args.eager and opts.no_sync) else None
+        torch.cuda.synchronize()
+        t_record = time.perf_counter() - t0
+        for s in range(args.warmup):
+            timed_step(s)
+        dt2, _, _ = timed_block(args.warmup, args.steps)
+        flush_status_log()
+        st2 = status_log[args.warmup:args.warmup + args.steps].cpu().numpy().astype("int64") & 0xFFFFFFFF
+        release_graphs(G)
+        if world > 1:
+            t2 = torch.tensor([dt2, t_event], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t2, op=torch.distributed.ReduceOp.MAX)
+            dt2, t_event = [float(v) for v in t2.tolist()]
+        density_event = dict(ev, grad_threshold=thr, event_ms=round(t_event * 1e3, 3), re_record_ms=round(t_record * 1e3, 1),
+                             ms_per_step_after=round(dt2 / args.steps * 1e3, 4), iters_per_s_after=round(world * args.steps / dt2, 2),
+                             overflow_after=int((st2[:, 1] & 1).sum()), D_mean_after=round(float(st2[:, 0].mean()), 1),
+                             note="one event behind the timed steps (statistics reduced over ranks -> clone / split / prune of the background Gaussians -> "
+                                  "fresh statistics), then the step recorded again for the new point count and the same views timed again; `value` "
+                                  "is the block BEFORE the event")
+    own = [dt_own / args.steps * 1e3]
     if world > 1:
         tmax = torch.tensor([dt] + [r_ * args.steps / 1e3 for r_ in rep], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         vals = tmax.tolist()
         dt, rep = float(vals[0]), [v / args.steps * 1e3 for v in vals[1:]]
-    st_all = status_log[args.warmup:args.warmup + args.steps].cpu().numpy().astype("int64") & 0xFFFFFFFF
+        t_all = torch.zeros(world, device=dev, dtype=torch.float64)
+        t_all[rank] = dt_own / args.steps * 1e3
+        torch.distributed.all_reduce(t_all, op=torch.distributed.ReduceOp.SUM)
+        own = [float(v) for v in t_all.tolist()]
     overflow = int((st_all[:, 1] & 1).sum())
     assert overflow == 0, "binning workspace overflowed during the timed region"
     assert int((st_all[:, 1] & 2).sum()) == 0, ("a timed step saw a visible Gaussian beyond 65 536 x the near plane with the three-pass depth sort: "
@@ -566,7 +724,7 @@ def main():
         T = ((W + 15) // 16) * ((H + 15) // 16)
         C = 7 if opts.compute_normal else 4
         passes = (max(T - 1, 1).bit_length() + 7) // 8            # radix passes over the D duplicates (tile bits)
-        ab = algorithmic_bytes(N, Vp, Dp, H * W, T, C, passes, C_bwd=4)   # the L1 loss sends no gradient into the normal image
+        ab = algorithmic_bytes(N, Vp, Dp, H * W, T, C, passes, residual=residual is not None, C_bwd=4)   # the L1 loss sends no gradient into the normal image
         stages = {}
         for name, (ms, cnt) in prof.items():
             if cnt and name in ab:
@@ -578,11 +736,23 @@ def main():
         total_alg = sum(ab.values())
         full = (N, H, W, args.config) == (2_000_000, 1066, 1600, 2)
         traffic = pmc_traffic(dom, passes) if full else None
+        if full:                                             # fabric bytes per stage from the same committed counter file (static)
+            for name in stages:
+                tb = pmc_traffic(name, passes)
+                if tb:
+                    stages[name]["fabric_GB_static"] = round(tb / 1e9, 4)
+                    stages[name]["fabric_over_algorithmic"] = round(tb / ab[name], 2)
+        if pairs is not None:
+            pairs["atomic_rows_per_launch"] = rows_k7 / pairs["launches"]
+            pairs["float_atomics_per_launch"] = atoms_k7 / pairs["launches"]
+            pairs["atomic_row_bytes_per_launch"] = 48.0 * rows_k7 / pairs["launches"]
+            pairs["compulsory_row_bytes_per_launch"] = 48.0 * Vp
         roofline = {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 4),
-                    "traffic": traffic,
+                    "traffic": traffic, "traffic_ratio": None if not traffic else round(traffic / ab[dom], 3),
                     "traffic_static": {"static": True, "source": None if _pmc_path(PMC_TRAFFIC_CSV) is None else "profiles/" + os.path.basename(_pmc_path(PMC_TRAFFIC_CSV)),
-                                       "note": "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the same command, bytes per launch; a committed file constant, not measured in this run"},
+                                       "note": "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of `bench.py --steps 20 --warmup 5 --eager` (the driver's flags: the same frames "
+                                               "as the timed region of a default driver run), bytes per launch; a committed file constant, not measured in this run"},
                     "secondary_bound": "fp32 vector issue rate: the render kernels are issue-bound (DESIGN.md section 6)",
                     "issue": issue_bound(dom, stages[dom]["ms"]) if full else None,
                     "pairs": pairs,
@@ -598,7 +768,8 @@ def main():
                                    "frac": round(total_alg / 1e9 / (kernel_ms * 1e-3) / HBM_PEAK_GBS, 4)},
                     "stages": stages}
         if world == 1:
-            mapping = "1 GPU: camera 0 of frame (step mod 50)" if num_actors else "1 GPU: camera 0 of frame 0 (static scene)"
+            mapping = ("1 GPU: camera 0 of frame (step mod 50)" if num_actors else "1 GPU: camera 0 of frame 0 (static scene)") if num_cams == 1 else \
+                      f"1 GPU walking the {num_cams}-camera rig: step s renders camera (s mod {num_cams}) of frame (s div {num_cams}) -- the per-rank workload of this configuration"
         elif world == num_cams:
             mapping = f"{world} GPUs: rank r <-> camera r of the {num_cams}-camera rig, all ranks of a step share one timestamp"
         else:
@@ -613,7 +784,7 @@ def main():
             "repeats_ms_per_step": None if not rep else {"n": len(rep), "min": round(rep_sorted[0], 4), "median": round(rep_sorted[len(rep) // 2], 4),
                                                         "max": round(rep_sorted[-1], 4),
                                                         "note": "the timed block replayed again back to back after it; `value` is the first block only"},
-            "settle": {"ms": args.settle_ms, "untimed_steps": settle_replays, "note": "untimed steps before the warm-up steps: an idle GPU's clocks settle under load"},
+            "settle": {"ms": args.settle_ms, "untimed_steps": settle["replays"], "note": "untimed steps before the warm-up steps: an idle GPU's clocks settle under load"},
             "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"] + (f" ({num_actors} actors x 5000" + (", learned per-actor track offsets" if heads_on else "") + ")" if num_actors else "")
@@ -624,12 +795,16 @@ def main():
                        "radix_passes_depth": "3 x 9 bits above the near plane: first over the N keys (compacting to V), two over the V pairs",
                        "radix_passes_tile_on_D": passes, "blended_channels_C": C, "views_per_step": world,
                        "rig_cameras": num_cams, "rank_view_mapping": mapping, "track_heads": heads_on,
+                       "ranks_seen": ranks_seen, "rank_ms_per_step": {"min": round(min(own), 4), "max": round(max(own), 4), "per_rank": [round(v, 4) for v in own],
+                                                                      "note": "each rank's own time for the timed block (before the closing barrier)"},
+                       "deformation_residual": None if residual is None else "residual_dx [N,3]" + (" + residual_dq [N,4]" if residual[1] is not None else "")
+                                               + " as inputs of the fused transform, gradients returned to both (not exchanged: activations of a network)",
                        "densification_stats_in_step": bool(args.densify_stats),
                        "step_issue": ("hipGraph replay (one capture; camera block, frame, frame time and coarse-to-fine level selected on the device by one launch"
                                       + (("; TWO graphs cut between the render backward and the projection backward: the SH-factor gathers are issued "
                                           "between their replays and travel under K8, the slab all-reduce behind the second)") if two_graphs else
                                          ("; the gradient exchange is issued behind each replay)" if (world > 1 or opts.factored_sh_grad) else ")")))
-                                     if graph is not None else "eager (Python issues every launch)",
+                                     if step_issue_graph else "eager (Python issues every launch)",
                        "parallelism": f"view-parallel dp{world}", "count_readback": bool(args.sync_count),
                        "gradient_exchange": ("none (1 GPU)" if world == 1 else
                                              "SH gradient as rank-one factors: all-gather of 12 B per Gaussian and rank + camera centres + per-view actor "
@@ -637,6 +812,8 @@ def main():
                                              "(one slab, started inside backward()) + actor poses / track heads")},
             "roofline": roofline,
         }
+        if density_event is not None:
+            res["density_control_event"] = density_event
         if world == 1 and not args.no_cpu_baseline:      # the CPU leg is timed on rank 0 of the 1-GPU run only
             f0, _, cam0 = cam_for(0)
             res["cpu_baseline"] = cpu_baseline(scene, cam0, frame=f0)
@@ -644,6 +821,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
 
 
 def bench_forward_only(args, cfg, scene, model, render, cam_for, bg, opts, _lib, N, H, W, rank):

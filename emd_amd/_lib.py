@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16

@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
     __syncthreads();
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // STATS (diagnostic instantiation, EmdBwdArgs.pair_stats): (pixel, entry) pairs this wave evaluates / pairs that contribute
-    unsigned long long st_eval = 0ull, st_hit = 0ull;
+    unsigned long long st_eval = 0ull, st_hit = 0ull, st_rows = 0ull, st_atoms = 0ull;       // + atomic rows with a non-zero float / float atomics issued
 
     // One batch of nb survivors: lane = entry, lane 0 the DEEPEST; `pos` = 0-based number of the lane's survivor, `gid` its Gaussian.
     // HALF (round 4): a batch of at most 32 survivors -- only the deepest step of a walk can be that short -- runs on both halves of the
@@ -532,9 +532,16 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
 #pragma unroll
         for (int k = 0; k < NX; k++) row[3 + k] = make_float4(xr_2[k].x + xr_2[k].y, xg_2[k].x + xg_2[k].y, xb_2[k].x + xb_2[k].y, 0.f);
         __syncthreads();
+        if (STATS) {
+            bool nz = false;
+            if (lane < nb)
+                for (int v = 0; v < STRIDE; v++) nz = nz || s_stage[lane * STRIDE + v] != 0.f;
+            st_rows += (unsigned long long)__popcll(__ballot(nz));
+        }
         for (uint32_t idx = lane; idx < nb * STRIDE; idx += EMD_WAVE) {
             const uint32_t e = idx / STRIDE, v = idx % STRIDE;
             const float val = s_stage[idx];
+            if (STATS) st_atoms += (unsigned long long)__popcll(__ballot(val != 0.f));
             if (val != 0.f) atomicAdd(grad_rec + (size_t)q_id[e] * STRIDE + v, val);
         }
         __syncthreads();
@@ -602,7 +609,7 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
             process_batch(std::false_type{}, nb, c0r, c1r, c2r, c3r, cxr, (uint32_t)max(idx, 0), cid);
         }
     }
-    if (STATS && lane == 0) { atomicAdd(pair_stats, st_eval); atomicAdd(pair_stats + 1, st_hit); }
+    if (STATS && lane == 0) { atomicAdd(pair_stats, st_eval); atomicAdd(pair_stats + 1, st_hit); atomicAdd(pair_stats + 2, st_rows); atomicAdd(pair_stats + 3, st_atoms); }
 }
 
 RenderDims make_dims(const EmdSettings& s, const float* sdev, const EmdExtra* x) {

@@ -209,7 +209,10 @@ class GradientExchange:
             self.num_collectives += 1
 
     def finish(self, sh_param, means3D, sh_degree, other_params=()):
-        """Sets `sh_param.grad` (dense, view-averaged) and averages the gradients of `other_params` over the ranks in place."""
+        """Sets `sh_param.grad` (dense, view-averaged) and averages the gradients of `other_params` over the ranks in place.
+        `sh_param`: the [N,K,3] SH parameter, or a tuple of parameters that split its coefficient axis -- the reference's
+        (`_features_dc` [N,1,3], `_features_rest` [N,15,3]), S3Gaussian/scene/gaussian_model.py:58-59: each receives its slice of the rebuilt
+        gradient (the rasterizer is then fed `torch.cat(...).detach()`: the factored backward returns no dL/dshs to chain through the cat)."""
         rec = self.rec
         if rec is None:
             raise RuntimeError("GradientExchange.finish before the backward pass ran (RasterCall.on_backward was not wired)")
@@ -224,8 +227,9 @@ class GradientExchange:
             lo = hi = None
             if self._slab_work is not None:
                 lo, hi = slab.data_ptr(), slab.data_ptr() + slab.numel() * 4
+            sh_parts = tuple(sh_param) if isinstance(sh_param, (tuple, list)) else (sh_param,)
             for p in other_params:
-                if p is sh_param or p.grad is None:
+                if any(p is q for q in sh_parts) or p.grad is None:
                     continue
                 g = p.grad
                 if lo is not None and lo <= g.data_ptr() < hi:
@@ -249,8 +253,16 @@ class GradientExchange:
                 w.wait()
             g_all, campos = self._g_cat.view(W, N, 3), self._campos
             pose = None if self._poses is None else self._poses.view(W, -1, self._poses.shape[1])
-        sh_param.grad = sh_grad_from_factors(means3D, campos, g_all, sh_degree, sh_param.shape[1], self.actor_ids, pose, self.residual_dx,
-                                             scale=(1.0 / W) if self.average else 1.0).view_as(sh_param)
+        parts = tuple(sh_param) if isinstance(sh_param, (tuple, list)) else (sh_param,)
+        dense = sh_grad_from_factors(means3D, campos, g_all, sh_degree, sum(int(q.shape[1]) for q in parts), self.actor_ids, pose, self.residual_dx,
+                                     scale=(1.0 / W) if self.average else 1.0)
+        if len(parts) == 1:
+            sh_param.grad = dense.view_as(sh_param)
+        else:
+            k0 = 0
+            for q in parts:
+                q.grad = dense[:, k0:k0 + q.shape[1]].contiguous()
+                k0 += q.shape[1]
         if self._slab_work is not None:
             self._slab_work.wait()
         for w in works:

@@ -69,6 +69,13 @@ class StepInputs:
         H, W = int(cams[0].image_height), int(cams[0].image_width)
         if any((int(c.image_height), int(c.image_width)) != (H, W) for c in cams):
             raise ValueError("the views of one recorded step share the image size")
+        # host constants of the capture that model.render reads from the camera object (`cam_no` indexes S3Gaussian's per-camera
+        # time_offset parameter, `time_diff` scales it): one value for all rows, or the recorded step would silently apply camera 0's
+        cam_nos = {int(getattr(c, "cam_no", 0)) for c in cams}
+        time_diffs = {float(getattr(c, "time_diff", 0.0)) for c in cams}
+        if len(cam_nos) > 1 or len(time_diffs) > 1:
+            raise ValueError(f"the views of one recorded step share cam_no and time_diff (got cam_no {sorted(cam_nos)}, time_diff "
+                             f"{sorted(time_diffs)}): group the views by camera and record one StepGraphs per group")
         rows = []
         bg = torch.as_tensor(bg, dtype=torch.float32).reshape(-1).cpu()
         for i, c in enumerate(cams):
@@ -88,7 +95,8 @@ class StepInputs:
         r = self.row
         self.bg, self.time, self.extra = r[0:3], r[61:62], r[62:]
         self.camera = types.SimpleNamespace(image_height=H, image_width=W, tanfovx=r[38:39], tanfovy=r[39:40], world_view_transform=r[3:19].view(4, 4),
-                                            full_proj_transform=r[19:35].view(4, 4), camera_center=r[35:38], sky_rays=r[40:61], time=r[61:62])
+                                            full_proj_transform=r[19:35].view(4, 4), camera_center=r[35:38], sky_rays=r[40:61], time=r[61:62],
+                                            cam_no=cam_nos.pop(), time_diff=time_diffs.pop())
 
     def launch_select(self):
         """The launch that copies row sel[0] to the fixed addresses (the first node of a recorded step; also usable eagerly)."""

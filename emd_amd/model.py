@@ -70,6 +70,53 @@ class StreetGaussians(torch.nn.Module):
         return actor_pose_table(self.instances_quats, self.instances_trans, self.instances_fv, frame, None, None)
 
 
+def density_control(model: "StreetGaussians", xyz_gradient_accum, denom, max_radii2D, max_grad=2e-4, min_opacity=0.005, extent=27.5,
+                    max_screen_size=None, percent_dense=0.01, seed=0, event=0):
+    """One density-control event of the training loop (S3Gaussian/train.py:404-423 -> scene/gaussian_model.py:442-556: clone the small,
+    split the large Gaussians whose accumulated view-space gradient exceeds `max_grad`, then prune the transparent / oversized ones) on a
+    StreetGaussians parameter store, in place; returns {"n_before", "n_after", "cloned", "split", "pruned"}.
+
+    The BACKGROUND Gaussians (actor id -1) take part; an actor's points stay as they are -- the reference holds every tracked actor at a
+    fixed budget (<= 5000 Gaussians, OmniRe/configs/paper_legacy/omnire.yaml:93; the bench scene's actors sit at that cap) and stores an
+    actor's points contiguously, which the per-actor kernels rely on.  The engine is emd_amd.gaussian_model.GaussianModel's device-side
+    decide -> scan -> index -> gather (csrc/densify.hip); the split samples are a Philox draw keyed by (seed, event), so every rank of a
+    view-parallel run that calls this with the same (reduced) statistics ends with bit-identical parameters.  The three statistics
+    tensors are consumed (the caller allocates fresh zeros for the new point count, as densification_postfix does, gaussian_model.py:526-530)."""
+    from .gaussian_model import GaussianModel
+    dev, N = model._xyz.device, model._xyz.shape[0]
+    n_dyn = int((model.actor_id >= 0).sum()) if model.has_actors else 0
+    if model.has_actors and n_dyn and not bool((model.actor_id[:n_dyn] >= 0).all()):
+        raise ValueError("density_control expects the actors' points in front of the background's (the reference's node order)")
+    gm = GaussianModel(sh_degree=3, device=dev, densify_seed=seed)
+    gm.densify_events = int(event)
+    P = lambda t: torch.nn.Parameter(t.detach()[n_dyn:].contiguous())
+    gm._xyz, gm._scaling, gm._rotation, gm._opacity = P(model._xyz), P(model._scaling), P(model._rotation), P(model._opacity)
+    gm._features_dc, gm._features_rest = P(model._features[:, :1]), P(model._features[:, 1:])
+    ns = N - n_dyn
+    gm._embedding = torch.nn.Parameter(torch.zeros(ns, gm.gaussian_embedding_dim, device=dev))
+    gm._deformation_table = torch.ones(ns, dtype=torch.bool, device=dev)
+    gm.xyz_gradient_accum = xyz_gradient_accum.reshape(N, 1)[n_dyn:].contiguous()
+    gm.denom = denom.reshape(N, 1)[n_dyn:].contiguous()
+    gm.max_radii2D = max_radii2D.reshape(N)[n_dyn:].contiguous()
+    gm.percent_dense = float(percent_dense)
+    with torch.no_grad():
+        _, n_clone, n_split = gm.densify(max_grad, min_opacity, extent, max_screen_size)
+        n_mid = gm._xyz.shape[0]
+        gm.prune(max_grad, min_opacity, extent, max_screen_size)
+        n_new = gm._xyz.shape[0]
+        front = lambda t: t.detach()[:n_dyn]
+        NP = lambda a, b: torch.nn.Parameter(torch.cat([a, b.detach()], 0).contiguous())
+        model._xyz = NP(front(model._xyz), gm._xyz)
+        model._scaling = NP(front(model._scaling), gm._scaling)
+        model._rotation = NP(front(model._rotation), gm._rotation)
+        model._opacity = NP(front(model._opacity), gm._opacity)
+        model._features = NP(front(model._features), torch.cat([gm._features_dc, gm._features_rest], 1))
+        if model.has_actors:
+            model.actor_id = torch.cat([model.actor_id[:n_dyn], torch.full((n_new,), -1, dtype=model.actor_id.dtype, device=dev)])
+    model._zero_xyz = None
+    return {"n_before": N, "n_after": n_dyn + n_new, "cloned": int(n_clone), "split": int(n_split), "pruned": int(n_mid - n_new)}
+
+
 def mix_dynamic_static(opacity_dynamic, opacity_static, shs_dynamic=None, shs_static=None, colors_dynamic=None, colors_static=None):
     """The `combine_dynamic_static` mixing of the reference's render() (S3Gaussian/gaussian_renderer/__init__.py:118-138; flag default off,
     arguments/gaussian_options.py:195): the deformed ("dynamic") and the undeformed ("static") copy of every Gaussian are drawn as ONE
@@ -95,7 +142,7 @@ def pre_compute_colors(shs, xyz, camera_center, degree):
 
 def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activations=True, deformation=None, embeddings=None,
            iteration=None, time=None, options=None, record=None, render_feat=False, need_feat=True, combine_dynamic_static=False,
-           convert_SHs_python=False):
+           convert_SHs_python=False, residual=None):
     """The reference render() restricted to the hot path; returns the dict the training loop consumes.
     `deformation` (an emd_amd.deformation.deform_network) switches on the "fine" stage of gaussian_renderer/__init__.py:86-96:
     the residuals of the self-supervised EMD network are added to the raw parameters before the activations.
@@ -107,7 +154,10 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
     `need_feat=False` (with an emd_amd deform_network): nobody will read ddict[...]["feat"], so the feature head is not evaluated.
     `combine_dynamic_static` (fine stage; the reference's args.combine_dynamic_static, :118-138): the deformed and the undeformed copy of
     every Gaussian drawn as one (mix_dynamic_static); `convert_SHs_python` evaluates the colours in front of the boundary (:106-110),
-    which is also the only configuration in which the reference's own decomposition passes run with that flag (render_decomposition)."""
+    which is also the only configuration in which the reference's own decomposition passes run with that flag (render_decomposition).
+    `residual` = (dx [N,3] or None, dq [N,4] or None): the learned per-Gaussian deformation residual of the supervised branch
+    (`means = _means + delta_xyz`, `quats = get_quats + delta_quat` IN FRONT of the rigid transform, OmniRe/models/nodes/deformable.py:49-68)
+    as inputs of the fused transform inside the projection kernel; gradients return to both tensors."""
     dev = model._xyz.device
     # the reference's zero "screen-space points" leaf that only collects dL/dmean2D: the zeros are never written, so one
     # cached buffer per model serves every step (a fresh leaf view each time, no 24 MB fill launch)
@@ -178,6 +228,8 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         from .motion import DeviceStep
         it = 0 if iteration is None else (iteration if isinstance(iteration, (torch.Tensor, DeviceStep)) else int(iteration))
         kw.update(actor_ids=model.actor_id, actor_pose=model.actor_pose(frame, it))
+    if residual is not None:
+        kw.update(residual_dx=residual[0], residual_dq=residual[1])
     image, depth, normal, weight, radii, extra = rasterizer(
         means3D=means3D, means2D=screenspace_points, shs=None if colors_precomp is not None else shs, colors_precomp=colors_precomp,
         opacities=opacity, scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None, raw_params=fuse_activations,

@@ -97,8 +97,9 @@ class RasterCall:
     (GradientExchange.start_factors) run under the projection backward instead of behind it.
     `status_buffer` (optional, set by the caller before the call): an int32[4] device tensor that receives the status words instead
     of a fresh allocation -- a fixed address for callers that replay the call from a hipGraph and read the words on the device.
-    `pair_stats` (diagnostic; an int64[2] device tensor set by the caller before backward()): the render backward adds the number of
-    (pixel, list entry) pairs it evaluated and the number that contributed (EmdBwdArgs.pair_stats)."""
+    `pair_stats` (diagnostic; an int64[4] device tensor set by the caller before backward()): the render backward adds the number of
+    (pixel, list entry) pairs it evaluated, the number that contributed, the accumulator rows it sent to memory as float atomics and the
+    float atomics issued (EmdBwdArgs.pair_stats)."""
     __slots__ = ("status", "num_rendered", "num_visible", "geom_ws", "bin_ws", "img_ws", "sizes", "capacity", "N", "H", "W",
                  "flags", "settings_dev", "absgrad", "sh_color_grad", "grad_slab", "on_backward", "render_grads", "pair_stats",
                  "status_buffer", "slab_inputs", "on_sh_factor")
@@ -487,7 +488,7 @@ class _Rasterize(torch.autograd.Function):
         b.dL_dscales, b.dL_drotations, b.dL_dcov3D = L.ptr(d_sc), L.ptr(d_rot), L.ptr(d_cov)
         b.dL_dactor_pose, b.dL_dresidual_dx, b.dL_dresidual_dq = L.ptr(d_pose), L.ptr(d_rdx), L.ptr(d_rdq)
         b.dL_dsh_color = L.ptr(d_shc)
-        b.pair_stats = L.ptr(rec.pair_stats)         # diagnostic: an int64[2] device tensor set on the record before backward(), or None
+        b.pair_stats = L.ptr(rec.pair_stats)         # diagnostic: an int64[4] device tensor set on the record before backward(), or None
         b.num_extra = nx
         for k in range(nx):
             b.colors_extra[k], b.out_extra[k] = extras[k].data_ptr(), out_extra[k].data_ptr()

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 24
+#define EMD_ABI_VERSION 25
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -274,8 +274,9 @@ typedef struct EmdBwdArgs {
     const float* out_extra[EMD_MAX_EXTRA];
     const float* dL_dextra[EMD_MAX_EXTRA];        /* [3,H,W] or NULL */
     float* dL_dcolors_extra[EMD_MAX_EXTRA];       /* [N,3] or NULL */
-    /* diagnostic (ABI 18): device uint64[2], ADDED to by the render backward: [0] (pixel, list entry) pairs its waves evaluated,
-     * [1] pairs that contributed (alpha >= 1/255 in front of the pixel's last contributor).  NULL in production: the counting
+    /* diagnostic (ABI 18; four words since ABI 25): device uint64[4], ADDED to by the render backward: [0] (pixel, list entry) pairs its
+     * waves evaluated, [1] pairs that contributed (alpha >= 1/255 in front of the pixel's last contributor), [2] accumulator rows it sent
+     * to memory as float atomics (one per (quadrant, survivor) with a non-zero entry), [3] float atomics issued.  NULL in production: the counting
      * instantiation of the kernel is only launched when the pointer is set (plain call only: no extra sets / absgrad / dL_dnormal) */
     uint64_t* pair_stats;
 } EmdBwdArgs;

@@ -68,3 +68,24 @@ def test_bench_presets_run(config, extra):
         assert d["unit"] == "ms" and d["config"]["gaussians"] == 10_000 and d["config"]["height"] == 256 and d["higher_is_better"] is False
     else:
         assert d["unit"] == "iters/s" and d["config"]["track_heads"] is False and d["config"]["step_issue"].startswith("hipGraph replay")
+
+
+@pytest.mark.parametrize("config,extra", [(3, ["--gaussians", "200000", "--height", "200", "--width", "304"]),
+                                          (4, ["--gaussians", "300000", "--height", "200", "--width", "304"])], ids=["config3-small", "config4-small"])
+def test_bench_multi_gpu_presets_run_as_the_per_rank_workload(config, extra):
+    """BASELINE configs[3] (4-camera rig, deformation residual as an input of the fused transform) and configs[4] (6-camera rig, 48 actors,
+    densification statistics every step + one density-control event behind the timed steps) at --gpus 1 = the per-rank workload."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(config), "--steps", "6", "--warmup", "2", "--repeats", "1",
+                        "--no-cpu-baseline"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2500:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    c = d["config"]
+    assert c["baseline_config_index"] == config and d["value"] > 0 and c["step_issue"].startswith("hipGraph replay") and c["ranks_seen"] == 1
+    if config == 3:
+        assert c["rig_cameras"] == 4 and "residual_dx" in c["deformation_residual"] and "residual_dq" in c["deformation_residual"]
+        assert "density_control_event" not in d
+    else:
+        ev = d["density_control_event"]
+        assert c["rig_cameras"] == 6 and c["densification_stats_in_step"] is True
+        assert ev["n_before"] == 300000 and ev["cloned"] + ev["split"] > 0 and ev["n_after"] == ev["n_before"] + ev["cloned"] + ev["split"] - ev["pruned"]
+        assert ev["overflow_after"] == 0 and ev["ms_per_step_after"] > 0
