@@ -248,6 +248,9 @@ def main():
     ap.add_argument("--exchange-only", action="store_true",
                     help="time ONLY the gradient exchange of a view-parallel step (GradientExchange.start + finish on a fixed backward's outputs): "
                          "separates communication from compute in the 2/4/8-GPU runs")
+    ap.add_argument("--exchange", choices=("auto", "dense", "compact"), default="auto",
+                    help="multi-GPU gradient exchange: dense (slab all-reduce + factor all-gather), compact (index + value rows of the visible Gaussians, "
+                         "added in rank order) or auto = whichever moves fewer bytes per xGMI link at this world size (dp.compact_pays)")
     ap.add_argument("--densify-grad-threshold", type=float, default=None,
                     help="config 4's density-control event: view-space gradient threshold (default: the value that selects ~5 %% of the seen Gaussians of the synthetic scene)")
     args = ap.parse_args()
@@ -314,6 +317,10 @@ def main():
         stats = [torch.zeros(N, 1, device=dev), torch.zeros(N, 1, device=dev), torch.zeros(N, device=dev)]
     S = {"params": params, "stats": stats, "N": N}          # what a density-control event replaces (config 4)
 
+    # the form of the multi-GPU exchange (set once the visible counts of the run's views are known, below): dense until then
+    X = {"cap": None, "compact": False, "overflow": torch.zeros(1, dtype=torch.int32, device=dev)}
+    xkw = lambda: dict(compact=X["compact"], compact_capacity=X["cap"], overflow=X["overflow"])
+
     def cam_for(step):
         # views are ordered timestamp-major and dealt out by dp.view_for: every rank renders a DISTINCT (frame, camera);
         # with 8 ranks on the 6-camera rig two ranks hold cameras of the next timestamp (dp.frame_and_camera).
@@ -337,7 +344,7 @@ def main():
             # SH gradient (81 % of the gradient bytes): rank-one factors, 12 B per Gaussian and rank instead of all-reducing
             # 192 B per Gaussian; the collectives are issued from inside backward(), right behind K8 (emd_amd/dp.py)
             xchg = dp.GradientExchange(campos_dev[(f, c)], actor_ids=model.actor_id if model.has_actors else None,
-                                       residual_dx=None if residual is None else residual[0].detach())
+                                       residual_dx=None if residual is None else residual[0].detach(), **xkw())
             rec.on_backward = xchg.start
             rec.on_sh_factor = xchg.start_factors        # (the factor gathers run under K8; needs the actor poses of this step: set below)
         out = render(model, cam, bg, frame=f, iteration=step, options=options, record=rec, residual=residual)
@@ -364,13 +371,24 @@ def main():
         cam_for(s_)
     sync_opts = opts.replace(no_sync=False)
     out = one_step(0, sync_opts, backward=not cfg["forward_only"])
-    dmax = out["raster_call"].last_status()["num_rendered"]
+    st0 = out["raster_call"].last_status()
+    dmax, vmax = st0["num_rendered"], st0["num_visible"]
     with torch.no_grad():
         for s_ in sorted(set(list(range(0, args.warmup + args.steps, 7)) + [args.warmup + args.steps - 1])):
             f, c, cam = cam_for(s_)
             o = render(model, cam, bg, frame=f, options=sync_opts, residual=residual)
-            dmax = max(dmax, o["raster_call"].last_status()["num_rendered"])
+            st_ = o["raster_call"].last_status()
+            dmax, vmax = max(dmax, st_["num_rendered"]), max(vmax, st_["num_visible"])
     opts.capacity_hint = int(dmax * 1.3) + 1024          # (an option of this run's calls: nothing process-wide is written)
+    # rows per view of the visibility-compacted exchange: the same number on every rank (MAX over the ranks' views + margin); dp.compact_pays
+    # then decides per world size whether the rows or the dense slab move fewer bytes per link
+    if world > 1 or (args.exchange == "compact" and factored):
+        v_all = torch.tensor([vmax], device=dev, dtype=torch.int64)
+        if world > 1:
+            torch.distributed.all_reduce(v_all, op=torch.distributed.ReduceOp.MAX)
+        X["cap"] = dp.visible_capacity(int(v_all) * 1.15)          # (sampled every 7th view: a wider margin than the default)
+        X["compact"] = {"auto": None, "dense": False, "compact": True}[args.exchange]
+        X["uses_rows"] = bool(X["compact"]) or (X["compact"] is None and dp.compact_pays(world, N, X["cap"]))
 
     if cfg["forward_only"]:
         return bench_forward_only(args, cfg, scene, model, render, cam_for, bg, opts, _lib, N, H, W, rank)
@@ -554,7 +572,7 @@ def main():
                 # slab all-reduce behind the second; one graph (--one-graph): the whole exchange behind the replay
                 gs = G.gstate
                 xchg = dp.GradientExchange(gs["campos"], actor_ids=model.actor_id if model.has_actors else None, actor_pose=gs["pose"],
-                                           residual_dx=None if residual is None else residual[0].detach())
+                                           residual_dx=None if residual is None else residual[0].detach(), **xkw())
                 if G.graph_b is not None:
                     xchg.start_factors(gs["rec"])
                     G.graph_b.replay()
@@ -711,6 +729,7 @@ def main():
         own = [float(v) for v in t_all.tolist()]
     overflow = int((st_all[:, 1] & 1).sum())
     assert overflow == 0, "binning workspace overflowed during the timed region"
+    assert int(X["overflow"]) == 0, f"the compacted exchange's capacity ({X['cap']} rows per view) was exceeded: gradients of a step were incomplete"
     assert int((st_all[:, 1] & 2).sum()) == 0, ("a timed step saw a visible Gaussian beyond 65 536 x the near plane with the three-pass depth sort: "
                                                  "its image was blank (use RasterOptions(wide_depth_sort=True))")
 
@@ -807,9 +826,14 @@ def main():
                                      if step_issue_graph else "eager (Python issues every launch)",
                        "parallelism": f"view-parallel dp{world}", "count_readback": bool(args.sync_count),
                        "gradient_exchange": ("none (1 GPU)" if world == 1 else
+                                             ("visibility-compacted rows (dp.compact_pays: fewer bytes per xGMI link at this world size): all-gather of (index, 3 floats) "
+                                              f"factor rows and (index, 11 floats) slab rows of each view's visible Gaussians, {X['cap']} rows per view, added in rank "
+                                              "order on every rank; + camera centres, per-view actor pose tables; dense SH average rebuilt locally; actor poses / track "
+                                              "heads as one bucket") if X.get("uses_rows") else
                                              "SH gradient as rank-one factors: all-gather of 12 B per Gaussian and rank + camera centres + per-view actor "
                                              "pose tables, dense average rebuilt locally; one RCCL all-reduce (AVG) of the remaining 44 B per Gaussian "
-                                             "(one slab, started inside backward()) + actor poses / track heads")},
+                                             "(one slab, started inside backward()) + actor poses / track heads"),
+                       "exchange_rows_per_view": X["cap"] if X.get("uses_rows") else None},
             "roofline": roofline,
         }
         if density_event is not None:

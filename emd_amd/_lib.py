@@ -213,7 +213,7 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_densify_decide", "emd_densify_index", "emd_densify_split_rank", "emd_densify_gather",
                     "emd_mlp_trunk_forward", "emd_mlp_trunk_backward", "emd_mlp_branch_forward", "emd_mlp_branch_backward",
                     "emd_abs_mean_backward", "emd_residual_l1_backward", "emd_tracked_pose_forward", "emd_tracked_pose_backward",
-                    "emd_select_step_inputs")
+                    "emd_select_step_inputs", "emd_compact_rows", "emd_scatter_rows")
 PROF_STAGES = 8
 
 _lib = None
@@ -264,6 +264,10 @@ def load():
     lib.emd_sh_grad_from_factors.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(EmdMotion), C.c_int32,
                                              C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     lib.emd_densification_stats.argtypes = [C.c_int32] + [C.c_void_p] * 6
+    lib.emd_compact_rows.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]
+    lib.emd_scatter_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.c_float,
+                                     C.c_void_p, C.c_void_p]
     lib.emd_hexplane_forward.argtypes = [C.POINTER(EmdHexArgs), C.c_void_p]
     lib.emd_hexplane_backward.argtypes = [C.POINTER(EmdHexArgs), C.POINTER(EmdHexGrads), C.c_void_p]
     lib.emd_hexplane_order_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]

@@ -102,7 +102,7 @@ class RasterCall:
     float atomics issued (EmdBwdArgs.pair_stats)."""
     __slots__ = ("status", "num_rendered", "num_visible", "geom_ws", "bin_ws", "img_ws", "sizes", "capacity", "N", "H", "W",
                  "flags", "settings_dev", "absgrad", "sh_color_grad", "grad_slab", "on_backward", "render_grads", "pair_stats",
-                 "status_buffer", "slab_inputs", "on_sh_factor")
+                 "status_buffer", "slab_inputs", "on_sh_factor", "radii")
 
     def __init__(self):
         for k in self.__slots__:
@@ -399,6 +399,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)   # unused outputs (normal, depth, alpha) arrive as None, not as zero images
         rec.status, rec.num_rendered, rec.num_visible = status, int(a.num_rendered), int(a.num_visible)
+        rec.radii = radii                       # (int32 [N]: > 0 = visible in this view; the compacted gradient exchange packs by it)
         rec.geom_ws, rec.bin_ws, rec.img_ws, rec.sizes, rec.capacity = geom_ws, bin_ws, img_ws, (gb, bb, ib), capacity
         rec.N, rec.H, rec.W, rec.flags, rec.settings_dev = N, H, W, flags, sdev
         return (out_color, out_depth, out_normal, out_alpha, radii, *out_extra)

@@ -30,6 +30,7 @@
  *   emd_densification_stats             <- add_densification_stats       S3Gaussian/scene/gaussian_model.py:728-730, train.py:403-406
  *   emd_adam_step                       <- optimizer.step()              S3Gaussian/scene/gaussian_model.py:188-201, train.py:428
  *   emd_sh_grad_from_factors            (multi-GPU: rebuilds the SH gradient from all-gathered rank-one factors; no reference counterpart)
+ *   emd_compact_rows / emd_scatter_rows (multi-GPU: visibility-compacted gradient rows for 2 / 4 ranks; no reference counterpart)
  *
  * Conventions
  *   - plain C, no C++ types, no exceptions across the ABI; every pointer is a DEVICE
@@ -362,6 +363,24 @@ int emd_sh_grad_from_factors(int32_t n, int32_t num_views, int32_t degree, int32
                              const EmdMotion* motion, int32_t pose_per_view, const float* campos /*[V,3]*/,
                              const float* sh_color_grads /*[V,N,3]*/, float scale, float* dL_dshs /*[N,sh_coeffs,3]*/,
                              void* hip_stream);
+
+/* Visibility-compacted rows for the view-parallel gradient exchange (ABI 25; no reference counterpart -- the
+ * reference trains one view per step on one GPU, S3Gaussian/train.py:203).  A view's gradient is zero for every Gaussian it does not see:
+ * a rank sends (index, values) rows of its visible Gaussians with an all-gather instead of all-reducing dense [N, .] tensors, and every
+ * rank adds the gathered rows into a dense buffer in rank order (a fixed order of float additions: replicas stay bit-identical).
+ *
+ * emd_compact_rows: rows is uint32 [(1 + capacity) * row_words], row_words = 1 + sum(widths).  rows[0 .. row_words) is the header
+ * (count of data rows, overflow flag: more visible Gaussians than capacity -- the surplus rows are dropped and the receiver must not
+ * trust the step -- then zeros); data row j = (Gaussian index, the widths[k] floats of sources[k][index] for k = 0 .. num_sources - 1) for
+ * the Gaussians with radii > 0, in no particular order.  counter: one device uint32 of scratch.
+ * emd_scatter_rows: one gathered view: for j < header.count: dests[k][index] = (add ? dests[k][index] : 0) + scale * value.  Indices are
+ * unique within a view (no atomics); launch the views one after the other.  overflow_out (optional device uint32) gets bit 0 set when the
+ * header carries the overflow flag. */
+#define EMD_ROW_SOURCES 4
+int emd_compact_rows(int32_t n, const int32_t* radii, int32_t num_sources, const float* const* sources, const int32_t* widths,
+                     int64_t capacity, uint32_t* rows, uint32_t* counter, void* hip_stream);
+int emd_scatter_rows(const uint32_t* rows, int64_t capacity, int32_t num_dst_rows, int32_t num_dests, float* const* dests,
+                     const int32_t* widths, int32_t add, float scale, uint32_t* overflow_out, void* hip_stream);
 
 /* Densification statistics of one view (the per-step part): for every Gaussian with radii > 0
  * grad_accum += |dL_dmeans2D.xy|, denom += 1, max_radii2D = max(max_radii2D, radii), in place -- gaussian_model.py:728-730 and

@@ -75,13 +75,18 @@ def test_bench_config4_two_ranks_agree_through_the_density_control_event():
     assert ev["iters_per_s_after"] > 0
 
 
-@pytest.mark.parametrize("ranks,mixed", [(2, False), (3, True)], ids=["2-ranks-one-timestamp", "3-ranks-mixed-timestamps"])
-def test_factored_sh_exchange_equals_dense_allreduce(ranks, mixed):
+@pytest.mark.parametrize("ranks,mixed,compact", [(2, False, False), (3, True, False), (2, False, True), (3, True, True)],
+                         ids=["2-ranks-one-timestamp", "3-ranks-mixed-timestamps", "2-ranks-compact-rows", "3-ranks-mixed-compact-rows"])
+def test_factored_sh_exchange_equals_dense_allreduce(ranks, mixed, compact):
     """The in-backward gradient exchange (SH factors + one slab) against the plain dense all-reduce; with three ranks on three
-    different timestamps the rebuild needs one gathered actor pose table per view (6 cameras on 8 GPUs, config 5)."""
+    different timestamps the rebuild needs one gathered actor pose table per view (6 cameras on 8 GPUs, config 5).  `compact`: the
+    visibility-compacted form (index + value rows of the visible Gaussians, added in rank order): same values, bit-identical replicas,
+    an undersized capacity reported."""
     env = dict(os.environ, EMD_BENCH_SHARE_GPU="1", EMD_DP_BACKEND="gloo")
     if mixed:
         env["EMD_DP_MIXED"] = "1"
+    if compact:
+        env["EMD_DP_COMPACT"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_factored_check.py")]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
