@@ -310,7 +310,8 @@ def main():
 
     factored = world > 1 or args.factored_sh or args.exchange_only
     # options of THIS run's rasterizer calls (an instance, handed to every call: nothing process-wide is written)
-    opts = RasterOptions(compute_normal=not args.no_normal, factored_sh_grad=factored, no_sync=not args.sync_count)
+    opts = RasterOptions(compute_normal=not args.no_normal, factored_sh_grad=factored, no_sync=not args.sync_count,
+                         aux_stream=bool(os.environ.get("EMD_BENCH_AUX")))          # (A/B knob: K1's colour half beside the binning stage)
     cams, campos_dev = {}, {}
     stats = None
     if args.densify_stats:
@@ -453,7 +454,7 @@ def main():
             gstate["rec"], gstate["campos"] = rec_g, blk[35:38]
             gstate["pose"] = None if o["actor_pose"] is None else o["actor_pose"].detach()
         try:
-            side = torch.cuda.Stream()
+            side = torch.cuda.Stream(priority=-1 if os.environ.get("EMD_BENCH_HIPRIO") else 0)      # (A/B knob: the captured chain above a forked branch)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for i_ in range(3):

@@ -213,7 +213,7 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_densify_decide", "emd_densify_index", "emd_densify_split_rank", "emd_densify_gather",
                     "emd_mlp_trunk_forward", "emd_mlp_trunk_backward", "emd_mlp_branch_forward", "emd_mlp_branch_backward",
                     "emd_abs_mean_backward", "emd_residual_l1_backward", "emd_tracked_pose_forward", "emd_tracked_pose_backward",
-                    "emd_select_step_inputs", "emd_compact_rows", "emd_scatter_rows")
+                    "emd_select_step_inputs", "emd_compact_rows", "emd_scatter_rows", "emd_l1_loss_ws")
 PROF_STAGES = 8
 
 _lib = None
@@ -257,6 +257,7 @@ def load():
     lib.emd_actor_pose_forward.argtypes = [C.c_int32] + [C.c_void_p] * 8
     lib.emd_actor_pose_backward.argtypes = [C.c_int32] + [C.c_void_p] * 10
     lib.emd_l1_loss.argtypes = [C.c_int64] + [C.c_void_p] * 5
+    lib.emd_l1_loss_ws.argtypes = [C.c_int64] + [C.c_void_p] * 6
     lib.emd_profile_enable.argtypes = [C.c_int]
     lib.emd_image_loss_workspace.argtypes = [C.c_int, C.c_int]
     lib.emd_image_loss_workspace.restype = C.c_size_t

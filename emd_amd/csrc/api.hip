@@ -144,7 +144,7 @@ int emd_launch_actor_pose_forward(int A, const float* q, const float* t, const u
                                   float* pose, const int32_t* frame_dev, hipStream_t st);
 int emd_launch_actor_pose_backward(int A, const float* q, const float* dt, const float* dq, const float* g_pose, float* d_q,
                                    float* d_t, float* d_dt, float* d_dq, const int32_t* frame_dev, hipStream_t st);
-int emd_launch_l1_loss(size_t n, const float* a, const float* b, float* loss, float* grad, hipStream_t st);
+int emd_launch_l1_loss(size_t n, const float* a, const float* b, float* loss, float* grad, uint32_t* scratch, hipStream_t st);
 int emd_launch_activations(int n, const float* ls, float* sc, const float* rq, float* q, const float* lo, float* o, hipStream_t st);
 int emd_launch_export_geometry(int N, const GeomWs& g, float* means2D, float* depths, float* conic_opacity, float* rgb,
                                float* normal, uint32_t* tiles_touched, hipStream_t st);
@@ -510,10 +510,15 @@ int emd_select_step_inputs(const EmdStepSelect* a, void* hip_stream) {
     return EMD_OK;
 }
 
-int emd_l1_loss(int64_t n, const float* a, const float* b, float* loss, float* grad, void* hip_stream) {
+int emd_l1_loss_ws(int64_t n, const float* a, const float* b, float* loss, float* grad, uint32_t* scratch, void* hip_stream) {
     if (n < 0 || !loss || (n > 0 && !a)) { emd_set_error("l1_loss: bad argument"); return EMD_ERR_INVALID; }
     if (((uintptr_t)a & 15) || ((uintptr_t)b & 15) || ((uintptr_t)grad & 15)) { emd_set_error("l1_loss: a, b, grad must be 16-byte aligned"); return EMD_ERR_INVALID; }
-    return emd_launch_l1_loss((size_t)n, a, b, loss, grad, (hipStream_t)hip_stream);
+    if ((uintptr_t)scratch & 7) { emd_set_error("l1_loss: scratch must be 8-byte aligned"); return EMD_ERR_INVALID; }
+    return emd_launch_l1_loss((size_t)n, a, b, loss, grad, scratch, (hipStream_t)hip_stream);
+}
+
+int emd_l1_loss(int64_t n, const float* a, const float* b, float* loss, float* grad, void* hip_stream) {
+    return emd_l1_loss_ws(n, a, b, loss, grad, nullptr, hip_stream);
 }
 
 int emd_abs_mean_backward(int64_t n, const float* x, const float* g, float* grad, void* hip_stream) {

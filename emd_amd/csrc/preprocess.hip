@@ -16,6 +16,46 @@
 
 #pragma clang fp contract(off)
 
+// Cache policy and traversal order (round 5; each a compile-time knob, A/B in profiles/r05_cache_policy_variants.txt).  A step moves ~2 GB
+// through a 256 MiB Infinity Cache; what decides the two projection kernels' time is which of it is still there when they ask:
+//   * streams that are touched once per step bypass the caches: the SH rows K1 reads (192 B per visible Gaussian, EMD_K1_NT_SH), the dense
+//     dL/dshs rows K8 writes (384 MB, EMD_K8_NT_SH), the colour Jacobian K1 leaves for K8 a whole step's traffic later (EMD_K1_NT_JAC);
+//   * K1 walks the Gaussians from the LAST block to the first (EMD_K1_REVERSE): the parameters K8 read last, at the end of the step
+//     before, are the ones K1 asks for first;
+//   * K8 takes the colour clamp bits from the Jacobian row it reads anyway (EMD_K8_BITS_IN_JAC) instead of fetching a 64-byte record for them.
+// Measured together on one box: K1 0.159 -> 0.121 ms, K8 0.229 -> 0.214 ms, 748 -> 782 it/s.  Not kept: nontemporal loads of the Jacobian in
+// K8 (+10 us there), nontemporal scalar stores of K8's small gradients (+8 us in K8 for -5 in K1).
+#ifndef EMD_K1_NT_SH
+#define EMD_K1_NT_SH 1
+#endif
+#ifndef EMD_K8_NT_SH
+#define EMD_K8_NT_SH 1
+#endif
+#ifndef EMD_K8_NT_ALL
+#define EMD_K8_NT_ALL 0          /* the small gradient outputs of K8 (means, scales, rotations, opacity, mean2D) */
+#endif
+#ifndef EMD_K8_NT_JAC
+#define EMD_K8_NT_JAC 0          /* K8's read of the colour Jacobian */
+#endif
+#ifndef EMD_K8_BITS_IN_JAC
+#define EMD_K8_BITS_IN_JAC 1     /* K8 takes the colour clamp bits from the Jacobian row (K1 stores them in its spare word) instead of fetching a 64-byte record for 4 bytes */
+#endif
+#ifndef EMD_K1_NT_JAC
+#define EMD_K1_NT_JAC 1          /* K1's store of the colour Jacobian (read once, by K8, a whole step's traffic later) */
+#endif
+#ifndef EMD_K1_REVERSE
+#define EMD_K1_REVERSE 1         /* K1 walks the Gaussians from the last block to the first: what K8 touched last is what K1 reads first */
+#endif
+typedef float emd_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_f(float* p, float v) { if (EMD_K8_NT_ALL) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ float4 load_f4_nt(const float4* p) {
+    const emd_v4f v = __builtin_nontemporal_load(reinterpret_cast<const emd_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_f4_nt(float4* p, float4 v) {
+    __builtin_nontemporal_store((emd_v4f){v.x, v.y, v.z, v.w}, reinterpret_cast<emd_v4f*>(p));
+}
+
 namespace {
 
 __device__ const float SH_C0 = 0.28209479177387814f;
@@ -267,7 +307,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
     EmdSettings S = a.s;
     emd_settings_from_device(S, a.sdev, a.flags);
     const bool sh_staged = a.shs && a.M == 16;
-    const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    const uint32_t blk = EMD_K1_REVERSE ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    const int i = blk * PRE_BLOCK + threadIdx.x;
     // the call's four status words are cleared here (the binning kernels behind this launch raise bits in them): no launch of its own
     if (PART != 2 && blockIdx.x == 0 && threadIdx.x < 4 && a.status) reinterpret_cast<uint32_t*>(a.status)[threadIdx.x] = 0u;
     uint32_t touched = 0, rect = 0, rect_h = 0, dkey = 0xFFFFFFFFu, skip = 0;
@@ -384,7 +425,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
         // rows of the VISIBLE Gaussians only, in two halves of 32 rows: coalesced dwordx4 pieces into LDS, then each lane of the half
         // takes its own row into registers
         const unsigned long long vmask = __ballot(vis);
-        const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12;
+        const size_t base4 = (size_t)blk * PRE_BLOCK * 12;
         const float4* src = (const float4*)a.shs;
         // Round 4: all twelve pieces of the wave's rows are requested at once -- both halves in flight together, one HBM round trip instead
         // of two -- and then staged half by half (48 registers more while they fly: four waves per SIMD instead of five; measured
@@ -396,7 +437,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
             for (int j = 0; j < 12; j++) {
                 const uint32_t idx = threadIdx.x + PRE_BLOCK * j, row = idx / 12;
                 pv[SH_ALL ? j : 0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((vmask >> row) & 1ull) pv[SH_ALL ? j : 0] = src[base4 + idx];
+                if ((vmask >> row) & 1ull) pv[SH_ALL ? j : 0] = EMD_K1_NT_SH ? load_f4_nt(src + base4 + idx) : src[base4 + idx];
             }
         }
 #pragma unroll
@@ -462,9 +503,16 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
             float J[9];
             sh_dir_jacobian(S.sh_degree, d, sh, J);
             float4* jr = a.g.shjac + (size_t)i * 3;
-            jr[0] = make_float4(J[0], J[1], J[2], 0.f);
-            jr[1] = make_float4(J[3], J[4], J[5], 0.f);
-            jr[2] = make_float4(J[6], J[7], J[8], 0.f);
+            // (the spare word of row 0 carries the clamp bits: the projection backward reads them here, with the Jacobian it needs anyway)
+            const float bw = __uint_as_float(bits);
+            if (EMD_K1_NT_JAC) {
+                store_f4_nt(jr, make_float4(J[0], J[1], J[2], bw)); store_f4_nt(jr + 1, make_float4(J[3], J[4], J[5], 0.f));
+                store_f4_nt(jr + 2, make_float4(J[6], J[7], J[8], 0.f));
+            } else {
+                jr[0] = make_float4(J[0], J[1], J[2], bw);
+                jr[1] = make_float4(J[3], J[4], J[5], 0.f);
+                jr[2] = make_float4(J[6], J[7], J[8], 0.f);
+            }
         }
         float4* rec = a.g.rec + (size_t)i * EMD_REC_F4;
         // the clamp bits of the colour ride in row 2 (with the colour they belong to), so that the two halves write disjoint rows
@@ -647,7 +695,8 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 gr[0] = z4; gr[1] = z4; gr[2] = z4;
             }
-            const uint32_t bits = __float_as_uint(a.g.rec[(size_t)i * EMD_REC_F4 + 2].w);
+            uint32_t bits = 0u;
+            if (!EMD_K8_BITS_IN_JAC) bits = __float_as_uint(a.g.rec[(size_t)i * EMD_REC_F4 + 2].w);   // (only the SH branch below reads them)
             gm2[0] = g0.x; gm2[1] = g0.y;
             if (a.flags & EMD_FLAG_ABSGRAD) { gabs[0] = g2.z; gabs[1] = g2.w; }
             g_depth = g0.z;
@@ -662,6 +711,10 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
                 float d0[3] = {m[0] - S.campos[0], m[1] - S.campos[1], m[2] - S.campos[2]};
                 float n = sqrtf((d0[0] * d0[0] + d0[1] * d0[1]) + d0[2] * d0[2]);
                 float d[3] = {d0[0] / n, d0[1] / n, d0[2] / n};
+                // d L / d dir = J^T gc with the 3x3 Jacobian K1 stored: no second pass over the 192 B of coefficients
+                const float4* jr = a.g.shjac + (size_t)i * 3;
+                const float4 j0 = EMD_K8_NT_JAC ? load_f4_nt(jr) : jr[0], j1 = EMD_K8_NT_JAC ? load_f4_nt(jr + 1) : jr[1], j2 = EMD_K8_NT_JAC ? load_f4_nt(jr + 2) : jr[2];
+                if (EMD_K8_BITS_IN_JAC) bits = __float_as_uint(j0.w);
                 float gc[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) gc[ch] = ((bits >> ch) & 1u) ? 0.f : gcol[ch];
@@ -670,9 +723,6 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
                 const int K = (deg + 1) * (deg + 1);
                 float bs[16];
                 sh_basis(deg, d, bs);
-                // d L / d dir = J^T gc with the 3x3 Jacobian K1 stored: no second pass over the 192 B of coefficients
-                const float4* jr = a.g.shjac + (size_t)i * 3;
-                const float4 j0 = jr[0], j1 = jr[1], j2 = jr[2];
                 float gd[3];
                 gd[0] = (j0.x * gc[0] + j1.x * gc[1]) + j2.x * gc[2];
                 gd[1] = (j0.y * gc[0] + j1.y * gc[1]) + j2.y * gc[2];
@@ -721,7 +771,10 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
 #pragma unroll
             for (int j = 0; j < 6; j++) {
                 const uint32_t idx = threadIdx.x + K8_BLOCK * j;
-                if (base4 + idx < lim4) out[base4 + idx] = s_sh[(idx / 12) * SH_ROW4 + (idx % 12)];
+                if (base4 + idx < lim4) {
+                    if (EMD_K8_NT_SH) store_f4_nt(out + base4 + idx, s_sh[(idx / 12) * SH_ROW4 + (idx % 12)]);
+                    else out[base4 + idx] = s_sh[(idx / 12) * SH_ROW4 + (idx % 12)];
+                }
             }
             __syncthreads();
         }
@@ -809,7 +862,7 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
                 if (raw) { ds[0] *= sc[0]; ds[1] *= sc[1]; ds[2] *= sc[2]; }   // d exp(x) = exp(x)
             }
         }
-        if (a.dL_dmeans2D) { a.dL_dmeans2D[3 * i] = gm2[0]; a.dL_dmeans2D[3 * i + 1] = gm2[1]; a.dL_dmeans2D[3 * i + 2] = 0.f; }
+        if (a.dL_dmeans2D) { st_f(a.dL_dmeans2D + 3 * i, gm2[0]); st_f(a.dL_dmeans2D + 3 * i + 1, gm2[1]); st_f(a.dL_dmeans2D + 3 * i + 2, 0.f); }
         if (a.dL_dmeans2D_abs) { a.dL_dmeans2D_abs[2 * i] = gabs[0]; a.dL_dmeans2D_abs[2 * i + 1] = gabs[1]; }
         if (a.dL_dsh_color) { a.dL_dsh_color[3 * i] = sh_gc[0]; a.dL_dsh_color[3 * i + 1] = sh_gc[1]; a.dL_dsh_color[3 * i + 2] = sh_gc[2]; }
         if (a.dL_dcolors) { a.dL_dcolors[3 * i] = gcol[0]; a.dL_dcolors[3 * i + 1] = gcol[1]; a.dL_dcolors[3 * i + 2] = gcol[2]; }
@@ -824,7 +877,7 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
 #pragma unroll
             for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * i + k] = dc6[k];
         }
-        if (a.dL_dscales) { a.dL_dscales[3 * i] = ds[0]; a.dL_dscales[3 * i + 1] = ds[1]; a.dL_dscales[3 * i + 2] = ds[2]; }
+        if (a.dL_dscales) { st_f(a.dL_dscales + 3 * i, ds[0]); st_f(a.dL_dscales + 3 * i + 1, ds[1]); st_f(a.dL_dscales + 3 * i + 2, ds[2]); }
         // (h) explicit motion
         float dl[3] = {dm[0], dm[1], dm[2]}, dql[4] = {dq[0], dq[1], dq[2], dq[3]}, dopl = dop;
         if (a_id >= 0)
@@ -834,13 +887,16 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
             const float o = sigmoidf_(a.opacities[i]);
             dopl *= o * (1.f - o);                                                 // through the sigmoid
         }
-        if (a.dL_dmeans3D) { a.dL_dmeans3D[3 * i] = dl[0]; a.dL_dmeans3D[3 * i + 1] = dl[1]; a.dL_dmeans3D[3 * i + 2] = dl[2]; }
+        if (a.dL_dmeans3D) { st_f(a.dL_dmeans3D + 3 * i, dl[0]); st_f(a.dL_dmeans3D + 3 * i + 1, dl[1]); st_f(a.dL_dmeans3D + 3 * i + 2, dl[2]); }
         if (a.dL_dresidual_dx) { a.dL_dresidual_dx[3 * i] = dl[0]; a.dL_dresidual_dx[3 * i + 1] = dl[1]; a.dL_dresidual_dx[3 * i + 2] = dl[2]; }
-        if (a.dL_drotations) *(float4*)(a.dL_drotations + 4 * i) = make_float4(dql[0], dql[1], dql[2], dql[3]);
+        if (a.dL_drotations) {
+            if (EMD_K8_NT_ALL) store_f4_nt((float4*)(a.dL_drotations + 4 * i), make_float4(dql[0], dql[1], dql[2], dql[3]));
+            else *(float4*)(a.dL_drotations + 4 * i) = make_float4(dql[0], dql[1], dql[2], dql[3]);
+        }
         if (a.dL_dresidual_dq) {
             *(float4*)(a.dL_dresidual_dq + 4 * i) = a_id >= 0 ? make_float4(dql[0], dql[1], dql[2], dql[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (a.dL_dopacities) a.dL_dopacities[i] = dopl;
+        if (a.dL_dopacities) st_f(a.dL_dopacities + i, dopl);
     }
     if ((a.flags & EMD_FLAG_MOTION) && a.dL_dactor_pose) reduce_pose_grad(a_id, pose_g, a.dL_dactor_pose);
 }
@@ -1120,8 +1176,14 @@ __global__ void k_actor_pose_backward(int A, const float* __restrict__ q_f, cons
 // sign(a - b) / n in one pass (the reference spends ~9 element-wise launches on it per step).
 // ---------------------------------------------------------------------------------------------------
 #define L1_THREADS 1024      // (the block count is capped by the same-address atomics below: wide blocks keep enough bytes in flight)
+// TICKET (round 5): the sum is formed in a caller-kept scratch pair (float accumulator, uint32 ticket; both zero between calls) instead of in
+// `loss` itself, so `loss` needs no zero fill in front of the kernel -- that fill was a launch of its own (4.6 us for 4 bytes in the replayed
+// step).  Every block adds its partial to the accumulator, waits for the returning atomic (the add has then been performed at the memory side),
+// draws a ticket; the block that draws the last one exchanges the accumulator for zero, writes the loss and clears the ticket.  Only
+// device-scope atomics on the two words: no fence, nothing another CU must see besides what the atomics themselves carry.
+template <bool TICKET>
 __global__ void __launch_bounds__(L1_THREADS) k_l1_loss(size_t n, const float* __restrict__ a, const float* __restrict__ b,
-                                                        float inv_n, float* __restrict__ loss, float* __restrict__ grad) {
+                                                        float inv_n, float* __restrict__ loss, float* __restrict__ grad, uint32_t* __restrict__ scratch) {
     __shared__ float s_part[L1_THREADS / 64];
     float acc = 0.f;
     const size_t n4 = n / 4, stride = (size_t)gridDim.x * L1_THREADS;
@@ -1146,7 +1208,16 @@ __global__ void __launch_bounds__(L1_THREADS) k_l1_loss(size_t n, const float* _
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < L1_THREADS / 64; w++) t += s_part[w];
-        atomicAdd(loss, t * inv_n);
+        if (!TICKET) { atomicAdd(loss, t * inv_n); return; }
+        float* acc_w = reinterpret_cast<float*>(scratch);
+        const float before = atomicAdd(acc_w, t * inv_n);                 // (returning form: the wait below covers it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t ticket = atomicAdd(scratch + 1, 1u + (__float_as_uint(before) & 0u));
+        if (ticket == gridDim.x - 1u) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            loss[0] = atomicExch(acc_w, 0.f);
+            atomicExch(scratch + 1, 0u);
+        }
     }
 }
 
@@ -1342,13 +1413,14 @@ int emd_launch_actor_pose_backward(int A, const float* q, const float* dt, const
     return EMD_OK;
 }
 
-int emd_launch_l1_loss(size_t n, const float* a, const float* b, float* loss, float* grad, hipStream_t st) {
-    { int zrc = emd_zero_async(loss, sizeof(float), st); if (zrc) return zrc; }
+int emd_launch_l1_loss(size_t n, const float* a, const float* b, float* loss, float* grad, uint32_t* scratch, hipStream_t st) {
+    if (!scratch || n == 0) { int zrc = emd_zero_async(loss, sizeof(float), st); if (zrc) return zrc; }
     if (n == 0) return EMD_OK;
     size_t blocks = (n / 4 + L1_THREADS - 1) / L1_THREADS;
     if (blocks > 512) blocks = 512;     // one same-address float atomic per block: 2048 of them serialised for ~20 us
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(k_l1_loss, dim3((unsigned)blocks), dim3(L1_THREADS), 0, st, n, a, b, 1.0f / (float)n, loss, grad);
+    if (scratch) hipLaunchKernelGGL((k_l1_loss<true>), dim3((unsigned)blocks), dim3(L1_THREADS), 0, st, n, a, b, 1.0f / (float)n, loss, grad, scratch);
+    else hipLaunchKernelGGL((k_l1_loss<false>), dim3((unsigned)blocks), dim3(L1_THREADS), 0, st, n, a, b, 1.0f / (float)n, loss, grad, scratch);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

@@ -348,6 +348,24 @@ def boundary_tensors(xyz, scaling, rotation, opacity, features, stage="coarse", 
                 shs=features)
 
 
+_l1_scratch = {}          # (device index, stream) -> the two scratch words of emd_l1_loss_ws (zero between calls)
+
+
+def _l1_call(n, a_ptr, b_ptr, loss, grad_ptr):
+    """emd_l1_loss_ws with the per-(device, stream) scratch pair: no zero-fill launch in front of the kernel.  The pair is created (zeroed)
+    outside of stream capture only -- a capture that meets a stream for the first time uses the plain entry point."""
+    import ctypes as C
+    from . import _lib as L
+    st = torch.cuda.current_stream()
+    key = (loss.device.index, st.cuda_stream)
+    sc = _l1_scratch.get(key)
+    if sc is None and not torch.cuda.is_current_stream_capturing():
+        while len(_l1_scratch) >= 16:
+            _l1_scratch.pop(next(iter(_l1_scratch)))
+        sc = _l1_scratch[key] = torch.zeros(2, dtype=torch.int32, device=loss.device)
+    L.check(L.load().emd_l1_loss_ws(n, a_ptr, b_ptr, loss.data_ptr(), grad_ptr, L.ptr(sc), C.c_void_p(st.cuda_stream)), "emd_l1_loss")
+
+
 class _L1Loss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -358,8 +376,7 @@ class _L1Loss(torch.autograd.Function):
         a, b = a.contiguous(), b.contiguous()
         loss = torch.empty(1, device=a.device, dtype=torch.float32)
         grad = torch.empty_like(a) if ctx.needs_input_grad[0] else None
-        L.check(L.load().emd_l1_loss(a.numel(), a.data_ptr(), b.data_ptr(), loss.data_ptr(), L.ptr(grad),
-                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_l1_loss")
+        _l1_call(a.numel(), a.data_ptr(), b.data_ptr(), loss, L.ptr(grad))
         ctx.save_for_backward(grad)
         return loss[0]
 
@@ -396,8 +413,7 @@ class _AbsMean(torch.autograd.Function):
             raise L.EmdError("abs_mean needs a tensor on a ROCm device; there is no CPU path")
         xc = x.detach().contiguous().float()
         out = torch.empty(1, device=x.device, dtype=torch.float32)
-        L.check(L.load().emd_l1_loss(xc.numel(), xc.data_ptr(), None, out.data_ptr(), None,
-                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_l1_loss")
+        _l1_call(xc.numel(), xc.data_ptr(), None, out, None)
         ctx.save_for_backward(xc)
         ctx.shape = x.shape
         return out[0]
@@ -436,9 +452,8 @@ class _ResidualPairL1(torch.autograd.Function):
             raise ValueError("residual_pair_l1: the two residuals must have one shape")
         a, b = xa.detach().contiguous().float(), xb.detach().contiguous().float()
         out = torch.empty(2, device=xa.device, dtype=torch.float32)
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        L.check(L.load().emd_l1_loss(a.numel(), a.data_ptr(), None, out.data_ptr(), None, st), "emd_l1_loss")
-        L.check(L.load().emd_l1_loss(b.numel(), b.data_ptr(), None, out[1:].data_ptr(), None, st), "emd_l1_loss")
+        _l1_call(a.numel(), a.data_ptr(), None, out, None)
+        _l1_call(b.numel(), b.data_ptr(), None, out[1:], None)
         ctx.save_for_backward(a, b)
         return a.view(xa.shape), b.view(xb.shape), out[0], out[1]
 

@@ -1,0 +1,9 @@
+#!/bin/bash
+# A/B of library builds inside ONE gpurun call (boxes differ by +-2.5 %): bash profiles/ab_variants.sh [bench flags --] NAME1 NAME2 ...
+# Each NAME is emd_amd/csrc/variants/lib_NAME.so (EMD_LIB_PATH selects the build); "base" is the in-tree library.  The list is run in the
+# order given; put "base" first and last to see the drift of the box.
+FLAGS="--steps 20 --warmup 5 --no-cpu-baseline"
+for v in "$@"; do
+  if [ "$v" != "base" ]; then export EMD_LIB_PATH=$PWD/emd_amd/csrc/variants/lib_$v.so; else unset EMD_LIB_PATH; fi
+  python3 bench.py $FLAGS 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value'],1), d['repeats_ms_per_step']['median'], {k:v['ms'] for k,v in d['roofline']['stages'].items()})"
+done
