@@ -35,12 +35,12 @@ PMC_STAGE_KERNELS = {"preprocess": ("k_preprocess",), "scan_duplicate": ("k_sort
                      "render_backward": ("k_render_backward_q",), "preprocess_backward": ("k_preprocess_backward",)}
 
 
-PMC_TRAFFIC_CSV = "r04_pmc_hbm_traffic.csv"
-PMC_VALU_CSV = "r04_pmc_valu.csv"
+PMC_TRAFFIC_CSV = "r05_pmc_hbm_traffic.csv"
+PMC_VALU_CSV = "r05_pmc_valu.csv"
 
 
 def _pmc_path(name):
-    for cand in (name, name.replace("r04_", "r03_"), name.replace("r04_", "r02_"), name.replace("r04_", "r01_")):
+    for cand in (name, name.replace("r05_", "r04_"), name.replace("r05_", "r03_"), name.replace("r05_", "r02_")):
         path = os.path.join(ROOT, "profiles", cand)
         if os.path.exists(path):
             return path

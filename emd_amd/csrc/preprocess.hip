@@ -24,7 +24,10 @@
 //     before, are the ones K1 asks for first;
 //   * K8 takes the colour clamp bits from the Jacobian row it reads anyway (EMD_K8_BITS_IN_JAC) instead of fetching a 64-byte record for them.
 // Measured together on one box: K1 0.159 -> 0.121 ms, K8 0.229 -> 0.214 ms, 748 -> 782 it/s.  Not kept: nontemporal loads of the Jacobian in
-// K8 (+10 us there), nontemporal scalar stores of K8's small gradients (+8 us in K8 for -5 in K1).
+// K8 (+10 us there), nontemporal scalar stores of K8's small gradients (+8 us in K8 for -5 in K1), nontemporal stores of the projected
+// records (K1 0.11 -> 0.19 ms: 48-byte pieces; and the render kernels do not care where the records come from: +2 us).
+//   * K8 compacts the visible Gaussians of a 256-block onto its first lanes (EMD_K8_COMPACT) and sends the five small gradients through
+//     the idle SH tile as whole 16-byte nontemporal stores (EMD_K8_STAGE_NT): K8 0.201 -> 0.193 ms, 799 -> 806 it/s.
 #ifndef EMD_K1_NT_SH
 #define EMD_K1_NT_SH 1
 #endif
@@ -33,6 +36,15 @@
 #endif
 #ifndef EMD_K8_NT_ALL
 #define EMD_K8_NT_ALL 0          /* the small gradient outputs of K8 (means, scales, rotations, opacity, mean2D) */
+#endif
+#ifndef EMD_K8_COMPACT
+#define EMD_K8_COMPACT 1         /* K8: the visible Gaussians of a 256-block are compacted onto its first lanes (full waves do the work, the others only write zero rows) */
+#endif
+#ifndef EMD_K8_STAGE_NT
+#define EMD_K8_STAGE_NT 1        /* the staged small gradients leave as nontemporal stores */
+#endif
+#ifndef EMD_K8_STAGE_SMALL
+#define EMD_K8_STAGE_SMALL 0     /* K8's five small gradients leave through LDS as whole 16-byte nontemporal stores */
 #endif
 #ifndef EMD_K8_NT_JAC
 #define EMD_K8_NT_JAC 0          /* K8's read of the colour Jacobian */
@@ -516,8 +528,13 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
         }
         float4* rec = a.g.rec + (size_t)i * EMD_REC_F4;
         // the clamp bits of the colour ride in row 2 (with the colour they belong to), so that the two halves write disjoint rows
+#ifdef EMD_K1_NT_REC          /* experiment: do the render kernels care whether the records are cache-resident? */
+        if (PART != 2) { store_f4_nt(rec, make_float4(ix, iy, p.tz, op)); store_f4_nt(rec + 1, make_float4(conA, conB, conC, 0.f)); }
+        if (PART != 1) store_f4_nt(rec + 2, make_float4(col[0], col[1], col[2], __uint_as_float(bits)));
+#else
         if (PART != 2) { rec[0] = make_float4(ix, iy, p.tz, op); rec[1] = make_float4(conA, conB, conC, 0.f); }
         if (PART != 1) rec[2] = make_float4(col[0], col[1], col[2], __uint_as_float(bits));
+#endif
         if (PART != 2 && (a.flags & EMD_FLAG_NORMAL)) {
             float nv[3] = {0.f, 0.f, 0.f};
             if (a.scales) {
@@ -648,8 +665,31 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
 #pragma unroll
     for (int k = 0; k < 16; k++) sh_b[k] = 0.f;
     const bool sh_staged = a.shs && a.M == 16;
+#if EMD_K8_COMPACT
+    // Round 5: 47 % of the Gaussians of a view are invisible, so a lane-per-Gaussian wave works with half of its lanes.  The visible Gaussians
+    // of the workgroup's 256 are compacted (in index order) onto its first lanes: ~2.1 full waves run the loads and the chain rule, the rest of
+    // the workgroup only writes the zero rows of the invisible ones ("natural" duties: thread t for Gaussian t of the block).
+    __shared__ uint32_t s_cscan[4];
+    __shared__ uint16_t s_list[K8_BLOCK];
+    const int inat = blockIdx.x * K8_BLOCK + threadIdx.x;
+    const bool nat_in = inat < a.N;
+    const bool nat_vis = nat_in && a.radii[inat] > 0;
+    uint32_t nv;
+    {
+        const uint32_t incl = block_scan_add_u32(nat_vis ? 1u : 0u, s_cscan, &nv);
+        if (nat_vis) s_list[incl - 1u] = (uint16_t)threadIdx.x;
+        __syncthreads();
+    }
+    const bool in_range = threadIdx.x < nv;                        // this thread carries a visible Gaussian
+    const int lrow = in_range ? (int)s_list[threadIdx.x] : 0;      // its row inside the block
+    const int i = blockIdx.x * K8_BLOCK + lrow;
+    const bool nat_zero = nat_in && !nat_vis;                      // this thread also owns the zero row of an invisible Gaussian
+#else
     const int i = blockIdx.x * K8_BLOCK + threadIdx.x;
     const bool in_range = i < a.N;
+    const int lrow = threadIdx.x, inat = i;
+    const bool nat_zero = false, nat_vis = true;
+#endif
     const float* V = S.viewmatrix;
     const float* P = S.projmatrix;
     const int W = S.image_width, H = S.image_height;
@@ -672,7 +712,7 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
     Proj p;
     p.tx = p.ty = p.tz = 0.f;
     if (in_range) {
-        visible = a.radii[i] > 0;
+        visible = EMD_K8_COMPACT ? true : a.radii[i] > 0;
         if (a.flags & EMD_FLAG_MOTION) {
             motion_point(i, a.means3D, a.rotations, a.opacities, a.motion, m, q, &op, raw);
             a_id = a.motion.actor_id ? a.motion.actor_id[i] : -1;
@@ -753,18 +793,26 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
             }
         }
     }
+    if (EMD_K8_COMPACT && nat_zero && a.dL_dshs && !sh_staged) {
+        float* o = a.dL_dshs + (size_t)inat * a.M * 3;
+        for (int k = 0; k < 3 * a.M; k++) o[k] = 0.f;
+    }
     if (sh_staged && a.dL_dshs) {
         const size_t lim4 = (size_t)a.N * 12;
         float4* out = (float4*)a.dL_dshs;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            if ((int)(threadIdx.x / K8_HALF) == h) {
+            if ((EMD_K8_COMPACT ? in_range : true) && (int)(lrow / K8_HALF) == h) {
                 float g48[48];
 #pragma unroll
                 for (int k = 0; k < 16; k++) { g48[3 * k] = sh_b[k] * sh_g[0]; g48[3 * k + 1] = sh_b[k] * sh_g[1]; g48[3 * k + 2] = sh_b[k] * sh_g[2]; }
 #pragma unroll
                 for (int j = 0; j < 12; j++)
-                    s_sh[(threadIdx.x % K8_HALF) * SH_ROW4 + j] = make_float4(g48[4 * j], g48[4 * j + 1], g48[4 * j + 2], g48[4 * j + 3]);
+                    s_sh[(lrow % K8_HALF) * SH_ROW4 + j] = make_float4(g48[4 * j], g48[4 * j + 1], g48[4 * j + 2], g48[4 * j + 3]);
+            }
+            if (EMD_K8_COMPACT && !nat_vis && (int)(threadIdx.x / K8_HALF) == h) {          // the zero row of an invisible (or absent) Gaussian
+#pragma unroll
+                for (int j = 0; j < 12; j++) s_sh[(threadIdx.x % K8_HALF) * SH_ROW4 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             __syncthreads();
             const size_t base4 = ((size_t)blockIdx.x * K8_BLOCK + K8_HALF * h) * 12;
@@ -780,6 +828,19 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
         }
     }
     // Part 2: the geometry chain and the remaining (small) stores
+#if EMD_K8_STAGE_SMALL || EMD_K8_COMPACT
+    // Round 5: the five small gradients every training step writes -- means3D [N,3], scales [N,3], rotations [N,4], opacities [N], means2D
+    // [N,3]: 56 bytes per Gaussian as fourteen dword stores at strides of 12 / 16 / 4 bytes -- leave through the (now idle) SH staging tile
+    // as whole 16-byte NONTEMPORAL stores: nothing reads them before the optimiser, and kept out of the Infinity Cache they stop evicting
+    // the parameters this kernel has just read and the next step's projection kernel asks for first.
+    // (compacted: the tile also is where the values of the compacted lanes and the zeros of the invisible Gaussians meet in index order)
+    const bool staged5 = a.dL_dmeans3D && a.dL_dscales && a.dL_drotations && a.dL_dopacities && a.dL_dmeans2D && !EMD_K8_NT_ALL &&
+                         (((uintptr_t)a.dL_dmeans3D | (uintptr_t)a.dL_dscales | (uintptr_t)a.dL_drotations | (uintptr_t)a.dL_dopacities |
+                           (uintptr_t)a.dL_dmeans2D) & 15) == 0 && (size_t)(blockIdx.x + 1) * K8_BLOCK <= (size_t)a.N;     // (uniform per workgroup; a ragged last block stores directly)
+    float o_dl[3] = {0.f, 0.f, 0.f}, o_ds[3] = {0.f, 0.f, 0.f}, o_dq[4] = {0.f, 0.f, 0.f, 0.f}, o_dop = 0.f;
+#else
+    const bool staged5 = false;
+#endif
     if (in_range) {
         if (visible) {
             // (a) conic -> cov2D, (b) cov2D -> Sigma and J, t
@@ -862,7 +923,7 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
                 if (raw) { ds[0] *= sc[0]; ds[1] *= sc[1]; ds[2] *= sc[2]; }   // d exp(x) = exp(x)
             }
         }
-        if (a.dL_dmeans2D) { st_f(a.dL_dmeans2D + 3 * i, gm2[0]); st_f(a.dL_dmeans2D + 3 * i + 1, gm2[1]); st_f(a.dL_dmeans2D + 3 * i + 2, 0.f); }
+        if (a.dL_dmeans2D && !staged5) { st_f(a.dL_dmeans2D + 3 * i, gm2[0]); st_f(a.dL_dmeans2D + 3 * i + 1, gm2[1]); st_f(a.dL_dmeans2D + 3 * i + 2, 0.f); }
         if (a.dL_dmeans2D_abs) { a.dL_dmeans2D_abs[2 * i] = gabs[0]; a.dL_dmeans2D_abs[2 * i + 1] = gabs[1]; }
         if (a.dL_dsh_color) { a.dL_dsh_color[3 * i] = sh_gc[0]; a.dL_dsh_color[3 * i + 1] = sh_gc[1]; a.dL_dsh_color[3 * i + 2] = sh_gc[2]; }
         if (a.dL_dcolors) { a.dL_dcolors[3 * i] = gcol[0]; a.dL_dcolors[3 * i + 1] = gcol[1]; a.dL_dcolors[3 * i + 2] = gcol[2]; }
@@ -877,7 +938,7 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
 #pragma unroll
             for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * i + k] = dc6[k];
         }
-        if (a.dL_dscales) { st_f(a.dL_dscales + 3 * i, ds[0]); st_f(a.dL_dscales + 3 * i + 1, ds[1]); st_f(a.dL_dscales + 3 * i + 2, ds[2]); }
+        if (a.dL_dscales && !staged5) { st_f(a.dL_dscales + 3 * i, ds[0]); st_f(a.dL_dscales + 3 * i + 1, ds[1]); st_f(a.dL_dscales + 3 * i + 2, ds[2]); }
         // (h) explicit motion
         float dl[3] = {dm[0], dm[1], dm[2]}, dql[4] = {dq[0], dq[1], dq[2], dq[3]}, dopl = dop;
         if (a_id >= 0)
@@ -887,17 +948,80 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
             const float o = sigmoidf_(a.opacities[i]);
             dopl *= o * (1.f - o);                                                 // through the sigmoid
         }
-        if (a.dL_dmeans3D) { st_f(a.dL_dmeans3D + 3 * i, dl[0]); st_f(a.dL_dmeans3D + 3 * i + 1, dl[1]); st_f(a.dL_dmeans3D + 3 * i + 2, dl[2]); }
+#if EMD_K8_STAGE_SMALL || EMD_K8_COMPACT
+        if (staged5) {
+            o_dl[0] = dl[0]; o_dl[1] = dl[1]; o_dl[2] = dl[2]; o_ds[0] = ds[0]; o_ds[1] = ds[1]; o_ds[2] = ds[2];
+            o_dq[0] = dql[0]; o_dq[1] = dql[1]; o_dq[2] = dql[2]; o_dq[3] = dql[3]; o_dop = dopl;
+        }
+#endif
+        if (a.dL_dmeans3D && !staged5) { st_f(a.dL_dmeans3D + 3 * i, dl[0]); st_f(a.dL_dmeans3D + 3 * i + 1, dl[1]); st_f(a.dL_dmeans3D + 3 * i + 2, dl[2]); }
         if (a.dL_dresidual_dx) { a.dL_dresidual_dx[3 * i] = dl[0]; a.dL_dresidual_dx[3 * i + 1] = dl[1]; a.dL_dresidual_dx[3 * i + 2] = dl[2]; }
-        if (a.dL_drotations) {
+        if (a.dL_drotations && !staged5) {
             if (EMD_K8_NT_ALL) store_f4_nt((float4*)(a.dL_drotations + 4 * i), make_float4(dql[0], dql[1], dql[2], dql[3]));
             else *(float4*)(a.dL_drotations + 4 * i) = make_float4(dql[0], dql[1], dql[2], dql[3]);
         }
         if (a.dL_dresidual_dq) {
             *(float4*)(a.dL_dresidual_dq + 4 * i) = a_id >= 0 ? make_float4(dql[0], dql[1], dql[2], dql[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (a.dL_dopacities) st_f(a.dL_dopacities + i, dopl);
+        if (a.dL_dopacities && !staged5) st_f(a.dL_dopacities + i, dopl);
     }
+#if EMD_K8_COMPACT
+    if (nat_zero) {
+        // the rows no compacted lane owns: zeros (the five main arrays only when they do not leave through the tile below)
+        const size_t z = (size_t)inat;
+        if (!staged5) {
+            if (a.dL_dmeans2D) { a.dL_dmeans2D[3 * z] = 0.f; a.dL_dmeans2D[3 * z + 1] = 0.f; a.dL_dmeans2D[3 * z + 2] = 0.f; }
+            if (a.dL_dscales) { a.dL_dscales[3 * z] = 0.f; a.dL_dscales[3 * z + 1] = 0.f; a.dL_dscales[3 * z + 2] = 0.f; }
+            if (a.dL_dmeans3D) { a.dL_dmeans3D[3 * z] = 0.f; a.dL_dmeans3D[3 * z + 1] = 0.f; a.dL_dmeans3D[3 * z + 2] = 0.f; }
+            if (a.dL_drotations) *(float4*)(a.dL_drotations + 4 * z) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.dL_dopacities) a.dL_dopacities[z] = 0.f;
+        }
+        if (a.dL_dmeans2D_abs) { a.dL_dmeans2D_abs[2 * z] = 0.f; a.dL_dmeans2D_abs[2 * z + 1] = 0.f; }
+        if (a.dL_dsh_color) { a.dL_dsh_color[3 * z] = 0.f; a.dL_dsh_color[3 * z + 1] = 0.f; a.dL_dsh_color[3 * z + 2] = 0.f; }
+        if (a.dL_dcolors) { a.dL_dcolors[3 * z] = 0.f; a.dL_dcolors[3 * z + 1] = 0.f; a.dL_dcolors[3 * z + 2] = 0.f; }
+        for (int k = 0; k < a.num_extra; k++)
+            if (a.dL_dextra[k]) { a.dL_dextra[k][3 * z] = 0.f; a.dL_dextra[k][3 * z + 1] = 0.f; a.dL_dextra[k][3 * z + 2] = 0.f; }
+        if (a.dL_dcov3D) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * z + k] = 0.f;
+        }
+        if (a.dL_dresidual_dx) { a.dL_dresidual_dx[3 * z] = 0.f; a.dL_dresidual_dx[3 * z + 1] = 0.f; a.dL_dresidual_dx[3 * z + 2] = 0.f; }
+        if (a.dL_dresidual_dq) *(float4*)(a.dL_dresidual_dq + 4 * z) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#endif
+#if EMD_K8_STAGE_SMALL || EMD_K8_COMPACT
+    if (staged5) {
+        // tile: [256 x 3 means3D | 256 x 3 scales | 256 x 4 rotations | 256 opacities | 256 x 3 means2D] floats = 14 KB of the 26 KB SH tile
+        float* sf = reinterpret_cast<float*>(s_sh);
+        const int t = threadIdx.x;
+        if (in_range) {
+            const int u = lrow;
+            sf[3 * u] = o_dl[0]; sf[3 * u + 1] = o_dl[1]; sf[3 * u + 2] = o_dl[2];
+            sf[768 + 3 * u] = o_ds[0]; sf[768 + 3 * u + 1] = o_ds[1]; sf[768 + 3 * u + 2] = o_ds[2];
+            *reinterpret_cast<float4*>(sf + 1536 + 4 * u) = make_float4(o_dq[0], o_dq[1], o_dq[2], o_dq[3]);
+            sf[2560 + u] = o_dop;
+            sf[2816 + 3 * u] = gm2[0]; sf[2816 + 3 * u + 1] = gm2[1]; sf[2816 + 3 * u + 2] = 0.f;
+        }
+        if (EMD_K8_COMPACT && !nat_vis) {
+            sf[3 * t] = 0.f; sf[3 * t + 1] = 0.f; sf[3 * t + 2] = 0.f;
+            sf[768 + 3 * t] = 0.f; sf[768 + 3 * t + 1] = 0.f; sf[768 + 3 * t + 2] = 0.f;
+            *reinterpret_cast<float4*>(sf + 1536 + 4 * t) = make_float4(0.f, 0.f, 0.f, 0.f);
+            sf[2560 + t] = 0.f;
+            sf[2816 + 3 * t] = 0.f; sf[2816 + 3 * t + 1] = 0.f; sf[2816 + 3 * t + 2] = 0.f;
+        }
+        __syncthreads();
+        const size_t b = (size_t)blockIdx.x * K8_BLOCK;
+        const float4* s4 = reinterpret_cast<const float4*>(sf);
+        auto st4 = [](float4* p, float4 v) { if (EMD_K8_STAGE_NT) store_f4_nt(p, v); else *p = v; };
+        if (t < 192) {
+            st4(reinterpret_cast<float4*>(a.dL_dmeans3D + 3 * b) + t, s4[t]);
+            st4(reinterpret_cast<float4*>(a.dL_dscales + 3 * b) + t, s4[192 + t]);
+            st4(reinterpret_cast<float4*>(a.dL_dmeans2D + 3 * b) + t, s4[704 + t]);
+        }
+        st4(reinterpret_cast<float4*>(a.dL_drotations + 4 * b) + t, s4[384 + t]);
+        if (t < 64) st4(reinterpret_cast<float4*>(a.dL_dopacities + b) + t, s4[640 + t]);
+    }
+#endif
     if ((a.flags & EMD_FLAG_MOTION) && a.dL_dactor_pose) reduce_pose_grad(a_id, pose_g, a.dL_dactor_pose);
 }
 
@@ -1176,11 +1300,13 @@ __global__ void k_actor_pose_backward(int A, const float* __restrict__ q_f, cons
 // sign(a - b) / n in one pass (the reference spends ~9 element-wise launches on it per step).
 // ---------------------------------------------------------------------------------------------------
 #define L1_THREADS 1024      // (the block count is capped by the same-address atomics below: wide blocks keep enough bytes in flight)
-// TICKET (round 5): the sum is formed in a caller-kept scratch pair (float accumulator, uint32 ticket; both zero between calls) instead of in
-// `loss` itself, so `loss` needs no zero fill in front of the kernel -- that fill was a launch of its own (4.6 us for 4 bytes in the replayed
-// step).  Every block adds its partial to the accumulator, waits for the returning atomic (the add has then been performed at the memory side),
-// draws a ticket; the block that draws the last one exchanges the accumulator for zero, writes the loss and clears the ticket.  Only
-// device-scope atomics on the two words: no fence, nothing another CU must see besides what the atomics themselves carry.
+// TICKET (round 5): `loss` needs no zero fill in front of the kernel -- that fill was a launch of its own (4.6 us for 4 bytes in the replayed
+// step).  Every workgroup publishes its partial sum as ONE aligned 8-byte {value, tag = 1} granule (a single device-scope store: no fence, no
+// wait -- MI355X_MICROARCH.md, "R2's granule needs no ordering at all") in a caller-kept scratch table that is zero between calls; workgroup 0
+// polls the table with device-scope loads, adds the partials in workgroup order (a deterministic sum, unlike the float atomics it replaces),
+// writes the loss and clears the tags for the next call.  Nobody but workgroup 0 waits for anything, so the scheme cannot deadlock however
+// few workgroups are resident.  (First built with a returning atomic add + a ticket per workgroup: two serialised memory round trips at the
+// end of EVERY workgroup made the kernel 5.8 us longer than the 4.6 us fill it replaced.)
 template <bool TICKET>
 __global__ void __launch_bounds__(L1_THREADS) k_l1_loss(size_t n, const float* __restrict__ a, const float* __restrict__ b,
                                                         float inv_n, float* __restrict__ loss, float* __restrict__ grad, uint32_t* __restrict__ scratch) {
@@ -1209,19 +1335,39 @@ __global__ void __launch_bounds__(L1_THREADS) k_l1_loss(size_t n, const float* _
 #pragma unroll
         for (int w = 0; w < L1_THREADS / 64; w++) t += s_part[w];
         if (!TICKET) { atomicAdd(loss, t * inv_n); return; }
-        float* acc_w = reinterpret_cast<float*>(scratch);
-        const float before = atomicAdd(acc_w, t * inv_n);                 // (returning form: the wait below covers it)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t ticket = atomicAdd(scratch + 1, 1u + (__float_as_uint(before) & 0u));
-        if (ticket == gridDim.x - 1u) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            loss[0] = atomicExch(acc_w, 0.f);
-            atomicExch(scratch + 1, 0u);
+        unsigned long long* tab = reinterpret_cast<unsigned long long*>(scratch);
+        const unsigned long long mine = ((unsigned long long)__float_as_uint(t * inv_n) << 32) | 1ull;
+        if (blockIdx.x != 0) __hip_atomic_store(tab + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else s_part[0] = t * inv_n;
+    }
+    if (TICKET && blockIdx.x == 0) {
+        __syncthreads();
+        // one poller per other workgroup (gridDim.x <= 512 <= L1_THREADS): spin on ITS granule, hand the value to thread 0 through LDS
+        unsigned long long* tab = reinterpret_cast<unsigned long long*>(scratch);
+        float v = threadIdx.x == 0 ? s_part[0] : 0.f;
+        if (threadIdx.x > 0 && threadIdx.x < gridDim.x) {
+            unsigned long long g = 0ull;
+            for (;;) {
+                g = __hip_atomic_load(tab + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (g & 1ull) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            v = __uint_as_float((uint32_t)(g >> 32));
+            __hip_atomic_store(tab + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the table is zero again for the next call
+        }
+        __syncthreads();                                      // (thread 0 has read s_part[0])
+        v = wave_reduce_to_lane63(v);                         // a fixed tree: the same sum for the same partials
+        if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < L1_THREADS / 64; w++) tot += s_part[w];
+            loss[0] = tot;
         }
     }
 }
 
-// gradient of w * mean |x| with the upstream gradient g on the DEVICE: out[i] = sign(x[i]) * g[0] / n -- one pass, no host read of g
 __global__ void __launch_bounds__(EMD_BLOCK) k_abs_mean_backward(size_t n, const float* __restrict__ x, const float* __restrict__ g, float inv_n,
                                                                  float* __restrict__ out) {
     const float s = g[0] * inv_n;

@@ -348,11 +348,11 @@ def boundary_tensors(xyz, scaling, rotation, opacity, features, stage="coarse", 
                 shs=features)
 
 
-_l1_scratch = {}          # (device index, stream) -> the two scratch words of emd_l1_loss_ws (zero between calls)
+_l1_scratch = {}          # (device index, stream) -> the scratch table of emd_l1_loss_ws (zero between calls)
 
 
 def _l1_call(n, a_ptr, b_ptr, loss, grad_ptr):
-    """emd_l1_loss_ws with the per-(device, stream) scratch pair: no zero-fill launch in front of the kernel.  The pair is created (zeroed)
+    """emd_l1_loss_ws with the per-(device, stream) scratch table: no zero-fill launch in front of the kernel.  The table is created (zeroed)
     outside of stream capture only -- a capture that meets a stream for the first time uses the plain entry point."""
     import ctypes as C
     from . import _lib as L
@@ -362,7 +362,7 @@ def _l1_call(n, a_ptr, b_ptr, loss, grad_ptr):
     if sc is None and not torch.cuda.is_current_stream_capturing():
         while len(_l1_scratch) >= 16:
             _l1_scratch.pop(next(iter(_l1_scratch)))
-        sc = _l1_scratch[key] = torch.zeros(2, dtype=torch.int32, device=loss.device)
+        sc = _l1_scratch[key] = torch.zeros(1024, dtype=torch.int32, device=loss.device)       # EMD_L1_SCRATCH_WORDS
     L.check(L.load().emd_l1_loss_ws(n, a_ptr, b_ptr, loss.data_ptr(), grad_ptr, L.ptr(sc), C.c_void_p(st.cuda_stream)), "emd_l1_loss")
 
 

@@ -405,10 +405,12 @@ int emd_actor_pose_backward(int32_t num_actors, const float* q_f, const float* d
  * b == NULL: loss[0] = mean |a| -- the residual regularisers of the fine stage (the L1 norms of dx / do / dshs, S3Gaussian/train.py);
  * emd_abs_mean_backward writes their gradient sign(x[i]) * g[0] / n with the upstream gradient g read on the device. */
 int emd_l1_loss(int64_t n, const float* a, const float* b, float* loss /*[1]*/, float* grad /*[n] or NULL*/, void* hip_stream);
-/* ABI 25.  The same with a caller-kept scratch pair (two 4-byte words, 8-byte aligned, ZERO at the first call and left zero by every call;
- * used by one stream at a time): the sum is formed there and `loss` is written once, by the last workgroup to finish -- no zero fill of
- * `loss` in front of the kernel (a launch of its own: 4.6 us of a 1.3 ms step).  scratch == NULL is emd_l1_loss. */
-int emd_l1_loss_ws(int64_t n, const float* a, const float* b, float* loss /*[1]*/, float* grad /*[n] or NULL*/, uint32_t* scratch /*[2]*/,
+/* ABI 25.  The same with a caller-kept scratch table (EMD_L1_SCRATCH_WORDS 4-byte words, 8-byte aligned, ZERO at the first call and left zero by
+ * every call; used by one stream at a time): every workgroup publishes its partial sum there as one 8-byte {value, tag} granule, workgroup 0
+ * adds them in workgroup order and writes `loss` -- no zero fill of `loss` in front of the kernel (a launch of its own: 4.6 us of a 1.3 ms
+ * step), and a sum that does not depend on the order of float atomics.  scratch == NULL is emd_l1_loss. */
+#define EMD_L1_SCRATCH_WORDS 1024
+int emd_l1_loss_ws(int64_t n, const float* a, const float* b, float* loss /*[1]*/, float* grad /*[n] or NULL*/, uint32_t* scratch /*[EMD_L1_SCRATCH_WORDS]*/,
                    void* hip_stream);
 int emd_abs_mean_backward(int64_t n, const float* x, const float* g /*[1], device*/, float* grad /*[n]*/, void* hip_stream);
 /* ABI 20.  The backward of a PAIR of regularised residuals that also feed the renderer (dshs_coarse / dshs_fine of the fine stage,

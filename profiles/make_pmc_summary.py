@@ -1,7 +1,7 @@
 """Condense two rocprofv3 counter passes into profiles/rNN_pmc_hbm_traffic.csv.
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d DIR -o fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d DIR -o write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d DIR -o fetch -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --eager --settle-ms 0 --repeats 0
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d DIR -o write -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --eager --settle-ms 0 --repeats 0
     python profiles/make_pmc_summary.py DIR > profiles/rNN_pmc_hbm_traffic.csv
 
 FETCH_SIZE / WRITE_SIZE are KiB per dispatch.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of
@@ -33,8 +33,7 @@ def load(path):
 
 def main(d):
     f, w = load(f"{d}/fetch_counter_collection.csv"), load(f"{d}/write_counter_collection.csv")
-    print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) -- python3 bench.py --steps 5 "
-          "--warmup 1 --no-cpu-baseline")
+    print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --eager --settle-ms 0 --repeats 0")
     print("# KiB per dispatch averaged over dispatches, in MB.  fetch_MB_x2 = gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md);")
     print("# WRITE_SIZE is exact for 16 B/lane stores and float atomics.  Infinity-Cache hits are counted: fabric traffic, an upper bound on HBM.")
     print("# k_radix_*[N]: passes of the Gaussian depth sort (grid over N), [D]: passes of the tile sort (grid over the duplicate capacity).")

@@ -1,6 +1,6 @@
 """Condense two rocprofv3 SQ counter passes into profiles/rNN_pmc_valu.csv.
 
-    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d DIR -o sq1 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d DIR -o sq1 -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --eager --settle-ms 0 --repeats 0
     rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d DIR -o sq2 -- (same)
     python profiles/make_valu_summary.py DIR > profiles/r02_pmc_valu.csv
 
@@ -38,7 +38,7 @@ def main(d):
             rows.setdefault(k, {}).update({c: sum(v) / len(v) for c, v in acc[k].items()})
     cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "dur_us", "valu_util"]
     print("# rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES / SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR")
-    print("# (two passes) -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline; wave-level instruction counts per dispatch, averaged over dispatches.")
+    print("# (two passes) -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --eager --settle-ms 0 --repeats 0; wave-level instruction counts per dispatch, averaged over dispatches.")
     print("# dur_us = duration of the same dispatches (kernel trace of the counter run); valu_util = SQ_INSTS_VALU x 1.32 ns / (1024 SIMDs x dur):")
     print("# every instruction priced as a plain fp32 VALU instruction at its MEASURED issue time with 8 waves resident (2.35 cycles at the 1.78 GHz the")
     print("# chip holds under that load, profiles/r02_issue_rate_microbench.txt) -- a LOWER bound: v_pk_*, DPP and v_readlane take 2.0 ns, transcendentals 3.4 ns.")
