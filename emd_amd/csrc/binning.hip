@@ -38,6 +38,13 @@
 #include "device_utils.h"
 #include "footprint.h"       // (EMD_ID_BITS: the quadrant mask rides above the 28-bit Gaussian id of a list word)
 
+// EMD_BIN_CARRY (round 5, measured and NOT kept; the code stays as the record of the experiment): the 8-byte binning records travel through the
+// depth passes as a second value instead of being gathered in depth order afterwards.  The gather kernel shrinks from 22 to 6 us, every one
+// of the three depth scatters grows by 7 us (16 KB more LDS per block, 8 more bytes per element each way): 798 against 803 it/s on one box.
+#ifndef EMD_BIN_CARRY
+#define EMD_BIN_CARRY 0
+#endif
+
 namespace {
 
 // number of elements of a radix pass: a launch-time constant (first pass of the Gaussian depth sort), or a device-side count
@@ -61,6 +68,10 @@ __device__ __forceinline__ uint32_t sort_n(const SortN& c) {
 // (Round 4, measured and dropped: this gather inside the last depth pass's scatter kernel, with the block sums as one float... integer
 //  atomic per (wave, output block) -- 117 k single-lane atomic instructions at ~117 clocks each on the CU's memory path made that pass
 //  78 us instead of 18; as its own launch with 4900 independent workgroups the gather takes 20.)
+// CARRIED (round 5): the records arrive in depth order already -- the depth passes carry them as a second value (the first pass reads them in
+// index order, coalesced) -- so the gather (150 MB of fabric traffic for 8.5 MB of records, 22 us) is gone and this kernel only adds up the
+// pairs of every block of 256 and clears the tile ranges.
+template <bool CARRIED>
 __global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32_t* __restrict__ num_sorted,
                                                              const uint32_t* __restrict__ perm,
                                                              const uint2* __restrict__ binrec,
@@ -70,8 +81,8 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sorted_counts(int N, const uint32
     __shared__ uint32_t s_scan[4];
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
     uint2 br = make_uint2(0u, 0u);
-    if (i < N && (uint32_t)i < *num_sorted) br = binrec[perm[i]];         // the depth sort kept the V visible Gaussians only
-    if (i < N) bin_s[i] = br;
+    if (i < N && (uint32_t)i < *num_sorted) br = CARRIED ? bin_s[i] : binrec[perm[i]];         // the depth sort kept the V visible Gaussians only
+    if (!CARRIED && i < N) bin_s[i] = br;
     // empty tiles keep the range (0, 0): cleared here instead of by a separate memset launch
     for (uint32_t r = (uint32_t)i; r < n_ranges; r += gridDim.x * EMD_BLOCK) ranges[r] = 0u;
     uint32_t total;
@@ -274,13 +285,15 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scan_bins(uint32_t* __restr
     }
 }
 
-template <int BITS, bool FIRST>
+// CARRY: a second, 8-byte value travels with every pair (the binning record of the Gaussian; FIRST: read at the element's own index).
+template <int BITS, bool FIRST, bool CARRY = false>
 __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                              const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out,
                                                              uint32_t* __restrict__ vals_out, SortN cnt, int shift,
                                                              uint32_t mask, uint32_t offset, uint32_t nblocks_cap,
-                                                             const uint32_t* __restrict__ hist_inc, uint32_t* __restrict__ count_out) {
+                                                             const uint32_t* __restrict__ hist_inc, uint32_t* __restrict__ count_out,
+                                                             const uint2* __restrict__ carry_in, uint2* __restrict__ carry_out) {
     // wave w of the block owns the contiguous slice [w*512, (w+1)*512) of the block's 2048 keys and walks it in
     // 8 rounds of 64 consecutive keys: order inside the block = (wave, round, lane) = memory order => stable.
     constexpr int BINS = 1 << BITS, PER = BINS / EMD_BLOCK;
@@ -288,6 +301,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __r
     __shared__ uint32_t s_gbase[BINS];
     __shared__ uint32_t s_keys[EMD_SORT_TILE];
     __shared__ uint32_t s_vals[EMD_SORT_TILE];
+    __shared__ uint2 s_carry[CARRY ? EMD_SORT_TILE : 1];
     __shared__ uint32_t s_scan[4];
     const uint32_t D = sort_n(cnt);
     const uint32_t nblocks = (D + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
@@ -302,6 +316,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __r
     uint32_t key[EMD_SORT_ITEMS];
     uint32_t val[EMD_SORT_ITEMS];
     uint32_t rank[EMD_SORT_ITEMS];
+    uint2 car[CARRY ? EMD_SORT_ITEMS : 1];
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // all loads of the block first (keys, values, the digit rows of the scanned histogram further down): one round trip, not three
 #pragma unroll
@@ -309,6 +324,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __r
         const size_t idx = wbase + (size_t)k * 64 + lane;
         key[k] = idx < D ? keys_in[idx] : 0xFFFFFFFFu;
         val[k] = FIRST ? (uint32_t)idx : (idx < D ? vals_in[idx] : 0u);
+        if (CARRY) car[k] = idx < D ? carry_in[idx] : make_uint2(0u, 0u);
     }
     uint32_t h_before[PER], h_tot[PER];
 #pragma unroll
@@ -383,6 +399,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __r
             const uint32_t pos = s_cnt[wave][digit] + rank[k];
             s_keys[pos] = key[k];
             s_vals[pos] = val[k];
+            if (CARRY) s_carry[pos] = car[k];
             nvalid_w++;
         }
     }
@@ -396,6 +413,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scatter(const uint32_t* __r
             const size_t dst = (size_t)s_gbase[((kk - offset) >> shift) & mask] + pos;
             keys_out[dst] = kk;
             vals_out[dst] = s_vals[pos];
+            if (CARRY) carry_out[dst] = s_carry[pos];
         }
     }
 }
@@ -474,7 +492,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_export_keys(size_t D, const uint3
 template <int BITS, bool FIRST>
 int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, SortN cnt, size_t n_cap, int shift,
                int bits, uint32_t offset, uint32_t* hist, bool skip_hist, int range_bits, uint32_t* overflow_word, uint32_t* count_out,
-               hipStream_t st) {
+               hipStream_t st, const uint2* carry_in = nullptr, uint2* carry_out = nullptr) {
     const uint32_t nsb = (uint32_t)((n_cap + EMD_SORT_TILE - 1) / EMD_SORT_TILE);
     const uint32_t mask = (1u << bits) - 1u;
     if (!skip_hist) {
@@ -484,8 +502,10 @@ int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_
     }
     hipLaunchKernelGGL(k_radix_scan_bins, dim3(1u << BITS), dim3(EMD_BLOCK), 0, st, hist, nsb);
     EMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_radix_scatter<BITS, FIRST>), dim3(nsb), dim3(EMD_BLOCK), 0, st, kin, vin, kout, vout, cnt, shift, mask, offset, nsb, hist,
-                       count_out);
+    if (carry_in) hipLaunchKernelGGL((k_radix_scatter<BITS, FIRST, true>), dim3(nsb), dim3(EMD_BLOCK), 0, st, kin, vin, kout, vout, cnt, shift, mask, offset, nsb,
+                                     hist, count_out, carry_in, carry_out);
+    else hipLaunchKernelGGL((k_radix_scatter<BITS, FIRST, false>), dim3(nsb), dim3(EMD_BLOCK), 0, st, kin, vin, kout, vout, cnt, shift, mask, offset, nsb, hist,
+                            count_out, carry_in, carry_out);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }
@@ -517,18 +537,23 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
         uint32_t near_bits = 0;
         if (!wide) { const float np = s.near_plane > 0.f ? s.near_plane : 0.f; memcpy(&near_bits, &np, 4); }
         uint32_t* ovf = &status->overflow;
+        // the binning records travel with the pairs (EMD_BIN_CARRY): pass p writes them to cb[p & 1], chosen so that the last pass lands in bin_s
+        uint2* const cb[2] = {(depth_passes & 1) ? g.bin_s : g.bin_t, (depth_passes & 1) ? g.bin_t : g.bin_s};
+        const bool carry = EMD_BIN_CARRY != 0;
         if (wide) {
-            rc = radix_pass<8, true>(g.depth_key, nullptr, g.gkeys[0], g.gvals[0], c0, (size_t)N, 0, 8, 0u, g.ghist, false, 32, ovf, sort_count, st);
+            rc = radix_pass<8, true>(g.depth_key, nullptr, g.gkeys[0], g.gvals[0], c0, (size_t)N, 0, 8, 0u, g.ghist, false, 32, ovf, sort_count, st,
+                                     carry ? g.binrec : nullptr, cb[0]);
             for (int p = 1; p < depth_passes && !rc; p++)
                 rc = radix_pass<8, false>(g.gkeys[(p - 1) & 1], g.gvals[(p - 1) & 1], g.gkeys[p & 1], g.gvals[p & 1], cv, (size_t)N, 8 * p, 8, 0u,
-                                          g.ghist, false, 32, ovf, nullptr, st);
+                                          g.ghist, false, 32, ovf, nullptr, st, carry ? cb[(p - 1) & 1] : nullptr, cb[p & 1]);
         } else {
             const int B = EMD_DEPTH_BITS_NARROW;
             rc = radix_pass<EMD_DEPTH_BITS_NARROW, true>(g.depth_key, nullptr, g.gkeys[0], g.gvals[0], c0, (size_t)N, 0, B, near_bits, g.ghist, false,
-                                                         EMD_DEPTH_RANGE_NARROW, ovf, sort_count, st);
+                                                         EMD_DEPTH_RANGE_NARROW, ovf, sort_count, st, carry ? g.binrec : nullptr, cb[0]);
             for (int p = 1; p < depth_passes && !rc; p++)
                 rc = radix_pass<EMD_DEPTH_BITS_NARROW, false>(g.gkeys[(p - 1) & 1], g.gvals[(p - 1) & 1], g.gkeys[p & 1], g.gvals[p & 1], cv, (size_t)N,
-                                                              B * p, B, near_bits, g.ghist, false, 32, ovf, nullptr, st);
+                                                              B * p, B, near_bits, g.ghist, false, 32, ovf, nullptr, st,
+                                                              carry ? cb[(p - 1) & 1] : nullptr, cb[p & 1]);
         }
         if (rc) return rc;
     }
@@ -537,8 +562,10 @@ int emd_launch_binning(const EmdSettings& s, int flags, int N, const GeomWs& g, 
     //    writes their (tile, Gaussian | quadrant mask) pairs; workgroup 0 publishes D / overflow / V
     emd_prof_switch(PROF_SORT, PROF_DUPLICATE, st);
     const int passes = emd_tile_passes(T), bits = emd_tile_pass_bits(T);
-    hipLaunchKernelGGL(k_sorted_counts, dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.bin_s, g.block_sums, b.ranges,
-                       (uint32_t)(2 * T));
+    if (EMD_BIN_CARRY) hipLaunchKernelGGL((k_sorted_counts<true>), dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.bin_s, g.block_sums, b.ranges,
+                                          (uint32_t)(2 * T));
+    else hipLaunchKernelGGL((k_sorted_counts<false>), dim3(nb), dim3(EMD_BLOCK), 0, st, N, sort_count, perm, g.binrec, g.bin_s, g.block_sums, b.ranges,
+                            (uint32_t)(2 * T));
     EMD_LAUNCH_CHECK();
     if (capacity <= 0) {    // D and V are still reported (capacity 0 is how callers size the workspace)
         hipLaunchKernelGGL(k_duplicate, dim3(1), dim3(EMD_BLOCK), 0, st, N, gx, g.bin_s, perm, g.block_sums, (uint64_t)0, status, b.tkeys[0], b.vals[0],

@@ -33,6 +33,7 @@ struct GeomWs {
     uint32_t* gkeys[2];      // [N] ping-pong of the Gaussian depth sort
     uint32_t* gvals[2];      // [N] Gaussian ids in depth order after the sort (gvals[1])
     uint2* bin_s;            // [N] the same records in depth order
+    uint2* bin_t;            // [N] ping-pong partner of bin_s: the records travel through the depth passes as a second value (round 5)
     uint32_t* ghist;         // radix histograms of the depth sort [bins][ceil(N / sort tile)]
     uint32_t* sort_count;    // [1] visible Gaussians V: published by the first depth pass (which compacts), read by the later ones
     uint32_t* block_sums;    // [ceil(N/256)] pairs emitted per block of 256 depth-ordered Gaussians (added up by the last depth pass)
@@ -99,6 +100,7 @@ static inline void emd_carve_geom(void* base, int N, GeomWs* w) {
     for (int i = 0; i < 2; i++) { w->gkeys[i] = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256); }
     for (int i = 0; i < 2; i++) { w->gvals[i] = (uint32_t*)(p + off); off = emd_align_up(off + n * 4, 256); }
     w->bin_s = (uint2*)(p + off); off = emd_align_up(off + n * 8, 256);
+    w->bin_t = (uint2*)(p + off); off = emd_align_up(off + n * 8, 256);
     size_t nsb = (n + EMD_SORT_TILE - 1) / EMD_SORT_TILE;
     w->ghist = (uint32_t*)(p + off); off = emd_align_up(off + nsb * EMD_DEPTH_BINS_MAX * 4, 256);
     w->sort_count = (uint32_t*)(p + off); off = emd_align_up(off + 16, 256);

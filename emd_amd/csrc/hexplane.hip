@@ -260,6 +260,11 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_time_tables(EmdHexArgs a
         }
 }
 
+#ifndef HEX_NT
+#define HEX_NT 1          /* round 5: the [N, 128] feature / gradient streams bypass the caches, the planes stay (fine-stage step 13.87 -> 13.72 ms; the same hint on the
+                             MLP kernels' tile loads costs 1.1 ms: 16-byte pieces of rows) */
+#endif
+typedef float hex_v4f __attribute__((ext_vector_type(4)));
 template <int C>
 __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsigned chunks) {
     constexpr int LPP = C / 4, GROUPS = EMD_BLOCK / LPP;
@@ -334,7 +339,11 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
                 prod.z = prod.z * (nw.z * w.x + ne.z * w.y + sw.z * w.z + se.z * w.w);
                 prod.w = prod.w * (nw.w * w.x + ne.w * w.y + sw.w * w.z + se.w * w.w);
             }
+#if HEX_NT
+            __builtin_nontemporal_store((hex_v4f){prod.x, prod.y, prod.z, prod.w}, reinterpret_cast<hex_v4f*>(a.out + ((size_t)s_n[j] * (S * C) + s * C + c4)));
+#else
             *(float4*)(a.out + ((size_t)s_n[j] * (S * C) + s * C + c4)) = prod;
+#endif
         }
         __syncthreads();
     }
@@ -499,7 +508,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         auto gather = [&](int it) {
             n = s_n[wave * PER_WAVE + it * GW + gw];
             if (n >= 0) {
-                go = g.dL_dout[(size_t)n * (S * C) + s * C + c];
+                go = HEX_NT ? __builtin_nontemporal_load(g.dL_dout + ((size_t)n * (S * C) + s * C + c)) : g.dL_dout[(size_t)n * (S * C) + s * C + c];
 #pragma unroll
                 for (int p = 0; p < 6; p++) {
                     const uint4 A = s_a[sb + ((it >> 1) & 1) * SROWS + (it & 1) * GW * 6 + gw * 6 + p];

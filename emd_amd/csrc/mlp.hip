@@ -78,6 +78,20 @@ __device__ __forceinline__ f32x16 mask16(f32x16 g, f32x16 y) {
 // of the wave time): the forward kernels gain 12-15 % from the straight form; the backward kernels, whose schedule is ruled by
 // register pressure, lose as much, so they keep the branch (both measured).
 // `width` (a multiple of 4): columns >= width do not exist and read as 0 (the last tile of a narrow xa)
+// A/B knob (round 5): the [N, 64..128] activation / gradient streams of these kernels are each far larger than the 256 MiB Infinity Cache and
+// are touched once or twice per step; nontemporal accesses keep them from evicting what IS reused (the HexPlane planes, the weights).
+#ifndef MLP_NT
+#define MLP_NT 0
+#endif
+typedef float mlp_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float* p) {
+    if (MLP_NT) { const mlp_v4f v = __builtin_nontemporal_load(reinterpret_cast<const mlp_v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    return *(const float4*)p;
+}
+__device__ __forceinline__ void st4(float* p, float4 v) {
+    if (MLP_NT) __builtin_nontemporal_store((mlp_v4f){v.x, v.y, v.z, v.w}, reinterpret_cast<mlp_v4f*>(p));
+    else *(float4*)p = v;
+}
 template <bool STRAIGHT = false>
 __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ src, size_t ld, size_t row, bool ok, int c0, int hh, int width = 1 << 30) {
     f32x16 t;
@@ -87,7 +101,7 @@ __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ src, size_
         for (int a = 0; a < 4; a++) {
             const int c = c0 + 8 * a + 4 * hh;
             const bool in = c < width;
-            const float4 q = *(const float4*)(p + (in ? c : 0));
+            const float4 q = ld4(p + (in ? c : 0));
             const float keep = (ok && in) ? 1.f : 0.f;
             t[4 * a] = q.x * keep; t[4 * a + 1] = q.y * keep; t[4 * a + 2] = q.z * keep; t[4 * a + 3] = q.w * keep;
         }
@@ -96,7 +110,7 @@ __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ src, size_
         for (int a = 0; a < 4; a++) {
             const int c = c0 + 8 * a + 4 * hh;
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && c < width) q = *(const float4*)(src + row * ld + c);
+            if (ok && c < width) q = ld4(src + row * ld + c);
             t[4 * a] = q.x; t[4 * a + 1] = q.y; t[4 * a + 2] = q.z; t[4 * a + 3] = q.w;
         }
     }
@@ -117,7 +131,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, size_t ld, s
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         const int c = c0 + 8 * a + 4 * hh;
-        if (c < width) *(float4*)(dst + row * ld + c) = make_float4(t[4 * a], t[4 * a + 1], t[4 * a + 2], t[4 * a + 3]);
+        if (c < width) st4(dst + row * ld + c, make_float4(t[4 * a], t[4 * a + 1], t[4 * a + 2], t[4 * a + 3]));
     }
 }
 __device__ __forceinline__ void store_tile_narrow(float* __restrict__ dst, int width, size_t row, bool ok, int c0, int hh, f32x16 t) {
