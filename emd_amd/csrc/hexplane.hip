@@ -156,7 +156,15 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_bwd(EmdHexArgs a, EmdHex
             if (c == 0) {
                 if (k < 3) { if (g.dL_dpts) g.dL_dpts[3 * n + k] = v * (2.f / (a.aabb[3 + k] - a.aabb[k])); }
                 else if (g.dL_dtimes) g.dL_dtimes[n] = v;
-                else if (g.dL_dtime_sum) atomicAdd(g.dL_dtime_sum, v);
+            }
+            // one broadcast timestamp: its gradient is the sum over ALL points -- summed over the wave first (the points' channel-0 lanes
+            // hold the per-point values), one atomic per wave instead of one same-address atomic per point (2 M serialised atomics)
+            if (k == 3 && !g.dL_dtimes && g.dL_dtime_sum) {
+                if (__ballot(true) == ~0ull) {                        // (every lane of the wave carries a point: all but the last wave of the grid)
+                    float w = c == 0 ? v : 0.f;
+                    for (int off = 32; off; off >>= 1) w += __shfl_xor(w, off);
+                    if ((threadIdx.x & 63) == 0) atomicAdd(g.dL_dtime_sum, w);
+                } else if (c == 0) atomicAdd(g.dL_dtime_sum, v);
             }
         }
     }

@@ -403,6 +403,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
                     float bx = __builtin_sqrtf(thr * p.a) * 1.0001f + 0.01f, by = __builtin_sqrtf(thr * p.c) * 1.0001f + 0.01f;
                     const bool never = !(op >= (1.f / 255.f));                            // cannot reach 1/255 anywhere (also NaN)
                     if (!(bx == bx) || !(by == by)) bx = by = 3.0e38f;                    // (NaN covariance entries: keep everything)
+                    //  the render kernels evaluate alpha with the float conic adj(cov) / fl(det), whose relative error is
+                    // ~1.2e-7 a c / det: for needle footprints (a c > 3e4 det -- hundreds of pixels long, under a pixel wide) the 1 % + 0.05
+                    // margin above no longer covers it, so such a Gaussian keeps upstream's rectangle and all four quadrants, exactly as
+                    // footprint.h refuses to cull it (`e.all`)
+                    if (!(p.det * 3.0e4f > p.a * p.c)) bx = by = 3.0e38f;
                     const float QMAX = 2047.f;
                     const float lqxf = floorf(ceilf(ix - bx) * 0.125f), hqxf = floorf(floorf(ix + bx) * 0.125f);
                     const float lqyf = floorf(ceilf(iy - by) * 0.125f), hqyf = floorf(floorf(iy + by) * 0.125f);

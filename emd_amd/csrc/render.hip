@@ -150,10 +150,12 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
     float4 px_[NX ? NX : 1];
 #pragma unroll
     for (int k = 0; k < (NX ? NX : 1); k++) px_[k] = zero4;
-    // Which entries of the tile list reach THIS quadrant was decided when the list was built: the duplicate kernel (binning.hip) runs the
-    // exact ellipse-rectangle test of footprint.h once per (tile, Gaussian) pair and leaves the four quadrant bits in the top bits of the
-    // list word.  The scan here reads 4 bytes per entry and fetches the 64-byte record of the survivors only (one step ahead; the list
-    // words two steps ahead).
+    // Which entries of the tile list can reach THIS quadrant was decided when the list was built: the duplicate kernel (binning.hip) derives the
+    // four quadrant bits of a (tile, Gaussian) pair from the alpha >= 1/255 BOUNDING BOX the projection kernel left as four skip bits per
+    // Gaussian (the exact ellipse-rectangle test of footprint.h per pair was measured there and dropped: its inputs are a 32-byte gather per
+    // Gaussian) and leaves them in the top bits of the list word -- a looser mask than the ellipse test; the exact test runs below, on the
+    // queued entries against the 4 x 4 sub-blocks.  The scan here reads 4 bytes per entry and fetches the 64-byte record of the entries whose
+    // bit is set only (one step ahead; the list words two steps ahead).
     const uint32_t qbit = 1u << (EMD_ID_BITS + quad);
     uint32_t w_nxt = 0, pgid = 0;
     bool pkeep = false;

@@ -56,6 +56,7 @@ class _HexLookup(torch.autograd.Function):
         out = torch.empty(N, S * Cc, device=pts.device, dtype=torch.float32)
         a.out = out.data_ptr()
         L.check(lib.emd_hexplane_forward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emd_hexplane_forward")
+        a.time_tables, a.out = None, None         # (forward-only pointers: `tables` and `out` are not kept alive by ctx, the backward reads neither)
         ctx.args, ctx.keep = a, (pts_c, times_c, cl, order, plane_orders)
         ctx.shapes = [tuple(p.shape) for p in planes]
         ctx.times_shape = tuple(times.shape)
@@ -245,7 +246,11 @@ class HexPlaneField(nn.Module):
         planes = [p for gp in self.grids for p in gp]
         t = timestamps.reshape(-1, 1)
         if t.shape[0] == pts.shape[0] and t.shape[0] > 1 and t.stride(0) == 0:
-            t = t[:1]         # one timestamp broadcast over the points (emd_amd.model.render, Deformation.forward_time_offset): its base, [1, 1]
+            # one timestamp broadcast over the points (emd_amd.model.render, Deformation.forward_time_offset).  The lookup takes the [1, 1] tensor
+            # that was expanded, not a slice of the expansion: slicing inside autograd makes the backward materialise an [N, 1] zero column, scatter
+            # the scalar into row 0 and sum N values again -- the column the in-kernel sum (dL_dtime_sum) exists to avoid
+            base = getattr(timestamps, "_base", None)
+            t = base if (base is not None and tuple(base.shape) == (1, 1) and base.dtype == t.dtype) else t[:1]
         return _HexLookup.apply(pts, t, self._aabb_host(), self._res, self._visiting_order(pts), *planes)
 
     def _visiting_order(self, pts):

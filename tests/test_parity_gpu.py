@@ -421,6 +421,32 @@ def test_baseline_config0_exact_size_10k_static_256():
     compare_backward(hip, orc)
 
 
+def test_long_diagonal_needles_keep_upstreams_rectangle():
+    """footprints more than 500 px long and under a pixel wide, on the diagonal.  The projection kernel cuts the rectangle it hands
+    to the binning down to the alpha >= 1/255 box computed from the exact 2-D covariance, while the render kernels evaluate alpha with the float
+    conic adj(cov) / fl(det): for a c / det above ~3e4 the box's margin no longer covers that rounding, so such a Gaussian must keep
+    upstream's rectangle and all quadrant bits (as csrc/footprint.h refuses to cull it).  Every dropped pair / cleared quadrant bit is checked
+    against the brute-force evaluation of the render loop's own skip test; images bit for bit in both list modes."""
+    case = make_case(n=600, H=512, W=768, seed=91)
+    g = torch.Generator().manual_seed(11)
+    n = case["N"]
+    case["scales"][: n // 2] = torch.tensor([30.0, 0.0015, 0.0015])       # needles: hundreds of pixels long at every depth of the scene
+    case["scales"][n // 2:] = torch.tensor([8.0, 0.004, 0.004])
+    q = torch.randn(n, 4, generator=g)
+    case["rotations"] = q / q.norm(dim=1, keepdim=True)
+    case["opacities"][:] = 0.9
+    orc = run_oracle(case, backward=False)
+    hip = run_hip(case, backward=False)
+    compare_forward(hip, orc, tol=IMAGE_TOL)
+    assert int(orc["pre"]["radii"].max()) > 500, int(orc["pre"]["radii"].max())
+    st = hip["cull_stats"]
+    assert st["contributing"] <= st["kept"] <= st["D"], st
+    full = run_hip(case, backward=False, keep_all_pairs=True)
+    compare_forward(full, orc, tol=IMAGE_TOL)
+    for k in ("color", "depth", "alpha", "normal"):
+        np.testing.assert_array_equal(full[k], hip[k], err_msg=k)
+
+
 def test_elongated_and_faint_footprints_are_not_overculled():
     """The footprint test of the duplicate stage decides which (tile, Gaussian) pairs exist and which quadrants the render forward
     visits (csrc/footprint.h).  Needles hundreds of pixels long and a pixel wide -- where det = A C - B^2 cancels and the test must
