@@ -92,3 +92,30 @@ def test_bench_view_mapping_gives_every_rank_a_distinct_view():
                 assert len({f for f, _ in views}) == 1
     v8 = [dp.frame_and_camera(0, r, 8, 50, 6) for r in range(8)]
     assert v8 == [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (1, 0), (1, 1)]
+
+
+def test_compact_exchange_is_chosen_by_bytes_per_link():
+    """dp.compact_pays: bytes ONE xGMI link carries per step, dense (2 x 44 N / W + 12 N) against compact (64 B x capacity); at the bench
+    scene's visibility (V / N = 0.53, capacity with its margins ~0.6 N) that means rows at 2 ranks, the dense slab at 4 and 8."""
+    from emd_amd import dp
+    N = 2_000_000
+    cap = dp.visible_capacity(int(0.53 * N * 1.15))
+    assert cap % 1024 == 0 and 0.6 * N < cap < 0.7 * N
+    assert dp.compact_pays(2, N, cap) and not dp.compact_pays(4, N, cap) and not dp.compact_pays(8, N, cap)
+    assert not dp.compact_pays(1, N, cap)
+    assert dp.compact_pays(4, N, int(0.3 * N)) and not dp.compact_pays(2, N, N)          # few visible: rows even at 4 ranks; all visible: never
+
+
+def test_bench_decides_about_ranks_before_touching_a_gpu():
+    """`python bench.py --gpus N` (N > 1) without torchrun starts its own ranks as a child process -- or, on a node with fewer GPUs, says so and
+    exits; a WORLD_SIZE that contradicts --gpus is refused.  Both decisions are taken before any GPU call: they work on this GPU-less box."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EMD_BENCH_SHARE_GPU")}
+    if __import__("torch").cuda.device_count() < 3:
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3"], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 2 and "--gpus 3 but this node shows" in p.stderr and not p.stdout.strip()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
