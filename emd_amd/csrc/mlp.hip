@@ -83,6 +83,9 @@ __device__ __forceinline__ f32x16 mask16(f32x16 g, f32x16 y) {
 #ifndef MLP_NT
 #define MLP_NT 0
 #endif
+#ifndef MLP_NARROW_OUT
+#define MLP_NARROW_OUT 1      /* output layers of <= 4 features run on the vector pipe instead of a padded 32-row MFMA tile (forward) */
+#endif
 typedef float mlp_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld4(const float* p) {
     if (MLP_NT) { const mlp_v4f v = __builtin_nontemporal_load(reinterpret_cast<const mlp_v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
@@ -498,6 +501,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
     const bool wide_out = (a.out_dim & 3) == 0;
+    const bool narrow_out = a.out_dim <= 4;
     float l1_acc = 0.f;
     const size_t tile0 = (size_t)blockIdx.x * MLP_WAVES + wave, tstep = (size_t)gridDim.x * MLP_WAVES;
     // the next tile's rows are loaded while this tile computes: one wave per SIMD has nothing else to hide the HBM latency behind
@@ -518,6 +522,39 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
             f32x16 m2[2] = {bias_tile(lds + L::b2, 0, hh), bias_tile(lds + L::b2, 32, hh)};
             layer_fwd<2, 2>(m2, m, lds + L::w2, WS, 0, r, hh);
             m[0] = relu16(m2[0]); m[1] = relu16(m2[1]);
+        }
+        if constexpr (MLP_NARROW_OUT && NTO == 1 && !L::SP) {
+            // Round 5: an output layer of at most four features (dx: 3, do: 1) on the VECTOR pipe.  As an MFMA tile it is padded to 32 output rows --
+            // 32 of the kernel's 96 MFMAs per 32-row tile for 3 or 1 useful rows -- while the contraction itself is 64 multiply-adds per output and
+            // row: a lane holds 32 of its row's 64 activations (the two lane halves hold the two feature halves), so it forms 4 x 32 products
+            // against weight rows read as broadcast ds_read_b128 and the halves meet in one cross-lane add.  (Summation order differs from the MFMA's
+            // k-ordered chain: fp32 rounding only.)
+            if (narrow_out) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int f0 = 32 * t + 8 * c + 4 * hh;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const float4 w = *(const float4*)(lds + L::wo + q * WS + f0);           // (rows >= out_dim of the staged matrix are zero)
+                            acc[q] = fmaf(w.x, m[t][4 * c], acc[q]); acc[q] = fmaf(w.y, m[t][4 * c + 1], acc[q]);
+                            acc[q] = fmaf(w.z, m[t][4 * c + 2], acc[q]); acc[q] = fmaf(w.w, m[t][4 * c + 3], acc[q]);
+                        }
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[q] = acc[q] + __shfl_xor(acc[q], 32) + lds[L::bo + q];
+                if (hh == 0 && ok) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (q < a.out_dim) {
+                            a.out[row * (size_t)a.out_dim + q] = acc[q];
+                            if (L1 && a.l1_sum) l1_acc += fabsf(acc[q]);
+                        }
+                }
+                continue;
+            }
         }
         f32x16 o[NTO];
 #pragma unroll
