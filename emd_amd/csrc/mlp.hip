@@ -195,7 +195,9 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&acc)[NT], const f32x16 (&in)[
 // rows (profiles/r04_mlp_split_variants.txt) -- the split costs 176 vector instructions per 32 x 32 tile, which a kernel with few MFMAs per
 // tile (the forward of the narrow heads) does not earn back.
 #ifndef MLP_SP_F11
-#define MLP_SP_F11 0          /* forward, one output tile (dx / do / feat heads) */
+#define MLP_SP_F11 1          /* forward, one output tile (dx / do / feat heads); round 5: 1 -- with the narrow output layer on the vector pipe the hidden
+                                 layer is what is left on the matrix pipe, and there the split wins (fine stage 13.61 -> 13.46 ms; 0 before: the split cost more
+                                 than it saved while a third of the MFMAs were a padded output tile) */
 #endif
 #ifndef MLP_SP_F12
 #define MLP_SP_F12 1          /* forward, two output tiles (the dshs head) */
@@ -474,7 +476,9 @@ __device__ __forceinline__ void branch_stage(float* lds, const EmdMlpBranch& a) 
             stage_split(lds + L::wot, 2, 2 * NTO, a.w_out, 64, 0, a.out_dim, 64, true);
         }
         stage_split(lds + L::w1, 2, 4, a.w_hidden[0], 64, 0, 64, 64, false);
-        stage_split(lds + L::wo, NTO, 4, a.w_out, 64, 0, a.out_dim, 64, false);
+        // (a narrow output layer runs on the vector pipe in the forward and reads plain fp32 rows: they fit the image's allocation)
+        if (!BWD && MLP_NARROW_OUT && NTO == 1 && a.out_dim <= 4) stage_matrix(lds + L::wo, WS, 32, 64, a.w_out, 64, 0, a.out_dim, 64);
+        else stage_split(lds + L::wo, NTO, 4, a.w_out, 64, 0, a.out_dim, 64, false);
     } else {
         if (BWD) {
             stage_matrix_t(lds + L::w1t, WS, 64, 64, a.w_hidden[0], 64, 0, 64, 64);
@@ -523,7 +527,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
             layer_fwd<2, 2>(m2, m, lds + L::w2, WS, 0, r, hh);
             m[0] = relu16(m2[0]); m[1] = relu16(m2[1]);
         }
-        if constexpr (MLP_NARROW_OUT && NTO == 1 && !L::SP) {
+        if constexpr (MLP_NARROW_OUT && NTO == 1) {
             // Round 5: an output layer of at most four features (dx: 3, do: 1) on the VECTOR pipe.  As an MFMA tile it is padded to 32 output rows --
             // 32 of the kernel's 96 MFMAs per 32-row tile for 3 or 1 useful rows -- while the contraction itself is 64 multiply-adds per output and
             // row: a lane holds 32 of its row's 64 activations (the two lane halves hold the two feature halves), so it forms 4 x 32 products
