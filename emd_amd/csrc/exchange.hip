@@ -88,7 +88,7 @@ extern "C" int emd_compact_rows(int32_t n, const int32_t* radii, int32_t num_sou
         s.p[k] = k < num_sources ? sources[k] : nullptr;
         s.d[k] = nullptr;
         s.w[k] = k < num_sources ? widths[k] : 0;
-        if (k < num_sources && (!sources[k] || widths[k] < 1 || widths[k] > 16)) { emd_set_error("compact_rows: source %d: null or width outside 1..16", k); return EMD_ERR_INVALID; }
+        if (k < num_sources && ((!sources[k] && n > 0) || widths[k] < 1 || widths[k] > 16)) { emd_set_error("compact_rows: source %d: null or width outside 1..16", k); return EMD_ERR_INVALID; }
         row_words += s.w[k];
     }
     if (row_words < 2) { emd_set_error("compact_rows: empty rows"); return EMD_ERR_INVALID; }
@@ -117,10 +117,10 @@ extern "C" int emd_scatter_rows(const uint32_t* rows, int64_t capacity, int32_t 
         s.p[k] = nullptr;
         s.d[k] = k < num_dests ? dests[k] : nullptr;
         s.w[k] = k < num_dests ? widths[k] : 0;
-        if (k < num_dests && (!dests[k] || widths[k] < 1 || widths[k] > 16)) { emd_set_error("scatter_rows: destination %d: null or width outside 1..16", k); return EMD_ERR_INVALID; }
+        if (k < num_dests && ((!dests[k] && num_dst_rows > 0) || widths[k] < 1 || widths[k] > 16)) { emd_set_error("scatter_rows: destination %d: null or width outside 1..16", k); return EMD_ERR_INVALID; }
         row_words += s.w[k];
     }
-    if (capacity == 0) return EMD_OK;
+    if (capacity == 0 || num_dst_rows == 0) return EMD_OK;
     hipStream_t st = (hipStream_t)hip_stream;
     const unsigned nb = (unsigned)((capacity + EMD_BLOCK - 1) / EMD_BLOCK);
     if (add) hipLaunchKernelGGL((k_scatter_rows<true>), dim3(nb < 8192u ? nb : 8192u), dim3(EMD_BLOCK), 0, st, rows, row_words, (uint32_t)capacity, (uint32_t)num_dst_rows, s, scale, overflow_out);

@@ -166,7 +166,8 @@ def compact_rows(radii, sources, capacity, out=None, counter=None):
     if radii.device.type != "cuda":
         raise L.EmdError("compact_rows needs tensors on a ROCm device; there is no CPU path")
     N = radii.shape[0]
-    srcs = [t.detach().reshape(N, -1) for t in sources]
+    width = lambda t: 1 if t.dim() < 2 else int(torch.tensor(t.shape[1:]).prod())
+    srcs = [t.detach().reshape(N, width(t)) for t in sources]
     for t in srcs:
         assert t.dtype == torch.float32 and t.is_contiguous(), "compact_rows: contiguous float32 sources"
     widths = [int(t.shape[1]) for t in srcs]
@@ -186,7 +187,7 @@ def scatter_rows(rows, dests, add, scale=1.0, overflow=None):
     import ctypes as C
     from . import _lib as L
     N = dests[0].shape[0]
-    ds = [t.view(N, -1) for t in dests]
+    ds = [t.view(N, 1 if t.dim() < 2 else int(torch.tensor(t.shape[1:]).prod())) for t in dests]
     for t in ds:
         assert t.dtype == torch.float32 and t.is_contiguous(), "scatter_rows: contiguous float32 destinations"
     widths = [int(t.shape[1]) for t in ds]
