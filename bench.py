@@ -319,8 +319,16 @@ def main():
     S = {"params": params, "stats": stats, "N": N}          # what a density-control event replaces (config 4)
 
     # the form of the multi-GPU exchange (set once the visible counts of the run's views are known, below): dense until then
-    X = {"cap": None, "compact": False, "overflow": torch.zeros(1, dtype=torch.int32, device=dev)}
-    xkw = lambda: dict(compact=X["compact"], compact_capacity=X["cap"], overflow=X["overflow"])
+    X = {"cap": None, "cap_by_row": None, "compact": False, "overflow": torch.zeros(1, dtype=torch.int32, device=dev)}
+
+    def xkw(step=None):
+        """Options of one step's GradientExchange: the row capacity of the compacted form is per STEP (the visible count moves between 0.6 and 1.5 M over
+        the clip; rows are padded to the capacity, so a clip-wide maximum would give the saving away)."""
+        cap = X["cap"]
+        if step is not None and X["cap_by_row"] is not None:
+            per = args.warmup + args.steps
+            cap = X["cap_by_row"][step if step < per else args.warmup + (step - args.warmup) % max(args.steps, 1)]
+        return dict(compact=X["compact"], compact_capacity=cap, overflow=X["overflow"])
 
     def cam_for(step):
         # views are ordered timestamp-major and dealt out by dp.view_for: every rank renders a DISTINCT (frame, camera);
@@ -345,7 +353,7 @@ def main():
             # SH gradient (81 % of the gradient bytes): rank-one factors, 12 B per Gaussian and rank instead of all-reducing
             # 192 B per Gaussian; the collectives are issued from inside backward(), right behind K8 (emd_amd/dp.py)
             xchg = dp.GradientExchange(campos_dev[(f, c)], actor_ids=model.actor_id if model.has_actors else None,
-                                       residual_dx=None if residual is None else residual[0].detach(), **xkw())
+                                       residual_dx=None if residual is None else residual[0].detach(), **xkw(step))
             rec.on_backward = xchg.start
             rec.on_sh_factor = xchg.start_factors        # (the factor gathers run under K8; needs the actor poses of this step: set below)
         out = render(model, cam, bg, frame=f, iteration=step, options=options, record=rec, residual=residual)
@@ -374,12 +382,15 @@ def main():
     out = one_step(0, sync_opts, backward=not cfg["forward_only"])
     st0 = out["raster_call"].last_status()
     dmax, vmax = st0["num_rendered"], st0["num_visible"]
+    v_by_row = {}
+    every = 1 if (world > 1 or args.exchange == "compact") else 7          # (the compacted exchange wants every view's visible count)
     with torch.no_grad():
-        for s_ in sorted(set(list(range(0, args.warmup + args.steps, 7)) + [args.warmup + args.steps - 1])):
+        for s_ in sorted(set(list(range(0, args.warmup + args.steps, every)) + [args.warmup + args.steps - 1])):
             f, c, cam = cam_for(s_)
             o = render(model, cam, bg, frame=f, options=sync_opts, residual=residual)
             st_ = o["raster_call"].last_status()
             dmax, vmax = max(dmax, st_["num_rendered"]), max(vmax, st_["num_visible"])
+            v_by_row[s_] = st_["num_visible"]
     opts.capacity_hint = int(dmax * 1.3) + 1024          # (an option of this run's calls: nothing process-wide is written)
     # rows per view of the visibility-compacted exchange: the same number on every rank (MAX over the ranks' views + margin); dp.compact_pays
     # then decides per world size whether the rows or the dense slab move fewer bytes per link
@@ -387,14 +398,24 @@ def main():
         v_all = torch.tensor([vmax], device=dev, dtype=torch.int64)
         if world > 1:
             torch.distributed.all_reduce(v_all, op=torch.distributed.ReduceOp.MAX)
-        X["cap"] = dp.visible_capacity(int(v_all) * 1.15)          # (sampled every 7th view: a wider margin than the default)
+        X["cap"] = dp.visible_capacity(int(v_all))
+        # per step: the largest visible count among the ranks' views of THAT step (a table gathered once, here; every rank uses the same numbers)
+        rows_n = args.warmup + args.steps
+        v_tab = torch.tensor([v_by_row.get(r_, vmax) for r_ in range(rows_n)], device=dev, dtype=torch.int64)
+        if world > 1:
+            torch.distributed.all_reduce(v_tab, op=torch.distributed.ReduceOp.MAX)
+        X["cap_by_row"] = [dp.visible_capacity(int(v_)) for v_ in v_tab.tolist()]
         X["compact"] = {"auto": None, "dense": False, "compact": True}[args.exchange]
-        X["uses_rows"] = bool(X["compact"]) or (X["compact"] is None and dp.compact_pays(world, N, X["cap"]))
+        mean_cap = sum(X["cap_by_row"][args.warmup:]) / max(len(X["cap_by_row"][args.warmup:]), 1)
+        if X["compact"] is None:          # one decision for the run, by the timed steps' mean capacity (dp.compact_pays: bytes per xGMI link)
+            X["compact"] = bool(dp.compact_pays(world, N, mean_cap))
+        X["uses_rows"] = bool(X["compact"])
+        X["mean_cap"] = mean_cap
 
     if cfg["forward_only"]:
         return bench_forward_only(args, cfg, scene, model, render, cam_for, bg, opts, _lib, N, H, W, rank)
     if args.exchange_only:
-        return bench_exchange_only(args, dp, model, params, one_step, cam_for, campos_dev, N, rank, world, dev)
+        return bench_exchange_only(args, dp, model, params, one_step, cam_for, campos_dev, N, rank, world, dev, xkw, X)
 
     # ---- the step as a hipGraph: the launches of a step are captured once and replayed; everything that changes from
     # step to step (camera block, frame index, frame time, coarse-to-fine level of the step) lives at fixed device addresses that
@@ -573,7 +594,7 @@ def main():
                 # slab all-reduce behind the second; one graph (--one-graph): the whole exchange behind the replay
                 gs = G.gstate
                 xchg = dp.GradientExchange(gs["campos"], actor_ids=model.actor_id if model.has_actors else None, actor_pose=gs["pose"],
-                                           residual_dx=None if residual is None else residual[0].detach(), **xkw())
+                                           residual_dx=None if residual is None else residual[0].detach(), **xkw(step))
                 if G.graph_b is not None:
                     xchg.start_factors(gs["rec"])
                     G.graph_b.replay()
@@ -828,13 +849,13 @@ def main():
                        "parallelism": f"view-parallel dp{world}", "count_readback": bool(args.sync_count),
                        "gradient_exchange": ("none (1 GPU)" if world == 1 else
                                              ("visibility-compacted rows (dp.compact_pays: fewer bytes per xGMI link at this world size): all-gather of (index, 3 floats) "
-                                              f"factor rows and (index, 11 floats) slab rows of each view's visible Gaussians, {X['cap']} rows per view, added in rank "
+                                              f"factor rows and (index, 11 floats) slab rows of each view's visible Gaussians, {int(X.get('mean_cap') or 0)} rows per view on average (a capacity per step), added in rank "
                                               "order on every rank; + camera centres, per-view actor pose tables; dense SH average rebuilt locally; actor poses / track "
                                               "heads as one bucket") if X.get("uses_rows") else
                                              "SH gradient as rank-one factors: all-gather of 12 B per Gaussian and rank + camera centres + per-view actor "
                                              "pose tables, dense average rebuilt locally; one RCCL all-reduce (AVG) of the remaining 44 B per Gaussian "
                                              "(one slab, started inside backward()) + actor poses / track heads"),
-                       "exchange_rows_per_view": X["cap"] if X.get("uses_rows") else None},
+                       "exchange_rows_per_view": int(X.get("mean_cap") or 0) if X.get("uses_rows") else None},
             "roofline": roofline,
         }
         if density_event is not None:
@@ -890,7 +911,7 @@ def bench_forward_only(args, cfg, scene, model, render, cam_for, bg, opts, _lib,
         print(json.dumps(res), flush=True)
 
 
-def bench_exchange_only(args, dp, model, params, one_step, cam_for, campos_dev, N, rank, world, dev):
+def bench_exchange_only(args, dp, model, params, one_step, cam_for, campos_dev, N, rank, world, dev, xkw, X):
     """Only the gradient exchange of a view-parallel step: one backward produces the factors / slab, then GradientExchange.start +
     finish are timed `steps` times on those buffers (on 1 GPU with a process group: the collectives run at world size 1)."""
     from emd_amd import RasterCall
@@ -900,7 +921,7 @@ def bench_exchange_only(args, dp, model, params, one_step, cam_for, campos_dev, 
     pose = None if out["actor_pose"] is None else out["actor_pose"].detach()
 
     def exchange():
-        x = dp.GradientExchange(campos_dev[(f, c)], actor_ids=model.actor_id if model.has_actors else None, actor_pose=pose)
+        x = dp.GradientExchange(campos_dev[(f, c)], actor_ids=model.actor_id if model.has_actors else None, actor_pose=pose, **xkw(args.warmup))
         x.start(rec)
         x.finish(model._features, model._xyz, model.active_sh_degree, other_params=params)
         return x
@@ -928,6 +949,8 @@ def bench_exchange_only(args, dp, model, params, one_step, cam_for, campos_dev, 
                           "config": {"workload": "exchange only: all-reduce(AVG) of the 44 B/Gaussian slab + all-gather of the 12 B/Gaussian SH factors, camera "
                                                  "centres and pose tables + local rebuild of dL/dshs + small all-reduces", "gaussians": N,
                                      "collectives_per_step": x.num_collectives, "forced_at_world_1": bool(dp.force_exchange()),
+                                     "form": "visibility-compacted rows" if x._rows_s is not None else "dense slab all-reduce + factor all-gather",
+                                     "rows_per_view": X["cap"] if x._rows_s is not None else None,
                                      "bytes_per_rank": {"slab_allreduce": 44 * N, "factor_allgather_sent": 12 * N,
                                                         "factor_allgather_received": 12 * N * world, "pose_tables": 48 * A * world}}}), flush=True)
     if world > 1 or torch.distributed.is_initialized():
