@@ -52,6 +52,23 @@ def test_bench_launches_its_own_ranks_without_torchrun():
     assert "cpu_baseline" not in d                       # the CPU leg belongs to the 1-GPU run
 
 
+@pytest.mark.parametrize("ranks,cams", [(4, 4), (8, 6)], ids=["4-ranks-4-camera-rig", "8-ranks-6-camera-rig"])
+def test_bench_at_the_world_sizes_of_the_scale_run(ranks, cams):
+    """`python bench.py --gpus 4` / `--gpus 8` (the other two points of the driver's scaling run) end to end on the test box's one GPU (gloo): the
+    rig of that world size, rank -> view mapping (8 ranks on 6 cameras: mixed timestamps, per-view pose tables gathered), the dense exchange
+    (dp.compact_pays says rows do not pay at 4 and 8 ranks), one line from rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(EMD_BENCH_SHARE_GPU="1", EMD_DP_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--repeats", "0",
+           "--gaussians", "60000", "--height", "128", "--width", "192"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2500:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    c = d["config"]
+    assert d["n_gpus"] == ranks and c["ranks_seen"] == ranks and c["rig_cameras"] == cams and len(c["rank_ms_per_step"]["per_rank"]) == ranks
+    assert c["step_issue"].startswith("hipGraph replay") and c["exchange_rows_per_view"] is None and d["value"] > 0
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus_before_touching_the_gpu():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
