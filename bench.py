@@ -8,8 +8,10 @@ One step = one pass of the hot path over one camera view per GPU (SURVEY.md sect
 Optimiser, densification and data loading are excluded (they are outside the path).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W            # N > 1: starts its own N ranks as a fresh child process (before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W              # ... or under an external torchrun (RANK / WORLD_SIZE from the environment)
+    python bench.py --config 3 | 4                           # BASELINE configs[3] / [4] (at --gpus 1: the per-rank workload)
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
