@@ -449,3 +449,46 @@ def test_segmented_step_graphs_are_cut_inside_backward():
     assert [s_[:2] for s_ in seen] == [(1, 0), (2, 0), (0, 0), (2, 0)]
     assert all(s_[2] <= 1e-5 * float(want[s_[0]][1].abs().max()) + 1e-12 for s_ in seen)
     two.release()
+
+
+def test_density_control_on_the_bench_parameter_store_leaves_the_actors_alone():
+    """emd_amd.model.density_control (bench.py --config 4's event, S3Gaussian/train.py:404-423 -> gaussian_model.py:442-556 on a StreetGaussians store): the
+    background Gaussians are cloned / split / pruned by the device-side engine exactly as a GaussianModel holding only them would be; the actors' points
+    (in front, contiguous, at their fixed budget) keep their values, ids and order; the same call on identical inputs gives identical parameters (Philox)."""
+    from emd_amd import scenes
+    from emd_amd.gaussian_model import GaussianModel
+    from emd_amd.model import StreetGaussians, density_control
+    N, A, P = 30000, 3, 2000
+    sc = scenes.add_actors(scenes.make_static_scene(N, seed=2), num_actors=A, pts_per_actor=P, num_frames=4, seed=1)
+    g = torch.Generator().manual_seed(4)
+    accum, denom, radii = torch.rand(N, 1, generator=g) * 4e-4, torch.randint(0, 3, (N, 1), generator=g).float(), torch.rand(N, generator=g) * 30
+    n_dyn = A * P
+
+    def run():
+        m = StreetGaussians(sc, DEV)
+        before = {k: getattr(m, k).detach().clone() for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features")}
+        ev = density_control(m, accum.to(DEV), denom.to(DEV), radii.to(DEV), max_grad=2e-4, min_opacity=0.005, extent=4.0, percent_dense=0.01, seed=5, event=2)
+        return m, before, ev
+    m, before, ev = run()
+    assert ev["n_before"] == N and ev["n_after"] == N + ev["cloned"] + ev["split"] - ev["pruned"] and ev["cloned"] + ev["split"] > 0
+    assert m._xyz.shape[0] == ev["n_after"] == m.actor_id.shape[0]
+    for k, v in before.items():                                   # the actors' rows: untouched, still in front
+        assert torch.equal(getattr(m, k).detach()[:n_dyn], v[:n_dyn]), k
+    assert bool((m.actor_id[:n_dyn] >= 0).all()) and bool((m.actor_id[n_dyn:] == -1).all())
+    # the background against a GaussianModel that holds only the background
+    ref = GaussianModel(device=DEV, densify_seed=5)
+    ref.densify_events = 2
+    Pm = lambda t: torch.nn.Parameter(t[n_dyn:].to(DEV).contiguous())
+    ref._xyz, ref._scaling, ref._rotation, ref._opacity = Pm(sc.means), Pm(sc.log_scales), Pm(sc.quats), Pm(sc.opacity_logits)
+    ref._features_dc, ref._features_rest = Pm(sc.shs[:, :1]), Pm(sc.shs[:, 1:])
+    ref._embedding = torch.nn.Parameter(torch.zeros(N - n_dyn, 4, device=DEV))
+    ref._deformation_table = torch.ones(N - n_dyn, dtype=torch.bool, device=DEV)
+    ref.xyz_gradient_accum, ref.denom, ref.max_radii2D = accum[n_dyn:].to(DEV).contiguous(), denom[n_dyn:].to(DEV).contiguous(), radii[n_dyn:].to(DEV).contiguous()
+    ref.percent_dense = 0.01
+    with torch.no_grad():
+        ref.densify(2e-4, 0.005, 4.0, None)
+        ref.prune(2e-4, 0.005, 4.0, None)
+    assert torch.equal(m._xyz.detach()[n_dyn:], ref._xyz.detach()) and torch.equal(m._scaling.detach()[n_dyn:], ref._scaling.detach())
+    assert torch.equal(m._features.detach()[n_dyn:], torch.cat([ref._features_dc, ref._features_rest], 1).detach())
+    m2, _, ev2 = run()                                            # a second replica: the same event, bit for bit
+    assert ev2 == ev and torch.equal(m2._xyz.detach(), m._xyz.detach()) and torch.equal(m2._rotation.detach(), m._rotation.detach())
