@@ -44,6 +44,9 @@
 #ifndef EMD_BIN_CARRY
 #define EMD_BIN_CARRY 0
 #endif
+#ifndef EMD_DUP_SCAN_OWNER
+#define EMD_DUP_SCAN_OWNER 1
+#endif
 
 namespace {
 
@@ -129,6 +132,10 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
     __shared__ uint32_t s_id[EMD_BLOCK];
     __shared__ uint32_t s_hs[EMD_BLOCK];       // height | skip-top << 10 | skip-bottom << 11
     __shared__ uint32_t s_h0[EMD_BLOCK];       // digit histogram of tile pass 0 (at most 8 bits per pass)
+#if EMD_DUP_SCAN_OWNER
+    __shared__ __attribute__((aligned(16))) uint16_t s_own[DUP_SLOTS];      // owner (index in the Gaussian block + 1) of every slot of the window: head marks, then their running maximum
+    __shared__ uint32_t s_wmax[8];             // per-wave maxima of the owner scan [0..3], of the first-slot owner [4..7]
+#endif
     s_h0[threadIdx.x] = 0;
     // ---- every workgroup scans the pair counts of the 256-Gaussian blocks itself (the last depth pass left them in block_sums; 7812
     //      words at 2 M Gaussians, from L2): D, and where its own 2048 slots start.  This replaces a single-workgroup scan kernel whose
@@ -184,6 +191,13 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
         const uint32_t i = gb * EMD_BLOCK + threadIdx.x;
         const uint2 br = (i < V) ? bin_s[i] : make_uint2(0u, 0u);
         const uint32_t cnt = ((br.x >> 20) & 1023u) * (br.y & 1023u);
+#if EMD_DUP_SCAN_OWNER
+        // Round 5: the owner of a slot comes from a running maximum over head marks instead of an 8-step binary search per slot (64 dependent
+        // LDS reads per thread and Gaussian block: the kernel's longest chain).  Every Gaussian of the block with pairs marks the slot its run
+        // starts at (distinct slots), the Gaussian that covers the window's first slot marks slot 0, and one block-wide max-scan over the window
+        // (8 consecutive slots per thread + a DPP scan of the threads' maxima) leaves every slot's owner in LDS.
+        reinterpret_cast<uint4*>(s_own)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);                 // (ordered before the marks by the scan's barriers)
+#endif
         uint32_t total;
         const uint32_t inc = block_scan_add_u32(cnt, s_scan, &total);
         const uint32_t end = base + total;
@@ -191,10 +205,39 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
         s_rect[threadIdx.x] = br.x;
         s_id[threadIdx.x] = cnt ? perm[i] : 0u;
         s_hs[threadIdx.x] = br.y & 4095u;
-        __syncthreads();
         const uint32_t lo_slot = max(S0, base), hi_slot = min(S1, end);
+#if EMD_DUP_SCAN_OWNER
+        {
+            const uint32_t st = base + inc - cnt;                                                    // first slot of this Gaussian's run
+            if (cnt && st >= lo_slot && st < hi_slot) s_own[st - lo_slot] = (uint16_t)(threadIdx.x + 1u);
+            // owner of the window's first slot: the last Gaussian with pairs that starts at or in front of it
+            const unsigned long long bal = __ballot(cnt && st <= lo_slot);
+            if ((threadIdx.x & 63) == 0) s_wmax[4 + (threadIdx.x >> 6)] = bal ? (threadIdx.x & ~63u) + (63u - (uint32_t)__builtin_clzll(bal)) + 1u : 0u;
+        }
+        __syncthreads();
+        {
+            const uint4 q = reinterpret_cast<const uint4*>(s_own)[threadIdx.x];
+            uint32_t o[8] = {q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16, q.z & 0xffffu, q.z >> 16, q.w & 0xffffu, q.w >> 16};
+            if (threadIdx.x == 0) o[0] = max(o[0], max(max(s_wmax[4], s_wmax[5]), max(s_wmax[6], s_wmax[7])));
+#pragma unroll
+            for (int k = 1; k < 8; k++) o[k] = max(o[k], o[k - 1]);
+            const uint32_t incm = wave_scan_max_u32(o[7]);
+            if ((threadIdx.x & 63) == 63) s_wmax[threadIdx.x >> 6] = incm;
+            const uint32_t before_lane = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incm, DPP_WAVE_SHR1, 0xf, 0xf, false);   // the lanes in front of this one
+            __syncthreads();
+            uint32_t pre = before_lane;
+            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) pre = max(pre, s_wmax[w]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) o[k] = max(o[k], pre);
+            reinterpret_cast<uint4*>(s_own)[threadIdx.x] = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
+        }
+#endif
+        __syncthreads();
         for (uint32_t eg = lo_slot + threadIdx.x; eg < hi_slot; eg += EMD_BLOCK) {
             const uint32_t e = eg - base;
+#if EMD_DUP_SCAN_OWNER
+            const int lo = (int)s_own[eg - lo_slot] - 1;
+#else
             // largest j with s_excl[j] <= e  (entries with cnt == 0 share offsets with their successor; the search
             // lands on the last of an equal run, which is the one that owns slot e)
             int lo = 0, hi = EMD_BLOCK - 1;
@@ -203,6 +246,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
                 int mid = (lo + hi + 1) >> 1;
                 if (s_excl[mid] <= e) lo = mid; else hi = mid - 1;
             }
+#endif
             const uint32_t local_e = e - s_excl[lo];
             const uint32_t r = s_rect[lo];
             const uint32_t w = (r >> 20) & 1023u, x0 = r & 1023u, y0 = (r >> 10) & 1023u, hs = s_hs[lo];

@@ -85,6 +85,22 @@ __device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
     return v + (uint32_t)src;
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
+    int src = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);          // (lanes without a source read 0: the identity of max on uint32)
+    return max(v, (uint32_t)src);
+}
+// inclusive running maximum over the wave's lanes
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v) {
+    v = dpp_max_u32<DPP_ROW_SHR(1), 0xf>(v);
+    v = dpp_max_u32<DPP_ROW_SHR(2), 0xf>(v);
+    v = dpp_max_u32<DPP_ROW_SHR(4), 0xf>(v);
+    v = dpp_max_u32<DPP_ROW_SHR(8), 0xf>(v);
+    v = dpp_max_u32<DPP_ROW_BCAST15, 0xa>(v);
+    v = dpp_max_u32<DPP_ROW_BCAST31, 0xc>(v);
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
     v = dpp_add_u32<DPP_ROW_SHR(1), 0xf>(v);
     v = dpp_add_u32<DPP_ROW_SHR(2), 0xf>(v);
