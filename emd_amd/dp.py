@@ -248,6 +248,8 @@ class GradientExchange:
             return
         dev, N = g_local.device, g_local.shape[0]
         self._campos = torch.empty(W, 3, device=dev, dtype=torch.float32)
+        if self._use_compact(W, N) and getattr(rec, "radii", None) is None:
+            raise RuntimeError("the compacted exchange packs by the call's radii (RasterCall.radii): this record carries none")
         if self._use_compact(W, N):
             cap = int(self.compact_capacity)
             mine = compact_rows(rec.radii, [g_local], cap)                             # (index, 3 floats) rows of the visible Gaussians
