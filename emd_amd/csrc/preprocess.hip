@@ -674,14 +674,22 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
     // Round 5: 47 % of the Gaussians of a view are invisible, so a lane-per-Gaussian wave works with half of its lanes.  The visible Gaussians
     // of the workgroup's 256 are compacted (in index order) onto its first lanes: ~2.1 full waves run the loads and the chain rule, the rest of
     // the workgroup only writes the zero rows of the invisible ones ("natural" duties: thread t for Gaussian t of the block).
-    __shared__ uint32_t s_cscan[4];
+    __shared__ uint32_t s_cscan[K8_BLOCK / 64];
     __shared__ uint16_t s_list[K8_BLOCK];
     const int inat = blockIdx.x * K8_BLOCK + threadIdx.x;
     const bool nat_in = inat < a.N;
     const bool nat_vis = nat_in && a.radii[inat] > 0;
     uint32_t nv;
     {
-        const uint32_t incl = block_scan_add_u32(nat_vis ? 1u : 0u, s_cscan, &nv);
+        // inclusive scan of the visibility flags over the workgroup (any number of waves)
+        const uint32_t winc = wave_scan_add_u32(nat_vis ? 1u : 0u), wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 63) s_cscan[wv] = winc;
+        __syncthreads();
+        uint32_t wbase = 0;
+        nv = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < K8_BLOCK / 64; w++) { const uint32_t c = s_cscan[w]; if (w < wv) wbase += c; nv += c; }
+        const uint32_t incl = wbase + winc;
         if (nat_vis) s_list[incl - 1u] = (uint16_t)threadIdx.x;
         __syncthreads();
     }
@@ -996,35 +1004,37 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
 #endif
 #if EMD_K8_STAGE_SMALL || EMD_K8_COMPACT
     if (staged5) {
-        // tile: [256 x 3 means3D | 256 x 3 scales | 256 x 4 rotations | 256 opacities | 256 x 3 means2D] floats = 14 KB of the 26 KB SH tile
+        // tile: [B x 3 means3D | B x 3 scales | B x 4 rotations | B opacities | B x 3 means2D] floats (B = K8_BLOCK): 14 of the SH tile's 26 KB at B = 256
+        constexpr int B = K8_BLOCK, O_SC = 3 * B, O_ROT = 6 * B, O_OP = 10 * B, O_M2 = 11 * B;
+        static_assert(14 * B * 4 <= (int)sizeof(float4) * K8_HALF * SH_ROW4, "the small-gradient tile must fit the SH staging tile");
         float* sf = reinterpret_cast<float*>(s_sh);
         const int t = threadIdx.x;
         if (in_range) {
             const int u = lrow;
             sf[3 * u] = o_dl[0]; sf[3 * u + 1] = o_dl[1]; sf[3 * u + 2] = o_dl[2];
-            sf[768 + 3 * u] = o_ds[0]; sf[768 + 3 * u + 1] = o_ds[1]; sf[768 + 3 * u + 2] = o_ds[2];
-            *reinterpret_cast<float4*>(sf + 1536 + 4 * u) = make_float4(o_dq[0], o_dq[1], o_dq[2], o_dq[3]);
-            sf[2560 + u] = o_dop;
-            sf[2816 + 3 * u] = gm2[0]; sf[2816 + 3 * u + 1] = gm2[1]; sf[2816 + 3 * u + 2] = 0.f;
+            sf[O_SC + 3 * u] = o_ds[0]; sf[O_SC + 3 * u + 1] = o_ds[1]; sf[O_SC + 3 * u + 2] = o_ds[2];
+            *reinterpret_cast<float4*>(sf + O_ROT + 4 * u) = make_float4(o_dq[0], o_dq[1], o_dq[2], o_dq[3]);
+            sf[O_OP + u] = o_dop;
+            sf[O_M2 + 3 * u] = gm2[0]; sf[O_M2 + 3 * u + 1] = gm2[1]; sf[O_M2 + 3 * u + 2] = 0.f;
         }
         if (EMD_K8_COMPACT && !nat_vis) {
             sf[3 * t] = 0.f; sf[3 * t + 1] = 0.f; sf[3 * t + 2] = 0.f;
-            sf[768 + 3 * t] = 0.f; sf[768 + 3 * t + 1] = 0.f; sf[768 + 3 * t + 2] = 0.f;
-            *reinterpret_cast<float4*>(sf + 1536 + 4 * t) = make_float4(0.f, 0.f, 0.f, 0.f);
-            sf[2560 + t] = 0.f;
-            sf[2816 + 3 * t] = 0.f; sf[2816 + 3 * t + 1] = 0.f; sf[2816 + 3 * t + 2] = 0.f;
+            sf[O_SC + 3 * t] = 0.f; sf[O_SC + 3 * t + 1] = 0.f; sf[O_SC + 3 * t + 2] = 0.f;
+            *reinterpret_cast<float4*>(sf + O_ROT + 4 * t) = make_float4(0.f, 0.f, 0.f, 0.f);
+            sf[O_OP + t] = 0.f;
+            sf[O_M2 + 3 * t] = 0.f; sf[O_M2 + 3 * t + 1] = 0.f; sf[O_M2 + 3 * t + 2] = 0.f;
         }
         __syncthreads();
         const size_t b = (size_t)blockIdx.x * K8_BLOCK;
         const float4* s4 = reinterpret_cast<const float4*>(sf);
         auto st4 = [](float4* p, float4 v) { if (EMD_K8_STAGE_NT) store_f4_nt(p, v); else *p = v; };
-        if (t < 192) {
+        if (t < 3 * B / 4) {
             st4(reinterpret_cast<float4*>(a.dL_dmeans3D + 3 * b) + t, s4[t]);
-            st4(reinterpret_cast<float4*>(a.dL_dscales + 3 * b) + t, s4[192 + t]);
-            st4(reinterpret_cast<float4*>(a.dL_dmeans2D + 3 * b) + t, s4[704 + t]);
+            st4(reinterpret_cast<float4*>(a.dL_dscales + 3 * b) + t, s4[O_SC / 4 + t]);
+            st4(reinterpret_cast<float4*>(a.dL_dmeans2D + 3 * b) + t, s4[O_M2 / 4 + t]);
         }
-        st4(reinterpret_cast<float4*>(a.dL_drotations + 4 * b) + t, s4[384 + t]);
-        if (t < 64) st4(reinterpret_cast<float4*>(a.dL_dopacities + b) + t, s4[640 + t]);
+        st4(reinterpret_cast<float4*>(a.dL_drotations + 4 * b) + t, s4[O_ROT / 4 + t]);
+        if (t < B / 4) st4(reinterpret_cast<float4*>(a.dL_dopacities + b) + t, s4[O_OP / 4 + t]);
     }
 #endif
     if ((a.flags & EMD_FLAG_MOTION) && a.dL_dactor_pose) reduce_pose_grad(a_id, pose_g, a.dL_dactor_pose);
