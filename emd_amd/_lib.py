@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16
@@ -181,7 +181,8 @@ class EmdMlpTrunkGrads(C.Structure):
 
 class EmdMlpBranch(C.Structure):
     _fields_ = [("num_points", C.c_int32), ("depth", C.c_int32), ("relu_input", C.c_int32), ("out_dim", C.c_int32), ("h", _f),
-                ("w_hidden", _f * 2), ("b_hidden", _f * 2), ("w_out", _f), ("b_out", _f), ("out", _f), ("l1_sum", _f)]
+                ("w_hidden", _f * 2), ("b_hidden", _f * 2), ("w_out", _f), ("b_out", _f), ("out", _f), ("l1_sum", _f),
+                ("xb", _f), ("w_in", _f), ("b_in", _f), ("kb_in", C.c_int32), ("ld_w_in", C.c_int32), ("col_in", C.c_int32), ("reserved", C.c_int32)]
 
 
 class EmdMlpBranchGrads(C.Structure):

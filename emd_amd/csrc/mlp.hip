@@ -411,6 +411,51 @@ __device__ __forceinline__ void stage_vector(float* __restrict__ dst, int n_pad,
     for (int idx = threadIdx.x; idx < n_pad; idx += MLP_THREADS) dst[idx] = (src && idx < n) ? src[idx] : 0.f;
 }
 
+// the xb block as ONE k-chunk of 8: register j of lane half hh holds xb[row][4 hh + j]
+template <bool STRAIGHT>
+__device__ __forceinline__ void load_xb(const float* __restrict__ xb, int kb, size_t row, bool ok, int hh, float (&v)[4]) {
+    if (STRAIGHT && xb && kb > 0) {
+        const float* p = xb + (ok ? row : 0) * (size_t)kb;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int c = 4 * hh + j;
+            const float x = p[c < kb ? c : 0];                   // (unconditional load, see load_tile)
+            v[j] = (ok && c < kb) ? x : 0.f;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int c = 4 * hh + j;
+        v[j] = (ok && xb && c < kb) ? xb[row * (size_t)kb + c] : 0.f;
+    }
+}
+
+// The heads that recompute h: the next tile's embedding values travel RAW across the loop iteration (clamped address, unconditional loads) and are
+// masked where they are used -- masking at the load (a select, or a product) makes the compiler wait for the load right there, inside the tile loop.
+__device__ __forceinline__ void load_xb_raw(const float* __restrict__ xb, int kb, size_t row, bool ok, int hh, float (&v)[4]) {
+    const float* p = xb + (ok ? row : 0) * (size_t)kb;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int c = 4 * hh + j; v[j] = p[c < kb ? c : 0]; }
+}
+__device__ __forceinline__ void mask_xb(const float (&raw)[4], int kb, bool ok, int hh, float (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = raw[j] * ((ok && 4 * hh + j < kb) ? 1.f : 0.f);
+}
+// h = b + Wb xb for one 32-row tile: the xb part of the trunk's forward (trunk_forward_tile with no xa block, the same MFMAs in the same order: the
+// same bits), from the [64][12] image of Wb and the bias behind it -- used by the trunk kernel and by the heads that recompute h (EmdMlpBranch.xb)
+__device__ __forceinline__ void embed_h(const float* __restrict__ wb, const float* __restrict__ b, int r, int hh, const float (&xb)[4], f32x16 (&h)[2], bool init = true) {
+    if (init) { h[0] = bias_tile(b, 0, hh); h[1] = bias_tile(b, 32, hh); }
+#pragma unroll
+    for (int to = 0; to < 2; to++) {
+        const float4 w = *(const float4*)(wb + (32 * to + r) * 12 + 4 * hh);
+        h[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, xb[0], h[to], 0, 0, 0);
+        h[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, xb[1], h[to], 0, 0, 0);
+        h[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xb[2], h[to], 0, 0, 0);
+        h[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xb[3], h[to], 0, 0, 0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // branch: [relu] -> Linear(64, 64) -> relu [-> Linear(64, 64) -> relu] -> Linear(64, out_dim)
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -438,6 +483,8 @@ struct BranchLds {
     static constexpr int wot = w2t + (DEPTH == 2 ? W64 : 0);
     static constexpr int scratch = wot + (SP ? split_floats(2, 2 * NTO) : 64 * WOT);
     static constexpr int bwd_floats = scratch + MLP_WAVES * 32 * TS;
+    // RC kernels (the head recomputes h from the embedding): Win [64][12] | b_in [64] behind the kernel's other regions
+    static constexpr int rc_floats = 64 * 12 + 64;
 };
 
 // one call for both weight forms: the fp32 path reads rows of a padded LDS matrix, the split path ready-made bf16 fragments
@@ -467,9 +514,14 @@ __device__ __forceinline__ void split_all(Split (&afs)[NI], const f32x16 (&af)[N
     }
 }
 
-template <int DEPTH, int NTO, bool BWD>
+template <int DEPTH, int NTO, bool BWD, bool RC = false>
 __device__ __forceinline__ void branch_stage(float* lds, const EmdMlpBranch& a) {
     typedef BranchLds<DEPTH, NTO, branch_mode(DEPTH, NTO, BWD)> L;
+    if constexpr (RC) {      // the trunk's embedding block and bias, in the trunk kernel's own layout (trunk_stage)
+        float* rc = lds + (BWD ? L::bwd_floats : L::fwd_floats);
+        stage_matrix(rc, 12, 64, 8, a.w_in, a.ld_w_in, a.col_in, 64, a.kb_in);
+        stage_vector(rc + 64 * 12, 64, a.b_in, 64);
+    }
     if constexpr (L::SP) {
         if (BWD) {
             stage_split(lds + L::w1t, 2, 4, a.w_hidden[0], 64, 0, 64, 64, true);
@@ -497,11 +549,13 @@ __device__ __forceinline__ void branch_stage(float* lds, const EmdMlpBranch& a) 
 
 // L1: the head's regulariser mean |out| is formed beside the outputs (EmdMlpBranch.l1_sum); a separate instantiation keeps the registers of
 // the usual kernels as they were
-template <int DEPTH, int NTO, bool L1 = false>
+// RC: the head forms h = b_in + W_in xb itself (EmdMlpBranch.xb, a level without HexPlane features) instead of reading a [N,64] tensor
+template <int DEPTH, int NTO, bool L1 = false, bool RC = false>
 __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 && !L1) ? MLP_W_F11 : MLP_FWD_WAVES) k_mlp_branch_fwd(EmdMlpBranch a) {
     typedef BranchLds<DEPTH, NTO, branch_mode(DEPTH, NTO, false)> L;
     extern __shared__ float lds[];
-    branch_stage<DEPTH, NTO, false>(lds, a);
+    branch_stage<DEPTH, NTO, false, RC>(lds, a);
+    const float* rc = lds + L::fwd_floats;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
     const bool wide_out = (a.out_dim & 3) == 0;
@@ -509,13 +563,22 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
     float l1_acc = 0.f;
     const size_t tile0 = (size_t)blockIdx.x * MLP_WAVES + wave, tstep = (size_t)gridDim.x * MLP_WAVES;
     // the next tile's rows are loaded while this tile computes: one wave per SIMD has nothing else to hide the HBM latency behind
-    f32x16 nx[2] = {load_tile<true>(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 0, hh), load_tile<true>(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 32, hh)};
+    f32x16 nx[2];
+    float nxb[4];
+    if constexpr (RC) load_xb_raw(a.xb, a.kb_in, tile0 * 32 + r, tile0 * 32 + r < N, hh, nxb);
+    else { nx[0] = load_tile<true>(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 0, hh); nx[1] = load_tile<true>(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 32, hh); }
     for (size_t tile = tile0; tile < tiles; tile += tstep) {
         const size_t row = tile * 32 + r;
         const bool ok = row < N;
-        f32x16 x[2] = {nx[0], nx[1]};
-        {
-            const size_t nrow = (tile + tstep) * 32 + r;
+        f32x16 x[2];
+        const size_t nrow = (tile + tstep) * 32 + r;
+        if constexpr (RC) {
+            float xb[4];
+            mask_xb(nxb, a.kb_in, ok, hh, xb);
+            load_xb_raw(a.xb, a.kb_in, nrow, nrow < N, hh, nxb);
+            embed_h(rc, rc + 64 * 12, r, hh, xb, x);
+        } else {
+            x[0] = nx[0]; x[1] = nx[1];
             nx[0] = load_tile<true>(a.h, 64, nrow, nrow < N, 0, hh); nx[1] = load_tile<true>(a.h, 64, nrow, nrow < N, 32, hh);
         }
         if (a.relu_input) { x[0] = relu16(x[0]); x[1] = relu16(x[1]); }
@@ -584,11 +647,12 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
     }
 }
 
-template <int DEPTH, int NTO, bool L1 = false>
+template <int DEPTH, int NTO, bool L1 = false, bool RC = false>
 __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_branch_bwd(EmdMlpBranch a, EmdMlpBranchGrads g) {
     typedef BranchLds<DEPTH, NTO, branch_mode(DEPTH, NTO, true)> L;
     extern __shared__ float lds[];
-    branch_stage<DEPTH, NTO, true>(lds, a);
+    branch_stage<DEPTH, NTO, true, RC>(lds, a);
+    const float* rc = lds + L::bwd_floats;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     float* T = lds + L::scratch + wave * 32 * TS;
     const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
@@ -617,7 +681,10 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
         return v;
     };
     // the next tile's h and g_out are loaded while this tile computes (one wave per SIMD: nothing else hides the HBM latency)
-    f32x16 nh[2] = {load_tile(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 0, hh), load_tile(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 32, hh)};
+    f32x16 nh[2];
+    float nxb[4];
+    if constexpr (RC) load_xb_raw(a.xb, a.kb_in, tile0 * 32 + r, tile0 * 32 + r < N, hh, nxb);
+    else { nh[0] = load_tile(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 0, hh); nh[1] = load_tile(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 32, hh); }
     f32x16 ngo[NTO];
 #pragma unroll
     for (int t = 0; t < NTO; t++) ngo[t] = load_go(tile0 * 32 + r, tile0 * 32 + r < N, t);
@@ -625,13 +692,21 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
         const size_t row = tile * 32 + r;
         const bool ok = row < N;
         // ---- recompute the forward
-        f32x16 hin[2] = {nh[0], nh[1]};
+        f32x16 hin[2];
         f32x16 go[NTO];
 #pragma unroll
         for (int t = 0; t < NTO; t++) go[t] = ngo[t];
         {
             const size_t nrow = (tile + tstep) * 32 + r;
-            nh[0] = load_tile(a.h, 64, nrow, nrow < N, 0, hh); nh[1] = load_tile(a.h, 64, nrow, nrow < N, 32, hh);
+            if constexpr (RC) {
+                float xb[4];
+                mask_xb(nxb, a.kb_in, ok, hh, xb);
+                load_xb_raw(a.xb, a.kb_in, nrow, nrow < N, hh, nxb);
+                embed_h(rc, rc + 64 * 12, r, hh, xb, hin);
+            } else {
+                hin[0] = nh[0]; hin[1] = nh[1];
+                nh[0] = load_tile(a.h, 64, nrow, nrow < N, 0, hh); nh[1] = load_tile(a.h, 64, nrow, nrow < N, 32, hh);
+            }
 #pragma unroll
             for (int t = 0; t < NTO; t++) ngo[t] = load_go(nrow, nrow < N, t);
         }
@@ -769,40 +844,13 @@ __device__ __forceinline__ void trunk_stage(float* lds, const EmdMlpTrunk& a) {
     __syncthreads();
 }
 
-// the xb block as ONE k-chunk of 8: register j of lane half hh holds xb[row][4 hh + j]
-template <bool STRAIGHT>
-__device__ __forceinline__ void load_xb(const float* __restrict__ xb, int kb, size_t row, bool ok, int hh, float (&v)[4]) {
-    if (STRAIGHT && xb && kb > 0) {
-        const float* p = xb + (ok ? row : 0) * (size_t)kb;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int c = 4 * hh + j;
-            const float x = p[c < kb ? c : 0];                   // (unconditional load, see load_tile)
-            v[j] = (ok && c < kb) ? x : 0.f;
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int c = 4 * hh + j;
-        v[j] = (ok && xb && c < kb) ? xb[row * (size_t)kb + c] : 0.f;
-    }
-}
-
 // this tile's xa / xb rows (already in registers) -> h
 template <int KTA>
 __device__ __forceinline__ void trunk_forward_tile(const float* lds, int r, int hh, const f32x16 (&xa)[KTA ? KTA : 1], const float (&xb)[4], f32x16 (&h)[2]) {
     typedef TrunkLds<KTA, MLP_SP_TF> L;
     h[0] = bias_tile(lds + L::b, 0, hh); h[1] = bias_tile(lds + L::b, 32, hh);
     if (KTA) mm<L::SP, (KTA ? KTA : 1), 2>(h, xa, lds + L::wa, L::SA, 0, 2, 2 * KTA, r, hh, r + 32 * hh);
-#pragma unroll
-    for (int to = 0; to < 2; to++) {
-        const float4 w = *(const float4*)(lds + L::wb + (32 * to + r) * 12 + 4 * hh);
-        h[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, xb[0], h[to], 0, 0, 0);
-        h[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, xb[1], h[to], 0, 0, 0);
-        h[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xb[2], h[to], 0, 0, 0);
-        h[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xb[3], h[to], 0, 0, 0);
-    }
+    embed_h(lds + L::wb, lds + L::b, r, hh, xb, h, false);
 }
 
 template <int KTA, bool STRAIGHT>
@@ -959,6 +1007,132 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(KTA == 0 ? MLP_W_TB0 : ML
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// trunk backward of a level WITHOUT HexPlane features (ka = 0, kb <= 4) on the vector pipe (round 5).  The MFMA form above pads the [64 x kb]
+// weight gradient and the [kb]-wide dL/dxb to 32-column tiles: 64 fp32 MFMAs + three LDS transposes per 32 rows for 2 x 64 x kb x 32 useful
+// multiply-adds, 244 us at 2 M rows while the kernel's only real traffic, the heads' dL/dh, is 512 MB.  Here a lane keeps the tile layout of its
+// row (32 of the row's 64 features), forms its share of dL/dxb as kb x 32 multiply-adds against broadcast LDS rows (the halves meet in one
+// cross-lane add) and keeps dWb[feature][c] += dL/dh[feature] xb[c] and db[feature] += dL/dh[feature] in 32 (kb + 1) per-lane accumulators that
+// are summed over the lanes once, at the end: no MFMA, no transpose, bound by the read of dL/dh.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#ifndef MLP_EMBED_BWD_VALU
+#define MLP_EMBED_BWD_VALU 1
+#endif
+// One wave per SIMD: the 512-entry register file holds the lane's 32 x kb weights (no LDS round trip in the tile loop), the 32 (kb + 1)
+// accumulators and the next two tiles' registers (8 KB per wave and tile; the rotation's register copy waits for the nearer one).  Every load of
+// the loop is unconditional (rows past the end read row 0 and are zeroed by load_tile's product; xb of such a row meets a zero dL/dh): a guarded load
+// makes the compiler wait for ALL outstanding loads -- the prefetches too -- at the join.  MULTI: more than one dL/dh tensor (a two-hidden-layer head
+// keeps its own): the others are added inside the loop.
+template <int KB, bool MULTI>          // KB = kb = 4
+__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(1) k_mlp_embed_bwd(EmdMlpTrunk a, EmdMlpTrunkGrads g) {
+    __shared__ float wt[KB][64];                                  // Wb^T: wt[c][feature]
+    __shared__ float red[MLP_WAVES][2][32][KB + 1];
+    for (int idx = threadIdx.x; idx < KB * 64; idx += MLP_THREADS) {
+        const int c = idx >> 6, k = idx & 63;
+        wt[c][k] = a.w[(size_t)k * a.ld_w + a.col_b + c];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const size_t N = (size_t)a.num_points, tiles = (N + 31) / 32;
+    float4 wreg[KB][2][4];
+#pragma unroll
+    for (int c = 0; c < KB; c++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) wreg[c][t][q] = *(const float4*)&wt[c][32 * t + 8 * q + 4 * hh];
+    float accw[2][16][KB], accb[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            accb[t][v] = 0.f;
+#pragma unroll
+            for (int c = 0; c < KB; c++) accw[t][v][c] = 0.f;
+        }
+    const size_t tile0 = (size_t)blockIdx.x * MLP_WAVES + wave, tstep = (size_t)gridDim.x * MLP_WAVES;
+    auto load_x = [&](size_t row_) -> float4 { return *(const float4*)(a.xb + (row_ < N ? row_ : 0) * 4); };
+    // (measured: three buffers in rotation with the loop unrolled by three -- no register copy of a travelling tile -- spill at 512 registers: 143 -> 358 us)
+    f32x16 n1[2], n2[2];
+    float4 x1, x2;
+    {
+        const size_t r1 = tile0 * 32 + r, r2 = (tile0 + tstep) * 32 + r;
+        n1[0] = load_tile<true>(g.g_h[0], 64, r1, r1 < N, 0, hh); n1[1] = load_tile<true>(g.g_h[0], 64, r1, r1 < N, 32, hh); x1 = load_x(r1);
+        n2[0] = load_tile<true>(g.g_h[0], 64, r2, r2 < N, 0, hh); n2[1] = load_tile<true>(g.g_h[0], 64, r2, r2 < N, 32, hh); x2 = load_x(r2);
+    }
+    for (size_t tile = tile0; tile < tiles; tile += tstep) {
+        const size_t row = tile * 32 + r;
+        const bool ok = row < N;
+        f32x16 gh[2] = {n1[0], n1[1]};                            // dL/dh (rows past the end: zero)
+        const float xb[KB] = {x1.x, x1.y, x1.z, x1.w};
+        n1[0] = n2[0]; n1[1] = n2[1]; x1 = x2;
+        {
+            const size_t nrow = (tile + 2 * tstep) * 32 + r;
+            n2[0] = load_tile<true>(g.g_h[0], 64, nrow, nrow < N, 0, hh); n2[1] = load_tile<true>(g.g_h[0], 64, nrow, nrow < N, 32, hh); x2 = load_x(nrow);
+        }
+        if constexpr (MULTI) {
+            for (int k = 1; k < g.num_gh; k++) {
+                const f32x16 p0 = load_tile<true>(g.g_h[k], 64, row, ok, 0, hh), p1 = load_tile<true>(g.g_h[k], 64, row, ok, 32, hh);
+#pragma unroll
+                for (int v = 0; v < 16; v++) { gh[0][v] += p0[v]; gh[1][v] += p1[v]; }
+            }
+        }
+        if (g.d_xb) {
+            float d[KB];
+#pragma unroll
+            for (int c = 0; c < KB; c++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float4 w = wreg[c][t][q];
+                        acc = fmaf(w.x, gh[t][4 * q], acc); acc = fmaf(w.y, gh[t][4 * q + 1], acc);
+                        acc = fmaf(w.z, gh[t][4 * q + 2], acc); acc = fmaf(w.w, gh[t][4 * q + 3], acc);
+                    }
+                d[c] = acc + __shfl_xor(acc, 32);
+            }
+            if (hh == 0 && ok) *(float4*)(g.d_xb + row * 4) = make_float4(d[0], d[1], d[2], d[3]);       // whole 16-byte rows: 512 contiguous bytes per instruction
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                accb[t][v] += gh[t][v];
+#pragma unroll
+                for (int c = 0; c < KB; c++) accw[t][v][c] = fmaf(gh[t][v], xb[c], accw[t][v][c]);
+            }
+    }
+    // ---- sums over the 32 rows of a lane half (xor shuffles stay inside the half), the waves, then one atomic per element and workgroup
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            float s[KB + 1];
+#pragma unroll
+            for (int c = 0; c < KB; c++) s[c] = accw[t][v][c];
+            s[KB] = accb[t][v];
+#pragma unroll
+            for (int c = 0; c <= KB; c++) {
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) s[c] += __shfl_xor(s[c], m);
+            }
+            if (r == 0) {
+#pragma unroll
+                for (int c = 0; c <= KB; c++) red[wave][t][8 * (v >> 2) + 4 * hh + (v & 3)][c] = s[c];
+            }
+        }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * (KB + 1); idx += MLP_THREADS) {
+        const int k = idx / (KB + 1), c = idx - k * (KB + 1);
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < MLP_WAVES; w++) s += red[w][k >> 5][k & 31][c];
+        if (c < KB) { if (g.d_w) unsafeAtomicAdd(g.d_w + (size_t)k * a.ld_w + a.col_b + c, s); }
+        else if (g.d_b) unsafeAtomicAdd(g.d_b + k, s);
+    }
+}
+
 unsigned mlp_grid(int num_points, int per_cu) {
     const size_t tiles = ((size_t)num_points + 31) / 32;
     const size_t wgs = (tiles + MLP_WAVES - 1) / MLP_WAVES, cap = (size_t)256 * per_cu;
@@ -971,22 +1145,27 @@ int check_branch(const EmdMlpBranch* a, const char* who) {
         emd_set_error("%s: bad sizes (depth 1..2, out_dim 1..64)", who); return EMD_ERR_INVALID;
     }
     if (a->num_points == 0) return EMD_OK;
-    if (!a->h || !a->w_hidden[0] || !a->b_hidden[0] || !a->w_out || !a->b_out || (a->depth == 2 && (!a->w_hidden[1] || !a->b_hidden[1]))) {
+    if ((!a->h && !a->xb) || !a->w_hidden[0] || !a->b_hidden[0] || !a->w_out || !a->b_out || (a->depth == 2 && (!a->w_hidden[1] || !a->b_hidden[1]))) {
         emd_set_error("%s: null pointer", who); return EMD_ERR_INVALID;
     }
-    if (((uintptr_t)a->h & 15)) { emd_set_error("%s: h must be 16-byte aligned", who); return EMD_ERR_INVALID; }
+    if (a->xb) {          // the head recomputes h from the embedding (ABI 26)
+        if (a->depth != 1) { emd_set_error("%s: xb (recomputed h) is served for depth 1 only", who); return EMD_ERR_INVALID; }
+        if (!a->w_in || !a->b_in || a->kb_in < 1 || a->kb_in > 8 || a->col_in < 0 || a->ld_w_in < a->col_in + a->kb_in) {
+            emd_set_error("%s: xb needs w_in, b_in, kb_in 1..8 and col_in + kb_in <= ld_w_in", who); return EMD_ERR_INVALID;
+        }
+    } else if (((uintptr_t)a->h & 15)) { emd_set_error("%s: h must be 16-byte aligned", who); return EMD_ERR_INVALID; }
     return EMD_OK;
 }
 
-int check_trunk(const EmdMlpTrunk* a, const char* who) {
+int check_trunk(const EmdMlpTrunk* a, const char* who, bool need_h = true) {
     if (!a) { emd_set_error("%s: null args", who); return EMD_ERR_INVALID; }
     if (a->num_points < 0 || (a->ka < 0 || a->ka > 128 || (a->ka & 3)) || a->kb < 0 || a->kb > 8 || a->ka + a->kb == 0 || a->ld_w < a->ka + a->kb ||
         a->col_a < 0 || a->col_b < 0 || a->col_a + a->ka > a->ld_w || a->col_b + a->kb > a->ld_w) {
         emd_set_error("%s: bad sizes (ka a multiple of 4 up to 128, kb <= 8)", who); return EMD_ERR_INVALID;
     }
     if (a->num_points == 0) return EMD_OK;
-    if (!a->w || !a->b || !a->h || (a->ka && !a->xa) || (a->kb && !a->xb)) { emd_set_error("%s: null pointer", who); return EMD_ERR_INVALID; }
-    if (((uintptr_t)a->h & 15) || (a->ka && ((uintptr_t)a->xa & 15))) { emd_set_error("%s: xa / h must be 16-byte aligned", who); return EMD_ERR_INVALID; }
+    if (!a->w || !a->b || (need_h && !a->h) || (a->ka && !a->xa) || (a->kb && !a->xb)) { emd_set_error("%s: null pointer", who); return EMD_ERR_INVALID; }
+    if ((need_h && ((uintptr_t)a->h & 15)) || (a->ka && ((uintptr_t)a->xa & 15))) { emd_set_error("%s: xa / h must be 16-byte aligned", who); return EMD_ERR_INVALID; }
     return EMD_OK;
 }
 
@@ -1018,6 +1197,15 @@ extern "C" int emd_mlp_branch_forward(const EmdMlpBranch* a, void* hip_stream) {
     if (!a->out) { emd_set_error("mlp_branch_forward: null output"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     const int nto = a->out_dim > 32 ? 2 : 1;
+    if (a->xb) {
+        typedef BranchLds<1, 1, branch_mode(1, 1, false)> L1_; typedef BranchLds<1, 2, branch_mode(1, 2, false)> L2_;
+        if (a->l1_sum) {
+            if (nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1, true, true>, MLP_FWD_WAVES>(L1_::fwd_floats + L1_::rc_floats, a->num_points, st, *a);
+            return mlp_launch<k_mlp_branch_fwd<1, 2, true, true>, MLP_FWD_WAVES>(L2_::fwd_floats + L2_::rc_floats, a->num_points, st, *a);
+        }
+        if (nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1, false, true>, MLP_W_F11>(L1_::fwd_floats + L1_::rc_floats, a->num_points, st, *a);
+        return mlp_launch<k_mlp_branch_fwd<1, 2, false, true>, MLP_FWD_WAVES>(L2_::fwd_floats + L2_::rc_floats, a->num_points, st, *a);
+    }
     if (a->l1_sum) {
         if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1, true>, MLP_FWD_WAVES>(BranchLds<1, 1, branch_mode(1, 1, false)>::fwd_floats, a->num_points, st, *a);
         if (a->depth == 1) return mlp_launch<k_mlp_branch_fwd<1, 2, true>, MLP_FWD_WAVES>(BranchLds<1, 2, branch_mode(1, 2, false)>::fwd_floats, a->num_points, st, *a);
@@ -1040,6 +1228,15 @@ extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranch
     if (((uintptr_t)g->g_h & 15)) { emd_set_error("mlp_branch_backward: g_h must be 16-byte aligned"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     const int nto = a->out_dim > 32 ? 2 : 1;
+    if (a->xb) {
+        typedef BranchLds<1, 1, branch_mode(1, 1, true)> L1_; typedef BranchLds<1, 2, branch_mode(1, 2, true)> L2_;
+        if (g->l1_grad) {
+            if (nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1, true, true>, MLP_BWD_WAVES>(L1_::bwd_floats + L1_::rc_floats, a->num_points, st, *a, *g);
+            return mlp_launch<k_mlp_branch_bwd<1, 2, true, true>, MLP_BWD_WAVES>(L2_::bwd_floats + L2_::rc_floats, a->num_points, st, *a, *g);
+        }
+        if (nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1, false, true>, MLP_BWD_WAVES>(L1_::bwd_floats + L1_::rc_floats, a->num_points, st, *a, *g);
+        return mlp_launch<k_mlp_branch_bwd<1, 2, false, true>, MLP_BWD_WAVES>(L2_::bwd_floats + L2_::rc_floats, a->num_points, st, *a, *g);
+    }
     if (g->l1_grad) {
         if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1, true>, MLP_BWD_WAVES>(BranchLds<1, 1, branch_mode(1, 1, true)>::bwd_floats, a->num_points, st, *a, *g);
         if (a->depth == 1) return mlp_launch<k_mlp_branch_bwd<1, 2, true>, MLP_BWD_WAVES>(BranchLds<1, 2, branch_mode(1, 2, true)>::bwd_floats, a->num_points, st, *a, *g);
@@ -1066,7 +1263,7 @@ extern "C" int emd_mlp_trunk_forward(const EmdMlpTrunk* a, void* hip_stream) {
 }
 
 extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGrads* g, void* hip_stream) {
-    int rc = check_trunk(a, "mlp_trunk_backward");
+    int rc = check_trunk(a, "mlp_trunk_backward", false);          // (the backward reads xa, xb and the heads' dL/dh, not h)
     if (rc || a->num_points == 0) return rc;
     if (!g || g->num_gh < 1 || g->num_gh > EMD_MLP_MAX_BRANCHES) { emd_set_error("mlp_trunk_backward: 1..%d gradient contributions", EMD_MLP_MAX_BRANCHES); return EMD_ERR_INVALID; }
     for (int k = 0; k < g->num_gh; k++)
@@ -1074,7 +1271,14 @@ extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGra
     if (g->d_xa && ((uintptr_t)g->d_xa & 15)) { emd_set_error("mlp_trunk_backward: d_xa must be 16-byte aligned"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     switch ((a->ka + 31) / 32) {
-        case 0: return mlp_launch<k_mlp_trunk_bwd<0>, MLP_W_TB0>(TrunkLds<0, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
+        case 0:
+            if (MLP_EMBED_BWD_VALU && a->kb == 4 && !((uintptr_t)a->xb & 15) && !((uintptr_t)g->d_xb & 15)) {     // (the reference's embedding width; static LDS)
+                if (g->num_gh == 1) hipLaunchKernelGGL((k_mlp_embed_bwd<4, false>), dim3(mlp_grid(a->num_points, 1)), dim3(MLP_THREADS), 0, st, *a, *g);
+                else hipLaunchKernelGGL((k_mlp_embed_bwd<4, true>), dim3(mlp_grid(a->num_points, 1)), dim3(MLP_THREADS), 0, st, *a, *g);
+                EMD_LAUNCH_CHECK();
+                return EMD_OK;
+            }
+            return mlp_launch<k_mlp_trunk_bwd<0>, MLP_W_TB0>(TrunkLds<0, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
         case 1: return mlp_launch<k_mlp_trunk_bwd<1>, MLP_BWD_WAVES>(TrunkLds<1, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
         case 2: return mlp_launch<k_mlp_trunk_bwd<2>, MLP_BWD_WAVES>(TrunkLds<2, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
         case 3: return mlp_launch<k_mlp_trunk_bwd<3>, MLP_BWD_WAVES>(TrunkLds<3, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);

@@ -92,6 +92,18 @@ class _TemporalEmbed(torch.autograd.Function):
         return g_w, (g_t.reshape(ctx.t_shape) if g_t is not None else None), None
 
 
+def _first_time(time_emb):
+    """`time_emb.reshape(-1)[:1]`: the level's one timestamp (deformation.py:283).  For a timestamp BROADCAST over the points (stride 0, what
+    `forward_time_offset` and emd_amd.model.render hand over) the [1, 1] tensor that was expanded is taken instead of a slice of the expansion: the
+    slice makes autograd fill an [N] zero column, copy the scalar into row 0 and sum N values again on the way back (three launches and 16 MB per
+    level for one float; the HexPlane lookup avoids the same thing, hexplane.py get_density)."""
+    if time_emb.dim() == 2 and time_emb.shape[0] > 1 and time_emb.stride(0) == 0 and time_emb.shape[1] == 1:
+        base = getattr(time_emb, "_base", None)
+        if base is not None and base.numel() == 1 and base.dtype == time_emb.dtype:
+            return base.reshape(1)
+    return time_emb.reshape(-1)[:1]
+
+
 def temporal_embed(weight, t, k):
     """Row of the temporal table (resized to k rows) at time t (a 1-element tensor ON THE DEVICE: no host sync)."""
     return _TemporalEmbed.apply(weight, t, k)
@@ -285,7 +297,7 @@ class Deformation(nn.Module):
         col = self.grid.feat_dim if use_hex else 0
         if not a.no_temporal_embedding_dim:
             T = self.temporal_embedding_dim
-            te = temporal_embed(self.weight, time_emb.reshape(-1)[:1], self._num_rows(coarse, it, num_down_emb))
+            te = temporal_embed(self.weight, _first_time(time_emb), self._num_rows(coarse, it, num_down_emb))
             bias = torch.addmv(bias, Wm[:, col:col + T], te)           # the same row for every Gaussian: a bias, not N copies
             col += T
         if not a.no_gaussian_embedding_dim and embeddings is not None:
@@ -348,7 +360,7 @@ class Deformation(nn.Module):
         Wm, bias, col = lin.weight, lin.bias, ka
         if not a.no_temporal_embedding_dim:
             T = self.temporal_embedding_dim
-            te = temporal_embed(self.weight, time_emb.reshape(-1)[:1], self._num_rows(coarse, it, num_down_emb))
+            te = temporal_embed(self.weight, _first_time(time_emb), self._num_rows(coarse, it, num_down_emb))
             bias = torch.addmv(bias, Wm[:, col:col + T], te)           # the same row for every Gaussian: a bias, not N copies
             col += T
         xa = self.grid(pts[:, :3], time_emb[:, :1]) if use_hex else None
@@ -450,7 +462,9 @@ class deform_network(nn.Module):
         ddict_c = net(point, times_sel, embeddings, is_coarse=True, iter=iter, num_down_emb_c=self.min_embeddings,
                       apply_deform=not self.no_coarse_deform, time_diff=time_diff, is_train=is_train, need_feat=need_feat, **lk)
         pts = point
-        if not self.no_coarse_deform and self.args.apply_coarse_dx:
+        # (the fine level reads its points only through the HexPlane lookup: with `no_fine_hexplane_features`, the run script's setting, the sum
+        # would be formed and differentiated for nothing -- an [N, 3] add each way)
+        if not self.no_coarse_deform and self.args.apply_coarse_dx and not self.args.no_fine_hexplane_features:
             pts = point + ddict_c["dx"]
         ddict_f = net(pts, times_sel, embeddings, is_coarse=False, iter=iter, num_down_emb_f=self.min_embeddings,
                       apply_deform=not self.no_fine_deform, time_diff=time_diff, is_train=is_train, need_feat=need_feat, **lk)

@@ -8,12 +8,15 @@ kernel per head (each writes its own contribution to dL/dh and accumulates its w
 contributions, writes dL/dxa, dL/dxb, accumulates dW0) -- no intermediate [N, 64..192] tensor and no element-wise launch exists in
 either direction.  There is no CPU path (the checker's restatement is oracle/deform_oracle.py)."""
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib as L
 
 WIDTH = 64
+# heads of a level without HexPlane features form h from the embedding themselves (csrc/mlp.hip, EmdMlpBranch.xb); EMD_MLP_RECOMPUTE_H=0: the trunk launch (A/B)
+RECOMPUTE_H = os.environ.get("EMD_MLP_RECOMPUTE_H", "1") != "0"
 
 
 def _stream():
@@ -40,17 +43,24 @@ class _LevelMLP(torch.autograd.Function):
         xa_c, xb_c, w0_c, b_c = f(xa), f(xb), f(w0), f(b_eff)
         params_c = [f(p) for p in params]
         N = (xa_c if xa_c is not None else xb_c).shape[0]
-        h = torch.empty(N, WIDTH, device=dev, dtype=torch.float32)
+        # A level without HexPlane features (`no_fine_hexplane_features`, the reference's run script): h = b + W0[:, emb] emb is eight MFMAs per 32
+        # rows, so every one-hidden-layer head recomputes it from the [N, kb] embedding (EmdMlpBranch.xb) -- no trunk launch, no [N, 64] tensor
+        # written once and read back by every head in both directions.  (RECOMPUTE_H = False keeps the trunk launch: the A/B switch.)
+        recompute = RECOMPUTE_H and xa_c is None and xb_c is not None and all(depth == 1 for _, depth, _ in branches)
+        h = None if recompute else torch.empty(N, WIDTH, device=dev, dtype=torch.float32)
         t = L.EmdMlpTrunk()
         t.num_points, t.ka, t.kb, t.ld_w = N, 0 if xa_c is None else xa_c.shape[1], 0 if xb_c is None else xb_c.shape[1], w0_c.shape[1]
         t.col_a, t.col_b = int(col_a), int(col_b)
-        t.xa, t.xb, t.w, t.b, t.h = L.ptr(xa_c), L.ptr(xb_c), w0_c.data_ptr(), b_c.data_ptr(), h.data_ptr()
-        L.check(lib.emd_mlp_trunk_forward(C.byref(t), _stream()), "emd_mlp_trunk_forward")
+        t.xa, t.xb, t.w, t.b, t.h = L.ptr(xa_c), L.ptr(xb_c), w0_c.data_ptr(), b_c.data_ptr(), L.ptr(h)
+        if not recompute:
+            L.check(lib.emd_mlp_trunk_forward(C.byref(t), _stream()), "emd_mlp_trunk_forward")
         outs, structs, i = [], [], 0
         l1 = torch.zeros(max(len(l1_heads), 1), device=dev, dtype=torch.float32)
         for k, (relu_input, depth, out_dim) in enumerate(branches):
             b = L.EmdMlpBranch()
-            b.num_points, b.depth, b.relu_input, b.out_dim, b.h = N, depth, 1 if relu_input else 0, out_dim, h.data_ptr()
+            b.num_points, b.depth, b.relu_input, b.out_dim, b.h = N, depth, 1 if relu_input else 0, out_dim, L.ptr(h)
+            if recompute:
+                b.xb, b.w_in, b.b_in, b.kb_in, b.ld_w_in, b.col_in = xb_c.data_ptr(), w0_c.data_ptr(), b_c.data_ptr(), t.kb, t.ld_w, t.col_b
             for d in range(depth):
                 b.w_hidden[d], b.b_hidden[d] = params_c[i].data_ptr(), params_c[i + 1].data_ptr()
                 i += 2

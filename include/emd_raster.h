@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 25
+#define EMD_ABI_VERSION 26
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -680,7 +680,7 @@ typedef struct EmdMlpTrunk {
     const float* xb;                             /* [N, kb] or NULL */
     const float* w;                              /* [64, ld_w] */
     const float* b;                              /* [64] effective bias */
-    float* h;                                    /* [N, 64] pre-activation: out (forward), in (backward) */
+    float* h;                                    /* [N, 64] pre-activation: written by the forward; the backward does not read it (may be NULL there, ABI 26) */
 } EmdMlpTrunk;
 
 typedef struct EmdMlpTrunkGrads {
@@ -702,6 +702,14 @@ typedef struct EmdMlpBranch {
     float* out;                                  /* [N,out_dim] (forward) */
     float* l1_sum;                               /* optional (ABI 20), [1], ZEROED BY THE CALLER: the forward adds mean |out| to it -- the L1 regulariser
                                                     of a residual head (S3Gaussian/train.py:238-310) formed while the outputs are stored */
+    /* optional (ABI 26), depth 1 only: a level WITHOUT HexPlane features (`no_fine_hexplane_features`, the reference's run script: the trunk's
+     * input is the per-Gaussian embedding alone, S3Gaussian/scene/deformation.py:256-296).  h = b_in + w_in[:, col_in : col_in + kb_in] xb is then
+     * eight fp32 MFMAs per 32 rows: with `xb` set the head forms h itself, in the trunk kernel's operation order (same bits), and `h` may be NULL --
+     * no [N,64] tensor is written by a trunk launch and read back by every head, forward and backward. */
+    const float* xb;                             /* [N,kb_in] */
+    const float* w_in;                           /* the trunk's weight [64, ld_w_in] */
+    const float* b_in;                           /* [64]: its bias plus whatever is constant over the Gaussians */
+    int32_t kb_in, ld_w_in, col_in, reserved;    /* kb_in 1..8 */
 } EmdMlpBranch;
 
 typedef struct EmdMlpBranchGrads {

@@ -38,10 +38,11 @@ def test_struct_layout_matches_c():
     prog = r'''
 #include <stdio.h>
 #include "emd_raster.h"
-int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(EmdSettings), sizeof(EmdMotion), sizeof(EmdDims),
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(EmdSettings), sizeof(EmdMotion), sizeof(EmdDims),
  sizeof(EmdFwdArgs), sizeof(EmdBwdArgs), sizeof(EmdStatus), sizeof(EmdSkyArgs), sizeof(EmdSkyBwdArgs), sizeof(EmdLossArgs),
  sizeof(EmdHexArgs), sizeof(EmdHexGrads), sizeof(EmdDeformInArgs), sizeof(EmdAdamTensor), sizeof(EmdAdamArgs),
- sizeof(EmdTrackArgs), sizeof(EmdTrackGrads), sizeof(EmdTrackedPoseArgs), sizeof(EmdTrackedPoseGrads), sizeof(EmdStepSelect));return 0;}
+ sizeof(EmdTrackArgs), sizeof(EmdTrackGrads), sizeof(EmdTrackedPoseArgs), sizeof(EmdTrackedPoseGrads), sizeof(EmdStepSelect),
+ sizeof(EmdMlpTrunk), sizeof(EmdMlpTrunkGrads), sizeof(EmdMlpBranch), sizeof(EmdMlpBranchGrads));return 0;}
 '''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
@@ -55,7 +56,8 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %
     assert sizes[6:] == [C.sizeof(L.EmdSkyArgs), C.sizeof(L.EmdSkyBwdArgs), C.sizeof(L.EmdLossArgs), C.sizeof(L.EmdHexArgs),
                          C.sizeof(L.EmdHexGrads), C.sizeof(L.EmdDeformInArgs), C.sizeof(L.EmdAdamTensor), C.sizeof(L.EmdAdamArgs),
                          C.sizeof(L.EmdTrackArgs), C.sizeof(L.EmdTrackGrads), C.sizeof(L.EmdTrackedPoseArgs),
-                         C.sizeof(L.EmdTrackedPoseGrads), C.sizeof(L.EmdStepSelect)]
+                         C.sizeof(L.EmdTrackedPoseGrads), C.sizeof(L.EmdStepSelect),
+                         C.sizeof(L.EmdMlpTrunk), C.sizeof(L.EmdMlpTrunkGrads), C.sizeof(L.EmdMlpBranch), C.sizeof(L.EmdMlpBranchGrads)]
 
 
 def test_workspace_size_host_only():

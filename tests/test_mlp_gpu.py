@@ -57,7 +57,11 @@ def _leaves(net):
     (96, 16, 4, [(True, 1, 3), (True, 1, 3), (True, 1, 4), (True, 1, 1), (True, 1, 48), (False, 2, 3)]),   # the goldens' network: 16 HexPlane features, six heads
     (500, 72, 5, [(True, 1, 7)]),                                                         # xa ends inside its third tile, odd embedding width
     (70001, 128, 4, [(True, 1, 3), (True, 1, 48)]),                                       # many tiles per wave
-], ids=["coarse", "fine", "ragged", "golden-shape", "ka72", "70k"])
+    # levels without HexPlane features whose heads all have one hidden layer: no trunk launch, every head forms h from the embedding (EmdMlpBranch.xb)
+    (1000, 0, 4, [(True, 1, 3), (True, 1, 1), (True, 1, 48)]),                            # the fine level of the run script without the feature head
+    (37, 0, 8, [(True, 1, 4), (False, 1, 64)]),                                           # ragged tile, the widest embedding, an un-rectified input
+    (70001, 0, 5, [(True, 1, 3), (True, 1, 48)]),                                         # many tiles per wave, odd embedding width
+], ids=["coarse", "fine", "ragged", "golden-shape", "ka72", "70k", "fine-recomputed", "ragged-recomputed", "70k-recomputed"])
 def test_level_mlp_matches_float64(N, ka, kb, heads):
     from emd_amd.mlp import level_mlp
     g = torch.Generator().manual_seed(N + ka + kb)
@@ -152,3 +156,55 @@ def test_level_mlp_head_regulariser_is_folded_into_the_head_kernels(with_gout):
         assert (x is None) == (y is None), k
         if x is not None:
             assert float((x - y).abs().max()) <= 2e-5 * max(float(y.abs().max()), 1e-20), (k, float((x - y).abs().max()), float(y.abs().max()))
+
+
+@pytest.mark.parametrize("l1", [False, True])
+def test_heads_that_recompute_h_equal_the_trunk_launch_bit_for_bit(l1):
+    """A level without HexPlane features: the heads form h = b + W0[:, emb] emb themselves (EmdMlpBranch.xb, eight MFMAs per 32 rows in the trunk
+    kernel's own operation order) instead of reading the [N, 64] tensor a trunk launch wrote.  Same bits in every head output and in dL/dxb;
+    the weight gradients (float atomics over the workgroups) to rounding."""
+    from emd_amd import mlp
+    g = torch.Generator().manual_seed(77)
+    N, kb, heads = 5003, 4, [(True, 1, 3), (True, 1, 48), (True, 1, 1)]
+    net = _net(g, 0, kb, heads)
+    xb = torch.randn(N, kb, generator=g)
+    gouts = [torch.randn(N, o, generator=g).to(DEV) for _, _, o in heads]
+
+    def run(recompute):
+        c = lambda t: t.detach().to(DEV, torch.float32).requires_grad_(True)
+        hb = c(xb)
+        hnet = dict(w0=c(net["w0"]), b=c(net["b"]), branches=[(ri, [(c(w), c(b)) for w, b in hid], (c(wo), c(bo))) for ri, hid, (wo, bo) in net["branches"]])
+        old, mlp.RECOMPUTE_H = mlp.RECOMPUTE_H, recompute
+        try:
+            outs = mlp.level_mlp(None, hb, hnet["w0"], hnet["b"], net["col_a"], net["col_b"], hnet["branches"], l1_heads=[1] if l1 else [])
+            loss = sum((o * go).sum() for o, go in zip(outs[:3], gouts))
+            if l1:
+                loss = loss + 0.9 * outs[3]
+            loss.backward()
+        finally:
+            mlp.RECOMPUTE_H = old
+        leaves = [hnet["w0"], hnet["b"]] + [t for _, hid, (wo, bo) in hnet["branches"] for t in [x for wb in hid for x in wb] + [wo, bo]]
+        return [o.detach() for o in outs], hb.grad, [t.grad for t in leaves]
+    oa, da, ga = run(True)
+    ob, db, gb = run(False)
+    for k, (x, y) in enumerate(zip(oa[:3], ob[:3])):
+        assert torch.equal(x, y), ("output", k)
+    assert torch.equal(da, db)
+    for k, (x, y) in enumerate(zip(ga, gb)):
+        assert float((x - y).abs().max()) <= 2e-5 * max(float(y.abs().max()), 1e-20), (k, float((x - y).abs().max()))
+
+
+def test_recomputed_h_is_refused_for_two_hidden_layers():
+    import ctypes as C
+    from emd_amd import _lib as L
+    lib = L.load()
+    t = torch.zeros(64, 64, device=DEV)
+    b = L.EmdMlpBranch()
+    b.num_points, b.depth, b.relu_input, b.out_dim = 32, 2, 0, 3
+    for d in range(2):
+        b.w_hidden[d], b.b_hidden[d] = t.data_ptr(), t.data_ptr()
+    b.w_out, b.b_out, b.out = t.data_ptr(), t.data_ptr(), t.data_ptr()
+    b.xb, b.w_in, b.b_in, b.kb_in, b.ld_w_in, b.col_in = t.data_ptr(), t.data_ptr(), t.data_ptr(), 4, 64, 0
+    assert lib.emd_mlp_branch_forward(C.byref(b), None) == L.EMD_ERR_INVALID
+    b.depth, b.kb_in = 1, 9
+    assert lib.emd_mlp_branch_forward(C.byref(b), None) == L.EMD_ERR_INVALID
