@@ -146,6 +146,30 @@ __device__ __forceinline__ void store_tile_narrow(float* __restrict__ dst, int w
     }
 }
 
+// RAW tile loads for the backward kernels' loop-carried prefetches (round 5).  A guarded load (a branch around it, or a select / product right behind
+// it) makes the compiler wait for the load where it is issued -- with `s_waitcnt vmcnt(0)`, i.e. for every other load in flight too: the head
+// kernels stalled for a full HBM round trip at the top of every tile.  So: the caller clamps the row, columns >= width read column 0, nothing is
+// masked here; the values travel raw across the loop iteration and are masked (mask_tile) where they are used.
+__device__ __forceinline__ f32x16 load_tile_raw(const float* __restrict__ src, size_t ld, size_t row_c, int c0, int hh, int width = 1 << 30) {
+    f32x16 t;
+    const float* p = src + row_c * ld;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int c = c0 + 8 * a + 4 * hh;
+        const float4 q = ld4(p + (c < width ? c : 0));
+        t[4 * a] = q.x; t[4 * a + 1] = q.y; t[4 * a + 2] = q.z; t[4 * a + 3] = q.w;
+    }
+    return t;
+}
+__device__ __forceinline__ f32x16 mask_tile(f32x16 t, bool ok, int c0, int hh, int width) {
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const float keep = (ok && c0 + 8 * a + 4 * hh < width) ? 1.f : 0.f;
+        t[4 * a] *= keep; t[4 * a + 1] *= keep; t[4 * a + 2] *= keep; t[4 * a + 3] *= keep;
+    }
+    return t;
+}
+
 // bias as the initial accumulator: register v of lane half hh holds feature c0 + 8 (v / 4) + 4 hh + v % 4
 __device__ __forceinline__ f32x16 bias_tile(const float* __restrict__ b_lds, int c0, int hh) {
     f32x16 t;
@@ -636,8 +660,8 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
         }
 #pragma unroll
         for (int t = 0; t < NTO; t++) {
-            // (a wide tile may still hang over the row's end: out_dim = 48 -> the second tile holds features 32..47)
-            if (wide_out && 32 * t + 32 <= a.out_dim) store_tile(a.out, a.out_dim, row, ok, 32 * t, hh, o[t]);
+            // (a wide tile may still hang over the row's end: out_dim = 48 -> the second tile holds features 32..47: whole 16-byte pieces, bounded by the width)
+            if (wide_out) store_tile(a.out, a.out_dim, row, ok, 32 * t, hh, o[t], a.out_dim);
             else store_tile_narrow(a.out, a.out_dim, row, ok, 32 * t, hh, o[t]);
         }
     }
@@ -647,7 +671,12 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
     }
 }
 
-template <int DEPTH, int NTO, bool L1 = false, bool RC = false>
+// GO: how dL/dout reaches the kernel.  0: at most four outputs (dx / do heads, NTO = 1): four raw values per row; 1: out_dim a multiple of 4
+// (dshs: 48): raw 16-byte pieces, a partial tile masked by whole pieces; 2: any width (guarded loads, masked at the load: the old path)
+// CHAIN (GO 0 / 1): g_h_in is present.  A runtime branch around a group of loads would do: but then the number of loads in flight differs between the
+// paths, the compiler's wait for the PREVIOUS iteration's prefetch has to assume the smaller one, and that wait lands on the loads just issued.
+// GO 0 / 1 therefore take every such decision at compile time (and need g_out; without it the launcher picks GO 2).
+template <int DEPTH, int NTO, bool L1 = false, bool RC = false, int GO = 2, bool CHAIN = false>
 __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_branch_bwd(EmdMlpBranch a, EmdMlpBranchGrads g) {
     typedef BranchLds<DEPTH, NTO, branch_mode(DEPTH, NTO, true)> L;
     extern __shared__ float lds[];
@@ -680,39 +709,64 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
         }
         return v;
     };
-    // the next tile's h and g_out are loaded while this tile computes (one wave per SIMD: nothing else hides the HBM latency)
+    // the next tile's h and g_out are loaded while this tile computes (one wave per SIMD: nothing else hides the HBM latency).  Every load of the
+    // loop is unconditional and raw (see load_tile_raw); rows past the end read row 0 and their dL/dout is masked to zero where it is used, which
+    // zeroes everything they could contribute (their h needs no mask: a finite activation times a zero gradient).
+    auto rowc = [&](size_t row_) -> size_t { return row_ < N ? row_ : 0; };
     f32x16 nh[2];
     float nxb[4];
-    if constexpr (RC) load_xb_raw(a.xb, a.kb_in, tile0 * 32 + r, tile0 * 32 + r < N, hh, nxb);
-    else { nh[0] = load_tile(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 0, hh); nh[1] = load_tile(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 32, hh); }
     f32x16 ngo[NTO];
+    float ngn[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](size_t row_) {                      // h (or the embedding) and dL/dout of one tile
+        const size_t rcl = rowc(row_);
+        if constexpr (RC) load_xb_raw(a.xb, a.kb_in, row_, row_ < N, hh, nxb);
+        else { nh[0] = load_tile_raw(a.h, 64, rcl, 0, hh); nh[1] = load_tile_raw(a.h, 64, rcl, 32, hh); }
+        if constexpr (GO == 0) {
 #pragma unroll
-    for (int t = 0; t < NTO; t++) ngo[t] = load_go(tile0 * 32 + r, tile0 * 32 + r < N, t);
+            for (int j = 0; j < 4; j++) ngn[j] = g.g_out[rcl * (size_t)a.out_dim + (j < a.out_dim ? j : 0)];
+        } else if constexpr (GO == 1) {
+#pragma unroll
+            for (int t = 0; t < NTO; t++) ngo[t] = load_tile_raw(g.g_out, a.out_dim, rcl, 32 * t, hh, a.out_dim);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NTO; t++) ngo[t] = load_go(row_, row_ < N, t);
+        }
+    };
+    fetch(tile0 * 32 + r);
     for (size_t tile = tile0; tile < tiles; tile += tstep) {
         const size_t row = tile * 32 + r;
         const bool ok = row < N;
         // ---- recompute the forward
         f32x16 hin[2];
         f32x16 go[NTO];
+        float gn[4];
+        if constexpr (GO == 0) {
 #pragma unroll
-        for (int t = 0; t < NTO; t++) go[t] = ngo[t];
-        {
-            const size_t nrow = (tile + tstep) * 32 + r;
-            if constexpr (RC) {
-                float xb[4];
-                mask_xb(nxb, a.kb_in, ok, hh, xb);
-                load_xb_raw(a.xb, a.kb_in, nrow, nrow < N, hh, nxb);
-                embed_h(rc, rc + 64 * 12, r, hh, xb, hin);
-            } else {
-                hin[0] = nh[0]; hin[1] = nh[1];
-                nh[0] = load_tile(a.h, 64, nrow, nrow < N, 0, hh); nh[1] = load_tile(a.h, 64, nrow, nrow < N, 32, hh);
-            }
+            for (int j = 0; j < 4; j++) gn[j] = ngn[j];
+        } else {
 #pragma unroll
-            for (int t = 0; t < NTO; t++) ngo[t] = load_go(nrow, nrow < N, t);
+            for (int t = 0; t < NTO; t++) go[t] = ngo[t];
         }
-        // the sum of the earlier heads' dL/dh for these rows (EmdMlpBranchGrads.g_h_in), requested now and added before the store
+        float xbm[4];
+        if constexpr (RC) mask_xb(nxb, a.kb_in, ok, hh, xbm);
+        else { hin[0] = nh[0]; hin[1] = nh[1]; }
+        // this tile's forward outputs (the L1 term's sign) and the earlier heads' dL/dh (EmdMlpBranchGrads.g_h_in, added before the store) are
+        // requested first -- older than the prefetches behind them, so waiting for them later does not wait for those
+        f32x16 oraw[NTO];
+        float on[4];
+        if constexpr (L1 && GO == 0) {                    // (an L1 kernel is launched with l1_grad and the forward's outputs present)
+#pragma unroll
+            for (int j = 0; j < 4; j++) on[j] = g.out[rowc(row) * (size_t)a.out_dim + (j < a.out_dim ? j : 0)];
+        } else if constexpr (L1 && GO == 1) {
+#pragma unroll
+            for (int t = 0; t < NTO; t++) oraw[t] = load_tile_raw(g.out, a.out_dim, rowc(row), 32 * t, hh, a.out_dim);
+        }
         f32x16 gin[2] = {zero16(), zero16()};
-        if (DEPTH == 1 && g.g_h_in) { gin[0] = load_tile(g.g_h_in, 64, row, ok, 0, hh); gin[1] = load_tile(g.g_h_in, 64, row, ok, 32, hh); }
+        if constexpr (GO == 2) {
+            if (DEPTH == 1 && g.g_h_in) { gin[0] = load_tile(g.g_h_in, 64, row, ok, 0, hh); gin[1] = load_tile(g.g_h_in, 64, row, ok, 32, hh); }
+        } else if constexpr (CHAIN) { gin[0] = load_tile_raw(g.g_h_in, 64, rowc(row), 0, hh); gin[1] = load_tile_raw(g.g_h_in, 64, rowc(row), 32, hh); }
+        fetch((tile + tstep) * 32 + r);
+        if constexpr (RC) embed_h(rc, rc + 64 * 12, r, hh, xbm, hin);
         f32x16 x[2] = {hin[0], hin[1]};
         if (a.relu_input) { x[0] = relu16(x[0]); x[1] = relu16(x[1]); }
         f32x16 m1[2] = {bias_tile(lds + L::b1, 0, hh), bias_tile(lds + L::b1, 32, hh)};
@@ -725,6 +779,25 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
             m2[0] = relu16(m2[0]); m2[1] = relu16(m2[1]);
         }
         f32x16 (&last)[2] = DEPTH == 2 ? m2 : m1;          // the activation that feeds the output layer
+        // ---- dL/dout of this tile from its raw pieces: masked here, after the forward's MFMAs, where it is first needed
+        if constexpr (GO == 0) {
+            go[0] = zero16();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float v = gn[j];
+                if constexpr (L1) v += on[j] > 0.f ? l1_s : (on[j] < 0.f ? -l1_s : 0.f);
+                go[0][j] = v * ((ok && hh == 0 && j < a.out_dim) ? 1.f : 0.f);
+            }
+        } else if constexpr (GO == 1) {
+#pragma unroll
+            for (int t = 0; t < NTO; t++) {
+                if constexpr (L1) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) go[t][k] += oraw[t][k] > 0.f ? l1_s : (oraw[t][k] < 0.f ? -l1_s : 0.f);
+                }
+                go[t] = mask_tile(go[t], ok, 32 * t, hh, a.out_dim);
+            }
+        }
         // ---- output layer
         f32x16 gl[2] = {zero16(), zero16()};
         if (NTO == 1 && a.out_dim <= 8) mm<L::SP, NTO, 2, 1>(gl, go, lds + L::wot, L::WOT, 0, 2, 2 * NTO, r, hh, lane);  // dx / do / feat: one 8-feature chunk carries everything
@@ -766,7 +839,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(MLP_BWD_WAVES) k_mlp_bran
         f32x16 gx[2] = {zero16(), zero16()};
         mm<L::SP, 2, 2>(gx, g1, lds + L::w1t, WS, 0, 2, 4, r, hh, lane);
         if (a.relu_input) { gx[0] = mask16(gx[0], hin[0]); gx[1] = mask16(gx[1], hin[1]); }
-        if (DEPTH == 1 && g.g_h_in) { gx[0] += gin[0]; gx[1] += gin[1]; }     // (one-hidden-layer heads only: the other kernel has no registers left)
+        if ((GO == 2 && DEPTH == 1 && g.g_h_in) || (GO != 2 && CHAIN)) { gx[0] += gin[0]; gx[1] += gin[1]; }     // (one-hidden-layer heads only: the other kernel has no registers left)
         store_tile(g.g_h, 64, row, ok, 0, hh, gx[0]);
         store_tile(g.g_h, 64, row, ok, 32, hh, gx[1]);
         {
@@ -892,7 +965,12 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(KTA == 0 ? MLP_W_T0 : MLP
     }
 }
 
-template <int KTA>
+// The loop's loads (round 5): dL/dh of the NEXT tile is the prefetch (32 registers; it is the first thing a tile needs), xa / xb of THIS tile are
+// requested at the top of the iteration and first read after the dL/dxa product (96 MFMAs later) -- before, xa / xb of the next tile travelled (64
+// registers) while dL/dh was loaded and waited for in place, a full HBM round trip per tile.  All of them raw and unconditional (load_tile_raw): rows
+// past the end read row 0, and dL/dh is zeroed for them where it is used, which zeroes all they could add.  MULTI: more than one dL/dh tensor (a
+// two-hidden-layer head keeps its own): the others are loaded inside the loop, guarded as before.
+template <int KTA, bool MULTI = false>
 __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(KTA == 0 ? MLP_W_TB0 : MLP_BWD_WAVES) k_mlp_trunk_bwd(EmdMlpTrunk a, EmdMlpTrunkGrads g) {
     typedef TrunkLds<KTA, MLP_SP_TB> L;
     extern __shared__ float lds[];
@@ -914,29 +992,33 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(KTA == 0 ? MLP_W_TB0 : ML
         for (int t = 0; t < (KTA ? KTA : 1); t++) dWa[to][t] = zero16();
     }
     const size_t tile0 = (size_t)blockIdx.x * MLP_WAVES + wave, tstep = (size_t)gridDim.x * MLP_WAVES;
-    // xa / xb of the next tile travel while this one computes; the dL/dh contributions are summed at the top of the tile
-    f32x16 nxa[KTA ? KTA : 1];
-    float nxb[4];
-    trunk_load_x<KTA, false>(a, tile0 * 32 + r, tile0 * 32 + r < N, hh, nxa, nxb);
+    auto rowc = [&](size_t row_) -> size_t { return row_ < N ? row_ : 0; };
+    f32x16 ngh[2] = {load_tile_raw(g.g_h[0], 64, rowc(tile0 * 32 + r), 0, hh), load_tile_raw(g.g_h[0], 64, rowc(tile0 * 32 + r), 32, hh)};
     for (size_t tile = tile0; tile < tiles; tile += tstep) {
         const size_t row = tile * 32 + r;
         const bool ok = row < N;
         // dL/dh: the sum of the branches' contributions
-        f32x16 gh[2] = {zero16(), zero16()};
-        for (int k = 0; k < g.num_gh; k++) {
-            const f32x16 p0 = load_tile(g.g_h[k], 64, row, ok, 0, hh), p1 = load_tile(g.g_h[k], 64, row, ok, 32, hh);
-#pragma unroll
-            for (int v = 0; v < 16; v++) { gh[0][v] += p0[v]; gh[1][v] += p1[v]; }
-        }
+        f32x16 gh[2] = {mask_tile(ngh[0], ok, 0, hh, 64), mask_tile(ngh[1], ok, 32, hh, 64)};
         f32x16 xa[KTA ? KTA : 1];
         float xb[4];
+        if (KTA) {
 #pragma unroll
-        for (int t = 0; t < (KTA ? KTA : 1); t++) xa[t] = nxa[t];
+            for (int t = 0; t < KTA; t++) xa[t] = load_tile_raw(a.xa, a.ka, rowc(row), 32 * t, hh, a.ka);
+        }
+        if (a.kb > 0) {                                  // (kernel-uniform, the same loads every iteration)
 #pragma unroll
-        for (int j = 0; j < 4; j++) xb[j] = nxb[j];
+            for (int j = 0; j < 4; j++) xb[j] = a.xb[rowc(row) * (size_t)a.kb + (4 * hh + j < a.kb ? 4 * hh + j : 0)];
+        }
         {
-            const size_t nrow = (tile + tstep) * 32 + r;
-            trunk_load_x<KTA, false>(a, nrow, nrow < N, hh, nxa, nxb);
+            const size_t nrow = rowc((tile + tstep) * 32 + r);
+            ngh[0] = load_tile_raw(g.g_h[0], 64, nrow, 0, hh); ngh[1] = load_tile_raw(g.g_h[0], 64, nrow, 32, hh);
+        }
+        if constexpr (MULTI) {
+            for (int k = 1; k < g.num_gh; k++) {
+                const f32x16 p0 = load_tile(g.g_h[k], 64, row, ok, 0, hh), p1 = load_tile(g.g_h[k], 64, row, ok, 32, hh);
+#pragma unroll
+                for (int v = 0; v < 16; v++) { gh[0][v] += p0[v]; gh[1][v] += p1[v]; }
+            }
         }
         const f32x16 gf[2] = {transpose_tile(gh[0], T, r, hh), transpose_tile(gh[1], T, r, hh)};
         db[0] += frag_sum(gf[0]); db[1] += frag_sum(gf[1]);
@@ -967,9 +1049,10 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(KTA == 0 ? MLP_W_TB0 : ML
             }
         }
         if (a.kb > 0) {
-            // xb as a tile: feature c = 8 (v / 4) + 4 hh + v % 4 < kb <= 8 lives in registers 0..3
+            // xb as a tile: feature c = 8 (v / 4) + 4 hh + v % 4 < kb <= 8 lives in registers 0..3 (columns >= kb were read from column 0: zeroed here)
             f32x16 xt = zero16();
-            xt[0] = xb[0]; xt[1] = xb[1]; xt[2] = xb[2]; xt[3] = xb[3];
+#pragma unroll
+            for (int j = 0; j < 4; j++) xt[j] = xb[j] * ((4 * hh + j < a.kb) ? 1.f : 0.f);
             const f32x16 af = transpose_tile(xt, T, r, hh);
             dWb[0] = outer_acc(dWb[0], gf[0], af);
             dWb[1] = outer_acc(dWb[1], gf[1], af);
@@ -1218,6 +1301,24 @@ extern "C" int emd_mlp_branch_forward(const EmdMlpBranch* a, void* hip_stream) {
     return mlp_launch<k_mlp_branch_fwd<2, 2>, MLP_FWD_WAVES>(BranchLds<2, 2, branch_mode(2, 2, false)>::fwd_floats, a->num_points, st, *a);
 }
 
+template <int DEPTH, int NTO, bool L1, bool RC, int GO, bool CHAIN = false>
+int launch_branch_bwd(const EmdMlpBranch* a, const EmdMlpBranchGrads* g, hipStream_t st) {
+    typedef BranchLds<DEPTH, NTO, branch_mode(DEPTH, NTO, true)> L;
+    return mlp_launch<k_mlp_branch_bwd<DEPTH, NTO, L1, RC, GO, CHAIN>, MLP_BWD_WAVES>(L::bwd_floats + (RC ? L::rc_floats : 0), a->num_points, st, *a, *g);
+}
+// one-hidden-layer heads: by output tiles, regulariser, recomputed h, the form dL/dout is loaded in and the chained dL/dh (k_mlp_branch_bwd's GO / CHAIN)
+template <int NTO, bool L1, bool RC>
+int launch_branch_bwd1(const EmdMlpBranch* a, const EmdMlpBranchGrads* g, hipStream_t st) {
+    const bool chain = g->g_h_in != nullptr;
+    if (g->g_out) {
+        if constexpr (NTO == 1) {
+            if (a->out_dim <= 4) return chain ? launch_branch_bwd<1, 1, L1, RC, 0, true>(a, g, st) : launch_branch_bwd<1, 1, L1, RC, 0, false>(a, g, st);
+        }
+        if ((a->out_dim & 3) == 0) return chain ? launch_branch_bwd<1, NTO, L1, RC, 1, true>(a, g, st) : launch_branch_bwd<1, NTO, L1, RC, 1, false>(a, g, st);
+    }
+    return launch_branch_bwd<1, NTO, L1, RC, 2>(a, g, st);
+}
+
 extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranchGrads* g, void* hip_stream) {
     int rc = check_branch(a, "mlp_branch_backward");
     if (rc || a->num_points == 0) return rc;
@@ -1226,27 +1327,22 @@ extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranch
     if (g->g_h_in && ((uintptr_t)g->g_h_in & 15)) { emd_set_error("mlp_branch_backward: g_h_in must be 16-byte aligned"); return EMD_ERR_INVALID; }
     if (g->l1_grad && !g->out) { emd_set_error("mlp_branch_backward: l1_grad needs the forward's output tensor"); return EMD_ERR_INVALID; }
     if (((uintptr_t)g->g_h & 15)) { emd_set_error("mlp_branch_backward: g_h must be 16-byte aligned"); return EMD_ERR_INVALID; }
+    if (!(a->out_dim & 3) && (((uintptr_t)g->g_out & 15) || ((uintptr_t)g->out & 15))) {
+        emd_set_error("mlp_branch_backward: g_out / out must be 16-byte aligned when out_dim is a multiple of 4"); return EMD_ERR_INVALID;
+    }
     hipStream_t st = (hipStream_t)hip_stream;
     const int nto = a->out_dim > 32 ? 2 : 1;
-    if (a->xb) {
-        typedef BranchLds<1, 1, branch_mode(1, 1, true)> L1_; typedef BranchLds<1, 2, branch_mode(1, 2, true)> L2_;
-        if (g->l1_grad) {
-            if (nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1, true, true>, MLP_BWD_WAVES>(L1_::bwd_floats + L1_::rc_floats, a->num_points, st, *a, *g);
-            return mlp_launch<k_mlp_branch_bwd<1, 2, true, true>, MLP_BWD_WAVES>(L2_::bwd_floats + L2_::rc_floats, a->num_points, st, *a, *g);
+    const bool l1 = g->l1_grad != nullptr, rcm = a->xb != nullptr;
+    if (a->depth == 1) {
+        if (nto == 1) {
+            if (l1) return rcm ? launch_branch_bwd1<1, true, true>(a, g, st) : launch_branch_bwd1<1, true, false>(a, g, st);
+            return rcm ? launch_branch_bwd1<1, false, true>(a, g, st) : launch_branch_bwd1<1, false, false>(a, g, st);
         }
-        if (nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1, false, true>, MLP_BWD_WAVES>(L1_::bwd_floats + L1_::rc_floats, a->num_points, st, *a, *g);
-        return mlp_launch<k_mlp_branch_bwd<1, 2, false, true>, MLP_BWD_WAVES>(L2_::bwd_floats + L2_::rc_floats, a->num_points, st, *a, *g);
+        if (l1) return rcm ? launch_branch_bwd1<2, true, true>(a, g, st) : launch_branch_bwd1<2, true, false>(a, g, st);
+        return rcm ? launch_branch_bwd1<2, false, true>(a, g, st) : launch_branch_bwd1<2, false, false>(a, g, st);
     }
-    if (g->l1_grad) {
-        if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1, true>, MLP_BWD_WAVES>(BranchLds<1, 1, branch_mode(1, 1, true)>::bwd_floats, a->num_points, st, *a, *g);
-        if (a->depth == 1) return mlp_launch<k_mlp_branch_bwd<1, 2, true>, MLP_BWD_WAVES>(BranchLds<1, 2, branch_mode(1, 2, true)>::bwd_floats, a->num_points, st, *a, *g);
-        if (nto == 1) return mlp_launch<k_mlp_branch_bwd<2, 1, true>, MLP_BWD_WAVES>(BranchLds<2, 1, branch_mode(2, 1, true)>::bwd_floats, a->num_points, st, *a, *g);
-        return mlp_launch<k_mlp_branch_bwd<2, 2, true>, MLP_BWD_WAVES>(BranchLds<2, 2, branch_mode(2, 2, true)>::bwd_floats, a->num_points, st, *a, *g);
-    }
-    if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_bwd<1, 1>, MLP_BWD_WAVES>(BranchLds<1, 1, branch_mode(1, 1, true)>::bwd_floats, a->num_points, st, *a, *g);
-    if (a->depth == 1) return mlp_launch<k_mlp_branch_bwd<1, 2>, MLP_BWD_WAVES>(BranchLds<1, 2, branch_mode(1, 2, true)>::bwd_floats, a->num_points, st, *a, *g);
-    if (nto == 1) return mlp_launch<k_mlp_branch_bwd<2, 1>, MLP_BWD_WAVES>(BranchLds<2, 1, branch_mode(2, 1, true)>::bwd_floats, a->num_points, st, *a, *g);
-    return mlp_launch<k_mlp_branch_bwd<2, 2>, MLP_BWD_WAVES>(BranchLds<2, 2, branch_mode(2, 2, true)>::bwd_floats, a->num_points, st, *a, *g);
+    if (l1) return nto == 1 ? launch_branch_bwd<2, 1, true, false, 2>(a, g, st) : launch_branch_bwd<2, 2, true, false, 2>(a, g, st);
+    return nto == 1 ? launch_branch_bwd<2, 1, false, false, 2>(a, g, st) : launch_branch_bwd<2, 2, false, false, 2>(a, g, st);
 }
 
 extern "C" int emd_mlp_trunk_forward(const EmdMlpTrunk* a, void* hip_stream) {
@@ -1260,6 +1356,12 @@ extern "C" int emd_mlp_trunk_forward(const EmdMlpTrunk* a, void* hip_stream) {
         case 3: return mlp_launch<k_mlp_trunk_fwd<3>, MLP_FWD_WAVES>(TrunkLds<3, MLP_SP_TF>::fwd_floats, a->num_points, st, *a);
         default: return mlp_launch<k_mlp_trunk_fwd<4>, MLP_FWD_WAVES>(TrunkLds<4, MLP_SP_TF>::fwd_floats, a->num_points, st, *a);
     }
+}
+
+template <int KTA, int PER_CU>
+int launch_trunk_bwd(const EmdMlpTrunk* a, const EmdMlpTrunkGrads* g, hipStream_t st) {
+    if (g->num_gh == 1) return mlp_launch<k_mlp_trunk_bwd<KTA, false>, PER_CU>(TrunkLds<KTA, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
+    return mlp_launch<k_mlp_trunk_bwd<KTA, true>, PER_CU>(TrunkLds<KTA, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
 }
 
 extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGrads* g, void* hip_stream) {
@@ -1278,10 +1380,10 @@ extern "C" int emd_mlp_trunk_backward(const EmdMlpTrunk* a, const EmdMlpTrunkGra
                 EMD_LAUNCH_CHECK();
                 return EMD_OK;
             }
-            return mlp_launch<k_mlp_trunk_bwd<0>, MLP_W_TB0>(TrunkLds<0, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
-        case 1: return mlp_launch<k_mlp_trunk_bwd<1>, MLP_BWD_WAVES>(TrunkLds<1, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
-        case 2: return mlp_launch<k_mlp_trunk_bwd<2>, MLP_BWD_WAVES>(TrunkLds<2, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
-        case 3: return mlp_launch<k_mlp_trunk_bwd<3>, MLP_BWD_WAVES>(TrunkLds<3, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
-        default: return mlp_launch<k_mlp_trunk_bwd<4>, MLP_BWD_WAVES>(TrunkLds<4, MLP_SP_TB>::bwd_floats, a->num_points, st, *a, *g);
+            return launch_trunk_bwd<0, MLP_W_TB0>(a, g, st);
+        case 1: return launch_trunk_bwd<1, MLP_BWD_WAVES>(a, g, st);
+        case 2: return launch_trunk_bwd<2, MLP_BWD_WAVES>(a, g, st);
+        case 3: return launch_trunk_bwd<3, MLP_BWD_WAVES>(a, g, st);
+        default: return launch_trunk_bwd<4, MLP_BWD_WAVES>(a, g, st);
     }
 }
