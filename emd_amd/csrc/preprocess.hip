@@ -55,6 +55,9 @@
 #ifndef EMD_K1_NT_JAC
 #define EMD_K1_NT_JAC 1          /* K1's store of the colour Jacobian (read once, by K8, a whole step's traffic later) */
 #endif
+#ifndef EMD_K1_HOIST
+#define EMD_K1_HOIST 1           /* round 5 (late): K1 issues every index-addressed load of a Gaussian together, before the first use */
+#endif
 #ifndef EMD_K1_REVERSE
 #define EMD_K1_REVERSE 1         /* K1 walks the Gaussians from the last block to the first: what K8 touched last is what K1 reads first */
 #endif
@@ -107,39 +110,29 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 
 // raw = EMD_FLAG_RAW_PARAMS: opacities are logits (sigmoid here), static quaternions are un-normalised (normalised
 // here, F.normalize eps 1e-12) -- the activations of S3Gaussian/gaussian_renderer/__init__.py:99-101 fused in.
-__device__ __forceinline__ void motion_point(int i, const float* __restrict__ means, const float* __restrict__ quats,
-                                             const float* __restrict__ opac, const EmdMotion& mo, float wm[3],
-                                             float wq[4], float* wo, bool raw = false) {
-    float m[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-    if (mo.residual_dx) {
-        m[0] += mo.residual_dx[3 * i]; m[1] += mo.residual_dx[3 * i + 1]; m[2] += mo.residual_dx[3 * i + 2];
-    }
-    int a = mo.actor_id ? mo.actor_id[i] : -1;
+// The arithmetic of motion_point on values already in registers (round 5: K8 issues every load of a Gaussian together before any of them is used):
+// m = local mean (residual_dx applied), a = actor id or -1, q = the stored quaternion, dq_res = OmniRe's quaternion residual (dynamic points),
+// op_in = the stored opacity, p0 / p1 / p2 = the actor's pose rows (read when a >= 0 only).
+__device__ __forceinline__ void motion_apply(const float m[3], int a, bool has_q, float4 q, bool has_dq, float4 dq_res, bool has_op, float op_in, float4 p0,
+                                             float4 p1, float4 p2, bool raw, float wm[3], float wq[4], float* wo) {
     if (a < 0) {
         wm[0] = m[0]; wm[1] = m[1]; wm[2] = m[2];
-        if (quats) {
-            const float4 q = *(const float4*)(quats + 4 * i);
+        if (has_q) {
             wq[0] = q.x; wq[1] = q.y; wq[2] = q.z; wq[3] = q.w;
             if (raw) { const float n = fmaxf(quat_norm(wq), 1e-12f); wq[0] /= n; wq[1] /= n; wq[2] /= n; wq[3] /= n; }
         }
-        if (opac) *wo = raw ? sigmoidf_(opac[i]) : opac[i];
+        if (has_op) *wo = raw ? sigmoidf_(op_in) : op_in;
         return;
     }
-    const float4* Pp = (const float4*)(mo.actor_pose + (size_t)a * EMD_ACTOR_STRIDE);
-    const float4 p0 = Pp[0], p1 = Pp[1], p2 = Pp[2];
     const float qm[4] = {p0.x, p0.y, p0.z, p0.w};
     float R[9];
     quat_to_R(qm, R);
     wm[0] = ((R[0] * m[0] + R[1] * m[1]) + R[2] * m[2]) + p1.x;
     wm[1] = ((R[3] * m[0] + R[4] * m[1]) + R[5] * m[2]) + p1.y;
     wm[2] = ((R[6] * m[0] + R[7] * m[1]) + R[8] * m[2]) + p1.z;
-    if (quats) {
-        const float4 q = *(const float4*)(quats + 4 * i);
+    if (has_q) {
         float ql[4] = {q.x, q.y, q.z, q.w};
-        if (mo.residual_dq) {
-            const float4 d = *(const float4*)(mo.residual_dq + 4 * i);
-            ql[0] += d.x; ql[1] += d.y; ql[2] += d.z; ql[3] += d.w;
-        }
+        if (has_dq) { ql[0] += dq_res.x; ql[1] += dq_res.y; ql[2] += dq_res.z; ql[3] += dq_res.w; }
         float n = fmaxf(quat_norm(ql), 1e-12f);
         float qn[4] = {ql[0] / n, ql[1] / n, ql[2] / n, ql[3] / n};
         const float qr[4] = {p2.x, p2.y, p2.z, p2.w};
@@ -148,7 +141,26 @@ __device__ __forceinline__ void motion_point(int i, const float* __restrict__ me
         float n2 = fmaxf(quat_norm(p), 1e-12f);
         wq[0] = p[0] / n2; wq[1] = p[1] / n2; wq[2] = p[2] / n2; wq[3] = p[3] / n2;
     }
-    if (opac) *wo = (raw ? sigmoidf_(opac[i]) : opac[i]) * p1.w;
+    if (has_op) *wo = (raw ? sigmoidf_(op_in) : op_in) * p1.w;
+}
+
+__device__ __forceinline__ void motion_point(int i, const float* __restrict__ means, const float* __restrict__ quats,
+                                             const float* __restrict__ opac, const EmdMotion& mo, float wm[3],
+                                             float wq[4], float* wo, bool raw = false) {
+    float m[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    if (mo.residual_dx) {
+        m[0] += mo.residual_dx[3 * i]; m[1] += mo.residual_dx[3 * i + 1]; m[2] += mo.residual_dx[3 * i + 2];
+    }
+    int a = mo.actor_id ? mo.actor_id[i] : -1;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 q = z4, dqr = z4, p0 = z4, p1 = z4, p2 = z4;
+    if (quats) q = *(const float4*)(quats + 4 * i);
+    if (a >= 0) {
+        const float4* Pp = (const float4*)(mo.actor_pose + (size_t)a * EMD_ACTOR_STRIDE);
+        p0 = Pp[0]; p1 = Pp[1]; p2 = Pp[2];
+        if (quats && mo.residual_dq) dqr = *(const float4*)(mo.residual_dq + 4 * i);
+    }
+    motion_apply(m, a, quats != nullptr, q, mo.residual_dq != nullptr, dqr, opac != nullptr, opac ? opac[i] : 0.f, p0, p1, p2, raw, wm, wq, wo);
 }
 
 __device__ __forceinline__ void sh_basis(int deg, const float d[3], float b[16]) {
@@ -333,7 +345,9 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
     // the scales are requested with the other parameters, not behind the near-plane test they used to wait for (one HBM round trip less
     // on the way to the visibility decision; a culled Gaussian's 12 bytes are read in vain: measured 0.180 -> 0.172 ms)
     float sc_raw[3] = {0.f, 0.f, 0.f};
+#if !EMD_K1_HOIST
     if (PART != 2 && i < a.N && !a.cov3D_precomp) { sc_raw[0] = a.scales[3 * i]; sc_raw[1] = a.scales[3 * i + 1]; sc_raw[2] = a.scales[3 * i + 2]; }
+#endif
     if (PART == 2) {
         // colour half: visibility from the geometry half's radii; the world mean again (static point: the parameter itself)
         if (i < a.N && a.radii[i] > 0) {
@@ -347,6 +361,46 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
         const int gx = (W + EMD_TILE_X - 1) / EMD_TILE_X, gy = (H + EMD_TILE_Y - 1) / EMD_TILE_Y;
         const float fx = (float)W / (2.f * S.tanfovx), fy = (float)H / (2.f * S.tanfovy);
         const bool raw = (a.flags & EMD_FLAG_RAW_PARAMS) != 0;
+#if EMD_K1_HOIST
+        {
+            // Round 5 (late), as in K8: every load whose address depends on the index alone is issued here, back to back, before any is used (optional
+            // inputs through a pointer that is valid either way -- the Gaussian's own mean stands in --, selected where they are used); then the actor's pose
+            // rows.  Before: mean -> actor id -> quaternion / pose rows -> opacity, each behind the wait of the one before.
+            const bool motion = (a.flags & EMD_FLAG_MOTION) != 0;
+            const bool has_ids = motion && a.motion.actor_id != nullptr, has_rot = a.rotations != nullptr;
+            const bool has_rdx = motion && a.motion.residual_dx != nullptr, has_rdq = motion && has_rot && a.motion.residual_dq != nullptr;
+            const float* mp = a.means3D + 3 * (size_t)i;
+            const float* xp = has_rdx ? a.motion.residual_dx + 3 * (size_t)i : mp;
+            const float* sp = a.cov3D_precomp ? mp : a.scales + 3 * (size_t)i;
+            const int aid_raw = *(has_ids ? a.motion.actor_id + i : (const int*)mp);
+            const float m0 = mp[0], m1 = mp[1], m2 = mp[2];
+            const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+            const float s0 = sp[0], s1 = sp[1], s2 = sp[2];
+            const float opv = a.opacities[i];
+            // (a quaternion row is 16 bytes at a 16-byte stride; without rotations the stand-in is read as three dwords + one)
+            float4 qq = make_float4(0.f, 0.f, 0.f, 0.f), dqq = qq;
+            if (has_rot) qq = *(const float4*)(a.rotations + 4 * (size_t)i);                 // (kernel-uniform; the loads above are already in flight)
+            if (has_rdq) dqq = *(const float4*)(a.motion.residual_dq + 4 * (size_t)i);
+            const int aid = has_ids ? aid_raw : -1;
+            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
+            if (aid >= 0) {
+                const float4* Pp = (const float4*)(a.motion.actor_pose + (size_t)aid * EMD_ACTOR_STRIDE);
+                p0 = Pp[0]; p1 = Pp[1]; p2 = Pp[2];
+            }
+            if (!a.cov3D_precomp) { sc_raw[0] = s0; sc_raw[1] = s1; sc_raw[2] = s2; }
+            if (motion) {
+                const float ml[3] = {has_rdx ? m0 + x0 : m0, has_rdx ? m1 + x1 : m1, has_rdx ? m2 + x2 : m2};
+                motion_apply(ml, aid, has_rot, qq, has_rdq, dqq, true, opv, p0, p1, p2, raw, m, q, &op);
+            } else {
+                op = raw ? sigmoidf_(opv) : opv;
+                m[0] = m0; m[1] = m1; m[2] = m2;
+                if (has_rot) {
+                    q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
+                    if (raw) { const float n = fmaxf(quat_norm(q), 1e-12f); q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
+                }
+            }
+        }
+#else
         if (a.flags & EMD_FLAG_MOTION) {
             motion_point(i, a.means3D, a.rotations, a.opacities, a.motion, m, q, &op, raw);
         } else {
@@ -357,6 +411,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 if (raw) { const float n = fmaxf(quat_norm(q), 1e-12f); q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
             }
         }
+#endif
         p.tx = ((V[0] * m[0] + V[4] * m[1]) + V[8] * m[2]) + V[12];
         p.ty = ((V[1] * m[0] + V[5] * m[1]) + V[9] * m[2]) + V[13];
         p.tz = ((V[2] * m[0] + V[6] * m[1]) + V[10] * m[2]) + V[14];
@@ -576,18 +631,13 @@ __device__ __forceinline__ void dnormalize4(const float vu[4], float n, const fl
 
 // Backward of motion_point for an actor point (a_id >= 0): world-space gradients (dm, dq, dop) -> local-space
 // gradients (dl, dql, dopl) and this point's contribution to its actor's pose row (pose_g[12]).
-__device__ __forceinline__ void motion_point_backward(int i, int a_id, const float* __restrict__ means,
-                                                      const float* __restrict__ quats, const float* __restrict__ opac,
-                                                      const EmdMotion& mo, const float dm[3], const float dq[4],
-                                                      float dop, float dl[3], float dql[4], float* dopl,
-                                                      float pose_g[12], bool raw = false) {
-    const float4* Pp = (const float4*)(mo.actor_pose + (size_t)a_id * EMD_ACTOR_STRIDE);
-    const float4 p0 = Pp[0], p1 = Pp[1], p2 = Pp[2];
+// (the arithmetic on values in registers; motion_point_backward below loads them)
+__device__ __forceinline__ void motion_backward_apply(const float ml[3], bool has_q, float4 qq, bool has_dq, float4 dq_res, bool has_op, float op_in,
+                                                      float4 p0, float4 p1, float4 p2, const float dm[3], const float dq[4], float dop, float dl[3],
+                                                      float dql[4], float* dopl, float pose_g[12], bool raw) {
     const float qm[4] = {p0.x, p0.y, p0.z, p0.w};
     float R[9];
     quat_to_R(qm, R);
-    float ml[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-    if (mo.residual_dx) { ml[0] += mo.residual_dx[3 * i]; ml[1] += mo.residual_dx[3 * i + 1]; ml[2] += mo.residual_dx[3 * i + 2]; }
 #pragma unroll
     for (int k = 0; k < 3; k++) dl[k] = (R[k] * dm[0] + R[3 + k] * dm[1]) + R[6 + k] * dm[2];
     float dRm[9];
@@ -599,16 +649,12 @@ __device__ __forceinline__ void motion_point_backward(int i, int a_id, const flo
     dR_to_dq(qm, dRm, dqm);
     pose_g[0] = dqm[0]; pose_g[1] = dqm[1]; pose_g[2] = dqm[2]; pose_g[3] = dqm[3];
     pose_g[4] = dm[0]; pose_g[5] = dm[1]; pose_g[6] = dm[2];
-    pose_g[7] = opac ? dop * (raw ? sigmoidf_(opac[i]) : opac[i]) : 0.f;
+    pose_g[7] = has_op ? dop * (raw ? sigmoidf_(op_in) : op_in) : 0.f;
     pose_g[8] = pose_g[9] = pose_g[10] = pose_g[11] = 0.f;
     dql[0] = dql[1] = dql[2] = dql[3] = 0.f;
-    if (quats) {
-        const float4 qq = *(const float4*)(quats + 4 * i);
+    if (has_q) {
         float ql[4] = {qq.x, qq.y, qq.z, qq.w};
-        if (mo.residual_dq) {
-            const float4 d = *(const float4*)(mo.residual_dq + 4 * i);
-            ql[0] += d.x; ql[1] += d.y; ql[2] += d.z; ql[3] += d.w;
-        }
+        if (has_dq) { ql[0] += dq_res.x; ql[1] += dq_res.y; ql[2] += dq_res.z; ql[3] += dq_res.w; }
         float n = fmaxf(quat_norm(ql), 1e-12f);
         float qn[4] = {ql[0] / n, ql[1] / n, ql[2] / n, ql[3] / n};
         const float qr[4] = {p2.x, p2.y, p2.z, p2.w};
@@ -627,6 +673,25 @@ __device__ __forceinline__ void motion_point_backward(int i, int a_id, const flo
         dnormalize4(qn, n, dqb, dql);
     }
     *dopl = dop * p1.w;
+}
+
+__device__ __forceinline__ void motion_point_backward(int i, int a_id, const float* __restrict__ means,
+                                                      const float* __restrict__ quats, const float* __restrict__ opac,
+                                                      const EmdMotion& mo, const float dm[3], const float dq[4],
+                                                      float dop, float dl[3], float dql[4], float* dopl,
+                                                      float pose_g[12], bool raw = false) {
+    const float4* Pp = (const float4*)(mo.actor_pose + (size_t)a_id * EMD_ACTOR_STRIDE);
+    const float4 p0 = Pp[0], p1 = Pp[1], p2 = Pp[2];
+    float ml[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    if (mo.residual_dx) { ml[0] += mo.residual_dx[3 * i]; ml[1] += mo.residual_dx[3 * i + 1]; ml[2] += mo.residual_dx[3 * i + 2]; }
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 qq = z4, dqr = z4;
+    if (quats) {
+        qq = *(const float4*)(quats + 4 * i);
+        if (mo.residual_dq) dqr = *(const float4*)(mo.residual_dq + 4 * i);
+    }
+    motion_backward_apply(ml, quats != nullptr, qq, mo.residual_dq != nullptr, dqr, opac != nullptr, opac ? opac[i] : 0.f, p0, p1, p2, dm, dq, dop, dl, dql,
+                          dopl, pose_g, raw);
 }
 
 // Segmented reduction of per-point pose gradients into dL_dactor_pose.  Actor points are stored contiguously
@@ -724,30 +789,60 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
     float sc_in[3] = {0.f, 0.f, 0.f};       // (loaded in part 1: no global load waits behind the staging barriers)
     Proj p;
     p.tx = p.ty = p.tz = 0.f;
+    // Round 5 (late): EVERY load of a visible Gaussian whose address depends on its index alone is issued here, back to back, before any of them is
+    // used -- its parameters, its accumulated gradient row, its colour Jacobian --, then the actor's pose rows (the one dependent address).  Before, the
+    // loads sat in the branches that use them (motion / raw quaternion / scales / gradient row / Jacobian, each kernel-uniform or per-lane): seven
+    // load -> s_waitcnt -> use rounds one behind the other, each a trip to the Infinity Cache or HBM, in a kernel whose compacted blocks keep ~2 waves
+    // busy.  Optional inputs are read through a pointer that is valid either way (the Gaussian's own gradient row stands in for an absent array) and
+    // selected where they are used: a branch around a load would put it back behind a wait.
+    const bool motion = (a.flags & EMD_FLAG_MOTION) != 0;
+    const bool has_ids = motion && a.motion.actor_id != nullptr, has_rot = a.rotations != nullptr;
+    const bool has_rdx = motion && a.motion.residual_dx != nullptr, has_rdq = motion && has_rot && a.motion.residual_dq != nullptr;
+    const float4 z4c = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mloc[3] = {0.f, 0.f, 0.f}, op_raw = 0.f;
+    float4 q_raw = z4c, rdq = z4c, pr0 = z4c, pr1 = z4c, pr2 = z4c;
     if (in_range) {
         visible = EMD_K8_COMPACT ? true : a.radii[i] > 0;
-        if (a.flags & EMD_FLAG_MOTION) {
-            motion_point(i, a.means3D, a.rotations, a.opacities, a.motion, m, q, &op, raw);
-            a_id = a.motion.actor_id ? a.motion.actor_id[i] : -1;
-        } else {
-            op = raw ? sigmoidf_(a.opacities[i]) : a.opacities[i];
-            m[0] = a.means3D[3 * i]; m[1] = a.means3D[3 * i + 1]; m[2] = a.means3D[3 * i + 2];
-            if (a.rotations) { const float4 qq = *(const float4*)(a.rotations + 4 * i); q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w; }
-        }
-        if (raw && a_id < 0 && a.rotations) {   // static point: q is the raw quaternion (no-motion path) or already unit (motion path)
-            const float4 qq = *(const float4*)(a.rotations + 4 * i);
-            const float qr[4] = {qq.x, qq.y, qq.z, qq.w};
-            q_norm = fmaxf(quat_norm(qr), 1e-12f);
-            q[0] = qr[0] / q_norm; q[1] = qr[1] / q_norm; q[2] = qr[2] / q_norm; q[3] = qr[3] / q_norm;
-        }
-        if (visible && !a.cov3D_precomp) { sc_in[0] = a.scales[3 * i]; sc_in[1] = a.scales[3 * i + 1]; sc_in[2] = a.scales[3 * i + 2]; }
+        // (the actor id of every Gaussian in range: the pose-gradient reduction at the end looks at whole waves)
+        const int aid_raw = *(has_ids ? a.motion.actor_id + i : a.radii + i);
+        a_id = has_ids ? aid_raw : -1;
         if (visible) {
             float4* gr = (float4*)(a.grad_rec + (size_t)i * a.bwd_stride);
+            const float* safe = (const float*)gr;                                          // 48 readable, 16-byte aligned bytes
+            const float* mp = a.means3D + 3 * (size_t)i;
+            const float* xp = has_rdx ? a.motion.residual_dx + 3 * (size_t)i : safe;
+            const float* sp = a.cov3D_precomp ? safe : a.scales + 3 * (size_t)i;
+            const float4* jr = a.colors_precomp ? (const float4*)gr : a.g.shjac + (size_t)i * 3;
+            const float m0 = mp[0], m1 = mp[1], m2 = mp[2];
+            const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+            const float4 qq = *(const float4*)(has_rot ? a.rotations + 4 * (size_t)i : safe);
+            const float4 dqq = *(const float4*)(has_rdq ? a.motion.residual_dq + 4 * (size_t)i : safe);
+            const float opv = a.opacities[i];
+            const float s0 = sp[0], s1 = sp[1], s2 = sp[2];
             const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2];
-            if (a.flags & EMD_FLAG_BWD_WS_CLEAN) {          // the row is handed back clean: the next backward needs no zero fill
-                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                gr[0] = z4; gr[1] = z4; gr[2] = z4;
+            const float4 j0 = EMD_K8_NT_JAC ? load_f4_nt(jr) : jr[0], j1 = EMD_K8_NT_JAC ? load_f4_nt(jr + 1) : jr[1], j2 = EMD_K8_NT_JAC ? load_f4_nt(jr + 2) : jr[2];
+            if (a_id >= 0) {                              // the one dependent address
+                const float4* Pp = (const float4*)(a.motion.actor_pose + (size_t)a_id * EMD_ACTOR_STRIDE);
+                pr0 = Pp[0]; pr1 = Pp[1]; pr2 = Pp[2];
             }
+            if (a.flags & EMD_FLAG_BWD_WS_CLEAN) {          // the row is handed back clean: the next backward needs no zero fill
+                gr[0] = z4c; gr[1] = z4c; gr[2] = z4c;
+            }
+            // ---- the Gaussian's world pose (motion_point's arithmetic on the values above)
+            mloc[0] = has_rdx ? m0 + x0 : m0; mloc[1] = has_rdx ? m1 + x1 : m1; mloc[2] = has_rdx ? m2 + x2 : m2;
+            q_raw = qq; rdq = dqq; op_raw = opv;
+            if (motion) motion_apply(mloc, a_id, has_rot, q_raw, has_rdq, rdq, true, op_raw, pr0, pr1, pr2, raw, m, q, &op);
+            else {
+                op = raw ? sigmoidf_(op_raw) : op_raw;
+                m[0] = m0; m[1] = m1; m[2] = m2;
+                if (has_rot) { q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w; }
+            }
+            if (raw && a_id < 0 && has_rot) {   // static point: q is the raw quaternion (no-motion path) or already unit (motion path)
+                const float qr[4] = {qq.x, qq.y, qq.z, qq.w};
+                q_norm = fmaxf(quat_norm(qr), 1e-12f);
+                q[0] = qr[0] / q_norm; q[1] = qr[1] / q_norm; q[2] = qr[2] / q_norm; q[3] = qr[3] / q_norm;
+            }
+            if (!a.cov3D_precomp) { sc_in[0] = s0; sc_in[1] = s1; sc_in[2] = s2; }
             uint32_t bits = 0u;
             if (!EMD_K8_BITS_IN_JAC) bits = __float_as_uint(a.g.rec[(size_t)i * EMD_REC_F4 + 2].w);   // (only the SH branch below reads them)
             gm2[0] = g0.x; gm2[1] = g0.y;
@@ -765,8 +860,6 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
                 float n = sqrtf((d0[0] * d0[0] + d0[1] * d0[1]) + d0[2] * d0[2]);
                 float d[3] = {d0[0] / n, d0[1] / n, d0[2] / n};
                 // d L / d dir = J^T gc with the 3x3 Jacobian K1 stored: no second pass over the 192 B of coefficients
-                const float4* jr = a.g.shjac + (size_t)i * 3;
-                const float4 j0 = EMD_K8_NT_JAC ? load_f4_nt(jr) : jr[0], j1 = EMD_K8_NT_JAC ? load_f4_nt(jr + 1) : jr[1], j2 = EMD_K8_NT_JAC ? load_f4_nt(jr + 2) : jr[2];
                 if (EMD_K8_BITS_IN_JAC) bits = __float_as_uint(j0.w);
                 float gc[3];
 #pragma unroll
@@ -954,11 +1047,11 @@ __global__ void __launch_bounds__(K8_BLOCK) __attribute__((amdgpu_waves_per_eu(E
         if (a.dL_dscales && !staged5) { st_f(a.dL_dscales + 3 * i, ds[0]); st_f(a.dL_dscales + 3 * i + 1, ds[1]); st_f(a.dL_dscales + 3 * i + 2, ds[2]); }
         // (h) explicit motion
         float dl[3] = {dm[0], dm[1], dm[2]}, dql[4] = {dq[0], dq[1], dq[2], dq[3]}, dopl = dop;
-        if (a_id >= 0)
-            motion_point_backward(i, a_id, a.means3D, a.rotations, a.opacities, a.motion, dm, dq, dop, dl, dql, &dopl, pose_g, raw);
-        if (raw) {
-            if (a_id < 0 && a.rotations) dnormalize4(q, q_norm, dq, dql);          // through F.normalize of the raw quaternion
-            const float o = sigmoidf_(a.opacities[i]);
+        if (a_id >= 0 && visible)           // (an invisible Gaussian -- uncompacted build only -- has zero gradients: nothing to transform)
+            motion_backward_apply(mloc, has_rot, q_raw, has_rdq, rdq, true, op_raw, pr0, pr1, pr2, dm, dq, dop, dl, dql, &dopl, pose_g, raw);
+        if (raw && visible) {
+            if (a_id < 0 && has_rot) dnormalize4(q, q_norm, dq, dql);              // through F.normalize of the raw quaternion
+            const float o = sigmoidf_(op_raw);
             dopl *= o * (1.f - o);                                                 // through the sigmoid
         }
 #if EMD_K8_STAGE_SMALL || EMD_K8_COMPACT
