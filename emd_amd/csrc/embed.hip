@@ -19,7 +19,10 @@
 namespace {
 
 // grid_sample coordinate: align_corners un-normalise, reflect over [0, size-1], clip; *mult = d(result)/d(coord)
+// (no contraction in the sampling arithmetic of this file -- reflect_coord, resized_row, te_rows, the column coordinate, te_eval: the same source is
+//  inlined into several kernels whose results are compared bit for bit, and left to itself the compiler fused e.g. `scale * r - h0` in one copy only)
 __device__ __forceinline__ float reflect_coord(float c, int size, float* mult) {
+#pragma clang fp contract(off)
     float v = ((c + 1.f) * 0.5f) * (float)(size - 1);
     float m = 0.5f * (float)(size - 1);
     if (size <= 1) { *mult = 0.f; return 0.f; }
@@ -36,6 +39,7 @@ __device__ __forceinline__ float reflect_coord(float c, int size, float* mult) {
 
 // row r of the table resized to k rows (upsample_bilinear2d, align_corners): two source rows and their weights
 __device__ __forceinline__ void resized_row(int r, int k, int rows, int* h0, int* h1, float* l0, float* l1) {
+#pragma clang fp contract(off)
     const float scale = k > 1 ? (float)(rows - 1) / (float)(k - 1) : 0.f;
     const float src = scale * (float)r;
     *h0 = (int)src;
@@ -174,6 +178,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_deform_input_bwd(int n, int E, int
 struct TeSample { int ha[2], hb[2]; float la[2], lb[2], wy0, wy1; bool in1; };
 
 __device__ __forceinline__ TeSample te_rows(float t, int k, int rows) {
+#pragma clang fp contract(off)
     TeSample s;
     float my;
     const float iy = reflect_coord((t - 0.5f) * 2.f, k, &my);
@@ -186,8 +191,35 @@ __device__ __forceinline__ TeSample te_rows(float t, int k, int rows) {
     return s;
 }
 
+// the eight taps of a sample, unconditionally (x1c: the column neighbour, clamped onto x0 where the sample has none)
+__device__ __forceinline__ void te_taps(const float* __restrict__ weight, int dim, const TeSample& s, int x0, int x1c, float (&wv)[2][4]) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        wv[r][0] = weight[s.ha[r] * dim + x0]; wv[r][1] = weight[s.hb[r] * dim + x0];
+        wv[r][2] = weight[s.ha[r] * dim + x1c]; wv[r][3] = weight[s.hb[r] * dim + x1c];
+    }
+}
+
+// the bilinear blend of a sample's eight taps.  ONE function without contraction for every caller: the one-launch actor chain (te_column2) and the
+// three-launch path (te_column) must produce the same bits (tests/test_motion_sh_gpu.py), and with contraction left to the compiler the two
+// inlined copies were fused differently.
+__device__ __forceinline__ float te_eval(const TeSample& s, const float (&wv)[2][4], float wx0, float wx1, bool inx1) {
+#pragma clang fp contract(off)
+    float out = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const float wy = r ? s.wy1 : s.wy0;
+        const float v0 = s.la[r] * wv[r][0] + s.lb[r] * wv[r][1];
+        const float v1 = inx1 ? s.la[r] * wv[r][2] + s.lb[r] * wv[r][3] : 0.f;
+        const float term = v0 * (wx0 * wy) + v1 * (wx1 * wy);
+        out = (r == 1 && !s.in1) ? out : out + term;
+    }
+    return out;
+}
+
 // column j of the sampled row (same arithmetic as k_temporal_embed); with G != nullptr scatters g into the table gradient instead
 __device__ __forceinline__ float te_column(const float* __restrict__ weight, int dim, const TeSample& s, int j, float g, float* __restrict__ G) {
+#pragma clang fp contract(off)
     float mx;
     const float gx = dim > 1 ? ((float)j / (float)(dim - 1) - 0.5f) * 2.f : -1.f;
     const float ix = reflect_coord(gx, dim, &mx);
@@ -196,14 +228,18 @@ __device__ __forceinline__ float te_column(const float* __restrict__ weight, int
     const float wx1 = ix - x0f, wx0 = 1.f - wx1;
     const bool inx1 = x1 <= dim - 1;
     float out = 0.f;
+    if (!G) {
+        // all eight taps first, unconditionally (a tap the sample does not use -- the row past the table's end, the column past its width -- is read
+        // from a valid neighbour and selected away): with the loads inside the row loop's branches each row waited for its own round trip
+        float wv[2][4];
+        te_taps(weight, dim, s, x0, inx1 ? x1 : x0, wv);
+        return te_eval(s, wv, wx0, wx1, inx1);
+    }
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         if (r == 1 && !s.in1) continue;
         const float wy = r ? s.wy1 : s.wy0;
         if (!G) {
-            const float v0 = s.la[r] * weight[s.ha[r] * dim + x0] + s.lb[r] * weight[s.hb[r] * dim + x0];
-            const float v1 = inx1 ? s.la[r] * weight[s.ha[r] * dim + x1] + s.lb[r] * weight[s.hb[r] * dim + x1] : 0.f;
-            out += v0 * (wx0 * wy) + v1 * (wx1 * wy);
         } else {
             atomicAdd(G + s.ha[r] * dim + x0, g * wx0 * wy * s.la[r]);
             atomicAdd(G + s.hb[r] * dim + x0, g * wx0 * wy * s.lb[r]);
@@ -214,6 +250,23 @@ __device__ __forceinline__ float te_column(const float* __restrict__ weight, int
         }
     }
     return out;
+}
+
+// two samples of the same table column (the coarse and the fine level of an actor's table): all sixteen taps are requested before either is evaluated
+__device__ __forceinline__ void te_column2(const float* __restrict__ weight, int dim, const TeSample& sa, const TeSample& sb, int j, float* oa, float* ob) {
+#pragma clang fp contract(off)
+    float mx;
+    const float gx = dim > 1 ? ((float)j / (float)(dim - 1) - 0.5f) * 2.f : -1.f;
+    const float ix = reflect_coord(gx, dim, &mx);
+    const float x0f = floorf(ix);
+    const int x0 = (int)x0f, x1 = x0 + 1;
+    const float wx1 = ix - x0f, wx0 = 1.f - wx1;
+    const bool inx1 = x1 <= dim - 1;
+    float wa[2][4], wb[2][4];
+    te_taps(weight, dim, sa, x0, inx1 ? x1 : x0, wa);
+    te_taps(weight, dim, sb, x0, inx1 ? x1 : x0, wb);
+    *oa = te_eval(sa, wa, wx0, wx1, inx1);
+    *ob = te_eval(sb, wb, wx0, wx1, inx1);
 }
 
 __device__ __forceinline__ float wave_sum_all(float v) {
@@ -374,10 +427,19 @@ __device__ __forceinline__ void tp_segment_sum(int E, const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; e++) acc[e] = 0.f;
     if (E == 4 && ((uintptr_t)emb & 15) == 0) {
+        // eight rows per thread in flight at once, unconditionally (a row past the segment's end reads its last row and counts as zero): the
+        // plain loop waited for every row before asking for the next -- five dependent trips to memory for a bench actor's 5 000 points.
+        // (The adds run in the same order, row i before row i + 1 024: the same sums.)
         const float4* e4 = (const float4*)emb;
-        for (int i = lo + (int)threadIdx.x; i < hi; i += SEG_THREADS) {
-            const float4 v = e4[i];
-            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        if (hi > lo) {
+            for (int base = lo + (int)threadIdx.x; base < hi; base += 8 * SEG_THREADS) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = e4[min(base + u * SEG_THREADS, hi - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (base + u * SEG_THREADS < hi) { acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w; }
+            }
         }
     } else {
         for (int i = lo + (int)threadIdx.x; i < hi; i += SEG_THREADS)
@@ -414,6 +476,8 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
     // wave 0's loads and arithmetic that do not depend on the embedding sums (temporal rows, head weights, the frame's pose row) are
     // issued FIRST: they overlap the segment sum / the clears of the other waves instead of following them (the kernel is pure latency)
     float hc_t = 0.f, hf_t = 0.f, wrow[8], hbias[8], cnt = 1.f, qf[4] = {1.f, 0.f, 0.f, 0.f}, tf[3] = {0.f, 0.f, 0.f}, vflag = 1.f;
+    float lane_in = 0.f, gp_in[12];
+    uint32_t valid_in = 1u;
     TeSample sc, sf;
 #pragma unroll
     for (int o = 0; o < 8; o++) wrow[o] = hbias[o] = 0.f;
@@ -422,19 +486,33 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
         const float t = a.t_dev ? a.t_dev[0] : a.t;
         const int k_fine = a.k_fine_dev ? min(max(a.k_fine_dev[0], 1), a.rows) : a.k_fine;
         sc = te_rows(t, a.k_coarse, a.rows); sf = te_rows(t, k_fine, a.rows);
-        cnt = a.count[act];
-        if (lane < dim) { hc_t = te_column(w, dim, sc, lane, 0.f, nullptr); hf_t = te_column(w, dim, sf, lane, 0.f, nullptr); }
+        // Round 5 (late): the wave's UNIFORM inputs -- eight head biases, the frame's quaternion and translation, the point count, the valid flag and
+        // (backward) the twelve floats of the pose row's gradient -- are one value per LANE of a single vector load.  As uniform loads the
+        // compiler moved each of them to a scalar register right behind its own load: one memory round trip per value, 20 - 32 of them one after
+        // the other in a kernel that is nothing but latency.  They are handed out with v_readlane where they are used (after the segment sum).
+        {
+            const float* q_f = p.q_all + ((size_t)frame * A + act) * 4;
+            const float* t_f = p.t_all + ((size_t)frame * A + act) * 3;
+            const float* src = nullptr;
+            if (lane < 3) src = a.head_b[0] + lane;
+            else if (lane < 6) src = a.head_b[1] + (lane - 3);
+            else if (lane == 6) src = a.head_b[2];
+            else if (lane == 7) src = a.head_b[3];
+            else if (lane < 12) src = q_f + (lane - 8);
+            else if (lane < 15) src = t_f + (lane - 12);
+            else if (lane == 15) src = a.count + act;
+            else if (BWD && lane < 28) src = g.g_pose + (size_t)act * EMD_ACTOR_STRIDE + (lane - 16);
+            if (src) lane_in = *src;
+            if (p.valid_all && lane == 28) valid_in = p.valid_all[(size_t)frame * A + act];
+        }
 #pragma unroll
         for (int o = 0; o < 8; o++) {
             const int hd = o < 3 ? 0 : o < 6 ? 1 : o - 4, r = o < 3 ? o : o < 6 ? o - 3 : 0;
-            wrow[o] = lane < width ? a.head_w[hd][r * width + lane] : 0.f;
-            hbias[o] = a.head_b[hd][r];
+            wrow[o] = a.head_w[hd][r * width + (lane < width ? lane : 0)];          // (unconditional; lanes past the width are zeroed below)
         }
-        const float* q_f = p.q_all + ((size_t)frame * A + act) * 4;
-        const float* t_f = p.t_all + ((size_t)frame * A + act) * 3;
-        qf[0] = q_f[0]; qf[1] = q_f[1]; qf[2] = q_f[2]; qf[3] = q_f[3];
-        tf[0] = t_f[0]; tf[1] = t_f[1]; tf[2] = t_f[2];
-        if (p.valid_all) vflag = p.valid_all[(size_t)frame * A + act] ? 1.f : 0.f;
+        if (lane < dim) te_column2(w, dim, sc, sf, lane, &hc_t, &hf_t);
+#pragma unroll
+        for (int o = 0; o < 8; o++) wrow[o] = lane < width ? wrow[o] : 0.f;
     }
     if (BWD) {
         // clear what this workgroup owns: its actor's temporal-table gradient and its column of the dense per-frame pose gradients
@@ -458,6 +536,21 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
     }
     if (wave == 0) {
         const float* w = a.weight + (size_t)act * a.rows * dim;
+        {   // the uniform inputs, from the lanes that loaded them
+            auto rl = [&](int k) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_in), k)); };
+#pragma unroll
+            for (int o = 0; o < 8; o++) hbias[o] = rl(o);
+#pragma unroll
+            for (int k = 0; k < 4; k++) qf[k] = rl(8 + k);
+#pragma unroll
+            for (int k = 0; k < 3; k++) tf[k] = rl(12 + k);
+            cnt = rl(15);
+            if (BWD) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) gp_in[k] = rl(16 + k);
+            }
+            vflag = __builtin_amdgcn_readlane((int)valid_in, 28) ? 1.f : 0.f;
+        }
         float hc = hc_t, hf = hf_t;
         if (lane >= dim && lane < width) hc = hf = s_sum[lane - dim] / cnt;
         float out[8];
@@ -489,7 +582,7 @@ __global__ void __launch_bounds__(SEG_THREADS) k_tracked_pose(EmdTrackedPoseArgs
                 for (int k = 0; k < 4; k++) P[8 + k] = pq[k] / n2;
             }
         } else {
-            const float* Gp = g.g_pose + (size_t)act * EMD_ACTOR_STRIDE;
+            const float* Gp = gp_in;                      // (the pose row's gradient: loaded with the other uniform inputs)
             const float qu[4] = {q[0] / n, q[1] / n, q[2] / n, q[3] / n};
             const float gm[4] = {Gp[0], Gp[1], Gp[2], Gp[3]};
             float dqf[4];
