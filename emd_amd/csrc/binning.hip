@@ -290,11 +290,19 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_hist(const uint32_t* __rest
     if (blockIdx.x < nblocks) {
         const size_t base = (size_t)blockIdx.x * EMD_SORT_TILE;
         bool wide = false;
+        // all of the thread's keys first, unconditionally (an index past the end reads the last key and is not counted): with the load inside the
+        // guard the compiler waited for every key before asking for the next -- eight trips to memory one after the other per workgroup
+        uint32_t kv[EMD_SORT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < EMD_SORT_ITEMS; k++) {
+            const size_t idx = base + (size_t)k * EMD_BLOCK + threadIdx.x;
+            kv[k] = keys[idx < D ? idx : (size_t)D - 1];
+        }
 #pragma unroll
         for (int k = 0; k < EMD_SORT_ITEMS; k++) {
             size_t idx = base + (size_t)k * EMD_BLOCK + threadIdx.x;
             if (idx < D) {
-                const uint32_t key = keys[idx];
+                const uint32_t key = kv[k];
                 if (FIRST && key == 0xFFFFFFFFu) continue;
                 const uint32_t rel = key - offset;
                 if (FIRST && range_bits < 32 && (rel >> range_bits)) wide = true;
@@ -470,12 +478,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_tile_ranges(const uint32_t* __res
                                                            uint32_t* __restrict__ ranges) {
     const uint32_t D = status->overflow ? 0u : status->num_rendered;
     for (size_t idx = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x; idx < D; idx += (size_t)gridDim.x * EMD_BLOCK) {
-        const uint32_t t = tkeys[idx];
+        const uint32_t t = tkeys[idx], tp = tkeys[idx ? idx - 1 : 0];          // (both requested before either is used)
         if (idx == 0) ranges[2 * t] = 0;
-        else {
-            const uint32_t tp = tkeys[idx - 1];
-            if (tp != t) { ranges[2 * tp + 1] = (uint32_t)idx; ranges[2 * t] = (uint32_t)idx; }
-        }
+        else if (tp != t) { ranges[2 * tp + 1] = (uint32_t)idx; ranges[2 * t] = (uint32_t)idx; }
         if (idx == D - 1) ranges[2 * t + 1] = D;
     }
 }
@@ -493,9 +498,27 @@ __global__ void __launch_bounds__(ORDER_BUCKETS) k_tile_order(const uint32_t* __
     __shared__ uint32_t s_w[ORDER_BUCKETS / 64];
     s_h[threadIdx.x] = 0;                                    // one thread per bucket
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < T; t += ORDER_BUCKETS) {
+    // a thread's tiles are requested together and kept for the second pass (as two plain loops the kernel made one trip to memory per tile and
+    // pass, fourteen one after the other at 6 700 tiles: it is a single workgroup, nothing else hides them); tiles past 8 192 take the plain loops
+    constexpr uint32_t KEEP = 8;
+    uint32_t bk[KEEP];
+    {
+        uint2 rg[KEEP];
+#pragma unroll
+        for (uint32_t k = 0; k < KEEP; k++) {
+            const uint32_t t = threadIdx.x + k * ORDER_BUCKETS;
+            rg[k] = reinterpret_cast<const uint2*>(ranges)[t < T ? t : 0];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < KEEP; k++) {
+            const uint32_t t = threadIdx.x + k * ORDER_BUCKETS;
+            bk[k] = ORDER_BUCKETS - 1 - min((rg[k].y - rg[k].x) >> 4, (uint32_t)ORDER_BUCKETS - 1);     // bucket 0 = longest
+            if (t < T) atomicAdd(&s_h[bk[k]], 1u);
+        }
+    }
+    for (uint32_t t = threadIdx.x + KEEP * ORDER_BUCKETS; t < T; t += ORDER_BUCKETS) {
         const uint32_t len = ranges[2 * t + 1] - ranges[2 * t];
-        atomicAdd(&s_h[ORDER_BUCKETS - 1 - min(len >> 4, (uint32_t)ORDER_BUCKETS - 1)], 1u);     // bucket 0 = longest
+        atomicAdd(&s_h[ORDER_BUCKETS - 1 - min(len >> 4, (uint32_t)ORDER_BUCKETS - 1)], 1u);
     }
     __syncthreads();
     {   // exclusive scan over the buckets: wave scans + the 16 wave totals
@@ -508,7 +531,12 @@ __global__ void __launch_bounds__(ORDER_BUCKETS) k_tile_order(const uint32_t* __
         s_h[threadIdx.x] = base + inc - v;
     }
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < T; t += ORDER_BUCKETS) {
+#pragma unroll
+    for (uint32_t k = 0; k < KEEP; k++) {
+        const uint32_t t = threadIdx.x + k * ORDER_BUCKETS;
+        if (t < T) order[atomicAdd(&s_h[bk[k]], 1u)] = t;
+    }
+    for (uint32_t t = threadIdx.x + KEEP * ORDER_BUCKETS; t < T; t += ORDER_BUCKETS) {
         const uint32_t len = ranges[2 * t + 1] - ranges[2 * t];
         order[atomicAdd(&s_h[ORDER_BUCKETS - 1 - min(len >> 4, (uint32_t)ORDER_BUCKETS - 1)], 1u)] = t;
     }
