@@ -48,32 +48,43 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_loss_pointwise(EmdLossArgs a, flo
     const size_t HW = (size_t)a.height * a.width;
     const size_t p = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x;
     float l1 = 0.f, dsq = 0.f, dcnt = 0.f, sky = 0.f, skyn = 0.f;
+    // every load of the pixel first, unconditionally (round 5: a pixel past the end reads pixel 0, an absent input reads the image instead and
+    // is not used): with the loads inside the branches that use them the thread made five trips to memory one after the other
+    const bool use_depth = a.depth && a.gt_depth && a.lambda_depth != 0.f, use_sky = a.weight && a.sky_mask && a.lambda_sky > 0.f;
+    const size_t pc = p < HW ? p : 0;
+    float im[3], gt[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { im[c] = a.image[c * HW + pc]; gt[c] = a.gt[c * HW + pc]; }
+    const float depth_v = (use_depth ? a.depth : a.image)[pc], gt_depth_v = (use_depth ? a.gt_depth : a.image)[pc];
+    const float mask_v = ((use_depth && a.mask) ? a.mask : a.image)[pc];
+    const float weight_v = (use_sky ? a.weight : a.image)[pc];
+    const uint8_t sky_v = (use_sky ? a.sky_mask : reinterpret_cast<const uint8_t*>(a.image))[pc];
     if (p < HW) {
         const float inv_n = 1.f / (float)(3 * HW);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const float d = a.image[c * HW + p] - a.gt[c * HW + p];
+            const float d = im[c] - gt[c];
             l1 += fabsf(d);
             if (a.dL_dimage) a.dL_dimage[c * HW + p] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
         }
-        if (a.depth && a.gt_depth && a.lambda_depth != 0.f) {
-            const float m = a.mask ? a.mask[p] : 1.f;
-            const float pd = a.depth[p] * m, gd = a.gt_depth[p] * m;
+        if (use_depth) {
+            const float m = a.mask ? mask_v : 1.f;
+            const float pd = depth_v * m, gd = gt_depth_v * m;
             float g = 0.f;
             if (gd > 0.01f && gd < a.max_depth) {
                 const float pn = pd / a.max_depth, gn = gd / a.max_depth;
-                const float pc = fminf(fmaxf(pn, 0.f), 1.f), gc = fminf(fmaxf(gn, 0.f), 1.f);
-                const float e = pc - gc;
+                const float pcl = fminf(fmaxf(pn, 0.f), 1.f), gc = fminf(fmaxf(gn, 0.f), 1.f);
+                const float e = pcl - gc;
                 dsq = e * e;
                 dcnt = 1.f;
                 if (pn >= 0.f && pn <= 1.f) g = 2.f * e * (m / a.max_depth);     // un-normalised: / count in k_ssim_backward
             }
             if (a.dL_ddepth) a.dL_ddepth[p] = g;
         }
-        if (a.weight && a.sky_mask && a.lambda_sky > 0.f) {
-            const float w0 = a.weight[p];
+        if (use_sky) {
+            const float w0 = weight_v;
             const float w = fminf(fmaxf(w0, 1e-6f), 1.f - 1e-6f);
-            const bool is_sky = a.sky_mask[p] != 0;
+            const bool is_sky = sky_v != 0;
             sky = is_sky ? -logf(1.f - w) : -logf(w);
             skyn = is_sky ? 1.f : 0.f;
             // (the reference applies the term only when the mask holds at least one sky pixel, train.py:360: the gradient is
@@ -94,12 +105,34 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_loss_pointwise(EmdLossArgs a, flo
     }
 }
 
-// stage the 26 x 26 halo of one channel (zero outside the image)
-__device__ __forceinline__ void load_halo(const float* __restrict__ img, int H, int W, int x0, int y0, float (*s)[SS_H + 1]) {
-    for (int i = threadIdx.x; i < SS_H * SS_H; i += EMD_BLOCK) {
-        const int ly = i / SS_H, lx = i % SS_H;
+// stage the 42 x 42 halos of NIMG planes (zero outside the image).  All of a thread's 7 x NIMG pixels are requested before the first is written to
+// LDS (round 5): as a plain loop -- load, wait, LDS store, next -- a workgroup made 14 - 21 trips to memory one after the other and the two SSIM
+// kernels, which move ~100 MB each, took 80 us.
+template <int NIMG>
+__device__ __forceinline__ void load_halos(const float* __restrict__ i0, const float* __restrict__ i1, const float* __restrict__ i2, int H, int W, int x0, int y0,
+                                           float (*s0)[SS_H + 1], float (*s1)[SS_H + 1], float (*s2)[SS_H + 1]) {
+    constexpr int IT = (SS_H * SS_H + EMD_BLOCK - 1) / EMD_BLOCK;
+    float v[3][IT];
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+        const int i = threadIdx.x + k * EMD_BLOCK, ly = i / SS_H, lx = i % SS_H;
         const int x = x0 + lx - SS_R, y = y0 + ly - SS_R;
-        s[ly][lx] = (x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0.f;
+        const bool in = i < SS_H * SS_H && x >= 0 && x < W && y >= 0 && y < H;
+        const size_t off = in ? (size_t)y * W + x : 0;
+        v[0][k] = i0[off];
+        if (NIMG > 1) v[1][k] = i1[off];
+        if (NIMG > 2) v[2][k] = i2[off];
+    }
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+        const int i = threadIdx.x + k * EMD_BLOCK, ly = i / SS_H, lx = i % SS_H;
+        const int x = x0 + lx - SS_R, y = y0 + ly - SS_R;
+        const bool in = x >= 0 && x < W && y >= 0 && y < H;
+        if (i < SS_H * SS_H) {
+            s0[ly][lx] = in ? v[0][k] : 0.f;
+            if (NIMG > 1) s1[ly][lx] = in ? v[1][k] : 0.f;
+            if (NIMG > 2) s2[ly][lx] = in ? v[2][k] : 0.f;
+        }
     }
 }
 
@@ -119,8 +152,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_ssim_forward(EmdLossArgs a, Win w
     const int tiles_x = (W + SS_T - 1) / SS_T;
     const int c = blockIdx.y;
     const int x0 = (int)(blockIdx.x % (unsigned)tiles_x) * SS_T, y0 = (int)(blockIdx.x / (unsigned)tiles_x) * SS_T;
-    load_halo(a.image + c * HW, H, W, x0, y0, sx);
-    load_halo(a.gt + c * HW, H, W, x0, y0, sy);
+    load_halos<2>(a.image + c * HW, a.gt + c * HW, nullptr, H, W, x0, y0, sx, sy, nullptr);
     __syncthreads();
     for (int i = threadIdx.x; i < SS_H * SS_T; i += EMD_BLOCK) {
         const int ly = i / SS_T, lx = i % SS_T;
@@ -193,9 +225,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_ssim_backward(EmdLossArgs a, Win 
     const int c = blockIdx.y;
     const int x0 = (int)(blockIdx.x % (unsigned)tiles_x) * SS_T, y0 = (int)(blockIdx.x / (unsigned)tiles_x) * SS_T;
     if (threadIdx.x == 0) { s_cnt = slot_sum(sums, 3); s_sky = slot_sum(sums, 5); }
-    load_halo(dmaps + (0 * 3 + c) * HW, H, W, x0, y0, s0);
-    load_halo(dmaps + (1 * 3 + c) * HW, H, W, x0, y0, s1);
-    load_halo(dmaps + (2 * 3 + c) * HW, H, W, x0, y0, s2);
+    load_halos<3>(dmaps + (0 * 3 + c) * HW, dmaps + (1 * 3 + c) * HW, dmaps + (2 * 3 + c) * HW, H, W, x0, y0, s0, s1, s2);
     __syncthreads();
     for (int i = threadIdx.x; i < SS_H * SS_T; i += EMD_BLOCK) {
         const int ly = i / SS_T, lx = i % SS_T;
@@ -220,16 +250,26 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_ssim_backward(EmdLossArgs a, Win 
     }
     const float scale = -a.lambda_dssim / (float)(3 * HW);          // d (lambda (1 - mean map)) / d map
     const float cnt = s_cnt, skyn = s_sky;
+    // the four outputs' inputs first (a pixel outside the image reads pixel 0 and is not stored), then the arithmetic and the stores
+    const bool fix_depth = c == 0 && a.dL_ddepth && a.depth && a.gt_depth && a.lambda_depth != 0.f;
+    size_t q[SS_V];
+    bool ok[SS_V];
+    float xv[SS_V], yv[SS_V], gi[SS_V], gd[SS_V];
 #pragma unroll
     for (int j = 0; j < SS_V; j++) {
         const int y = y0 + lyb + j;
-        if (x < W && y < H) {
-            const size_t q = (size_t)y * W + x;
-            const float xv = a.image[c * HW + q], yv = a.gt[c * HW + q];
-            if (a.dL_dimage) a.dL_dimage[c * HW + q] += scale * (acc[j][0] + 2.f * xv * acc[j][1] + yv * acc[j][2]);
-            if (c == 0 && a.dL_ddepth && a.depth && a.gt_depth && a.lambda_depth != 0.f)
-                a.dL_ddepth[q] = cnt > 0.f ? a.dL_ddepth[q] * (a.lambda_depth / cnt) : 0.f;
-            if (c == 0 && a.dL_dweight && a.weight && a.sky_mask && a.lambda_sky > 0.f && !(skyn > 0.f)) a.dL_dweight[q] = 0.f;
+        ok[j] = x < W && y < H;
+        q[j] = ok[j] ? (size_t)y * W + x : 0;
+        xv[j] = a.image[c * HW + q[j]]; yv[j] = a.gt[c * HW + q[j]];
+        gi[j] = (a.dL_dimage ? a.dL_dimage : a.image)[c * HW + q[j]];
+        gd[j] = (fix_depth ? a.dL_ddepth : a.image)[q[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < SS_V; j++) {
+        if (ok[j]) {
+            if (a.dL_dimage) a.dL_dimage[c * HW + q[j]] = gi[j] + scale * (acc[j][0] + 2.f * xv[j] * acc[j][1] + yv[j] * acc[j][2]);
+            if (fix_depth) a.dL_ddepth[q[j]] = cnt > 0.f ? gd[j] * (a.lambda_depth / cnt) : 0.f;
+            if (c == 0 && a.dL_dweight && a.weight && a.sky_mask && a.lambda_sky > 0.f && !(skyn > 0.f)) a.dL_dweight[q[j]] = 0.f;
         }
     }
 }
