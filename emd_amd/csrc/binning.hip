@@ -152,7 +152,12 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const uint32_t e0 = c0 + (uint32_t)c * 4u * EMD_BLOCK + 4u * threadIdx.x;
-            v[c] = e0 < nbv ? bs4[e0 / 4u] : make_uint4(0u, 0u, 0u, 0u);
+            v[c] = bs4[(e0 < nbv ? e0 : 0u) / 4u];                               // (unconditional: a guarded load is waited for where it is issued --
+        }                                                                       //  the eight chunks were eight trips to L2 one after the other)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const uint32_t e0 = c0 + (uint32_t)c * 4u * EMD_BLOCK + 4u * threadIdx.x;
+            if (!(e0 < nbv)) v[c] = make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int c = 0; c < 8; c++) {
@@ -189,7 +194,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
     uint32_t base = s_first[1];
     for (uint32_t gb = s_first[0]; gb < nbv && base < S1; gb++) {
         const uint32_t i = gb * EMD_BLOCK + threadIdx.x;
-        const uint2 br = (i < V) ? bin_s[i] : make_uint2(0u, 0u);
+        const uint2 br_raw = bin_s[i < V ? i : 0u];
+        const uint32_t pid_raw = perm[i < V ? i : 0u];                          // (requested with the record, not behind its count)
+        const uint2 br = (i < V) ? br_raw : make_uint2(0u, 0u);
         const uint32_t cnt = ((br.x >> 20) & 1023u) * (br.y & 1023u);
 #if EMD_DUP_SCAN_OWNER
         // Round 5: the owner of a slot comes from a running maximum over head marks instead of an 8-step binary search per slot (64 dependent
@@ -203,7 +210,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_duplicate(int N, int gx, const ui
         const uint32_t end = base + total;
         s_excl[threadIdx.x] = inc - cnt;
         s_rect[threadIdx.x] = br.x;
-        s_id[threadIdx.x] = cnt ? perm[i] : 0u;
+        s_id[threadIdx.x] = cnt ? pid_raw : 0u;
         s_hs[threadIdx.x] = br.y & 4095u;
         const uint32_t lo_slot = max(S0, base), hi_slot = min(S1, end);
 #if EMD_DUP_SCAN_OWNER

@@ -388,6 +388,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
 // fewer vector instructions per point) was built and measured SLOWER, 5.2 ms: 48 tap registers in flight per iteration, spills at the
 // 128-VGPR cap or three waves per SIMD without them -- four un-spilled waves per SIMD are worth more than the instruction count (DESIGN.md
 // section 8, round 4).  Built without SLP vectorisation (Makefile): the packer cost 129 v_mov per iteration and 8 spilled registers.
+#ifndef HEX_STORES_FIRST
+#define HEX_STORES_FIRST 1
+#endif
 #ifndef HEX_AGG_THREADS
 #define HEX_AGG_THREADS 1024             /* one block per CU (152 KB of LDS at 32 channels), four waves per SIMD */
 #define HEX_AGG_POINTS 256
@@ -582,6 +585,21 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // stage(it + 1) is visible to the wave
             __builtin_amdgcn_wave_barrier();
+#if HEX_STORES_FIRST
+            // Round 5 (late): the rows of a deferred scale's spatial planes leave BEFORE the next gathers are requested.  gfx9 counts loads and
+            // stores on ONE counter, in order: with the stores issued after the gathers, the wait for the gathers at the top of the next
+            // iteration (vmcnt(0): the number of stores in between is not a compile-time constant) also waited for the stores' acknowledgements,
+            // which are the youngest operations in flight; now the gathers are, and the LDS adds below (a different counter) run under them.
+            if (n_cur >= 0 && deferred) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    if (p == 2 || !g.dL_dplanes[s][p]) continue;
+                    const int pidx = p == 3 ? 2 : p;                      // the row itself, at the point's position in that plane's order (plain store)
+                    char* rows = (char*)(g.defer_rows + (defer_base + pidx) * (size_t)a.num_points * C);
+                    *(float*)(rows + (((uint32_t)s_pos[3 * pt + pidx] * C + c) << 2)) = gi[p];
+                }
+            }
+#endif
             if (it + 1 < ITERS) gather(it + 1);                          // in flight while the rows of `it` are scattered
             // ---- the 24 tap rows of the point: rows inside the windows are native fp64 LDS adds, rows outside leave as global float
             // atomics; both are fire and forget
@@ -592,9 +610,11 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     float* gp = g.dL_dplanes[s][p];
                     if (!gp) continue;
                     if (deferred && p != 2 && p < 4) {                    // spatial plane of a deferred scale: the row itself, at the point's
+#if !HEX_STORES_FIRST
                         const int pidx = p == 3 ? 2 : p;                  // position in that plane's order (plain store)
                         char* rows = (char*)(g.defer_rows + (defer_base + pidx) * (size_t)a.num_points * C);
                         *(float*)(rows + (((uint32_t)s_pos[3 * pt + pidx] * C + c) << 2)) = gi[p];
+#endif
                         continue;
                     }
                     if (gi[p] == 0.f) continue;
