@@ -484,9 +484,13 @@ __device__ __forceinline__ void embed_h(const float* __restrict__ wb, const floa
 // branch: [relu] -> Linear(64, 64) -> relu [-> Linear(64, 64) -> relu] -> Linear(64, out_dim)
 // ---------------------------------------------------------------------------------------------------------------------------------
 // LDS (floats): W1 [64][WS] | W2 [64][WS] (DEPTH 2) | Wo [32 NTO][WS] | b1 [64] | b2 [64] | bo [64] | scratch [waves][32][TS] (backward)
+#ifndef MLP_SP_F2
+#define MLP_SP_F2 1           /* forward of the two-hidden-layer feature head: both hidden layers on split bf16 (round 5, late) */
+#endif
 constexpr int branch_mode(int depth, int nto, bool bwd) {
-    // (the two-hidden-layer feature head keeps fp32 MFMA: its six images + transposes would need 167 KB of LDS)
-    return depth != 1 ? 0 : (bwd ? (nto == 1 ? MLP_SP_B11 : MLP_SP_B12) : (nto == 1 ? MLP_SP_F11 : MLP_SP_F12));
+    // (the BACKWARD of the two-hidden-layer feature head keeps fp32 MFMA: its six images + transposes would need 167 KB of LDS; its forward has
+    //  three images only)
+    return depth != 1 ? (bwd ? 0 : MLP_SP_F2) : (bwd ? (nto == 1 ? MLP_SP_B11 : MLP_SP_B12) : (nto == 1 ? MLP_SP_F11 : MLP_SP_F12));
 }
 template <int DEPTH, int NTO, int MODE = 0>
 struct BranchLds {
@@ -552,6 +556,7 @@ __device__ __forceinline__ void branch_stage(float* lds, const EmdMlpBranch& a) 
             stage_split(lds + L::wot, 2, 2 * NTO, a.w_out, 64, 0, a.out_dim, 64, true);
         }
         stage_split(lds + L::w1, 2, 4, a.w_hidden[0], 64, 0, 64, 64, false);
+        if (DEPTH == 2) stage_split(lds + L::w2, 2, 4, a.w_hidden[1], 64, 0, 64, 64, false);        // (forward only: branch_mode)
         // (a narrow output layer runs on the vector pipe in the forward and reads plain fp32 rows: they fit the image's allocation)
         if (!BWD && MLP_NARROW_OUT && NTO == 1 && a.out_dim <= 4) stage_matrix(lds + L::wo, WS, 32, 64, a.w_out, 64, 0, a.out_dim, 64);
         else stage_split(lds + L::wo, NTO, 4, a.w_out, 64, 0, a.out_dim, 64, false);
@@ -611,7 +616,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
         m[0] = relu16(m[0]); m[1] = relu16(m[1]);
         if (DEPTH == 2) {
             f32x16 m2[2] = {bias_tile(lds + L::b2, 0, hh), bias_tile(lds + L::b2, 32, hh)};
-            layer_fwd<2, 2>(m2, m, lds + L::w2, WS, 0, r, hh);
+            mm<L::SP, 2, 2>(m2, m, lds + L::w2, WS, 0, 2, 4, r, hh, lane);
             m[0] = relu16(m2[0]); m[1] = relu16(m2[1]);
         }
         if constexpr (MLP_NARROW_OUT && NTO == 1) {
@@ -1340,6 +1345,13 @@ extern "C" int emd_mlp_branch_backward(const EmdMlpBranch* a, const EmdMlpBranch
         }
         if (l1) return rcm ? launch_branch_bwd1<2, true, true>(a, g, st) : launch_branch_bwd1<2, true, false>(a, g, st);
         return rcm ? launch_branch_bwd1<2, false, true>(a, g, st) : launch_branch_bwd1<2, false, false>(a, g, st);
+    }
+    // two hidden layers (the feature head): the raw-load forms where dL/dout allows them (no chained dL/dh: refused above)
+    if (g->g_out && nto == 1 && a->out_dim <= 4)
+        return l1 ? launch_branch_bwd<2, 1, true, false, 0>(a, g, st) : launch_branch_bwd<2, 1, false, false, 0>(a, g, st);
+    if (g->g_out && (a->out_dim & 3) == 0) {
+        if (l1) return nto == 1 ? launch_branch_bwd<2, 1, true, false, 1>(a, g, st) : launch_branch_bwd<2, 2, true, false, 1>(a, g, st);
+        return nto == 1 ? launch_branch_bwd<2, 1, false, false, 1>(a, g, st) : launch_branch_bwd<2, 2, false, false, 1>(a, g, st);
     }
     if (l1) return nto == 1 ? launch_branch_bwd<2, 1, true, false, 2>(a, g, st) : launch_branch_bwd<2, 2, true, false, 2>(a, g, st);
     return nto == 1 ? launch_branch_bwd<2, 1, false, false, 2>(a, g, st) : launch_branch_bwd<2, 2, false, false, 2>(a, g, st);
