@@ -19,27 +19,58 @@ namespace {
 
 struct RowSrc { const float* p[EMD_ROW_SOURCES]; float* d[EMD_ROW_SOURCES]; int w[EMD_ROW_SOURCES]; int n; };
 
+// A workgroup takes COMPACT_TILES x 256 consecutive Gaussians and claims its output range with ONE atomic (round 5, late): with a claim per 256
+// Gaussians the kernel was 7 800 returning atomics on one address, served one after the other -- 94 us for 100 MB at 2 M Gaussians, whatever the loads
+// and stores around them did (requesting a row's values together, assembling the rows in LDS: both measured, no change).  Ranks inside the range: wave
+// ballots + a 32-entry table of (tile, wave) counts, so the rows of a workgroup stay in index order.
+#define COMPACT_TILES 8
 __global__ void __launch_bounds__(EMD_BLOCK) k_compact_rows(int N, const int32_t* __restrict__ radii, RowSrc s, int row_words, uint32_t cap,
                                                             uint32_t* __restrict__ rows, uint32_t* __restrict__ counter) {
-    __shared__ uint32_t s_scan[4];
+    __shared__ uint32_t s_cnt[COMPACT_TILES][EMD_BLOCK / 64];
     __shared__ uint32_t s_base;
-    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
-    const bool vis = i < N && radii[i] > 0;
-    uint32_t total;
-    const uint32_t incl = block_scan_add_u32(vis ? 1u : 0u, s_scan, &total);
-    if (threadIdx.x == 0) s_base = total ? atomicAdd(counter, total) : 0u;
-    __syncthreads();
-    if (!vis) return;
-    const uint32_t slot = s_base + incl - 1u;
-    if (slot >= cap) return;                                       // (the header reports it: the caller must not use this step's exchange)
-    uint32_t* r = rows + (size_t)(slot + 1u) * row_words;
-    r[0] = (uint32_t)i;
-    int o = 1;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const size_t chunk0 = (size_t)blockIdx.x * (COMPACT_TILES * EMD_BLOCK);
+    int32_t rad[COMPACT_TILES];
 #pragma unroll
-    for (int k = 0; k < EMD_ROW_SOURCES; k++) {
-        if (k >= s.n) break;
-        for (int c = 0; c < s.w[k]; c++) r[o + c] = __float_as_uint(s.p[k][(size_t)i * s.w[k] + c]);
-        o += s.w[k];
+    for (int t = 0; t < COMPACT_TILES; t++) {                       // (all of the thread's radii together)
+        const size_t i = chunk0 + (size_t)t * EMD_BLOCK + threadIdx.x;
+        rad[t] = radii[i < (size_t)N ? i : 0];
+    }
+    unsigned long long bal[COMPACT_TILES];
+#pragma unroll
+    for (int t = 0; t < COMPACT_TILES; t++) {
+        const size_t i = chunk0 + (size_t)t * EMD_BLOCK + threadIdx.x;
+        bal[t] = __ballot(i < (size_t)N && rad[t] > 0);
+        if (lane == 0) s_cnt[t][wave] = (uint32_t)__popcll(bal[t]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int t = 0; t < COMPACT_TILES; t++)
+            for (int w = 0; w < EMD_BLOCK / 64; w++) total += s_cnt[t][w];
+        s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t run = s_base;                                          // rows in front of (tile t, this wave)
+#pragma unroll
+    for (int t = 0; t < COMPACT_TILES; t++) {
+        uint32_t before = run;
+#pragma unroll
+        for (int w = 0; w < EMD_BLOCK / 64; w++) { if ((uint32_t)w < wave) before += s_cnt[t][w]; run += s_cnt[t][w]; }
+        const bool vis = (bal[t] >> lane) & 1ull;
+        if (!vis) continue;
+        const uint32_t slot = before + (uint32_t)__popcll(bal[t] & ((1ull << lane) - 1ull));
+        if (slot >= cap) continue;                                  // (the header reports it: the caller must not use this step's exchange)
+        const size_t i = chunk0 + (size_t)t * EMD_BLOCK + threadIdx.x;
+        uint32_t* r = rows + (size_t)(slot + 1u) * row_words;
+        r[0] = (uint32_t)i;
+        int o = 1;
+#pragma unroll
+        for (int k = 0; k < EMD_ROW_SOURCES; k++) {
+            if (k >= s.n) break;
+            for (int c = 0; c < s.w[k]; c++) r[o + c] = __float_as_uint(s.p[k][i * s.w[k] + c]);
+            o += s.w[k];
+        }
     }
 }
 
@@ -96,7 +127,8 @@ extern "C" int emd_compact_rows(int32_t n, const int32_t* radii, int32_t num_sou
     int rc = emd_zero_async(counter, 4, st);
     if (rc) return rc;
     if (n > 0) {
-        hipLaunchKernelGGL(k_compact_rows, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, st, n, radii, s, row_words, (uint32_t)capacity, rows, counter);
+        hipLaunchKernelGGL(k_compact_rows, dim3((n + COMPACT_TILES * EMD_BLOCK - 1) / (COMPACT_TILES * EMD_BLOCK)), dim3(EMD_BLOCK), 0, st, n, radii, s, row_words,
+                           (uint32_t)capacity, rows, counter);
         EMD_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_rows_header, dim3(1), dim3(64), 0, st, counter, (uint32_t)capacity, row_words, rows);
