@@ -13,6 +13,7 @@
 // HBM-bound by construction: 3 planar image reads/writes per pixel + 4 x 12 B texel gathers that hit L2.
 // The lookup restates the published nvdiffrast algorithm (oracle/sky_oracle.py; PARITY UNPINNED for that part).
 #include "common.h"
+#include "device_utils.h"
 
 namespace {
 
@@ -147,10 +148,12 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sky_forward(EmdSkyArgs a) {
 // global atomic.  One global atomic per touched texel and channel leaves the workgroup.
 #define SKY_WIN 24
 __global__ void __launch_bounds__(EMD_BLOCK) k_sky_backward(EmdSkyBwdArgs b) {
-    __shared__ float s_val[SKY_WIN * SKY_WIN * 3];
+    // fp64 cells: ds_add_f64 is the native LDS float add that runs at rate on gfx950 (8.9 clocks per wave64 instruction; ds_add_f32, which a plain
+    // atomicAdd on a __shared__ float compiles to, takes 193: profiles/r03_lds_atomic_microbench.txt -- twelve of them per pixel were this kernel)
+    __shared__ double s_val[SKY_WIN * SKY_WIN * 3];
     __shared__ int s_org[3];     // face, u0, v0 of the window
     const EmdSkyArgs& a = b.f;
-    for (int i = threadIdx.x; i < SKY_WIN * SKY_WIN * 3; i += EMD_BLOCK) s_val[i] = 0.f;
+    for (int i = threadIdx.x; i < SKY_WIN * SKY_WIN * 3; i += EMD_BLOCK) s_val[i] = 0.0;
     const size_t P = (size_t)a.height * a.width;
     const int res = a.resolution;
     size_t p;
@@ -167,12 +170,25 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sky_backward(EmdSkyBwdArgs b) {
         valid = p < P;
         px = (int)p; py = 0;
     }
-    const bool il = (a.flags & EMD_SKY_INTERLEAVED) != 0;
     float acc = 0.f, gs[3] = {0.f, 0.f, 0.f};
     bool sampled = false;
     Tap tp;
+    const bool il = (a.flags & EMD_SKY_INTERLEAVED) != 0;
+    // the pixel's inputs first, unconditionally (an absent input reads the cube map's first texel and is not used; a pixel outside the image reads
+    // pixel 0): with the loads inside the branches that use them the thread made a trip to memory per input, one after the other
+    const size_t pcl = valid ? p : 0;
+    const bool blend = b.dL_dout && a.fg;
+    const float acc_raw = *(a.acc ? a.acc + pcl : a.cube);
+    float gsky_raw[3], gout_raw[3], fg_raw[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const size_t q = il ? 3 * pcl + c : (size_t)c * P + pcl;
+        gsky_raw[c] = *(b.dL_dsky ? b.dL_dsky + q : a.cube);
+        gout_raw[c] = *(blend ? b.dL_dout + q : a.cube);
+        fg_raw[c] = *(blend ? a.fg + q : a.cube);
+    }
     if (valid) {
-        acc = a.acc ? a.acc[p] : 0.f;
+        acc = a.acc ? acc_raw : 0.f;
         sampled = !(a.acc && a.mask_threshold >= 0.f) || (1.f - acc) > a.mask_threshold;
         float s[3] = {a.fill, a.fill, a.fill};
         bool pass[3] = {false, false, false};
@@ -197,9 +213,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sky_backward(EmdSkyBwdArgs b) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const size_t q = il ? 3 * p + c : (size_t)c * P + p;
-            gs[c] = b.dL_dsky ? b.dL_dsky[q] : 0.f;
-            if (b.dL_dout && a.fg) {
-                const float g = b.dL_dout[q], f = a.fg[q];
+            gs[c] = b.dL_dsky ? gsky_raw[c] : 0.f;
+            if (blend) {
+                const float g = gout_raw[c], f = fg_raw[c];
                 gs[c] += g * (1.f - acc);
                 if (a.flags & EMD_SKY_BLEND_S3G) { dacc += g * (f - s[c]); if (b.dL_dfg) b.dL_dfg[q] = g * acc; }
                 else { dacc -= g * s[c]; if (b.dL_dfg) b.dL_dfg[q] = g; }
@@ -235,14 +251,14 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_sky_backward(EmdSkyBwdArgs b) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 if (gs[c] == 0.f) continue;
-                if (in_win) atomicAdd(&s_val[(wv * SKY_WIN + wu) * 3 + c], tp.w[k] * gs[c]);
+                if (in_win) lds_add_f64(&s_val[(wv * SKY_WIN + wu) * 3 + c], tp.w[k] * gs[c]);
                 else atomicAdd(b.dL_dcube + (size_t)key * 3 + c, tp.w[k] * gs[c]);
             }
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SKY_WIN * SKY_WIN * 3; i += EMD_BLOCK) {
-        const float v = s_val[i];
+        const float v = (float)s_val[i];
         if (v == 0.f) continue;
         const int t = i / 3, wu = t % SKY_WIN + ou, wv = t / SKY_WIN + ov;
         if (wu < 0 || wu >= res || wv < 0 || wv >= res) continue;     // never written: in_win implies a real texel
