@@ -44,7 +44,6 @@ __device__ __forceinline__ float block_sum(float v, float* s4) {
 // sums: [0] sum |x - y|   [1] sum ssim map   [2] sum depth sq. err   [3] valid depth count   [4] sum sky bce   [5] sky pixel count
 #define NUM_SUMS 6
 __global__ void __launch_bounds__(EMD_BLOCK) k_loss_pointwise(EmdLossArgs a, float* __restrict__ sums) {
-    __shared__ float s4[4];
     const size_t HW = (size_t)a.height * a.width;
     const size_t p = (size_t)blockIdx.x * EMD_BLOCK + threadIdx.x;
     float l1 = 0.f, dsq = 0.f, dcnt = 0.f, sky = 0.f, skyn = 0.f;
@@ -95,7 +94,17 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_loss_pointwise(EmdLossArgs a, flo
             }
         }
     }
-    l1 = block_sum(l1, s4); dsq = block_sum(dsq, s4); dcnt = block_sum(dcnt, s4); sky = block_sum(sky, s4); skyn = block_sum(skyn, s4);
+    {   // the five block sums through ONE barrier (five block_sum calls were ten)
+        __shared__ float s5[5][4];
+        const float w0 = wave_scan_add_f32(l1), w1 = wave_scan_add_f32(dsq), w2 = wave_scan_add_f32(dcnt), w3 = wave_scan_add_f32(sky), w4 = wave_scan_add_f32(skyn);
+        if ((threadIdx.x & 63) == 63) { const int w = threadIdx.x >> 6; s5[0][w] = w0; s5[1][w] = w1; s5[2][w] = w2; s5[3][w] = w3; s5[4][w] = w4; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            l1 = (s5[0][0] + s5[0][1]) + (s5[0][2] + s5[0][3]); dsq = (s5[1][0] + s5[1][1]) + (s5[1][2] + s5[1][3]);
+            dcnt = (s5[2][0] + s5[2][1]) + (s5[2][2] + s5[2][3]); sky = (s5[3][0] + s5[3][1]) + (s5[3][2] + s5[3][3]);
+            skyn = (s5[4][0] + s5[4][1]) + (s5[4][2] + s5[4][3]);
+        }
+    }
     if (threadIdx.x == 0) {
         const int slot = blockIdx.x & (SUM_SLOTS - 1);
         atomicAdd(sums + SUM_AT(0) + slot, l1);
