@@ -75,8 +75,8 @@ __device__ __forceinline__ f32x16 mask16(f32x16 g, f32x16 y) {
 // wide: ld and c0 multiples of 4, the whole 32-feature tile inside the row.
 // STRAIGHT: rows past the end load row 0 and are zeroed afterwards instead of branching around the load.  A branch makes the compiler
 // fall back to s_waitcnt vmcnt(0) at the join, which waits for the prefetch of the NEXT tile in every iteration (SQ_WAIT_ANY 15-25 %
-// of the wave time): the forward kernels gain 12-15 % from the straight form; the backward kernels, whose schedule is ruled by
-// register pressure, lose as much, so they keep the branch (both measured).
+// of the wave time): the forward kernels gain 12-15 % from the straight form.  (The backward kernels lost as much with it when this was written --
+// the product behind the load put the wait AT the load -- and kept the branch until round 5: they now use load_tile_raw / mask_tile below.)
 // `width` (a multiple of 4): columns >= width do not exist and read as 0 (the last tile of a narrow xa)
 // A/B knob (round 5): the [N, 64..128] activation / gradient streams of these kernels are each far larger than the 256 MiB Infinity Cache and
 // are touched once or twice per step; nontemporal accesses keep them from evicting what IS reused (the HexPlane planes, the weights).
