@@ -594,8 +594,11 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
     // the next tile's rows are loaded while this tile computes: one wave per SIMD has nothing else to hide the HBM latency behind
     f32x16 nx[2];
     float nxb[4];
+    // (h travels raw: a row past the end reads row 0 and its outputs are neither stored nor counted -- a product or select behind the load puts the
+    //  wait for the prefetch AT the load)
+    auto hrow = [&](size_t row_) -> size_t { return row_ < N ? row_ : 0; };
     if constexpr (RC) load_xb_raw(a.xb, a.kb_in, tile0 * 32 + r, tile0 * 32 + r < N, hh, nxb);
-    else { nx[0] = load_tile<true>(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 0, hh); nx[1] = load_tile<true>(a.h, 64, tile0 * 32 + r, tile0 * 32 + r < N, 32, hh); }
+    else { nx[0] = load_tile_raw(a.h, 64, hrow(tile0 * 32 + r), 0, hh); nx[1] = load_tile_raw(a.h, 64, hrow(tile0 * 32 + r), 32, hh); }
     for (size_t tile = tile0; tile < tiles; tile += tstep) {
         const size_t row = tile * 32 + r;
         const bool ok = row < N;
@@ -608,7 +611,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
             embed_h(rc, rc + 64 * 12, r, hh, xb, x);
         } else {
             x[0] = nx[0]; x[1] = nx[1];
-            nx[0] = load_tile<true>(a.h, 64, nrow, nrow < N, 0, hh); nx[1] = load_tile<true>(a.h, 64, nrow, nrow < N, 32, hh);
+            nx[0] = load_tile_raw(a.h, 64, hrow(nrow), 0, hh); nx[1] = load_tile_raw(a.h, 64, hrow(nrow), 32, hh);
         }
         if (a.relu_input) { x[0] = relu16(x[0]); x[1] = relu16(x[1]); }
         f32x16 m[2] = {bias_tile(lds + L::b1, 0, hh), bias_tile(lds + L::b1, 32, hh)};
@@ -931,6 +934,22 @@ __device__ __forceinline__ void trunk_forward_tile(const float* lds, int r, int 
     embed_h(lds + L::wb, lds + L::b, r, hh, xb, h, false);
 }
 
+// raw rows for the forward's prefetch: clamped row, a column past the width reads column 0 (its weights are zero: the staged images are zero padded);
+// nothing is masked -- the rows past the end are not stored
+template <int KTA>
+__device__ __forceinline__ void trunk_load_x_raw(const EmdMlpTrunk& a, size_t row_c, int hh, f32x16 (&xa)[KTA ? KTA : 1], float (&xb)[4]) {
+    if (KTA) {
+#pragma unroll
+        for (int t = 0; t < KTA; t++) xa[t] = load_tile_raw(a.xa, a.ka, row_c, 32 * t, hh, a.ka);
+    }
+    if (a.kb > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) xb[j] = a.xb[row_c * (size_t)a.kb + (4 * hh + j < a.kb ? 4 * hh + j : 0)];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) xb[j] = 0.f;
+    }
+}
 template <int KTA, bool STRAIGHT>
 __device__ __forceinline__ void trunk_load_x(const EmdMlpTrunk& a, size_t row, bool ok, int hh, f32x16 (&xa)[KTA ? KTA : 1], float (&xb)[4]) {
     if (KTA) {
@@ -950,7 +969,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(KTA == 0 ? MLP_W_T0 : MLP
     // the next tile's rows are loaded while this tile computes (one wave per SIMD: nothing else hides the HBM latency)
     f32x16 nxa[KTA ? KTA : 1];
     float nxb[4];
-    trunk_load_x<KTA, (KTA > 0)>(a, tile0 * 32 + r, tile0 * 32 + r < N, hh, nxa, nxb);
+    trunk_load_x_raw<KTA>(a, tile0 * 32 + r < N ? tile0 * 32 + r : 0, hh, nxa, nxb);
     for (size_t tile = tile0; tile < tiles; tile += tstep) {
         const size_t row = tile * 32 + r;
         const bool ok = row < N;
@@ -962,7 +981,7 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC(KTA == 0 ? MLP_W_T0 : MLP
         for (int j = 0; j < 4; j++) xb[j] = nxb[j];
         {
             const size_t nrow = (tile + tstep) * 32 + r;
-            trunk_load_x<KTA, (KTA > 0)>(a, nrow, nrow < N, hh, nxa, nxb);
+            trunk_load_x_raw<KTA>(a, nrow < N ? nrow : 0, hh, nxa, nxb);
         }
         trunk_forward_tile<KTA>(lds, r, hh, xa, xb, h);
         store_tile(a.h, 64, row, ok, 0, hh, h[0]);
