@@ -673,9 +673,17 @@ __global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 &
             else store_tile_narrow(a.out, a.out_dim, row, ok, 32 * t, hh, o[t]);
         }
     }
-    if (L1 && a.l1_sum) {                             // one atomic per wave: mean |out| over the N x out_dim outputs
+    if (L1 && a.l1_sum) {                             // mean |out| over the N x out_dim outputs: ONE atomic per workgroup (a float atomic per wave was
+        __shared__ float s_l1[MLP_WAVES];             // 1 024 - 2 048 atomics on one address at the very end of the kernel, served one after the other: ~40 us)
         const float s = wave_reduce_to_lane63(l1_acc);
-        if (lane == 63) atomicAdd(a.l1_sum, s / ((float)a.num_points * (float)a.out_dim));
+        if (lane == 63) s_l1[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < MLP_WAVES; w++) t += s_l1[w];
+            atomicAdd(a.l1_sum, t / ((float)a.num_points * (float)a.out_dim));
+        }
     }
 }
 

@@ -336,7 +336,7 @@ class Deformation(nn.Module):
     _HEADS = (("pos_deform", "no_dx", "dx"), ("scales_deform", "no_ds", "ds"), ("rotations_deform", "no_dr", "dr"),
               ("opacity_deform", "no_do", "do"), ("shs_deform", "no_dshs", "dshs"))
 
-    def _level_fused(self, pts, time_emb, embeddings, coarse, it, num_down_emb, need_feat=True, l1_dshs=False):
+    def _level_fused(self, pts, time_emb, embeddings, coarse, it, num_down_emb, need_feat=True, l1_dshs=False, l1_keys=()):
         """The same level as `_feature` + `_heads`, or None when the configuration is outside what the fused kernels serve (width 64,
         defor_depth 1, at most 128 HexPlane features, an embedding of at most 8 values, at most six heads): the GEMM path then runs."""
         from . import mlp
@@ -365,20 +365,25 @@ class Deformation(nn.Module):
             col += T
         xa = self.grid(pts[:, :3], time_emb[:, :1]) if use_hex else None
         keys = [key for _, key in heads]
-        l1_heads = [keys.index("dshs")] if (l1_dshs and "dshs" in keys) else []
+        l1_names = [k for k in (tuple(l1_keys) + (("dshs",) if l1_dshs else ())) if k in keys]
+        l1_names = list(dict.fromkeys(l1_names))                   # (unique, in the order asked for)
+        l1_heads = [keys.index(k) for k in l1_names]
         outs = mlp.level_mlp(xa, embeddings if use_emb else None, Wm, bias, 0, col, branches, l1_heads=l1_heads)
         out = dict(dx=None, ds=None, dr=None, do=None, dshs=None, feat=None)
         for (_, key), o in zip(heads, outs):
             out[key] = o.reshape(o.shape[0], 16, 3) if key == "dshs" else o
         if feat:
             out["feat"] = outs[len(branches) - 1]
-        if l1_heads:
-            out["dshs_abs_mean"] = outs[len(branches)]          # mean |dshs| from the head's own kernels (regulariser of train.py:238-310)
+        for j, k in enumerate(l1_names):
+            out[k + "_abs_mean"] = outs[len(branches) + j]      # mean |residual| from the head's own kernels (regularisers of train.py:238-310)
         return out
 
     def forward(self, rays_pts_emb, time_emb=None, embeddings=None, is_coarse=True, iter=None, num_down_emb_c=30, num_down_emb_f=30,
-                apply_deform=True, time_diff=1.0, is_train=False, need_feat=True, l1_dshs=False):
+                apply_deform=True, time_diff=1.0, is_train=False, need_feat=True, l1_dshs=False, l1_keys=()):
         """`l1_dshs` (not a reference argument): on the fused kernels the level's dict also carries "dshs_abs_mean" = mean |dshs|.
+        `l1_keys` (likewise): residual names ("dx", "do", "ds", "dr", "dshs") whose mean |.| is formed by the head's own kernels and returned as
+        "<key>_abs_mean" -- the regularisers of train.py:238-310 without an abs-mean launch each way and without the add autograd needs to join the
+        regulariser's gradient with the rasterizer's (emd_amd.model.residual_abs_mean picks them up).
         `need_feat=False` (not a reference argument): the caller will not read ddict["feat"], so the feature head is not evaluated
         (its entry is None); the default evaluates it whenever `feat_head` is set, as the reference does."""
         if time_emb is None:
@@ -386,7 +391,7 @@ class Deformation(nn.Module):
         if not apply_deform:
             return None
         n_rows = num_down_emb_c if is_coarse else num_down_emb_f
-        fused = self._level_fused(rays_pts_emb, time_emb, embeddings, is_coarse, iter, n_rows, need_feat, l1_dshs)
+        fused = self._level_fused(rays_pts_emb, time_emb, embeddings, is_coarse, iter, n_rows, need_feat, l1_dshs, l1_keys)
         if fused is not None:
             return fused
         hidden = self._feature(rays_pts_emb, time_emb, embeddings, is_coarse, iter, n_rows)
@@ -450,7 +455,7 @@ class deform_network(nn.Module):
         return point_f, scales_f, rot_f, opac_f, shs_f
 
     def forward(self, point, scales=None, rotations=None, opacity=None, shs=None, times_sel=None, embeddings=None, iter=None, cam_no=None,
-                time_diff=None, is_train=None, need_feat=True, fused_shs_residuals=False):
+                time_diff=None, is_train=None, need_feat=True, fused_shs_residuals=False, fused_l1=()):
         """`fused_shs_residuals` (not in the reference): the SH residuals are NOT added to `shs`; they are returned as
         ddict["shs_residuals"] for `GaussianRasterizer(..., shs_residuals=...)`, which forms shs + dshs_c + dshs_f for the visible Gaussians
         inside its projection kernel, and each level's dict carries "dshs_abs_mean" -- mean |dshs|, the regulariser of train.py:238-310,
@@ -459,6 +464,8 @@ class deform_network(nn.Module):
         net = self.deformation_net
         times_sel = net.forward_time_offset(times_sel, cam_no)
         lk = {"l1_dshs": True} if fused_shs_residuals else {}
+        if fused_l1:                                               # (`fused_l1`, not in the reference: see Deformation.forward's l1_keys)
+            lk["l1_keys"] = tuple(fused_l1)
         ddict_c = net(point, times_sel, embeddings, is_coarse=True, iter=iter, num_down_emb_c=self.min_embeddings,
                       apply_deform=not self.no_coarse_deform, time_diff=time_diff, is_train=is_train, need_feat=need_feat, **lk)
         pts = point

@@ -142,7 +142,7 @@ def pre_compute_colors(shs, xyz, camera_center, degree):
 
 def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activations=True, deformation=None, embeddings=None,
            iteration=None, time=None, options=None, record=None, render_feat=False, need_feat=True, combine_dynamic_static=False,
-           convert_SHs_python=False, residual=None):
+           convert_SHs_python=False, residual=None, fused_l1=()):
     """The reference render() restricted to the hot path; returns the dict the training loop consumes.
     `deformation` (an emd_amd.deformation.deform_network) switches on the "fine" stage of gaussian_renderer/__init__.py:86-96:
     the residuals of the self-supervised EMD network are added to the raw parameters before the activations.
@@ -178,6 +178,8 @@ def render(model: StreetGaussians, cam, bg, frame=0, debug=False, fuse_activatio
         from .deformation import deform_network as _dn
         # (an emd_amd network hands the SH residuals over unsummed: `shs + dshs_c + dshs_f` is formed inside the projection kernel)
         extra_kw = {"need_feat": bool(need_feat or render_feat), "fused_shs_residuals": True} if isinstance(deformation, _dn) else {}
+        if fused_l1 and isinstance(deformation, _dn):
+            extra_kw["fused_l1"] = tuple(fused_l1)      # ddict[level]["<key>_abs_mean"]: the residual regularisers formed by the head kernels (residual_abs_mean)
         means3D, scales, rotations, opacity, shs, ddict = deformation(
             means3D, scales, rotations, opacity, shs, times_sel, embeddings, iteration, int(getattr(cam, "cam_no", 0)),
             getattr(cam, "time_diff", 0.0), True, **extra_kw)

@@ -14,6 +14,8 @@ images rendered as extra colour sets of the main rasterizer call (one binning, t
 and sky rays are host constants of a frame and are baked into its graph) and replayed -- the host then spends ~0.05 ms per step
 instead of 15-19 ms issuing ~170 launches from Python, so the rate is the GPU's whatever the host is doing; one replay is checked
 against the eager step of the same frame before the timed region.
+--fused-l1 (with --fine): the dx / do regularisers formed by the head kernels (render(..., fused_l1=("dx", "do"))) instead of abs_mean launches --
+measured SLOWER (12.38 against 12.30 ms: the regularised instantiation of the narrow heads' forward takes 172 us against 130-140), so not the default.
 --adam / --torch-adam: also take the optimiser step (train.py:428) with emd_amd.optim.Adam / torch.optim.Adam over the groups of
 gaussian_model.py:188-199 (per-group learning rates, eps 1e-15)."""
 import json
@@ -87,7 +89,7 @@ def step(s):
         p.grad = None
     sky.sky_cube_map.grad = None
     out = render(model, cams[f], bg, frame=f, deformation=deform, embeddings=embeddings, iteration=12000 + s, time=f / (F - 1), options=OPTS[0],
-                 render_feat=FEAT and not FEAT_SEP, need_feat=FEAT)
+                 render_feat=FEAT and not FEAT_SEP, need_feat=FEAT, fused_l1=("dx", "do") if (FINE and "--fused-l1" in sys.argv) else ())
     if FEAT and FEAT_SEP:        # the reference's three calls: main pass above + one call per feature set, same rasterizer object
         bd, dd = out["boundary"], out["ddict"]
         base = dict(means3D=bd["means3D"], means2D=out["viewspace_points"], opacities=bd["opacities"], scales=bd["scales"],
@@ -99,7 +101,7 @@ def step(s):
     if FINE:                                           # residual regularisers (train.py: lambda_dx / do / dshs on both levels)
         for lvl in ("coarse", "fine"):
             d = out["ddict"][lvl]
-            loss = loss + 0.001 * (abs_mean(d["dx"]) + abs_mean(d["do"]) + residual_abs_mean(d, "dshs"))
+            loss = loss + 0.001 * (residual_abs_mean(d, "dx") + residual_abs_mean(d, "do") + residual_abs_mean(d, "dshs"))
     if FEAT:
         loss = loss + 0.001 * (((out["feat_c"] - gt_feat) ** 2).mean() + ((out["feat_f"] - gt_feat) ** 2).mean())
     loss.backward()

@@ -285,6 +285,52 @@ def test_fused_sh_residuals_and_regulariser_equal_the_reference_formulation():
             assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(b_.abs().max()), 1e-20), tuple(p.shape)
 
 
+def test_residual_regularisers_folded_into_the_head_kernels_equal_the_separate_ops():
+    """render(..., fused_l1=("dx", "do")): the regularisers mean |dx|, mean |do| of train.py:238-310 formed by the head kernels themselves
+    (ddict[level]["dx_abs_mean"], picked up by model.residual_abs_mean) against abs_mean() on the residual tensors: same image, same loss,
+    same gradients of every parameter -- without an abs-mean launch each way per residual and level, and without the add autograd needs to
+    join the regulariser's gradient with the rasterizer's."""
+    from emd_amd import scenes
+    from emd_amd.deformation import DeformOptions, deform_network
+    from emd_amd.model import StreetGaussians, abs_mean, l1_loss, render, residual_abs_mean
+    dev = torch.device("cuda", 0)
+    N, H, W = 15000, 80, 128
+    model = StreetGaussians(scenes.make_static_scene(N, seed=8), dev)
+    torch.manual_seed(9)
+    deform = deform_network(DeformOptions()).to(dev)
+    deform.deformation_net.set_aabb([120.0, 30.0, 10.0], [0.0, -30.0, -2.0])
+    for n_, p_ in deform.named_parameters():
+        if p_.dim() > 1 and "grid" not in n_:
+            p_.data.mul_(0.05)
+    emb = torch.nn.Parameter(0.1 * torch.randn(N, 4, device=dev))
+    cam, bg = scenes.rig_camera(3, 0, H, W), torch.zeros(3)
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    params = list(model.parameters()) + list(deform.parameters()) + [emb]
+
+    def run(folded):
+        for p in params:
+            p.grad = None
+        out = render(model, cam, bg, frame=0, deformation=deform, embeddings=emb, iteration=12000, time=0.4, fused_l1=("dx", "do") if folded else ())
+        loss = l1_loss(out["render"], target)
+        for lvl in ("coarse", "fine"):
+            d = out["ddict"][lvl]
+            assert ("dx_abs_mean" in d) == folded and ("do_abs_mean" in d) == folded
+            if folded:
+                loss = loss + 0.02 * residual_abs_mean(d, "dx") + 0.03 * residual_abs_mean(d, "do") + 0.01 * residual_abs_mean(d, "dshs")
+            else:
+                loss = loss + 0.02 * abs_mean(d["dx"]) + 0.03 * abs_mean(d["do"]) + 0.01 * residual_abs_mean(d, "dshs")
+        loss.backward()
+        return out["render"].detach().clone(), float(loss.detach()), [None if p.grad is None else p.grad.clone() for p in params]
+    img_a, loss_a, g_a = run(True)
+    img_b, loss_b, g_b = run(False)
+    assert torch.equal(img_a, img_b)
+    assert abs(loss_a - loss_b) <= 1e-6 * abs(loss_b)
+    for p, a_, b_ in zip(params, g_a, g_b):
+        assert (a_ is None) == (b_ is None)
+        if a_ is not None:
+            assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(b_.abs().max()), 1e-20), tuple(p.shape)
+
+
 def test_step_graphs_replay_the_fine_stage_step_per_frame():
     """emd_amd.graphs.StepGraphs: one hipGraph per frame of a fine-stage step (deformation network -> rasterizer -> sky blend -> loss -> backward
     -> densification statistics -> capturable Adam), all in one pool.  (a) Without the optimiser every replay leaves the gradients of the eager
