@@ -83,6 +83,9 @@ __device__ __forceinline__ f32x16 mask16(f32x16 g, f32x16 y) {
 #ifndef MLP_NT
 #define MLP_NT 0
 #endif
+#ifndef MLP_L1_F11_TWO
+#define MLP_L1_F11_TWO 1      /* the narrow heads' forward WITH the folded L1 sum also runs two waves per SIMD (195 -> 182 us at 2 M rows; 152 without the sum) */
+#endif
 #ifndef MLP_NARROW_OUT
 #define MLP_NARROW_OUT 1      /* output layers of <= 4 features run on the vector pipe instead of a padded 32-row MFMA tile (forward) */
 #endif
@@ -580,7 +583,7 @@ __device__ __forceinline__ void branch_stage(float* lds, const EmdMlpBranch& a) 
 // the usual kernels as they were
 // RC: the head forms h = b_in + W_in xb itself (EmdMlpBranch.xb, a level without HexPlane features) instead of reading a [N,64] tensor
 template <int DEPTH, int NTO, bool L1 = false, bool RC = false>
-__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 && !L1) ? MLP_W_F11 : MLP_FWD_WAVES) k_mlp_branch_fwd(EmdMlpBranch a) {
+__global__ void __launch_bounds__(MLP_THREADS) MLP_OCC((DEPTH == 1 && NTO == 1 && (!L1 || MLP_L1_F11_TWO)) ? MLP_W_F11 : MLP_FWD_WAVES) k_mlp_branch_fwd(EmdMlpBranch a) {
     typedef BranchLds<DEPTH, NTO, branch_mode(DEPTH, NTO, false)> L;
     extern __shared__ float lds[];
     branch_stage<DEPTH, NTO, false, RC>(lds, a);
@@ -1315,14 +1318,14 @@ extern "C" int emd_mlp_branch_forward(const EmdMlpBranch* a, void* hip_stream) {
     if (a->xb) {
         typedef BranchLds<1, 1, branch_mode(1, 1, false)> L1_; typedef BranchLds<1, 2, branch_mode(1, 2, false)> L2_;
         if (a->l1_sum) {
-            if (nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1, true, true>, MLP_FWD_WAVES>(L1_::fwd_floats + L1_::rc_floats, a->num_points, st, *a);
+            if (nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1, true, true>, (MLP_L1_F11_TWO ? MLP_W_F11 : MLP_FWD_WAVES)>(L1_::fwd_floats + L1_::rc_floats, a->num_points, st, *a);
             return mlp_launch<k_mlp_branch_fwd<1, 2, true, true>, MLP_FWD_WAVES>(L2_::fwd_floats + L2_::rc_floats, a->num_points, st, *a);
         }
         if (nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1, false, true>, MLP_W_F11>(L1_::fwd_floats + L1_::rc_floats, a->num_points, st, *a);
         return mlp_launch<k_mlp_branch_fwd<1, 2, false, true>, MLP_FWD_WAVES>(L2_::fwd_floats + L2_::rc_floats, a->num_points, st, *a);
     }
     if (a->l1_sum) {
-        if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1, true>, MLP_FWD_WAVES>(BranchLds<1, 1, branch_mode(1, 1, false)>::fwd_floats, a->num_points, st, *a);
+        if (a->depth == 1 && nto == 1) return mlp_launch<k_mlp_branch_fwd<1, 1, true>, (MLP_L1_F11_TWO ? MLP_W_F11 : MLP_FWD_WAVES)>(BranchLds<1, 1, branch_mode(1, 1, false)>::fwd_floats, a->num_points, st, *a);
         if (a->depth == 1) return mlp_launch<k_mlp_branch_fwd<1, 2, true>, MLP_FWD_WAVES>(BranchLds<1, 2, branch_mode(1, 2, false)>::fwd_floats, a->num_points, st, *a);
         if (nto == 1) return mlp_launch<k_mlp_branch_fwd<2, 1, true>, MLP_FWD_WAVES>(BranchLds<2, 1, branch_mode(2, 1, false)>::fwd_floats, a->num_points, st, *a);
         return mlp_launch<k_mlp_branch_fwd<2, 2, true>, MLP_FWD_WAVES>(BranchLds<2, 2, branch_mode(2, 2, false)>::fwd_floats, a->num_points, st, *a);
