@@ -61,7 +61,10 @@ def _leaves(net):
     (1000, 0, 4, [(True, 1, 3), (True, 1, 1), (True, 1, 48)]),                            # the fine level of the run script without the feature head
     (37, 0, 8, [(True, 1, 4), (False, 1, 64)]),                                           # ragged tile, the widest embedding, an un-rectified input
     (70001, 0, 5, [(True, 1, 3), (True, 1, 48)]),                                         # many tiles per wave, odd embedding width
-], ids=["coarse", "fine", "ragged", "golden-shape", "ka72", "70k", "fine-recomputed", "ragged-recomputed", "70k-recomputed"])
+    # every way dL/dout reaches the backward kernels: one output tile of 8 / 16 / 32 floats (16-byte pieces, partial tile), odd widths (guarded path), with h read ...
+    (333, 16, 4, [(True, 1, 16), (True, 1, 32), (True, 1, 8), (True, 1, 7), (True, 1, 33)]),
+    (333, 0, 4, [(True, 1, 16), (True, 1, 7), (True, 1, 33), (False, 1, 12)]),            # ... and with h recomputed from the embedding
+], ids=["coarse", "fine", "ragged", "golden-shape", "ka72", "70k", "fine-recomputed", "ragged-recomputed", "70k-recomputed", "dout-forms", "dout-forms-recomputed"])
 def test_level_mlp_matches_float64(N, ka, kb, heads):
     from emd_amd.mlp import level_mlp
     g = torch.Generator().manual_seed(N + ka + kb)
