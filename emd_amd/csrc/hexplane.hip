@@ -65,10 +65,15 @@ __device__ __forceinline__ Bilin make_bilin(const Tap1& tx, const Tap1& ty) {
 }
 
 // plane pair p of (0,1),(0,2),(0,3),(1,2),(1,3),(2,3): first index -> width axis, second -> height axis
+// (arithmetic, not a table: with a lane-varying p -- the staging phases, item = (point, plane) -- a table is a load from constant memory, and
+// the a.res[s][axis] behind it a second, dependent one from the kernel arguments: two to three HBM-latency round trips per staging call)
 __device__ __forceinline__ void pair_axes(int p, int& a, int& b) {
-    const int A[6] = {0, 0, 0, 1, 1, 2}, B[6] = {1, 2, 3, 2, 3, 3};
-    a = A[p]; b = B[p];
+    a = (p >= 3) + (p >= 5);
+    b = p < 3 ? p + 1 : (p == 3 ? 2 : 3);
 }
+
+__device__ __forceinline__ int sel4i(int v0, int v1, int v2, int v3, int k) { return k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3)); }
+__device__ __forceinline__ float sel4f(float v0, float v1, float v2, float v3, int k) { return k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3)); }
 
 // element offset of tap (x, y), channel c, in a channel-last plane (32-bit: a plane holds < 2^30 floats, checked on the host)
 __device__ __forceinline__ uint32_t tap_at(int x, int y, int W, int C, int c) { return ((uint32_t)y * (uint32_t)W + (uint32_t)x) * (uint32_t)C + (uint32_t)c; }
@@ -170,8 +175,6 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_bwd(EmdHexArgs a, EmdHex
     }
 }
 
-__device__ __forceinline__ int sel4i(int v0, int v1, int v2, int v3, int k) { return k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3)); }
-__device__ __forceinline__ float sel4f(float v0, float v1, float v2, float v3, int k) { return k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3)); }
 
 // ---- forward, two-phase ---------------------------------------------------------------------------------------------------
 // With lane = channel every lane of a point repeats the point's scalar work (un-normalise, clip, floor, tap offsets, bilinear
@@ -200,8 +203,8 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd2(EmdHexArgs a) {
             pair_axes(p, ax, ay);
             const float qx = (a.pts[3 * n + ax] - a.aabb[ax]) * (2.f / (a.aabb[3 + ax] - a.aabb[ax])) - 1.f;     // ax < 3 always
             const float qy = ay < 3 ? (a.pts[3 * n + ay] - a.aabb[ay]) * (2.f / (a.aabb[3 + ay] - a.aabb[ay])) - 1.f : a.times[a.times_broadcast ? 0 : n];
-            const int W = a.res[s][ax];
-            const Tap1 tx = tap1(qx, W), ty = tap1(qy, a.res[s][ay]);
+            const int W = sel4i(a.res[s][0], a.res[s][1], a.res[s][2], a.res[s][3], ax);
+            const Tap1 tx = tap1(qx, W), ty = tap1(qy, sel4i(a.res[s][0], a.res[s][1], a.res[s][2], a.res[s][3], ay));
             s_off[item] = make_uint4(tap_at(tx.i0, ty.i0, W, C, 0), tap_at(tx.i1, ty.i0, W, C, 0), tap_at(tx.i0, ty.i1, W, C, 0),
                                      tap_at(tx.i1, ty.i1, W, C, 0));
             // grid_sampler_2d: nw * (1-fx)(1-fy) + ne * fx (1-fy) + sw * (1-fx) fy + se * fx fy
@@ -299,22 +302,24 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
     }
     __syncthreads();
     for (int s = 0; s < S; s++) {
-        // phase A: item = (point, plane)
+        // phase A: item = (point, plane).  The scale's four resolutions as scalars, picked per lane by selects (no lane-indexed argument reads)
+        const int r0 = a.res[s][0], r1 = a.res[s][1], r2 = a.res[s][2], r3 = a.res[s][3];
+        const uint32_t tb0 = uni ? time_table_offset(a, s, 0) : 0u;
         for (int item = tid; item < HEX_F4_POINTS * 6; item += EMD_BLOCK) {
             const int j = item / 6, p = item - 6 * j;
             if (j >= count) continue;
             int ax, ay;
             pair_axes(p, ax, ay);
             const float4 q = s_q[j];
-            const int W = a.res[s][ax];
+            const int W = sel4i(r0, r1, r2, r3, ax);
             const Tap1 tx = tap1(sel4f(q.x, q.y, q.z, q.w, ax), W);
             if (uni && ay == 3) {                       // two taps of the (scale, axis) table
-                const uint32_t tb = time_table_offset(a, s, ax);
+                const uint32_t tb = tb0 + (uint32_t)((ax > 0 ? r0 : 0) + (ax > 1 ? r1 : 0)) * (uint32_t)a.channels;
                 s_off[item] = make_uint4((tb + (uint32_t)tx.i0 * C) << 2, (tb + (uint32_t)tx.i1 * C) << 2, 0u, 0u);
                 s_w[item] = make_float4(1.f - tx.f, tx.f, 0.f, 0.f);
                 continue;
             }
-            const Tap1 ty = tap1(sel4f(q.x, q.y, q.z, q.w, ay), a.res[s][ay]);
+            const Tap1 ty = tap1(sel4f(q.x, q.y, q.z, q.w, ay), sel4i(r0, r1, r2, r3, ay));
             s_off[item] = make_uint4(tap_at(tx.i0, ty.i0, W, C, 0) << 2, tap_at(tx.i1, ty.i0, W, C, 0) << 2, tap_at(tx.i0, ty.i1, W, C, 0) << 2,
                                      tap_at(tx.i1, ty.i1, W, C, 0) << 2);
             // grid_sampler_2d: nw * (1-fx)(1-fy) + ne * fx (1-fy) + sw * (1-fx) fy + se * fx fy
@@ -433,11 +438,18 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
     for (int item = tid; item < HEX_AGG_POINTS * 4; item += HEX_AGG_THREADS) {
         const int j = item >> 2, k = item & 3;
         const long slot = first + j;
+        const bool live = slot < a.num_points;
+        const int n = live ? (a.order ? a.order[slot] : (int)slot) : -1, ns = live ? n : 0;
+        // one workgroup per CU: nothing else hides this prologue.  The coordinate and the plane position travel together, unconditionally (point 0
+        // stands in past the end), from addresses picked by selects: a lane-indexed read of the kernel arguments (a.aabb[k], g.pos2d[k - 1])
+        // is itself a load, with the real one waiting behind it
+        const float raw = *(k < 3 ? a.pts + (3 * (long)ns + k) : a.times + (a.times_broadcast ? 0 : ns));
+        int pos = 0;
+        if (g.defer_mask) pos = (k <= 1 ? g.pos2d[0] : (k == 2 ? g.pos2d[1] : g.pos2d[2]))[ns];
+        const float lo = sel4f(a.aabb[0], a.aabb[1], a.aabb[2], 0.f, k), hi = sel4f(a.aabb[3], a.aabb[4], a.aabb[5], 0.f, k);
         float qv = 0.f;
-        int n = -1;
-        if (slot < a.num_points) {
-            n = a.order ? a.order[slot] : (int)slot;
-            qv = k < 3 ? (a.pts[3 * (long)n + k] - a.aabb[k]) * (2.f / (a.aabb[3 + k] - a.aabb[k])) - 1.f : a.times[a.times_broadcast ? 0 : n];
+        if (live) {
+            qv = k < 3 ? (raw - lo) * (2.f / (hi - lo)) - 1.f : raw;
             const int key = order_key(qv);
             atomicMin(&qmin[k], key);
             atomicMax(&qmax[k], key);
@@ -445,7 +457,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         ((float*)&s_q[j])[k] = qv;
         ((float*)&s_dq[j])[k] = 0.f;
         if (k == 0) s_n[j] = n;
-        else if (g.defer_mask && n >= 0) s_pos[3 * j + k - 1] = g.pos2d[k - 1][n];
+        else if (g.defer_mask && live) s_pos[3 * j + k - 1] = pos;
     }
     __syncthreads();
     if (g.defer_mask && tid < HEX_AGG_POINTS * 3) {
@@ -466,9 +478,9 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
     const int twy = tuni ? 1 : 2;
     const int sb = wave * 2 * SROWS;                    // the wave's staging rows
     for (int s = 0; s < S; s++) {
-        int anc[4];
+        int anc[4], rs[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) anc[k] = tap1(qlo[k], a.res[s][k]).i0;
+        for (int k = 0; k < 4; k++) { rs[k] = a.res[s][k]; anc[k] = tap1(qlo[k], rs[k]).i0; }
         const Tap1 tt = tap1(qlo[3], a.res[s][3]);      // the block's time tap (meaningful when tuni)
         // deferred scale: the rows of the spatial planes go to the per-plane pass (k_hexplane_bwd_plane) instead of the windows
         const bool deferred = (g.defer_mask >> s) & 1u;
@@ -491,7 +503,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     int ax, ay;
                     pair_axes(p, ax, ay);
                     const float4 q = s_q[pt];
-                    const int W = a.res[s][ax], H = a.res[s][ay];
+                    const int W = sel4i(rs[0], rs[1], rs[2], rs[3], ax), H = sel4i(rs[0], rs[1], rs[2], rs[3], ay);   // (selects: no lane-indexed argument reads)
                     const Tap1 tx = tap1(sel4f(q.x, q.y, q.z, q.w, ax), W), ty = tap1(sel4f(q.x, q.y, q.z, q.w, ay), H);
                     const bool time_plane = ay == 3, marg = time_plane && tuni;
                     const int wx = time_plane ? twx : HEX_SW, wy = time_plane ? twy : HEX_SW;
@@ -646,7 +658,12 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
-        // ---- flush: every touched cell row goes to HBM once; the windows are left clean for the next scale
+        // ---- flush: every touched cell row goes to HBM once; the windows are left clean for the next scale.  The plane of a cell varies
+        // over the lane groups: its gradient pointer and its width are SELECTED from scalars (indexing the kernel arguments by a lane value
+        // is a load from them, and the atomic's address then waits for two dependent round trips per cell row)
+        float* gpl[6];
+#pragma unroll
+        for (int p = 0; p < 6; p++) gpl[p] = g.dL_dplanes[s][p];
         for (int cell = group; cell < HEX_WIN_CELLS; cell += GROUPS) {
             const float v = (float)win[cell * C + c];
             if (v == 0.f) continue;                       // (only cells a tap reached are non-zero)
@@ -656,11 +673,11 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                 int ax, ay;
                 pair_axes(p, ax, ay);
                 const int x = sel4i(anc[0], anc[1], anc[2], anc[3], ax) + local % HEX_SW, y = sel4i(anc[0], anc[1], anc[2], anc[3], ay) + local / HEX_SW;
-                atomicAdd(g.dL_dplanes[s][p] + tap_at(x, y, a.res[s][ax], C, c), v);
+                atomicAdd((idx == 0 ? gpl[0] : (idx == 1 ? gpl[1] : gpl[3])) + tap_at(x, y, sel4i(rs[0], rs[1], rs[2], rs[3], ax), C, c), v);
             } else {
-                const int idx = (cell - tbase) / tw, local = cell - tbase - idx * tw, p = idx == 0 ? 2 : (idx == 1 ? 4 : 5);
-                const int ax = idx, W = a.res[s][ax];       // planes 2, 4, 5 pair x, y, z with the time
-                float* gp = g.dL_dplanes[s][p];
+                const int idx = (cell - tbase) / tw, local = cell - tbase - idx * tw;
+                const int ax = idx, W = sel4i(rs[0], rs[1], rs[2], rs[3], ax);       // planes 2, 4, 5 pair x, y, z with the time
+                float* gp = idx == 0 ? gpl[2] : (idx == 1 ? gpl[4] : gpl[5]);
                 if (tuni) {
                     const int x = sel4i(anc[0], anc[1], anc[2], anc[3], ax) + local;
                     atomicAdd(gp + tap_at(x, tt.i0, W, C, c), v * (1.f - tt.f));
@@ -679,7 +696,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
             const int j = item >> 2, k = item & 3, n = s_n[j];
             if (n < 0) continue;
             const float v = ((const float*)&s_dq[j])[k];
-            if (k < 3) { if (g.dL_dpts) g.dL_dpts[3 * (long)n + k] = v * (2.f / (a.aabb[3 + k] - a.aabb[k])); }
+            if (k < 3) { if (g.dL_dpts) g.dL_dpts[3 * (long)n + k] = v * (2.f / (sel4f(a.aabb[3], a.aabb[4], a.aabb[5], 0.f, k) - sel4f(a.aabb[0], a.aabb[1], a.aabb[2], 0.f, k))); }
             else if (DT == 1 && g.dL_dtimes) g.dL_dtimes[n] = v;
         }
     if (DT == 2) {                                      // the workgroup's share of sum_n dL/dtimes[n]: wave sums, then one atomic
