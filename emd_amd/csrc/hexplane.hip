@@ -396,9 +396,20 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
 #ifndef HEX_STORES_FIRST
 #define HEX_STORES_FIRST 1
 #endif
+#ifndef HEX_STAGE_BYTES
+#define HEX_STAGE_BYTES 1  /* the staged tap offset, row stride and dx in BYTES: four address instructions per plane in the gathers instead of seven (4.31 -> 4.25 ms) */
+#endif
+#ifndef HEX_LERP
+#define HEX_LERP 1
+#endif
+#ifndef HEX_NEXT_SCALE_EARLY
+#define HEX_NEXT_SCALE_EARLY 1
+#endif
 #ifndef HEX_AGG_THREADS
-#define HEX_AGG_THREADS 1024             /* one block per CU (152 KB of LDS at 32 channels), four waves per SIMD */
-#define HEX_AGG_POINTS 256
+#define HEX_AGG_THREADS 1024             /* one block per CU (159 KB of LDS at 32 channels), four waves per SIMD */
+#define HEX_AGG_POINTS 512               /* round 5 (late): 512 points per block instead of 256, in the 12 KB the dropped slope rows freed -- 16 iterations per wave between
+                                            two flushes instead of 8 (the pipeline fills once per scale, with every wave in the same phase), half the barriers, and
+                                            more taps per flushed cell row: backward 4.14 -> 3.98 ms at 2 M points */
 #define HEX_SW 10                        /* spatial window: HEX_SW x HEX_SW cells (finer scales go through the per-plane pass) */
 #endif
 #define HEX_TW 48                        /* time-plane window: HEX_TW marginal cells, or (HEX_TW / 2) x 2 cells (a run spans ~46 cells of a 512-cell axis) */
@@ -418,9 +429,13 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
     constexpr int SROWS = 2 * GW * 6;                   // staging rows of TWO iterations (one stage() call)
     static_assert(SROWS <= 64 && C <= 32 && PER_WAVE % GW == 0 && ITERS % 2 == 0, "staging geometry");
     __shared__ double win[HEX_WIN_CELLS * C];           // fp64 cells: ds_add_f64 is the one native LDS float add that runs at rate on gfx950
-    __shared__ uint4 s_a[WAVES * 2 * SROWS];            // per wave, two buffers of (point, plane) rows: offset of tap (x0, y0), row stride to y1, window address, dx | sy << 8
+    __shared__ uint4 s_a[WAVES * 2 * SROWS];            // per wave, two buffers of (point, plane) rows: BYTE offset of tap (x0, y0), row stride to y1 in bytes, window address, dx * 4 | sy << 8
+#if HEX_LERP
+    __shared__ float4 s_w[WAVES * 2 * SROWS];           //   the fractions fx, fy and the slopes d(ix)/d(coord), d(iy)/d(coord) (0 where the coordinate was clipped)
+#else
     __shared__ float4 s_w[WAVES * 2 * SROWS];           //   the four bilinear weights (nw, ne, sw, se)
     __shared__ float4 s_c[WAVES * 2 * SROWS];           //   slope coefficients: d(ix)/d(coord) (1 - fy), d(ix)/d(coord) fy, d(iy)/d(coord) (1 - fx), d(iy)/d(coord) fx
+#endif
     __shared__ float4 s_q[HEX_AGG_POINTS];              // box-normalised x, y, z and the time of every point of the block
     __shared__ float4 s_dq[HEX_AGG_POINTS];             // dL/d(those), summed over the scales
     __shared__ int s_n[HEX_AGG_POINTS];                 // its index (-1 past the end)
@@ -460,9 +475,9 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         else if (g.defer_mask && live) s_pos[3 * j + k - 1] = pos;
     }
     __syncthreads();
-    if (g.defer_mask && tid < HEX_AGG_POINTS * 3) {
+    if (g.defer_mask) for (int t = tid; t < HEX_AGG_POINTS * 3; t += HEX_AGG_THREADS) {
         // the per-plane pass reads the two normalised coordinates of a point at its position in the plane's order (behind the rows)
-        const int j = tid / 3, pidx = tid - 3 * j;
+        const int j = t / 3, pidx = t - 3 * j;
         if (s_n[j] >= 0) {
             const float4 q = s_q[j];
             float2* defer_q = (float2*)(g.defer_rows + (size_t)__builtin_popcount(g.defer_mask) * 3 * (size_t)a.num_points * C) + (size_t)pidx * a.num_points;
@@ -477,18 +492,27 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
     float t_acc = 0.f;                                  // (DT == 2)
     const int twy = tuni ? 1 : 2;
     const int sb = wave * 2 * SROWS;                    // the wave's staging rows
-    for (int s = 0; s < S; s++) {
-        int anc[4], rs[4];
+    // ---- the scale the waves are staging and gathering for (`cs`): its resolutions, the block's anchor cells, its window layout.  It runs ONE
+    // stage() + gather() ahead of the scale `s` being scattered and flushed: the first gathers of scale s + 1 are requested before the block
+    // meets at the flush of scale s (HEX_NEXT_SCALE_EARLY), so their latency passes under the barrier and the flush instead of in front of an
+    // idle CU -- after a flush all sixteen waves sit in the same phase and nothing hides a round trip
+    int cs = 0, anc[4], rs[4], tw = 0, tbase = 0, twx = 0;
+    bool deferred = false;
+    size_t defer_base = 0;
+    auto enter_scale = [&](int ss) {
+        cs = ss;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { rs[k] = a.res[s][k]; anc[k] = tap1(qlo[k], rs[k]).i0; }
-        const Tap1 tt = tap1(qlo[3], a.res[s][3]);      // the block's time tap (meaningful when tuni)
+        for (int k = 0; k < 4; k++) { rs[k] = a.res[ss][k]; anc[k] = tap1(qlo[k], rs[k]).i0; }
         // deferred scale: the rows of the spatial planes go to the per-plane pass (k_hexplane_bwd_plane) instead of the windows
-        const bool deferred = (g.defer_mask >> s) & 1u;
-        const size_t defer_base = (size_t)__builtin_popcount(g.defer_mask & ((1u << s) - 1u)) * 3u;
+        deferred = (g.defer_mask >> ss) & 1u;
+        defer_base = (size_t)__builtin_popcount(g.defer_mask & ((1u << ss) - 1u)) * 3u;
         // a deferred scale does not use the spatial windows: its three time windows take the whole memory (148 cells each instead of 48 -- on
         // the fine scales, the deferred ones, a run spans 35 - 50 cells of an axis and 18 % of its x taps left the 48-cell window, each such
         // tap four partly filled atomic instructions)
-        const int tw = deferred ? HEX_WIN_CELLS / 3 : HEX_TW, tbase = deferred ? 0 : 3 * HEX_SCELLS, twx = tuni ? tw : tw / 2;
+        tw = deferred ? HEX_WIN_CELLS / 3 : HEX_TW; tbase = deferred ? 0 : 3 * HEX_SCELLS; twx = tuni ? tw : tw / 2;
+    };
+#define HEX_PL(p) ((const char*)a.planes[cs][p])
+#define HEX_GP(p) (g.dL_dplanes[s][p])
         // The waves of the block run on their own from here to the flush, GW points (one per C-lane group) per iteration, as a
         // software pipeline:  stage(it + 1) | wait for the taps of `it` | sample, slopes, product rule | issue the gathers of it + 1 |
         // scatter the rows of `it`.  No block barrier in the loop, so the waves drift apart and one wave's gathers overlap another's
@@ -517,11 +541,16 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     const uint32_t lds = inside ? (uint32_t)((wbase + cy0 * wx + cx0) * C) : 0xffffffffu;
                     const uint32_t dx = (uint32_t)((tx.i1 - tx.i0) * C), sy = (uint32_t)((cy1 - cy0) * wx * C);
                     const int row = sb + ((it >> 1) & 1) * SROWS + lane;
-                    s_a[row] = make_uint4(tap_at(tx.i0, ty.i0, W, C, 0), (uint32_t)(ty.i1 - ty.i0) * (uint32_t)W * (uint32_t)C, lds, dx | (sy << 8));
+                    constexpr int SH = HEX_STAGE_BYTES ? 2 : 0;
+                    s_a[row] = make_uint4(tap_at(tx.i0, ty.i0, W, C, 0) << SH, ((uint32_t)(ty.i1 - ty.i0) * (uint32_t)W * (uint32_t)C) << SH, lds, (dx << SH) | (sy << 8));
                     // grid_sampler_2d: nw * (1-fx)(1-fy) + ne * fx (1-fy) + sw * (1-fx) fy + se * fx fy; the clamped neighbour
                     // (x1 == x0 at the border) contributes no slope: its weight is 0 and the clip mask is 0
+#if HEX_LERP
+                    s_w[row] = make_float4(tx.f, ty.f, tx.ds, ty.ds);
+#else
                     s_w[row] = make_float4((1.f - tx.f) * (1.f - ty.f), tx.f * (1.f - ty.f), (1.f - tx.f) * ty.f, tx.f * ty.f);
                     s_c[row] = make_float4(tx.ds * (1.f - ty.f), tx.ds * ty.f, ty.ds * (1.f - tx.f), ty.ds * tx.f);
+#endif
                 }
             }
         };
@@ -531,21 +560,31 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         auto gather = [&](int it) {
             n = s_n[wave * PER_WAVE + it * GW + gw];
             if (n >= 0) {
-                go = HEX_NT ? __builtin_nontemporal_load(g.dL_dout + ((size_t)n * (S * C) + s * C + c)) : g.dL_dout[(size_t)n * (S * C) + s * C + c];
+                go = HEX_NT ? __builtin_nontemporal_load(g.dL_dout + ((size_t)n * (S * C) + cs * C + c)) : g.dL_dout[(size_t)n * (S * C) + cs * C + c];
 #pragma unroll
                 for (int p = 0; p < 6; p++) {
                     const uint4 A = s_a[sb + ((it >> 1) & 1) * SROWS + (it & 1) * GW * 6 + gw * 6 + p];
-                    const char* __restrict__ pl = (const char*)a.planes[s][p];
+                    const char* __restrict__ pl = HEX_PL(p);
+#if HEX_STAGE_BYTES
+                    const uint32_t dx = A.w & 0xffu, o00 = A.x + ((uint32_t)c << 2), dy = A.y;          // (bytes, as staged)
+#else
                     const uint32_t dx = (A.w & 0xffu) << 2, o00 = (A.x + c) << 2, dy = A.y << 2;
+#endif
                     nw[p] = *(const float*)(pl + o00); ne[p] = *(const float*)(pl + (o00 + dx));
                     sw[p] = *(const float*)(pl + (o00 + dy)); se[p] = *(const float*)(pl + (o00 + dy + dx));
                 }
             }
         };
+    static_assert(ITERS % 4 == 0, "the last iterations of a scale read staging buffer 1: buffer 0 is free for the next scale's first rows");
+    auto first_rows = [&](int ss) {
+        enter_scale(ss);
         stage(0);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // the wave's own LDS writes, read back by its other lanes
         __builtin_amdgcn_wave_barrier();
         gather(0);
+    };
+    first_rows(0);
+    for (int s = 0; s < S; s++) {
 #pragma unroll 1
         for (int it = 0; it < ITERS; it++) {
             if ((it & 1) && it + 1 < ITERS) stage(it + 1);               // (the rows of the next two iterations)
@@ -555,10 +594,21 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                 float f[6], dix[6], diy[6];
 #pragma unroll
                 for (int p = 0; p < 6; p++) {
+#if HEX_LERP
+                    // the sample as nested interpolations: the differences it forms ARE the slopes (ten instructions for value and both slopes where
+                    // the weight form took twelve, and ONE staged row per plane, (fx, fy, slope x, slope y), instead of two)
+                    const float4 F = s_w[rowb + p];
+                    const float d0 = ne[p] - nw[p], d1 = se[p] - sw[p];
+                    const float top = nw[p] + F.x * d0, bot = sw[p] + F.x * d1, dv = bot - top;
+                    f[p] = top + F.y * dv;
+                    dix[p] = (d0 + F.y * (d1 - d0)) * F.z;
+                    diy[p] = dv * F.w;
+#else
                     const float4 w = s_w[rowb + p], sc = s_c[rowb + p];
                     f[p] = nw[p] * w.x + ne[p] * w.y + sw[p] * w.z + se[p] * w.w;
                     dix[p] = (ne[p] - nw[p]) * sc.x + (se[p] - sw[p]) * sc.y;
                     diy[p] = (sw[p] - nw[p]) * sc.z + (se[p] - ne[p]) * sc.w;
+#endif
                 }
                 float pre[7], suf[7], dq[4] = {0.f, 0.f, 0.f, 0.f};
                 pre[0] = 1.f; suf[6] = 1.f;
@@ -605,7 +655,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
             if (n_cur >= 0 && deferred) {
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
-                    if (p == 2 || !g.dL_dplanes[s][p]) continue;
+                    if (p == 2 || !HEX_GP(p)) continue;
                     const int pidx = p == 3 ? 2 : p;                      // the row itself, at the point's position in that plane's order (plain store)
                     char* rows = (char*)(g.defer_rows + (defer_base + pidx) * (size_t)a.num_points * C);
                     *(float*)(rows + (((uint32_t)s_pos[3 * pt + pidx] * C + c) << 2)) = gi[p];
@@ -619,7 +669,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
 #pragma unroll
                 for (int p = 0; p < 6; p++) {
                     const bool marg = (p == 2 || p >= 4) && tuni;         // marginal over the block's time: two rows
-                    float* gp = g.dL_dplanes[s][p];
+                    float* gp = HEX_GP(p);
                     if (!gp) continue;
                     if (deferred && p != 2 && p < 4) {                    // spatial plane of a deferred scale: the row itself, at the point's
 #if !HEX_STORES_FIRST
@@ -631,10 +681,27 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     }
                     if (gi[p] == 0.f) continue;
                     const uint4 A = s_a[rowb + p];                       // (read again: cheaper than live registers)
+#if HEX_LERP
+                    const float4 F = s_w[rowb + p];
+                    const float gx1 = gi[p] * F.x, gx0 = gi[p] - gx1;      // gi (1 - fx), gi fx: the x-marginals of the four weights
+#else
                     const float4 w = s_w[rowb + p];
-                    const uint32_t dx = A.w & 0xffu, sy = A.w >> 8;
+#endif
+                    const uint32_t dx = (A.w & 0xffu) >> (HEX_STAGE_BYTES ? 2 : 0), sy = A.w >> 8;
                     if (A.z != 0xffffffffu) {
                         double* w0 = &win[A.z + c];
+#if HEX_LERP
+                        if (marg) {                                       // the x-marginals: the two time rows summed
+                            lds_add_f64(w0, gx0);
+                            lds_add_f64(w0 + dx, gx1);
+                        } else {
+                            const float s0 = gx0 * F.y, s1 = gx1 * F.y;
+                            lds_add_f64(w0, gx0 - s0);
+                            lds_add_f64(w0 + dx, gx1 - s1);
+                            lds_add_f64(w0 + sy, s0);
+                            lds_add_f64(w0 + sy + dx, s1);
+                        }
+#else
                         if (marg) {                                       // the x-marginals: the two time rows summed
                             lds_add_f64(w0, gi[p] * (w.x + w.z));
                             lds_add_f64(w0 + dx, gi[p] * (w.y + w.w));
@@ -644,51 +711,73 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                             lds_add_f64(w0 + sy, gi[p] * w.z);
                             lds_add_f64(w0 + sy + dx, gi[p] * w.w);
                         }
+#endif
                     } else {
                         char* g0 = (char*)gp;
-                        const uint32_t b00 = (A.x + c) << 2, bdx = dx << 2, bdy = A.y << 2;
+                        constexpr int USH = HEX_STAGE_BYTES ? 0 : 2;
+                        const uint32_t b00 = (A.x << USH) + ((uint32_t)c << 2), bdx = (A.w & 0xffu) << USH, bdy = A.y << USH;
+#if HEX_LERP
+                        const float s0 = gx0 * F.y, s1 = gx1 * F.y;
+                        atomicAdd((float*)(g0 + b00), gx0 - s0);
+                        atomicAdd((float*)(g0 + (b00 + bdx)), gx1 - s1);
+                        atomicAdd((float*)(g0 + (b00 + bdy)), s0);
+                        atomicAdd((float*)(g0 + (b00 + bdy + bdx)), s1);
+#else
                         atomicAdd((float*)(g0 + b00), gi[p] * w.x);
                         atomicAdd((float*)(g0 + (b00 + bdx)), gi[p] * w.y);
                         atomicAdd((float*)(g0 + (b00 + bdy)), gi[p] * w.z);
                         atomicAdd((float*)(g0 + (b00 + bdy + bdx)), gi[p] * w.w);
+#endif
                     }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (stage(it + 2) overwrites the rows read here)
             __builtin_amdgcn_wave_barrier();
         }
+        // the flush of scale s by its own values (the waves' state moves on to scale s + 1 first)
+        int ancf[4], rsf[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { ancf[k] = anc[k]; rsf[k] = rs[k]; }
+        const int twf = tw, tbasef = tbase;
+        const Tap1 tt = tap1(qlo[3], rs[3]);            // the block's time tap (meaningful when tuni)
+        float* gpl[6];
+#pragma unroll
+        for (int p = 0; p < 6; p++) gpl[p] = g.dL_dplanes[s][p];
+#if HEX_NEXT_SCALE_EARLY
+        if (s + 1 < S) first_rows(s + 1);
+#endif
         __syncthreads();
         // ---- flush: every touched cell row goes to HBM once; the windows are left clean for the next scale.  The plane of a cell varies
         // over the lane groups: its gradient pointer and its width are SELECTED from scalars (indexing the kernel arguments by a lane value
         // is a load from them, and the atomic's address then waits for two dependent round trips per cell row)
-        float* gpl[6];
-#pragma unroll
-        for (int p = 0; p < 6; p++) gpl[p] = g.dL_dplanes[s][p];
         for (int cell = group; cell < HEX_WIN_CELLS; cell += GROUPS) {
             const float v = (float)win[cell * C + c];
             if (v == 0.f) continue;                       // (only cells a tap reached are non-zero)
             win[cell * C + c] = 0.0;
-            if (cell < tbase) {
+            if (cell < tbasef) {
                 const int idx = cell / HEX_SCELLS, local = cell - idx * HEX_SCELLS, p = idx == 2 ? 3 : idx;
                 int ax, ay;
                 pair_axes(p, ax, ay);
-                const int x = sel4i(anc[0], anc[1], anc[2], anc[3], ax) + local % HEX_SW, y = sel4i(anc[0], anc[1], anc[2], anc[3], ay) + local / HEX_SW;
-                atomicAdd((idx == 0 ? gpl[0] : (idx == 1 ? gpl[1] : gpl[3])) + tap_at(x, y, sel4i(rs[0], rs[1], rs[2], rs[3], ax), C, c), v);
+                const int x = sel4i(ancf[0], ancf[1], ancf[2], ancf[3], ax) + local % HEX_SW, y = sel4i(ancf[0], ancf[1], ancf[2], ancf[3], ay) + local / HEX_SW;
+                atomicAdd((idx == 0 ? gpl[0] : (idx == 1 ? gpl[1] : gpl[3])) + tap_at(x, y, sel4i(rsf[0], rsf[1], rsf[2], rsf[3], ax), C, c), v);
             } else {
-                const int idx = (cell - tbase) / tw, local = cell - tbase - idx * tw;
-                const int ax = idx, W = sel4i(rs[0], rs[1], rs[2], rs[3], ax);       // planes 2, 4, 5 pair x, y, z with the time
+                const int idx = (cell - tbasef) / twf, local = cell - tbasef - idx * twf;
+                const int ax = idx, W = sel4i(rsf[0], rsf[1], rsf[2], rsf[3], ax);       // planes 2, 4, 5 pair x, y, z with the time
                 float* gp = idx == 0 ? gpl[2] : (idx == 1 ? gpl[4] : gpl[5]);
                 if (tuni) {
-                    const int x = sel4i(anc[0], anc[1], anc[2], anc[3], ax) + local;
+                    const int x = sel4i(ancf[0], ancf[1], ancf[2], ancf[3], ax) + local;
                     atomicAdd(gp + tap_at(x, tt.i0, W, C, c), v * (1.f - tt.f));
                     if (tt.f != 0.f) atomicAdd(gp + tap_at(x, tt.i1, W, C, c), v * tt.f);
                 } else {
-                    const int x = sel4i(anc[0], anc[1], anc[2], anc[3], ax) + local % (tw / 2), y = anc[3] + local / (tw / 2);
+                    const int x = sel4i(ancf[0], ancf[1], ancf[2], ancf[3], ax) + local % (twf / 2), y = ancf[3] + local / (twf / 2);
                     atomicAdd(gp + tap_at(x, y, W, C, c), v);
                 }
             }
         }
         __syncthreads();
+#if !HEX_NEXT_SCALE_EARLY
+        if (s + 1 < S) first_rows(s + 1);
+#endif
     }
     // dL/dpts through normalize_aabb (the time coordinate is used as given)
     if (want_dq)
