@@ -399,8 +399,8 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
 #ifndef HEX_STAGE_BYTES
 #define HEX_STAGE_BYTES 1  /* the staged tap offset, row stride and dx in BYTES: four address instructions per plane in the gathers instead of seven (4.31 -> 4.25 ms) */
 #endif
-#ifndef HEX_LERP
-#define HEX_LERP 1
+#ifndef HEX_STAGE_ITERS
+#define HEX_STAGE_ITERS 0  /* iterations staged per stage() call: 0 = as many as fit the wave's lanes (4 at 32 channels, 2 at 16) */
 #endif
 #ifndef HEX_NEXT_SCALE_EARLY
 #define HEX_NEXT_SCALE_EARLY 1
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
                                             more taps per flushed cell row: backward 4.14 -> 3.98 ms at 2 M points */
 #define HEX_SW 10                        /* spatial window: HEX_SW x HEX_SW cells (finer scales go through the per-plane pass) */
 #endif
-#define HEX_TW 48                        /* time-plane window: HEX_TW marginal cells, or (HEX_TW / 2) x 2 cells (a run spans ~46 cells of a 512-cell axis) */
+#define HEX_TW 40                        /* time-plane window: HEX_TW marginal cells, or (HEX_TW / 2) x 2 cells (a run spans ~46 cells of a 512-cell axis) */
 #define HEX_SCELLS (HEX_SW * HEX_SW)
 #define HEX_WIN_CELLS (3 * HEX_SCELLS + 3 * HEX_TW)
 
@@ -426,16 +426,14 @@ __device__ __forceinline__ float key_value(int k) { return __int_as_float(k >= 0
 template <int C, int DT>
 __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexArgs a, EmdHexGrads g, unsigned chunk_stride) {
     constexpr int WAVES = HEX_AGG_THREADS / 64, GW = 64 / C, PER_WAVE = HEX_AGG_POINTS / WAVES, ITERS = PER_WAVE / GW, GROUPS = HEX_AGG_THREADS / C;
-    constexpr int SROWS = 2 * GW * 6;                   // staging rows of TWO iterations (one stage() call)
-    static_assert(SROWS <= 64 && C <= 32 && PER_WAVE % GW == 0 && ITERS % 2 == 0, "staging geometry");
+    // staging: one stage() call prepares the rows of SK iterations (lane = (iteration, point, plane): 48 of 64 lanes busy at 32 channels) into a ring of
+    // SK + 1 iteration slots -- when the call for the next SK iterations runs, at the top of the last iteration of the current group, that
+    // iteration's rows are the only live ones
+    constexpr int IROWS = GW * 6, SK = HEX_STAGE_ITERS ? HEX_STAGE_ITERS : (64 / IROWS >= 4 ? 4 : 2), RING = SK + 1, SROWS = RING * IROWS;
+    static_assert(SK * IROWS <= 64 && C <= 32 && PER_WAVE % GW == 0 && ITERS % SK == 0, "staging geometry");
     __shared__ double win[HEX_WIN_CELLS * C];           // fp64 cells: ds_add_f64 is the one native LDS float add that runs at rate on gfx950
-    __shared__ uint4 s_a[WAVES * 2 * SROWS];            // per wave, two buffers of (point, plane) rows: BYTE offset of tap (x0, y0), row stride to y1 in bytes, window address, dx * 4 | sy << 8
-#if HEX_LERP
-    __shared__ float4 s_w[WAVES * 2 * SROWS];           //   the fractions fx, fy and the slopes d(ix)/d(coord), d(iy)/d(coord) (0 where the coordinate was clipped)
-#else
-    __shared__ float4 s_w[WAVES * 2 * SROWS];           //   the four bilinear weights (nw, ne, sw, se)
-    __shared__ float4 s_c[WAVES * 2 * SROWS];           //   slope coefficients: d(ix)/d(coord) (1 - fy), d(ix)/d(coord) fy, d(iy)/d(coord) (1 - fx), d(iy)/d(coord) fx
-#endif
+    __shared__ uint4 s_a[WAVES * SROWS];                // per wave, a ring of (point, plane) rows: BYTE offset of tap (x0, y0), row stride to y1 in bytes, window address, dx * 4 | sy << 8
+    __shared__ float4 s_w[WAVES * SROWS];               //   the fractions fx, fy and the slopes d(ix)/d(coord), d(iy)/d(coord) (0 where the coordinate was clipped)
     __shared__ float4 s_q[HEX_AGG_POINTS];              // box-normalised x, y, z and the time of every point of the block
     __shared__ float4 s_dq[HEX_AGG_POINTS];             // dL/d(those), summed over the scales
     __shared__ int s_n[HEX_AGG_POINTS];                 // its index (-1 past the end)
@@ -491,7 +489,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
     const bool want_dq = g.dL_dpts || g.dL_dtimes || g.dL_dtime_sum;
     float t_acc = 0.f;                                  // (DT == 2)
     const int twy = tuni ? 1 : 2;
-    const int sb = wave * 2 * SROWS;                    // the wave's staging rows
+    const int sb = wave * SROWS;                        // the wave's staging rows
     // ---- the scale the waves are staging and gathering for (`cs`): its resolutions, the block's anchor cells, its window layout.  It runs ONE
     // stage() + gather() ahead of the scale `s` being scattered and flushed: the first gathers of scale s + 1 are requested before the block
     // meets at the flush of scale s (HEX_NEXT_SCALE_EARLY), so their latency passes under the barrier and the flush instead of in front of an
@@ -519,9 +517,9 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         // arithmetic and a third's adds; and within a wave the next gathers are in flight while the adds and atomics are issued
         // (with block-wide batches every wave sat in the same phase at the same time: 70 % of a wave's life in s_waitcnt).
         // ---- staging, item = (point, plane), lanes 0 .. 6 GW - 1 of the wave: un-normalise, clip, floor, offsets, window address
-        auto stage = [&](int it) {                      // `it` even: rows of iterations it and it + 1 into buffer (it >> 1) & 1
-            if (lane < SROWS) {
-                const int k2 = lane / (GW * 6), rem = lane - k2 * GW * 6, jj = rem / 6, p = rem - 6 * jj;
+        auto stage = [&](int it) {                      // `it` a multiple of SK: rows of iterations it .. it + SK - 1 into their ring slots
+            if (lane < SK * IROWS) {
+                const int k2 = lane / IROWS, rem = lane - k2 * IROWS, jj = rem / 6, p = rem - 6 * jj;
                 const int pt = wave * PER_WAVE + (it + k2) * GW + jj, n = s_n[pt];
                 if (n >= 0) {
                     int ax, ay;
@@ -540,17 +538,14 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     const bool inside = cx0 >= 0 && cy0 >= 0 && cx1 < wx && cy1 < wy;
                     const uint32_t lds = inside ? (uint32_t)((wbase + cy0 * wx + cx0) * C) : 0xffffffffu;
                     const uint32_t dx = (uint32_t)((tx.i1 - tx.i0) * C), sy = (uint32_t)((cy1 - cy0) * wx * C);
-                    const int row = sb + ((it >> 1) & 1) * SROWS + lane;
+                    int slot = it % RING + k2;
+                    slot -= slot >= RING ? RING : 0;
+                    const int row = sb + slot * IROWS + rem;
                     constexpr int SH = HEX_STAGE_BYTES ? 2 : 0;
                     s_a[row] = make_uint4(tap_at(tx.i0, ty.i0, W, C, 0) << SH, ((uint32_t)(ty.i1 - ty.i0) * (uint32_t)W * (uint32_t)C) << SH, lds, (dx << SH) | (sy << 8));
                     // grid_sampler_2d: nw * (1-fx)(1-fy) + ne * fx (1-fy) + sw * (1-fx) fy + se * fx fy; the clamped neighbour
                     // (x1 == x0 at the border) contributes no slope: its weight is 0 and the clip mask is 0
-#if HEX_LERP
                     s_w[row] = make_float4(tx.f, ty.f, tx.ds, ty.ds);
-#else
-                    s_w[row] = make_float4((1.f - tx.f) * (1.f - ty.f), tx.f * (1.f - ty.f), (1.f - tx.f) * ty.f, tx.f * ty.f);
-                    s_c[row] = make_float4(tx.ds * (1.f - ty.f), tx.ds * ty.f, ty.ds * (1.f - tx.f), ty.ds * tx.f);
-#endif
                 }
             }
         };
@@ -563,7 +558,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                 go = HEX_NT ? __builtin_nontemporal_load(g.dL_dout + ((size_t)n * (S * C) + cs * C + c)) : g.dL_dout[(size_t)n * (S * C) + cs * C + c];
 #pragma unroll
                 for (int p = 0; p < 6; p++) {
-                    const uint4 A = s_a[sb + ((it >> 1) & 1) * SROWS + (it & 1) * GW * 6 + gw * 6 + p];
+                    const uint4 A = s_a[sb + (it % RING) * IROWS + gw * 6 + p];
                     const char* __restrict__ pl = HEX_PL(p);
 #if HEX_STAGE_BYTES
                     const uint32_t dx = A.w & 0xffu, o00 = A.x + ((uint32_t)c << 2), dy = A.y;          // (bytes, as staged)
@@ -575,7 +570,6 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                 }
             }
         };
-    static_assert(ITERS % 4 == 0, "the last iterations of a scale read staging buffer 1: buffer 0 is free for the next scale's first rows");
     auto first_rows = [&](int ss) {
         enter_scale(ss);
         stage(0);
@@ -587,14 +581,13 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
     for (int s = 0; s < S; s++) {
 #pragma unroll 1
         for (int it = 0; it < ITERS; it++) {
-            if ((it & 1) && it + 1 < ITERS) stage(it + 1);               // (the rows of the next two iterations)
-            const int rowb = sb + ((it >> 1) & 1) * SROWS + (it & 1) * GW * 6 + gw * 6, pt = wave * PER_WAVE + it * GW + gw, n_cur = n;
+            if (it % SK == SK - 1 && it + 1 < ITERS) stage(it + 1);      // (the rows of the next SK iterations)
+            const int rowb = sb + (it % RING) * IROWS + gw * 6, pt = wave * PER_WAVE + it * GW + gw, n_cur = n;
             float gi[6];
             if (n_cur >= 0) {
                 float f[6], dix[6], diy[6];
 #pragma unroll
                 for (int p = 0; p < 6; p++) {
-#if HEX_LERP
                     // the sample as nested interpolations: the differences it forms ARE the slopes (ten instructions for value and both slopes where
                     // the weight form took twelve, and ONE staged row per plane, (fx, fy, slope x, slope y), instead of two)
                     const float4 F = s_w[rowb + p];
@@ -603,12 +596,6 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     f[p] = top + F.y * dv;
                     dix[p] = (d0 + F.y * (d1 - d0)) * F.z;
                     diy[p] = dv * F.w;
-#else
-                    const float4 w = s_w[rowb + p], sc = s_c[rowb + p];
-                    f[p] = nw[p] * w.x + ne[p] * w.y + sw[p] * w.z + se[p] * w.w;
-                    dix[p] = (ne[p] - nw[p]) * sc.x + (se[p] - sw[p]) * sc.y;
-                    diy[p] = (sw[p] - nw[p]) * sc.z + (se[p] - ne[p]) * sc.w;
-#endif
                 }
                 float pre[7], suf[7], dq[4] = {0.f, 0.f, 0.f, 0.f};
                 pre[0] = 1.f; suf[6] = 1.f;
@@ -681,16 +668,11 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     }
                     if (gi[p] == 0.f) continue;
                     const uint4 A = s_a[rowb + p];                       // (read again: cheaper than live registers)
-#if HEX_LERP
                     const float4 F = s_w[rowb + p];
                     const float gx1 = gi[p] * F.x, gx0 = gi[p] - gx1;      // gi (1 - fx), gi fx: the x-marginals of the four weights
-#else
-                    const float4 w = s_w[rowb + p];
-#endif
                     const uint32_t dx = (A.w & 0xffu) >> (HEX_STAGE_BYTES ? 2 : 0), sy = A.w >> 8;
                     if (A.z != 0xffffffffu) {
                         double* w0 = &win[A.z + c];
-#if HEX_LERP
                         if (marg) {                                       // the x-marginals: the two time rows summed
                             lds_add_f64(w0, gx0);
                             lds_add_f64(w0 + dx, gx1);
@@ -701,33 +683,15 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                             lds_add_f64(w0 + sy, s0);
                             lds_add_f64(w0 + sy + dx, s1);
                         }
-#else
-                        if (marg) {                                       // the x-marginals: the two time rows summed
-                            lds_add_f64(w0, gi[p] * (w.x + w.z));
-                            lds_add_f64(w0 + dx, gi[p] * (w.y + w.w));
-                        } else {
-                            lds_add_f64(w0, gi[p] * w.x);
-                            lds_add_f64(w0 + dx, gi[p] * w.y);
-                            lds_add_f64(w0 + sy, gi[p] * w.z);
-                            lds_add_f64(w0 + sy + dx, gi[p] * w.w);
-                        }
-#endif
                     } else {
                         char* g0 = (char*)gp;
                         constexpr int USH = HEX_STAGE_BYTES ? 0 : 2;
                         const uint32_t b00 = (A.x << USH) + ((uint32_t)c << 2), bdx = (A.w & 0xffu) << USH, bdy = A.y << USH;
-#if HEX_LERP
                         const float s0 = gx0 * F.y, s1 = gx1 * F.y;
                         atomicAdd((float*)(g0 + b00), gx0 - s0);
                         atomicAdd((float*)(g0 + (b00 + bdx)), gx1 - s1);
                         atomicAdd((float*)(g0 + (b00 + bdy)), s0);
                         atomicAdd((float*)(g0 + (b00 + bdy + bdx)), s1);
-#else
-                        atomicAdd((float*)(g0 + b00), gi[p] * w.x);
-                        atomicAdd((float*)(g0 + (b00 + bdx)), gi[p] * w.y);
-                        atomicAdd((float*)(g0 + (b00 + bdy)), gi[p] * w.z);
-                        atomicAdd((float*)(g0 + (b00 + bdy + bdx)), gi[p] * w.w);
-#endif
                     }
                 }
             }
