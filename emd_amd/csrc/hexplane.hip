@@ -412,7 +412,9 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
                                             more taps per flushed cell row: backward 4.14 -> 3.98 ms at 2 M points */
 #define HEX_SW 10                        /* spatial window: HEX_SW x HEX_SW cells (finer scales go through the per-plane pass) */
 #endif
+#ifndef HEX_TW
 #define HEX_TW 40                        /* time-plane window: HEX_TW marginal cells, or (HEX_TW / 2) x 2 cells (a run spans ~46 cells of a 512-cell axis) */
+#endif
 #define HEX_SCELLS (HEX_SW * HEX_SW)
 #define HEX_WIN_CELLS (3 * HEX_SCELLS + 3 * HEX_TW)
 
