@@ -799,7 +799,9 @@ __global__ void __launch_bounds__(HEX_PL_THREADS) k_hexplane_bwd_plane(EmdHexArg
     const size_t NC = (size_t)a.num_points * C;
     const float2* defer_q = (const float2*)(g.defer_rows + (size_t)__builtin_popcount(g.defer_mask) * 3 * NC) + (size_t)pidx * a.num_points;
     for (int i = tid; i < WCELLS * C; i += HEX_PL_THREADS) win[i] = 0.0;
-    const float2 q = tid < count ? defer_q[first + tid] : make_float2(0.f, 0.f);
+    // (unconditional, from a clamped position: a guarded load is waited for where it is issued -- DESIGN.md section 6 -- and the sixteen rows below would be
+    // requested one round trip later; the value is used by the threads with a point only)
+    const float2 q = defer_q[min(first + tid, (long)a.num_points - 1)];
     // one workgroup per (run, plane, deferred scale): nothing is carried from scale to scale, and the chain load -> taps -> adds -> flush of one
     // scale no longer waits for the flush of the one before
     const int sidx = blockIdx.z;
@@ -816,7 +818,7 @@ __global__ void __launch_bounds__(HEX_PL_THREADS) k_hexplane_bwd_plane(EmdHexArg
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             const int j = group + GROUPS * k;
-            gis[k] = j < count ? rows[(size_t)(first + j) * C + c] : 0.f;
+            gis[k] = rows[(size_t)min(first + j, (long)a.num_points - 1) * C + c];     // (clamped, not guarded: rows past the end are skipped below)
         }
         if (tid < 2) cmin[tid] = INT_MAX;
         __syncthreads();
@@ -829,22 +831,36 @@ __global__ void __launch_bounds__(HEX_PL_THREADS) k_hexplane_bwd_plane(EmdHexArg
         }
         __syncthreads();
         const int ancx = cmin[0], ancy = cmin[1];
+        // Round 5 (late): the kernel is bound by its vector instructions (4.9 x 10^8 per launch = 0.79 of its 1.05 ms), and every one of a row's 32 channel
+        // lanes decoded the tap, placed it in the window and formed the four weights.  The point's own thread now rewrites its tap in window form once the
+        // anchor is known -- byte address of the (x0, y0) cell row | dx C << 16 | dy PW << 24 | 1 << 31 -- (one more barrier), and the weights come out of the
+        // row as nested differences: 54 -> ~35 vector instructions per row; backward 3.84 -> 3.74 ms at 2 M points
+        static_assert(WCELLS * C * 8 <= 0x10000 && HEX_PW < 128 && C <= 32, "window tap encoding");
+        if (tid < count) {
+            const uint32_t tap = s_tap[tid];
+            const int x0 = tap & 0x3fffu, y0 = (tap >> 14) & 0x3fffu, dx = (tap >> 28) & 1u, dy = (tap >> 29) & 1u;
+            const int cx0 = x0 - ancx, cy0 = y0 - ancy;
+            if (cx0 + dx < HEX_PW && cy0 + dy < HEX_PW)                    // (cx0, cy0 >= 0: the anchor is the block's smallest tap)
+                s_tap[tid] = (uint32_t)((cy0 * HEX_PW + cx0) * C * 8) | ((uint32_t)(dx * C) << 16) | ((uint32_t)(dy * HEX_PW) << 24) | 0x80000000u;
+        }
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             const int j = group + GROUPS * k;
             const float gi = gis[k];
             if (j >= count || gi == 0.f) continue;
             const uint32_t tap = s_tap[j];
-            const int x0 = tap & 0x3fffu, y0 = (tap >> 14) & 0x3fffu, dx = (tap >> 28) & 1u, dy = (tap >> 29) & 1u;
             const float fx = s_f[j].x, fy = s_f[j].y;
-            const int cx0 = x0 - ancx, cy0 = y0 - ancy;
-            const float w00 = gi * ((1.f - fx) * (1.f - fy)), w10 = gi * (fx * (1.f - fy)), w01 = gi * ((1.f - fx) * fy), w11 = gi * (fx * fy);
-            if (cx0 + dx < HEX_PW && cy0 + dy < HEX_PW) {                  // (cx0, cy0 >= 0: the anchor is the block's smallest tap)
-                double* w0 = &win[(cy0 * HEX_PW + cx0) * C + c];
-                lds_add_f64(w0, w00);
-                lds_add_f64(w0 + dx * C, w10);
-                lds_add_f64(w0 + dy * HEX_PW * C, w01);
-                lds_add_f64(w0 + (dy * HEX_PW + dx) * C, w11);
+            const float gx1 = gi * fx, gx0 = gi - gx1, s0 = gx0 * fy, s1 = gx1 * fy;
+            const float w00 = gx0 - s0, w10 = gx1 - s1, w01 = s0, w11 = s1;
+            const int x0 = tap & 0x3fffu, y0 = (tap >> 14) & 0x3fffu, dx = (tap >> 28) & 1u, dy = (tap >> 29) & 1u;      // (meaningful outside the window)
+            if ((int)tap < 0) {
+                char* w0 = (char*)win + ((tap & 0xffffu) + (uint32_t)c * 8u);
+                const uint32_t ox = ((tap >> 16) & 0xffu) << 3, oy = ((tap >> 24) & 0x7fu) * (uint32_t)(C * 8);
+                lds_add_f64((double*)w0, w00);
+                lds_add_f64((double*)(w0 + ox), w10);
+                lds_add_f64((double*)(w0 + oy), w01);
+                lds_add_f64((double*)(w0 + oy + ox), w11);
             } else {
                 atomicAdd(gp + tap_at(x0, y0, W, C, c), w00);
                 atomicAdd(gp + tap_at(x0 + dx, y0, W, C, c), w10);
