@@ -393,9 +393,6 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
 // fewer vector instructions per point) was built and measured SLOWER, 5.2 ms: 48 tap registers in flight per iteration, spills at the
 // 128-VGPR cap or three waves per SIMD without them -- four un-spilled waves per SIMD are worth more than the instruction count (DESIGN.md
 // section 8, round 4).  Built without SLP vectorisation (Makefile): the packer cost 129 v_mov per iteration and 8 spilled registers.
-#ifndef HEX_STORES_FIRST
-#define HEX_STORES_FIRST 1
-#endif
 #ifndef HEX_STAGE_BYTES
 #define HEX_STAGE_BYTES 1  /* the staged tap offset, row stride and dx in BYTES: four address instructions per plane in the gathers instead of seven (4.31 -> 4.25 ms) */
 #endif
@@ -438,8 +435,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
     __shared__ float4 s_w[WAVES * SROWS];               //   the fractions fx, fy and the slopes d(ix)/d(coord), d(iy)/d(coord) (0 where the coordinate was clipped)
     __shared__ float4 s_q[HEX_AGG_POINTS];              // box-normalised x, y, z and the time of every point of the block
     __shared__ float4 s_dq[HEX_AGG_POINTS];             // dL/d(those), summed over the scales
-    __shared__ int s_n[HEX_AGG_POINTS];                 // its index (-1 past the end)
-    __shared__ int s_pos[HEX_AGG_POINTS * 3];           // its position in the visiting orders of the planes xy, xz, yz (deferred scales)
+    __shared__ int4 s_pn[HEX_AGG_POINTS];               // its position in the visiting orders of the planes xy, xz, yz (deferred scales: ONE read in front of the three row stores) and its index (-1 past the end)
     __shared__ int qmin[4], qmax[4];
     const int tid = threadIdx.x, group = tid / C, c = tid % C, S = a.num_scales, lane = tid & 63, wave = tid >> 6, gw = lane / C;
     // blocks that run side by side take chunks far apart along the curve (stride coprime with the grid): neighbouring chunks
@@ -471,17 +467,17 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         }
         ((float*)&s_q[j])[k] = qv;
         ((float*)&s_dq[j])[k] = 0.f;
-        if (k == 0) s_n[j] = n;
-        else if (g.defer_mask && live) s_pos[3 * j + k - 1] = pos;
+        if (k == 0) s_pn[j].w = n;
+        else if (g.defer_mask && live) ((int*)&s_pn[j])[k - 1] = pos;
     }
     __syncthreads();
     if (g.defer_mask) for (int t = tid; t < HEX_AGG_POINTS * 3; t += HEX_AGG_THREADS) {
         // the per-plane pass reads the two normalised coordinates of a point at its position in the plane's order (behind the rows)
         const int j = t / 3, pidx = t - 3 * j;
-        if (s_n[j] >= 0) {
+        if (s_pn[j].w >= 0) {
             const float4 q = s_q[j];
             float2* defer_q = (float2*)(g.defer_rows + (size_t)__builtin_popcount(g.defer_mask) * 3 * (size_t)a.num_points * C) + (size_t)pidx * a.num_points;
-            defer_q[s_pos[3 * j + pidx]] = pidx == 0 ? make_float2(q.x, q.y) : (pidx == 1 ? make_float2(q.x, q.z) : make_float2(q.y, q.z));
+            defer_q[((const int*)&s_pn[j])[pidx]] = pidx == 0 ? make_float2(q.x, q.y) : (pidx == 1 ? make_float2(q.x, q.z) : make_float2(q.y, q.z));
         }
     }
     float qlo[4];
@@ -522,7 +518,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         auto stage = [&](int it) {                      // `it` a multiple of SK: rows of iterations it .. it + SK - 1 into their ring slots
             if (lane < SK * IROWS) {
                 const int k2 = lane / IROWS, rem = lane - k2 * IROWS, jj = rem / 6, p = rem - 6 * jj;
-                const int pt = wave * PER_WAVE + (it + k2) * GW + jj, n = s_n[pt];
+                const int pt = wave * PER_WAVE + (it + k2) * GW + jj, n = s_pn[pt].w;
                 if (n >= 0) {
                     int ax, ay;
                     pair_axes(p, ax, ay);
@@ -555,7 +551,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
         int n = -1;
         // ---- the gathers of iteration `it`: uniform plane base + 32-bit byte offsets (the saddr form: no 64-bit address arithmetic)
         auto gather = [&](int it) {
-            n = s_n[wave * PER_WAVE + it * GW + gw];
+            n = s_pn[wave * PER_WAVE + it * GW + gw].w;
             if (n >= 0) {
                 go = HEX_NT ? __builtin_nontemporal_load(g.dL_dout + ((size_t)n * (S * C) + cs * C + c)) : g.dL_dout[(size_t)n * (S * C) + cs * C + c];
 #pragma unroll
@@ -636,21 +632,20 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // stage(it + 1) is visible to the wave
             __builtin_amdgcn_wave_barrier();
-#if HEX_STORES_FIRST
             // Round 5 (late): the rows of a deferred scale's spatial planes leave BEFORE the next gathers are requested.  gfx9 counts loads and
             // stores on ONE counter, in order: with the stores issued after the gathers, the wait for the gathers at the top of the next
             // iteration (vmcnt(0): the number of stores in between is not a compile-time constant) also waited for the stores' acknowledgements,
             // which are the youngest operations in flight; now the gathers are, and the LDS adds below (a different counter) run under them.
             if (n_cur >= 0 && deferred) {
+                const int4 P = s_pn[pt];
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     if (p == 2 || !HEX_GP(p)) continue;
                     const int pidx = p == 3 ? 2 : p;                      // the row itself, at the point's position in that plane's order (plain store)
                     char* rows = (char*)(g.defer_rows + (defer_base + pidx) * (size_t)a.num_points * C);
-                    *(float*)(rows + (((uint32_t)s_pos[3 * pt + pidx] * C + c) << 2)) = gi[p];
+                    *(float*)(rows + (((uint32_t)(pidx == 0 ? P.x : (pidx == 1 ? P.y : P.z)) * C + c) << 2)) = gi[p];
                 }
             }
-#endif
             if (it + 1 < ITERS) gather(it + 1);                          // in flight while the rows of `it` are scattered
             // ---- the 24 tap rows of the point: rows inside the windows are native fp64 LDS adds, rows outside leave as global float
             // atomics; both are fire and forget
@@ -660,14 +655,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     const bool marg = (p == 2 || p >= 4) && tuni;         // marginal over the block's time: two rows
                     float* gp = HEX_GP(p);
                     if (!gp) continue;
-                    if (deferred && p != 2 && p < 4) {                    // spatial plane of a deferred scale: the row itself, at the point's
-#if !HEX_STORES_FIRST
-                        const int pidx = p == 3 ? 2 : p;                  // position in that plane's order (plain store)
-                        char* rows = (char*)(g.defer_rows + (defer_base + pidx) * (size_t)a.num_points * C);
-                        *(float*)(rows + (((uint32_t)s_pos[3 * pt + pidx] * C + c) << 2)) = gi[p];
-#endif
-                        continue;
-                    }
+                    if (deferred && p != 2 && p < 4) continue;            // spatial plane of a deferred scale: its row left above
                     if (gi[p] == 0.f) continue;
                     const uint4 A = s_a[rowb + p];                       // (read again: cheaper than live registers)
                     const float4 F = s_w[rowb + p];
@@ -748,7 +736,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
     // dL/dpts through normalize_aabb (the time coordinate is used as given)
     if (want_dq)
         for (int item = tid; item < HEX_AGG_POINTS * 4; item += HEX_AGG_THREADS) {
-            const int j = item >> 2, k = item & 3, n = s_n[j];
+            const int j = item >> 2, k = item & 3, n = s_pn[j].w;
             if (n < 0) continue;
             const float v = ((const float*)&s_dq[j])[k];
             if (k < 3) { if (g.dL_dpts) g.dL_dpts[3 * (long)n + k] = v * (2.f / (sel4f(a.aabb[3], a.aabb[4], a.aabb[5], 0.f, k) - sel4f(a.aabb[0], a.aabb[1], a.aabb[2], 0.f, k))); }
