@@ -71,10 +71,12 @@ def test_hexplane_vs_oracle(N, C, res, multires):
             _close(prm.grad, planes0[s][p].grad.numpy(), f"plane {s} {p}")
 
 
-@pytest.mark.parametrize("C,layout", [(32, "morton"), (32, "random_order"), (16, "morton"), (32, "clustered"), (32, "same_time"),
-                                      (32, "plane_pass"), (16, "plane_pass"), (32, "plane_pass_some_scales"), (32, "plane_pass_random_orders"),
-                                      (32, "plane_pass_clustered")])
-def test_hexplane_aggregating_backward(C, layout):
+@pytest.mark.parametrize("C,layout,N", [(32, "morton", 30011), (32, "random_order", 30011), (16, "morton", 30011), (32, "clustered", 30011),
+                                        (32, "same_time", 30011), (32, "plane_pass", 30011), (16, "plane_pass", 30011),
+                                        (32, "plane_pass_some_scales", 30011), (32, "plane_pass_random_orders", 30011), (32, "plane_pass_clustered", 30011),
+                                        # the edges of the main kernel's 512-point workgroups and of the per-plane pass's 256-point runs
+                                        (32, "plane_pass", 1), (32, "plane_pass", 255), (32, "plane_pass", 512), (32, "plane_pass", 513), (16, "same_time", 1025)])
+def test_hexplane_aggregating_backward(C, layout, N):
     """The LDS-aggregating backward (taken when a visiting order is given) against the oracle: Morton order (windows hit), an
     arbitrary permutation (almost every tap falls back to the direct atomic), points piled into a few cells, one shared time; and
     with the spatial planes of all / some scales deferred to the per-plane pass (EmdHexGrads.defer_mask), under plane-coherent
@@ -82,7 +84,7 @@ def test_hexplane_aggregating_backward(C, layout):
     from emd_amd.hexplane import HexPlaneField, VisitingOrders, _HexLookup, morton_order
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(C + len(layout))
-    N, res, multires = 30011, [16, 12, 10, 6], [1, 2, 4]
+    res, multires = [16, 12, 10, 6], [1, 2, 4]
     cfg = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": C, "resolution": res}
     field = HexPlaneField(1.6, cfg, multires).to(dev)
     for gp in field.grids:
