@@ -393,6 +393,16 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
 // fewer vector instructions per point) was built and measured SLOWER, 5.2 ms: 48 tap registers in flight per iteration, spills at the
 // 128-VGPR cap or three waves per SIMD without them -- four un-spilled waves per SIMD are worth more than the instruction count (DESIGN.md
 // section 8, round 4).  Built without SLP vectorisation (Makefile): the packer cost 129 v_mov per iteration and 8 spilled registers.
+//
+// Round 5, late (3.67 -> 2.93 ms without / 3.05 ms with the time-gradient sum; DESIGN.md section 8 "HexPlane, round 5 late" has the A/B of every step):
+//  * no lane-indexed reads of the kernel arguments (pair_axes as arithmetic, the scale's resolutions / anchors / gradient pointers as selects of
+//    scalars): `a.res[s][axis]` with a lane-varying axis is a global load, and the staging call had two of them, dependent, behind the gathers' wait;
+//  * 512 points per workgroup (16 iterations per wave between two flushes), four iterations per staging call into a ring of five iteration slots,
+//    one staged row per (point, plane): (fx, fy, slope x, slope y) -- the sample as nested interpolations, whose differences are the slopes;
+//  * the next scale's first rows are staged, and its first gathers requested, before the block meets at the flush of the current scale;
+//  * a point's three plane positions and its index share one LDS row (s_pn): one read in front of the three deferred-row stores.
+//  The numbers in the paragraphs above (256 points, 12 x 12 / 32-cell windows, two iterations per staging call, 152 KB) describe the rounds they are
+//  dated with; the geometry now is HEX_AGG_POINTS / HEX_SW / HEX_TW below, 159 KB of LDS at 32 channels.
 #ifndef HEX_STAGE_BYTES
 #define HEX_STAGE_BYTES 1  /* the staged tap offset, row stride and dx in BYTES: four address instructions per plane in the gathers instead of seven (4.31 -> 4.25 ms) */
 #endif
