@@ -330,11 +330,21 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_radix_scan_bins(uint32_t* __restr
     __shared__ uint32_t s[4];
     uint32_t* row = hist + (size_t)blockIdx.x * nblocks_cap;
     uint32_t carry = 0;
+    // the counts of the NEXT tile travel while this one is scanned (two barriers and the stores): unconditional loads from clamped positions, masked
+    // where they are used -- a row of a few thousand counts was load -> scan -> store, one round trip per 1024 counts in a 5 us kernel
+    uint32_t nv[SCAN_ITEMS];
+    const uint32_t last = nblocks_cap ? nblocks_cap - 1 : 0u;
+    auto request = [&](uint32_t base) {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) nv[k] = row[min(base + threadIdx.x * SCAN_ITEMS + k, last)];
+    };
+    request(0);
     for (uint32_t base = 0; base < nblocks_cap; base += SCAN_TILE) {
         const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
         uint32_t v[SCAN_ITEMS], sum = 0;
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < nblocks_cap) ? row[i0 + k] : 0u; sum += v[k]; }
+        for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < nblocks_cap) ? nv[k] : 0u; sum += v[k]; }
+        request(base + SCAN_TILE);                    // (past the end: the row's last count again, unused)
         uint32_t total;
         const uint32_t inc = block_scan_add_u32(sum, s, &total);
         uint32_t run = carry + inc - sum;
