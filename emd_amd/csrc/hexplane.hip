@@ -397,12 +397,14 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
 // Round 5, late (3.67 -> 2.93 ms without / 3.05 ms with the time-gradient sum; DESIGN.md section 8 "HexPlane, round 5 late" has the A/B of every step):
 //  * no lane-indexed reads of the kernel arguments (pair_axes as arithmetic, the scale's resolutions / anchors / gradient pointers as selects of
 //    scalars): `a.res[s][axis]` with a lane-varying axis is a global load, and the staging call had two of them, dependent, behind the gathers' wait;
-//  * 512 points per workgroup (16 iterations per wave between two flushes), four iterations per staging call into a ring of five iteration slots,
+//  * 16 iterations per wave between two flushes (first as 512 points per 1024-thread workgroup), four iterations per staging call into a ring of five iteration slots,
 //    one staged row per (point, plane): (fx, fy, slope x, slope y) -- the sample as nested interpolations, whose differences are the slopes;
 //  * the next scale's first rows are staged, and its first gathers requested, before the block meets at the flush of the current scale;
 //  * a point's three plane positions and its index share one LDS row (s_pn): one read in front of the three deferred-row stores.
-//  The numbers in the paragraphs above (256 points, 12 x 12 / 32-cell windows, two iterations per staging call, 152 KB) describe the rounds they are
-//  dated with; the geometry now is HEX_AGG_POINTS / HEX_SW / HEX_TW below, 159 KB of LDS at 32 channels.
+//  * TWO workgroups of 512 threads per CU (256 points, 7 x 7 spatial windows, 80 KB each) instead of one of 1024: one computes while the other meets at
+//    its flush (3.69 -> 3.49 ms for the whole backward at 2 M points).
+//  The numbers in the paragraphs above (12 x 12 / 32-cell windows, two iterations per staging call, one 1024-thread block owning 152 KB) describe the
+//  rounds they are dated with; the geometry now is HEX_AGG_THREADS / HEX_AGG_POINTS / HEX_SW / HEX_TW below.
 #ifndef HEX_STAGE_BYTES
 #define HEX_STAGE_BYTES 1  /* the staged tap offset, row stride and dx in BYTES: four address instructions per plane in the gathers instead of seven (4.31 -> 4.25 ms) */
 #endif
@@ -413,14 +415,15 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
 #define HEX_NEXT_SCALE_EARLY 1
 #endif
 #ifndef HEX_AGG_THREADS
-#define HEX_AGG_THREADS 1024             /* one block per CU (159 KB of LDS at 32 channels), four waves per SIMD */
-#define HEX_AGG_POINTS 512               /* round 5 (late): 512 points per block instead of 256, in the 12 KB the dropped slope rows freed -- 16 iterations per wave between
-                                            two flushes instead of 8 (the pipeline fills once per scale, with every wave in the same phase), half the barriers, and
-                                            more taps per flushed cell row: backward 4.14 -> 3.98 ms at 2 M points */
-#define HEX_SW 10                        /* spatial window: HEX_SW x HEX_SW cells (finer scales go through the per-plane pass) */
+#define HEX_AGG_THREADS 512              /* round 5 (end): TWO workgroups of 512 threads per CU (80 KB of LDS each at 32 channels; four waves per SIMD as before) instead of one of
+                                            1024 -- while one meets at its flush (barrier, atomics, the next scale's first round trip) the other one computes, and a barrier holds
+                                            8 waves instead of 16: backward 3.69 -> 3.49 ms at 2 M points, fine-stage step 11.50 -> 11.25 ms */
+#define HEX_AGG_POINTS 256               /* points per workgroup: 16 iterations per wave between two flushes (one workgroup of 1024 threads: 512 points were worth 0.16 ms over 256) */
+#define HEX_SW 7                         /* spatial window: HEX_SW x HEX_SW cells (finer scales go through the per-plane pass) */
 #endif
 #ifndef HEX_TW
-#define HEX_TW 40                        /* time-plane window: HEX_TW marginal cells, or (HEX_TW / 2) x 2 cells (a run spans ~46 cells of a 512-cell axis) */
+#define HEX_TW 19                        /* time-plane window of a scale with spatial windows: HEX_TW marginal cells, or (HEX_TW / 2) x 2 cells; a deferred scale gives each time
+                                            plane a third of all cells (68: a run of 256 points spans 35 - 50 cells of a 512-cell axis) */
 #endif
 #define HEX_SCELLS (HEX_SW * HEX_SW)
 #define HEX_WIN_CELLS (3 * HEX_SCELLS + 3 * HEX_TW)

@@ -161,13 +161,14 @@ class VisitingOrders:
         self.order, self.order2d, self.pos2d, self.defer_mask = order, order2d, pos2d, defer_mask
 
     @staticmethod
-    def build(pts, aabb, res, run=512, window=10):
-        """Scales on whose spatial planes a run of `run` points (compact in 3-D) spreads over more than the 10 x 10 window are deferred to
+    def build(pts, aabb, res, run=256, window=7):
+        """Scales on whose spatial planes a run of `run` points (compact in 3-D) spreads over more than the 7 x 7 window are deferred to
         the per-plane pass: a run fills run / N of the box, i.e. ~1.7 (run / N)^(1/3) of its side along the curve, times the scale's
-        resolution (2 M points, runs of 512: 6.9 cells at resolution 64, 14 at 128, 28 at 256; with the 256-point runs of rounds 3-4: 5.5 / 11 --
-        where 37 % of the taps already left the window, each four partly filled atomic instructions -- / 22).  Round 4: with the per-plane
-        pass at 0.32 ms per scale the threshold came down from 1.5 x to 1 x the window: main kernel 4.08 -> 3.69 ms, per-plane pass
-        0.63 -> 0.95 ms at 2 M points.  `run` is the main kernel's HEX_AGG_POINTS (a mismatch costs time, never correctness)."""
+        resolution (2 M points, runs of 256: 5.5 cells at resolution 64, 11 at 128 -- where 37 % of the taps already left a 10 x 10 window,
+        each four partly filled atomic instructions --, 22 at 256).  Round 4: with the per-plane pass at 0.32 ms per scale the threshold came
+        down from 1.5 x to 1 x the window: main kernel 4.08 -> 3.69 ms, per-plane pass 0.63 -> 0.95 ms at 2 M points.  `run` and `window` are
+        the main kernel's HEX_AGG_POINTS and HEX_SW (round 5: 256 points and 7 x 7 cells per workgroup, two workgroups per CU; a mismatch
+        costs time, never correctness)."""
         n = pts.shape[0]
         side = min(1.0, 1.7 * (run / max(n, 1)) ** (1.0 / 3.0))       # (a run spans no more than the box)
         mask = 0

@@ -34,7 +34,7 @@ def test_hexplane_oracle_matches_reference_values_and_gradients():
 def test_visiting_orders_are_permutations_with_inverses_and_defer_the_fine_scales():
     """Host logic of the aggregating backward's orders (emd_amd.hexplane.VisitingOrders, EmdHexGrads.order2d / pos2d / defer_mask):
     every order is a permutation, pos2d is its inverse, consecutive points of a plane order are close in that plane's two coordinates,
-    and the scales a 512-point run of the main kernel overflows the windows of are the deferred ones (reference configuration: 128, 256 and 512 at 2 M points)."""
+    and the scales a 256-point run of the main kernel overflows the 7 x 7 windows of are the deferred ones (reference configuration: 128, 256 and 512 at 2 M points)."""
     from emd_amd.hexplane import VisitingOrders, morton_order, plane_order
     g = torch.Generator().manual_seed(0)
     N = 50_000
@@ -43,7 +43,7 @@ def test_visiting_orders_are_permutations_with_inverses_and_defer_the_fine_scale
     res = [[64, 64, 64, 25], [128, 128, 128, 25], [256, 256, 256, 25], [512, 512, 512, 25]]
     vo = VisitingOrders.build(pts, aabb, res)
     assert sorted(vo.order.tolist()) == list(range(N)) and torch.equal(vo.order, morton_order(pts, aabb))
-    assert vo.defer_mask == 0b1111                               # 50 k points: a run spans 0.37 of the box, 24 cells even at resolution 64 (> the 10-cell window)
+    assert vo.defer_mask == 0b1111                               # 50 k points: a run spans 0.29 of the box, 19 cells even at resolution 64 (> the 7-cell window)
     for k, (ax, ay) in enumerate(((0, 1), (0, 2), (1, 2))):
         o, inv = vo.order2d[k].long(), vo.pos2d[k].long()
         assert sorted(o.tolist()) == list(range(N))
@@ -53,7 +53,7 @@ def test_visiting_orders_are_permutations_with_inverses_and_defer_the_fine_scale
         ext = (run.max(dim=1)[0] - run.min(dim=1)[0]) / 3.2     # extent of a run as a fraction of the box
         other = 3 - ax - ay
         assert float(ext[:, ax].median()) < 0.15 and float(ext[:, ay].median()) < 0.15 and float(ext[:, other].median()) > 0.9
-    # the mask follows N: at 2 M points resolution 64 stays in the main kernel's windows (6.9 cells), 128 (14 cells) and finer are deferred,
+    # the mask follows N: at 2 M points resolution 64 stays in the main kernel's windows (5.5 cells), 128 (11 cells) and finer are deferred,
     # and a small cloud defers nothing at coarse resolutions
     big = VisitingOrders.build(torch.rand(2_000_000, 3, generator=g) * 3.2 - 1.6, aabb, res)
     assert big.defer_mask == 0b1110

@@ -74,7 +74,7 @@ def test_hexplane_vs_oracle(N, C, res, multires):
 @pytest.mark.parametrize("C,layout,N", [(32, "morton", 30011), (32, "random_order", 30011), (16, "morton", 30011), (32, "clustered", 30011),
                                         (32, "same_time", 30011), (32, "plane_pass", 30011), (16, "plane_pass", 30011),
                                         (32, "plane_pass_some_scales", 30011), (32, "plane_pass_random_orders", 30011), (32, "plane_pass_clustered", 30011),
-                                        # the edges of the main kernel's 512-point workgroups and of the per-plane pass's 256-point runs
+                                        # the edges of the main kernel's 256-point workgroups and of the per-plane pass's 256-point runs
                                         (32, "plane_pass", 1), (32, "plane_pass", 255), (32, "plane_pass", 512), (32, "plane_pass", 513), (16, "same_time", 1025)])
 def test_hexplane_aggregating_backward(C, layout, N):
     """The LDS-aggregating backward (taken when a visiting order is given) against the oracle: Morton order (windows hit), an
@@ -265,7 +265,7 @@ def test_backward_without_the_time_gradient_equals_the_one_with_it():
         for gp in field.grids:
             for p in gp:
                 p.copy_(torch.rand_like(p) * 0.8 + 0.6)
-    N = 800_000                                                         # (512-point runs: resolution 64 stays in the main kernel's windows from ~0.7 M points on)
+    N = 1_200_000                                                       # (256-point runs against 7 x 7 windows: resolution 64 stays in the main kernel from ~1 M points on)
     pts = (torch.rand(N, 3, device=dev) * 3.2 - 1.6).requires_grad_(True)
     gout = torch.randn(N, 128, device=dev)
     res = {}
