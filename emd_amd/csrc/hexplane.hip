@@ -408,6 +408,10 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_hexplane_fwd4(EmdHexArgs a, unsig
 #ifndef HEX_STAGE_BYTES
 #define HEX_STAGE_BYTES 1  /* the staged tap offset, row stride and dx in BYTES: four address instructions per plane in the gathers instead of seven (4.31 -> 4.25 ms) */
 #endif
+#ifndef HEX_NT_ROWS
+#define HEX_NT_ROWS 1     /* the deferred rows (2.3 GB written by the main kernel, read once by the per-plane pass) bypass the caches: they evicted the planes the gathers
+                              and the cell-row atomics work on -- backward 3.55 -> 3.39 ms at 2 M points, fine-stage step 11.08 -> 10.99 ms */
+#endif
 #ifndef HEX_STAGE_ITERS
 #define HEX_STAGE_ITERS 0  /* iterations staged per stage() call: 0 = as many as fit the wave's lanes (4 at 32 channels, 2 at 16) */
 #endif
@@ -656,7 +660,11 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
                     if (p == 2 || !HEX_GP(p)) continue;
                     const int pidx = p == 3 ? 2 : p;                      // the row itself, at the point's position in that plane's order (plain store)
                     char* rows = (char*)(g.defer_rows + (defer_base + pidx) * (size_t)a.num_points * C);
+#if HEX_NT_ROWS
+                    __builtin_nontemporal_store(gi[p], (float*)(rows + (((uint32_t)(pidx == 0 ? P.x : (pidx == 1 ? P.y : P.z)) * C + c) << 2)));
+#else
                     *(float*)(rows + (((uint32_t)(pidx == 0 ? P.x : (pidx == 1 ? P.y : P.z)) * C + c) << 2)) = gi[p];
+#endif
                 }
             }
             if (it + 1 < ITERS) gather(it + 1);                          // in flight while the rows of `it` are scattered
@@ -819,7 +827,11 @@ __global__ void __launch_bounds__(HEX_PL_THREADS) k_hexplane_bwd_plane(EmdHexArg
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             const int j = group + GROUPS * k;
+#if HEX_NT_ROWS
+            gis[k] = __builtin_nontemporal_load(rows + ((size_t)min(first + j, (long)a.num_points - 1) * C + c));
+#else
             gis[k] = rows[(size_t)min(first + j, (long)a.num_points - 1) * C + c];     // (clamped, not guarded: rows past the end are skipped below)
+#endif
         }
         if (tid < 2) cmin[tid] = INT_MAX;
         __syncthreads();
