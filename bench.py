@@ -330,7 +330,9 @@ def main():
         if step is not None and X["cap_by_row"] is not None:
             per = args.warmup + args.steps
             cap = X["cap_by_row"][step if step < per else args.warmup + (step - args.warmup) % max(args.steps, 1)]
-        return dict(compact=X["compact"], compact_capacity=cap, overflow=X["overflow"])
+        # slab_pure: this step's loss reaches the four small per-Gaussian tensors through the rasterizer alone (L1 on the image, no regulariser),
+        # so the slab of a REPLAYED step may travel as rows of the visible Gaussians too (dp.GradientExchange's precondition)
+        return dict(compact=X["compact"], compact_capacity=cap, overflow=X["overflow"], slab_pure=True)
 
     def cam_for(step):
         # views are ordered timestamp-major and dealt out by dp.view_for: every rank renders a DISTINCT (frame, camera);

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemd_raster.so")
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 MAX_EXTRA = 2
 SETTINGS_DEV_FLOATS = 38
 TILE = 16
@@ -117,7 +117,7 @@ class EmdDeformInArgs(C.Structure):
                 ("t", _f), ("out", _f)]
 
 
-DENSIFY_MODE_DENSIFY, DENSIFY_MODE_PRUNE = 0, 1
+DENSIFY_MODE_DENSIFY, DENSIFY_MODE_PRUNE, DENSIFY_MODE_REFINE = 0, 1, 2
 DENSIFY_ROLE_COPY, DENSIFY_ROLE_XYZ, DENSIFY_ROLE_SCALING, DENSIFY_ROLE_STATE, DENSIFY_ROLE_ZERO = 0, 1, 2, 3, 4
 DENSIFY_MAX_TENSORS = 40
 
@@ -126,6 +126,13 @@ class EmdDensifyArgs(C.Structure):
     _fields_ = [("num_points", C.c_int32), ("mode", C.c_int32), ("scaling", _f), ("opacity", _f), ("grad_accum", _f), ("denom", _f),
                 ("max_radii2D", _f), ("extra_drop", _f), ("grad_threshold", C.c_float), ("percent_dense", C.c_float),
                 ("scene_extent", C.c_float), ("min_opacity", C.c_float), ("max_screen_size", C.c_float)]
+
+
+class EmdRefineArgs(C.Structure):
+    _fields_ = [("num_points", C.c_int32), ("do_densify", C.c_int32), ("do_cull", C.c_int32), ("use_split_screen", C.c_int32), ("cull_big", C.c_int32),
+                ("use_cull_screen", C.c_int32), ("scaling", _f), ("opacity", _f), ("grad_norm", _f), ("vis_counts", _f), ("max_2Dsize", _f),
+                ("grad_threshold", C.c_float), ("size_threshold", C.c_float), ("split_screen", C.c_float), ("cull_alpha", C.c_float),
+                ("cull_size", C.c_float), ("cull_screen", C.c_float)]
 
 
 class EmdDensifyTensor(C.Structure):
@@ -212,6 +219,7 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_temporal_embed_forward", "emd_temporal_embed_backward", "emd_deform_input_width", "emd_deform_input_forward",
                     "emd_deform_input_backward", "emd_adam_step", "emd_track_heads_forward", "emd_track_heads_backward",
                     "emd_densify_decide", "emd_densify_index", "emd_densify_split_rank", "emd_densify_gather",
+                    "emd_refine_decide", "emd_refine_index", "emd_after_train_stats",
                     "emd_mlp_trunk_forward", "emd_mlp_trunk_backward", "emd_mlp_branch_forward", "emd_mlp_branch_backward",
                     "emd_abs_mean_backward", "emd_residual_l1_backward", "emd_tracked_pose_forward", "emd_tracked_pose_backward",
                     "emd_select_step_inputs", "emd_compact_rows", "emd_scatter_rows", "emd_l1_loss_ws")
@@ -283,6 +291,9 @@ def load():
     lib.emd_densify_index.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_densify_split_rank.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.emd_densify_gather.argtypes = [C.POINTER(EmdDensifyGather), C.c_void_p]
+    lib.emd_refine_decide.argtypes = [C.POINTER(EmdRefineArgs), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_refine_index.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_after_train_stats.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     lib.emd_abs_mean_backward.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_residual_l1_backward.argtypes = [C.c_int64] + [C.c_void_p] * 9
     lib.emd_mlp_trunk_forward.argtypes = [C.POINTER(EmdMlpTrunk), C.c_void_p]

@@ -107,6 +107,30 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_densify_gather(EmdDensifyGather g
         const int j = (int)(idx / t.width), c = (int)(idx % t.width);
         const int i = g.src[j], kd = g.kind[j];
         float v;
+        if (g.mode == EMD_DENSIFY_MODE_REFINE) {
+            // OmniRe (vanilla.py:256-263,328-349; basics.py:219-242): kind 0 original, 1 duplicate, 2 + r sample of replica r, + 16 = the source was split
+            const int base = kd & 15;
+            v = t.src[(size_t)i * t.width + c];
+            if (t.role == EMD_DENSIFY_ROLE_STATE || t.role == EMD_DENSIFY_ROLE_ZERO) { if (base != 0) v = 0.f; }
+            else if (t.role == EMD_DENSIFY_ROLE_SCALING) { if (kd & 16) v = logf(expf(v) / 1.6f); }      // original, samples and duplicate of a split source alike
+            else if (t.role == EMD_DENSIFY_ROLE_XYZ && base >= 2) {
+                float n[3];
+                if (g.samples) { const float* s_ = g.samples + ((size_t)(base - 2) * g.num_split + g.split_rank[j]) * 3; n[0] = s_[0]; n[1] = s_[1]; n[2] = s_[2]; }
+                else normal3(g.seed, (uint32_t)i, (uint32_t)(base - 2), n);
+                const float* sc = g.scaling + 3 * (size_t)i;          // the scale BEFORE the reduction (vanilla.py:337-340)
+                const float* qq = g.rotation + 4 * (size_t)i;
+                const float e0 = expf(sc[0]) * n[0], e1 = expf(sc[1]) * n[1], e2 = expf(sc[2]) * n[2];
+                const float qn = sqrtf(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+                const float r = qq[0] / qn, x = qq[1] / qn, y = qq[2] / qn, z = qq[3] / qn;
+                float R0, R1, R2;
+                if (c == 0) { R0 = 1.f - 2.f * (y * y + z * z); R1 = 2.f * (x * y - r * z); R2 = 2.f * (x * z + r * y); }
+                else if (c == 1) { R0 = 2.f * (x * y + r * z); R1 = 1.f - 2.f * (x * x + z * z); R2 = 2.f * (y * z - r * x); }
+                else { R0 = 2.f * (x * z - r * y); R1 = 2.f * (y * z + r * x); R2 = 1.f - 2.f * (x * x + y * y); }
+                v = ((R0 * e0 + R1 * e1) + R2 * e2) + v;
+            }
+            t.dst[idx] = v;
+            continue;
+        }
         if (t.role == EMD_DENSIFY_ROLE_STATE) v = kd == 0 ? t.src[(size_t)i * t.width + c] : 0.f;             // Adam moments of new rows: zero
         else if (t.role == EMD_DENSIFY_ROLE_ZERO) v = (g.mode == EMD_DENSIFY_MODE_DENSIFY) ? 0.f : t.src[(size_t)i * t.width + c];   // statistics: reset by a densification
         else {
@@ -143,7 +167,115 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_densify_split_rank(int num_out, i
     rank[j] = j < base ? 0 : (j - base) % (n_split > 0 ? n_split : 1);
 }
 
+// ---- OmniRe refinement (EmdRefineArgs in include/emd_raster.h restates the semantics) ------------------------------------------------------------
+enum { RCODE_KEEP = 1, RCODE_DUP = 2, RCODE_SAMPLES = 4, RCODE_SPLIT = 8 };
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_refine_decide(EmdRefineArgs a, int32_t* __restrict__ code, int32_t* __restrict__ cols /*[4][N]*/) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i >= a.num_points) return;
+    const float l0 = a.scaling[3 * i], l1 = a.scaling[3 * i + 1], l2 = a.scaling[3 * i + 2];
+    float smax = fmaxf(expf(l0), fmaxf(expf(l1), expf(l2)));
+    const float m2d = a.max_2Dsize ? a.max_2Dsize[i] : 0.f;
+    bool split = false, dup = false;
+    float smax_new = smax;
+    if (a.do_densify) {
+        const bool high = a.grad_norm[i] / a.vis_counts[i] > a.grad_threshold;
+        split = (smax > a.size_threshold || (a.use_split_screen && m2d > a.split_screen)) && high;
+        if (split) {
+            // the original takes log(exp(s) / 1.6) in place; what the later tests see is exp() of THAT (vanilla.py:344-345,302-309)
+            smax_new = fmaxf(expf(logf(expf(l0) / 1.6f)), fmaxf(expf(logf(expf(l1) / 1.6f)), expf(logf(expf(l2) / 1.6f))));
+            smax = smax_new;
+        }
+        dup = smax <= a.size_threshold && high;
+    }
+    bool keep = true, keep_samples = split, keep_dup = dup;
+    if (a.do_cull) {
+        const float op = 1.f / (1.f + expf(-a.opacity[i]));
+        const bool faint = op < a.cull_alpha;
+        const bool big = a.cull_big && smax > a.cull_size;                        // the same (possibly reduced) scale on the original, its samples, its duplicate
+        const bool wide_old = a.cull_big && a.use_cull_screen && m2d > a.cull_screen;
+        const bool wide_new = a.cull_big && a.use_cull_screen && 0.f > a.cull_screen;      // new rows carry max_2Dsize 0 (vanilla.py:266-269)
+        keep = !(faint || big || wide_old);
+        keep_samples = split && !(faint || big || wide_new);
+        keep_dup = dup && !(faint || big || wide_new);
+    }
+    code[i] = (keep ? RCODE_KEEP : 0) | (keep_dup ? RCODE_DUP : 0) | (keep_samples ? RCODE_SAMPLES : 0) | (split ? RCODE_SPLIT : 0);
+    const size_t N = (size_t)a.num_points;
+    cols[i] = keep ? 1 : 0;
+    cols[N + i] = keep_dup ? 1 : 0;
+    cols[2 * N + i] = keep_samples ? 1 : 0;
+    cols[3 * N + i] = split ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_refine_index(int n, int num_samples, const int32_t* __restrict__ code, const int32_t* __restrict__ inc,
+                                                            int32_t* __restrict__ src, int32_t* __restrict__ kind, int32_t* __restrict__ split_rank) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = (size_t)n;
+    const int n_keep = inc[N - 1], n_samp = inc[3 * N - 1];
+    const int c = code[i];
+    const int sp = (c & RCODE_SPLIT) ? 16 : 0;
+    if (c & RCODE_KEEP) { const int j = inc[i] - 1; src[j] = i; kind[j] = sp; if (split_rank) split_rank[j] = 0; }
+    if (c & RCODE_SAMPLES) {
+        const int r = inc[2 * N + i] - 1, rank = inc[3 * N + i] - 1;
+        for (int rep = 0; rep < num_samples; rep++) {
+            const int j = n_keep + rep * n_samp + r;
+            src[j] = i; kind[j] = (2 + rep) | sp;
+            if (split_rank) split_rank[j] = rank;
+        }
+    }
+    if (c & RCODE_DUP) { const int j = n_keep + num_samples * n_samp + inc[N + i] - 1; src[j] = i; kind[j] = 1 | sp; if (split_rank) split_rank[j] = 0; }
+}
+
+// VanillaGaussians.after_train (vanilla.py:163-191) for one view, in place
+__global__ void __launch_bounds__(EMD_BLOCK) k_after_train_stats(int n, const int32_t* __restrict__ radii, const float* __restrict__ g, int stride,
+                                                                 float* __restrict__ grad_norm, float* __restrict__ vis, float* __restrict__ m2d, float last_size) {
+    const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float gx = g[(size_t)stride * i], gy = g[(size_t)stride * i + 1];
+    if (grad_norm) grad_norm[i] += sqrtf(gx * gx + gy * gy);
+    if (vis) vis[i] += 1.f;
+    if (m2d) m2d[i] = fmaxf(m2d[i], (float)r / last_size);
+}
+
 }  // namespace
+
+extern "C" int emd_refine_decide(const EmdRefineArgs* a, int32_t* code, int32_t* columns, void* hip_stream) {
+    if (!a || !code || !columns) { emd_set_error("refine_decide: null argument"); return EMD_ERR_INVALID; }
+    if (a->num_points < 0) { emd_set_error("refine_decide: bad size"); return EMD_ERR_INVALID; }
+    if (a->num_points == 0) return EMD_OK;
+    if (!a->scaling || (a->do_densify && (!a->grad_norm || !a->vis_counts)) || (a->do_cull && !a->opacity) ||
+        (((a->do_densify && a->use_split_screen) || (a->do_cull && a->cull_big && a->use_cull_screen)) && !a->max_2Dsize)) {
+        emd_set_error("refine_decide: null input"); return EMD_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(k_refine_decide, dim3((a->num_points + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, *a, code, columns);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+extern "C" int emd_refine_index(int32_t num_points, int32_t num_out, int32_t num_samples, const int32_t* code, const int32_t* inclusive_scans, int32_t* src,
+                                int32_t* kind, int32_t* split_rank, void* hip_stream) {
+    if (num_points < 0 || num_out < 0 || num_samples < 1 || num_samples > 13 || (num_points > 0 && (!code || !inclusive_scans)) || (num_out > 0 && (!src || !kind))) {
+        emd_set_error("refine_index: bad argument"); return EMD_ERR_INVALID;
+    }
+    if (num_points == 0) return EMD_OK;
+    hipLaunchKernelGGL(k_refine_index, dim3((num_points + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, num_points, num_samples, code,
+                       inclusive_scans, src, kind, split_rank);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+extern "C" int emd_after_train_stats(int32_t n, const int32_t* radii, const float* xys_grad, int32_t grad_stride, float* grad_norm, float* vis_counts,
+                                     float* max_2Dsize, float last_size, void* hip_stream) {
+    if (n < 0 || grad_stride < 2 || !(last_size > 0.f) || (n > 0 && (!radii || !xys_grad))) { emd_set_error("after_train_stats: bad argument"); return EMD_ERR_INVALID; }
+    if (n == 0) return EMD_OK;
+    hipLaunchKernelGGL(k_after_train_stats, dim3((n + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, n, radii, xys_grad, grad_stride, grad_norm,
+                       vis_counts, max_2Dsize, last_size);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
 
 extern "C" int emd_densify_decide(const EmdDensifyArgs* a, int32_t* code, int32_t* columns, void* hip_stream) {
     if (!a || !code || !columns) { emd_set_error("densify_decide: null argument"); return EMD_ERR_INVALID; }
@@ -183,7 +315,7 @@ extern "C" int emd_densify_gather(const EmdDensifyGather* g, void* hip_stream) {
         if (t.role == EMD_DENSIFY_ROLE_XYZ) { has_xyz = true; if (t.width != 3) { emd_set_error("densify_gather: xyz width must be 3"); return EMD_ERR_INVALID; } }
         if ((size_t)t.width > widest) widest = (size_t)t.width;
     }
-    if (has_xyz && g->mode == EMD_DENSIFY_MODE_DENSIFY && (!g->scaling || !g->rotation)) { emd_set_error("densify_gather: split needs scaling and rotation"); return EMD_ERR_INVALID; }
+    if (has_xyz && g->mode != EMD_DENSIFY_MODE_PRUNE && (!g->scaling || !g->rotation)) { emd_set_error("densify_gather: split needs scaling and rotation"); return EMD_ERR_INVALID; }
     if (g->samples && !g->split_rank) { emd_set_error("densify_gather: caller-supplied samples need split_rank"); return EMD_ERR_INVALID; }
     hipStream_t st = (hipStream_t)hip_stream;
     const size_t total = (size_t)g->num_out * widest;

@@ -219,14 +219,24 @@ class GradientExchange:
     and the slab as (index, 11 floats) rows of the view's visible Gaussians (all-gathers of `1 + capacity` rows; emd_compact_rows), and every
     rank adds the gathered rows into the zeroed slab in RANK order (emd_scatter_rows: a fixed order of float additions, so the replicas stay
     bit-identical).  At 2 ranks that is 37 MB per million Gaussians and link against 56.  The capacity is the caller's (host) number, like
-    the binning capacity: more visible Gaussians than rows raise bit 0 of `overflow` (a device int32 the caller owns and polls -- the step's
-    gradients are then incomplete); `dp.visible_capacity(V_max)` adds the margin."""
+    the binning capacity: more visible Gaussians than rows raise bit 0 of `overflow` (a device int32: the caller's, or one the exchange
+    allocates when none is given -- never a null pointer, so a dropped row is always recorded; `overflowed()` reads it, one device-to-host
+    copy, and the step's gradients are then incomplete); `dp.visible_capacity(V_max)` adds the margin.
+
+    PRECONDITION of the compacted SLAB (not of the compacted factors): `finish()` zeroes the slab and re-creates it from the gathered rows of
+    the visible Gaussians, so the slab must hold NOTHING but this call's rasterizer gradients -- zero on every Gaussian the view does not
+    see.  Inside backward() that is what `slab_is_exclusive(rec)` establishes (four leaves without a `.grad`: K8's output is all there is).
+    AFTER backward() (a replayed graph) the leaves' `.grad` are views of the slab and autograd may have accumulated other terms into them in
+    place (a scale / opacity regulariser, a gradient the leaf already held): the rows are then used only when the caller states
+    `slab_pure=True` (the step's loss reaches the four tensors through the rasterizer alone); otherwise the slab travels as the dense
+    all-reduce, which keeps and averages every term.  EMD_DP_DEBUG=1 checks the statement on the device before the rows are packed."""
 
     def __init__(self, campos_local, actor_ids=None, actor_pose=None, residual_dx=None, average=True, bucket_small=True, bucket_bytes=16 << 20,
-                 compact=None, compact_capacity=None, overflow=None):
+                 compact=None, compact_capacity=None, overflow=None, slab_pure=False):
         self.campos_local, self.actor_ids, self.residual_dx = campos_local, actor_ids, residual_dx
         self.bucket_small, self.bucket_bytes = bucket_small, bucket_bytes
         self.compact, self.compact_capacity, self.overflow = compact, compact_capacity, overflow
+        self.slab_pure = bool(slab_pure)
         self._rows_f = self._rows_s = None
         self.actor_pose = None if actor_pose is None else actor_pose.detach()       # values only: no reference into an autograd graph
         self.average = average
@@ -252,6 +262,7 @@ class GradientExchange:
             raise RuntimeError("the compacted exchange packs by the call's radii (RasterCall.radii): this record carries none")
         if self._use_compact(W, N):
             cap = int(self.compact_capacity)
+            self._overflow_word(dev)
             mine = compact_rows(rec.radii, [g_local], cap)                             # (index, 3 floats) rows of the visible Gaussians
             self._rows_f = torch.empty(W * mine.numel(), dtype=torch.int32, device=dev)
             self._gathers = [dist.all_gather_into_tensor(self._rows_f, mine.view(-1), async_op=True)]
@@ -265,6 +276,32 @@ class GradientExchange:
             self._poses = torch.empty(W * A, self.actor_pose.shape[1], device=dev, dtype=torch.float32)
             self._gathers.append(dist.all_gather_into_tensor(self._poses, self.actor_pose.detach().float().contiguous(), async_op=True))
         self.num_collectives = len(self._gathers)
+
+    def _overflow_word(self, dev):
+        """The device word the row kernels raise on a dropped row: the caller's, or one of this exchange's own (the kernels never get a null)."""
+        if self.overflow is None:
+            self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        return self.overflow
+
+    def overflowed(self):
+        """True when a view held more visible Gaussians than `compact_capacity` rows (this step's gradients are incomplete on every rank: raise
+        the capacity, or run the next step with compact=False).  One device-to-host copy; False for the dense form."""
+        return self.overflow is not None and bool(int(self.overflow.reshape(-1)[0].item()) & 1)
+
+    def _slab_rows_allowed(self, rec):
+        """Whether the slab may travel as rows of the visible Gaussians (see the class docstring's precondition)."""
+        if _in_backward():
+            return slab_is_exclusive(rec)
+        if not (self.slab_pure and slab_holds_leaf_grads(rec)):
+            return False
+        if os.environ.get("EMD_DP_DEBUG", "") not in ("", "0"):
+            sl, N = rec.grad_slab, rec.grad_slab.numel() // 11
+            hidden = (rec.radii.reshape(-1) <= 0)
+            rows = torch.cat([sl[:3 * N].view(N, 3), sl[3 * N:6 * N].view(N, 3), sl[6 * N:10 * N].view(N, 4), sl[10 * N:].view(N, 1)], dim=1)
+            if bool((rows[hidden] != 0).any()):
+                raise RuntimeError("GradientExchange(slab_pure=True): the gradient slab holds non-zero rows on Gaussians this view does not see "
+                                   "(another loss term reaches the leaves): the compacted slab would drop them")
+        return True
 
     def _use_compact(self, W, N):
         if self.compact is False or self.compact_capacity is None:
@@ -281,7 +318,7 @@ class GradientExchange:
         W = world_size()
         if W == 1 and not force_exchange():
             return
-        if self._rows_f is not None and (slab_is_exclusive(rec) if _in_backward() else slab_holds_leaf_grads(rec)):
+        if self._rows_f is not None and self._slab_rows_allowed(rec):
             N = rec.grad_slab.numel() // 11
             sl = rec.grad_slab
             mine = compact_rows(rec.radii, [sl[:3 * N].view(N, 3), sl[3 * N:6 * N].view(N, 3), sl[6 * N:10 * N].view(N, 4), sl[10 * N:].view(N, 1)],
@@ -347,7 +384,7 @@ class GradientExchange:
                 g_all = torch.zeros(W, N, 3, device=g_local.device, dtype=torch.float32)
                 rf = self._rows_f.view(W, 1 + int(self.compact_capacity), 4)
                 for v in range(W):
-                    scatter_rows(rf[v], [g_all[v]], add=False, overflow=self.overflow)
+                    scatter_rows(rf[v], [g_all[v]], add=False, overflow=self._overflow_word(g_local.device))
             else:
                 g_all = self._g_cat.view(W, N, 3)
             campos = self._campos
@@ -372,7 +409,7 @@ class GradientExchange:
                 dests = [sl[:3 * Ns].view(Ns, 3), sl[3 * Ns:6 * Ns].view(Ns, 3), sl[6 * Ns:10 * Ns].view(Ns, 4), sl[10 * Ns:].view(Ns, 1)]
                 rs = self._rows_s.view(W, 1 + int(self.compact_capacity), 12)
                 for v in range(W):
-                    scatter_rows(rs[v], dests, add=True, scale=(1.0 / W) if self.average else 1.0, overflow=self.overflow)
+                    scatter_rows(rs[v], dests, add=True, scale=(1.0 / W) if self.average else 1.0, overflow=self._overflow_word(sl.device))
         for w in works:
             w.wait()
         if W > 1 or force_exchange():

@@ -350,7 +350,9 @@ def boundary_tensors(xyz, scaling, rotation, opacity, features, stage="coarse", 
                 shs=features)
 
 
-_l1_scratch = {}          # (device index, stream) -> the scratch table of emd_l1_loss_ws (zero between calls)
+# (device index, stream) -> the scratch table of emd_l1_loss_ws (zero between calls).  Tables live for the process: 4 KB each, and a hipGraph
+# captured with one has its ADDRESS baked in -- an evicted (freed) table would be written by every later replay.
+_l1_scratch = {}
 
 
 def _l1_call(n, a_ptr, b_ptr, loss, grad_ptr):
@@ -362,8 +364,6 @@ def _l1_call(n, a_ptr, b_ptr, loss, grad_ptr):
     key = (loss.device.index, st.cuda_stream)
     sc = _l1_scratch.get(key)
     if sc is None and not torch.cuda.is_current_stream_capturing():
-        while len(_l1_scratch) >= 16:
-            _l1_scratch.pop(next(iter(_l1_scratch)))
         sc = _l1_scratch[key] = torch.zeros(1024, dtype=torch.int32, device=loss.device)       # EMD_L1_SCRATCH_WORDS
     L.check(L.load().emd_l1_loss_ws(n, a_ptr, b_ptr, loss.data_ptr(), grad_ptr, L.ptr(sc), C.c_void_p(st.cuda_stream)), "emd_l1_loss")
 

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define EMD_ABI_VERSION 26
+#define EMD_ABI_VERSION 27
 
 /* tile geometry is part of the sort-key contract (tile_id << 32 | depth bits) */
 #define EMD_TILE_X 16
@@ -743,7 +743,9 @@ int emd_mlp_branch_backward(const EmdMlpBranch* args, const EmdMlpBranchGrads* g
  *   emd_densify_index   -> src[num_out], kind[num_out] (0 survivor, 1 clone, 2 / 3 split sample replica 0 / 1), in the
  *                          reference's output order: survivors, clones, replica 0, replica 1
  *   emd_densify_gather  -> every output tensor */
-enum { EMD_DENSIFY_MODE_DENSIFY = 0, EMD_DENSIFY_MODE_PRUNE = 1 };
+enum { EMD_DENSIFY_MODE_DENSIFY = 0, EMD_DENSIFY_MODE_PRUNE = 1,
+       EMD_DENSIFY_MODE_REFINE = 2   /* OmniRe's per-class refinement (VanillaGaussians.refinement_after, models/gaussians/vanilla.py:206-297): split (the original
+                                        STAYS, its log-scale reduced in place), duplicate and cull as ONE event -- see EmdRefineArgs below */ };
 enum {
     EMD_DENSIFY_ROLE_COPY = 0,     /* parameter copied row for row (features, opacity, rotation, embedding, deformation table ...) */
     EMD_DENSIFY_ROLE_XYZ = 1,      /* means: split samples get R(q) (exp(scaling) * n) + xyz, n ~ N(0, 1)   gaussian_model.py:541-545 */
@@ -783,6 +785,46 @@ typedef struct EmdDensifyGather {
     const int32_t* split_rank;     /* [num_out] rank of a split row inside its replica (emd_densify_split_rank); needed with `samples` */
     EmdDensifyTensor tensors[EMD_DENSIFY_MAX_TENSORS];
 } EmdDensifyGather;
+
+/* ---- OmniRe refinement: VanillaGaussians.refinement_after = split_gaussians + dup_gaussians + cull_gaussians, models/gaussians/vanilla.py:206-376,
+ * and dup_in_optim / remove_from_optim, models/gaussians/basics.py:198-242 -- fused into ONE decide -> scan -> index -> gather event.
+ * Semantics restated from the reference (they differ from S3Gaussian's in every step):
+ *   high   = xys_grad_norm / vis_counts > densify_grad_thresh                               (no NaN -> 0 step: NaN compares false)
+ *   split  = (max exp(scale) > size_thresh  [or max_2Dsize > split_screen while step < stop_screen_size_at]) and high
+ *            -> n_split_samples new rows  R(q^)(exp(scale) * n) + mean, n ~ N(0,1), scale log(exp(s) / 1.6); the ORIGINAL stays and takes the
+ *               same reduced scale in place (vanilla.py:345)
+ *   dup    = (max exp(scale) <= size_thresh) and high, evaluated AFTER the in-place reduction: a Gaussian just above the threshold is split
+ *            AND duplicated (its duplicate carries the reduced scale)                        (vanilla.py:240-254)
+ *   cull   = on every row of the grown arrays: sigmoid(opacity) < cull_alpha, or -- past the first opacity reset -- max exp(scale) > cull_size,
+ *            or (while step < stop_screen_size_at) max_2Dsize > cull_screen, new rows carrying max_2Dsize 0       (vanilla.py:299-326)
+ *   output order: surviving originals, split samples replica 0, replica 1, ..., duplicates (vanilla.py:256-263); Adam moments of new rows zero.
+ * Thresholds are the host's products (size_thresh = densify_size_thresh * scene_scale ...) rounded to float once, as torch rounds a Python scalar.
+ * Sequence: emd_refine_decide -> code[N], columns[4][N] (original kept, duplicate kept, samples kept, source is split) -> inclusive prefix sums by the
+ * caller (one host read: num_out = keep + num_samples * samples + dup) -> emd_refine_index -> emd_densify_gather with mode EMD_DENSIFY_MODE_REFINE. */
+typedef struct EmdRefineArgs {
+    int32_t num_points;
+    int32_t do_densify;            /* split / duplicate this event (step < stop_split_at and past the opacity-reset guard, vanilla.py:213-216) */
+    int32_t do_cull;               /* cull this event (vanilla.py:281) */
+    int32_t use_split_screen;      /* step < stop_screen_size_at: the screen-size split test is on */
+    int32_t cull_big;              /* step > reset_alpha_interval: the world-size (and screen-size) cull tests are on */
+    int32_t use_cull_screen;       /* ... and step < stop_screen_size_at */
+    const float* scaling;          /* [N,3] log-scales */
+    const float* opacity;          /* [N] logits */
+    const float* grad_norm;        /* [N] xys_grad_norm */
+    const float* vis_counts;       /* [N] */
+    const float* max_2Dsize;       /* [N] */
+    float grad_threshold, size_threshold, split_screen, cull_alpha, cull_size, cull_screen;
+} EmdRefineArgs;
+int emd_refine_decide(const EmdRefineArgs* args, int32_t* code /*[N]*/, int32_t* columns /*[4,N]*/, void* hip_stream);
+/* kind[j]: 0 original, 1 duplicate, 2 + r split sample of replica r; + 16 when the source row was split (its scale is reduced wherever it is
+ * copied); split_rank[j]: rank of a sample's source among ALL split sources (the row of a caller-supplied normal draw [num_samples, n_split, 3]) */
+int emd_refine_index(int32_t num_points, int32_t num_out, int32_t num_samples, const int32_t* code, const int32_t* inclusive_scans /*[4,N]*/,
+                     int32_t* src, int32_t* kind, int32_t* split_rank, void* hip_stream);
+
+/* OmniRe's running refinement statistics of one view (VanillaGaussians.after_train, models/gaussians/vanilla.py:163-191), one launch: where radii > 0
+ * grad_norm += |xys_grad| (2 components, row stride `grad_stride` floats), vis_counts += 1, max_2Dsize = max(max_2Dsize, radii / last_size). */
+int emd_after_train_stats(int32_t n, const int32_t* radii, const float* xys_grad, int32_t grad_stride, float* grad_norm, float* vis_counts,
+                          float* max_2Dsize, float last_size, void* hip_stream);
 
 int emd_densify_decide(const EmdDensifyArgs* args, int32_t* code /*[N]*/, int32_t* columns /*[3,N]*/, void* hip_stream);
 int emd_densify_index(int32_t num_points, int32_t num_out, const int32_t* code, const int32_t* inclusive_scans /*[3,N]*/, int32_t* src,

@@ -39,6 +39,9 @@ Fixtures (all fp32):
   or_nodes.npz      RigidNodes.get_gaussians and DeformableNodes.get_gaussians (+ gradients), with a recording stand-in for the absent gsplat
                     spherical_harmonics             OmniRe/models/nodes/rigid.py:570-615, models/nodes/deformable.py:49-114
   or_envlight.npz   EnvLight.forward with the same stand-in                OmniRe/models/modules.py:174-208
+  or_refine.npz     VanillaGaussians.after_train (running refinement statistics over several views) and refinement_after (split + duplicate + cull
+                    with the torch.randn draw recorded, cull only, opacity reset) with a torch.optim.Adam whose moments are non-trivial: parameters,
+                    both moments and the statistics after every call      OmniRe/models/gaussians/vanilla.py:150-376, models/gaussians/basics.py:198-242
   or_rigid.npz      RigidNodes.transform_means / transform_quats / opacity mask (+ gradients), train and
                     test-interpolation branches, non-zero track heads  OmniRe/models/nodes/rigid.py:42-46,150-246,478-615
 """
@@ -969,6 +972,119 @@ def gen_omnire():
     unload(["models", "utils", "datasets"])
 
 
+def gen_or_refine():
+    """OmniRe's per-class density control on CPU: VanillaGaussians.after_train over views with partial visibility, then refinement_after at four
+    steps that exercise every branch -- 3600: split (size and screen-size tests) + duplicate + cull (alpha, world size, screen size); 700: split +
+    duplicate + cull by alpha only (before the first opacity reset); 3100: the opacity reset alone (inside the guard behind a reset); 16000: cull
+    only (past stop_split_at, screen tests off).  The optimiser is the one the trainer builds (torch.optim.Adam, eps 1e-15, class-prefixed group
+    names) after two steps on seeded gradients, so the moments that dup_in_optim / remove_from_optim move are non-trivial."""
+    sys.path.insert(0, os.path.join(REF, "OmniRe"))
+    import pytorch3d.transforms as p3t
+    p3t.matrix_to_quaternion = lambda M: _matrix_to_quaternion(M).reshape(*M.shape[:-2], 4)
+    with _CpuMode():
+        from models.gaussians import basics
+        basics.matrix_to_quaternion = p3t.matrix_to_quaternion
+        from models.gaussians.vanilla import VanillaGaussians
+        cfg = dict(sh_degree=1, warmup_steps=500, reset_alpha_interval=3000, refine_interval=100, sh_degree_interval=1000, n_split_samples=2,
+                   reset_alpha_value=0.01, densify_grad_thresh=0.0003, densify_size_thresh=0.003, cull_alpha_thresh=0.005, cull_scale_thresh=0.5,
+                   cull_screen_size=0.15, split_screen_size=0.05, stop_screen_size_at=4000, stop_split_at=15000)
+        ctrl = _Cfg(cfg)
+        ctrl.get = lambda k, d=None: dict.get(ctrl, k, d)
+        scene_scale, n_images, last_size = 2.0, 10, 1600
+        node = VanillaGaussians(class_name="Background", ctrl=ctrl, reg=_Cfg(), networks=_Cfg(), scene_scale=scene_scale, scene_origin=torch.zeros(3),
+                                num_train_images=n_images, device=torch.device("cpu"))
+        g = torch.Generator().manual_seed(1300)
+        N = 160          # (SH degree 1 keeps the fixture small: the row width is generic in the gather, 45-wide rows are pinned by s3g_surgery.npz)
+        P = torch.nn.Parameter
+        node._means = P(torch.randn(N, 3, generator=g) * 4)
+        # log-uniform scales from 1e-3 to 3: below / just above (split AND duplicated) / far above the size threshold 0.006, some above the cull size 1.0
+        node._scales = P(torch.log(torch.tensor(1e-3)) + torch.rand(N, 3, generator=g) * (torch.log(torch.tensor(3.0)) - torch.log(torch.tensor(1e-3))))
+        node._scales.data[: N // 3] -= 1.5
+        node._quats = P(torch.randn(N, 4, generator=g))
+        node._opacities = P(torch.randn(N, 1, generator=g) * 3.0 - 1.0)
+        node._features_dc = P(torch.randn(N, 3, generator=g))
+        node._features_rest = P(torch.randn(N, 3, 3, generator=g) * 0.1)
+        names = ("xyz", "sh_dc", "sh_rest", "opacity", "scaling", "rotation")
+        attr = dict(xyz="_means", sh_dc="_features_dc", sh_rest="_features_rest", opacity="_opacities", scaling="_scales", rotation="_quats")
+        lrs = dict(xyz=1.6e-4, sh_dc=2.5e-3, sh_rest=1.25e-4, opacity=0.05, scaling=5e-3, rotation=1e-3)
+        opt = torch.optim.Adam([{"params": v, "lr": lrs[k.split("#")[1]], "name": k} for k, v in node.get_gaussian_param_groups().items()], lr=0.0, eps=1e-15)
+        for it in range(2):
+            for n_ in names:
+                p = getattr(node, attr[n_])
+                p.grad = torch.randn(p.shape, generator=g) * 1e-2
+            opt.step()
+        out = dict(scene_scale=scene_scale, num_train_images=n_images, last_size=last_size, class_name=np.array("Background"),
+                   cfg_keys=np.array(list(cfg)), cfg_values=np.array([float(v) for v in cfg.values()]), group_names=np.array([g_["name"] for g_ in opt.param_groups]))
+
+        def state_of(n_):
+            for grp in opt.param_groups:
+                if grp["name"] == "Background#" + n_:
+                    return opt.state[grp["params"][0]]
+
+        def snap(tag):
+            for n_ in names:
+                out[f"{tag}_{n_}"] = getattr(node, attr[n_]).detach().clone()
+                st = state_of(n_)
+                out[f"{tag}_m_{n_}"], out[f"{tag}_v_{n_}"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+
+        def views(tag, count):
+            """`count` calls of after_train with seeded radii (a third invisible) and gradients; inputs and the statistics after each call"""
+            n = node.num_points
+            node.filter_mask = torch.ones_like(node._means[:, 0], dtype=torch.bool)          # what get_gaussians leaves behind every step (vanilla.py:379-380)
+            for v in range(count):
+                radii = torch.randint(0, 400, (n,), generator=g, dtype=torch.int32)
+                radii[torch.rand(n, generator=g) < 0.35] = 0
+                grad = (torch.rand(n, 2, generator=g) - 0.5) * 0.9e-3
+                grad[radii == 0] = 0.0
+                node.after_train(radii, grad, last_size)
+                out[f"{tag}_radii{v}"], out[f"{tag}_grad{v}"] = radii.clone(), grad.clone()
+                out[f"{tag}_norm{v}"], out[f"{tag}_vis{v}"], out[f"{tag}_m2d{v}"] = node.xys_grad_norm.clone(), node.vis_counts.clone(), node.max_2Dsize.clone()
+
+        real_randn = torch.randn
+
+        def refine(tag, step):
+            rec = {}
+
+            def recording_randn(size, **kw):
+                z = real_randn(tuple(size), generator=g)
+                rec["z"] = z.clone()
+                return z
+            node.step = step
+            torch.randn = recording_randn
+            try:
+                node.refinement_after(step, opt)
+            finally:
+                torch.randn = real_randn
+            out[f"{tag}_step"] = step
+            out[f"{tag}_randn"] = rec.get("z", torch.zeros(0, 3))
+            snap(tag)
+
+        snap("in")
+        views("a", 3)
+        refine("A", 3600)
+
+        def drift(tag, faint, huge):
+            """what training between two events does to a few rows: some fade below the cull threshold, some grow past the world-size limit"""
+            n = node.num_points
+            i_f = torch.randperm(n, generator=g)[:faint]
+            i_h = torch.randperm(n, generator=g)[:huge]
+            node._opacities.data[i_f] = -6.0 - torch.rand(faint, 1, generator=g)
+            node._scales.data[i_h] = torch.log(torch.tensor(1.0)) + torch.rand(huge, 3, generator=g)
+            out[f"{tag}_faint_rows"], out[f"{tag}_huge_rows"] = i_f.to(torch.int32), i_h.to(torch.int32)
+            out[f"{tag}_opacity_in"], out[f"{tag}_scaling_in"] = node._opacities.detach().clone(), node._scales.detach().clone()
+        drift("B", 25, 10)
+        views("b", 2)
+        refine("B", 700)
+        views("c", 1)
+        refine("C", 3100)
+        drift("D", 30, 20)
+        views("d", 2)
+        refine("D", 16000)
+        save("or_refine.npz", **out)
+    sys.path.pop(0)
+    unload(["models", "utils", "datasets"])
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
     install_shims()
@@ -988,3 +1104,4 @@ if __name__ == "__main__":
     gen_or_envlight()
     gen_or_deform()
     gen_or_nodes()
+    gen_or_refine()

@@ -38,11 +38,12 @@ def test_struct_layout_matches_c():
     prog = r'''
 #include <stdio.h>
 #include "emd_raster.h"
-int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(EmdSettings), sizeof(EmdMotion), sizeof(EmdDims),
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(EmdSettings), sizeof(EmdMotion), sizeof(EmdDims),
  sizeof(EmdFwdArgs), sizeof(EmdBwdArgs), sizeof(EmdStatus), sizeof(EmdSkyArgs), sizeof(EmdSkyBwdArgs), sizeof(EmdLossArgs),
  sizeof(EmdHexArgs), sizeof(EmdHexGrads), sizeof(EmdDeformInArgs), sizeof(EmdAdamTensor), sizeof(EmdAdamArgs),
  sizeof(EmdTrackArgs), sizeof(EmdTrackGrads), sizeof(EmdTrackedPoseArgs), sizeof(EmdTrackedPoseGrads), sizeof(EmdStepSelect),
- sizeof(EmdMlpTrunk), sizeof(EmdMlpTrunkGrads), sizeof(EmdMlpBranch), sizeof(EmdMlpBranchGrads));return 0;}
+ sizeof(EmdMlpTrunk), sizeof(EmdMlpTrunkGrads), sizeof(EmdMlpBranch), sizeof(EmdMlpBranchGrads),
+ sizeof(EmdRefineArgs), sizeof(EmdDensifyArgs), sizeof(EmdDensifyGather));return 0;}
 '''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
@@ -57,7 +58,8 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %
                          C.sizeof(L.EmdHexGrads), C.sizeof(L.EmdDeformInArgs), C.sizeof(L.EmdAdamTensor), C.sizeof(L.EmdAdamArgs),
                          C.sizeof(L.EmdTrackArgs), C.sizeof(L.EmdTrackGrads), C.sizeof(L.EmdTrackedPoseArgs),
                          C.sizeof(L.EmdTrackedPoseGrads), C.sizeof(L.EmdStepSelect),
-                         C.sizeof(L.EmdMlpTrunk), C.sizeof(L.EmdMlpTrunkGrads), C.sizeof(L.EmdMlpBranch), C.sizeof(L.EmdMlpBranchGrads)]
+                         C.sizeof(L.EmdMlpTrunk), C.sizeof(L.EmdMlpTrunkGrads), C.sizeof(L.EmdMlpBranch), C.sizeof(L.EmdMlpBranchGrads),
+                         C.sizeof(L.EmdRefineArgs), C.sizeof(L.EmdDensifyArgs), C.sizeof(L.EmdDensifyGather)]
 
 
 def test_workspace_size_host_only():
