@@ -30,19 +30,19 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-PMC_STAGE_KERNELS = {"preprocess": ("k_preprocess",), "scan_duplicate": ("k_sorted_counts", "k_scan_publish", "k_duplicate"),
+PMC_STAGE_KERNELS = {"preprocess": ("k_preprocess",), "scan_duplicate": ("k_sorted_counts", "k_duplicate"),
                      "radix_sort": ("k_radix_hist[N]", "k_radix_scatter[N]", "k_radix_scan_bins[N]", "k_radix_hist[D]",
                                     "k_radix_scatter[D]"),
-                     "tile_ranges": ("k_tile_ranges",), "render_forward": ("k_render_forward_q",),
+                     "tile_ranges": ("k_tile_ranges", "k_tile_order"), "render_forward": ("k_render_forward_q",),
                      "render_backward": ("k_render_backward_q",), "preprocess_backward": ("k_preprocess_backward",)}
 
 
-PMC_TRAFFIC_CSV = "r05_pmc_hbm_traffic.csv"
-PMC_VALU_CSV = "r05_pmc_valu.csv"
+PMC_TRAFFIC_CSV = "r06_pmc_hbm_traffic.csv"
+PMC_VALU_CSV = "r06_pmc_valu.csv"
 
 
 def _pmc_path(name):
-    for cand in (name, name.replace("r05_", "r04_"), name.replace("r05_", "r03_"), name.replace("r05_", "r02_")):
+    for cand in (name, name.replace("r06_", "r05_"), name.replace("r06_", "r04_"), name.replace("r06_", "r03_"), name.replace("r06_", "r02_")):
         path = os.path.join(ROOT, "profiles", cand)
         if os.path.exists(path):
             return path
@@ -72,6 +72,29 @@ def pmc_traffic(stage, passes):
     return tot or None
 
 
+ISA_MIX_TXT = "r06_render_isa_mix.txt"
+
+
+def load_isa_mix():
+    """{kernel: {valu, plain, pk, dpp, trans, wide_fraction, ns_per_valu, loop}} of each render kernel's hottest loop, from the committed disassembly summary
+    (profiles/make_isa_mix.py -> profiles/r06_render_isa_mix.txt, its `MIX` lines).  Empty when the file is missing."""
+    path = os.path.join(ROOT, "profiles", ISA_MIX_TXT)
+    mix = {}
+    if os.path.exists(path):
+        for line in open(path):
+            if line.startswith("MIX "):
+                f = line.split()
+                d = {}
+                for kv in f[2:]:
+                    k, v = kv.split("=", 1)
+                    try:
+                        d[k] = float(v)
+                    except ValueError:
+                        d[k] = v
+                mix[f[1]] = d
+    return mix
+
+
 def issue_bound(stage, avg_ms):
     """Secondary bound of the render kernels: the fraction of the MEASURED vector-issue capacity the stage's dominant kernel uses.
     Instruction counts per launch come from the committed counter summary (rocprofv3 --pmc SQ_INSTS_VALU ..., static, like
@@ -79,12 +102,12 @@ def issue_bound(stage, avg_ms):
     (profiles/r02_issue_rate_microbench.txt): a plain fp32 VALU instruction occupies its SIMD for 1.32 ns with 8 waves resident
     (2.35 cycles at the 1.78 GHz the chip holds under that load -- not the 0.83 ns of "2 cycles at 2.4 GHz"), v_pk_* / DPP /
     v_readlane 2.0 ns, transcendentals 3.4 ns.  Counters do not split the classes, so two fractions are given: every instruction
-    priced as a plain one (lower bound of the utilisation) and priced with the kernel's static instruction mix (from the ISA of
-    its inner loop)."""
+    priced as a plain one (lower bound of the utilisation) and priced with the instruction mix of the kernel's hottest loop, counted in the
+    disassembly of the shipped build (profiles/make_isa_mix.py -> profiles/r06_render_isa_mix.txt; no literal in this file)."""
     path = _pmc_path(PMC_VALU_CSV)
     if path is None:
         return None
-    mix = {"k_render_backward_q": 0.55, "k_render_forward_q": 0.12}          # fraction of 2-slot instructions (pk / DPP / readlane) in the inner loop
+    mix = load_isa_mix()
     names = PMC_STAGE_KERNELS.get(stage, ())
     for line in open(path):
         if line.startswith("#") or line.startswith("kernel,"):
@@ -92,14 +115,17 @@ def issue_bound(stage, avg_ms):
         f = line.rstrip("\n").split(",")
         if f[0] in names:
             n = float(f[2])
-            plain_ns, wide_ns = 1.32, 2.0
+            plain_ns = 1.32
             lo = n * plain_ns / 1024.0 * 1e-6 / avg_ms
-            w = mix.get(f[0], 0.0)
-            hi = n * ((1 - w) * plain_ns + w * wide_ns) / 1024.0 * 1e-6 / avg_ms
+            m = mix.get(f[0])
+            mixed_ns = float(m["ns_per_valu"]) if m else plain_ns
+            hi = n * mixed_ns / 1024.0 * 1e-6 / avg_ms
             return {"kernel": f[0], "SQ_INSTS_VALU_per_launch": n, "static": True, "source": "profiles/" + os.path.basename(path),
                     "ceiling_source": "profiles/r02_issue_rate_microbench.txt", "ns_per_plain_valu_per_simd": plain_ns,
-                    "ns_per_pk_dpp_valu_per_simd": wide_ns, "issue_utilisation_all_plain": round(lo, 3),
-                    "issue_utilisation_with_mix": round(hi, 3), "wide_instruction_fraction": w}
+                    "ns_per_valu_with_mix": round(mixed_ns, 4), "issue_utilisation_all_plain": round(lo, 3),
+                    "issue_utilisation_with_mix": round(hi, 3), "wide_instruction_fraction": None if not m else m["wide_fraction"],
+                    "mix_source": None if not m else f"profiles/{ISA_MIX_TXT} (loop {m.get('loop')}: {int(m['plain'])} plain, {int(m['pk'])} v_pk_*, "
+                                                     f"{int(m['dpp'])} DPP / cross-lane, {int(m['trans'])} transcendental of {int(m['valu'])} vector instructions)"}
     return None
 
 
@@ -237,6 +263,8 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--repeats", type=int, default=5, help="extra back-to-back repeats of the timed block after it (min / median / max reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fine-stage", action="store_true", help="skip the `fine_stage` block (the S3G fine-stage step at the headline size, measured after the timed "
+                    "region and outside `value`; 1 GPU, headline configuration only; ~10 s)")
     ap.add_argument("--sync-count", action="store_true", help="read the duplicate count back every forward (reference behaviour)")
     ap.add_argument("--no-normal", action="store_true", help="skip the normal image (unused by the training loss)")
     ap.add_argument("--factored-sh", action="store_true", help="use the multi-GPU SH-gradient factor exchange at any world size (1 GPU: measures its local cost)")
@@ -332,7 +360,7 @@ def main():
             cap = X["cap_by_row"][step if step < per else args.warmup + (step - args.warmup) % max(args.steps, 1)]
         # slab_pure: this step's loss reaches the four small per-Gaussian tensors through the rasterizer alone (L1 on the image, no regulariser),
         # so the slab of a REPLAYED step may travel as rows of the visible Gaussians too (dp.GradientExchange's precondition)
-        return dict(compact=X["compact"], compact_capacity=cap, overflow=X["overflow"], slab_pure=True)
+        return dict(compact=X["compact"], compact_capacity=cap, overflow=X["overflow"], slab_pure=True, timing=X.get("timing", False))
 
     def cam_for(step):
         # views are ordered timestamp-major and dealt out by dp.view_for: every rank renders a DISTINCT (frame, camera);
@@ -443,10 +471,22 @@ def main():
     th = model.track_heads
     k_sched = (th.min_embeddings, th.max_embeddings, th.c2f_temporal_iter) if th is not None else None
 
-    def record_step():
+    def settle_replays(replay):
+        """replay the step (untimed) until the clocks have settled: the GPU has idled through set-up, capture and host-side checks (measured: with
+        --steps 20 --warmup 5 the first timed block was 2.4 % slower than its back-to-back repeats)"""
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            for _ in range(8):
+                replay()
+                settle["replays"] += 1
+            torch.cuda.synchronize()
+
+    def record_step(light=False):
         """Capture the step for the CURRENT parameter tensors (S) as one hipGraph (or two, cut inside backward()); returns the state a replay
         needs, or None when the capture failed (the step is then issued from Python).  Called again after a density-control event: the point
-        count, every parameter tensor and the workspaces behind them have changed."""
+        count, every parameter tensor and the workspaces behind them have changed.  `light` (the re-capture behind an event, which a training
+        loop pays every 100 iterations): ONE eager step on the capture stream instead of three (it forms the per-stream workspaces for the new
+        point count), no self-check against an eager step and no settle phase -- the caller settles, outside of what it reports as re-record time."""
         G = types.SimpleNamespace(graph=None, graph_b=None, gstate={}, two_graphs=False)
         params = S["params"]
         G.sel = sel = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -482,7 +522,7 @@ def main():
             side = torch.cuda.Stream(priority=-1 if os.environ.get("EMD_BENCH_HIPRIO") else 0)      # (A/B knob: the captured chain above a forked branch)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for i_ in range(3):
+                for i_ in range(1 if light else 3):
                     sel.fill_(i_)
                     graph_body()
             torch.cuda.current_stream().wait_stream(side)
@@ -532,6 +572,11 @@ def main():
                 graph.replay()
                 if graph_b is not None:
                     graph_b.replay()
+            G.replay_compute = replay_compute
+            if light:
+                sel.fill_(0)
+                prev_sel.fill_(-1)
+                return G
             # ---- self-check of the captured graph before it is trusted with the timed region: two replays of row 0 must reproduce the
             # eager step's device status words (D, V) and leave finite, identical parameter gradients (a memset node captured on ROCm 7.2
             # replayed with a corrupt fill pattern from the SECOND replay on: that is how the library's zero fills became kernels)
@@ -554,15 +599,8 @@ def main():
                     raise RuntimeError(f"replay {rep_}: non-finite parameter gradients")
                 if world == 1 and float((g_ - want_grad).abs().max()) > 1e-4 * float(want_grad.abs().max()) + 1e-12:      # (N > 1: the eager step averaged over ranks)
                     raise RuntimeError(f"replay {rep_}: parameter gradients differ from the eager step's")
-            # ---- settle: the GPU has idled through set-up, capture and the host-side checks above; replay the step (untimed, rows walk
-            # on from row 1) until the clocks have settled, so that the warm-up steps and the timed region run at the rate a training
-            # run sees (measured: with --steps 20 --warmup 5 the first timed block was 2.4 % slower than its back-to-back repeats)
-            t_settle = time.perf_counter()
-            while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
-                for _ in range(8):
-                    replay_compute()
-                    settle["replays"] += 1
-                torch.cuda.synchronize()
+            # ---- settle (untimed replays, rows walk on from row 1), so that the warm-up steps and the timed region run at the rate a training run sees
+            settle_replays(replay_compute)
             if keep_stats is not None:                        # the checks and the settle phase are not training steps: their statistics do not count
                 for t_, k_ in zip(S["stats"], keep_stats):
                     t_.copy_(k_)
@@ -604,6 +642,8 @@ def main():
                     G.graph_b.replay()
                 xchg.start(gs["rec"])
                 xchg.finish(model._features, model._xyz, model.active_sh_degree, other_params=S["params"])
+                if X.get("timing"):
+                    X["timed"].append(xchg)
             elif world > 1:
                 dp.allreduce_gradients(S["params"])
         else:
@@ -637,7 +677,19 @@ def main():
         torch.cuda.synchronize()
         _lib.profile_enable(True)
         _lib.profile_read()
+    # N > 1 (or the forced one-rank exchange): HIP events around the phases of every timed step's exchange, read after the timed region
+    X["timing"], X["timed"] = bool(G is not None and opts.factored_sh_grad and (world > 1 or dp.force_exchange())), []
     dt, t_enqueue, dt_own = timed_block(args.warmup, args.steps)
+    exchange_times = None
+    if X["timed"]:
+        rows_t = [x_.times_ms() for x_ in X["timed"]]
+        mean = lambda k: (lambda v: None if not v else round(sum(v) / len(v), 4))([r_[k] for r_ in rows_t if r_[k] is not None])
+        exchange_times = {k: mean(k) for k in ("exposed_ms", "slab_ms", "gather_ms", "rebuild_ms")}
+        exchange_times["steps"] = len(rows_t)
+        exchange_times["note"] = ("HIP events on the stream the exchange is issued from, means over the timed steps of rank 0: exposed = end of this rank's backward "
+                                  "kernels -> end of the exchange (what the step pays for communicating); slab / gather = issue -> completion of the slab all-reduce "
+                                  "(behind K8) and of the factor gathers (issued between K7 and K8: they travel under K8); rebuild = the local dL/dshs rebuild")
+    X["timing"], X["timed"] = False, []
     prof_timed = None
     if G is None:
         prof_timed = _lib.profile_read()
@@ -693,56 +745,85 @@ def main():
             G_.gstate.clear()
     release_graphs(G)
 
-    # ---- config 4: ONE density-control event behind the timed steps, timed on its own, then the loop goes on with the new point count
+    # ---- config 4: density-control events behind the timed steps, timed on their own; the loop goes on with the new point count.  TWO events: the
+    # first pays what a process pays once (the first allocations of the grown tensors, the first launch of every kernel of the event), the second
+    # is what a training loop pays every `densification_interval` = 100 iterations (S3Gaussian/arguments/gaussian_options.py:112-117) -- that one
+    # is `event_ms` / `re_record_ms`.  Between them the timed views run again and accumulate the statistics the second event decides on.
     density_event = None
     if cfg.get("densify"):
         from emd_amd.model import density_control
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dp.reduce_densification_stats(*S["stats"])          # every rank then holds the statistics of all views of all ranks (SUM, SUM, MAX)
-        thr = args.densify_grad_threshold
-        if thr is None:
-            # (the synthetic scene's gradients have nothing of a real scene's scale: the reference's 2e-4 would select nothing or everything.
-            #  The threshold is the 95 % quantile of the mean view-space gradient over the Gaussians seen at least once -- computed from the REDUCED
-            #  statistics, hence identical on every rank)
-            seen = S["stats"][1].reshape(-1) > 0
-            avg = (S["stats"][0].reshape(-1) / S["stats"][1].reshape(-1).clamp_min(1.0))[seen]
-            thr = float(torch.quantile(avg[:: max(avg.numel() // 1_000_000, 1)], 0.95)) if avg.numel() else 2e-4
-        ev = density_control(model, *S["stats"], max_grad=thr, min_opacity=0.005, extent=27.5, percent_dense=0.01, seed=0, event=0)
-        N2 = ev["n_after"]
-        S["params"] = [p for p in model.parameters()]
-        S["stats"] = [torch.zeros(N2, 1, device=dev), torch.zeros(N2, 1, device=dev), torch.zeros(N2, device=dev)]
-        S["N"] = N2
-        torch.cuda.synchronize()
-        t_event = time.perf_counter() - t0
-        if world > 1:          # replicas must agree on the new point count before the next collective
-            n_all = torch.tensor([N2], device=dev, dtype=torch.int64)
-            n_max, n_min = n_all.clone(), n_all.clone()
-            torch.distributed.all_reduce(n_max, op=torch.distributed.ReduceOp.MAX)
-            torch.distributed.all_reduce(n_min, op=torch.distributed.ReduceOp.MIN)
-            assert int(n_max) == int(n_min) == N2, f"ranks disagree on the point count after density control: {int(n_min)}..{int(n_max)}"
-        opts.capacity_hint = int(opts.capacity_hint * (1.0 + 1.5 * max(N2 - N, 0) / N)) + 1024
-        gc.collect()
-        t0 = time.perf_counter()
-        G = record_step() if (not args.eager and opts.no_sync) else None
-        torch.cuda.synchronize()
-        t_record = time.perf_counter() - t0
-        for s in range(args.warmup):
-            timed_step(s)
-        dt2, _, _ = timed_block(args.warmup, args.steps)
-        flush_status_log()
-        st2 = status_log[args.warmup:args.warmup + args.steps].cpu().numpy().astype("int64") & 0xFFFFFFFF
-        release_graphs(G)
-        if world > 1:
-            t2 = torch.tensor([dt2, t_event], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t2, op=torch.distributed.ReduceOp.MAX)
-            dt2, t_event = [float(v) for v in t2.tolist()]
-        density_event = dict(ev, grad_threshold=thr, event_ms=round(t_event * 1e3, 3), re_record_ms=round(t_record * 1e3, 1),
-                             ms_per_step_after=round(dt2 / args.steps * 1e3, 4), iters_per_s_after=round(world * args.steps / dt2, 2),
-                             overflow_after=int((st2[:, 1] & 1).sum()), D_mean_after=round(float(st2[:, 0].mean()), 1),
-                             note="one event behind the timed steps (statistics reduced over ranks -> clone / split / prune of the background Gaussians -> "
-                                  "fresh statistics), then the step recorded again for the new point count and the same views timed again; `value` "
-                                  "is the block BEFORE the event")
+        events = []
+        for ev_i in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dp.reduce_densification_stats(*S["stats"])          # every rank then holds the statistics of all views of all ranks (SUM, SUM, MAX)
+            thr = args.densify_grad_threshold
+            if thr is None:
+                # (the synthetic scene's gradients have nothing of a real scene's scale: the reference's 2e-4 would select nothing or everything.
+                #  The threshold is the 95 % quantile of the mean view-space gradient over the Gaussians seen at least once -- computed from the REDUCED
+                #  statistics, hence identical on every rank.  A real loop has a constant here: the quantile is timed separately.)
+                seen = S["stats"][1].reshape(-1) > 0
+                avg = (S["stats"][0].reshape(-1) / S["stats"][1].reshape(-1).clamp_min(1.0))[seen]
+                thr = float(torch.quantile(avg[:: max(avg.numel() // 1_000_000, 1)], 0.95)) if avg.numel() else 2e-4
+            torch.cuda.synchronize()
+            t_thr = time.perf_counter() - t0
+            N_before = S["N"]
+            ev = density_control(model, *S["stats"], max_grad=thr, min_opacity=0.005, extent=27.5, percent_dense=0.01, seed=0, event=ev_i)
+            N2 = ev["n_after"]
+            S["params"] = [p for p in model.parameters()]
+            S["stats"] = [torch.zeros(N2, 1, device=dev), torch.zeros(N2, 1, device=dev), torch.zeros(N2, device=dev)]
+            S["N"] = N2
+            torch.cuda.synchronize()
+            t_event = time.perf_counter() - t0 - t_thr
+            if world > 1:          # replicas must agree on the new point count before the next collective
+                n_all = torch.tensor([N2], device=dev, dtype=torch.int64)
+                n_max, n_min = n_all.clone(), n_all.clone()
+                torch.distributed.all_reduce(n_max, op=torch.distributed.ReduceOp.MAX)
+                torch.distributed.all_reduce(n_min, op=torch.distributed.ReduceOp.MIN)
+                assert int(n_max) == int(n_min) == N2, f"ranks disagree on the point count after density control: {int(n_min)}..{int(n_max)}"
+            opts.capacity_hint = int(opts.capacity_hint * (1.0 + 1.5 * max(N2 - N_before, 0) / N_before)) + 1024
+            # the visible counts grow with the point count: so do the row capacities of the compacted exchange (host numbers, like the binning capacity;
+            # an overflow would be reported by the assert on X["overflow"] below, never accepted silently)
+            # (the new points are clones / samples of Gaussians that WERE seen: every one of them may be visible in every view)
+            more = int(1.1 * max(N2 - N_before, 0)) + 1
+            if X["cap"] is not None:
+                X["cap"] = min(dp.visible_capacity(X["cap"] + more, margin=1.0), dp.visible_capacity(N2, margin=1.0))
+            if X["cap_by_row"] is not None:
+                X["cap_by_row"] = [min(dp.visible_capacity(c_ + more, margin=1.0), dp.visible_capacity(N2, margin=1.0)) for c_ in X["cap_by_row"]]
+            gc.collect()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            G = record_step(light=True) if (not args.eager and opts.no_sync) else None
+            torch.cuda.synchronize()
+            t_record = time.perf_counter() - t0
+            if G is not None:
+                keep_stats = [t.clone() for t in S["stats"]]
+                settle_replays(G.replay_compute)                 # (untimed, and not part of the re-record time)
+                for t_, k_ in zip(S["stats"], keep_stats):
+                    t_.copy_(k_)
+                G.sel.fill_(0)
+                G.prev_sel.fill_(-1)
+                torch.cuda.synchronize()
+            for s in range(args.warmup):
+                timed_step(s)
+            dt2, _, _ = timed_block(args.warmup, args.steps)
+            flush_status_log()
+            st2 = status_log[args.warmup:args.warmup + args.steps].cpu().numpy().astype("int64") & 0xFFFFFFFF
+            release_graphs(G)
+            if world > 1:
+                t2 = torch.tensor([dt2, t_event, t_record], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t2, op=torch.distributed.ReduceOp.MAX)
+                dt2, t_event, t_record = [float(v) for v in t2.tolist()]
+            events.append(dict(ev, grad_threshold=thr, event_ms=round(t_event * 1e3, 3), threshold_quantile_ms=round(t_thr * 1e3, 3),
+                               re_record_ms=round(t_record * 1e3, 2), ms_per_step_after=round(dt2 / args.steps * 1e3, 4),
+                               iters_per_s_after=round(world * args.steps / dt2, 2), overflow_after=int((st2[:, 1] & 1).sum()),
+                               D_mean_after=round(float(st2[:, 0].mean()), 1)))
+        density_event = dict(events[1], first_event=events[0],
+                             note="two events behind the timed steps (statistics reduced over ranks -> clone / split / prune of the background Gaussians -> fresh "
+                                  "statistics), each followed by ONE re-capture of the step for the new point count (one eager step + the capture; no self-check, "
+                                  "the settle replays are not counted) and the same views timed again; the top-level fields are the SECOND event -- what a loop "
+                                  "pays every 100 iterations --, `first_event` carries the process's one-off costs (first allocations, first kernel loads); "
+                                  "`value` is the block BEFORE the events")
     own = [dt_own / args.steps * 1e3]
     if world > 1:
         tmax = torch.tensor([dt] + [r_ * args.steps / 1e3 for r_ in rep], device=dev, dtype=torch.float64)
@@ -862,8 +943,21 @@ def main():
                        "exchange_rows_per_view": int(X.get("mean_cap") or 0) if X.get("uses_rows") else None},
             "roofline": roofline,
         }
+        if exchange_times is not None:
+            res["exchange"] = exchange_times
         if density_event is not None:
             res["density_control_event"] = density_event
+        if world == 1 and full and not args.no_fine_stage:
+            # the step S3Gaussian runs for 50 000 of its 55 000 iterations (deformation network in front of the rasterizer, full loss, sky): measured
+            # AFTER the timed region and reported beside it -- `value` stays BASELINE.json's metric (profiles/fine_stage.py)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "profiles"))
+                import fine_stage
+                gc.collect()
+                torch.cuda.empty_cache()
+                res["fine_stage"] = fine_stage.measure(dev, N, H, W)
+            except Exception as e:          # the headline line must not depend on the extra block
+                res["fine_stage"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:      # the CPU leg is timed on rank 0 of the 1-GPU run only
             f0, _, cam0 = cam_for(0)
             res["cpu_baseline"] = cpu_baseline(scene, cam0, frame=f0)

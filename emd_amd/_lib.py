@@ -55,7 +55,7 @@ class EmdFwdArgs(C.Structure):
                 ("geom_ws", _f), ("geom_bytes", C.c_size_t), ("bin_ws", _f), ("bin_bytes", C.c_size_t),
                 ("img_ws", _f), ("img_bytes", C.c_size_t), ("status", _f),
                 ("num_rendered", C.c_int64), ("num_visible", C.c_int64), ("settings_dev", _f),
-                ("num_extra", C.c_int32), ("colors_extra", _f * 2), ("out_extra", _f * 2), ("aux_stream", _f), ("shs_residual", _f * 2)]
+                ("num_extra", C.c_int32), ("colors_extra", _f * 2), ("out_extra", _f * 2), ("aux_stream", _f), ("shs_residual", _f * 2), ("loop_stats", _f)]
 
 
 class EmdBwdArgs(C.Structure):
@@ -219,7 +219,7 @@ EXPORTED_SYMBOLS = ("emd_abi_version", "emd_last_error", "emd_raster_workspace_s
                     "emd_temporal_embed_forward", "emd_temporal_embed_backward", "emd_deform_input_width", "emd_deform_input_forward",
                     "emd_deform_input_backward", "emd_adam_step", "emd_track_heads_forward", "emd_track_heads_backward",
                     "emd_densify_decide", "emd_densify_index", "emd_densify_split_rank", "emd_densify_gather",
-                    "emd_refine_decide", "emd_refine_index", "emd_after_train_stats",
+                    "emd_refine_decide", "emd_refine_index", "emd_after_train_stats", "emd_densify_scan",
                     "emd_mlp_trunk_forward", "emd_mlp_trunk_backward", "emd_mlp_branch_forward", "emd_mlp_branch_backward",
                     "emd_abs_mean_backward", "emd_residual_l1_backward", "emd_tracked_pose_forward", "emd_tracked_pose_backward",
                     "emd_select_step_inputs", "emd_compact_rows", "emd_scatter_rows", "emd_l1_loss_ws")
@@ -288,11 +288,12 @@ def load():
     lib.emd_deform_input_backward.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_adam_step.argtypes = [C.POINTER(EmdAdamArgs), C.c_void_p]
     lib.emd_densify_decide.argtypes = [C.POINTER(EmdDensifyArgs), C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.emd_densify_index.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_densify_index.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_densify_scan.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_densify_split_rank.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.emd_densify_gather.argtypes = [C.POINTER(EmdDensifyGather), C.c_void_p]
     lib.emd_refine_decide.argtypes = [C.POINTER(EmdRefineArgs), C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.emd_refine_index.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emd_refine_index.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_after_train_stats.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     lib.emd_abs_mean_backward.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emd_residual_l1_backward.argtypes = [C.c_int64] + [C.c_void_p] * 9

@@ -316,7 +316,9 @@ int emd_raster_forward(EmdFwdArgs* a, void* hip_stream) {
     memset(&ex, 0, sizeof(ex));
     ex.num = a->num_extra;
     for (int k = 0; k < a->num_extra; k++) { ex.colors[k] = a->colors_extra[k]; ex.out[k] = a->out_extra[k]; }
-    rc = emd_launch_render_forward(a->s, a->settings_dev, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->out_alpha, &ex, st);
+    if (a->loop_stats && a->num_extra > 0) { emd_set_error("forward: loop_stats (diagnostic counters) only without extra colour sets"); return EMD_ERR_INVALID; }
+    rc = emd_launch_render_forward(a->s, a->settings_dev, a->flags, g, b, im, a->out_color, a->out_depth, a->out_normal, a->out_alpha, &ex,
+                                   (unsigned long long*)a->loop_stats, st);
     emd_prof_end(PROF_RENDER_FWD, st);
     if (rc) return rc;
     STAGE_SYNC("render_forward");

@@ -183,7 +183,7 @@ struct EmdExtra {
 static inline int emd_bwd_stride(int num_extra) { return EMD_BWD_STRIDE + 4 * num_extra; }
 int emd_launch_render_forward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                               float* out_color, float* out_depth, float* out_normal, float* out_alpha, const EmdExtra* x,
-                              hipStream_t st);                                 // render.hip
+                              unsigned long long* loop_stats, hipStream_t st);   // render.hip
 int emd_launch_render_backward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                                const float* out_color, const float* out_depth, const float* out_normal,
                                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,

@@ -8,9 +8,11 @@
 // every parameter and both Adam moments (~60 launches and as many temporaries), and draws the split samples from the global
 // CUDA generator (`torch.normal`, gaussian_model.py:543) -- a different stream on every rank.  Here one event is
 //   k_densify_decide   one pass over the N Gaussians: per point a code (keep / clone / split / drop) from the accumulated
-//                      statistics, the activated scale and opacity; three 0/1 columns for the caller's prefix sum
-//   [prefix sum of the three columns: the caller; ONE host read of the new point count]
-//   k_densify_index    for every OUTPUT row its source row and kind, in the reference's order:
+//                      statistics, the activated scale and opacity; per 256-point block the number of survivors / clones / splits
+//   k_densify_scan     exclusive prefix sums of the block counts (one workgroup per column) + the column totals
+//                      [ONE host read: the totals = the new point count.  Round 6: the scan used to be torch.cumsum over [3, N] -- three rows
+//                       of 3 M elements, i.e. three workgroups: 7.3 ms of the event's 8.2 at 3 M Gaussians, profiles/r06_density_event.txt]
+//   k_densify_index    for every OUTPUT row its source row and kind (position = block offset + ballot prefix), in the reference's order:
 //                      survivors (in order), clones (in order), split samples replica 0 (in order), replica 1 (in order)
 //   k_densify_gather   one launch for ALL tensors (7 parameters + 14 Adam moments + statistics): output row <- source row;
 //                      the moments and statistics of new rows are zero; split samples get xyz = R(q) (std * n) + xyz with
@@ -26,12 +28,81 @@ namespace {
 
 enum { CODE_KEEP = 1, CODE_CLONE = 2, CODE_SPLIT = 4 };
 
-__global__ void __launch_bounds__(EMD_BLOCK) k_densify_decide(EmdDensifyArgs a, int32_t* __restrict__ code, int32_t* __restrict__ cols /*[3][N]*/) {
+// ---- 0/1 columns of a 256-thread block: counts per block (decide), exclusive position inside the block (index) --------------------------------
+// Every thread of the block calls these (threads past the end with all flags false).
+template <int NC>
+__device__ __forceinline__ void block_flag_counts(const bool (&f)[NC], int32_t* __restrict__ counts, int nblocks) {
+    __shared__ uint32_t s_cnt[NC][EMD_BLOCK / EMD_WAVE];
+    const int wave = threadIdx.x / EMD_WAVE, lane = threadIdx.x % EMD_WAVE;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const unsigned long long b = __ballot(f[c]);
+        if (lane == 0) s_cnt[c][wave] = (uint32_t)__popcll(b);
+    }
+    __syncthreads();
+    if (threadIdx.x < NC) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < EMD_BLOCK / EMD_WAVE; w++) t += s_cnt[threadIdx.x][w];
+        counts[(size_t)threadIdx.x * nblocks + blockIdx.x] = (int32_t)t;
+    }
+}
+// position of the thread's 1 among the 1s of its column = block offset + 1s of the waves before + 1s of the lanes before
+template <int NC>
+__device__ __forceinline__ void block_flag_positions(const bool (&f)[NC], const int32_t* __restrict__ offsets, int nblocks, int (&pos)[NC]) {
+    __shared__ uint32_t s_cnt[NC][EMD_BLOCK / EMD_WAVE];
+    const int wave = threadIdx.x / EMD_WAVE, lane = threadIdx.x % EMD_WAVE;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int in_wave[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const unsigned long long b = __ballot(f[c]);
+        in_wave[c] = __popcll(b & lt);
+        if (lane == 0) s_cnt[c][wave] = (uint32_t)__popcll(b);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        int before = offsets[(size_t)c * nblocks + blockIdx.x];
+        for (int w = 0; w < wave; w++) before += (int)s_cnt[c][w];
+        pos[c] = before + in_wave[c];
+    }
+}
+
+// exclusive prefix sums over the blocks, in place; one 1024-thread workgroup per column; totals[c] = the column's sum
+__global__ void __launch_bounds__(1024) k_densify_scan(int nblocks, int32_t* __restrict__ counts, int32_t* __restrict__ totals) {
+    __shared__ int32_t s_wave[16];
+    __shared__ int32_t s_carry;
+    int32_t* col = counts + (size_t)blockIdx.x * nblocks;
+    const int lane = threadIdx.x % EMD_WAVE, wave = threadIdx.x / EMD_WAVE;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const int32_t v = i < nblocks ? col[i] : 0;
+        int32_t x = v;                                  // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < EMD_WAVE; off <<= 1) { const int32_t y = __shfl_up(x, off); if (lane >= off) x += y; }
+        if (lane == EMD_WAVE - 1) s_wave[wave] = x;
+        __syncthreads();
+        int32_t before = s_carry;
+        for (int w = 0; w < wave; w++) before += s_wave[w];
+        if (i < nblocks) col[i] = before + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = s_carry;
+}
+
+__global__ void __launch_bounds__(EMD_BLOCK) k_densify_decide(EmdDensifyArgs a, int32_t* __restrict__ code, int32_t* __restrict__ counts /*[3][nblocks]*/) {
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
-    if (i >= a.num_points) return;
+    const bool live = i < a.num_points;
+    int c = 0;
+    if (live) {
     const float s0 = expf(a.scaling[3 * i]), s1 = expf(a.scaling[3 * i + 1]), s2 = expf(a.scaling[3 * i + 2]);
     const float smax = fmaxf(s0, fmaxf(s1, s2));
-    int c = CODE_KEEP;
+    c = CODE_KEEP;
     if (a.mode == EMD_DENSIFY_MODE_DENSIFY) {
         // grads = xyz_gradient_accum / denom, NaN -> 0 (gaussian_model.py:697-698); clone: small Gaussians, split: large ones
         float g = a.grad_accum[i] / a.denom[i];
@@ -50,25 +121,24 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_densify_decide(EmdDensifyArgs a, 
         if (drop) c = 0;
     }
     code[i] = c;
-    const size_t N = (size_t)a.num_points;
-    cols[i] = (c & CODE_KEEP) ? 1 : 0;
-    cols[N + i] = (c & CODE_CLONE) ? 1 : 0;
-    cols[2 * N + i] = (c & CODE_SPLIT) ? 1 : 0;
+    }
+    const bool f[3] = {(c & CODE_KEEP) != 0, (c & CODE_CLONE) != 0, (c & CODE_SPLIT) != 0};
+    block_flag_counts<3>(f, counts, (int)gridDim.x);
 }
 
-// inc: inclusive prefix sums of the three columns; totals = last entries
-__global__ void __launch_bounds__(EMD_BLOCK) k_densify_index(int n, const int32_t* __restrict__ code, const int32_t* __restrict__ inc,
-                                                             int32_t* __restrict__ src, int32_t* __restrict__ kind) {
+// offsets: exclusive prefix sums of the block counts (k_densify_scan); totals: the three column sums
+__global__ void __launch_bounds__(EMD_BLOCK) k_densify_index(int n, const int32_t* __restrict__ code, const int32_t* __restrict__ offsets,
+                                                             const int32_t* __restrict__ totals, int32_t* __restrict__ src, int32_t* __restrict__ kind) {
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const size_t N = (size_t)n;
-    const int n_keep = inc[N - 1], n_clone = inc[2 * N - 1], n_split = inc[3 * N - 1];
-    const int c = code[i];
-    if (c & CODE_KEEP) { const int j = inc[i] - 1; src[j] = i; kind[j] = 0; }
-    if (c & CODE_CLONE) { const int j = n_keep + inc[N + i] - 1; src[j] = i; kind[j] = 1; }
+    const int c = i < n ? code[i] : 0;
+    const bool f[3] = {(c & CODE_KEEP) != 0, (c & CODE_CLONE) != 0, (c & CODE_SPLIT) != 0};
+    int pos[3];
+    block_flag_positions<3>(f, offsets, (int)gridDim.x, pos);
+    const int n_keep = totals[0], n_clone = totals[1], n_split = totals[2];
+    if (c & CODE_KEEP) { const int j = pos[0]; src[j] = i; kind[j] = 0; }
+    if (c & CODE_CLONE) { const int j = n_keep + pos[1]; src[j] = i; kind[j] = 1; }
     if (c & CODE_SPLIT) {
-        const int r = inc[2 * N + i] - 1;
-        const int j0 = n_keep + n_clone + r, j1 = j0 + n_split;
+        const int j0 = n_keep + n_clone + pos[2], j1 = j0 + n_split;
         src[j0] = i; kind[j0] = 2;
         src[j1] = i; kind[j1] = 3;
     }
@@ -170,13 +240,14 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_densify_split_rank(int num_out, i
 // ---- OmniRe refinement (EmdRefineArgs in include/emd_raster.h restates the semantics) ------------------------------------------------------------
 enum { RCODE_KEEP = 1, RCODE_DUP = 2, RCODE_SAMPLES = 4, RCODE_SPLIT = 8 };
 
-__global__ void __launch_bounds__(EMD_BLOCK) k_refine_decide(EmdRefineArgs a, int32_t* __restrict__ code, int32_t* __restrict__ cols /*[4][N]*/) {
+__global__ void __launch_bounds__(EMD_BLOCK) k_refine_decide(EmdRefineArgs a, int32_t* __restrict__ code, int32_t* __restrict__ counts /*[4][nblocks]*/) {
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
-    if (i >= a.num_points) return;
+    bool keep = false, keep_samples = false, keep_dup = false, split = false;
+    if (i < a.num_points) {
     const float l0 = a.scaling[3 * i], l1 = a.scaling[3 * i + 1], l2 = a.scaling[3 * i + 2];
     float smax = fmaxf(expf(l0), fmaxf(expf(l1), expf(l2)));
     const float m2d = a.max_2Dsize ? a.max_2Dsize[i] : 0.f;
-    bool split = false, dup = false;
+    bool dup = false;
     float smax_new = smax;
     if (a.do_densify) {
         const bool high = a.grad_norm[i] / a.vis_counts[i] > a.grad_threshold;
@@ -188,7 +259,7 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_refine_decide(EmdRefineArgs a, in
         }
         dup = smax <= a.size_threshold && high;
     }
-    bool keep = true, keep_samples = split, keep_dup = dup;
+    keep = true; keep_samples = split; keep_dup = dup;
     if (a.do_cull) {
         const float op = 1.f / (1.f + expf(-a.opacity[i]));
         const bool faint = op < a.cull_alpha;
@@ -200,31 +271,30 @@ __global__ void __launch_bounds__(EMD_BLOCK) k_refine_decide(EmdRefineArgs a, in
         keep_dup = dup && !(faint || big || wide_new);
     }
     code[i] = (keep ? RCODE_KEEP : 0) | (keep_dup ? RCODE_DUP : 0) | (keep_samples ? RCODE_SAMPLES : 0) | (split ? RCODE_SPLIT : 0);
-    const size_t N = (size_t)a.num_points;
-    cols[i] = keep ? 1 : 0;
-    cols[N + i] = keep_dup ? 1 : 0;
-    cols[2 * N + i] = keep_samples ? 1 : 0;
-    cols[3 * N + i] = split ? 1 : 0;
+    }
+    const bool f[4] = {keep, keep_dup, keep_samples, split};
+    block_flag_counts<4>(f, counts, (int)gridDim.x);
 }
 
-__global__ void __launch_bounds__(EMD_BLOCK) k_refine_index(int n, int num_samples, const int32_t* __restrict__ code, const int32_t* __restrict__ inc,
-                                                            int32_t* __restrict__ src, int32_t* __restrict__ kind, int32_t* __restrict__ split_rank) {
+__global__ void __launch_bounds__(EMD_BLOCK) k_refine_index(int n, int num_samples, const int32_t* __restrict__ code, const int32_t* __restrict__ offsets,
+                                                            const int32_t* __restrict__ totals, int32_t* __restrict__ src, int32_t* __restrict__ kind,
+                                                            int32_t* __restrict__ split_rank) {
     const int i = blockIdx.x * EMD_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const size_t N = (size_t)n;
-    const int n_keep = inc[N - 1], n_samp = inc[3 * N - 1];
-    const int c = code[i];
+    const int c = i < n ? code[i] : 0;
+    const bool f[4] = {(c & RCODE_KEEP) != 0, (c & RCODE_DUP) != 0, (c & RCODE_SAMPLES) != 0, (c & RCODE_SPLIT) != 0};
+    int pos[4];
+    block_flag_positions<4>(f, offsets, (int)gridDim.x, pos);
+    const int n_keep = totals[0], n_samp = totals[2];
     const int sp = (c & RCODE_SPLIT) ? 16 : 0;
-    if (c & RCODE_KEEP) { const int j = inc[i] - 1; src[j] = i; kind[j] = sp; if (split_rank) split_rank[j] = 0; }
+    if (c & RCODE_KEEP) { const int j = pos[0]; src[j] = i; kind[j] = sp; if (split_rank) split_rank[j] = 0; }
     if (c & RCODE_SAMPLES) {
-        const int r = inc[2 * N + i] - 1, rank = inc[3 * N + i] - 1;
         for (int rep = 0; rep < num_samples; rep++) {
-            const int j = n_keep + rep * n_samp + r;
+            const int j = n_keep + rep * n_samp + pos[2];
             src[j] = i; kind[j] = (2 + rep) | sp;
-            if (split_rank) split_rank[j] = rank;
+            if (split_rank) split_rank[j] = pos[3];          // rank among ALL split sources (the row of a caller-supplied draw)
         }
     }
-    if (c & RCODE_DUP) { const int j = n_keep + num_samples * n_samp + inc[N + i] - 1; src[j] = i; kind[j] = 1 | sp; if (split_rank) split_rank[j] = 0; }
+    if (c & RCODE_DUP) { const int j = n_keep + num_samples * n_samp + pos[1]; src[j] = i; kind[j] = 1 | sp; if (split_rank) split_rank[j] = 0; }
 }
 
 // VanillaGaussians.after_train (vanilla.py:163-191) for one view, in place
@@ -255,14 +325,14 @@ extern "C" int emd_refine_decide(const EmdRefineArgs* a, int32_t* code, int32_t*
     return EMD_OK;
 }
 
-extern "C" int emd_refine_index(int32_t num_points, int32_t num_out, int32_t num_samples, const int32_t* code, const int32_t* inclusive_scans, int32_t* src,
-                                int32_t* kind, int32_t* split_rank, void* hip_stream) {
-    if (num_points < 0 || num_out < 0 || num_samples < 1 || num_samples > 13 || (num_points > 0 && (!code || !inclusive_scans)) || (num_out > 0 && (!src || !kind))) {
+extern "C" int emd_refine_index(int32_t num_points, int32_t num_out, int32_t num_samples, const int32_t* code, const int32_t* block_offsets, const int32_t* totals,
+                                int32_t* src, int32_t* kind, int32_t* split_rank, void* hip_stream) {
+    if (num_points < 0 || num_out < 0 || num_samples < 1 || num_samples > 13 || (num_points > 0 && (!code || !block_offsets || !totals)) || (num_out > 0 && (!src || !kind))) {
         emd_set_error("refine_index: bad argument"); return EMD_ERR_INVALID;
     }
     if (num_points == 0) return EMD_OK;
     hipLaunchKernelGGL(k_refine_index, dim3((num_points + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, num_points, num_samples, code,
-                       inclusive_scans, src, kind, split_rank);
+                       block_offsets, totals, src, kind, split_rank);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }
@@ -290,14 +360,23 @@ extern "C" int emd_densify_decide(const EmdDensifyArgs* a, int32_t* code, int32_
     return EMD_OK;
 }
 
-extern "C" int emd_densify_index(int32_t num_points, int32_t num_out, const int32_t* code, const int32_t* inclusive_scans, int32_t* src,
+extern "C" int emd_densify_scan(int32_t num_points, int32_t num_columns, int32_t* block_counts, int32_t* totals, void* hip_stream) {
+    if (num_points < 0 || num_columns < 1 || num_columns > 8 || !totals || (num_points > 0 && !block_counts)) { emd_set_error("densify_scan: bad argument"); return EMD_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (num_points == 0) return emd_zero_async(totals, sizeof(int32_t) * (size_t)num_columns, st);
+    hipLaunchKernelGGL(k_densify_scan, dim3((unsigned)num_columns), dim3(1024), 0, st, (num_points + EMD_BLOCK - 1) / EMD_BLOCK, block_counts, totals);
+    EMD_LAUNCH_CHECK();
+    return EMD_OK;
+}
+
+extern "C" int emd_densify_index(int32_t num_points, int32_t num_out, const int32_t* code, const int32_t* block_offsets, const int32_t* totals, int32_t* src,
                                  int32_t* kind, void* hip_stream) {
-    if (num_points < 0 || num_out < 0 || (num_points > 0 && (!code || !inclusive_scans)) || (num_out > 0 && (!src || !kind))) {
+    if (num_points < 0 || num_out < 0 || (num_points > 0 && (!code || !block_offsets || !totals)) || (num_out > 0 && (!src || !kind))) {
         emd_set_error("densify_index: bad argument"); return EMD_ERR_INVALID;
     }
     if (num_points == 0) return EMD_OK;
     hipLaunchKernelGGL(k_densify_index, dim3((num_points + EMD_BLOCK - 1) / EMD_BLOCK), dim3(EMD_BLOCK), 0, (hipStream_t)hip_stream, num_points, code,
-                       inclusive_scans, src, kind);
+                       block_offsets, totals, src, kind);
     EMD_LAUNCH_CHECK();
     return EMD_OK;
 }

@@ -114,15 +114,18 @@ __device__ __forceinline__ v2f pinned_exp2(v2f x) {
 // ---------------------------------------------------------------------------------------------------
 #define FQ_RING 128
 
-template <bool NORMAL, int NX>
+// STATS (diagnostic instantiation, EmdFwdArgs.loop_stats): trip counts of the kernel's loops, summed over the waves -- with the static instruction
+// counts of each loop's body (profiles/make_isa_mix.py) they split the kernel's instructions into scan / cull / queue and compositing.
+template <bool NORMAL, int NX, bool STATS = false>
 __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ ranges,
                                                                const uint32_t* __restrict__ point_list,
                                                                const float4* __restrict__ rec, float* __restrict__ out_color,
                                                                float* __restrict__ out_depth, float* __restrict__ out_normal,
                                                                float* __restrict__ out_alpha, float* __restrict__ final_T,
                                                                uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ surv,
-                                                               uint32_t* __restrict__ quad_need) {
+                                                               uint32_t* __restrict__ quad_need, unsigned long long* __restrict__ loop_stats) {
 #pragma clang fp contract(off)   // the forward image is a bit-exact contract: only the explicit fma calls below fuse
+    unsigned long long st_scan = 0ull, st_cull = 0ull, st_drain = 0ull, st_useful = 0ull, st_round = 0ull;
     __shared__ float4 s0[FQ_RING], s1[FQ_RING], s2[FQ_RING];
     __shared__ float4 s3[NORMAL ? FQ_RING : 1];
     __shared__ float4 sx[NX ? NX : 1][NX ? FQ_RING : 1];       // extra colour sets: (r, g, b, -) per ring slot
@@ -182,7 +185,9 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
         if (__ballot(!done) == 0ull) break;
         // ---- scan: queue the entries whose footprint reaches this quadrant until more than 64 wait or the list ends ----
         uint32_t head = 0, len0 = 0, len1 = 0, len2 = 0, len3 = 0;
+        if (STATS) st_round++;
         while (head <= EMD_WAVE && scanned < n_tile) {
+            if (STATS) st_scan++;
             const uint32_t idx = scanned + lane;
             const float4 c0r = p0, c1r = p1, c3r = p3;
             float4 c2r = p2;
@@ -220,6 +225,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
         // ---- the queued entries (not the whole list) get the exact per-sub-block test; one byte list per sub-block.  The entries that
         //      reach at least one sub-block are the quadrant's SURVIVORS: numbered here, in list order, ids written out for the backward
         for (uint32_t base = 0; base < head; base += EMD_WAVE) {
+            if (STATS) st_cull++;
             const uint32_t slot = base + lane;
             uint32_t m4 = 0u, gid = 0u;
             if (slot < head) { gid = __float_as_uint(reinterpret_cast<const float*>(&s2[slot])[3]); m4 = ellipse_subblock_mask(s0[slot], s1[slot], qx0, qy0); }
@@ -239,6 +245,7 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
         }
         __syncthreads();
         const uint32_t nmax = max(max(len0, len1), max(len2, len3));
+        if (STATS) { st_drain += nmax; st_useful += len0 + len1 + len2 + len3; }
         if (nmax) {
             const uint32_t n = row == 0 ? len0 : row == 1 ? len1 : row == 2 ? len2 : len3;
             const uint8_t* list = s_list[row];
@@ -299,6 +306,12 @@ __global__ void __launch_bounds__(EMD_WAVE) k_render_forward_q(RenderDims d, con
     uint32_t need = inside ? last : 0u;
     for (int off = 32; off; off >>= 1) need = max(need, (uint32_t)__shfl_xor((int)need, off));
     if (lane == 0) quad_need[4 * tile + quad] = need;
+    if (STATS && lane == 0) {
+        // [0] scan steps (64 list words each)  [1] cull steps (64 queued entries each)  [2] drain iterations (one entry per 16-lane row each)
+        // [3] entries the four rows actually held (<= 4 x [2])  [4] scan -> cull -> drain rounds  [5] waves with a non-empty tile
+        atomicAdd(loop_stats, st_scan); atomicAdd(loop_stats + 1, st_cull); atomicAdd(loop_stats + 2, st_drain); atomicAdd(loop_stats + 3, st_useful);
+        atomicAdd(loop_stats + 4, st_round); atomicAdd(loop_stats + 5, 1ull);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -390,11 +403,15 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
 #pragma unroll
     for (int k = 0; k < (NX ? NX : 1); k++) dX[k][0] = dX[k][1] = dX[k][2] = 0.f;
     if (inside) {
-        Tf = final_T[pix];
         float dA = 0.f;
+#ifndef K7_ABL_NO_PROLOGUE       /* ablation build: the per-pixel inputs are constants instead of five image-sized loads (the walk itself is unchanged) */
+        Tf = final_T[pix];
         if (dL_dcolor) { dC0 = dL_dcolor[pix]; dC1 = dL_dcolor[HW + pix]; dC2 = dL_dcolor[2 * HW + pix]; }
         if (dL_ddepth) dD = dL_ddepth[pix];
         if (dL_dalpha) dA = dL_dalpha[pix];
+#else
+        Tf = 0.37f; dC0 = 1e-6f; dC1 = -2e-6f; dC2 = 3e-6f;
+#endif
         if (NORMAL && dL_dnormal) { dN0 = dL_dnormal[pix]; dN1 = dL_dnormal[HW + pix]; dN2 = dL_dnormal[2 * HW + pix]; }
         const float bg0 = d.bg_dev ? d.bg_dev[0] : d.bg[0], bg1 = d.bg_dev ? d.bg_dev[1] : d.bg[1], bg2 = d.bg_dev ? d.bg_dev[2] : d.bg[2];
         float bgdot = bg0 * dC0 + bg1 * dC1 + bg2 * dC2;
@@ -544,7 +561,11 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
             const uint32_t e = idx / STRIDE, v = idx % STRIDE;
             const float val = s_stage[idx];
             if (STATS) st_atoms += (unsigned long long)__popcll(__ballot(val != 0.f));
+#ifndef K7_ABL_NO_FLUSH          /* ablation build (profiles/r06_render_ablations.txt): the rows are staged but never added to HBM */
             if (val != 0.f) atomicAdd(grad_rec + (size_t)q_id[e] * STRIDE + v, val);
+#else
+            if (val == 12345.678f) grad_rec[0] = val;
+#endif
         }
         __syncthreads();
     };
@@ -633,7 +654,7 @@ RenderDims make_dims(const EmdSettings& s, const float* sdev, const EmdExtra* x)
 
 int emd_launch_render_forward(const EmdSettings& s, const float* sdev, int flags, const GeomWs& g, const BinWs& b, const ImgWs& im,
                               float* out_color, float* out_depth, float* out_normal, float* out_alpha, const EmdExtra* x,
-                              hipStream_t st) {
+                              unsigned long long* loop_stats, hipStream_t st) {
     const RenderDims d = make_dims(s, sdev, x);
     const int T = d.gx * d.gy;
     if (T <= 0) return EMD_OK;
@@ -641,9 +662,15 @@ int emd_launch_render_forward(const EmdSettings& s, const float* sdev, int flags
     const int nx = x ? x->num : 0;
 #define LAUNCH_FWD(N_, X_)                                                                                                          \
     hipLaunchKernelGGL((k_render_forward_q<N_, X_>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec, \
-                       out_color, out_depth, out_normal, out_alpha, im.final_T, im.n_contrib, b.surv, b.quad_need)
+                       out_color, out_depth, out_normal, out_alpha, im.final_T, im.n_contrib, b.surv, b.quad_need, nullptr)
     const bool nrm = (flags & EMD_FLAG_NORMAL) != 0;
-    if (nx == 0) { if (nrm) LAUNCH_FWD(true, 0); else LAUNCH_FWD(false, 0); }
+    if (nx == 0 && loop_stats) {          // diagnostic: the same kernel with the loop counters compiled in
+        if (nrm) hipLaunchKernelGGL((k_render_forward_q<true, 0, true>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec,
+                                    out_color, out_depth, out_normal, out_alpha, im.final_T, im.n_contrib, b.surv, b.quad_need, loop_stats);
+        else hipLaunchKernelGGL((k_render_forward_q<false, 0, true>), dim3(4 * padded_tile_grid(T)), dim3(EMD_WAVE), 0, st, d, b.tile_order, b.ranges, pl, g.rec,
+                                out_color, out_depth, out_normal, out_alpha, im.final_T, im.n_contrib, b.surv, b.quad_need, loop_stats);
+    }
+    else if (nx == 0) { if (nrm) LAUNCH_FWD(true, 0); else LAUNCH_FWD(false, 0); }
     else if (nx == 1) { if (nrm) LAUNCH_FWD(true, 1); else LAUNCH_FWD(false, 1); }
     else { if (nrm) LAUNCH_FWD(true, 2); else LAUNCH_FWD(false, 2); }
 #undef LAUNCH_FWD

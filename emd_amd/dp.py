@@ -232,11 +232,14 @@ class GradientExchange:
     all-reduce, which keeps and averages every term.  EMD_DP_DEBUG=1 checks the statement on the device before the rows are packed."""
 
     def __init__(self, campos_local, actor_ids=None, actor_pose=None, residual_dx=None, average=True, bucket_small=True, bucket_bytes=16 << 20,
-                 compact=None, compact_capacity=None, overflow=None, slab_pure=False):
+                 compact=None, compact_capacity=None, overflow=None, slab_pure=False, timing=False):
         self.campos_local, self.actor_ids, self.residual_dx = campos_local, actor_ids, residual_dx
         self.bucket_small, self.bucket_bytes = bucket_small, bucket_bytes
         self.compact, self.compact_capacity, self.overflow = compact, compact_capacity, overflow
         self.slab_pure = bool(slab_pure)
+        # timing=True: HIP events on the stream the exchange is issued from (a collective's completion reaches that stream through work.wait()):
+        # `times_ms()` then says where a step's exchange went -- see there.  Events are only READ after the caller's synchronisation.
+        self._ev = {} if timing else None
         self._rows_f = self._rows_s = None
         self.actor_pose = None if actor_pose is None else actor_pose.detach()       # values only: no reference into an autograd graph
         self.average = average
@@ -257,6 +260,7 @@ class GradientExchange:
         if (W == 1 and not force_exchange()) or self._gathers:
             return
         dev, N = g_local.device, g_local.shape[0]
+        self._mark("gather_issue")
         self._campos = torch.empty(W, 3, device=dev, dtype=torch.float32)
         if self._use_compact(W, N) and getattr(rec, "radii", None) is None:
             raise RuntimeError("the compacted exchange packs by the call's radii (RasterCall.radii): this record carries none")
@@ -276,6 +280,25 @@ class GradientExchange:
             self._poses = torch.empty(W * A, self.actor_pose.shape[1], device=dev, dtype=torch.float32)
             self._gathers.append(dist.all_gather_into_tensor(self._poses, self.actor_pose.detach().float().contiguous(), async_op=True))
         self.num_collectives = len(self._gathers)
+
+    def _mark(self, name):
+        if self._ev is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._ev[name] = e
+
+    def times_ms(self):
+        """After the step has been synchronised, with timing=True: {"gather_ms": issue of the factor / camera / pose gathers -> their completion as
+        seen by the issuing stream (they travel under K8: mostly hidden), "slab_ms": issue of the slab all-reduce (or its row all-gather) -> its
+        completion, "rebuild_ms": the local rebuild of dL/dshs from the gathered factors (+ the row scatters of the compacted form), "exposed_ms":
+        end of this rank's own backward kernels (`finish()` is called right behind them) -> end of the exchange: what the step pays for
+        communicating}.  Intervals on ONE stream, so they include whatever else that stream did in between."""
+        ev = self._ev or {}
+
+        def dt(a, b):
+            return ev[a].elapsed_time(ev[b]) if a in ev and b in ev else None
+        return {"gather_ms": dt("gather_issue", "gather_done"), "slab_ms": dt("slab_issue", "slab_done"), "rebuild_ms": dt("gather_done", "rebuild_done"),
+                "exposed_ms": dt("finish_begin", "finish_end")}
 
     def _overflow_word(self, dev):
         """The device word the row kernels raise on a dropped row: the caller's, or one of this exchange's own (the kernels never get a null)."""
@@ -318,6 +341,7 @@ class GradientExchange:
         W = world_size()
         if W == 1 and not force_exchange():
             return
+        self._mark("slab_issue")
         if self._rows_f is not None and self._slab_rows_allowed(rec):
             N = rec.grad_slab.numel() // 11
             sl = rec.grad_slab
@@ -346,6 +370,7 @@ class GradientExchange:
             raise RuntimeError("GradientExchange.finish before the backward pass ran (RasterCall.on_backward was not wired)")
         W = world_size()
         g_local = rec.sh_color_grad
+        self._mark("finish_begin")
         works, others, small, bucket, bucket_work = [], [], [], None, None
         if W == 1 and not force_exchange():
             g_all, campos, pose = g_local[None], self.campos_local.reshape(1, 3).to(g_local.device), self.actor_pose
@@ -379,6 +404,7 @@ class GradientExchange:
             self.num_collectives += len(works) + (1 if bucket is not None else 0)
             for w in self._gathers:
                 w.wait()
+            self._mark("gather_done")
             if self._rows_f is not None:
                 # the gathered factor rows back into dense [W, N, 3] columns (zeros where a view does not see the Gaussian)
                 g_all = torch.zeros(W, N, 3, device=g_local.device, dtype=torch.float32)
@@ -399,8 +425,10 @@ class GradientExchange:
             for q in parts:
                 q.grad = dense[:, k0:k0 + q.shape[1]].contiguous()
                 k0 += q.shape[1]
+        self._mark("rebuild_done")
         if self._slab_work is not None:
             self._slab_work.wait()
+            self._mark("slab_done")
             if self._rows_s is not None:
                 # every view's rows added into the zeroed slab, in rank order on every rank: the same float additions everywhere
                 sl = rec.grad_slab
@@ -423,6 +451,7 @@ class GradientExchange:
                 g.div_(float(W))
             if self._slab_work is not None and self._rows_s is None:
                 rec.grad_slab.div_(float(W))
+        self._mark("finish_end")
 
 
 def visible_capacity(v_max, margin=1.1, multiple=1024):

@@ -295,11 +295,13 @@ class GaussianModel:
         if N == 0:
             return 0, 0, 0
         code = torch.empty(N, dtype=torch.int32, device=dev)
-        cols = torch.empty(3, N, dtype=torch.int32, device=dev)
+        nblocks = (N + 255) // 256
+        inc = torch.empty(3, nblocks, dtype=torch.int32, device=dev)          # per-block counts, then exclusive block offsets
+        totals = torch.empty(3, dtype=torch.int32, device=dev)
         args.num_points, args.mode = N, mode
-        L.check(lib.emd_densify_decide(C.byref(args), code.data_ptr(), cols.data_ptr(), _stream()), "emd_densify_decide")
-        inc = torch.cumsum(cols, dim=1, dtype=torch.int32).contiguous()
-        n_keep, n_clone, n_split = (int(v) for v in inc[:, -1].tolist())          # the event's single host read
+        L.check(lib.emd_densify_decide(C.byref(args), code.data_ptr(), inc.data_ptr(), _stream()), "emd_densify_decide")
+        L.check(lib.emd_densify_scan(N, 3, inc.data_ptr(), totals.data_ptr(), _stream()), "emd_densify_scan")
+        n_keep, n_clone, n_split = (int(v) for v in totals.tolist())          # the event's single host read
         if mode == L.DENSIFY_MODE_DENSIFY and n_clone == 0 and n_split == 0:
             # nothing selected: the reference's densify_and_clone still runs densification_postfix, which clears the three statistics
             # (gaussian_model.py:526-530) -- stale ones would leak into the next interval and into prune()'s max_radii2D test
@@ -312,13 +314,13 @@ class GaussianModel:
         M = n_keep + n_clone + 2 * n_split
         src = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
         kind = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
-        L.check(lib.emd_densify_index(N, M, code.data_ptr(), inc.data_ptr(), src.data_ptr(), kind.data_ptr(), _stream()), "emd_densify_index")
+        L.check(lib.emd_densify_index(N, M, code.data_ptr(), inc.data_ptr(), totals.data_ptr(), src.data_ptr(), kind.data_ptr(), _stream()), "emd_densify_index")
         g = L.EmdDensifyGather()
         g.num_out, g.mode, g.num_split = M, mode, n_split
         g.src, g.kind = src.data_ptr(), kind.data_ptr()
         g.scaling, g.rotation = self._scaling.data_ptr(), self._rotation.data_ptr()
         g.seed = (self.densify_seed * 0x9E3779B97F4A7C15 + self.densify_events) & 0xFFFFFFFFFFFFFFFF
-        keep_alive = [src, kind, code, inc]
+        keep_alive = [src, kind, code, inc, totals]
         if samples is not None:
             samples = samples.to(dev).float().contiguous()
             assert samples.shape == (2, n_split, 3), (tuple(samples.shape), n_split)

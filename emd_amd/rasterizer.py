@@ -99,10 +99,12 @@ class RasterCall:
     of a fresh allocation -- a fixed address for callers that replay the call from a hipGraph and read the words on the device.
     `pair_stats` (diagnostic; an int64[4] device tensor set by the caller before backward()): the render backward adds the number of
     (pixel, list entry) pairs it evaluated, the number that contributed, the accumulator rows it sent to memory as float atomics and the
-    float atomics issued (EmdBwdArgs.pair_stats)."""
+    float atomics issued (EmdBwdArgs.pair_stats).
+    `loop_stats` (diagnostic; an int64[6] device tensor set by the caller before the call): the compositing kernel adds the trip counts of its scan /
+    cull / drain loops (EmdFwdArgs.loop_stats; profiles/render_loop_trips.py)."""
     __slots__ = ("status", "num_rendered", "num_visible", "geom_ws", "bin_ws", "img_ws", "sizes", "capacity", "N", "H", "W",
                  "flags", "settings_dev", "absgrad", "sh_color_grad", "grad_slab", "on_backward", "render_grads", "pair_stats",
-                 "status_buffer", "slab_inputs", "on_sh_factor", "radii")
+                 "status_buffer", "slab_inputs", "on_sh_factor", "radii", "loop_stats")
 
     def __init__(self):
         for k in self.__slots__:
@@ -347,6 +349,7 @@ class _Rasterize(torch.autograd.Function):
             a.num_gaussians, a.sh_coeffs, a.flags, a.bin_capacity = N, M, flags, capacity
             a.means3D, a.shs, a.colors_precomp = L.ptr(means3D), L.ptr(shs), L.ptr(colors_precomp)
             a.shs_residual[0], a.shs_residual[1] = L.ptr(shs_res0), L.ptr(shs_res1)
+            a.loop_stats = L.ptr(rec.loop_stats)         # diagnostic: an int64[6] device tensor set on the record before the call, or None
             a.opacities, a.scales, a.rotations = L.ptr(opacities), L.ptr(scales), L.ptr(rotations)
             a.cov3D_precomp = L.ptr(cov3Ds_precomp)
             _fill_motion(a.motion, actor_ids, actor_pose, residual_dx, residual_dq)

@@ -111,6 +111,8 @@ class VanillaGaussians(torch.nn.Module):
             n = self.num_points
             if self.filter_mask is not None and not bool(self.filter_mask.all()):
                 raise NotImplementedError("a partial filter_mask (rows hidden from the rasterizer) is not used by the reference's VanillaGaussians")
+            if radii.device.type != "cuda" or xys_grad.device.type != "cuda":
+                raise L.EmdError("VanillaGaussians.after_train needs tensors on a ROCm device; there is no CPU path")
             r = radii.reshape(-1).to(torch.int32).contiguous()
             g = xys_grad.reshape(n, -1).float()
             if g.stride(1) != 1:
@@ -177,10 +179,11 @@ class VanillaGaussians(torch.nn.Module):
         a.split_screen, a.cull_alpha = float(_get(c, "split_screen_size")), float(_get(c, "cull_alpha_thresh"))
         a.cull_size, a.cull_screen = float(_get(c, "cull_scale_thresh") * self.scene_scale), float(_get(c, "cull_screen_size"))
         code = torch.empty(N, dtype=torch.int32, device=dev)
-        cols = torch.empty(4, N, dtype=torch.int32, device=dev)
-        L.check(lib.emd_refine_decide(C.byref(a), code.data_ptr(), cols.data_ptr(), _stream()), "emd_refine_decide")
-        inc = torch.cumsum(cols, dim=1, dtype=torch.int32).contiguous()
-        n_keep, n_dup, n_samp, n_split = (int(v) for v in inc[:, -1].tolist())          # the event's single host read
+        inc = torch.empty(4, (N + 255) // 256, dtype=torch.int32, device=dev)          # per-block counts, then exclusive block offsets
+        totals = torch.empty(4, dtype=torch.int32, device=dev)
+        L.check(lib.emd_refine_decide(C.byref(a), code.data_ptr(), inc.data_ptr(), _stream()), "emd_refine_decide")
+        L.check(lib.emd_densify_scan(N, 4, inc.data_ptr(), totals.data_ptr(), _stream()), "emd_densify_scan")
+        n_keep, n_dup, n_samp, n_split = (int(v) for v in totals.tolist())          # the event's single host read
         M = n_keep + ns * n_samp + n_dup
         info = {"n_before": N, "n_after": M, "split": n_split, "originals_kept": n_keep, "samples_kept": ns * n_samp, "dups_kept": n_dup}
         if M == N and n_keep == N and n_split == 0:
@@ -188,7 +191,7 @@ class VanillaGaussians(torch.nn.Module):
         src = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
         kind = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
         rank = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
-        L.check(lib.emd_refine_index(N, M, ns, code.data_ptr(), inc.data_ptr(), src.data_ptr(), kind.data_ptr(), rank.data_ptr(), _stream()),
+        L.check(lib.emd_refine_index(N, M, ns, code.data_ptr(), inc.data_ptr(), totals.data_ptr(), src.data_ptr(), kind.data_ptr(), rank.data_ptr(), _stream()),
                 "emd_refine_index")
         g = L.EmdDensifyGather()
         g.num_out, g.mode, g.num_split = M, L.DENSIFY_MODE_REFINE, n_split

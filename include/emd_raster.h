@@ -214,6 +214,10 @@ typedef struct EmdFwdArgs {
      * (S3Gaussian/scene/deformation.py:468-481); here the sum exists only for the Gaussians that are visible, inside the projection
      * kernel.  dL/dshs of the backward is the gradient of each of the three terms (the sum's Jacobian is the identity). */
     const float* shs_residual[2];
+    /* diagnostic (ABI 27): device uint64[6], ADDED to by the compositing kernel's counting instantiation: [0] scan steps (64 list words each),
+     * [1] cull steps (64 queued entries each), [2] drain iterations (one entry per 16-pixel row each), [3] entries the rows held, [4] scan -> cull ->
+     * drain rounds, [5] waves that ran.  NULL in every training path (the counters are compiled out); num_extra must be 0. */
+    uint64_t* loop_stats;
 } EmdFwdArgs;
 
 typedef struct EmdBwdArgs {
@@ -738,8 +742,8 @@ int emd_mlp_branch_backward(const EmdMlpBranch* args, const EmdMlpBranchGrads* g
  * densify = densify_and_clone + densify_and_split, prune = prune / prune_points of S3Gaussian/scene/gaussian_model.py:441-603,
  * 683-701 (OmniRe: models/gaussians/vanilla.py:206-376), rewriting the SoA parameters, both Adam moments and the statistics in
  * one gather launch -- see the block comment of csrc/densify.hip.  Call sequence of one event:
- *   emd_densify_decide  -> code[N], columns[3][N] (0/1: survives, cloned, split)
- *   [inclusive prefix sums of the three columns by the caller; num_out = keep + clone + 2 split: the event's one host read]
+ *   emd_densify_decide  -> code[N], block_counts[3][ceil(N / 256)] (per 256-point block: survivors, clones, splits)
+ *   emd_densify_scan    -> the counts become exclusive block offsets; totals[3]: num_out = keep + clone + 2 split is the event's one host read
  *   emd_densify_index   -> src[num_out], kind[num_out] (0 survivor, 1 clone, 2 / 3 split sample replica 0 / 1), in the
  *                          reference's output order: survivors, clones, replica 0, replica 1
  *   emd_densify_gather  -> every output tensor */
@@ -799,8 +803,9 @@ typedef struct EmdDensifyGather {
  *            or (while step < stop_screen_size_at) max_2Dsize > cull_screen, new rows carrying max_2Dsize 0       (vanilla.py:299-326)
  *   output order: surviving originals, split samples replica 0, replica 1, ..., duplicates (vanilla.py:256-263); Adam moments of new rows zero.
  * Thresholds are the host's products (size_thresh = densify_size_thresh * scene_scale ...) rounded to float once, as torch rounds a Python scalar.
- * Sequence: emd_refine_decide -> code[N], columns[4][N] (original kept, duplicate kept, samples kept, source is split) -> inclusive prefix sums by the
- * caller (one host read: num_out = keep + num_samples * samples + dup) -> emd_refine_index -> emd_densify_gather with mode EMD_DENSIFY_MODE_REFINE. */
+ * Sequence: emd_refine_decide -> code[N], per-block counts of four 0/1 columns (original kept, duplicate kept, samples kept, source is split) ->
+ * emd_densify_scan (4 columns; one host read of the totals: num_out = keep + num_samples * samples + dup) -> emd_refine_index ->
+ * emd_densify_gather with mode EMD_DENSIFY_MODE_REFINE. */
 typedef struct EmdRefineArgs {
     int32_t num_points;
     int32_t do_densify;            /* split / duplicate this event (step < stop_split_at and past the opacity-reset guard, vanilla.py:213-216) */
@@ -815,20 +820,22 @@ typedef struct EmdRefineArgs {
     const float* max_2Dsize;       /* [N] */
     float grad_threshold, size_threshold, split_screen, cull_alpha, cull_size, cull_screen;
 } EmdRefineArgs;
-int emd_refine_decide(const EmdRefineArgs* args, int32_t* code /*[N]*/, int32_t* columns /*[4,N]*/, void* hip_stream);
+int emd_refine_decide(const EmdRefineArgs* args, int32_t* code /*[N]*/, int32_t* block_counts /*[4, ceil(N / 256)]*/, void* hip_stream);
 /* kind[j]: 0 original, 1 duplicate, 2 + r split sample of replica r; + 16 when the source row was split (its scale is reduced wherever it is
  * copied); split_rank[j]: rank of a sample's source among ALL split sources (the row of a caller-supplied normal draw [num_samples, n_split, 3]) */
-int emd_refine_index(int32_t num_points, int32_t num_out, int32_t num_samples, const int32_t* code, const int32_t* inclusive_scans /*[4,N]*/,
-                     int32_t* src, int32_t* kind, int32_t* split_rank, void* hip_stream);
+int emd_refine_index(int32_t num_points, int32_t num_out, int32_t num_samples, const int32_t* code, const int32_t* block_offsets /*[4, ceil(N / 256)]*/,
+                     const int32_t* totals /*[4]*/, int32_t* src, int32_t* kind, int32_t* split_rank, void* hip_stream);
 
 /* OmniRe's running refinement statistics of one view (VanillaGaussians.after_train, models/gaussians/vanilla.py:163-191), one launch: where radii > 0
  * grad_norm += |xys_grad| (2 components, row stride `grad_stride` floats), vis_counts += 1, max_2Dsize = max(max_2Dsize, radii / last_size). */
 int emd_after_train_stats(int32_t n, const int32_t* radii, const float* xys_grad, int32_t grad_stride, float* grad_norm, float* vis_counts,
                           float* max_2Dsize, float last_size, void* hip_stream);
 
-int emd_densify_decide(const EmdDensifyArgs* args, int32_t* code /*[N]*/, int32_t* columns /*[3,N]*/, void* hip_stream);
-int emd_densify_index(int32_t num_points, int32_t num_out, const int32_t* code, const int32_t* inclusive_scans /*[3,N]*/, int32_t* src,
-                      int32_t* kind, void* hip_stream);
+int emd_densify_decide(const EmdDensifyArgs* args, int32_t* code /*[N]*/, int32_t* block_counts /*[3, ceil(N / 256)]*/, void* hip_stream);
+/* exclusive prefix sums of the per-block counts over the blocks, in place, + totals[c] = sum of column c (device int32[num_columns]) */
+int emd_densify_scan(int32_t num_points, int32_t num_columns, int32_t* block_counts, int32_t* totals, void* hip_stream);
+int emd_densify_index(int32_t num_points, int32_t num_out, const int32_t* code, const int32_t* block_offsets /*[3, ceil(N / 256)]*/,
+                      const int32_t* totals /*[3]*/, int32_t* src, int32_t* kind, void* hip_stream);
 int emd_densify_split_rank(int32_t num_out, int32_t n_keep, int32_t n_clone, int32_t n_split, int32_t* rank, void* hip_stream);
 int emd_densify_gather(const EmdDensifyGather* args, void* hip_stream);
 

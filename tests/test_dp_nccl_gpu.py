@@ -57,3 +57,6 @@ def test_bench_step_with_the_exchange_over_rccl_on_one_gpu(one_graph):
     assert issue.startswith("hipGraph replay"), issue
     assert ("TWO graphs" in issue) == (not one_graph), issue
     assert d["value"] > 0 and "capture failed" not in p.stderr
+    # where the step's exchange went (HIP events around its phases, dp.GradientExchange(timing=True)): present whenever collectives are issued
+    ex = d["exchange"]
+    assert ex["steps"] == 4 and ex["exposed_ms"] > 0 and ex["slab_ms"] > 0 and ex["gather_ms"] > 0 and ex["rebuild_ms"] > 0, ex
