@@ -71,7 +71,7 @@ class StreetGaussians(torch.nn.Module):
 
 
 def density_control(model: "StreetGaussians", xyz_gradient_accum, denom, max_radii2D, max_grad=2e-4, min_opacity=0.005, extent=27.5,
-                    max_screen_size=None, percent_dense=0.01, seed=0, event=0):
+                    max_screen_size=None, percent_dense=0.01, seed=0, event=0, optimizer=None):
     """One density-control event of the training loop (S3Gaussian/train.py:404-423 -> scene/gaussian_model.py:442-556: clone the small,
     split the large Gaussians whose accumulated view-space gradient exceeds `max_grad`, then prune the transparent / oversized ones) on a
     StreetGaussians parameter store, in place; returns {"n_before", "n_after", "cloned", "split", "pruned"}.
@@ -81,7 +81,13 @@ def density_control(model: "StreetGaussians", xyz_gradient_accum, denom, max_rad
     actor's points contiguously, which the per-actor kernels rely on.  The engine is emd_amd.gaussian_model.GaussianModel's device-side
     decide -> scan -> index -> gather (csrc/densify.hip); the split samples are a Philox draw keyed by (seed, event), so every rank of a
     view-parallel run that calls this with the same (reduced) statistics ends with bit-identical parameters.  The three statistics
-    tensors are consumed (the caller allocates fresh zeros for the new point count, as densification_postfix does, gaussian_model.py:526-530)."""
+    tensors are consumed (the caller allocates fresh zeros for the new point count, as densification_postfix does, gaussian_model.py:526-530).
+
+    Every per-Gaussian parameter of the store is REPLACED by a fresh `nn.Parameter` (the point count changes).  `optimizer` (torch.optim.Adam /
+    emd_amd.optim.Adam whose groups hold `_xyz`, `_scaling`, `_rotation`, `_opacity`, `_features` as single-parameter groups): its groups are
+    pointed at the new parameters and both Adam moments travel with the rows -- survivors keep theirs, new rows start at zero -- as the reference's
+    `cat_tensors_to_optimizer` / `_prune_optimizer` do (gaussian_model.py:454-500); the actors' rows keep theirs.  WITHOUT it a caller's optimizer
+    still points at the old tensors and must be rebuilt (its state for these five parameters is lost)."""
     from .gaussian_model import GaussianModel
     dev, N = model._xyz.device, model._xyz.shape[0]
     n_dyn = int((model.actor_id >= 0).sum()) if model.has_actors else 0
@@ -99,6 +105,29 @@ def density_control(model: "StreetGaussians", xyz_gradient_accum, denom, max_rad
     gm.denom = denom.reshape(N, 1)[n_dyn:].contiguous()
     gm.max_radii2D = max_radii2D.reshape(N)[n_dyn:].contiguous()
     gm.percent_dense = float(percent_dense)
+    # the caller's optimizer state rides along: a stand-in with the engine's group names whose moments are the background rows of the caller's
+    # (the SH moments split like the parameter: f_dc | f_rest)
+    own = {"xyz": model._xyz, "scaling": model._scaling, "rotation": model._rotation, "opacity": model._opacity, "f": model._features}
+    found = {}
+    if optimizer is not None:
+        for grp in optimizer.param_groups:
+            for key, prm in own.items():
+                if len(grp["params"]) == 1 and grp["params"][0] is prm:
+                    found[key] = grp
+        shim_state, shim_groups = {}, []
+        for key, prm_new in (("xyz", gm._xyz), ("scaling", gm._scaling), ("rotation", gm._rotation), ("opacity", gm._opacity), ("f_dc", gm._features_dc),
+                             ("f_rest", gm._features_rest)):
+            src_key = "f" if key.startswith("f_") else key
+            grp = found.get(src_key)
+            st = optimizer.state.get(own[src_key]) if grp is not None else None
+            if st and "exp_avg" in st:
+                cut = (lambda t: t.detach()[n_dyn:, :1]) if key == "f_dc" else (lambda t: t.detach()[n_dyn:, 1:]) if key == "f_rest" else (lambda t: t.detach()[n_dyn:])
+                shim_state[prm_new] = {"exp_avg": cut(st["exp_avg"]).contiguous(), "exp_avg_sq": cut(st["exp_avg_sq"]).contiguous()}
+                shim_groups.append({"name": key, "params": [prm_new]})
+        if shim_groups:
+            import types as _types
+            gm.optimizer = _types.SimpleNamespace(param_groups=shim_groups, state=shim_state)
+    old_state = {key: optimizer.state.get(own[key]) for key in found} if optimizer is not None else {}
     with torch.no_grad():
         _, n_clone, n_split = gm.densify(max_grad, min_opacity, extent, max_screen_size)
         n_mid = gm._xyz.shape[0]
@@ -113,6 +142,21 @@ def density_control(model: "StreetGaussians", xyz_gradient_accum, denom, max_rad
         model._features = NP(front(model._features), torch.cat([gm._features_dc, gm._features_rest], 1))
         if model.has_actors:
             model.actor_id = torch.cat([model.actor_id[:n_dyn], torch.full((n_new,), -1, dtype=model.actor_id.dtype, device=dev)])
+        if found:
+            new = {"xyz": model._xyz, "scaling": model._scaling, "rotation": model._rotation, "opacity": model._opacity, "f": model._features}
+            moved = {}          # engine group name -> its state after the event
+            if gm.optimizer is not None:
+                for grp in gm.optimizer.param_groups:
+                    moved[grp["name"]] = gm.optimizer.state.get(grp["params"][0])
+            for key, grp in found.items():
+                st = old_state.get(key)
+                optimizer.state.pop(own[key], None)
+                grp["params"] = [new[key]]
+                if st and "exp_avg" in st:
+                    for mom in ("exp_avg", "exp_avg_sq"):
+                        back = torch.cat([moved["f_dc"][mom], moved["f_rest"][mom]], 1) if key == "f" else moved[key][mom]
+                        st[mom] = torch.cat([st[mom].detach()[:n_dyn], back], 0).contiguous()
+                    optimizer.state[new[key]] = st
     model._zero_xyz = None
     return {"n_before": N, "n_after": n_dyn + n_new, "cloned": int(n_clone), "split": int(n_split), "pruned": int(n_mid - n_new)}
 

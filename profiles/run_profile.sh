@@ -13,7 +13,8 @@ export TMPDIR=/tmp
 # the same frames (5..24 of the clip); the counter passes add --eager --settle-ms 0 --repeats 0: without the settle replays of frame 0 and the
 # repeats, 20 of the 26 forward and 20 of the 26 backward dispatches of a pass are the timed steps (the rest: one sizing step and five warm-up steps on
 # frames 0..4; the five pair-statistics steps run a differently named instantiation of K7 and re-run timed frames for the other kernels)
-B="python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
+# (--no-fine-stage under rocprofv3: the fine_stage block uses torch.profiler, i.e. roctracer, which must not run inside a traced process)
+B="python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-fine-stage"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o stats -- $B > "$OUT/bench_profiled.json" 2> "$OUT/stats.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o stats_eager -- $B --eager > "$OUT/bench_profiled_eager.json" 2> "$OUT/stats_eager.err"
 P="$B --eager --settle-ms 0 --repeats 0"

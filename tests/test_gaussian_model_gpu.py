@@ -492,3 +492,67 @@ def test_density_control_on_the_bench_parameter_store_leaves_the_actors_alone():
     assert torch.equal(m._features.detach()[n_dyn:], torch.cat([ref._features_dc, ref._features_rest], 1).detach())
     m2, _, ev2 = run()                                            # a second replica: the same event, bit for bit
     assert ev2 == ev and torch.equal(m2._xyz.detach(), m._xyz.detach()) and torch.equal(m2._rotation.detach(), m._rotation.detach())
+
+
+@pytest.mark.parametrize("opt_kind", ["hip_adam", "torch_adam"])
+def test_density_control_carries_the_callers_optimizer_state(opt_kind):
+    """density_control(..., optimizer=...): the optimiser's groups point at the NEW parameters and both Adam moments travel with the rows -- a survivor's
+    moments are its old ones (found again through its xyz, which a clone shares with its source: the FIRST row with that position is the survivor),
+    new rows start at zero, the actors' rows are untouched -- as cat_tensors_to_optimizer / _prune_optimizer do (gaussian_model.py:454-500);
+    a step of the optimiser afterwards works on the new tensors."""
+    from emd_amd import scenes
+    from emd_amd.model import StreetGaussians, density_control
+    from emd_amd.optim import Adam
+    N, A, P = 20000, 2, 1500
+    n_dyn = A * P
+    sc = scenes.add_actors(scenes.make_static_scene(N, seed=3), num_actors=A, pts_per_actor=P, num_frames=4, seed=1)
+    m = StreetGaussians(sc, DEV)
+    g = torch.Generator().manual_seed(9)
+    names = {"xyz": "_xyz", "f": "_features", "opacity": "_opacity", "scaling": "_scaling", "rotation": "_rotation"}
+    opt = (Adam if opt_kind == "hip_adam" else torch.optim.Adam)([{"params": [getattr(m, a)], "lr": 1e-3, "name": n} for n, a in names.items()], lr=0.0, eps=1e-15)
+    for _ in range(2):
+        for a in names.values():
+            p = getattr(m, a)
+            p.grad = (torch.randn(p.shape, generator=g) * 1e-2).to(DEV)
+        opt.step()
+    old = {n: (getattr(m, a).detach().clone(), opt.state[getattr(m, a)]["exp_avg"].clone(), opt.state[getattr(m, a)]["exp_avg_sq"].clone()) for n, a in names.items()}
+    accum, denom, radii = (torch.rand(N, 1, generator=g) * 4e-4).to(DEV), torch.randint(0, 3, (N, 1), generator=g).float().to(DEV), torch.zeros(N, device=DEV)
+    ev = density_control(m, accum, denom, radii, max_grad=2e-4, min_opacity=0.005, extent=4.0, percent_dense=0.01, seed=1, event=0, optimizer=opt)
+    M = ev["n_after"]
+    assert ev["cloned"] > 0 and M != N
+    # which old row every new row came from: survivors keep their xyz (split samples move, clones share their source's: the first hit is the survivor)
+    new_xyz, old_xyz = m._xyz.detach(), old["xyz"][0]
+    n_keep = N - ev["split"] - ev["pruned"] if ev["pruned"] == 0 else None
+    for n, a in names.items():
+        p = getattr(m, a)
+        grp = [g_ for g_ in opt.param_groups if g_["name"] == n][0]
+        assert grp["params"][0] is p and p.shape[0] == M and p in opt.state
+        st = opt.state[p]
+        assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
+        assert torch.equal(st["exp_avg"][:n_dyn], old[n][1][:n_dyn]) and torch.equal(st["exp_avg_sq"][:n_dyn], old[n][2][:n_dyn])      # the actors' rows
+    # survivors are the leading background rows in their old order (minus the split / pruned ones): match by position
+    keep_mask = torch.zeros(N, dtype=torch.bool, device=DEV)
+    key_old = {tuple(r): i for i, r in enumerate(old_xyz[n_dyn:].cpu().tolist())}
+    rows_new = new_xyz[n_dyn:].cpu().tolist()
+    seen, survivors = set(), []
+    for j, r in enumerate(rows_new):
+        i = key_old.get(tuple(r))
+        if i is not None and i not in seen:
+            seen.add(i)
+            survivors.append((j, i))
+    assert len(survivors) >= (N - n_dyn) - ev["split"] - ev["pruned"] - 1
+    jj = torch.tensor([n_dyn + j for j, _ in survivors], device=DEV)
+    ii = torch.tensor([n_dyn + i for _, i in survivors], device=DEV)
+    for n, a in names.items():
+        st = opt.state[getattr(m, a)]
+        assert torch.equal(st["exp_avg"][jj], old[n][1][ii]) and torch.equal(st["exp_avg_sq"][jj], old[n][2][ii]), n
+        rest = torch.ones(M, dtype=torch.bool, device=DEV)
+        rest[jj] = False
+        rest[:n_dyn] = False
+        assert float(st["exp_avg"][rest].abs().max()) == 0.0 and float(st["exp_avg_sq"][rest].abs().max()) == 0.0, n          # new rows start at zero
+    for a in names.values():
+        p = getattr(m, a)
+        p.grad = torch.ones_like(p) * 1e-3
+    before = m._xyz.detach().clone()
+    opt.step()
+    assert not torch.equal(before, m._xyz.detach())

@@ -108,3 +108,51 @@ def test_rasterization_rejects_unsupported_options():
         gsplat_api.rasterization(**kw, packed=True)
     with pytest.raises(NotImplementedError):            # a finite far plane would have to cull: refused, not ignored
         gsplat_api.rasterization(**kw, far_plane=80.0)
+
+
+def test_after_train_running_sums_on_top_of_means2d_absgrad():
+    """SURVEY row a17 end to end: `rasterization(..., absgrad=True)` -> `info["means2d"].absgrad` scaled to pixels as the trainer does
+    (OmniRe/models/trainers/base.py:279-286: x (W/2 B), y (H/2 B), B = 1) -> `VanillaGaussians.after_train` over three views with different
+    visibility.  Expected: vanilla.py:163-191 written out in numpy (first call: the norm of EVERY row and a count of one everywhere; later calls
+    only where radii > 0; max_2Dsize = max over views of radii / max(W, H)) applied to the CPU ORACLE's absgrad and radii of the same views --
+    so the chain kernel (K7 |grad| column) -> adapter -> statistics kernel is pinned against a path that shares none of its code."""
+    from emd_amd.vanilla import VanillaGaussians
+    case = make_case(n=2500, H=72, W=104, seed=77, colors_precomp=True)
+    H, W, N = case["H"], case["W"], case["N"]
+    views = [_camera(case), _camera(case, yaw_deg=25.0, dx=-1.5, dy=4.0), _camera(case, yaw_deg=-40.0, dx=0.5, dy=0.0)]
+    quats_raw = case["rotations"]
+    node = VanillaGaussians("Background", dict(sh_degree=3, refine_interval=100), device=DEV)
+    node._means = torch.nn.Parameter(case["means3D"].to(DEV))
+    exp_norm = exp_vis = exp_m2d = None
+    rng = np.random.default_rng(5)
+    for v, (c2w, K, cam) in enumerate(views):
+        d = lambda t: t.to(DEV).clone().requires_grad_(True)
+        means, quats, scales, opac, colors = d(case["means3D"]), d(quats_raw), d(case["scales"]), d(case["opacities"]), d(case["colors_precomp"])
+        renders, alphas, info = gsplat_api.rasterization(
+            means=means, quats=quats, scales=scales, opacities=opac.squeeze(), colors=colors, viewmats=torch.linalg.inv(c2w)[None].to(DEV),
+            Ks=K[None].to(DEV), width=W, height=H, packed=False, absgrad=True, sparse_grad=False, rasterize_mode="classic", near_plane=0.1,
+            far_plane=1e10, render_mode="RGB+ED", radius_clip=0.0, sh_degree=None)
+        info["means2d"].retain_grad()
+        gC = rng.standard_normal((3, H, W)).astype(np.float32)
+        (renders[0, ..., :3] * torch.tensor(gC).to(DEV).permute(1, 2, 0)).sum().backward()
+        grads = info["means2d"].absgrad.clone()                      # base.py:281-286
+        grads[..., 0] *= info["width"] / 2.0 * 1
+        grads[..., 1] *= info["height"] / 2.0 * 1
+        node.after_train(info["radii"][0], grads[0], last_size=max(info["width"], info["height"]))
+        # the same view on the oracle
+        S, sc, pre, b, img = _oracle_view(case, cam, quats_raw, False)
+        g = co.backward(S, sc, pre, b, img, gC, None, None, None, co.F_ABSGRAD)
+        ab = np.asarray(g["render_grads"]["abs"], np.float64) * np.array([W / 2.0, H / 2.0])
+        norm = np.sqrt((ab ** 2).sum(1))
+        vis = pre["radii"] > 0
+        if exp_norm is None:
+            exp_norm, exp_vis, exp_m2d = norm.copy(), np.ones(N), np.zeros(N)
+        else:
+            exp_norm[vis] += norm[vis]
+            exp_vis[vis] += 1
+        exp_m2d[vis] = np.maximum(exp_m2d[vis], pre["radii"][vis] / float(max(W, H)))
+        np.testing.assert_array_equal(info["radii"][0].cpu().numpy(), pre["radii"])
+    assert (exp_vis > 1).any() and (exp_vis == 1).any()
+    np.testing.assert_array_equal(node.vis_counts.cpu().numpy(), exp_vis.astype(np.float32))
+    np.testing.assert_allclose(node.max_2Dsize.cpu().numpy(), exp_m2d.astype(np.float32), rtol=1e-7, atol=0)
+    assert_grad_close(node.xys_grad_norm.cpu().numpy(), exp_norm, "xys_grad_norm after three views")
