@@ -103,6 +103,61 @@ def read_ply(path):
         return {n: np.asarray(arr[n]) for n, _ in props}
 
 
+def restructure_rows(mode, args, jobs, N, seed=0, samples=None, front_rows=0):
+    """One density-control event on `N` rows of an arbitrary set of per-point tensors: decide -> scan -> index -> ONE gather (csrc/densify.hip).
+    `args`: an EmdDensifyArgs with the decision inputs filled (pointers to the N rows); `jobs`: [(tensor [N, ...] float32 contiguous, role)];
+    `front_rows`: every output tensor gets that many extra rows in FRONT of the gathered ones, left for the caller to fill (rows of a store
+    that do not take part: the actors of emd_amd.model.density_control).  -> (outs or None when nothing changes, (n_keep, n_clone, n_split)).
+    The event's single host read is the three totals."""
+    lib = L.load()
+    if N == 0:
+        return None, (0, 0, 0)
+    dev = jobs[0][0].device
+    code = torch.empty(N, dtype=torch.int32, device=dev)
+    inc = torch.empty(3, (N + 255) // 256, dtype=torch.int32, device=dev)          # per-block counts, then exclusive block offsets
+    totals = torch.empty(3, dtype=torch.int32, device=dev)
+    args.num_points, args.mode = N, mode
+    L.check(lib.emd_densify_decide(C.byref(args), code.data_ptr(), inc.data_ptr(), _stream()), "emd_densify_decide")
+    L.check(lib.emd_densify_scan(N, 3, inc.data_ptr(), totals.data_ptr(), _stream()), "emd_densify_scan")
+    n_keep, n_clone, n_split = (int(v) for v in totals.tolist())
+    if (mode == L.DENSIFY_MODE_DENSIFY and n_clone == 0 and n_split == 0) or (mode == L.DENSIFY_MODE_PRUNE and n_keep == N):
+        return None, (n_keep, n_clone, n_split)
+    M = n_keep + n_clone + 2 * n_split
+    src = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    kind = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    L.check(lib.emd_densify_index(N, M, code.data_ptr(), inc.data_ptr(), totals.data_ptr(), src.data_ptr(), kind.data_ptr(), _stream()), "emd_densify_index")
+    g = L.EmdDensifyGather()
+    g.num_out, g.mode, g.num_split = M, mode, n_split
+    g.src, g.kind = src.data_ptr(), kind.data_ptr()
+    g.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    keep_alive = [src, kind, code, inc, totals]
+    for t, role in jobs:
+        if role == L.DENSIFY_ROLE_SCALING:
+            g.scaling = t.data_ptr()
+        if role == "rotation":
+            g.rotation = t.data_ptr()
+    if samples is not None:
+        samples = samples.to(dev).float().contiguous()
+        assert samples.shape == (2, n_split, 3), (tuple(samples.shape), n_split)
+        rank = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+        L.check(lib.emd_densify_split_rank(M, n_keep, n_clone, n_split, rank.data_ptr(), _stream()), "emd_densify_split_rank")
+        g.samples, g.split_rank = samples.data_ptr(), rank.data_ptr()
+        keep_alive += [samples, rank]
+    assert len(jobs) <= L.DENSIFY_MAX_TENSORS
+    outs = []
+    for k, (t, role) in enumerate(jobs):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] == N
+        width = t.numel() // N
+        out = torch.empty((front_rows + M,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev)
+        g.tensors[k].src, g.tensors[k].dst, g.tensors[k].width = t.data_ptr(), out.data_ptr() + 4 * width * front_rows, width
+        g.tensors[k].role = L.DENSIFY_ROLE_COPY if role == "rotation" else role
+        outs.append(out)
+    g.num_tensors = len(jobs)
+    L.check(lib.emd_densify_gather(C.byref(g), _stream()), "emd_densify_gather")
+    del keep_alive
+    return outs, (n_keep, n_clone, n_split)
+
+
 class GaussianModel:
     """Parameters in the reference's layout: `_xyz [N,3]`, `_features_dc [N,1,3]`, `_features_rest [N,15,3]`, `_scaling [N,3]` (log),
     `_rotation [N,4]` (raw), `_opacity [N,1]` (logit), `_embedding [N,E]`; statistics `max_radii2D [N]`, `xyz_gradient_accum [N,1]`,

@@ -78,87 +78,102 @@ def density_control(model: "StreetGaussians", xyz_gradient_accum, denom, max_rad
 
     The BACKGROUND Gaussians (actor id -1) take part; an actor's points stay as they are -- the reference holds every tracked actor at a
     fixed budget (<= 5000 Gaussians, OmniRe/configs/paper_legacy/omnire.yaml:93; the bench scene's actors sit at that cap) and stores an
-    actor's points contiguously, which the per-actor kernels rely on.  The engine is emd_amd.gaussian_model.GaussianModel's device-side
-    decide -> scan -> index -> gather (csrc/densify.hip); the split samples are a Philox draw keyed by (seed, event), so every rank of a
-    view-parallel run that calls this with the same (reduced) statistics ends with bit-identical parameters.  The three statistics
-    tensors are consumed (the caller allocates fresh zeros for the new point count, as densification_postfix does, gaussian_model.py:526-530).
+    actor's points contiguously, which the per-actor kernels rely on.  The engine is emd_amd.gaussian_model.restructure_rows -- the device-side
+    decide -> scan -> index -> gather of GaussianModel (csrc/densify.hip), here applied to the background rows of the store's own tensors IN
+    PLACE of a copy (round 6: no slice / cat passes around the gather; `_features` travels as one 48-float row): two events (densify, prune),
+    two host reads.  The split samples are a Philox draw keyed by (seed, event, source row, replica), so every rank of a view-parallel run that
+    calls this with the same (reduced) statistics ends with bit-identical parameters -- and the background ends exactly as a GaussianModel
+    holding only the background would.  The three statistics tensors are consumed (the caller allocates fresh zeros for the new point count,
+    as densification_postfix does, gaussian_model.py:526-530).
 
     Every per-Gaussian parameter of the store is REPLACED by a fresh `nn.Parameter` (the point count changes).  `optimizer` (torch.optim.Adam /
     emd_amd.optim.Adam whose groups hold `_xyz`, `_scaling`, `_rotation`, `_opacity`, `_features` as single-parameter groups): its groups are
     pointed at the new parameters and both Adam moments travel with the rows -- survivors keep theirs, new rows start at zero -- as the reference's
     `cat_tensors_to_optimizer` / `_prune_optimizer` do (gaussian_model.py:454-500); the actors' rows keep theirs.  WITHOUT it a caller's optimizer
     still points at the old tensors and must be rebuilt (its state for these five parameters is lost)."""
-    from .gaussian_model import GaussianModel
+    from . import _lib as L
+    from .gaussian_model import restructure_rows
     dev, N = model._xyz.device, model._xyz.shape[0]
+    if dev.type != "cuda":
+        raise L.EmdError("density_control needs the store on a ROCm device; there is no CPU path")
     n_dyn = int((model.actor_id >= 0).sum()) if model.has_actors else 0
     if model.has_actors and n_dyn and not bool((model.actor_id[:n_dyn] >= 0).all()):
         raise ValueError("density_control expects the actors' points in front of the background's (the reference's node order)")
-    gm = GaussianModel(sh_degree=3, device=dev, densify_seed=seed)
-    gm.densify_events = int(event)
-    P = lambda t: torch.nn.Parameter(t.detach()[n_dyn:].contiguous())
-    gm._xyz, gm._scaling, gm._rotation, gm._opacity = P(model._xyz), P(model._scaling), P(model._rotation), P(model._opacity)
-    gm._features_dc, gm._features_rest = P(model._features[:, :1]), P(model._features[:, 1:])
-    ns = N - n_dyn
-    gm._embedding = torch.nn.Parameter(torch.zeros(ns, gm.gaussian_embedding_dim, device=dev))
-    gm._deformation_table = torch.ones(ns, dtype=torch.bool, device=dev)
-    gm.xyz_gradient_accum = xyz_gradient_accum.reshape(N, 1)[n_dyn:].contiguous()
-    gm.denom = denom.reshape(N, 1)[n_dyn:].contiguous()
-    gm.max_radii2D = max_radii2D.reshape(N)[n_dyn:].contiguous()
-    gm.percent_dense = float(percent_dense)
-    # the caller's optimizer state rides along: a stand-in with the engine's group names whose moments are the background rows of the caller's
-    # (the SH moments split like the parameter: f_dc | f_rest)
-    own = {"xyz": model._xyz, "scaling": model._scaling, "rotation": model._rotation, "opacity": model._opacity, "f": model._features}
-    found = {}
+    names = ("_xyz", "_scaling", "_rotation", "_opacity", "_features")
+    roles = {"_xyz": L.DENSIFY_ROLE_XYZ, "_scaling": L.DENSIFY_ROLE_SCALING, "_rotation": "rotation", "_opacity": L.DENSIFY_ROLE_COPY,
+             "_features": L.DENSIFY_ROLE_COPY}
+    groups = {}
     if optimizer is not None:
         for grp in optimizer.param_groups:
-            for key, prm in own.items():
-                if len(grp["params"]) == 1 and grp["params"][0] is prm:
-                    found[key] = grp
-        shim_state, shim_groups = {}, []
-        for key, prm_new in (("xyz", gm._xyz), ("scaling", gm._scaling), ("rotation", gm._rotation), ("opacity", gm._opacity), ("f_dc", gm._features_dc),
-                             ("f_rest", gm._features_rest)):
-            src_key = "f" if key.startswith("f_") else key
-            grp = found.get(src_key)
-            st = optimizer.state.get(own[src_key]) if grp is not None else None
-            if st and "exp_avg" in st:
-                cut = (lambda t: t.detach()[n_dyn:, :1]) if key == "f_dc" else (lambda t: t.detach()[n_dyn:, 1:]) if key == "f_rest" else (lambda t: t.detach()[n_dyn:])
-                shim_state[prm_new] = {"exp_avg": cut(st["exp_avg"]).contiguous(), "exp_avg_sq": cut(st["exp_avg_sq"]).contiguous()}
-                shim_groups.append({"name": key, "params": [prm_new]})
-        if shim_groups:
-            import types as _types
-            gm.optimizer = _types.SimpleNamespace(param_groups=shim_groups, state=shim_state)
-    old_state = {key: optimizer.state.get(own[key]) for key in found} if optimizer is not None else {}
+            for nm in names:
+                if len(grp["params"]) == 1 and grp["params"][0] is getattr(model, nm):
+                    groups[nm] = grp
+    state = {nm: optimizer.state.get(getattr(model, nm)) for nm in groups}
+    # the rows that take part: views of the background rows (a dim-0 slice of a contiguous tensor is contiguous: no copy)
+    cur = {nm: getattr(model, nm).detach() for nm in names}
+    mom = {(nm, k): state[nm][k].detach() for nm in groups if state[nm] and "exp_avg" in state[nm] for k in ("exp_avg", "exp_avg_sq")}
+    stats = [xyz_gradient_accum.reshape(N, 1), denom.reshape(N, 1), max_radii2D.reshape(N)]
+    full = {k: v for k, v in cur.items()}
+    counts = {"cloned": 0, "split": 0, "pruned": 0}
+    seed_word = (int(seed) * 0x9E3779B97F4A7C15 + int(event)) & 0xFFFFFFFFFFFFFFFF
     with torch.no_grad():
-        _, n_clone, n_split = gm.densify(max_grad, min_opacity, extent, max_screen_size)
-        n_mid = gm._xyz.shape[0]
-        gm.prune(max_grad, min_opacity, extent, max_screen_size)
-        n_new = gm._xyz.shape[0]
-        front = lambda t: t.detach()[:n_dyn]
-        NP = lambda a, b: torch.nn.Parameter(torch.cat([a, b.detach()], 0).contiguous())
-        model._xyz = NP(front(model._xyz), gm._xyz)
-        model._scaling = NP(front(model._scaling), gm._scaling)
-        model._rotation = NP(front(model._rotation), gm._rotation)
-        model._opacity = NP(front(model._opacity), gm._opacity)
-        model._features = NP(front(model._features), torch.cat([gm._features_dc, gm._features_rest], 1))
+        for mode in (L.DENSIFY_MODE_DENSIFY, L.DENSIFY_MODE_PRUNE):
+            n_rows = full["_xyz"].shape[0]
+            nb = n_rows - n_dyn
+            bg = lambda t: t[n_dyn:]
+            a = L.EmdDensifyArgs()
+            a.scaling = bg(full["_scaling"]).data_ptr()
+            if mode == L.DENSIFY_MODE_DENSIFY:
+                a.grad_accum, a.denom = bg(stats[0]).data_ptr(), bg(stats[1]).data_ptr()
+                a.grad_threshold, a.percent_dense, a.scene_extent = float(max_grad), float(percent_dense), float(extent)
+            else:
+                a.opacity, a.max_radii2D = bg(full["_opacity"]).data_ptr(), bg(stats[2]).data_ptr()
+                a.min_opacity, a.scene_extent = float(min_opacity), float(extent)
+                a.max_screen_size = float(max_screen_size) if max_screen_size else 0.0
+            jobs = [(bg(full[nm]), roles[nm]) for nm in names]
+            keys = [("param", nm) for nm in names]
+            for (nm, k), t in mom.items():
+                jobs.append((bg(t), L.DENSIFY_ROLE_STATE))
+                keys.append(("mom", (nm, k)))
+            for i_, t in enumerate(stats):
+                jobs.append((bg(t), L.DENSIFY_ROLE_ZERO))
+                keys.append(("stat", i_))
+            outs, (n_keep, n_clone, n_split) = restructure_rows(mode, a, jobs, nb, seed=seed_word, front_rows=n_dyn)
+            if mode == L.DENSIFY_MODE_DENSIFY:
+                counts["cloned"], counts["split"] = n_clone, n_split
+                if outs is None:          # nothing selected: the reference's densification_postfix still clears the statistics (gaussian_model.py:526-530)
+                    for t in stats:
+                        t[n_dyn:].zero_()
+            else:
+                counts["pruned"] = nb - n_keep
+            if outs is None:
+                continue
+            for (what, key), (t_old, _), out in zip(keys, jobs, outs):
+                if what == "param":
+                    out[:n_dyn].copy_(full[key][:n_dyn])
+                    full[key] = out
+                elif what == "mom":
+                    out[:n_dyn].copy_(mom[key][:n_dyn])
+                    mom[key] = out
+                else:
+                    out[:n_dyn].copy_(stats[key][:n_dyn])
+                    stats[key] = out
+        n_new = full["_xyz"].shape[0] - n_dyn
+        for nm in names:
+            old = getattr(model, nm)
+            new = torch.nn.Parameter(full[nm]) if full[nm] is not cur[nm] else old
+            if nm in groups and new is not old:
+                st = optimizer.state.pop(old, None)
+                groups[nm]["params"] = [new]
+                if st:
+                    if (nm, "exp_avg") in mom:
+                        st["exp_avg"], st["exp_avg_sq"] = mom[(nm, "exp_avg")], mom[(nm, "exp_avg_sq")]
+                    optimizer.state[new] = st
+            setattr(model, nm, new)
         if model.has_actors:
             model.actor_id = torch.cat([model.actor_id[:n_dyn], torch.full((n_new,), -1, dtype=model.actor_id.dtype, device=dev)])
-        if found:
-            new = {"xyz": model._xyz, "scaling": model._scaling, "rotation": model._rotation, "opacity": model._opacity, "f": model._features}
-            moved = {}          # engine group name -> its state after the event
-            if gm.optimizer is not None:
-                for grp in gm.optimizer.param_groups:
-                    moved[grp["name"]] = gm.optimizer.state.get(grp["params"][0])
-            for key, grp in found.items():
-                st = old_state.get(key)
-                optimizer.state.pop(own[key], None)
-                grp["params"] = [new[key]]
-                if st and "exp_avg" in st:
-                    for mom in ("exp_avg", "exp_avg_sq"):
-                        back = torch.cat([moved["f_dc"][mom], moved["f_rest"][mom]], 1) if key == "f" else moved[key][mom]
-                        st[mom] = torch.cat([st[mom].detach()[:n_dyn], back], 0).contiguous()
-                    optimizer.state[new[key]] = st
     model._zero_xyz = None
-    return {"n_before": N, "n_after": n_dyn + n_new, "cloned": int(n_clone), "split": int(n_split), "pruned": int(n_mid - n_new)}
+    return {"n_before": N, "n_after": n_dyn + n_new, "cloned": int(counts["cloned"]), "split": int(counts["split"]), "pruned": int(counts["pruned"])}
 
 
 def mix_dynamic_static(opacity_dynamic, opacity_static, shs_dynamic=None, shs_static=None, colors_dynamic=None, colors_static=None):
