@@ -13,10 +13,10 @@ cp "$OUT/bench_line.json" profiles/r06_bench_line.json 2>/dev/null
 cp "$OUT/bench_profiled.json" profiles/r06_bench_line_profiled.json 2>/dev/null
 FO=$PWD/gpurun_out/r06fine; mkdir -p $FO
 P="python3 profiles/bench_full_step.py --fine --adam"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$FO" -o fetch -- $P > /dev/null 2> "$FO/pmc.err"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$FO" -o write -- $P > /dev/null 2>> "$FO/pmc.err"
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$FO" -o fetch -- $P > /dev/null 2> "$FO/pmc.err"
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$FO" -o write -- $P > /dev/null 2>> "$FO/pmc.err"
 python3 profiles/make_pmc_summary.py "$FO" | sed 's#python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --eager --settle-ms 0 --repeats 0#python3 profiles/bench_full_step.py --fine --adam (60 eager steps)#' > profiles/r06_pmc_fine_traffic.csv
 rm -f "$FO"/*_kernel_trace.csv "$FO"/*_counter_collection.csv
-python3 profiles/make_roofline_table.py > profiles/r06_roofline_table.md 2> gpurun_out/r06_table.err
+timeout 900 python3 profiles/make_roofline_table.py > profiles/r06_roofline_table.md 2> gpurun_out/r06_table.err
 mkdir -p gpurun_out/r06_keep; cp profiles/r06_* gpurun_out/r06_keep/
 tail -5 gpurun_out/r06_table.err; wc -l profiles/r06_roofline_table.md
