@@ -557,16 +557,11 @@ __global__ void __launch_bounds__(EMD_WAVE) __attribute__((amdgpu_waves_per_eu(N
                 for (int v = 0; v < STRIDE; v++) nz = nz || s_stage[lane * STRIDE + v] != 0.f;
             st_rows += (unsigned long long)__popcll(__ballot(nz));
         }
-        // (round 6) without absgrad the last two floats of a row's first 12 are zero: the flush walks 10 (+ 4 per extra set) floats per row, so a
-        // batch of 64 rows is 10 atomic instructions instead of 12 -- what the flush costs is the NUMBER of atomic instructions
-#ifdef K7_FLUSH_ROW12                 /* A/B build: the round-5 flush */
-        constexpr uint32_t ROWF = (uint32_t)STRIDE;
-#else
-        constexpr uint32_t ROWF = (ABS || NX > 0) ? (uint32_t)STRIDE : 10u;
-#endif
-        for (uint32_t idx = lane; idx < nb * ROWF; idx += EMD_WAVE) {
-            const uint32_t e = idx / ROWF, v = idx % ROWF;
-            const float val = s_stage[e * STRIDE + v];
+        // (round 6, measured and not kept: walking 10 instead of 12 floats per row without absgrad -- 10 atomic instructions per 64 rows instead of 12 -- changes
+        //  nothing: 0.4337 / 0.4362 against 0.4348 / 0.4372 ms, profiles/r06_render_ablations.txt; the lanes of floats 10, 11 were already masked off)
+        for (uint32_t idx = lane; idx < nb * STRIDE; idx += EMD_WAVE) {
+            const uint32_t e = idx / STRIDE, v = idx % STRIDE;
+            const float val = s_stage[idx];
             if (STATS) st_atoms += (unsigned long long)__popcll(__ballot(val != 0.f));
 #ifndef K7_ABL_NO_FLUSH          /* ablation build (profiles/r06_render_ablations.txt): the rows are staged but never added to HBM */
             if (val != 0.f) atomicAdd(grad_rec + (size_t)q_id[e] * STRIDE + v, val);
