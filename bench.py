@@ -519,14 +519,20 @@ def main():
             gstate["rec"], gstate["campos"] = rec_g, blk[35:38]
             gstate["pose"] = None if o["actor_pose"] is None else o["actor_pose"].detach()
         try:
-            side = torch.cuda.Stream(priority=-1 if os.environ.get("EMD_BENCH_HIPRIO") else 0)      # (A/B knob: the captured chain above a forked branch)
+            # ONE capture stream for every recording of this run (a re-capture behind a density-control event reuses it: what the step keeps per
+            # stream -- the rasterizer's kept-clean backward workspace, the loss's granule table -- is then formed once)
+            side = settle.get("side")
+            if side is None:
+                side = settle["side"] = torch.cuda.Stream(priority=-1 if os.environ.get("EMD_BENCH_HIPRIO") else 0)      # (A/B knob: the captured chain above a forked branch)
             side.wait_stream(torch.cuda.current_stream())
+            t_dbg = [time.perf_counter()]
             with torch.cuda.stream(side):
                 for i_ in range(1 if light else 3):
                     sel.fill_(i_)
                     graph_body()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            t_dbg.append(time.perf_counter())
             prev_sel.fill_(-1)
             graph = torch.cuda.CUDAGraph()
             graph_b = None
@@ -573,6 +579,9 @@ def main():
                 if graph_b is not None:
                     graph_b.replay()
             G.replay_compute = replay_compute
+            t_dbg.append(time.perf_counter())
+            if os.environ.get("EMD_BENCH_DEBUG_RECORD"):
+                print(f"[bench] record_step(light={light}): eager warm-up {1e3 * (t_dbg[1] - t_dbg[0]):.1f} ms, capture {1e3 * (t_dbg[2] - t_dbg[1]):.1f} ms", file=sys.stderr)
             if light:
                 sel.fill_(0)
                 prev_sel.fill_(-1)
@@ -581,11 +590,19 @@ def main():
             # eager step's device status words (D, V) and leave finite, identical parameter gradients (a memset node captured on ROCm 7.2
             # replayed with a corrupt fill pattern from the SECOND replay on: that is how the library's zero fills became kernels)
             keep_stats = None if S["stats"] is None else [t.clone() for t in S["stats"]]
+            # the `.grad` tensors the capture left on the leaves live in the graph's pool and are what every replay writes: the eager step below
+            # replaces them with its own, so they are put back afterwards -- the comparison then reads the REPLAY's gradients, and the exchange
+            # of a multi-GPU step finds the leaves' `.grad` inside the captured slab again (dp.slab_holds_leaf_grads: ONE all-reduce of the slab
+            # instead of four of stale tensors; found in round 6 through `exchange.slab_ms` coming back empty)
+            leaves_ = list(params) + list(res_leaves)
+            captured_grads = [p.grad for p in leaves_]
             eager = one_step(0)
             torch.cuda.synchronize()
             want_status = eager["raster_call"].status.clone()
             want_grad = model._xyz.grad.clone()
             del eager
+            for p_, g_cap in zip(leaves_, captured_grads):
+                p_.grad = g_cap
             gc.collect()
             for rep_ in range(2):
                 sel.fill_(0)
