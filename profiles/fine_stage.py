@@ -195,6 +195,11 @@ def kernel_models(N, V, D, HW, C_img=7, planes_bytes=None, sky_face=1024):
         (r"k_sky_backward", "sky backward (texel scatter)", "hbm", HW * 4 * (3 + 1 + 3 + 1), "dL/dimage + weight + render read, dL/dweight; + 4 texel rows of atomics per pixel"),
         (r"k_adam", "Adam step", "hbm", None, "16 B read + 12 B written per parameter element"),
         (r"k_densification_stats", "densification statistics", "hbm", N * (4 + 12 + 3 * 8), "radii + dL/dmean2D read, three statistics updated"),
+        # binning and small launches: priced per stage in section A of the table; latency-bound at 4-25 us each
+        (r"k_radix_|k_duplicate|k_sorted_counts|k_tile_ranges|k_tile_order", "binning stage (depth sort, duplication, tile sort, ranges): see section A", "hbm", None,
+         "launch-bound: 19 launches of 4-25 us"),
+        (r"k_l1_loss|k_abs_mean|k_residual_l1|k_loss_finalize", "scalar reductions of the residual regularisers / loss terms", "hbm", None, "launch-bound"),
+        (r"k_temporal_embed|k_tracked_pose|k_track_|k_select_step|k_zero_words|k_hexplane_order_keys", "small per-step launches", "hbm", None, "launch-bound"),
     ]
     return M
 
@@ -214,7 +219,7 @@ def price(name, ms, models):
                              peak="416.7 TFLOP/s fp32-equivalent = the 2.5 PFLOP/s bf16 MFMA peak / six products of the three-term split; measured ceiling 252")
                 e["formula"] = formula
             return e
-    return {"kernel": short_name(name), "what": "(torch / other)", "ms": round(ms, 4), "bound": None}
+    return {"kernel": short_name(name), "what": "(HIP kernel without a model)" if re.search(r"\bk_[a-z]", name) else "(torch / library kernel)", "ms": round(ms, 4), "bound": None}
 
 
 def short_name(name):

@@ -163,7 +163,10 @@ with torch.no_grad():
                 options=RasterOptions(no_sync=False))["raster_call"].last_status()
 n_param = sum(p.numel() for p in S.params)
 models_b = fine_stage.kernel_models(N, st["num_visible"], st["num_rendered"], H * W)
-models_b = [m if not m[0].startswith("k_adam") else (m[0], m[1], m[2], n_param * 28, f"{n_param / 1e6:.1f} M parameter elements x (16 B read + 12 B written)") for m in models_b]
+adam_launches = max(sum(n for k, (ms, n) in prof_b.items() if "k_adam" in k), 1.0)
+models_b = [m if not m[0].startswith("k_adam") else (m[0], m[1], m[2], n_param * 28 / adam_launches,
+                                                     f"{n_param / 1e6:.1f} M parameter elements x (16 B read + 12 B written) / {adam_launches:.0f} launches of <= 32 tensors")
+            for m in models_b]
 fab_b, src_b = fabric_table("pmc_fine_traffic.csv")
 emit("B. S3Gaussian fine-stage step + Adam (profiles/fine_stage.py: HexPlane, MLP heads, rasterizer, sky, full loss, optimiser)", prof_b, models_b, fab_b, src_b)
 del S
@@ -179,7 +182,7 @@ g = torch.Generator().manual_seed(0)
 
 def event(i):
     n = model._xyz.shape[0]
-    acc, den, mr = (torch.rand(n, 1, generator=g) * 1e-3).to(dev), torch.ones(n, 1, device=dev), torch.zeros(n, device=dev)
+    acc, den, mr = torch.rand(n, 1, device=dev) * 1e-3, torch.ones(n, 1, device=dev), torch.zeros(n, device=dev)          # (statistics of the event: set-up, three fills)
     density_control(model, acc, den, mr, max_grad=9.5e-4, min_opacity=0.005, extent=27.5, percent_dense=0.01, seed=0, event=i)
 
 
@@ -191,5 +194,5 @@ models_c = [(r"k_densify_gather", "gather of every parameter / moment / statisti
             (r"k_densify_decide|k_refine_decide", "per-point decision + block counts", "hbm", n3 * (12 + 8 + 4), "scales + two statistics read, code written"),
             (r"k_densify_index|k_refine_index", "output row -> (source, kind)", "hbm", n3 * (4 + 8), "code read, src + kind written"),
             (r"k_densify_scan", "block-count scan", "hbm", None, "launch-bound: 12 k blocks")]
-emit("C. One density-control event at 3 M Gaussians (densify + prune of `emd_amd.model.density_control`; per EVENT, not per step: the torch copies around the gather are listed as they are)",
+emit("C. One density-control event at 3 M Gaussians (densify + prune of `emd_amd.model.density_control`; per EVENT, not per step; the torch fills / `rand` / reductions are the table's own synthetic statistics and the actor-count checks)",
      prof_c, models_c, {}, None)

@@ -126,3 +126,33 @@ def test_after_train_rejects_cpu_tensors():
     node = VanillaGaussians("Background", dict(sh_degree=1, refine_interval=100), device="cpu")
     with pytest.raises(Exception):
         node.after_train(torch.ones(1, dtype=torch.int32), torch.ones(1, 2), 100.0)
+
+
+def test_refinement_edge_cases_nothing_to_do_and_everything_culled():
+    """(a) no Gaussian above the gradient threshold and none to cull: the event leaves every tensor object (and the optimiser) as it is; (b) every Gaussian
+    transparent: the class ends with zero rows and the optimiser with zero-row moments (the reference's mask indexing gives the same); (c) a step inside
+    the warm-up returns None and keeps the statistics."""
+    from emd_amd.optim import Adam
+    z = np.load(os.path.join(G, "or_refine.npz"))
+    node, opt = _setup(z, Adam)
+    n = node.num_points
+    node.preprocess_per_train_step(300)                       # (c) warm-up: refinement_after returns before touching anything
+    node.after_train(torch.ones(n, dtype=torch.int32, device=DEV), torch.zeros(n, 2, device=DEV), 1600.0)
+    assert node.refinement_after(300, opt) is None and node.xys_grad_norm is not None
+    # (a) gradients far below the threshold, opacities well above the cull threshold, step before the first reset (alpha-only cull)
+    node._opacities.data.fill_(2.0)
+    before = {k: getattr(node, v) for k, v in ATTR.items()}
+    node.preprocess_per_train_step(700)
+    info = node.refinement_after(700, opt)
+    assert info["n_after"] == n and info["split"] == 0 and info["dups_kept"] == 0 and info["originals_kept"] == n
+    assert all(getattr(node, v) is before[k] for k, v in ATTR.items())
+    assert node.xys_grad_norm is None                          # the statistics restart after every event
+    # (b) everything transparent
+    node._opacities.data.fill_(-12.0)
+    node.after_train(torch.ones(n, dtype=torch.int32, device=DEV), torch.zeros(n, 2, device=DEV), 1600.0)
+    node.preprocess_per_train_step(800)
+    info = node.refinement_after(800, opt)
+    assert info["n_after"] == 0 and node.num_points == 0
+    for k, v in ATTR.items():
+        p = getattr(node, v)
+        assert p.shape[0] == 0 and opt.state[p]["exp_avg"].shape[0] == 0
