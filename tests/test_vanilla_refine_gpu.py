@@ -156,3 +156,80 @@ def test_refinement_edge_cases_nothing_to_do_and_everything_culled():
     for k, v in ATTR.items():
         p = getattr(node, v)
         assert p.shape[0] == 0 and opt.state[p]["exp_avg"].shape[0] == 0
+
+
+def test_after_train_takes_three_column_gradients_by_their_first_two():
+    """`xys_grad` may arrive as the [n, 3] screen-space gradient of the diff_gauss surface (means2D.grad): the statistics use columns 0, 1 with the
+    row stride of the tensor handed over, first call (norm of every row) and later calls (masked adds) alike."""
+    from emd_amd.vanilla import VanillaGaussians
+    n = 1000
+    g = torch.Generator().manual_seed(3)
+    a, b = VanillaGaussians("A", dict(sh_degree=1, refine_interval=100), device=DEV), VanillaGaussians("B", dict(sh_degree=1, refine_interval=100), device=DEV)
+    for node in (a, b):
+        node._means = torch.nn.Parameter(torch.zeros(n, 3, device=DEV))
+    for v in range(3):
+        radii = torch.randint(0, 50, (n,), generator=g, dtype=torch.int32)
+        radii[torch.rand(n, generator=g) < 0.4] = 0
+        g3 = torch.randn(n, 3, generator=g) * 1e-3
+        a.after_train(radii.to(DEV), g3.to(DEV), 800.0)
+        b.after_train(radii.to(DEV), g3[:, :2].contiguous().to(DEV), 800.0)
+    assert torch.equal(a.xys_grad_norm, b.xys_grad_norm) and torch.equal(a.vis_counts, b.vis_counts) and torch.equal(a.max_2Dsize, b.max_2Dsize)
+    assert float(a.vis_counts.max()) == 3.0 and float(a.max_2Dsize.max()) > 0
+
+
+def test_refinement_at_scale_matches_a_torch_restatement_of_the_reference():
+    """300 000 rows (1 172 blocks of 256: the block-count scan runs more than one 1024-block chunk per column): the fused event against
+    vanilla.py:206-376 written out with torch mask indexing / repeat / cat on the GPU (split with the original kept and reduced in place, duplicate
+    decided AFTER the reduction, cull of the grown arrays with max_2Dsize 0 on new rows) -- row count, row order and every value."""
+    from emd_amd.optim import Adam
+    from emd_amd.vanilla import VanillaGaussians
+    N, ns, scene_scale = 300_000, 2, 2.0
+    g = torch.Generator().manual_seed(11)
+    cfg = dict(sh_degree=1, warmup_steps=500, reset_alpha_interval=3000, refine_interval=100, n_split_samples=ns, reset_alpha_value=0.01, densify_grad_thresh=0.0003,
+               densify_size_thresh=0.003, cull_alpha_thresh=0.005, cull_scale_thresh=0.5, cull_screen_size=0.15, split_screen_size=0.05, stop_screen_size_at=4000,
+               stop_split_at=15000)
+    node = VanillaGaussians("Background", cfg, scene_scale=scene_scale, num_train_images=10, device=DEV)
+    P = lambda t: torch.nn.Parameter(t.to(DEV).contiguous())
+    node._means = P(torch.randn(N, 3, generator=g) * 4)
+    node._scales = P(torch.log(torch.tensor(1e-3)) + torch.rand(N, 3, generator=g) * 8.0 - 1.0)
+    node._quats = P(torch.randn(N, 4, generator=g))
+    node._opacities = P(torch.randn(N, 1, generator=g) * 3.0 - 1.0)
+    node._features_dc = P(torch.randn(N, 3, generator=g))
+    node._features_rest = P(torch.randn(N, 3, 3, generator=g) * 0.1)
+    opt = Adam([{"params": v, "lr": 1e-3, "name": k} for k, v in node.get_gaussian_param_groups().items()], lr=0.0, eps=1e-15)
+    for v in node.get_gaussian_param_groups().values():
+        opt.state[v[0]] = {"step": torch.tensor(1.0), "exp_avg": torch.randn(v[0].shape, generator=g).to(DEV), "exp_avg_sq": torch.rand(v[0].shape, generator=g).to(DEV)}
+    node.xys_grad_norm = (torch.rand(N, generator=g) * 1.2e-3).to(DEV)
+    node.vis_counts = torch.randint(1, 4, (N,), generator=g).float().to(DEV)
+    node.max_2Dsize = (torch.rand(N, generator=g) * 0.2).to(DEV)
+    step = 3600
+    # ---- the reference's sequence with torch ops (vanilla.py:218-326), on clones
+    m, s, q, o = node._means.detach().clone(), node._scales.detach().clone(), node._quats.detach().clone(), node._opacities.detach().clone()
+    dc, mom = node._features_dc.detach().clone(), opt.state[node._scales]["exp_avg"].clone()
+    high = (node.xys_grad_norm / node.vis_counts) > cfg["densify_grad_thresh"]
+    splits = (torch.exp(s).max(dim=-1).values > cfg["densify_size_thresh"] * scene_scale) | (node.max_2Dsize > cfg["split_screen_size"])
+    splits &= high
+    n_split = int(splits.sum())
+    samples = torch.randn(ns * n_split, 3, generator=g).to(DEV)
+    qn = q[splits] / q[splits].norm(dim=-1, keepdim=True)
+    w_, x_, y_, z_ = qn.unbind(-1)
+    R = torch.stack([1 - 2 * (y_ ** 2 + z_ ** 2), 2 * (x_ * y_ - w_ * z_), 2 * (x_ * z_ + w_ * y_), 2 * (x_ * y_ + w_ * z_), 1 - 2 * (x_ ** 2 + z_ ** 2), 2 * (y_ * z_ - w_ * x_),
+                     2 * (x_ * z_ - w_ * y_), 2 * (y_ * z_ + w_ * x_), 1 - 2 * (x_ ** 2 + y_ ** 2)], -1).reshape(-1, 3, 3)
+    new_means = torch.bmm(R.repeat(ns, 1, 1), (torch.exp(s[splits]).repeat(ns, 1) * samples)[..., None]).squeeze(-1) + m[splits].repeat(ns, 1)
+    new_scales = torch.log(torch.exp(s[splits]) / 1.6).repeat(ns, 1)
+    s[splits] = torch.log(torch.exp(s[splits]) / 1.6)
+    dups = (torch.exp(s).max(dim=-1).values <= cfg["densify_size_thresh"] * scene_scale) & high
+    cat = lambda base, a, b: torch.cat([base, a, b], 0)
+    M_ = cat(m, new_means, m[dups]); S_ = cat(s, new_scales, s[dups]); O_ = cat(o, o[splits].repeat(ns, 1), o[dups]); D_ = cat(dc, dc[splits].repeat(ns, 1), dc[dups])
+    mom_ = cat(mom, torch.zeros_like(new_scales), torch.zeros_like(s[dups]))
+    m2d = torch.cat([node.max_2Dsize, torch.zeros(ns * n_split + int(dups.sum()), device=DEV)])
+    culls = (torch.sigmoid(O_).squeeze(-1) < cfg["cull_alpha_thresh"]) | (torch.exp(S_).max(dim=-1).values > cfg["cull_scale_thresh"] * scene_scale) | (m2d > cfg["cull_screen_size"])
+    keep = ~culls
+    # ---- the fused event
+    node.preprocess_per_train_step(step)
+    info = node.refinement_after(step, opt, samples=samples.view(ns, n_split, 3))
+    assert info["split"] == n_split and info["n_after"] == int(keep.sum()) and n_split > 1000 and int(dups.sum()) > 100 and int(culls.sum()) > 1000
+    assert torch.equal(node._features_dc.detach(), D_[keep]) and torch.equal(node._opacities.detach(), O_[keep])
+    torch.testing.assert_close(node._scales.detach(), S_[keep], rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(node._means.detach(), M_[keep], rtol=2e-6, atol=2e-5)
+    assert torch.equal(opt.state[node._scales]["exp_avg"], mom_[keep])
