@@ -103,9 +103,10 @@ def read_ply(path):
         return {n: np.asarray(arr[n]) for n, _ in props}
 
 
-def restructure_rows(mode, args, jobs, N, seed=0, samples=None, front_rows=0):
+def restructure_rows(mode, args, jobs, N, seed=0, samples=None, front_rows=0, scaling=None, rotation=None):
     """One density-control event on `N` rows of an arbitrary set of per-point tensors: decide -> scan -> index -> ONE gather (csrc/densify.hip).
     `args`: an EmdDensifyArgs with the decision inputs filled (pointers to the N rows); `jobs`: [(tensor [N, ...] float32 contiguous, role)];
+    `scaling` [N,3] / `rotation` [N,4]: the source log-scales and quaternions a split sample's position is drawn from (needed in DENSIFY mode);
     `front_rows`: every output tensor gets that many extra rows in FRONT of the gathered ones, left for the caller to fill (rows of a store
     that do not take part: the actors of emd_amd.model.density_control).  -> (outs or None when nothing changes, (n_keep, n_clone, n_split)).
     The event's single host read is the three totals."""
@@ -130,12 +131,8 @@ def restructure_rows(mode, args, jobs, N, seed=0, samples=None, front_rows=0):
     g.num_out, g.mode, g.num_split = M, mode, n_split
     g.src, g.kind = src.data_ptr(), kind.data_ptr()
     g.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    keep_alive = [src, kind, code, inc, totals]
-    for t, role in jobs:
-        if role == L.DENSIFY_ROLE_SCALING:
-            g.scaling = t.data_ptr()
-        if role == "rotation":
-            g.rotation = t.data_ptr()
+    keep_alive = [src, kind, code, inc, totals, scaling, rotation]
+    g.scaling, g.rotation = L.ptr(scaling), L.ptr(rotation)
     if samples is not None:
         samples = samples.to(dev).float().contiguous()
         assert samples.shape == (2, n_split, 3), (tuple(samples.shape), n_split)
@@ -150,7 +147,7 @@ def restructure_rows(mode, args, jobs, N, seed=0, samples=None, front_rows=0):
         width = t.numel() // N
         out = torch.empty((front_rows + M,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev)
         g.tensors[k].src, g.tensors[k].dst, g.tensors[k].width = t.data_ptr(), out.data_ptr() + 4 * width * front_rows, width
-        g.tensors[k].role = L.DENSIFY_ROLE_COPY if role == "rotation" else role
+        g.tensors[k].role = role
         outs.append(out)
     g.num_tensors = len(jobs)
     L.check(lib.emd_densify_gather(C.byref(g), _stream()), "emd_densify_gather")

@@ -100,7 +100,7 @@ def density_control(model: "StreetGaussians", xyz_gradient_accum, denom, max_rad
     if model.has_actors and n_dyn and not bool((model.actor_id[:n_dyn] >= 0).all()):
         raise ValueError("density_control expects the actors' points in front of the background's (the reference's node order)")
     names = ("_xyz", "_scaling", "_rotation", "_opacity", "_features")
-    roles = {"_xyz": L.DENSIFY_ROLE_XYZ, "_scaling": L.DENSIFY_ROLE_SCALING, "_rotation": "rotation", "_opacity": L.DENSIFY_ROLE_COPY,
+    roles = {"_xyz": L.DENSIFY_ROLE_XYZ, "_scaling": L.DENSIFY_ROLE_SCALING, "_rotation": L.DENSIFY_ROLE_COPY, "_opacity": L.DENSIFY_ROLE_COPY,
              "_features": L.DENSIFY_ROLE_COPY}
     groups = {}
     if optimizer is not None:
@@ -138,7 +138,8 @@ def density_control(model: "StreetGaussians", xyz_gradient_accum, denom, max_rad
             for i_, t in enumerate(stats):
                 jobs.append((bg(t), L.DENSIFY_ROLE_ZERO))
                 keys.append(("stat", i_))
-            outs, (n_keep, n_clone, n_split) = restructure_rows(mode, a, jobs, nb, seed=seed_word, front_rows=n_dyn)
+            outs, (n_keep, n_clone, n_split) = restructure_rows(mode, a, jobs, nb, seed=seed_word, front_rows=n_dyn, scaling=bg(full["_scaling"]),
+                                                                rotation=bg(full["_rotation"]))
             if mode == L.DENSIFY_MODE_DENSIFY:
                 counts["cloned"], counts["split"] = n_clone, n_split
                 if outs is None:          # nothing selected: the reference's densification_postfix still clears the statistics (gaussian_model.py:526-530)
