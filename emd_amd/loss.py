@@ -54,8 +54,12 @@ class _ImageLoss(torch.autograd.Function):
     def backward(ctx, g, _g_terms):
         g_img, g_dep, g_wgt = ctx.saved_tensors
         s = ctx.shapes
-        return (None if g_img is None else (g_img * g).view(s[0]), None, None if g_dep is None else (g_dep * g).view(s[1]), None, None,
-                None if g_wgt is None else (g_wgt * g).view(s[2]), None, None, None, None, None)
+        have = [t for t in (g_img, g_dep, g_wgt) if t is not None]
+        # the three gradients were formed by the forward's launches; the upstream scalar scales them in ONE multi-tensor launch (three image-sized
+        # element-wise launches before round 6)
+        scaled = iter(torch._foreach_mul(have, g) if len(have) > 1 else [t * g for t in have])
+        pick = lambda t, shape: None if t is None else next(scaled).view(shape)
+        return (pick(g_img, s[0]), None, pick(g_dep, s[1]), None, None, pick(g_wgt, s[2]), None, None, None, None, None)
 
 
 def image_loss(image, gt, depth=None, gt_depth=None, mask=None, weight=None, sky_mask=None, lambda_dssim=0.2, lambda_depth=0.5,

@@ -69,8 +69,10 @@ def build(dev, N=2_000_000, H=1066, W=1600, F=50, fine=True, feat=False, feat_se
     gt = torch.rand(3, H, W, generator=g).to(dev)
     gt_depth = (torch.rand(1, H, W, generator=g) * 90).to(dev)
     gt_feat = torch.rand(3, H, W, generator=g).to(dev)
-    sky_mask = (torch.rand(1, H, W, generator=g) < 0.2).to(dev)
-    not_sky = ~sky_mask
+    # (the two masks are dataset constants of a frame: held in the dtypes the loss kernels read -- float32 for the depth mask, uint8 for the sky
+    #  mask -- so that the step converts nothing; 17 us per step of image-sized copies before round 6)
+    sky_bool = (torch.rand(1, H, W, generator=g) < 0.2).to(dev)
+    sky_mask, not_sky = sky_bool.to(torch.uint8), (~sky_bool).float()
     accum, denom, maxr = (torch.zeros(N, device=dev) for _ in range(3))
     cams, skycams = {}, {}
     for f in range(F):

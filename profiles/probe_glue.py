@@ -1,4 +1,4 @@
-"""Which Python lines issue the small torch kernels (add / fill / copy) of the fine-stage step?"""
+"""Which Python lines issue the small torch kernels (add / fill / copy ...) of the fine-stage step?  (torch.profiler, with_stack)"""
 import sys
 sys.path.insert(0, "."); sys.path.insert(0, "profiles")
 import torch
@@ -11,20 +11,18 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     S.step(5)
     torch.cuda.synchronize()
+ka = prof.key_averages(group_by_input_shape=True, group_by_stack_n=8)
 rows = []
-for e in prof.events():
-    if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::") and e.name.split("::")[1] in (
-            "add", "add_", "fill_", "zero_", "copy_", "mul", "mul_", "zeros", "zeros_like", "ones_like", "sum", "clone", "contiguous", "cat", "sub", "div", "neg", "abs", "mean", "expand", "to", "_to_copy"):
-        if e.cpu_parent is not None and e.cpu_parent.name.startswith("aten::"):
-            continue          # only top-level aten ops
-        dev_us = sum(float(getattr(k, "device_time", 0.0)) for k in e.kernels) if hasattr(e, "kernels") else 0.0
-        st = [f for f in (e.stack or []) if "/repo/" in f or "emd_amd" in f or "profiles" in f][:3]
-        rows.append((e.name, str(e.input_shapes)[:60], dev_us, " <- ".join(s_.split("/")[-1] for s_ in st)))
-from collections import Counter
-c = Counter()
-t = Counter()
-for name, shp, us, st in rows:
-    c[(name, shp, st)] += 1
-    t[(name, shp, st)] += us
-for k, n in sorted(c.items(), key=lambda kv: -t[kv[0]])[:60]:
-    print(f"{n:3d} x {t[k]:8.1f} us  {k[0]:14s} {k[1]:62s} {k[2]}")
+for e in ka:
+    if not e.key.startswith("aten::"):
+        continue
+    dev_us = float(getattr(e, "self_device_time_total", 0.0) or 0.0)
+    if dev_us <= 0:
+        continue
+    st = [f for f in (e.stack or []) if ("/repo/" in f or "emd_amd" in f or "profiles/" in f)]
+    rows.append((dev_us, e.count, e.key, str(e.input_shapes)[:70], " <- ".join(x.split("/")[-1][:60] for x in st[:3])))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print(f"aten ops with device time: {tot:.1f} us over {sum(r[1] for r in rows)} calls")
+for r in rows[:70]:
+    print(f"{r[0]:8.1f} us x{r[1]:3d}  {r[2]:22s} {r[3]:72s} {r[4]}")
