@@ -14,7 +14,8 @@ and sky rays are host constants of a frame and are baked into its graph) and rep
 instead of 15-19 ms issuing ~170 launches from Python, so the rate is the GPU's whatever the host is doing; one replay is checked
 against the eager step of the same frame before the timed region.
 --fused-l1 (with --fine): the dx / do regularisers formed by the head kernels (render(..., fused_l1=("dx", "do"))) instead of abs_mean launches --
-measured SLOWER (12.38 against 12.30 ms: the regularised instantiation of the narrow heads' forward takes 172 us against 130-140), so not the default.
+measured SLOWER in round 4 (12.38 against 12.30 ms: the regularised instantiation of the narrow heads' forward took 172 us against 130-140) and FASTER in
+round 6 (11.04 / 11.01 against 11.15 / 11.08 ms, alternated in one call: that instantiation runs two waves per SIMD since round 5): bench.py's fine_stage block uses it.
 --adam / --torch-adam: also take the optimiser step (train.py:428) with emd_amd.optim.Adam / torch.optim.Adam over the groups of
 gaussian_model.py:188-199 (per-group learning rates, eps 1e-15)."""
 import json

@@ -255,7 +255,9 @@ def measure(dev, N=2_000_000, H=1066, W=1600, F=50, graph_frames=10, steps=50, p
     """The `fine_stage` block of bench.py's JSON line: ms per step of the graph-replayed S3G fine-stage step (graphs of `graph_frames` frames of
     the clip, replayed round robin), and the `top` longest kernels of the same step issued eagerly under torch.profiler, each priced."""
     t_all = time.perf_counter()
-    S = build(dev, N, H, W, F, fine=True)
+    # (fused_l1: the dx / do regularisers formed by the head kernels, render(..., fused_l1=("dx", "do")) -- 11.15 / 11.08 ms without against 11.04 / 11.01
+    #  with, alternated in one call in round 6; it lost in round 4, before the regularised narrow-head forward ran two waves per SIMD)
+    S = build(dev, N, H, W, F, fine=True, fused_l1=True)
     for s in range(4):
         S.step(s)
     torch.cuda.synchronize()
@@ -314,7 +316,7 @@ def measure(dev, N=2_000_000, H=1066, W=1600, F=50, graph_frames=10, steps=50, p
         groups[key] = groups.get(key, 0.0) + ms
     return {"ms_per_step": round(dt / steps * 1e3, 4), "ms_per_step_repeat": round(dt2 / steps * 1e3, 4), "iters_per_s": round(steps / dt, 2), "steps": steps,
             "workload": f"S3Gaussian fine-stage step (50 000 of 55 000 iterations): EMD deformation network (HexPlane 4 x 6 planes x 32 ch + temporal table + dx / do / dshs heads, "
-                        f"run-script flags) -> raster -> sky cube map + blend -> L1 + depth L2 + D-SSIM + sky BCE + residual regularisers -> backward to Gaussians, planes, "
+                        f"run-script flags; the dx / do regularisers formed inside the head kernels) -> raster -> sky cube map + blend -> L1 + depth L2 + D-SSIM + sky BCE + residual regularisers -> backward to Gaussians, planes, "
                         f"table, heads -> densification statistics; N={N}, {H}x{W}, no optimiser step (as `value`)",
             "step_issue": f"hipGraph replay, one graph per frame, {len(frames)} frames of the {F}-frame clip round robin", "graph_record_s": round(t_record, 2),
             "visible_V": V, "duplicates_D": D,
