@@ -653,6 +653,7 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
             // stores on ONE counter, in order: with the stores issued after the gathers, the wait for the gathers at the top of the next
             // iteration (vmcnt(0): the number of stores in between is not a compile-time constant) also waited for the stores' acknowledgements,
             // which are the youngest operations in flight; now the gathers are, and the LDS adds below (a different counter) run under them.
+#ifndef HEX_ABL_NO_DEFER_STORE      /* ablation build (profiles/r06_hexplane_ablations.txt): the rows of the deferred scales are computed but never stored */
             if (n_cur >= 0 && deferred) {
                 const int4 P = s_pn[pt];
 #pragma unroll
@@ -667,10 +668,22 @@ __global__ void __launch_bounds__(HEX_AGG_THREADS, 4) k_hexplane_bwd_agg(EmdHexA
 #endif
                 }
             }
+#else
+            if (n_cur >= 0 && deferred) {          // (the rows stay computed: their sum reaches memory only for a value that never occurs)
+                float sink = 0.f;
+#pragma unroll
+                for (int p = 0; p < 4; p++) if (p != 2 && HEX_GP(p)) sink += gi[p];
+                if (sink == 12345.678f) g.defer_rows[0] = sink;
+            }
+#endif
             if (it + 1 < ITERS) gather(it + 1);                          // in flight while the rows of `it` are scattered
             // ---- the 24 tap rows of the point: rows inside the windows are native fp64 LDS adds, rows outside leave as global float
             // atomics; both are fire and forget
+#ifdef HEX_ABL_NO_ADDS              /* ablation build: no LDS window adds and no fallback atomics (hence empty flushes) */
+            if (false) {
+#else
             if (n_cur >= 0) {
+#endif
 #pragma unroll
                 for (int p = 0; p < 6; p++) {
                     const bool marg = (p == 2 || p >= 4) && tuni;         // marginal over the block's time: two rows
